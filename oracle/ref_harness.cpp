@@ -1,0 +1,677 @@
+/* oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Thin C-ABI harness over the REAL reference mixer (kcat/openal-soft, compiled in
+ * place from /root/reference by oracle/Makefile).  It implements oracle/oalref.h by
+ * calling the reference's own functions:
+ *   Resample_*_{C,SSE,SSE2,SSE4}   core/mixer/defs.h:78-141
+ *   Mix_*, MixHrtf_*, MixHrtfBlend_*, MixDirectHrtf_*   core/mixer/mixer_{c,sse}.cpp
+ *   BiquadInterpFilter, BandSplitter   core/filters/{biquad,splitter}.cpp
+ *   PrepareResampler   alc/alu.cpp:253-281
+ *   LoadHrtf / HrtfStore::getCoeffs   core/hrtf_loader.cpp:726, core/hrtf.cpp:192-260
+ *   Voice::prepare / Voice::mix   core/voice.cpp:1235,988
+ * No reference source is copied; this file only drives it.
+ */
+#include "config.h"
+#include "config_simd.h"
+
+/* The harness needs to read/write filter state that the reference keeps private.
+ * Everything those two headers include is pulled in first so the keyword
+ * redefinitions only touch biquad.h / splitter.h themselves. */
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <numbers>
+#include <span>
+#include "alnumeric.h"
+#include "opthelpers.h"
+#define private public
+#define protected public
+#define class struct
+#include "core/filters/biquad.h"
+#include "core/filters/splitter.h"
+#undef class
+#undef private
+#undef protected
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <memory>
+#include <vector>
+
+#include "alnumeric.h"
+#include "core/bformatdec.h"
+#include "core/bs2b.h"
+#include "core/bsinc_tables.h"
+#include "core/encoderbase.hpp"
+#include "core/front_stablizer.h"
+#include "core/mastering.h"
+#include "core/buffer_storage.h"
+#include "core/context.h"
+#include "core/cpu_caps.h"
+#include "core/cubic_tables.h"
+#include "core/device.h"
+#include "core/effectslot.h"
+#include "core/fpu_ctrl.h"
+#include "core/hrtf.h"
+#include "core/hrtf_loader.hpp"
+#include "core/mixer.h"
+#include "core/mixer/defs.h"
+#include "core/mixer/hrtfdefs.h"
+#include "core/voice.h"
+#include "core/async_event.h"
+#include "ringbuffer.h"
+
+#include "oalref.h"
+
+#include "alc/alu.h"
+
+namespace {
+
+bool gSimd = true;
+bool gInit = false;
+
+void EnsureInit()
+{
+    if(gInit) return;
+    gInit = true;
+    if(auto info = GetCPUInfo())
+        CPUCapFlags = info->mCaps;
+}
+
+void ApplySimd()
+{
+    EnsureInit();
+    static CPUCapBitset detected = CPUCapFlags;
+    CPUCapFlags = gSimd ? detected : CPUCapBitset{};
+    aluInit({}, 1.0f);
+    Voice::InitMixer(std::nullopt);
+}
+
+std::unique_ptr<HrtfStore> gHrtfOwner;
+HrtfStore *gHrtf = nullptr;
+
+BSincTable const *GetBsinc(int which)
+{
+    switch(which)
+    {
+    case 12: return &gBSinc12;
+    case 24: return &gBSinc24;
+    case 48: return &gBSinc48;
+    }
+    return nullptr;
+}
+
+void ToBiquad(BiquadInterpFilter const &f, oal_biquad *o)
+{
+    o->z1 = f.mZ1; o->z2 = f.mZ2;
+    o->b0 = f.mCoeffs.mB0; o->b1 = f.mCoeffs.mB1; o->b2 = f.mCoeffs.mB2;
+    o->a1 = f.mCoeffs.mA1; o->a2 = f.mCoeffs.mA2;
+    o->tb0 = f.mTargetCoeffs.mB0; o->tb1 = f.mTargetCoeffs.mB1; o->tb2 = f.mTargetCoeffs.mB2;
+    o->ta1 = f.mTargetCoeffs.mA1; o->ta2 = f.mTargetCoeffs.mA2;
+    o->counter = f.mCounter;
+}
+void FromBiquad(oal_biquad const *o, BiquadInterpFilter &f)
+{
+    f.mZ1 = o->z1; f.mZ2 = o->z2;
+    f.mCoeffs.mB0 = o->b0; f.mCoeffs.mB1 = o->b1; f.mCoeffs.mB2 = o->b2;
+    f.mCoeffs.mA1 = o->a1; f.mCoeffs.mA2 = o->a2;
+    f.mTargetCoeffs.mB0 = o->tb0; f.mTargetCoeffs.mB1 = o->tb1; f.mTargetCoeffs.mB2 = o->tb2;
+    f.mTargetCoeffs.mA1 = o->ta1; f.mTargetCoeffs.mA2 = o->ta2;
+    f.mCounter = o->counter;
+}
+void ToSplitter(BandSplitter const &b, oal_splitter *s)
+{ s->coeff = b.mCoeff; s->lp_z1 = b.mLpZ1; s->lp_z2 = b.mLpZ2; s->ap_z1 = b.mApZ1; }
+void FromSplitter(oal_splitter const *s, BandSplitter &b)
+{ b.mCoeff = s->coeff; b.mLpZ1 = s->lp_z1; b.mLpZ2 = s->lp_z2; b.mApZ1 = s->ap_z1; }
+
+struct Dev final : DeviceBase { Dev() : DeviceBase{DeviceType::Loopback} { } };
+struct Ctx final : ContextBase { explicit Ctx(DeviceBase *d) : ContextBase{d} { } };
+struct Item final : VoiceBufferItem { };
+
+struct BufferData {
+    std::vector<std::byte> bytes;
+    Item item;
+};
+
+} // namespace
+
+struct oal_scene {
+    oal_device_desc desc{};
+    std::unique_ptr<Dev> dev;
+    std::unique_ptr<Ctx> ctx;
+    std::deque<BufferData> buffers;
+    std::deque<Voice> voices;
+    std::vector<int> vstate;
+    std::deque<EffectSlotBase> slots;
+    HrtfStorePtr hrtf;
+};
+
+extern "C" {
+
+const char *oal_kind(void) { return "reference"; }
+
+void oal_set_simd(int enable) { gSimd = enable != 0; ApplySimd(); }
+
+int oal_bsinc_table_get(int which, oal_bsinc_table *out)
+{
+    auto const *t = GetBsinc(which);
+    if(!t) return -1;
+    out->scaleBase = t->scaleBase.c_val;
+    out->scaleRange = t->scaleRange.c_val;
+    for(size_t i{0};i < 16;++i)
+    {
+        out->m[i] = t->m[i].c_val;
+        out->filterOffset[i] = t->filterOffset[i].c_val;
+    }
+    out->tab = t->Tab.data();
+    out->tablen = t->Tab.size();
+    return 0;
+}
+
+int oal_cubic_table_get(int which, float *out)
+{
+    CubicTable const *t = (which == 0) ? static_cast<CubicTable const*>(&gSplineFilter)
+        : static_cast<CubicTable const*>(&gGaussianFilter);
+    for(size_t pi{0};pi < CubicPhaseCount;++pi)
+    {
+        std::copy_n(t->mTable[pi].mCoeffs.data(), 4, out + pi*8);
+        std::copy_n(t->mTable[pi].mDeltas.data(), 4, out + pi*8 + 4);
+    }
+    return 0;
+}
+
+static ResamplerFunc PrepareFor(int resampler, uint32_t increment, InterpState *state)
+{
+    ApplySimd();
+    return PrepareResampler(static_cast<Resampler>(resampler), increment, state);
+}
+
+void oal_prepare_resampler(int resampler, uint32_t increment, oal_interp_state *out)
+{
+    auto state = InterpState{};
+    std::ignore = PrepareFor(resampler, increment, &state);
+    std::memset(out, 0, sizeof(*out));
+    auto const r = static_cast<Resampler>(resampler);
+    switch(r)
+    {
+    case Resampler::Point: out->kind = 0; break;
+    case Resampler::Linear: out->kind = 1; break;
+    case Resampler::Spline: out->kind = 2; out->table = 0; break;
+    case Resampler::Gaussian: out->kind = 2; out->table = 1; break;
+    default:
+        {
+            auto const &bs = std::get<BsincState>(state);
+            auto const which = (r == Resampler::FastBSinc12 || r == Resampler::BSinc12) ? 12
+                : (r == Resampler::FastBSinc24 || r == Resampler::BSinc24) ? 24 : 48;
+            auto const isfast = (r == Resampler::FastBSinc12 || r == Resampler::FastBSinc24
+                || r == Resampler::FastBSinc48);
+            out->kind = (!isfast && increment > MixerFracOne) ? 4 : 3;
+            out->table = which;
+            out->sf = bs.sf;
+            out->m = bs.m.c_val;
+            out->l = bs.l.c_val;
+            out->filter_offset = static_cast<uint32_t>(bs.filter.data() - GetBsinc(which)->Tab.data());
+        }
+    }
+}
+
+void oal_resample(int resampler, uint32_t increment, const float *src, size_t srclen,
+    uint32_t frac, float *dst, size_t n)
+{
+    auto state = InterpState{};
+    auto const func = PrepareFor(resampler, increment, &state);
+    auto const fpuctl = FPUCtl{};
+    /* SSE variants want a 16-byte aligned destination (voice.cpp:636 keeps multiples of 4). */
+    alignas(16) static thread_local std::array<float, 2048> tmp;
+    func(&state, std::span{src, srclen}, frac, increment, std::span{tmp.data(), n});
+    std::copy_n(tmp.data(), n, dst);
+}
+
+void oal_mix(const float *in, size_t n, float *out, size_t nlines, float *cur_gains,
+    const float *target_gains, size_t counter, size_t outpos)
+{
+    ApplySimd();
+    auto const fpuctl = FPUCtl{};
+    auto lines = al::vector<FloatBufferLine,16>(nlines);
+    for(size_t c{0};c < nlines;++c)
+        std::copy_n(out + c*BufferLineSize, BufferLineSize, lines[c].data());
+    alignas(16) std::array<float, BufferLineSize> inbuf{};
+    std::copy_n(in, n, inbuf.data());
+    MixSamples(std::span{inbuf}.first(n), std::span{lines}, std::span{cur_gains, nlines},
+        std::span{target_gains, nlines}, counter, outpos);
+    for(size_t c{0};c < nlines;++c)
+        std::copy_n(lines[c].data(), BufferLineSize, out + c*BufferLineSize);
+}
+
+void oal_mix_one(const float *in, size_t n, float *out, float *cur_gain, float target_gain,
+    size_t counter)
+{
+    ApplySimd();
+    auto const fpuctl = FPUCtl{};
+    alignas(16) std::array<float, BufferLineSize> inbuf{};
+    alignas(16) std::array<float, BufferLineSize> outbuf{};
+    std::copy_n(in, n, inbuf.data());
+    std::copy_n(out, n, outbuf.data());
+    MixSamples(std::span{inbuf}.first(n), std::span{outbuf}.first(n), *cur_gain, target_gain,
+        counter);
+    std::copy_n(outbuf.data(), n, out);
+}
+
+/* MixHrtf_/MixHrtfBlend_ are file-static selections in voice.cpp; call the variants directly. */
+void oal_mix_hrtf(const float *in, float *accum, uint32_t irsize, const float *coeffs,
+    const uint32_t delay[2], float gain, float gainstep, size_t n)
+{
+    EnsureInit();
+    auto const fpuctl = FPUCtl{};
+    alignas(16) HrirArray hc{};
+    std::memcpy(hc.data(), coeffs, sizeof(hc));
+    alignas(16) std::array<float, BufferLineSize+HrtfHistoryLength> inbuf{};
+    std::copy_n(in, n+HrtfHistoryLength, inbuf.data());
+    alignas(16) std::array<f32x2, BufferLineSize+HrirLength> acc{};
+    std::memcpy(acc.data(), accum, sizeof(acc));
+    auto const parms = MixHrtfFilter{hc, {delay[0], delay[1]}, gain, gainstep};
+    if(gSimd) MixHrtf_SSE(inbuf, acc, irsize, &parms, n);
+    else MixHrtf_C(inbuf, acc, irsize, &parms, n);
+    std::memcpy(accum, acc.data(), sizeof(acc));
+}
+
+void oal_mix_hrtf_blend(const float *in, float *accum, uint32_t irsize, const float *oldcoeffs,
+    const uint32_t olddelay[2], float oldgain, const float *newcoeffs,
+    const uint32_t newdelay[2], float newgainstep, size_t n)
+{
+    EnsureInit();
+    auto const fpuctl = FPUCtl{};
+    auto oldf = HrtfFilter{};
+    std::memcpy(oldf.Coeffs.data(), oldcoeffs, sizeof(oldf.Coeffs));
+    oldf.Delay = {olddelay[0], olddelay[1]};
+    oldf.Gain = oldgain;
+    alignas(16) HrirArray hc{};
+    std::memcpy(hc.data(), newcoeffs, sizeof(hc));
+    alignas(16) std::array<float, BufferLineSize+HrtfHistoryLength> inbuf{};
+    std::copy_n(in, n+HrtfHistoryLength, inbuf.data());
+    alignas(16) std::array<f32x2, BufferLineSize+HrirLength> acc{};
+    std::memcpy(acc.data(), accum, sizeof(acc));
+    auto const parms = MixHrtfFilter{hc, {newdelay[0], newdelay[1]}, 0.0f, newgainstep};
+    if(gSimd) MixHrtfBlend_SSE(inbuf, acc, irsize, &oldf, &parms, n);
+    else MixHrtfBlend_C(inbuf, acc, irsize, &oldf, &parms, n);
+    std::memcpy(accum, acc.data(), sizeof(acc));
+}
+
+void oal_splitter_init(oal_splitter *s, float f0norm)
+{ auto b = BandSplitter{}; b.init(f0norm); ToSplitter(b, s); }
+
+void oal_splitter_process_hfscale(oal_splitter *s, const float *in, float *out, size_t n,
+    float hfscale)
+{
+    auto const fpuctl = FPUCtl{};
+    auto b = BandSplitter{}; FromSplitter(s, b);
+    b.processHfScale(std::span{in, n}, std::span{out, n}, hfscale);
+    ToSplitter(b, s);
+}
+
+void oal_splitter_process_scale(oal_splitter *s, float *samples, size_t n, float hfscale,
+    float lfscale)
+{
+    auto const fpuctl = FPUCtl{};
+    auto b = BandSplitter{}; FromSplitter(s, b);
+    b.processScale(std::span{samples, n}, hfscale, lfscale);
+    ToSplitter(b, s);
+}
+
+void oal_mix_direct_hrtf(float *left, float *right, const float *in, size_t nch, float *accum,
+    oal_splitter *splitters, const float *hfscales, const float *chan_coeffs, size_t irsize,
+    size_t n)
+{
+    EnsureInit();
+    auto const fpuctl = FPUCtl{};
+    auto lines = al::vector<FloatBufferLine,16>(nch+2);
+    for(size_t c{0};c < nch;++c)
+        std::copy_n(in + c*BufferLineSize, BufferLineSize, lines[c].data());
+    std::copy_n(left, BufferLineSize, lines[nch].data());
+    std::copy_n(right, BufferLineSize, lines[nch+1].data());
+    auto state = DirectHrtfState::Create(nch);
+    for(size_t c{0};c < nch;++c)
+    {
+        FromSplitter(&splitters[c], state->mChannels[c].mSplitter);
+        state->mChannels[c].mHfScale = hfscales[c];
+        std::memcpy(state->mChannels[c].mCoeffs.data(), chan_coeffs + c*HrirLength*2,
+            sizeof(HrirArray));
+    }
+    alignas(16) std::array<f32x2, BufferLineSize+HrirLength> acc{};
+    std::memcpy(acc.data(), accum, sizeof(acc));
+    auto const ins = std::span<FloatBufferLine const>{lines.data(), nch};
+    if(gSimd)
+        MixDirectHrtf_SSE(lines[nch], lines[nch+1], ins, acc, state->mTemp, state->mChannels,
+            irsize, n);
+    else
+        MixDirectHrtf_C(lines[nch], lines[nch+1], ins, acc, state->mTemp, state->mChannels,
+            irsize, n);
+    std::memcpy(accum, acc.data(), sizeof(acc));
+    std::copy_n(lines[nch].data(), BufferLineSize, left);
+    std::copy_n(lines[nch+1].data(), BufferLineSize, right);
+    for(size_t c{0};c < nch;++c)
+        ToSplitter(state->mChannels[c].mSplitter, &splitters[c]);
+}
+
+void oal_biquad_reset(oal_biquad *f) { auto b = BiquadInterpFilter{}; ToBiquad(b, f); }
+void oal_biquad_clear(oal_biquad *f)
+{ auto b = BiquadInterpFilter{}; FromBiquad(f, b); b.clear(); ToBiquad(b, f); }
+void oal_biquad_set_params_from_slope(oal_biquad *f, int type, float f0norm, float gain,
+    float slope)
+{
+    auto b = BiquadInterpFilter{}; FromBiquad(f, b);
+    b.setParamsFromSlope(static_cast<BiquadType>(type), f0norm, gain, slope);
+    ToBiquad(b, f);
+}
+void oal_biquad_dual_process(oal_biquad *f0, oal_biquad *f1, const float *src, float *dst,
+    size_t n)
+{
+    auto const fpuctl = FPUCtl{};
+    auto b0 = BiquadInterpFilter{}; FromBiquad(f0, b0);
+    auto b1 = BiquadInterpFilter{}; FromBiquad(f1, b1);
+    DualBiquadInterp{b0, b1}.process(std::span{src, n}, std::span{dst, n});
+    ToBiquad(b0, f0); ToBiquad(b1, f1);
+}
+
+int oal_hrtf_load(const char *path)
+{
+    auto f = std::ifstream{path, std::ios::binary};
+    if(!f.is_open()) return -1;
+    try {
+        auto store = LoadHrtf(f);
+        if(!store) return -2;
+        gHrtfOwner = std::move(store);
+        gHrtf = gHrtfOwner.get();
+    }
+    catch(...) { return -3; }
+    return 0;
+}
+
+int oal_hrtf_info_get(oal_hrtf_info *out)
+{
+    if(!gHrtf) return -1;
+    out->sample_rate = gHrtf->mSampleRate;
+    out->ir_size = gHrtf->mIrSize;
+    out->num_fields = static_cast<uint32_t>(gHrtf->mFields.size());
+    out->num_elevs = static_cast<uint32_t>(gHrtf->mElev.size());
+    out->num_irs = static_cast<uint32_t>(gHrtf->mCoeffs.size());
+    return 0;
+}
+
+int oal_hrtf_raw(float *field_distance, uint8_t *field_evcount, uint16_t *elev_azcount,
+    uint16_t *elev_iroffset, float *coeffs, uint8_t *delays)
+{
+    if(!gHrtf) return -1;
+    for(size_t i{0};i < gHrtf->mFields.size();++i)
+    {
+        field_distance[i] = gHrtf->mFields[i].distance;
+        field_evcount[i] = gHrtf->mFields[i].evCount.c_val;
+    }
+    for(size_t i{0};i < gHrtf->mElev.size();++i)
+    {
+        elev_azcount[i] = gHrtf->mElev[i].azCount.c_val;
+        elev_iroffset[i] = gHrtf->mElev[i].irOffset.c_val;
+    }
+    std::memcpy(coeffs, gHrtf->mCoeffs.data(), gHrtf->mCoeffs.size()*sizeof(HrirArray));
+    for(size_t i{0};i < gHrtf->mDelays.size();++i)
+    {
+        delays[i*2+0] = gHrtf->mDelays[i][0].c_val;
+        delays[i*2+1] = gHrtf->mDelays[i][1].c_val;
+    }
+    return 0;
+}
+
+void oal_hrtf_get_coeffs(float elevation, float azimuth, float distance, float spread,
+    float *coeffs, uint32_t delays[2])
+{
+    auto const fpuctl = FPUCtl{};
+    alignas(16) HrirArray hc{};
+    auto d = std::array<unsigned,2>{};
+    gHrtf->getCoeffs(elevation, azimuth, distance, spread, hc, d);
+    std::memcpy(coeffs, hc.data(), sizeof(hc));
+    delays[0] = d[0]; delays[1] = d[1];
+}
+
+
+oal_scene *oal_scene_create(const oal_device_desc *desc)
+{
+    ApplySimd();
+    auto s = std::make_unique<oal_scene>();
+    s->desc = *desc;
+    s->dev = std::make_unique<Dev>();
+    auto &dev = *s->dev;
+    dev.mSampleRate = desc->sample_rate;
+    dev.mUpdateSize = BufferLineSize;
+    dev.mBufferSize = BufferLineSize;
+    dev.FmtType = DevFmtFloat;
+    dev.NumAuxSends = desc->num_aux_sends;
+    dev.MixBuffer.resize(desc->num_dry_channels + desc->num_real_channels);
+    dev.Dry.Buffer = std::span{dev.MixBuffer}.first(desc->num_dry_channels);
+    dev.RealOut.Buffer = desc->num_real_channels
+        ? std::span{dev.MixBuffer}.subspan(desc->num_dry_channels) : dev.Dry.Buffer;
+    if(desc->hrtf)
+    {
+        if(!gHrtf) return nullptr;
+        dev.mRenderMode = RenderMode::Hrtf;
+        dev.mIrSize = gHrtf->mIrSize;
+        dev.RealOut.ChannelIndex[FrontLeft] = 0_u8;
+        dev.RealOut.ChannelIndex[FrontRight] = 1_u8;
+        auto state = DirectHrtfState::Create(desc->num_dry_channels);
+        state->mIrSize = gHrtf->mIrSize;
+        dev.mPostProcess.emplace<HrtfPostProcess>(HrtfPostProcess{std::move(state)});
+    }
+    s->ctx = std::make_unique<Ctx>(s->dev.get());
+    s->ctx->mEnabledEvts.store({}, std::memory_order_relaxed);
+    s->ctx->mAsyncEvents = FifoBuffer<AsyncEvent>::Create(64, false);
+    for(uint32_t i{0};i < desc->num_slots;++i)
+    {
+        auto &slot = s->slots.emplace_back();
+        slot.mWetBuffer.resize(desc->wet_channels);
+        slot.Wet.Buffer = slot.mWetBuffer;
+        slot.EffectType = EffectSlotType::Reverb;
+    }
+    return s.release();
+}
+
+void oal_scene_destroy(oal_scene *s) { delete s; }
+
+int oal_scene_add_buffer(oal_scene *s, const void *data, int fmt_type, uint32_t frame_step,
+    uint32_t sample_len, uint32_t loop_start, uint32_t loop_end)
+{
+    static constexpr std::array<size_t,7> bps{1, 2, 4, 4, 8, 1, 1};
+    auto const nbytes = size_t{sample_len} * frame_step * bps.at(static_cast<size_t>(fmt_type));
+    auto &b = s->buffers.emplace_back();
+    b.bytes.resize(nbytes + 16);
+    std::memcpy(b.bytes.data(), data, nbytes);
+    auto const count = size_t{sample_len} * frame_step;
+    auto *p = b.bytes.data();
+    /* NOLINTBEGIN */
+    switch(fmt_type)
+    {
+    case OAL_FMT_UBYTE: b.item.mSamples = std::span{reinterpret_cast<u8*>(p), count}; break;
+    case OAL_FMT_SHORT: b.item.mSamples = std::span{reinterpret_cast<i16*>(p), count}; break;
+    case OAL_FMT_INT: b.item.mSamples = std::span{reinterpret_cast<i32*>(p), count}; break;
+    case OAL_FMT_FLOAT: b.item.mSamples = std::span{reinterpret_cast<f32*>(p), count}; break;
+    case OAL_FMT_DOUBLE: b.item.mSamples = std::span{reinterpret_cast<f64*>(p), count}; break;
+    case OAL_FMT_MULAW: b.item.mSamples = std::span{reinterpret_cast<MulawSample*>(p), count}; break;
+    case OAL_FMT_ALAW: b.item.mSamples = std::span{reinterpret_cast<AlawSample*>(p), count}; break;
+    default: s->buffers.pop_back(); return -1;
+    }
+    /* NOLINTEND */
+    b.item.mBlockAlign = 1;
+    b.item.mSampleLen = sample_len;
+    b.item.mLoopStart = loop_start;
+    b.item.mLoopEnd = loop_end;
+    /* stash the frame step where add_voice can find it */
+    b.bytes.back() = static_cast<std::byte>(frame_step);
+    b.bytes[b.bytes.size()-2] = static_cast<std::byte>(fmt_type);
+    return static_cast<int>(s->buffers.size()-1);
+}
+
+int oal_scene_add_voice(oal_scene *s, const oal_voice_desc *desc)
+{
+    static constexpr std::array<unsigned,7> bps{1, 2, 4, 4, 8, 1, 1};
+    auto &buf = s->buffers.at(static_cast<size_t>(desc->buffer));
+    auto const frame_step = static_cast<unsigned>(buf.bytes.back());
+    auto const fmt = static_cast<size_t>(buf.bytes[buf.bytes.size()-2]);
+    auto &v = s->voices.emplace_back();
+    s->vstate.push_back(OAL_VOICE_PLAYING);
+    /* InitVoice, al/source.cpp:639-670 */
+    v.mLoopBuffer.store(desc->looping ? &buf.item : nullptr, std::memory_order_relaxed);
+    v.mFmtChannels = FmtMono;
+    v.mFrequency = desc->frequency;
+    v.mFrameStep = frame_step;
+    v.mBytesPerBlock = frame_step * bps.at(fmt);
+    v.mSamplesPerBlock = 1;
+    v.mAmbiOrder = 0;
+    v.mFlags.reset();
+    v.mFlags.set(VoiceFlag::IsStatic);
+    v.mNumCallbackBlocks = 0;
+    v.mCallbackBlockOffset = 0;
+    v.prepare(s->dev.get());
+    v.mPosition.store(desc->position, std::memory_order_relaxed);
+    v.mPositionFrac.store(desc->position_frac, std::memory_order_relaxed);
+    v.mCurrentBuffer.store(&buf.item, std::memory_order_relaxed);
+    v.mStartTime = {};
+    v.mSourceID.store(static_cast<unsigned>(s->voices.size()), std::memory_order_relaxed);
+    v.mPlayState.store(Voice::Playing, std::memory_order_relaxed);
+    if(s->desc.hrtf) v.mFlags.set(VoiceFlag::HasHrtf);
+    v.mDuplicateMono = false;
+    return static_cast<int>(s->voices.size()-1);
+}
+
+int oal_scene_set_voice_params(oal_scene *s, int voice, const oal_voice_params *p)
+{
+    auto &v = s->voices.at(static_cast<size_t>(voice));
+    auto &dev = *s->dev;
+    auto const fpuctl = FPUCtl{};
+    /* CalcNonAttnVoiceParams, alc/alu.cpp:1664-1686 */
+    v.mDirect.Buffer = dev.Dry.Buffer;
+    for(size_t i{0};i < dev.NumAuxSends;++i)
+    {
+        if(p->send_slot[i] < 0) v.mSend[i].Buffer = {};
+        else v.mSend[i].Buffer = s->slots.at(static_cast<size_t>(p->send_slot[i])).Wet.Buffer;
+    }
+    v.mStep = p->step;
+    v.mResampler = PrepareResampler(static_cast<Resampler>(p->resampler), v.mStep,
+        &v.mResampleState);
+
+    auto &chan = v.mChans[0];
+    if(s->desc.hrtf)
+    {
+        /* CalcPanningAndFilters HRTF branch, alc/alu.cpp:1600-1611; CalcHrtfPanning :1207-1217 */
+        v.mDirect.Buffer = dev.RealOut.Buffer;
+        dev.mHrtf = nullptr;
+        gHrtf->getCoeffs(p->hrtf_ev, p->hrtf_az, p->hrtf_dist, p->hrtf_spread,
+            chan.mDryParams.Hrtf.Target.Coeffs, chan.mDryParams.Hrtf.Target.Delay);
+        chan.mDryParams.Hrtf.Target.Gain = p->hrtf_gain;
+        v.mFlags.set(VoiceFlag::HasHrtf);
+    }
+    else
+        std::copy_n(p->dry_gains, MaxOutputChannels, chan.mDryParams.Gains.Target.begin());
+    for(size_t i{0};i < dev.NumAuxSends;++i)
+        std::copy_n(p->send_gains[i], MaxAmbiChannels, chan.mWetParams[i].Gains.Target.begin());
+
+    /* alc/alu.cpp:1619-1656 */
+    v.mDirect.FilterActive = p->direct_filter.active != 0;
+    chan.mDryParams.LowPass.setParamsFromSlope(BiquadType::HighShelf, p->direct_filter.hf_norm,
+        p->direct_filter.gain_hf, 1.0f);
+    chan.mDryParams.HighPass.setParamsFromSlope(BiquadType::LowShelf, p->direct_filter.lf_norm,
+        p->direct_filter.gain_lf, 1.0f);
+    for(size_t i{0};i < dev.NumAuxSends;++i)
+    {
+        v.mSend[i].FilterActive = p->send_filter[i].active != 0;
+        chan.mWetParams[i].LowPass.setParamsFromSlope(BiquadType::HighShelf,
+            p->send_filter[i].hf_norm, p->send_filter[i].gain_hf, 1.0f);
+        chan.mWetParams[i].HighPass.setParamsFromSlope(BiquadType::LowShelf,
+            p->send_filter[i].lf_norm, p->send_filter[i].gain_lf, 1.0f);
+    }
+    return 0;
+}
+
+int oal_scene_set_voice_state(oal_scene *s, int voice, int vstate)
+{
+    s->vstate.at(static_cast<size_t>(voice)) = vstate;
+    auto &v = s->voices.at(static_cast<size_t>(voice));
+    v.mPlayState.store(static_cast<Voice::State>(vstate), std::memory_order_relaxed);
+    return 0;
+}
+
+int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process)
+{
+    auto &dev = *s->dev;
+    auto const fpuctl = FPUCtl{};
+    /* DeviceBase::renderSamples(unsigned), alc/alu.cpp:2412-2443 */
+    for(auto &line : dev.MixBuffer) line.fill(0.0f);
+    /* ProcessContexts, alc/alu.cpp:2196-2206 */
+    for(auto &slot : s->slots)
+        for(auto &line : slot.mWetBuffer) line.fill(0.0f);
+    auto const curtime = dev.getClockTime();
+    for(auto &v : s->voices)
+    {
+        auto const vstate = v.mPlayState.load(std::memory_order_acquire);
+        if(vstate != Voice::Stopped && vstate != Voice::Pending)
+            v.mix(vstate, s->ctx.get(), curtime, samples_to_do);
+    }
+    if(post_process && s->desc.hrtf)
+    {
+        auto &proc = std::get<HrtfPostProcess>(dev.mPostProcess);
+        dev.Process(proc, samples_to_do);
+    }
+    return 0;
+}
+
+const float *oal_scene_dry(oal_scene *s) { return s->dev->MixBuffer[0].data(); }
+const float *oal_scene_wet(oal_scene *s, int slot)
+{ return s->slots.at(static_cast<size_t>(slot)).mWetBuffer[0].data(); }
+const float *oal_scene_hrtf_accum(oal_scene *s) { return s->dev->HrtfAccumData[0].data(); }
+
+int oal_scene_voice_state(oal_scene *s, int voice, oal_voice_state *out)
+{
+    auto &v = s->voices.at(static_cast<size_t>(voice));
+    auto &chan = v.mChans[0];
+    std::memset(out, 0, sizeof(*out));
+    out->play_state = static_cast<int>(v.mPlayState.load());
+    out->position = v.mPosition.load();
+    out->position_frac = v.mPositionFrac.load();
+    out->has_buffer = v.mCurrentBuffer.load() != nullptr;
+    out->fading = v.mFlags.test(VoiceFlag::IsFading);
+    std::copy_n(v.mPrevSamples[0].data(), MaxResamplerPadding, out->prev_samples);
+    std::copy_n(chan.mDryParams.Gains.Current.data(), MaxOutputChannels, out->dry_current);
+    out->hrtf_old_gain = chan.mDryParams.Hrtf.Old.Gain;
+    out->hrtf_old_delay[0] = chan.mDryParams.Hrtf.Old.Delay[0];
+    out->hrtf_old_delay[1] = chan.mDryParams.Hrtf.Old.Delay[1];
+    std::copy_n(chan.mDryParams.Hrtf.History.data(), HrtfHistoryLength, out->hrtf_history);
+    ToBiquad(chan.mDryParams.LowPass, &out->direct_lp);
+    ToBiquad(chan.mDryParams.HighPass, &out->direct_hp);
+    for(size_t i{0};i < MaxSendCount;++i)
+    {
+        std::copy_n(chan.mWetParams[i].Gains.Current.data(), MaxAmbiChannels,
+            out->send_current[i]);
+        ToBiquad(chan.mWetParams[i].LowPass, &out->send_lp[i]);
+        ToBiquad(chan.mWetParams[i].HighPass, &out->send_hp[i]);
+    }
+    return 0;
+}
+
+int oal_scene_set_direct_hrtf(oal_scene *s, const float *chan_coeffs, const float *hfscales,
+    float xover_norm, uint32_t irsize)
+{
+    if(!s->desc.hrtf) return -1;
+    auto &proc = std::get<HrtfPostProcess>(s->dev->mPostProcess);
+    auto &state = *proc.mHrtfState;
+    state.mIrSize = irsize;
+    for(size_t c{0};c < state.mChannels.size();++c)
+    {
+        state.mChannels[c].mSplitter.init(xover_norm);
+        state.mChannels[c].mHfScale = hfscales[c];
+        std::memcpy(state.mChannels[c].mCoeffs.data(), chan_coeffs + c*HrirLength*2,
+            sizeof(HrirArray));
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,353 @@
+"""ctypes binding of oracle/oalref.h -- TEST INFRASTRUCTURE.
+
+Loads either oracle library (both export the same C API):
+  * ``load("ref")``  -> oracle/_ref/liboalref.so  (the reference itself, compiled in place)
+  * ``load("port")`` -> oracle/liboalport.so      (plain-C restatement)
+
+Nothing under openal-soft_amd/ imports this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BUFFER_LINE = 1024
+MAX_PAD = 48
+MAX_EDGE = 24
+HRTF_HIST = 64
+HRIR_LEN = 128
+MAX_SENDS = 6
+MAX_OUT = 32
+MAX_AMBI = 25
+
+(RS_POINT, RS_LINEAR, RS_SPLINE, RS_GAUSSIAN, RS_FAST_BSINC12, RS_BSINC12, RS_FAST_BSINC24,
+ RS_BSINC24, RS_FAST_BSINC48, RS_BSINC48) = range(10)
+FMT_UBYTE, FMT_SHORT, FMT_INT, FMT_FLOAT, FMT_DOUBLE, FMT_MULAW, FMT_ALAW = range(7)
+FMT_DTYPES = {FMT_UBYTE: np.uint8, FMT_SHORT: np.int16, FMT_INT: np.int32, FMT_FLOAT: np.float32,
+              FMT_DOUBLE: np.float64, FMT_MULAW: np.uint8, FMT_ALAW: np.uint8}
+VOICE_STOPPED, VOICE_PLAYING, VOICE_STOPPING, VOICE_PENDING = range(4)
+BIQUAD_HIGHSHELF, BIQUAD_LOWSHELF = 0, 1
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+
+
+class BsincTable(C.Structure):
+    _fields_ = [("scaleBase", C.c_float), ("scaleRange", C.c_float), ("m", C.c_uint32 * 16),
+                ("filterOffset", C.c_uint32 * 16), ("tab", f32p), ("tablen", C.c_size_t)]
+
+
+class InterpState(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("table", C.c_int32), ("sf", C.c_float), ("m", C.c_uint32),
+                ("l", C.c_uint32), ("filter_offset", C.c_uint32)]
+
+
+class Splitter(C.Structure):
+    _fields_ = [("coeff", C.c_float), ("lp_z1", C.c_float), ("lp_z2", C.c_float),
+                ("ap_z1", C.c_float)]
+
+
+class Biquad(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("z1", "z2", "b0", "b1", "b2", "a1", "a2", "tb0", "tb1",
+                                         "tb2", "ta1", "ta2")] + [("counter", C.c_int32)]
+
+    def as_tuple(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+class HrtfInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("sample_rate", "ir_size", "num_fields", "num_elevs",
+                                          "num_irs")]
+
+
+class DeviceDesc(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("sample_rate", "num_dry_channels", "num_real_channels",
+                                          "num_aux_sends", "num_slots", "wet_channels")] + \
+               [("hrtf", C.c_int32)]
+
+
+class VoiceDesc(C.Structure):
+    _fields_ = [("buffer", C.c_int32), ("looping", C.c_int32), ("position", C.c_int32),
+                ("position_frac", C.c_uint32), ("frequency", C.c_uint32)]
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("active", C.c_int32), ("gain_hf", C.c_float), ("hf_norm", C.c_float),
+                ("gain_lf", C.c_float), ("lf_norm", C.c_float)]
+
+
+class VoiceParams(C.Structure):
+    _fields_ = [("step", C.c_uint32), ("resampler", C.c_int32), ("direct_filter", FilterParams),
+                ("dry_gains", C.c_float * MAX_OUT),
+                ("hrtf_ev", C.c_float), ("hrtf_az", C.c_float), ("hrtf_dist", C.c_float),
+                ("hrtf_spread", C.c_float), ("hrtf_gain", C.c_float),
+                ("send_slot", C.c_int32 * MAX_SENDS), ("send_filter", FilterParams * MAX_SENDS),
+                ("send_gains", (C.c_float * MAX_AMBI) * MAX_SENDS)]
+
+
+class VoiceState(C.Structure):
+    _fields_ = [("play_state", C.c_int32), ("position", C.c_int32), ("position_frac", C.c_uint32),
+                ("has_buffer", C.c_int32), ("fading", C.c_int32),
+                ("prev_samples", C.c_float * MAX_PAD), ("dry_current", C.c_float * MAX_OUT),
+                ("hrtf_old_gain", C.c_float), ("hrtf_old_delay", C.c_uint32 * 2),
+                ("hrtf_history", C.c_float * HRTF_HIST),
+                ("direct_lp", Biquad), ("direct_hp", Biquad),
+                ("send_current", (C.c_float * MAX_AMBI) * MAX_SENDS),
+                ("send_lp", Biquad * MAX_SENDS), ("send_hp", Biquad * MAX_SENDS)]
+
+
+def default_filter(active=0, gain_hf=1.0, hf_norm=5000.0 / 48000.0, gain_lf=1.0,
+                   lf_norm=250.0 / 48000.0):
+    return FilterParams(active, gain_hf, hf_norm, gain_lf, lf_norm)
+
+
+def make_voice_params(step, resampler, dry_gains=None, hrtf=None, direct_filter=None, sends=None):
+    """sends: list of (slot, gains[<=25], FilterParams|None) per aux send."""
+    p = VoiceParams()
+    p.step = step
+    p.resampler = resampler
+    p.direct_filter = direct_filter if direct_filter is not None else default_filter()
+    if dry_gains is not None:
+        for i, g in enumerate(dry_gains):
+            p.dry_gains[i] = g
+    if hrtf is not None:
+        p.hrtf_ev, p.hrtf_az, p.hrtf_dist, p.hrtf_spread, p.hrtf_gain = hrtf
+    for i in range(MAX_SENDS):
+        p.send_slot[i] = -1
+        p.send_filter[i] = default_filter()
+    for i, snd in enumerate(sends or []):
+        slot, gains, filt = snd
+        p.send_slot[i] = slot
+        for c, g in enumerate(gains):
+            p.send_gains[i][c] = g
+        if filt is not None:
+            p.send_filter[i] = filt
+    return p
+
+
+def _fp(a):
+    return a.ctypes.data_as(f32p)
+
+
+class OracleLib:
+    def __init__(self, path):
+        self.path = path
+        L = self.L = C.CDLL(path)
+        L.oal_kind.restype = C.c_char_p
+        L.oal_set_simd.argtypes = [C.c_int]
+        L.oal_bsinc_table_get.argtypes = [C.c_int, C.POINTER(BsincTable)]
+        L.oal_cubic_table_get.argtypes = [C.c_int, f32p]
+        L.oal_prepare_resampler.argtypes = [C.c_int, C.c_uint32, C.POINTER(InterpState)]
+        L.oal_resample.argtypes = [C.c_int, C.c_uint32, f32p, C.c_size_t, C.c_uint32, f32p,
+                                   C.c_size_t]
+        L.oal_mix.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, f32p, f32p, C.c_size_t,
+                              C.c_size_t]
+        L.oal_mix_one.argtypes = [f32p, C.c_size_t, f32p, f32p, C.c_float, C.c_size_t]
+        L.oal_mix_hrtf.argtypes = [f32p, f32p, C.c_uint32, f32p, u32p, C.c_float, C.c_float,
+                                   C.c_size_t]
+        L.oal_mix_hrtf_blend.argtypes = [f32p, f32p, C.c_uint32, f32p, u32p, C.c_float, f32p,
+                                         u32p, C.c_float, C.c_size_t]
+        L.oal_splitter_init.argtypes = [C.POINTER(Splitter), C.c_float]
+        L.oal_splitter_process_hfscale.argtypes = [C.POINTER(Splitter), f32p, f32p, C.c_size_t,
+                                                   C.c_float]
+        L.oal_splitter_process_scale.argtypes = [C.POINTER(Splitter), f32p, C.c_size_t, C.c_float,
+                                                 C.c_float]
+        L.oal_mix_direct_hrtf.argtypes = [f32p, f32p, f32p, C.c_size_t, f32p, C.POINTER(Splitter),
+                                          f32p, f32p, C.c_size_t, C.c_size_t]
+        L.oal_biquad_reset.argtypes = [C.POINTER(Biquad)]
+        L.oal_biquad_clear.argtypes = [C.POINTER(Biquad)]
+        L.oal_biquad_set_params_from_slope.argtypes = [C.POINTER(Biquad), C.c_int, C.c_float,
+                                                       C.c_float, C.c_float]
+        L.oal_biquad_dual_process.argtypes = [C.POINTER(Biquad), C.POINTER(Biquad), f32p, f32p,
+                                              C.c_size_t]
+        L.oal_hrtf_load.argtypes = [C.c_char_p]
+        L.oal_hrtf_info_get.argtypes = [C.POINTER(HrtfInfo)]
+        L.oal_hrtf_raw.argtypes = [f32p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16),
+                                   C.POINTER(C.c_uint16), f32p, C.POINTER(C.c_uint8)]
+        L.oal_hrtf_get_coeffs.argtypes = [C.c_float] * 4 + [f32p, u32p]
+        L.oal_scene_create.argtypes = [C.POINTER(DeviceDesc)]
+        L.oal_scene_create.restype = C.c_void_p
+        L.oal_scene_destroy.argtypes = [C.c_void_p]
+        L.oal_scene_add_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32,
+                                           C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oal_scene_add_voice.argtypes = [C.c_void_p, C.POINTER(VoiceDesc)]
+        L.oal_scene_set_voice_params.argtypes = [C.c_void_p, C.c_int, C.POINTER(VoiceParams)]
+        L.oal_scene_set_voice_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oal_scene_mix.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        for n in ("oal_scene_dry", "oal_scene_hrtf_accum"):
+            getattr(L, n).argtypes = [C.c_void_p]
+            getattr(L, n).restype = f32p
+        L.oal_scene_wet.argtypes = [C.c_void_p, C.c_int]
+        L.oal_scene_wet.restype = f32p
+        L.oal_scene_voice_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(VoiceState)]
+        L.oal_scene_set_direct_hrtf.argtypes = [C.c_void_p, f32p, f32p, C.c_float, C.c_uint32]
+        self.kind = L.oal_kind().decode()
+
+    # ---- tables ----
+    def bsinc_table(self, which):
+        t = BsincTable()
+        assert self.L.oal_bsinc_table_get(which, C.byref(t)) == 0
+        tab = np.ctypeslib.as_array(t.tab, shape=(t.tablen,)).copy()
+        return dict(scaleBase=t.scaleBase, scaleRange=t.scaleRange, m=list(t.m),
+                    filterOffset=list(t.filterOffset), tab=tab)
+
+    def cubic_table(self, which):
+        out = np.zeros((32, 8), np.float32)
+        self.L.oal_cubic_table_get(which, _fp(out))
+        return out
+
+    def prepare_resampler(self, resampler, increment):
+        st = InterpState()
+        self.L.oal_prepare_resampler(resampler, increment, C.byref(st))
+        return st
+
+    # ---- per-call kernels ----
+    def resample(self, resampler, increment, src, frac, n):
+        src = np.ascontiguousarray(src, np.float32)
+        dst = np.zeros(n, np.float32)
+        self.L.oal_resample(resampler, increment, _fp(src), src.size, frac, _fp(dst), n)
+        return dst
+
+    def mix(self, inp, out, cur, tgt, counter, outpos):
+        inp = np.ascontiguousarray(inp, np.float32)
+        tgt = np.ascontiguousarray(tgt, np.float32)
+        assert out.dtype == np.float32 and out.shape[1] == BUFFER_LINE and cur.dtype == np.float32
+        self.L.oal_mix(_fp(inp), inp.size, _fp(out), out.shape[0], _fp(cur), _fp(tgt), counter,
+                       outpos)
+
+    def mix_hrtf(self, inp, accum, irsize, coeffs, delay, gain, gainstep, n):
+        inp = np.ascontiguousarray(inp, np.float32)
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        d = (C.c_uint32 * 2)(*delay)
+        self.L.oal_mix_hrtf(_fp(inp), _fp(accum), irsize, _fp(coeffs), d, gain, gainstep, n)
+
+    def mix_hrtf_blend(self, inp, accum, irsize, oldc, oldd, oldgain, newc, newd, newstep, n):
+        inp = np.ascontiguousarray(inp, np.float32)
+        oldc = np.ascontiguousarray(oldc, np.float32)
+        newc = np.ascontiguousarray(newc, np.float32)
+        self.L.oal_mix_hrtf_blend(_fp(inp), _fp(accum), irsize, _fp(oldc), (C.c_uint32 * 2)(*oldd),
+                                  oldgain, _fp(newc), (C.c_uint32 * 2)(*newd), newstep, n)
+
+    def mix_direct_hrtf(self, left, right, inp, accum, splitters, hfscales, chan_coeffs, irsize, n):
+        nch = inp.shape[0]
+        sp = (Splitter * nch)(*splitters)
+        hf = np.ascontiguousarray(hfscales, np.float32)
+        cc = np.ascontiguousarray(chan_coeffs, np.float32)
+        self.L.oal_mix_direct_hrtf(_fp(left), _fp(right), _fp(inp), nch, _fp(accum), sp, _fp(hf),
+                                   _fp(cc), irsize, n)
+        return list(sp)
+
+    # ---- HRTF ----
+    def hrtf_load(self, path):
+        rc = self.L.oal_hrtf_load(path.encode())
+        assert rc == 0, f"oal_hrtf_load({path}) = {rc}"
+        info = HrtfInfo()
+        assert self.L.oal_hrtf_info_get(C.byref(info)) == 0
+        return info
+
+    def hrtf_raw(self):
+        info = HrtfInfo()
+        assert self.L.oal_hrtf_info_get(C.byref(info)) == 0
+        fd = np.zeros(info.num_fields, np.float32)
+        fe = np.zeros(info.num_fields, np.uint8)
+        az = np.zeros(info.num_elevs, np.uint16)
+        io = np.zeros(info.num_elevs, np.uint16)
+        co = np.zeros((info.num_irs, HRIR_LEN, 2), np.float32)
+        de = np.zeros((info.num_irs, 2), np.uint8)
+        self.L.oal_hrtf_raw(_fp(fd), fe.ctypes.data_as(C.POINTER(C.c_uint8)),
+                            az.ctypes.data_as(C.POINTER(C.c_uint16)),
+                            io.ctypes.data_as(C.POINTER(C.c_uint16)), _fp(co),
+                            de.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return dict(info=info, field_distance=fd, field_evcount=fe, elev_azcount=az,
+                    elev_iroffset=io, coeffs=co, delays=de)
+
+    def hrtf_get_coeffs(self, ev, az, dist, spread):
+        co = np.zeros((HRIR_LEN, 2), np.float32)
+        d = (C.c_uint32 * 2)()
+        self.L.oal_hrtf_get_coeffs(ev, az, dist, spread, _fp(co), d)
+        return co, (d[0], d[1])
+
+
+class Scene:
+    """Scene-level driver (Voice::mix loop) of one oracle library."""
+
+    def __init__(self, lib, sample_rate=48000, num_dry=3, num_real=0, num_sends=0, num_slots=0,
+                 wet_channels=4, hrtf=False):
+        self.lib = lib
+        self.desc = DeviceDesc(sample_rate, num_dry, num_real, num_sends, num_slots, wet_channels,
+                               1 if hrtf else 0)
+        self.h = lib.L.oal_scene_create(C.byref(self.desc))
+        assert self.h, "oal_scene_create failed"
+        self.nvoices = 0
+
+    def close(self):
+        if self.h:
+            self.lib.L.oal_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def add_buffer(self, data, fmt, frame_step=1, loop_start=0, loop_end=None):
+        data = np.ascontiguousarray(data, FMT_DTYPES[fmt])
+        n = data.size // frame_step
+        if loop_end is None:
+            loop_end = n
+        return self.lib.L.oal_scene_add_buffer(self.h, data.ctypes.data_as(C.c_void_p), fmt,
+                                               frame_step, n, loop_start, loop_end)
+
+    def add_voice(self, buffer, looping, position=0, frac=0, frequency=44100):
+        d = VoiceDesc(buffer, 1 if looping else 0, position, frac, frequency)
+        v = self.lib.L.oal_scene_add_voice(self.h, C.byref(d))
+        assert v >= 0
+        self.nvoices += 1
+        return v
+
+    def set_params(self, voice, params):
+        assert self.lib.L.oal_scene_set_voice_params(self.h, voice, C.byref(params)) == 0
+
+    def set_state(self, voice, vstate):
+        assert self.lib.L.oal_scene_set_voice_state(self.h, voice, vstate) == 0
+
+    def set_direct_hrtf(self, chan_coeffs, hfscales, xover_norm, irsize):
+        cc = np.ascontiguousarray(chan_coeffs, np.float32)
+        hf = np.ascontiguousarray(hfscales, np.float32)
+        assert self.lib.L.oal_scene_set_direct_hrtf(self.h, _fp(cc), _fp(hf), xover_norm,
+                                                    irsize) == 0
+
+    def mix(self, samples_to_do=BUFFER_LINE, post_process=False):
+        assert self.lib.L.oal_scene_mix(self.h, samples_to_do, 1 if post_process else 0) == 0
+
+    def dry(self):
+        n = self.desc.num_dry_channels + self.desc.num_real_channels
+        return np.ctypeslib.as_array(self.lib.L.oal_scene_dry(self.h), shape=(n, BUFFER_LINE)).copy()
+
+    def wet(self, slot):
+        return np.ctypeslib.as_array(self.lib.L.oal_scene_wet(self.h, slot),
+                                     shape=(self.desc.wet_channels, BUFFER_LINE)).copy()
+
+    def hrtf_accum(self):
+        return np.ctypeslib.as_array(self.lib.L.oal_scene_hrtf_accum(self.h),
+                                     shape=(BUFFER_LINE + HRIR_LEN, 2)).copy()
+
+    def voice_state(self, voice):
+        st = VoiceState()
+        assert self.lib.L.oal_scene_voice_state(self.h, voice, C.byref(st)) == 0
+        return st
+
+
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "liboalref.so")
+PORT_PATH = os.path.join(ROOT, "oracle", "liboalport.so")
+_cache = {}
+
+
+def available(which):
+    return os.path.exists(REF_PATH if which == "ref" else PORT_PATH)
+
+
+def load(which):
+    if which not in _cache:
+        _cache[which] = OracleLib(REF_PATH if which == "ref" else PORT_PATH)
+    return _cache[which]
