@@ -1,0 +1,94 @@
+"""Synthetic inputs shared by tests/ and bench.py (no reference data is shipped).
+
+* ``synth_mhr_bytes()`` builds an HRTF data set in the reference's on-disk ``.mhr`` v3 format
+  (``MinPHR03``, core/hrtf_loader.cpp:583-721) with exactly the geometry of the reference's
+  ``hrtf/Default HRTF.mhr`` -- 48 kHz, left-only (mirrored), irSize 64, one field at 1.2 m,
+  13 elevations with azimuth counts {1, 180 x 11, 1} = 1982 HRIRs -- but synthetic impulse
+  responses (decaying noise with a direction-dependent onset/ITD).  BASELINE config 3/5 cost
+  depends only on that geometry; parity holds for any coefficient values.
+* ``Lcg`` is the 32-bit LCG of SURVEY.md section 8(d) used to build the synthetic scenes.
+"""
+import struct
+
+import numpy as np
+
+DEFAULT_AZ_COUNTS = [1] + [180] * 11 + [1]
+
+
+class Lcg:
+    """s = s*1664525 + 1013904223 (mod 2^32); SURVEY.md 8(d)."""
+
+    def __init__(self, seed):
+        self.s = seed & 0xFFFFFFFF
+
+    def next_u32(self):
+        self.s = (self.s * 1664525 + 1013904223) & 0xFFFFFFFF
+        return self.s
+
+    def uniform(self, lo=0.0, hi=1.0):
+        return lo + (hi - lo) * (self.next_u32() / 4294967296.0)
+
+    def array_u32(self, n):
+        out = np.empty(n, np.uint64)
+        s = self.s
+        for i in range(n):
+            s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            out[i] = s
+        self.s = s
+        return out.astype(np.uint32)
+
+
+def lcg_block_f32(seed, n):
+    """n floats uniform in [-1, 1) from the LCG, vectorised (jump-ahead by doubling)."""
+    # x_k = a^k x_0 + c (a^k - 1)/(a - 1); build a^k and the geometric sums by prefix doubling.
+    a, c, mask = 1664525, 1013904223, 0xFFFFFFFF
+    mult = np.empty(n, np.uint64)
+    add = np.empty(n, np.uint64)
+    mult[0], add[0] = a, c
+    filled = 1
+    while filled < n:
+        take = min(filled, n - filled)
+        am, aa = mult[filled - 1], add[filled - 1]   # advance-by-`filled` map
+        mult[filled:filled + take] = (mult[:take] * am) & mask
+        add[filled:filled + take] = (add[:take] * am + aa) & mask
+        filled += take
+    x = (mult * np.uint64(seed & mask) + add) & np.uint64(mask)
+    return (x.astype(np.float64) / 2147483648.0 - 1.0).astype(np.float32)
+
+
+def synth_mhr_bytes(seed=0x5EED1234, ir_size=64, az_counts=None, rate=48000, dist_mm=1200):
+    az_counts = list(DEFAULT_AZ_COUNTS if az_counts is None else az_counts)
+    ev_count = len(az_counts)
+    n_ir = sum(az_counts)
+    rng = np.random.default_rng(seed)
+    hdr = b"MinPHR03" + struct.pack("<IBBB", rate, 0, ir_size, 1)
+    hdr += struct.pack("<HB", dist_mm, ev_count) + bytes(az_counts)
+    t = np.arange(ir_size)
+    coeffs = np.zeros((n_ir, ir_size), np.float64)
+    delays = np.zeros(n_ir, np.uint8)
+    k = 0
+    for e, azc in enumerate(az_counts):
+        ev = -np.pi / 2 + np.pi * e / (ev_count - 1)
+        for a in range(azc):
+            az = 2 * np.pi * a / azc
+            lateral = np.sin(az) * np.cos(ev)          # +1 = source on the right
+            onset = 4.0 + 3.0 * (1.0 + lateral)        # left ear hears right-side sources later
+            env = np.exp(-np.maximum(t - onset, 0) / 6.0) * (t >= np.floor(onset))
+            ir = rng.standard_normal(ir_size) * env * (0.25 + 0.2 * (1.0 - lateral))
+            coeffs[k] = np.clip(ir, -0.95, 0.95)
+            delays[k] = int(round((20.0 + 18.0 * (1.0 + lateral)) * 4.0))   # quarter samples, <= 252
+            k += 1
+    q = np.round(coeffs * 8388608.0).astype(np.int64)
+    q = np.clip(q, -8388608, 8388607) & 0xFFFFFF
+    b = np.empty((n_ir, ir_size, 3), np.uint8)
+    b[..., 0] = q & 0xFF
+    b[..., 1] = (q >> 8) & 0xFF
+    b[..., 2] = (q >> 16) & 0xFF
+    return hdr + b.tobytes() + delays.tobytes()
+
+
+def write_synth_mhr(path, **kw):
+    data = synth_mhr_bytes(**kw)
+    with open(path, "wb") as f:
+        f.write(data)
+    return path
