@@ -185,6 +185,9 @@ class OracleLib:
         L.oal_scene_set_direct_hrtf.argtypes = [C.c_void_p, f32p, f32p, C.c_float, C.c_uint32]
         self.kind = L.oal_kind().decode()
 
+    def make_scene(self, **kw):
+        return Scene(self, **kw)
+
     # ---- tables ----
     def bsinc_table(self, which):
         t = BsincTable()
