@@ -1,0 +1,297 @@
+/* oalgpu.h -- C ABI of the MI355X-native voice-mixing path for OpenAL Soft.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++ or torch types.
+ * It replaces, for the per-voice mixing hot path only, what alc/alu.cpp's voice loop
+ * (ProcessContexts, alc/alu.cpp:2201-2206) reaches through the reference's function-pointer
+ * surface.  Each entry point cites the reference interface it stands in for (paths relative
+ * to kcat/openal-soft @ 2026-08-21).  INTEGRATION.md shows the reference-side binding.
+ *
+ * Two granularities:
+ *   1. per-call mirrors of the reference kernels (Resample_*, Mix_*, MixHrtf_*, MixHrtfBlend_*,
+ *      MixDirectHrtf_*, BiquadInterpFilter::dualProcess, HrtfStore::getCoeffs) operating on
+ *      host buffers -- one launch each; these exist for parity tests and small callers;
+ *   2. the batched path: a device context holding source buffers, tables, the HRIR set and all
+ *      per-voice mixing state in HBM, and oalgpu_mix_update() = "for every Playing|Stopping
+ *      voice: voice->mix(...)" for one update of <= 1024 samples, then the HRTF post-process.
+ *
+ * All functions return 0 on success or a negative oalgpu_error.  Nothing here throws.  A
+ * context is driven by one thread at a time (the reference's mixer thread); different contexts
+ * are independent.  There is NO CPU fallback: without a usable HIP device every call fails
+ * with OALGPU_ERR_NO_DEVICE.
+ */
+#ifndef OALGPU_H
+#define OALGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OALGPU_BUFFER_LINE_SIZE 1024      /* BufferLineSize, core/bufferline.h:11 */
+#define OALGPU_MAX_RESAMPLER_PADDING 48   /* core/resampler_limits.h:8 */
+#define OALGPU_MAX_RESAMPLER_EDGE 24      /* core/resampler_limits.h:10 */
+#define OALGPU_HRTF_HISTORY_LENGTH 64     /* core/mixer/hrtfdefs.h:16 */
+#define OALGPU_HRIR_LENGTH 128            /* core/mixer/hrtfdefs.h:20 */
+#define OALGPU_MAX_SENDS 6                /* MaxSendCount, core/voice.h:31 */
+#define OALGPU_MAX_OUTPUT_CHANNELS 32     /* core/devformat.h:81 */
+#define OALGPU_MAX_AMBI_CHANNELS 25       /* core/ambidefs.h:19 */
+#define OALGPU_MIXER_FRAC_BITS 16         /* core/mixer/defs.h:23 */
+
+typedef enum oalgpu_error {
+    OALGPU_OK = 0,
+    OALGPU_ERR_NO_DEVICE = -1,     /* no HIP device / HIP runtime failure at init */
+    OALGPU_ERR_INVALID = -2,       /* bad argument */
+    OALGPU_ERR_HIP = -3,           /* a HIP call failed; see oalgpu_last_error() */
+    OALGPU_ERR_NO_HRTF = -4,       /* HRTF requested but no data set loaded */
+    OALGPU_ERR_CAPACITY = -5       /* more voices/buffers than the context was created for */
+} oalgpu_error;
+
+/* enum class Resampler, core/mixer/defs.h:31-45 (same numeric values) */
+typedef enum oalgpu_resampler {
+    OALGPU_RESAMPLER_POINT, OALGPU_RESAMPLER_LINEAR, OALGPU_RESAMPLER_SPLINE,
+    OALGPU_RESAMPLER_GAUSSIAN, OALGPU_RESAMPLER_FAST_BSINC12, OALGPU_RESAMPLER_BSINC12,
+    OALGPU_RESAMPLER_FAST_BSINC24, OALGPU_RESAMPLER_BSINC24, OALGPU_RESAMPLER_FAST_BSINC48,
+    OALGPU_RESAMPLER_BSINC48
+} oalgpu_resampler;
+
+/* FmtType, core/storage_formats.h:9-19 (PCM types; ADPCM is a "next" row) */
+typedef enum oalgpu_fmt_type {
+    OALGPU_FMT_UBYTE, OALGPU_FMT_SHORT, OALGPU_FMT_INT, OALGPU_FMT_FLOAT, OALGPU_FMT_DOUBLE,
+    OALGPU_FMT_MULAW, OALGPU_FMT_ALAW
+} oalgpu_fmt_type;
+
+/* Voice::State, core/voice.h:178-183 */
+typedef enum oalgpu_play_state {
+    OALGPU_VOICE_STOPPED, OALGPU_VOICE_PLAYING, OALGPU_VOICE_STOPPING, OALGPU_VOICE_PENDING
+} oalgpu_play_state;
+
+/* BiquadType, core/filters/biquad.h:24-39 */
+typedef enum oalgpu_biquad_type {
+    OALGPU_BIQUAD_HIGHSHELF, OALGPU_BIQUAD_LOWSHELF, OALGPU_BIQUAD_PEAKING, OALGPU_BIQUAD_LOWPASS,
+    OALGPU_BIQUAD_HIGHPASS, OALGPU_BIQUAD_BANDPASS
+} oalgpu_biquad_type;
+
+/* Arithmetic mode of a context / per-call kernel.
+ * EXACT: every kernel reproduces the operation order and rounding (separate mul/add, FTZ) of
+ *        the reference's x86 SSE build, so single-voice results are bit-identical to it.
+ * FAST:  fused multiply-add in the FIR inner loops (resampler taps, HRTF taps); results agree
+ *        with the reference within the fp32 tolerance stated in DESIGN.md. */
+typedef enum oalgpu_math_mode { OALGPU_MATH_EXACT = 0, OALGPU_MATH_FAST = 1 } oalgpu_math_mode;
+
+const char *oalgpu_version(void);
+/* Human-readable text of the last failure on this thread ("" if none). */
+const char *oalgpu_last_error(void);
+/* Number of usable HIP devices (0 when there is none; never negative). */
+int oalgpu_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Tables and parameter preparation (host side, no GPU needed)
+ * ---------------------------------------------------------------------------------------- */
+/* BSincTable, core/bsinc_tables.h:11-20, generated as core/bsinc_tables.cpp:147-371 does. */
+typedef struct oalgpu_bsinc_table {
+    float scaleBase, scaleRange;
+    uint32_t m[16];
+    uint32_t filterOffset[16];
+    const float *tab;
+    size_t tablen;
+} oalgpu_bsinc_table;
+int oalgpu_bsinc_table_get(int which /* 12, 24, 48 */, oalgpu_bsinc_table *out);
+/* gSplineFilter / gGaussianFilter, core/cubic_tables.cpp:39-106; out = float[32][8]. */
+int oalgpu_cubic_table_get(int which /* 0 spline, 1 gaussian */, float *out);
+
+/* InterpState after PrepareResampler(resampler, increment, &state), alc/alu.cpp:253-281
+ * (BsincPrepare :140-164, kernel selection :167-238). */
+typedef struct oalgpu_interp_state {
+    int32_t kind;           /* 0 point, 1 linear, 2 cubic, 3 fast bsinc, 4 bsinc */
+    int32_t table;          /* cubic: 0 spline / 1 gaussian; bsinc: 12/24/48 */
+    float sf;               /* BsincState::sf */
+    uint32_t m, l;          /* BsincState::m, ::l */
+    uint32_t filter_offset; /* BsincState::filter as an offset (floats) into the table */
+} oalgpu_interp_state;
+int oalgpu_prepare_resampler(int resampler, uint32_t increment, oalgpu_interp_state *out);
+
+/* BiquadInterpFilter, core/filters/biquad.h:136-217 (coefficients, targets, counter, z). */
+typedef struct oalgpu_biquad {
+    float z1, z2;
+    float b0, b1, b2, a1, a2;
+    float tb0, tb1, tb2, ta1, ta2;
+    int32_t counter;
+} oalgpu_biquad;
+void oalgpu_biquad_reset(oalgpu_biquad *f);
+/* BiquadInterpFilter::setParamsFromSlope, biquad.h:172-177 -> biquad.cpp:48-149 (host libm). */
+void oalgpu_biquad_set_params_from_slope(oalgpu_biquad *f, int type, float f0norm, float gain,
+    float slope);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-call mirrors of the reference kernels.  Host pointers in, host pointers out; each call
+ * uploads, runs ONE hand-written HIP kernel on device `device`, downloads.  `mode` is an
+ * oalgpu_math_mode.
+ * ---------------------------------------------------------------------------------------- */
+/* ResamplerFunc, core/mixer/defs.h:71-72 (Resample_{Point,Linear,Cubic,FastBSinc,BSinc}_*).
+ * src = the reference's `src` span (mResampleData: starts MaxResamplerEdge samples before the
+ * first source sample). */
+int oalgpu_resample(int device, int mode, int resampler, uint32_t increment, const float *src,
+    size_t srclen, uint32_t frac, float *dst, size_t n);
+/* MixerOutFunc, core/mixer.h:22-25 (Mix_*, N lines): out = nlines x 1024 floats. */
+int oalgpu_mix(int device, const float *in, size_t n, float *out, size_t nlines,
+    float *current_gains, const float *target_gains, size_t counter, size_t outpos);
+/* HrtfMixerFunc, core/voice.cpp:73-75 (MixHrtf_*): in = n+64 floats, accum = (1024+128) f32x2. */
+int oalgpu_mix_hrtf(int device, int mode, const float *in, float *accum, uint32_t irsize,
+    const float *coeffs, const uint32_t delay[2], float gain, float gainstep, size_t n);
+/* HrtfMixerBlendFunc, core/voice.cpp:76-78 (MixHrtfBlend_*). */
+int oalgpu_mix_hrtf_blend(int device, int mode, const float *in, float *accum, uint32_t irsize,
+    const float *oldcoeffs, const uint32_t olddelay[2], float oldgain, const float *newcoeffs,
+    const uint32_t newdelay[2], float newgainstep, size_t n);
+/* BandSplitter state, core/filters/splitter.h:10-14 */
+typedef struct oalgpu_splitter { float coeff, lp_z1, lp_z2, ap_z1; } oalgpu_splitter;
+void oalgpu_splitter_init(oalgpu_splitter *s, float f0norm); /* splitter.cpp:14-26 */
+/* HrtfDirectMixerFunc, alc/alu.cpp:117-120 (MixDirectHrtf_*). */
+int oalgpu_mix_direct_hrtf(int device, int mode, float *left, float *right, const float *in,
+    size_t nch, float *accum, oalgpu_splitter *splitters, const float *hfscales,
+    const float *chan_coeffs, size_t irsize, size_t n);
+/* DualBiquadInterp::process, core/filters/biquad.h:211-217 -> biquad.cpp:284-343. */
+int oalgpu_biquad_dual_process(int device, oalgpu_biquad *f0, oalgpu_biquad *f1, const float *src,
+    float *dst, size_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched path: device context
+ * ---------------------------------------------------------------------------------------- */
+typedef struct oalgpu_context oalgpu_context;
+
+/* The part of DeviceBase (core/device.h:225-416) the voice path reads. */
+typedef struct oalgpu_context_desc {
+    int32_t  device;              /* HIP device ordinal */
+    int32_t  math_mode;           /* oalgpu_math_mode */
+    uint32_t sample_rate;         /* DeviceBase::mSampleRate */
+    uint32_t num_dry_channels;    /* Dry.Buffer lines (3 stereo, 5 for 7.1, 4 HRTF) */
+    uint32_t num_real_channels;   /* RealOut lines after Dry in MixBuffer (HRTF device: 2) */
+    uint32_t num_aux_sends;       /* DeviceBase::NumAuxSends (<= 6) */
+    uint32_t num_slots;           /* effect slots = wet buses */
+    uint32_t wet_channels;        /* lines per wet bus (4 = 1st order, 9 = 2nd order) */
+    int32_t  hrtf;                /* RenderMode::Hrtf: voices use the dual-ear FIR */
+    uint32_t max_voices;
+    uint32_t max_buffers;
+    uint32_t voices_per_group;    /* 0 = choose automatically (tuning knob) */
+} oalgpu_context_desc;
+
+int  oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out);
+void oalgpu_context_destroy(oalgpu_context *ctx);
+
+/* LoadHrtf(std::istream&), core/hrtf_loader.hpp:10 (format v3 "MinPHR03",
+ * core/hrtf_loader.cpp:583-721); the store is uploaded to HBM.  Must precede any HRTF voice. */
+int oalgpu_hrtf_load_mhr(oalgpu_context *ctx, const void *data, size_t size);
+typedef struct oalgpu_hrtf_info {
+    uint32_t sample_rate, ir_size, num_fields, num_elevs, num_irs;
+} oalgpu_hrtf_info;
+int oalgpu_hrtf_info_get(oalgpu_context *ctx, oalgpu_hrtf_info *out);
+/* Host copy of the parsed store, HrtfStore layout (core/hrtf.h:22-44). */
+int oalgpu_hrtf_raw(oalgpu_context *ctx, float *field_distance, uint8_t *field_evcount,
+    uint16_t *elev_azcount, uint16_t *elev_iroffset, float *coeffs, uint8_t *delays);
+/* HrtfStore::getCoeffs, core/hrtf.cpp:192-260, evaluated ON THE GPU for `count` directions.
+ * dirs = count x {elevation, azimuth, distance, spread}; coeffs = count x 128 x 2;
+ * delays = count x 2. */
+int oalgpu_hrtf_get_coeffs(oalgpu_context *ctx, const float *dirs, size_t count, float *coeffs,
+    uint32_t *delays);
+/* DirectHrtfState (core/hrtf.h:85-109) used by the post-process: per dry channel decoder IR,
+ * HF scale and the shared crossover (the decoder design itself, alc/panning.cpp:847-1138, is
+ * one-time init and stays with the caller). */
+int oalgpu_set_direct_hrtf(oalgpu_context *ctx, const float *chan_coeffs /* ndry x 128 x 2 */,
+    const float *hfscales, float xover_norm, uint32_t irsize);
+
+/* al::Buffer storage / VoiceBufferItem (core/voice.h:84-98): sample data is copied to HBM once.
+ * frame_step = interleaved samples per frame; mono voices read channel 0.  Returns the handle
+ * (>= 0) or a negative error. */
+int oalgpu_buffer_register(oalgpu_context *ctx, const void *data, int fmt_type,
+    uint32_t frame_step, uint32_t sample_len, uint32_t loop_start, uint32_t loop_end);
+
+/* Voice::prepare + the source attach of InitVoice (al/source.cpp:639-670) for a static mono
+ * voice: mixing state cleared, position set, state Playing, not fading. */
+typedef struct oalgpu_voice_desc {
+    int32_t  buffer;
+    int32_t  looping;             /* mLoopBuffer != nullptr */
+    int32_t  position;            /* mPosition */
+    uint32_t position_frac;       /* mPositionFrac */
+    uint32_t frequency;           /* mFrequency */
+} oalgpu_voice_desc;
+int oalgpu_voice_init(oalgpu_context *ctx, uint32_t voice, const oalgpu_voice_desc *desc);
+
+typedef struct oalgpu_filter_params {
+    int32_t active;               /* TargetData::FilterActive */
+    float gain_hf, hf_norm;       /* HighShelf gain, HFReference / sample_rate */
+    float gain_lf, lf_norm;       /* LowShelf gain, LFReference / sample_rate */
+} oalgpu_filter_params;
+
+/* What CalcVoiceParams (alc/alu.cpp:1512-1710,2012-2031) leaves in the Voice for mix() to use. */
+typedef struct oalgpu_voice_params {
+    uint32_t step;                                   /* mStep */
+    int32_t  resampler;                              /* props.mResampler */
+    oalgpu_filter_params direct_filter;              /* alc/alu.cpp:1619-1637 */
+    float    dry_gains[OALGPU_MAX_OUTPUT_CHANNELS];  /* mDryParams.Gains.Target */
+    float    hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread; /* getCoeffs arguments, alu.cpp:1214 */
+    float    hrtf_gain;                              /* Hrtf.Target.Gain */
+    int32_t  send_slot[OALGPU_MAX_SENDS];            /* -1: mSend[i].Buffer empty */
+    oalgpu_filter_params send_filter[OALGPU_MAX_SENDS];
+    float    send_gains[OALGPU_MAX_SENDS][OALGPU_MAX_AMBI_CHANNELS]; /* mWetParams[i].Gains.Target */
+} oalgpu_voice_params;
+/* Applies `count` parameter blocks (voices[i] <- params[i]); the HRIR blend of getCoeffs and
+ * the BiquadInterpFilter::setParams state machine run on the GPU. */
+int oalgpu_voice_set_params(oalgpu_context *ctx, const uint32_t *voices,
+    const oalgpu_voice_params *params, size_t count);
+/* ProcessVoiceChanges side (alc/alu.cpp:2057-2151): Playing / Stopping / Stopped. */
+int oalgpu_voice_set_state(oalgpu_context *ctx, uint32_t voice, int play_state);
+
+/* One update: zero the dry/real and wet buses, mix every Playing|Stopping voice
+ * (Voice::mix, core/voice.cpp:988-1233), and -- HRTF context, post_process != 0 -- run
+ * MixDirectHrtf over the dry bus (DeviceBase::Process(HrtfPostProcess), alc/alu.cpp:289-298).
+ * Asynchronous on the context's stream; oalgpu_sync() or a read-back waits. */
+int oalgpu_mix_update(oalgpu_context *ctx, uint32_t samples_to_do, int post_process);
+int oalgpu_sync(oalgpu_context *ctx);
+
+/* Bus read-back (host copies).  dry: (num_dry+num_real) x 1024; wet: wet_channels x 1024;
+ * hrtf_accum: (1024+128) x 2. */
+int oalgpu_read_dry(oalgpu_context *ctx, float *out);
+int oalgpu_read_wet(oalgpu_context *ctx, uint32_t slot, float *out);
+int oalgpu_read_hrtf_accum(oalgpu_context *ctx, float *out);
+/* Device address of the bus block [dry+real lines | wet buses | hrtf accum], its length in
+ * floats, and the stream it is produced on, for zero-copy consumers (e.g. an RCCL reduce). */
+int oalgpu_bus_device_ptr(oalgpu_context *ctx, void **ptr, size_t *nfloats, void **hip_stream);
+/* Multi-GPU split of one update: mix_voices fills this rank's partial buses (no post-process);
+ * after the caller has summed the bus block across ranks (one RCCL all-reduce/reduce),
+ * post_process runs MixDirectHrtf on the summed buses. */
+int oalgpu_mix_voices(oalgpu_context *ctx, uint32_t samples_to_do);
+int oalgpu_post_process(oalgpu_context *ctx, uint32_t samples_to_do);
+/* Whether this context's voice kernel continues the HRTF accumulator tail carried over from
+ * the previous update (HrtfAccumData, core/device.h:288).  Default on.  With the buses summed
+ * across ranks exactly one rank -- the one whose post-process owns the tail -- keeps it on. */
+int oalgpu_set_carry_accum(oalgpu_context *ctx, int enable);
+
+/* Mixing state of one voice after the last update (the fields Voice::mix mutates). */
+typedef struct oalgpu_voice_state {
+    int32_t  play_state;
+    int32_t  position;
+    uint32_t position_frac;
+    int32_t  has_buffer;
+    int32_t  fading;
+    float    prev_samples[OALGPU_MAX_RESAMPLER_PADDING];
+    float    dry_current[OALGPU_MAX_OUTPUT_CHANNELS];
+    float    hrtf_old_gain;
+    uint32_t hrtf_old_delay[2];
+    float    hrtf_history[OALGPU_HRTF_HISTORY_LENGTH];
+    oalgpu_biquad direct_lp, direct_hp;
+    float    send_current[OALGPU_MAX_SENDS][OALGPU_MAX_AMBI_CHANNELS];
+    oalgpu_biquad send_lp[OALGPU_MAX_SENDS], send_hp[OALGPU_MAX_SENDS];
+} oalgpu_voice_state;
+int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_state *out);
+
+/* Timing of the last oalgpu_mix_update/mix_voices launch sequence, measured with HIP events on
+ * the context's stream: total milliseconds, and the share of the voice kernel. */
+int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);
+/* Enables/disables the event timing above (off by default: it adds two event records). */
+int oalgpu_set_timing(oalgpu_context *ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OALGPU_H */

@@ -1,0 +1,751 @@
+// C-ABI shim (include/oalgpu.h) over the HIP kernels.  Host logic only: argument checks,
+// HBM allocation/upload, parameter preparation that the reference does with libm on its mixer
+// thread (resampler state, biquad design), and kernel launches on the context's stream.
+// No CPU fallback exists anywhere in this file: without a HIP device every entry point fails.
+#include "../../include/oalgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../host/mhr.hpp"
+#include "../host/params.hpp"
+#include "../host/tables.hpp"
+#include "kernels.hpp"
+
+using namespace oalgpu;
+
+namespace {
+
+thread_local std::string gLastError;
+
+int Fail(int code, const std::string &msg)
+{
+    gLastError = msg;
+    return code;
+}
+
+#define HIP_TRY(expr) do { \
+    const hipError_t err_ = (expr); \
+    if(err_ != hipSuccess) \
+        return Fail(OALGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err_)); \
+} while(0)
+
+int UseDevice(int device)
+{
+    int count = 0;
+    if(hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return Fail(OALGPU_ERR_NO_DEVICE, "no HIP device available (the product has no CPU path)");
+    if(device < 0 || device >= count) return Fail(OALGPU_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    return OALGPU_OK;
+}
+
+// device scratch that frees itself
+template<typename T>
+struct DevBuf {
+    T *p{nullptr};
+    size_t n{0};
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf &operator=(const DevBuf&) = delete;
+    ~DevBuf() { if(p) (void)hipFree(p); }
+    hipError_t alloc(size_t count)
+    {
+        if(p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    }
+    hipError_t upload(const T *src, size_t count) { return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice); }
+    hipError_t download(T *dst, size_t count) const { return hipMemcpy(dst, p, count * sizeof(T), hipMemcpyDeviceToHost); }
+    hipError_t zero() { return hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)); }
+};
+
+// One blob with every resampler table: [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
+struct TableBlob {
+    std::vector<float> data;
+    uint32_t bsincBase[3]{};
+    uint32_t cubicBase[2]{};
+    TableBlob()
+    {
+        const int fam[3] = {12, 24, 48};
+        for(int i = 0; i < 3; ++i)
+        {
+            const BsincTable *t = GetBsincTable(fam[i]);
+            bsincBase[i] = uint32_t(data.size());
+            data.insert(data.end(), t->tab.begin(), t->tab.end());
+        }
+        for(int i = 0; i < 2; ++i)
+        {
+            const CubicTable *t = GetCubicTable(i);
+            cubicBase[i] = uint32_t(data.size());
+            data.insert(data.end(), &t->phase[0][0], &t->phase[0][0] + 256);
+        }
+    }
+    uint32_t filterBase(const oalgpu_interp_state &st) const
+    {
+        switch(st.kind)
+        {
+        case 2: return cubicBase[st.table ? 1 : 0];
+        case 3: case 4: return bsincBase[st.table == 12 ? 0 : st.table == 24 ? 1 : 2] + st.filter_offset;
+        default: return 0;
+        }
+    }
+};
+const TableBlob &Blob() { static const TableBlob b; return b; }
+
+} // namespace
+
+struct oalgpu_context {
+    oalgpu_context_desc desc{};
+    bool exact{true};
+    hipStream_t stream{nullptr};
+    hipEvent_t evStart{nullptr}, evVoice{nullptr}, evEnd{nullptr};
+    bool timing{false}, timed{false};
+    DeviceLayout L{};
+    HrtfStoreDev hrtfDev{};
+    HrtfData hrtfHost;
+    bool hrtfLoaded{false};
+    bool carryAccum{true};
+
+    DevBuf<float> tables;
+    DevBuf<BufferItem> buffers;
+    std::vector<void*> bufferData;
+    uint32_t numBuffers{0};
+    DevBuf<VoiceCtl> ctl;
+    DevBuf<float> prev, hrtfOld, hrtfTgt, hist, gainCur, gainTgt, sendCur, sendTgt;
+    DevBuf<BiquadSlot> dfilt, sfilt;
+    DevBuf<float> partLines, partHrtf, bus;
+    // HRTF store
+    DevBuf<float> hFieldDist, hCoeffs;
+    DevBuf<uint8_t> hEvCount, hDelays;
+    DevBuf<uint16_t> hAzCount, hIrOffset;
+    // DirectHrtfState
+    DevBuf<SplitterState> dSplit;
+    DevBuf<float> dHfScale, dCoeffs, dTemp;
+    uint32_t dIrSize{0};
+    bool directSet{false};
+    // staging
+    DevBuf<ParamRecord> paramDev;
+    std::vector<ParamRecord> paramHost;
+    DevBuf<VoiceInitRecord> initDev;
+    std::vector<VoiceInitRecord> initPending;
+
+    ~oalgpu_context()
+    {
+        for(void *p : bufferData) if(p) (void)hipFree(p);
+        if(evStart) (void)hipEventDestroy(evStart);
+        if(evVoice) (void)hipEventDestroy(evVoice);
+        if(evEnd) (void)hipEventDestroy(evEnd);
+        if(stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int FlushInits(oalgpu_context *c)
+{
+    if(c->initPending.empty()) return OALGPU_OK;
+    const size_t n = c->initPending.size();
+    if(c->initDev.n < n) HIP_TRY(c->initDev.alloc(n));
+    HIP_TRY(hipMemcpyAsync(c->initDev.p, c->initPending.data(), n * sizeof(VoiceInitRecord), hipMemcpyHostToDevice, c->stream));
+    LaunchInitVoices(c->stream, c->L, c->initDev.p, uint32_t(n));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the host vector is reused
+    c->initPending.clear();
+    return OALGPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *oalgpu_version(void) { return "oalgpu 0.1 (gfx950)"; }
+const char *oalgpu_last_error(void) { return gLastError.c_str(); }
+
+int oalgpu_device_count(void)
+{
+    int count = 0;
+    if(hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count < 0 ? 0 : count;
+}
+
+// ---------------------------------------------------------------- host-side tables / params
+int oalgpu_bsinc_table_get(int which, oalgpu_bsinc_table *out)
+{
+    const BsincTable *t = GetBsincTable(which);
+    if(!t || !out) return Fail(OALGPU_ERR_INVALID, "bsinc table: which must be 12, 24 or 48");
+    out->scaleBase = t->scaleBase; out->scaleRange = t->scaleRange;
+    std::memcpy(out->m, t->m, sizeof(out->m));
+    std::memcpy(out->filterOffset, t->filterOffset, sizeof(out->filterOffset));
+    out->tab = t->tab.data(); out->tablen = t->tab.size();
+    return OALGPU_OK;
+}
+
+int oalgpu_cubic_table_get(int which, float *out)
+{
+    const CubicTable *t = GetCubicTable(which);
+    if(!t || !out) return Fail(OALGPU_ERR_INVALID, "cubic table: which must be 0 or 1");
+    std::memcpy(out, t->phase, sizeof(t->phase));
+    return OALGPU_OK;
+}
+
+int oalgpu_prepare_resampler(int resampler, uint32_t increment, oalgpu_interp_state *out)
+{
+    if(!out || resampler < 0 || resampler > OALGPU_RESAMPLER_BSINC48) return Fail(OALGPU_ERR_INVALID, "bad resampler");
+    PrepareResampler(resampler, increment, out);
+    return OALGPU_OK;
+}
+
+void oalgpu_biquad_reset(oalgpu_biquad *f)
+{
+    std::memset(f, 0, sizeof(*f));
+    f->b0 = 1.0f; f->tb0 = 1.0f; f->counter = -1;
+}
+
+void oalgpu_biquad_set_params_from_slope(oalgpu_biquad *f, int type, float f0norm, float gain, float slope)
+{
+    float c[5];
+    DesignBiquadFromSlope(type, f0norm, gain, slope, c);
+    ApplyBiquadTarget(f, c);
+}
+
+void oalgpu_splitter_init(oalgpu_splitter *s, float f0norm)
+{
+    s->coeff = SplitterCoeff(f0norm);
+    s->lp_z1 = s->lp_z2 = s->ap_z1 = 0.0f;
+}
+
+// ---------------------------------------------------------------- per-call kernels
+int oalgpu_resample(int device, int mode, int resampler, uint32_t increment, const float *src, size_t srclen,
+    uint32_t frac, float *dst, size_t n)
+{
+    if(!src || !dst || n == 0 || n > 4096 || frac >= kFracOne || increment < 1) return Fail(OALGPU_ERR_INVALID, "oalgpu_resample: bad arguments");
+    if(int rc = UseDevice(device)) return rc;
+    oalgpu_interp_state st;
+    if(int rc = oalgpu_prepare_resampler(resampler, increment, &st)) return rc;
+    const TableBlob &blob = Blob();
+    DevBuf<float> dTab, dSrc, dDst;
+    HIP_TRY(dTab.alloc(blob.data.size())); HIP_TRY(dTab.upload(blob.data.data(), blob.data.size()));
+    HIP_TRY(dSrc.alloc(srclen)); HIP_TRY(dSrc.upload(src, srclen));
+    HIP_TRY(dDst.alloc(n));
+    ResampleSpec spec{st.kind, st.m, st.l, st.sf, dTab.p + blob.filterBase(st)};
+    LaunchResample(nullptr, mode == OALGPU_MATH_EXACT, spec, dSrc.p, frac, increment, dDst.p, uint32_t(n));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dDst.download(dst, n));
+    return OALGPU_OK;
+}
+
+int oalgpu_mix(int device, const float *in, size_t n, float *out, size_t nlines, float *current_gains,
+    const float *target_gains, size_t counter, size_t outpos)
+{
+    if(!in || !out || !current_gains || !target_gains || n == 0 || n + outpos > kLine || nlines == 0 || nlines > 64)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_mix: bad arguments");
+    if(int rc = UseDevice(device)) return rc;
+    DevBuf<float> dIn, dOut, dCur, dTgt;
+    HIP_TRY(dIn.alloc(n)); HIP_TRY(dIn.upload(in, n));
+    HIP_TRY(dOut.alloc(nlines * kLine)); HIP_TRY(dOut.upload(out, nlines * kLine));
+    HIP_TRY(dCur.alloc(nlines)); HIP_TRY(dCur.upload(current_gains, nlines));
+    HIP_TRY(dTgt.alloc(nlines)); HIP_TRY(dTgt.upload(target_gains, nlines));
+    LaunchMix(nullptr, dIn.p, uint32_t(n), dOut.p, uint32_t(nlines), dCur.p, dTgt.p, uint32_t(counter), uint32_t(outpos));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dOut.download(out, nlines * kLine));
+    HIP_TRY(dCur.download(current_gains, nlines));
+    return OALGPU_OK;
+}
+
+static int MixHrtfCommon(int device, int mode, const float *in, float *accum, uint32_t irsize, const float *coeffs,
+    const uint32_t delay[2], float gain, float step, const float *oldcoeffs, const uint32_t olddelay[2], float oldgain,
+    int blend, size_t n)
+{
+    if(!in || !accum || !coeffs || !delay || n == 0 || n > kLine || irsize < 8 || irsize > kHrirLen
+        || delay[0] > 63 || delay[1] > 63)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_mix_hrtf: bad arguments");
+    if(int rc = UseDevice(device)) return rc;
+    constexpr size_t accLen = (kLine + kHrirLen) * 2;
+    DevBuf<float> dIn, dAcc, dCo, dOld;
+    HIP_TRY(dIn.alloc(n + kHist)); HIP_TRY(dIn.upload(in, n + kHist));
+    HIP_TRY(dAcc.alloc(accLen)); HIP_TRY(dAcc.upload(accum, accLen));
+    HIP_TRY(dCo.alloc(kHrirLen * 2)); HIP_TRY(dCo.upload(coeffs, kHrirLen * 2));
+    HIP_TRY(dOld.alloc(kHrirLen * 2));
+    if(blend) HIP_TRY(dOld.upload(oldcoeffs, kHrirLen * 2));
+    LaunchMixHrtf(nullptr, mode == OALGPU_MATH_EXACT, dIn.p, dAcc.p, irsize, dCo.p, delay[0], delay[1], gain, step,
+        dOld.p, blend ? olddelay[0] : 0, blend ? olddelay[1] : 0, oldgain, blend, uint32_t(n));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dAcc.download(accum, accLen));
+    return OALGPU_OK;
+}
+
+int oalgpu_mix_hrtf(int device, int mode, const float *in, float *accum, uint32_t irsize, const float *coeffs,
+    const uint32_t delay[2], float gain, float gainstep, size_t n)
+{ return MixHrtfCommon(device, mode, in, accum, irsize, coeffs, delay, gain, gainstep, nullptr, nullptr, 0.0f, 0, n); }
+
+int oalgpu_mix_hrtf_blend(int device, int mode, const float *in, float *accum, uint32_t irsize,
+    const float *oldcoeffs, const uint32_t olddelay[2], float oldgain, const float *newcoeffs,
+    const uint32_t newdelay[2], float newgainstep, size_t n)
+{
+    if(!oldcoeffs || !olddelay || olddelay[0] > 63 || olddelay[1] > 63) return Fail(OALGPU_ERR_INVALID, "oalgpu_mix_hrtf_blend: bad arguments");
+    return MixHrtfCommon(device, mode, in, accum, irsize, newcoeffs, newdelay, 0.0f, newgainstep, oldcoeffs, olddelay,
+        oldgain, 1, n);
+}
+
+int oalgpu_mix_direct_hrtf(int device, int mode, float *left, float *right, const float *in, size_t nch,
+    float *accum, oalgpu_splitter *splitters, const float *hfscales, const float *chan_coeffs, size_t irsize, size_t n)
+{
+    if(!left || !right || !in || !accum || !splitters || !hfscales || !chan_coeffs || nch == 0 || nch > 64 || n == 0
+        || n > kLine || irsize < 8 || irsize > kHrirLen)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_mix_direct_hrtf: bad arguments");
+    if(int rc = UseDevice(device)) return rc;
+    constexpr size_t accLen = (kLine + kHrirLen) * 2;
+    DevBuf<float> dL, dR, dIn, dAcc, dHf, dCo, dTemp;
+    DevBuf<SplitterState> dSp;
+    HIP_TRY(dL.alloc(kLine)); HIP_TRY(dL.upload(left, kLine));
+    HIP_TRY(dR.alloc(kLine)); HIP_TRY(dR.upload(right, kLine));
+    HIP_TRY(dIn.alloc(nch * kLine)); HIP_TRY(dIn.upload(in, nch * kLine));
+    HIP_TRY(dAcc.alloc(accLen)); HIP_TRY(dAcc.upload(accum, accLen));
+    HIP_TRY(dHf.alloc(nch)); HIP_TRY(dHf.upload(hfscales, nch));
+    HIP_TRY(dCo.alloc(nch * kHrirLen * 2)); HIP_TRY(dCo.upload(chan_coeffs, nch * kHrirLen * 2));
+    HIP_TRY(dTemp.alloc(nch * kLine + accLen));
+    HIP_TRY(dSp.alloc(nch)); HIP_TRY(dSp.upload(reinterpret_cast<const SplitterState*>(splitters), nch));
+    LaunchMixDirectHrtf(nullptr, mode == OALGPU_MATH_EXACT, dL.p, dR.p, dIn.p, uint32_t(nch), dAcc.p, dSp.p, dHf.p,
+        dCo.p, uint32_t(irsize), uint32_t(n), dTemp.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dL.download(left, kLine)); HIP_TRY(dR.download(right, kLine));
+    HIP_TRY(dAcc.download(accum, accLen));
+    HIP_TRY(dSp.download(reinterpret_cast<SplitterState*>(splitters), nch));
+    return OALGPU_OK;
+}
+
+int oalgpu_biquad_dual_process(int device, oalgpu_biquad *f0, oalgpu_biquad *f1, const float *src, float *dst, size_t n)
+{
+    if(!f0 || !f1 || !src || !dst || n == 0 || n > (1u << 20)) return Fail(OALGPU_ERR_INVALID, "oalgpu_biquad_dual_process: bad arguments");
+    if(int rc = UseDevice(device)) return rc;
+    DevBuf<BiquadState> dF;
+    DevBuf<float> dSrc, dDst;
+    BiquadState st[2];
+    std::memcpy(&st[0], f0, sizeof(BiquadState)); std::memcpy(&st[1], f1, sizeof(BiquadState));
+    HIP_TRY(dF.alloc(2)); HIP_TRY(dF.upload(st, 2));
+    HIP_TRY(dSrc.alloc(n)); HIP_TRY(dSrc.upload(src, n));
+    HIP_TRY(dDst.alloc(n));
+    LaunchBiquadDual(nullptr, dF.p, dF.p + 1, dSrc.p, dDst.p, uint32_t(n));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(dDst.download(dst, n));
+    HIP_TRY(dF.download(st, 2));
+    std::memcpy(f0, &st[0], sizeof(BiquadState)); std::memcpy(f1, &st[1], sizeof(BiquadState));
+    return OALGPU_OK;
+}
+
+// ---------------------------------------------------------------- context
+int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
+{
+    if(!desc || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if(desc->max_voices == 0 || desc->num_dry_channels == 0 || desc->num_dry_channels > OALGPU_MAX_OUTPUT_CHANNELS
+        || desc->num_aux_sends > OALGPU_MAX_SENDS || desc->wet_channels > OALGPU_MAX_AMBI_CHANNELS
+        || (desc->num_aux_sends && (desc->num_slots == 0 || desc->wet_channels == 0)))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_context_create: bad descriptor");
+    const uint32_t mixLines = (desc->hrtf ? 0u : desc->num_dry_channels) + desc->num_slots * desc->wet_channels;
+    if(mixLines > 32) return Fail(OALGPU_ERR_CAPACITY, "more than 32 mixing lines (dry + wet) are not supported yet");
+    if(int rc = UseDevice(desc->device)) return rc;
+
+    auto c = std::make_unique<oalgpu_context>();
+    c->desc = *desc;
+    c->exact = desc->math_mode == OALGPU_MATH_EXACT;
+    HIP_TRY(hipStreamCreate(&c->stream));
+    HIP_TRY(hipEventCreate(&c->evStart)); HIP_TRY(hipEventCreate(&c->evVoice)); HIP_TRY(hipEventCreate(&c->evEnd));
+
+    DeviceLayout &L = c->L;
+    L.numVoices = desc->max_voices;
+    L.numDry = desc->num_dry_channels; L.numReal = desc->num_real_channels;
+    L.numSends = desc->num_aux_sends; L.numSlots = desc->num_slots; L.wetChannels = desc->wet_channels;
+    L.hrtf = desc->hrtf ? 1u : 0u;
+    L.irSize = 0; L.irStride = 8;
+    L.mixLines = mixLines;
+    uint32_t vpg = desc->voices_per_group;
+    if(vpg == 0)
+    {
+        // enough groups to put several workgroups on each of the 256 CUs, but no more partial
+        // buses than needed: aim for ~1024 groups, at least 2 voices per group
+        vpg = std::max<uint32_t>(2u, (desc->max_voices + 1023u) / 1024u);
+    }
+    L.voicesPerGroup = vpg;
+    L.numGroups = std::max<uint32_t>(1u, (desc->max_voices + vpg - 1u) / vpg);
+
+    const TableBlob &blob = Blob();
+    HIP_TRY(c->tables.alloc(blob.data.size())); HIP_TRY(c->tables.upload(blob.data.data(), blob.data.size()));
+    L.tables = c->tables.p;
+    HIP_TRY(c->buffers.alloc(std::max<uint32_t>(desc->max_buffers, 1u))); HIP_TRY(c->buffers.zero());
+    L.buffers = c->buffers.p;
+    c->bufferData.assign(std::max<uint32_t>(desc->max_buffers, 1u), nullptr);
+
+    const size_t nv = desc->max_voices;
+    HIP_TRY(c->ctl.alloc(nv)); HIP_TRY(c->ctl.zero()); L.ctl = c->ctl.p;
+    HIP_TRY(c->prev.alloc(nv * kMaxPad)); HIP_TRY(c->prev.zero()); L.prev = c->prev.p;
+    HIP_TRY(c->dfilt.alloc(nv * 2)); HIP_TRY(c->dfilt.zero()); L.dfilt = c->dfilt.p;
+    HIP_TRY(c->hist.alloc(nv * kHist)); HIP_TRY(c->hist.zero()); L.hist = c->hist.p;
+    HIP_TRY(c->gainCur.alloc(nv * L.numDry)); HIP_TRY(c->gainCur.zero()); L.gainCur = c->gainCur.p;
+    HIP_TRY(c->gainTgt.alloc(nv * L.numDry)); HIP_TRY(c->gainTgt.zero()); L.gainTgt = c->gainTgt.p;
+    HIP_TRY(c->sfilt.alloc(nv * L.numSends * 2)); HIP_TRY(c->sfilt.zero()); L.sfilt = c->sfilt.p;
+    HIP_TRY(c->sendCur.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendCur.zero()); L.sendCur = c->sendCur.p;
+    HIP_TRY(c->sendTgt.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendTgt.zero()); L.sendTgt = c->sendTgt.p;
+    HIP_TRY(c->partLines.alloc(size_t{L.numGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
+    HIP_TRY(c->partHrtf.alloc(L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0)); L.partHrtf = c->partHrtf.p;
+    HIP_TRY(c->bus.alloc(BusFloats(L))); HIP_TRY(c->bus.zero()); L.bus = c->bus.p;
+    // HRTF voice filters are sized when the data set is loaded
+    L.hrtfOld = nullptr; L.hrtfTgt = nullptr;
+
+    HIP_TRY(c->dSplit.alloc(L.numDry)); HIP_TRY(c->dSplit.zero());
+    HIP_TRY(c->dHfScale.alloc(L.numDry)); HIP_TRY(c->dHfScale.zero());
+    HIP_TRY(c->dCoeffs.alloc(size_t{L.numDry} * kHrirLen * 2)); HIP_TRY(c->dCoeffs.zero());
+    HIP_TRY(c->dTemp.alloc(size_t{L.numDry} * kLine + (kLine + kHrirLen) * 2));
+    *out = c.release();
+    return OALGPU_OK;
+}
+
+void oalgpu_context_destroy(oalgpu_context *ctx)
+{
+    if(!ctx) return;
+    (void)hipSetDevice(ctx->desc.device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete ctx;
+}
+
+int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
+{
+    if(!c || !data) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    const std::string err = ParseMhr(data, size, c->hrtfHost);
+    if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
+    const HrtfData &h = c->hrtfHost;
+    HIP_TRY(c->hFieldDist.alloc(h.fieldDistance.size())); HIP_TRY(c->hFieldDist.upload(h.fieldDistance.data(), h.fieldDistance.size()));
+    HIP_TRY(c->hEvCount.alloc(h.fieldEvCount.size())); HIP_TRY(c->hEvCount.upload(h.fieldEvCount.data(), h.fieldEvCount.size()));
+    HIP_TRY(c->hAzCount.alloc(h.elevAzCount.size())); HIP_TRY(c->hAzCount.upload(h.elevAzCount.data(), h.elevAzCount.size()));
+    HIP_TRY(c->hIrOffset.alloc(h.elevIrOffset.size())); HIP_TRY(c->hIrOffset.upload(h.elevIrOffset.data(), h.elevIrOffset.size()));
+    HIP_TRY(c->hCoeffs.alloc(h.coeffs.size())); HIP_TRY(c->hCoeffs.upload(h.coeffs.data(), h.coeffs.size()));
+    HIP_TRY(c->hDelays.alloc(h.delays.size())); HIP_TRY(c->hDelays.upload(h.delays.data(), h.delays.size()));
+    HrtfStoreDev &d = c->hrtfDev;
+    d.irSize = h.irSize; d.numFields = uint32_t(h.fieldDistance.size()); d.numElevs = uint32_t(h.elevAzCount.size());
+    d.numIrs = h.numIrs();
+    d.fieldDistance = c->hFieldDist.p; d.fieldEvCount = c->hEvCount.p; d.elevAzCount = c->hAzCount.p;
+    d.elevIrOffset = c->hIrOffset.p; d.coeffs = c->hCoeffs.p; d.delays = c->hDelays.p;
+    c->hrtfLoaded = true;
+
+    DeviceLayout &L = c->L;
+    L.irSize = h.irSize;
+    L.irStride = (h.irSize + 7u) & ~7u;
+    if(L.hrtf)
+    {
+        const size_t n = size_t{L.numVoices} * L.irStride * 2;
+        HIP_TRY(c->hrtfOld.alloc(n)); HIP_TRY(c->hrtfOld.zero()); L.hrtfOld = c->hrtfOld.p;
+        HIP_TRY(c->hrtfTgt.alloc(n)); HIP_TRY(c->hrtfTgt.zero()); L.hrtfTgt = c->hrtfTgt.p;
+        if(!c->directSet) c->dIrSize = h.irSize;
+    }
+    return OALGPU_OK;
+}
+
+int oalgpu_hrtf_info_get(oalgpu_context *c, oalgpu_hrtf_info *out)
+{
+    if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "no HRTF data set loaded");
+    const HrtfData &h = c->hrtfHost;
+    out->sample_rate = h.sampleRate; out->ir_size = h.irSize;
+    out->num_fields = uint32_t(h.fieldDistance.size()); out->num_elevs = uint32_t(h.elevAzCount.size());
+    out->num_irs = h.numIrs();
+    return OALGPU_OK;
+}
+
+int oalgpu_hrtf_raw(oalgpu_context *c, float *field_distance, uint8_t *field_evcount, uint16_t *elev_azcount,
+    uint16_t *elev_iroffset, float *coeffs, uint8_t *delays)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "no HRTF data set loaded");
+    const HrtfData &h = c->hrtfHost;
+    std::copy(h.fieldDistance.begin(), h.fieldDistance.end(), field_distance);
+    std::copy(h.fieldEvCount.begin(), h.fieldEvCount.end(), field_evcount);
+    std::copy(h.elevAzCount.begin(), h.elevAzCount.end(), elev_azcount);
+    std::copy(h.elevIrOffset.begin(), h.elevIrOffset.end(), elev_iroffset);
+    std::copy(h.coeffs.begin(), h.coeffs.end(), coeffs);
+    std::copy(h.delays.begin(), h.delays.end(), delays);
+    return OALGPU_OK;
+}
+
+int oalgpu_hrtf_get_coeffs(oalgpu_context *c, const float *dirs, size_t count, float *coeffs, uint32_t *delays)
+{
+    if(!c || !dirs || !coeffs || !delays || count == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_hrtf_get_coeffs: bad arguments");
+    if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "no HRTF data set loaded");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    DevBuf<float> dDirs, dCo;
+    DevBuf<uint32_t> dDel;
+    HIP_TRY(dDirs.alloc(count * 4)); HIP_TRY(dDirs.upload(dirs, count * 4));
+    HIP_TRY(dCo.alloc(count * kHrirLen * 2));
+    HIP_TRY(dDel.alloc(count * 2));
+    LaunchGetCoeffs(c->stream, c->hrtfDev, dDirs.p, uint32_t(count), dCo.p, dDel.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(dCo.download(coeffs, count * kHrirLen * 2));
+    HIP_TRY(dDel.download(delays, count * 2));
+    return OALGPU_OK;
+}
+
+int oalgpu_set_direct_hrtf(oalgpu_context *c, const float *chan_coeffs, const float *hfscales, float xover_norm,
+    uint32_t irsize)
+{
+    if(!c || !chan_coeffs || !hfscales || irsize < 8 || irsize > kHrirLen) return Fail(OALGPU_ERR_INVALID, "oalgpu_set_direct_hrtf: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    const uint32_t nd = c->L.numDry;
+    std::vector<SplitterState> sp(nd);
+    for(auto &s : sp) { s.coeff = SplitterCoeff(xover_norm); s.lpZ1 = s.lpZ2 = s.apZ1 = 0.0f; }
+    HIP_TRY(c->dSplit.upload(sp.data(), nd));
+    HIP_TRY(c->dHfScale.upload(hfscales, nd));
+    HIP_TRY(c->dCoeffs.upload(chan_coeffs, size_t{nd} * kHrirLen * 2));
+    c->dIrSize = irsize;
+    c->directSet = true;
+    return OALGPU_OK;
+}
+
+int oalgpu_buffer_register(oalgpu_context *c, const void *data, int fmt_type, uint32_t frame_step,
+    uint32_t sample_len, uint32_t loop_start, uint32_t loop_end)
+{
+    static const size_t bytesPer[7] = {1, 2, 4, 4, 8, 1, 1};
+    if(!c || !data || fmt_type < 0 || fmt_type > OALGPU_FMT_ALAW || frame_step == 0 || sample_len == 0
+        || loop_end > sample_len || loop_start >= (loop_end ? loop_end : 1u))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_register: bad arguments");
+    if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    const size_t nbytes = size_t{sample_len} * frame_step * bytesPer[fmt_type];
+    void *dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, nbytes + 16));
+    const hipError_t e = hipMemcpy(dev, data, nbytes, hipMemcpyHostToDevice);
+    if(e != hipSuccess) { (void)hipFree(dev); return Fail(OALGPU_ERR_HIP, hipGetErrorString(e)); }
+    const uint32_t h = c->numBuffers++;
+    c->bufferData[h] = dev;
+    BufferItem item{dev, fmt_type, frame_step, sample_len, loop_start, loop_end, 0};
+    HIP_TRY(hipMemcpy(c->buffers.p + h, &item, sizeof(item), hipMemcpyHostToDevice));
+    return int(h);
+}
+
+int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc *d)
+{
+    if(!c || !d || voice >= c->L.numVoices || d->buffer < 0 || uint32_t(d->buffer) >= c->numBuffers
+        || d->position_frac >= kFracOne)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: bad arguments");
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    c->initPending.push_back(VoiceInitRecord{voice, d->buffer, d->looping ? 1 : 0, d->position, d->position_frac});
+    return OALGPU_OK;
+}
+
+int oalgpu_voice_set_params(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params, size_t count)
+{
+    if(!c || !voices || !params) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(count == 0) return OALGPU_OK;
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    const TableBlob &blob = Blob();
+    c->paramHost.resize(count);
+    for(size_t i = 0; i < count; ++i)
+    {
+        const oalgpu_voice_params &p = params[i];
+        if(voices[i] >= c->L.numVoices || p.resampler < 0 || p.resampler > OALGPU_RESAMPLER_BSINC48)
+            return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_params: bad voice index or resampler");
+        ParamRecord &r = c->paramHost[i];
+        std::memset(&r, 0, sizeof(r));
+        r.voice = voices[i];
+        r.step = p.step;
+        oalgpu_interp_state st;
+        PrepareResampler(p.resampler, p.step ? p.step : 1u, &st);
+        r.rsKind = st.kind; r.rsM = st.m; r.rsL = st.l; r.rsSf = st.sf;
+        r.rsFilterOffset = blob.filterBase(st);
+        r.flags = p.direct_filter.active ? kFlagDirectFilter : 0u;
+        DesignBiquadFromSlope(OALGPU_BIQUAD_HIGHSHELF, p.direct_filter.hf_norm, p.direct_filter.gain_hf, 1.0f, r.dirLp);
+        DesignBiquadFromSlope(OALGPU_BIQUAD_LOWSHELF, p.direct_filter.lf_norm, p.direct_filter.gain_lf, 1.0f, r.dirHp);
+        for(uint32_t s = 0; s < OALGPU_MAX_SENDS; ++s)
+        {
+            r.sendSlot[s] = -1;
+            if(s >= c->L.numSends) continue;
+            if(p.send_slot[s] >= int32_t(c->L.numSlots)) return Fail(OALGPU_ERR_INVALID, "send slot out of range");
+            r.sendSlot[s] = p.send_slot[s] < 0 ? -1 : p.send_slot[s];
+            if(p.send_filter[s].active) r.flags |= 1u << (kFlagSendFilterShift + s);
+            DesignBiquadFromSlope(OALGPU_BIQUAD_HIGHSHELF, p.send_filter[s].hf_norm, p.send_filter[s].gain_hf, 1.0f, r.sendLp[s]);
+            DesignBiquadFromSlope(OALGPU_BIQUAD_LOWSHELF, p.send_filter[s].lf_norm, p.send_filter[s].gain_lf, 1.0f, r.sendHp[s]);
+            std::memcpy(r.sendGains[s], p.send_gains[s], sizeof(r.sendGains[s]));
+        }
+        r.hrtfDir[0] = p.hrtf_ev; r.hrtfDir[1] = p.hrtf_az; r.hrtfDir[2] = p.hrtf_dist; r.hrtfDir[3] = p.hrtf_spread;
+        r.hrtfGain = p.hrtf_gain;
+        std::memcpy(r.dryGains, p.dry_gains, sizeof(r.dryGains));
+    }
+    if(c->paramDev.n < count) HIP_TRY(c->paramDev.alloc(count));
+    HIP_TRY(hipMemcpyAsync(c->paramDev.p, c->paramHost.data(), count * sizeof(ParamRecord), hipMemcpyHostToDevice, c->stream));
+    LaunchApplyParams(c->stream, c->L, c->hrtfDev, c->paramDev.p, uint32_t(count));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));   // paramHost is reused by the next call
+    return OALGPU_OK;
+}
+
+int oalgpu_voice_set_state(oalgpu_context *c, uint32_t voice, int play_state)
+{
+    if(!c || voice >= c->L.numVoices || play_state < OALGPU_VOICE_STOPPED || play_state > OALGPU_VOICE_PENDING)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_state: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    const int32_t st = play_state;
+    HIP_TRY(hipMemcpyAsync(&c->ctl.p[voice].playState, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OALGPU_OK;
+}
+
+int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
+{
+    if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
+    HIP_TRY(LaunchVoiceMix(c->stream, c->exact, c->L, samples_to_do, c->carryAccum));
+    if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
+    LaunchBusReduce(c->stream, c->L, samples_to_do);
+    HIP_TRY(hipGetLastError());
+    if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
+    return OALGPU_OK;
+}
+
+int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
+{
+    if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
+    if(!c->L.hrtf) return OALGPU_OK;
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    const DeviceLayout &L = c->L;
+    if(L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
+    float *left = L.bus + size_t{L.numDry} * kLine;
+    float *right = left + kLine;
+    LaunchMixDirectHrtf(c->stream, c->exact, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
+        c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
+    HIP_TRY(hipGetLastError());
+    if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
+    return OALGPU_OK;
+}
+
+int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_process)
+{
+    if(int rc = oalgpu_mix_voices(c, samples_to_do)) return rc;
+    if(post_process) return oalgpu_post_process(c, samples_to_do);
+    return OALGPU_OK;
+}
+
+int oalgpu_sync(oalgpu_context *c)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OALGPU_OK;
+}
+
+int oalgpu_read_dry(oalgpu_context *c, float *out)
+{
+    if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = oalgpu_sync(c)) return rc;
+    HIP_TRY(hipMemcpy(out, c->L.bus, BusWetOffset(c->L) * sizeof(float), hipMemcpyDeviceToHost));
+    return OALGPU_OK;
+}
+
+int oalgpu_read_wet(oalgpu_context *c, uint32_t slot, float *out)
+{
+    if(!c || !out || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "bad slot");
+    if(int rc = oalgpu_sync(c)) return rc;
+    const size_t n = size_t{c->L.wetChannels} * kLine;
+    HIP_TRY(hipMemcpy(out, c->L.bus + BusWetOffset(c->L) + slot * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    return OALGPU_OK;
+}
+
+int oalgpu_read_hrtf_accum(oalgpu_context *c, float *out)
+{
+    if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = oalgpu_sync(c)) return rc;
+    HIP_TRY(hipMemcpy(out, c->L.bus + BusAccumOffset(c->L), size_t{kLine + kHrirLen} * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    return OALGPU_OK;
+}
+
+int oalgpu_bus_device_ptr(oalgpu_context *c, void **ptr, size_t *nfloats, void **hip_stream)
+{
+    if(!c || !ptr || !nfloats) return Fail(OALGPU_ERR_INVALID, "null argument");
+    *ptr = c->L.bus;
+    *nfloats = BusFloats(c->L);
+    if(hip_stream) *hip_stream = c->stream;
+    return OALGPU_OK;
+}
+
+int oalgpu_voice_readback(oalgpu_context *c, uint32_t v, oalgpu_voice_state *out)
+{
+    if(!c || !out || v >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_readback: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    const DeviceLayout &L = c->L;
+    std::memset(out, 0, sizeof(*out));
+    VoiceCtl ctl;
+    HIP_TRY(hipMemcpy(&ctl, L.ctl + v, sizeof(ctl), hipMemcpyDeviceToHost));
+    out->play_state = ctl.playState; out->position = ctl.position; out->position_frac = ctl.positionFrac;
+    out->has_buffer = ctl.curBuffer >= 0; out->fading = (ctl.flags & kFlagFading) != 0;
+    out->hrtf_old_gain = ctl.hrtfOldGain;
+    out->hrtf_old_delay[0] = ctl.hrtfOldDelay[0]; out->hrtf_old_delay[1] = ctl.hrtfOldDelay[1];
+    HIP_TRY(hipMemcpy(out->prev_samples, L.prev + size_t{v} * kMaxPad, sizeof(out->prev_samples), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->hrtf_history, L.hist + size_t{v} * kHist, sizeof(out->hrtf_history), hipMemcpyDeviceToHost));
+    if(!L.hrtf)
+        HIP_TRY(hipMemcpy(out->dry_current, L.gainCur + size_t{v} * L.numDry, L.numDry * sizeof(float), hipMemcpyDeviceToHost));
+    BiquadSlot slots[2 * OALGPU_MAX_SENDS];
+    HIP_TRY(hipMemcpy(slots, L.dfilt + size_t{v} * 2, 2 * sizeof(BiquadSlot), hipMemcpyDeviceToHost));
+    std::memcpy(&out->direct_lp, &slots[0].f, sizeof(oalgpu_biquad));
+    std::memcpy(&out->direct_hp, &slots[1].f, sizeof(oalgpu_biquad));
+    for(uint32_t s = 0; s < OALGPU_MAX_SENDS; ++s) { oalgpu_biquad_reset(&out->send_lp[s]); oalgpu_biquad_reset(&out->send_hp[s]); }
+    if(L.numSends)
+    {
+        HIP_TRY(hipMemcpy(slots, L.sfilt + size_t{v} * L.numSends * 2, L.numSends * 2 * sizeof(BiquadSlot), hipMemcpyDeviceToHost));
+        std::vector<float> cur(size_t{L.numSends} * L.wetChannels);
+        HIP_TRY(hipMemcpy(cur.data(), L.sendCur + size_t{v} * L.numSends * L.wetChannels, cur.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for(uint32_t s = 0; s < L.numSends; ++s)
+        {
+            std::memcpy(&out->send_lp[s], &slots[s * 2].f, sizeof(oalgpu_biquad));
+            std::memcpy(&out->send_hp[s], &slots[s * 2 + 1].f, sizeof(oalgpu_biquad));
+            std::memcpy(out->send_current[s], cur.data() + size_t{s} * L.wetChannels, L.wetChannels * sizeof(float));
+        }
+    }
+    return OALGPU_OK;
+}
+
+int oalgpu_set_timing(oalgpu_context *c, int enable)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    c->timing = enable != 0;
+    c->timed = false;
+    return OALGPU_OK;
+}
+
+int oalgpu_last_update_ms(oalgpu_context *c, float *total_ms, float *voice_kernel_ms)
+{
+    if(!c || !c->timed) return Fail(OALGPU_ERR_INVALID, "no timed update (call oalgpu_set_timing first)");
+    if(int rc = oalgpu_sync(c)) return rc;
+    if(total_ms) HIP_TRY(hipEventElapsedTime(total_ms, c->evStart, c->evEnd));
+    if(voice_kernel_ms) HIP_TRY(hipEventElapsedTime(voice_kernel_ms, c->evStart, c->evVoice));
+    return OALGPU_OK;
+}
+
+/* Multi-GPU: whether this context's voice kernel continues the carried HRTF accumulator tail
+ * (exactly one rank must, the one that runs the post-process on the reduced buses). */
+int oalgpu_set_carry_accum(oalgpu_context *c, int enable)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    c->carryAccum = enable != 0;
+    return OALGPU_OK;
+}
+
+} // extern "C"

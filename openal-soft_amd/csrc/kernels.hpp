@@ -1,0 +1,135 @@
+// Host-visible declarations of the kernel launchers and the device-side data layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dev_hrtf.hpp"
+#include "dev_mix.hpp"
+#include "dev_resample.hpp"
+
+namespace oalgpu {
+
+// ---------------------------------------------------------------------------------------------
+// HBM layout of the batched path.  Everything Voice::mix reads or mutates lives in
+// structure-of-arrays form indexed by voice, so a workgroup streaming voice v touches a few
+// contiguous segments:
+//   ctl[v]        VoiceCtl (128 B): integer state + resampler state + flags (core/voice.h:176-270)
+//   prev[v][48]   mPrevSamples[0]
+//   dfilt[v][2]   DirectParams::{LowPass,HighPass}
+//   hrtfOld/Tgt   [v][irStride][2]  HrtfFilter::Coeffs of Hrtf.Old / Hrtf.Target
+//   hist[v][64]   DirectParams::Hrtf.History
+//   gainCur/Tgt   [v][numDry]       DirectParams::Gains
+//   sfilt[v][sends][2], sendCur/Tgt [v][sends][wet]   SendParams
+// ---------------------------------------------------------------------------------------------
+enum VoiceFlagBits : uint32_t {
+    kFlagFading = 1u << 0,          // VoiceFlag::IsFading
+    kFlagHasHrtf = 1u << 1,         // VoiceFlag::HasHrtf
+    kFlagDirectFilter = 1u << 2,    // mDirect.FilterActive
+    kFlagSendFilterShift = 8        // bits 8..13: mSend[i].FilterActive
+};
+
+struct alignas(16) VoiceCtl {
+    int32_t playState;
+    int32_t position;               // mPosition
+    uint32_t positionFrac;          // mPositionFrac
+    int32_t curBuffer;              // mCurrentBuffer (-1 = null)
+    int32_t loopBuffer;             // mLoopBuffer (-1 = null)
+    uint32_t step;                  // mStep
+    int32_t rsKind;                 // which Resample_* (oalgpu_interp_state.kind)
+    uint32_t rsM, rsL;
+    float rsSf;
+    uint32_t rsFilterOffset;        // float offset of the filter inside the table blob
+    uint32_t flags;
+    int32_t sendSlot[6];
+    uint32_t hrtfOldDelay[2];
+    float hrtfOldGain;
+    uint32_t hrtfTgtDelay[2];
+    float hrtfTgtGain;
+    uint32_t pad[8];
+};
+static_assert(sizeof(VoiceCtl) == 128, "VoiceCtl is one 128-byte line");
+
+struct alignas(16) BufferItem {     // VoiceBufferItem, core/voice.h:84-98
+    const void *data;
+    int32_t fmt;
+    uint32_t frameStep, sampleLen, loopStart, loopEnd;
+    uint32_t pad;
+};
+
+// a BiquadState padded to 64 bytes so each filter is one aligned segment
+struct alignas(16) BiquadSlot { BiquadState f; uint32_t pad[3]; };
+static_assert(sizeof(BiquadSlot) == 64, "BiquadSlot");
+
+struct DeviceLayout {
+    // configuration
+    uint32_t numVoices, numDry, numReal, numSends, numSlots, wetChannels;
+    uint32_t hrtf, irSize, irStride;       // irStride: taps stored per voice filter (irSize rounded up to 8)
+    uint32_t voicesPerGroup, numGroups;
+    uint32_t mixLines;                      // lines accumulated by the voice kernel
+    // tables + buffers
+    const float *tables;                    // [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
+    const BufferItem *buffers;
+    // voice state
+    VoiceCtl *ctl;
+    float *prev;
+    BiquadSlot *dfilt;
+    float *hrtfOld, *hrtfTgt, *hist;
+    float *gainCur, *gainTgt;
+    BiquadSlot *sfilt;
+    float *sendCur, *sendTgt;
+    // partial buses written by the voice kernel: [group][mixLines][1024], [group][1152][2]
+    float *partLines, *partHrtf;
+    // final bus block: [(numDry+numReal) x 1024 | numSlots*wetChannels x 1024 | 1152 x 2]
+    float *bus;
+};
+
+__host__ __device__ inline size_t BusWetOffset(const DeviceLayout &L) { return size_t{L.numDry + L.numReal} * kLine; }
+__host__ __device__ inline size_t BusAccumOffset(const DeviceLayout &L)
+{ return BusWetOffset(L) + size_t{L.numSlots} * L.wetChannels * kLine; }
+__host__ __device__ inline size_t BusFloats(const DeviceLayout &L)
+{ return BusAccumOffset(L) + size_t{kLine + kHrirLen} * 2; }
+
+// Parameter block applied on the GPU by ApplyParamsKernel (one per changed voice).
+struct ParamRecord {
+    uint32_t voice;
+    uint32_t step;
+    int32_t rsKind;
+    uint32_t rsM, rsL;
+    float rsSf;
+    uint32_t rsFilterOffset;
+    uint32_t flags;                 // kFlagDirectFilter | send filter bits
+    int32_t sendSlot[6];
+    float dirLp[5], dirHp[5];       // designed biquad coefficients (host libm)
+    float sendLp[6][5], sendHp[6][5];
+    float hrtfDir[4];               // elevation, azimuth, distance, spread
+    float hrtfGain;
+    float dryGains[32];
+    float sendGains[6][25];
+};
+
+struct VoiceInitRecord { uint32_t voice; int32_t buffer, looping, position; uint32_t positionFrac; };
+
+// ---- launchers (percall_kernels.hip) ----
+void LaunchResample(hipStream_t s, bool exact, const ResampleSpec &spec, const float *src, uint32_t frac,
+    uint32_t increment, float *dst, uint32_t n);
+void LaunchMix(hipStream_t s, const float *in, uint32_t n, float *out, uint32_t nlines, float *cur,
+    const float *tgt, uint32_t counter, uint32_t outpos);
+void LaunchMixHrtf(hipStream_t s, bool exact, const float *in, float *accum, uint32_t irsize, const float *coeffs,
+    uint32_t dL, uint32_t dR, float gain, float step, const float *oldcoeffs, uint32_t odL, uint32_t odR,
+    float oldgain, int blend, uint32_t n);
+void LaunchMixDirectHrtf(hipStream_t s, bool exact, float *left, float *right, const float *in, uint32_t nch,
+    float *accum, SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize,
+    uint32_t n, float *temp);
+void LaunchBiquadDual(hipStream_t s, BiquadState *f0, BiquadState *f1, const float *src, float *dst, uint32_t n);
+void LaunchGetCoeffs(hipStream_t s, const HrtfStoreDev &st, const float *dirs, uint32_t count, float *coeffs,
+    uint32_t *delays);
+
+// ---- launchers (voice_kernel.hip) ----
+void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);
+void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev &st, const ParamRecord *recs,
+    uint32_t count);
+// returns hipSuccess or the launch error
+hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum);
+void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo);
+
+} // namespace oalgpu

@@ -1,0 +1,803 @@
+// The batched voice path: "for every Playing|Stopping voice: voice->mix(...)" for one update
+// (ProcessContexts voice loop, alc/alu.cpp:2201-2206 -> Voice::mix, core/voice.cpp:988-1233),
+// as three launches:
+//
+//   ApplyParamsKernel  parameter side: scatter the CalcVoiceParams results into the voice
+//                      arrays, HrtfStore::getCoeffs HRIR blend (core/hrtf.cpp:192-260) and the
+//                      BiquadInterpFilter::setParams state machine (biquad.cpp:131-149).
+//   VoiceMixKernel     one 256-thread workgroup per group of voices.  Per voice: coalesced
+//                      source-window load with format decode into LDS (LoadResampledSamples,
+//                      voice.cpp:642-824), resample (4 outputs per thread), serial dual-biquad
+//                      IIRs on spare lanes (DoFilters, voice.cpp:255-267), then either the
+//                      register-tiled dual-ear FIR (DoHrtfMix, voice.cpp:827-902) or the
+//                      gain-ramped bus mix (MixSamples).  Bus contributions stay in registers
+//                      across the group's voices and leave as ONE partial per group.
+//   BusReduceKernel    sums the per-group partials in group order into the bus block.
+//
+// Deterministic by construction: fixed voice->group mapping, fixed summation order, no atomics.
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace oalgpu {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kInLen = kHist + kLine;          // [History | samples], DoHrtfMix HrtfSamples
+constexpr int kXPad = 128;                     // zero padding either side of the x' arrays
+constexpr int kXLen = kXPad + kLine + kXPad;
+constexpr int kXOldLen = kXPad + 256;         // old-filter fade: <= 64 inputs, frames < 256
+
+// ---- SampleInfo<T>::to_float, core/fmt_traits.h:91-139 (+ the mu-law/A-law tables :12-80 in
+// closed form) ----
+__device__ __forceinline__ float DecodeMulaw(uint32_t u)
+{
+    u = ~u & 0xffu;
+    const int exponent = (u >> 4) & 7, mantissa = u & 15;
+    const int seg = ((33 << exponent) - 33) << 2;             // 0,132,396,924,...
+    const int mag = seg + (mantissa << (exponent + 3));
+    return float((u & 0x80u) ? -mag : mag) * (1.0f / 32768.0f);
+}
+__device__ __forceinline__ float DecodeAlaw(uint32_t a)
+{
+    a = (a ^ 0x55u) & 0xffu;
+    const int exponent = (a >> 4) & 7, mantissa = a & 15;
+    const int mag = (exponent == 0) ? ((mantissa << 4) + 8) : (((mantissa << 4) + 0x108) << (exponent - 1));
+    return float((a & 0x80u) ? mag : -mag) * (1.0f / 32768.0f);
+}
+
+template<int FMT>
+__device__ __forceinline__ float LoadSample(const void *data, size_t idx)
+{
+    if constexpr(FMT == OALGPU_FMT_UBYTE) return (float(static_cast<const uint8_t*>(data)[idx]) - 128.0f) * (1.0f / 128.0f);
+    else if constexpr(FMT == OALGPU_FMT_SHORT) return float(static_cast<const int16_t*>(data)[idx]) * (1.0f / 32768.0f);
+    else if constexpr(FMT == OALGPU_FMT_INT) return float(static_cast<const int32_t*>(data)[idx]) * (1.0f / 2147483648.0f);
+    else if constexpr(FMT == OALGPU_FMT_FLOAT) return static_cast<const float*>(data)[idx];
+    else if constexpr(FMT == OALGPU_FMT_DOUBLE) return float(static_cast<const double*>(data)[idx]);
+    else if constexpr(FMT == OALGPU_FMT_MULAW) return DecodeMulaw(static_cast<const uint8_t*>(data)[idx]);
+    else return DecodeAlaw(static_cast<const uint8_t*>(data)[idx]);
+}
+
+// LoadBufferStatic, core/voice.cpp:500-544: element k of the `count` source samples starting
+// at buffer position dataPos (loop wrap by modulo; past-the-end holds the last sample).
+template<int FMT>
+__device__ __forceinline__ void FillFromStatic(float *dst, uint32_t count, const BufferItem &b, bool looping,
+    uint32_t dataPos)
+{
+    const uint32_t fs = b.frameStep;
+    if(!looping)
+    {
+        const bool any = b.sampleLen > dataPos;
+        const uint32_t avail = any ? b.sampleLen - dataPos : 0u;
+        const float last = any ? LoadSample<FMT>(b.data, size_t{b.sampleLen - 1u} * fs) : 0.0f;
+        for(uint32_t k = threadIdx.x; k < count; k += kThreads)
+            dst[k] = (k < avail) ? LoadSample<FMT>(b.data, size_t{dataPos + k} * fs) : last;
+    }
+    else
+    {
+        const uint32_t ls = b.loopStart, le = b.loopEnd, size = le - ls;
+        const uint32_t intPos = (dataPos < le) ? dataPos : ((dataPos - ls) % size) + ls;
+        const uint32_t first = le - intPos;
+        for(uint32_t k = threadIdx.x; k < count; k += kThreads)
+        {
+            const uint32_t idx = (k < first) ? intPos + k : ls + ((k - first) % size);
+            dst[k] = LoadSample<FMT>(b.data, size_t{idx} * fs);
+        }
+    }
+}
+
+__device__ __forceinline__ void FillFromBuffer(float *dst, uint32_t count, const BufferItem &b, bool looping,
+    uint32_t dataPos)
+{
+    switch(b.fmt)
+    {
+    case OALGPU_FMT_UBYTE: FillFromStatic<OALGPU_FMT_UBYTE>(dst, count, b, looping, dataPos); break;
+    case OALGPU_FMT_SHORT: FillFromStatic<OALGPU_FMT_SHORT>(dst, count, b, looping, dataPos); break;
+    case OALGPU_FMT_INT: FillFromStatic<OALGPU_FMT_INT>(dst, count, b, looping, dataPos); break;
+    case OALGPU_FMT_FLOAT: FillFromStatic<OALGPU_FMT_FLOAT>(dst, count, b, looping, dataPos); break;
+    case OALGPU_FMT_DOUBLE: FillFromStatic<OALGPU_FMT_DOUBLE>(dst, count, b, looping, dataPos); break;
+    case OALGPU_FMT_MULAW: FillFromStatic<OALGPU_FMT_MULAW>(dst, count, b, looping, dataPos); break;
+    default: FillFromStatic<OALGPU_FMT_ALAW>(dst, count, b, looping, dataPos); break;
+    }
+}
+
+// CalculateBufferSize, core/voice.cpp:600-640 (integer, bit-exact).
+__device__ __forceinline__ void CalcBufferSize(uint32_t fracPos, uint32_t increment, uint32_t dstRemaining,
+    uint32_t &dst, uint32_t &src)
+{
+    constexpr uint32_t srcMax = kResampleDataSize - kMaxEdge;
+    const uint32_t ext = increment <= kFracOne ? 1u : 0u;
+    const uint64_t srcSize = ((uint64_t{dstRemaining - ext} * increment + fracPos) >> kFracBits) + ext + kMaxEdge;
+    if(srcSize <= srcMax) { dst = dstRemaining; src = uint32_t(srcSize); return; }
+    const uint64_t dstSize = ((uint64_t{srcMax - kMaxEdge} << kFracBits) - fracPos) / increment;
+    if(dstSize < dstRemaining) { dst = uint32_t(dstSize) & ~3u; src = srcMax; return; }
+    dst = dstRemaining; src = srcMax;
+}
+
+__device__ __forceinline__ int32_t AddSat(int32_t a, int32_t b)
+{
+    const int64_t r = int64_t{a} + b;
+    return r > 2147483647ll ? 2147483647 : (r < -2147483648ll ? int32_t(-2147483647 - 1) : int32_t(r));
+}
+
+struct alignas(16) SharedMem {
+    float rdata[kResampleDataSize + 8];        // DeviceBase::mResampleData
+    float in[kInLen];                          // [hrtf history | resampled samples]
+    float filt[kWaves][kInLen];                // filter outputs, one per concurrently running IIR
+    float xl[kXLen], xr[kXLen];                // x'_ear[i] = In[64-delay+i]*g(i), zero padded
+    float xol[kXOldLen], xor_[kXOldLen];       // old-filter fade-out inputs
+    float stage[(kLine + kHrirLen) * 2];       // end-of-kernel accumulator exchange
+    float gCur[7][32], gTgt[7][32];            // Gains.Current/Target snapshot: [direct | send i][line]
+    int32_t sendSlot[8];
+    int32_t best;
+};
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Parameter side
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfStoreDev st, const ParamRecord *__restrict__ recs)
+{
+    const ParamRecord &r = recs[blockIdx.x];
+    const uint32_t v = r.voice;
+    const uint32_t t = threadIdx.x;
+    VoiceCtl &ctl = L.ctl[v];
+    if(t == 0)
+    {
+        ctl.step = r.step;
+        ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
+        ctl.rsFilterOffset = r.rsFilterOffset;
+        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf);
+        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf)) | (L.hrtf ? kFlagHasHrtf : 0u);
+        for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
+        BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
+        BiquadSetTarget(L.dfilt[size_t{v} * 2 + 1].f, r.dirHp);
+    }
+    if(t >= 64 && t < 64 + L.numSends)
+    {
+        const uint32_t i = t - 64;
+        BiquadSetTarget(L.sfilt[(size_t{v} * L.numSends + i) * 2 + 0].f, r.sendLp[i]);
+        BiquadSetTarget(L.sfilt[(size_t{v} * L.numSends + i) * 2 + 1].f, r.sendHp[i]);
+    }
+    if(L.hrtf)
+    {
+        const HrirBlend b = HrtfBlendFor(st, r.hrtfDir[0], r.hrtfDir[1], r.hrtfDir[2], r.hrtfDir[3]);
+        if(t < L.irStride * 2)
+            L.hrtfTgt[size_t{v} * L.irStride * 2 + t] = HrtfBlendElement(st, b, t);
+        if(t == 0)
+        {
+            ctl.hrtfTgtDelay[0] = b.delay[0]; ctl.hrtfTgtDelay[1] = b.delay[1];
+            ctl.hrtfTgtGain = r.hrtfGain;
+        }
+    }
+    else if(t < L.numDry)
+        L.gainTgt[size_t{v} * L.numDry + t] = r.dryGains[t];
+    for(uint32_t k = t; k < L.numSends * L.wetChannels; k += blockDim.x)
+        L.sendTgt[size_t{v} * L.numSends * L.wetChannels + k] = r.sendGains[k / L.wetChannels][k % L.wetChannels];
+}
+
+// Voice::prepare (core/voice.cpp:1235-1397) + InitVoice's source attach (al/source.cpp:639-670)
+// for `count` static mono voices: mixing state cleared, filters default-constructed
+// (BiquadInterpFilter{}: identity coefficients, mCounter = -1), mStep = 0, Playing, not fading.
+__global__ void __launch_bounds__(64) InitVoicesKernel(DeviceLayout L, const VoiceInitRecord *__restrict__ recs)
+{
+    const VoiceInitRecord r = recs[blockIdx.x];
+    const uint32_t v = r.voice, t = threadIdx.x;
+    BiquadState def{};
+    def.b0 = 1.0f; def.tb0 = 1.0f; def.counter = -1;
+    if(t == 0)
+    {
+        VoiceCtl c{};
+        c.playState = OALGPU_VOICE_PLAYING;
+        c.position = r.position;
+        c.positionFrac = r.positionFrac;
+        c.curBuffer = r.buffer;
+        c.loopBuffer = r.looping ? r.buffer : -1;
+        c.flags = L.hrtf ? kFlagHasHrtf : 0u;
+        for(int i = 0; i < 6; ++i) c.sendSlot[i] = -1;
+        L.ctl[v] = c;
+        L.dfilt[size_t{v} * 2 + 0].f = def;
+        L.dfilt[size_t{v} * 2 + 1].f = def;
+    }
+    if(t < kMaxPad) L.prev[size_t{v} * kMaxPad + t] = 0.0f;
+    if(L.hrtf)
+    {
+        L.hist[size_t{v} * kHist + t] = 0.0f;
+        for(uint32_t k = t; k < L.irStride * 2; k += 64)
+        {
+            L.hrtfOld[size_t{v} * L.irStride * 2 + k] = 0.0f;
+            L.hrtfTgt[size_t{v} * L.irStride * 2 + k] = 0.0f;
+        }
+    }
+    else if(t < L.numDry)
+    {
+        L.gainCur[size_t{v} * L.numDry + t] = 0.0f;
+        L.gainTgt[size_t{v} * L.numDry + t] = 0.0f;
+    }
+    if(t < L.numSends * 2) L.sfilt[size_t{v} * L.numSends * 2 + t].f = def;
+    for(uint32_t k = t; k < L.numSends * L.wetChannels; k += 64)
+    {
+        L.sendCur[size_t{v} * L.numSends * L.wetChannels + k] = 0.0f;
+        L.sendTgt[size_t{v} * L.numSends * L.wetChannels + k] = 0.0f;
+    }
+}
+
+void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count)
+{
+    if(count) hipLaunchKernelGGL(InitVoicesKernel, dim3(count), dim3(64), 0, s, L, recs);
+}
+
+void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev &st, const ParamRecord *recs, uint32_t count)
+{
+    if(count) hipLaunchKernelGGL(ApplyParamsKernel, dim3(count), dim3(256), 0, s, L, st, recs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Voice kernel
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// LoadResampledSamples, core/voice.cpp:642-824, for one real channel of a static voice.
+// Produces samplesToLoad resampled samples at sm.in[kHist..]; updates prev[v] when Playing.
+template<bool EXACT>
+__device__ __forceinline__ void LoadResampled(SharedMem &sm, const DeviceLayout &L, uint32_t v, const VoiceCtl &ctl,
+    bool playing, int32_t intPos, uint32_t fracPos, uint32_t increment, uint32_t samplesToLoad,
+    uint32_t samplesToMix, int32_t bufferItem, bool looping)
+{
+    const uint32_t t = threadIdx.x;
+    float *rdata = sm.rdata;
+    float *srcBuffer = rdata + kMaxEdge;
+    float *mixing = sm.in + kHist;
+    if(t < kMaxPad) rdata[t] = L.prev[size_t{v} * kMaxPad + t];
+    __syncthreads();
+    const float *filter = L.tables + ctl.rsFilterOffset;
+    const int kind = ctl.rsKind;
+    const uint32_t rsM = ctl.rsM, rsL = ctl.rsL;
+    const float rsSf = ctl.rsSf;
+
+    for(uint32_t loaded = 0; loaded < samplesToLoad;)
+    {
+        uint32_t bdst, bsrc;
+        CalcBufferSize(fracPos, increment, samplesToLoad - loaded, bdst, bsrc);
+        uint32_t srcDelay = 0;
+        bool silent = false;
+        if(intPos < 0)
+        {
+            srcDelay = uint32_t(-intPos);
+            if(srcDelay >= bsrc)
+            {   // voice.cpp:679-697: everything needed is before the buffer start
+                for(uint32_t k = t; k < bdst; k += kThreads) mixing[loaded + k] = 0.0f;
+                for(uint32_t k = t; k < bsrc; k += kThreads) srcBuffer[k] = 0.0f;
+                silent = true;
+            }
+            else
+                for(uint32_t k = t; k < srcDelay; k += kThreads) srcBuffer[k] = 0.0f;
+        }
+        if(silent)
+        {
+            __syncthreads();
+            loaded += bdst;
+            if(loaded < samplesToLoad)
+            {
+                fracPos += bdst * increment;
+                const uint32_t srcOffset = fracPos >> kFracBits;
+                fracPos &= kFracMask;
+                intPos = AddSat(intPos, int32_t(srcOffset));
+            }
+            continue;
+        }
+
+        if(bufferItem < 0)
+        {   // voice.cpp:704-719: hold the available sample nearest zero
+            const uint32_t avail = bsrc < uint32_t(kMaxEdge) ? bsrc : uint32_t(kMaxEdge);
+            const uint32_t tofill = bsrc > uint32_t(kMaxEdge) ? bsrc : uint32_t(kMaxEdge);
+            if(t == 0)
+            {
+                uint32_t best = 0;
+                for(uint32_t i = 1; i < avail; ++i)
+                    if(fabsf(srcBuffer[i]) < fabsf(srcBuffer[best])) best = i;
+                sm.best = int32_t(best);
+            }
+            __syncthreads();
+            const uint32_t best = uint32_t(sm.best);
+            const float hold = srcBuffer[best];
+            __syncthreads();
+            for(uint32_t k = best + 1 + t; k < tofill; k += kThreads) srcBuffer[k] = hold;
+        }
+        else
+        {
+            const uint32_t upos = intPos < 0 ? 0u : uint32_t(intPos);
+            FillFromBuffer(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos);
+        }
+        __syncthreads();
+
+        // voice.cpp:764-769
+        if(increment == kFracOne && fracPos == 0)
+        {
+            for(uint32_t k = t; k < bdst; k += kThreads) mixing[loaded + k] = srcBuffer[k];
+        }
+        else
+        {
+            for(uint32_t k = t; k < bdst; k += kThreads)
+                mixing[loaded + k] = ResampleAt<EXACT>(kind, rsM, rsL, rsSf, filter, rdata, fracPos, increment, k, bdst);
+        }
+
+        // voice.cpp:772-785: history for the next update, taken at the end-of-mix position
+        if(playing)
+        {
+            const uint32_t loadEnd = loaded + bdst;
+            if(samplesToMix > loaded && samplesToMix <= loadEnd)
+            {
+                const uint32_t dstOffset = samplesToMix - loaded;
+                const uint32_t srcOffset = uint32_t((uint64_t{dstOffset} * increment + fracPos) >> kFracBits);
+                if(t < kMaxPad) L.prev[size_t{v} * kMaxPad + t] = rdata[srcOffset + t];
+            }
+        }
+        loaded += bdst;
+        if(loaded < samplesToLoad)
+        {
+            fracPos += bdst * increment;
+            const uint32_t srcOffset = fracPos >> kFracBits;
+            fracPos &= kFracMask;
+            if(intPos < 0) intPos += int32_t(srcOffset);
+            else intPos = AddSat(intPos, int32_t(srcOffset));
+            // voice.cpp:807-810: slide the last 48 source samples to the front
+            __syncthreads();
+            float carry = 0.0f;
+            if(t < kMaxPad) carry = rdata[srcOffset + t];
+            __syncthreads();
+            if(t < kMaxPad) rdata[t] = carry;
+        }
+        __syncthreads();
+    }
+}
+
+// Register-tiled dual-ear FIR (FAST): thread t owns output frames 4t..4t+3.  Per 8 taps it
+// needs x'[n0-j0-8 .. n0-j0+3] per ear = three aligned ds_read_b128, against 64 FMAs.
+__device__ __forceinline__ void FirMain(float (&accL)[4], float (&accR)[4], const float *xl, const float *xr,
+    const float *__restrict__ coeffs, uint32_t irStride, uint32_t n0)
+{
+    for(uint32_t j0 = 0; j0 < irStride; j0 += 8)
+    {
+        const float4 *pl = reinterpret_cast<const float4*>(xl + kXPad + n0 - j0 - 8);
+        const float4 *pr = reinterpret_cast<const float4*>(xr + kXPad + n0 - j0 - 8);
+        const float4 l0 = pl[0], l1 = pl[1], l2 = pl[2];
+        const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2];
+        const float wl[12] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w};
+        const float wr[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+        for(int jj = 0; jj < 8; ++jj)
+        {
+            const float cl = coeffs[(j0 + jj) * 2 + 0];
+            const float cr = coeffs[(j0 + jj) * 2 + 1];
+#pragma unroll
+            for(int r = 0; r < 4; ++r)
+            {
+                accL[r] = __builtin_fmaf(cl, wl[8 + r - jj], accL[r]);
+                accR[r] = __builtin_fmaf(cr, wr[8 + r - jj], accR[r]);
+            }
+        }
+    }
+}
+
+// one output frame, one ear, all taps (used for the 128 tail frames and the old-filter fade)
+__device__ __forceinline__ float FirOne(float acc, const float *x /* x'[frame] */, const float *__restrict__ coeffs,
+    uint32_t irStride, uint32_t ear)
+{
+    for(uint32_t j = 0; j < irStride; ++j)
+        acc = __builtin_fmaf(coeffs[j * 2 + ear], x[-int32_t(j)], acc);
+    return acc;
+}
+
+template<bool EXACT, int LINES>
+__global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint32_t samplesToDo, uint32_t carryAccum)
+{
+    __shared__ SharedMem sm;
+    const uint32_t t = threadIdx.x;
+    const uint32_t wave = t >> 6, lane = t & 63;
+    const uint32_t group = blockIdx.x;
+    const uint32_t numSends = L.numSends, wetCh = L.wetChannels, numDry = L.numDry;
+    const uint32_t irStride = L.irStride;
+    const uint32_t irEff = EXACT ? ((L.irSize + 1u) & ~1u) : L.irSize;
+
+    // bus accumulators kept in registers across this group's voices
+    float lineAcc[LINES][4];
+#pragma unroll
+    for(int c = 0; c < LINES; ++c)
+#pragma unroll
+        for(int k = 0; k < 4; ++k) lineAcc[c][k] = 0.0f;
+    // FAST: frames 4t..4t+3 (main), 1024+(t&127) ear t>>7 (tail), (t&127)[+128] ear t>>7 (old fade)
+    float hL[4] = {0, 0, 0, 0}, hR[4] = {0, 0, 0, 0};
+    float hTail = 0.0f, hOld0 = 0.0f, hOld1 = 0.0f;
+    // EXACT: frames t + 256k, k < 5, both ears, one ordered chain per frame
+    float eL[5] = {0, 0, 0, 0, 0}, eR[5] = {0, 0, 0, 0, 0};
+
+    if(L.hrtf && carryAccum && group == 0)
+    {   // group 0 continues the running accumulator (HrtfAccumData tail carried by MixDirectHrtf)
+        const float *acc = L.bus + BusAccumOffset(L);
+        if constexpr(EXACT)
+        {
+#pragma unroll
+            for(int k = 0; k < 5; ++k)
+            {
+                const uint32_t o = t + 256u * k;
+                if(o < kLine + kHrirLen) { eL[k] = acc[o * 2]; eR[k] = acc[o * 2 + 1]; }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for(int r = 0; r < 4; ++r) { hL[r] = acc[(4 * t + r) * 2]; hR[r] = acc[(4 * t + r) * 2 + 1]; }
+            hTail = acc[(kLine + (t & 127)) * 2 + (t >> 7)];
+        }
+    }
+
+    // zero padding of the x' arrays (never written below)
+    for(uint32_t k = t; k < kXLen; k += kThreads) { sm.xl[k] = 0.0f; sm.xr[k] = 0.0f; }
+    for(uint32_t k = t; k < kXOldLen; k += kThreads) { sm.xol[k] = 0.0f; sm.xor_[k] = 0.0f; }
+    __syncthreads();
+
+    const uint32_t vBegin = group * L.voicesPerGroup;
+    const uint32_t vEnd = (vBegin + L.voicesPerGroup < L.numVoices) ? vBegin + L.voicesPerGroup : L.numVoices;
+    for(uint32_t v = vBegin; v < vEnd; ++v)
+    {
+        const VoiceCtl ctl = L.ctl[v];
+        const int vstate = ctl.playState;
+        if(vstate != OALGPU_VOICE_PLAYING && vstate != OALGPU_VOICE_STOPPING) continue;
+        const bool playing = vstate == OALGPU_VOICE_PLAYING;
+        const uint32_t increment = ctl.step;
+        if(increment < 1)
+        {   // voice.cpp:1002-1010
+            if(!playing && t == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
+            continue;
+        }
+        int32_t bufPosInt = ctl.position;
+        uint32_t bufPosFrac = ctl.positionFrac;
+        int32_t bufferItem = ctl.curBuffer;
+        int32_t loopItem = ctl.loopBuffer;
+        if(loopItem >= 0 && bufferItem >= 0)
+        {   // voice.cpp:1015-1019
+            if(bufPosInt >= 0 && uint32_t(bufPosInt) >= L.buffers[bufferItem].loopEnd) loopItem = -1;
+        }
+        const uint32_t samplesToMix = samplesToDo;          // no delayed start (outPos = 0)
+        const uint32_t N = samplesToMix;
+
+        // snapshot of this voice's gain pairs and send slots (read by every thread below while
+        // thread 0 writes the updated Gains.Current back to HBM)
+        if(t < 32)
+        {
+            if(!L.hrtf && t < numDry)
+            {
+                sm.gCur[0][t] = L.gainCur[size_t{v} * numDry + t];
+                sm.gTgt[0][t] = L.gainTgt[size_t{v} * numDry + t];
+            }
+            if(t < 6) sm.sendSlot[t] = ctl.sendSlot[t];
+        }
+        for(uint32_t k = t; k < numSends * wetCh; k += kThreads)
+        {
+            sm.gCur[1 + k / wetCh][k % wetCh] = L.sendCur[size_t{v} * numSends * wetCh + k];
+            sm.gTgt[1 + k / wetCh][k % wetCh] = L.sendTgt[size_t{v} * numSends * wetCh + k];
+        }
+
+        LoadResampled<EXACT>(sm, L, v, ctl, playing, bufPosInt, bufPosFrac, increment, N, N, bufferItem, loopItem >= 0);
+
+        const bool hasHrtf = (ctl.flags & kFlagHasHrtf) != 0;
+        const uint32_t counter = (ctl.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
+
+        // ---- DoFilters for the direct path and every send (voice.cpp:255-267,945-946,971-973):
+        // each active dual-biquad is a serial recurrence; run up to four at once on lane 0 of
+        // the four waves, each into its own LDS line.  Inactive filters are cleared.
+        // target index 0 = direct, 1+i = send i.
+        const uint32_t numTargets = 1 + numSends;
+        for(uint32_t base = 0; base < numTargets; base += kWaves)
+        {
+            const uint32_t tg = base + wave;
+            if(tg < numTargets && lane == 0)
+            {
+                const bool isDirect = tg == 0;
+                const uint32_t si = tg - 1;
+                const bool used = isDirect || sm.sendSlot[isDirect ? 0 : si] >= 0;
+                const bool active = isDirect ? (ctl.flags & kFlagDirectFilter) != 0
+                    : (ctl.flags >> (kFlagSendFilterShift + si)) & 1u;
+                BiquadSlot *slots = isDirect ? &L.dfilt[size_t{v} * 2] : &L.sfilt[(size_t{v} * numSends + si) * 2];
+                if(used)
+                {
+                    BiquadState f0 = slots[0].f, f1 = slots[1].f;
+                    if(active) BiquadDualInterp(f0, f1, sm.in + kHist, sm.filt[wave] + kHist, N);
+                    else { BiquadClear(f0); BiquadClear(f1); }
+                    slots[0].f = f0; slots[1].f = f1;
+                }
+            }
+            __syncthreads();
+
+            for(uint32_t w = 0; w < kWaves; ++w)
+            {
+                const uint32_t tg2 = base + w;
+                if(tg2 >= numTargets) break;
+                const bool isDirect = tg2 == 0;
+                const uint32_t si = tg2 - 1;
+                const bool active = isDirect ? (ctl.flags & kFlagDirectFilter) != 0
+                    : (ctl.flags >> (kFlagSendFilterShift + si)) & 1u;
+                float *inbuf = active ? sm.filt[w] : sm.in;         // [64 history slots | samples]
+                const float *samples = inbuf + kHist;
+
+                if(isDirect && hasHrtf)
+                {
+                    // ---------------- DoHrtfMix, voice.cpp:827-902 ----------------
+                    if(t < kHist) inbuf[t] = L.hist[size_t{v} * kHist + t];
+                    __syncthreads();
+                    if(playing && t < kHist) L.hist[size_t{v} * kHist + t] = inbuf[N + t];
+
+                    const float targetGain = ctl.hrtfTgtGain * (playing ? 1.0f : 0.0f);
+                    const float oldGain = counter ? ctl.hrtfOldGain : ctl.hrtfTgtGain;   // voice.cpp:1100
+                    uint32_t fademix = 0;
+                    float blendGain = targetGain;
+                    if(counter)
+                    {
+                        fademix = N < counter ? N : counter;
+                        if(counter > fademix)
+                            blendGain = lerpf(oldGain, targetGain, float(fademix) / float(counter));
+                    }
+                    const float newStep = fademix ? blendGain / float(fademix) : 0.0f;
+                    const float gainAfterBlend = fademix ? blendGain : oldGain;
+                    const uint32_t todo = N - fademix;
+                    float endGain = targetGain;
+                    if(todo && counter > N)
+                        endGain = lerpf(gainAfterBlend, targetGain, float(todo) / float(counter - fademix));
+                    const float mainStep = todo ? (endGain - gainAfterBlend) / float(todo) : 0.0f;
+                    const bool oldOn = fademix && oldGain > kGainSilence;
+                    const bool newOn = fademix && newStep * float(fademix) > kGainSilence;
+                    const uint32_t odL = ctl.hrtfOldDelay[0], odR = ctl.hrtfOldDelay[1];
+                    const uint32_t dL = ctl.hrtfTgtDelay[0], dR = ctl.hrtfTgtDelay[1];
+                    const float *oldCo = L.hrtfOld + size_t{v} * irStride * 2;
+                    const float *tgtCo = L.hrtfTgt + size_t{v} * irStride * 2;
+
+                    if constexpr(EXACT)
+                    {
+#pragma unroll
+                        for(int k = 0; k < 5; ++k)
+                        {
+                            const uint32_t o = t + 256u * k;
+                            if(o >= kLine + kHrirLen) continue;
+                            if(oldOn)
+                                HrtfGatherFrame<true, kGainOldFade>(eL[k], eR[k], inbuf, oldCo, irEff, odL, odR, 0.0f,
+                                    oldGain / float(fademix), fademix, o);
+                            if(newOn)
+                                HrtfGatherFrame<true, kGainNewFade>(eL[k], eR[k], inbuf, tgtCo, irEff, dL, dR, 0.0f, newStep,
+                                    fademix, o);
+                            if(todo && o >= fademix)
+                                HrtfGatherFrame<true, kGainRamp>(eL[k], eR[k], inbuf + fademix, tgtCo, irEff, dL, dR,
+                                    gainAfterBlend, mainStep, todo, o - fademix);
+                        }
+                    }
+                    else
+                    {
+                        // x'[i] for the target filter: fade-in ramp for i < fademix, then the gain ramp
+                        for(uint32_t i = t; i < N; i += kThreads)
+                        {
+                            float g;
+                            if(i < fademix) g = newOn ? newStep * float(i) : 0.0f;
+                            else g = gainAfterBlend + mainStep * float(i - fademix);
+                            sm.xl[kXPad + i] = inbuf[kHist - dL + i] * g;
+                            sm.xr[kXPad + i] = inbuf[kHist - dR + i] * g;
+                        }
+                        if(t < 64)
+                        {
+                            float lv = 0.0f, rv = 0.0f;
+                            if(oldOn && t < fademix)
+                            {
+                                const float g = (oldGain / float(fademix)) * float(fademix - t);
+                                lv = inbuf[kHist - odL + t] * g;
+                                rv = inbuf[kHist - odR + t] * g;
+                            }
+                            sm.xol[kXPad + t] = lv;
+                            sm.xor_[kXPad + t] = rv;
+                        }
+                        __syncthreads();
+                        FirMain(hL, hR, sm.xl, sm.xr, tgtCo, irStride, 4 * t);
+                        {
+                            const uint32_t ear = t >> 7, fr = t & 127;
+                            const float *xe = ear ? sm.xr : sm.xl;
+                            hTail = FirOne(hTail, xe + kXPad + kLine + fr, tgtCo, irStride, ear);
+                            if(oldOn)
+                            {
+                                const float *xo = ear ? sm.xor_ : sm.xol;
+                                hOld0 = FirOne(hOld0, xo + kXPad + fr, oldCo, irStride, ear);
+                                if(irStride > 64) hOld1 = FirOne(hOld1, xo + kXPad + 128 + fr, oldCo, irStride, ear);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    // voice.cpp:1094-1101 / :869-873,900: Old <- Target, Old.Gain <- reached gain
+                    if(counter == 0 || fademix)
+                        for(uint32_t k = t; k < irStride * 2; k += kThreads)
+                            L.hrtfOld[size_t{v} * irStride * 2 + k] = tgtCo[k];
+                    if(t == 0)
+                    {
+                        VoiceCtl &c = L.ctl[v];
+                        if(counter == 0 || fademix) { c.hrtfOldDelay[0] = dL; c.hrtfOldDelay[1] = dR; }
+                        c.hrtfOldGain = todo ? endGain : gainAfterBlend;
+                    }
+                    continue;
+                }
+
+                // ---------------- MixSamples (voice.cpp:962-963, 978-979) ----------------
+                uint32_t nlines, lineBase;
+                float *cur;
+                const float *curSnap = sm.gCur[tg2], *tgtSnap = sm.gTgt[tg2];
+                if(isDirect)
+                {
+                    nlines = numDry; lineBase = 0;
+                    cur = L.gainCur + size_t{v} * numDry;
+                }
+                else
+                {
+                    const int32_t slot = sm.sendSlot[si];
+                    if(slot < 0) continue;
+                    nlines = wetCh;
+                    lineBase = (L.hrtf ? 0u : numDry) + uint32_t(slot) * wetCh;
+                    cur = L.sendCur + (size_t{v} * numSends + si) * wetCh;
+                }
+                float s4[4];
+#pragma unroll
+                for(int k = 0; k < 4; ++k) s4[k] = (t + 256u * k < N) ? samples[t + 256u * k] : 0.0f;
+#pragma unroll
+                for(int c = 0; c < LINES; ++c)
+                {
+                    const uint32_t rel = uint32_t(c) - lineBase;
+                    if(uint32_t(c) < lineBase || rel >= nlines) continue;
+                    const float tg = playing ? tgtSnap[rel] : 0.0f;      // SilentCoeffs when Stopping
+                    const float cu = counter ? curSnap[rel] : tg;        // voice.cpp:1094-1112
+                    const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+#pragma unroll
+                    for(int k = 0; k < 4; ++k)
+                    {
+                        const uint32_t p = t + 256u * k;
+                        if(p < N && MixLineActive(g, p)) lineAcc[c][k] = lineAcc[c][k] + MixLineValue(g, s4[k], p);
+                    }
+                    if(t == 0) cur[rel] = g.newCur;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- voice.cpp:1116-1232: flags, position, loop wrap / end of buffer ----
+        if(t == 0)
+        {
+            VoiceCtl &c = L.ctl[v];
+            c.flags = ctl.flags | kFlagFading;
+            if(!playing) c.playState = OALGPU_VOICE_STOPPED;
+            else
+            {
+                bufPosFrac += increment * samplesToMix;
+                const uint32_t samplesDone = bufPosFrac >> kFracBits;
+                bufPosInt = AddSat(bufPosInt, int32_t(samplesDone));
+                bufPosFrac &= kFracMask;
+                if(bufferItem >= 0 && bufPosInt > 0)
+                {
+                    const BufferItem &b = L.buffers[bufferItem];
+                    if(loopItem >= 0)
+                    {
+                        uint32_t pos = uint32_t(bufPosInt);
+                        if(pos >= b.loopEnd)
+                        {
+                            pos = ((pos - b.loopStart) % (b.loopEnd - b.loopStart)) + b.loopStart;
+                            bufPosInt = int32_t(pos);
+                        }
+                    }
+                    else if(uint32_t(bufPosInt) >= b.sampleLen)
+                        bufferItem = -1;
+                }
+                c.position = bufPosInt;
+                c.positionFrac = bufPosFrac;
+                c.curBuffer = bufferItem;
+                if(bufferItem < 0)
+                {
+                    c.loopBuffer = -1;
+                    c.playState = OALGPU_VOICE_STOPPING;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- one partial per group ----
+    float *pl = L.partLines + size_t{group} * L.mixLines * kLine;
+#pragma unroll
+    for(int c = 0; c < LINES; ++c)
+    {
+        if(uint32_t(c) >= L.mixLines) continue;
+#pragma unroll
+        for(int k = 0; k < 4; ++k) pl[size_t{uint32_t(c)} * kLine + t + 256u * k] = lineAcc[c][k];
+    }
+    if(L.hrtf)
+    {
+        float *ph = L.partHrtf + size_t{group} * (kLine + kHrirLen) * 2;
+        if constexpr(EXACT)
+        {
+#pragma unroll
+            for(int k = 0; k < 5; ++k)
+            {
+                const uint32_t o = t + 256u * k;
+                if(o < kLine + kHrirLen) { ph[o * 2] = eL[k]; ph[o * 2 + 1] = eR[k]; }
+            }
+        }
+        else
+        {
+            __syncthreads();
+#pragma unroll
+            for(int r = 0; r < 4; ++r) { sm.stage[(4 * t + r) * 2] = hL[r]; sm.stage[(4 * t + r) * 2 + 1] = hR[r]; }
+            sm.stage[(kLine + (t & 127)) * 2 + (t >> 7)] = hTail;
+            __syncthreads();
+            sm.stage[(t & 127) * 2 + (t >> 7)] += hOld0;
+            sm.stage[(128 + (t & 127)) * 2 + (t >> 7)] += hOld1;
+            __syncthreads();
+            for(uint32_t k = t; k < (kLine + kHrirLen) * 2; k += kThreads) ph[k] = sm.stage[k];
+        }
+    }
+}
+
+template<bool EXACT, int LINES>
+hipError_t LaunchVoiceMixT(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool carry)
+{
+    hipLaunchKernelGGL((VoiceMixKernel<EXACT, LINES>), dim3(L.numGroups), dim3(kThreads), 0, s, L, samplesToDo,
+        carry ? 1u : 0u);
+    return hipGetLastError();
+}
+
+// sums the per-group partials in group order; lines without partials (HRTF context: dry/real)
+// are zero-filled (alc/alu.cpp:2417, :2196-2198)
+__global__ void __launch_bounds__(256) BusReduceKernel(DeviceLayout L, uint32_t samplesToDo)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t dryLines = L.numDry + L.numReal;
+    const uint32_t wetLines = L.numSlots * L.wetChannels;
+    const uint32_t lineFloats = (dryLines + wetLines) * kLine;
+    if(idx < lineFloats)
+    {
+        const uint32_t line = idx / kLine, p = idx % kLine;
+        int32_t src = -1;
+        if(line < dryLines) { if(!L.hrtf && line < L.numDry) src = int32_t(line); }
+        else src = int32_t((L.hrtf ? 0u : L.numDry) + (line - dryLines));
+        float sum = 0.0f;
+        if(src >= 0)
+            for(uint32_t g = 0; g < L.numGroups; ++g)
+                sum = sum + L.partLines[(size_t{g} * L.mixLines + uint32_t(src)) * kLine + p];
+        L.bus[idx] = sum;
+    }
+    else if(L.hrtf && idx < lineFloats + (kLine + kHrirLen) * 2)
+    {
+        const uint32_t k = idx - lineFloats;
+        float sum = 0.0f;
+        for(uint32_t g = 0; g < L.numGroups; ++g)
+            sum = sum + L.partHrtf[size_t{g} * (kLine + kHrirLen) * 2 + k];
+        L.bus[BusAccumOffset(L) + k] = sum;
+    }
+    (void)samplesToDo;
+}
+
+} // namespace
+
+hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum)
+{
+    const uint32_t lines = L.mixLines;
+    if(exact)
+    {
+        if(lines <= 8) return LaunchVoiceMixT<true, 8>(s, L, samplesToDo, carryAccum);
+        if(lines <= 16) return LaunchVoiceMixT<true, 16>(s, L, samplesToDo, carryAccum);
+        return LaunchVoiceMixT<true, 32>(s, L, samplesToDo, carryAccum);
+    }
+    if(lines <= 8) return LaunchVoiceMixT<false, 8>(s, L, samplesToDo, carryAccum);
+    if(lines <= 16) return LaunchVoiceMixT<false, 16>(s, L, samplesToDo, carryAccum);
+    return LaunchVoiceMixT<false, 32>(s, L, samplesToDo, carryAccum);
+}
+
+void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo)
+{
+    const uint32_t total = uint32_t(BusFloats(L));
+    hipLaunchKernelGGL(BusReduceKernel, dim3((total + 255u) / 256u), dim3(256), 0, s, L, samplesToDo);
+}
+
+} // namespace oalgpu

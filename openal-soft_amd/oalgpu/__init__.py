@@ -1,0 +1,398 @@
+"""ctypes binding of the product C-ABI (include/oalgpu.h, openal-soft_amd/liboalgpu.so).
+
+This is driver/test plumbing only -- the product is the shared library.  Importing the module
+loads the library and fails loudly when it has not been built; every compute call fails with
+OALGPU_ERR_NO_DEVICE when there is no GPU (there is no CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "liboalgpu.so")
+
+BUFFER_LINE = 1024
+MAX_PAD = 48
+HRTF_HIST = 64
+HRIR_LEN = 128
+MAX_SENDS = 6
+MAX_OUT = 32
+MAX_AMBI = 25
+MATH_EXACT, MATH_FAST = 0, 1
+(RS_POINT, RS_LINEAR, RS_SPLINE, RS_GAUSSIAN, RS_FAST_BSINC12, RS_BSINC12, RS_FAST_BSINC24,
+ RS_BSINC24, RS_FAST_BSINC48, RS_BSINC48) = range(10)
+FMT_UBYTE, FMT_SHORT, FMT_INT, FMT_FLOAT, FMT_DOUBLE, FMT_MULAW, FMT_ALAW = range(7)
+FMT_DTYPES = {FMT_UBYTE: np.uint8, FMT_SHORT: np.int16, FMT_INT: np.int32, FMT_FLOAT: np.float32,
+              FMT_DOUBLE: np.float64, FMT_MULAW: np.uint8, FMT_ALAW: np.uint8}
+VOICE_STOPPED, VOICE_PLAYING, VOICE_STOPPING, VOICE_PENDING = range(4)
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+
+
+class OalgpuError(RuntimeError):
+    pass
+
+
+class BsincTable(C.Structure):
+    _fields_ = [("scaleBase", C.c_float), ("scaleRange", C.c_float), ("m", C.c_uint32 * 16),
+                ("filterOffset", C.c_uint32 * 16), ("tab", f32p), ("tablen", C.c_size_t)]
+
+
+class InterpState(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("table", C.c_int32), ("sf", C.c_float), ("m", C.c_uint32),
+                ("l", C.c_uint32), ("filter_offset", C.c_uint32)]
+
+
+class Biquad(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("z1", "z2", "b0", "b1", "b2", "a1", "a2", "tb0", "tb1",
+                                         "tb2", "ta1", "ta2")] + [("counter", C.c_int32)]
+
+    def as_tuple(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+class Splitter(C.Structure):
+    _fields_ = [("coeff", C.c_float), ("lp_z1", C.c_float), ("lp_z2", C.c_float),
+                ("ap_z1", C.c_float)]
+
+
+class HrtfInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("sample_rate", "ir_size", "num_fields", "num_elevs",
+                                          "num_irs")]
+
+
+class ContextDesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("math_mode", C.c_int32), ("sample_rate", C.c_uint32),
+                ("num_dry_channels", C.c_uint32), ("num_real_channels", C.c_uint32),
+                ("num_aux_sends", C.c_uint32), ("num_slots", C.c_uint32),
+                ("wet_channels", C.c_uint32), ("hrtf", C.c_int32), ("max_voices", C.c_uint32),
+                ("max_buffers", C.c_uint32), ("voices_per_group", C.c_uint32)]
+
+
+class VoiceDesc(C.Structure):
+    _fields_ = [("buffer", C.c_int32), ("looping", C.c_int32), ("position", C.c_int32),
+                ("position_frac", C.c_uint32), ("frequency", C.c_uint32)]
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("active", C.c_int32), ("gain_hf", C.c_float), ("hf_norm", C.c_float),
+                ("gain_lf", C.c_float), ("lf_norm", C.c_float)]
+
+
+class VoiceParams(C.Structure):
+    _fields_ = [("step", C.c_uint32), ("resampler", C.c_int32), ("direct_filter", FilterParams),
+                ("dry_gains", C.c_float * MAX_OUT),
+                ("hrtf_ev", C.c_float), ("hrtf_az", C.c_float), ("hrtf_dist", C.c_float),
+                ("hrtf_spread", C.c_float), ("hrtf_gain", C.c_float),
+                ("send_slot", C.c_int32 * MAX_SENDS), ("send_filter", FilterParams * MAX_SENDS),
+                ("send_gains", (C.c_float * MAX_AMBI) * MAX_SENDS)]
+
+
+class VoiceState(C.Structure):
+    _fields_ = [("play_state", C.c_int32), ("position", C.c_int32), ("position_frac", C.c_uint32),
+                ("has_buffer", C.c_int32), ("fading", C.c_int32),
+                ("prev_samples", C.c_float * MAX_PAD), ("dry_current", C.c_float * MAX_OUT),
+                ("hrtf_old_gain", C.c_float), ("hrtf_old_delay", C.c_uint32 * 2),
+                ("hrtf_history", C.c_float * HRTF_HIST),
+                ("direct_lp", Biquad), ("direct_hp", Biquad),
+                ("send_current", (C.c_float * MAX_AMBI) * MAX_SENDS),
+                ("send_lp", Biquad * MAX_SENDS), ("send_hp", Biquad * MAX_SENDS)]
+
+
+def _fp(a):
+    return a.ctypes.data_as(f32p)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise OalgpuError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                          "(hipcc --offload-arch=gfx950); there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    L.oalgpu_version.restype = C.c_char_p
+    L.oalgpu_last_error.restype = C.c_char_p
+    L.oalgpu_bsinc_table_get.argtypes = [C.c_int, C.POINTER(BsincTable)]
+    L.oalgpu_cubic_table_get.argtypes = [C.c_int, f32p]
+    L.oalgpu_prepare_resampler.argtypes = [C.c_int, C.c_uint32, C.POINTER(InterpState)]
+    L.oalgpu_biquad_reset.argtypes = [C.POINTER(Biquad)]
+    L.oalgpu_biquad_reset.restype = None
+    L.oalgpu_biquad_set_params_from_slope.argtypes = [C.POINTER(Biquad), C.c_int, C.c_float,
+                                                      C.c_float, C.c_float]
+    L.oalgpu_biquad_set_params_from_slope.restype = None
+    L.oalgpu_splitter_init.argtypes = [C.POINTER(Splitter), C.c_float]
+    L.oalgpu_splitter_init.restype = None
+    L.oalgpu_resample.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, f32p, C.c_size_t,
+                                  C.c_uint32, f32p, C.c_size_t]
+    L.oalgpu_mix.argtypes = [C.c_int, f32p, C.c_size_t, f32p, C.c_size_t, f32p, f32p, C.c_size_t,
+                             C.c_size_t]
+    L.oalgpu_mix_hrtf.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint32, f32p, u32p, C.c_float,
+                                  C.c_float, C.c_size_t]
+    L.oalgpu_mix_hrtf_blend.argtypes = [C.c_int, C.c_int, f32p, f32p, C.c_uint32, f32p, u32p,
+                                        C.c_float, f32p, u32p, C.c_float, C.c_size_t]
+    L.oalgpu_mix_direct_hrtf.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p, C.c_size_t, f32p,
+                                         C.POINTER(Splitter), f32p, f32p, C.c_size_t, C.c_size_t]
+    L.oalgpu_biquad_dual_process.argtypes = [C.c_int, C.POINTER(Biquad), C.POINTER(Biquad), f32p,
+                                             f32p, C.c_size_t]
+    L.oalgpu_context_create.argtypes = [C.POINTER(ContextDesc), C.POINTER(C.c_void_p)]
+    L.oalgpu_context_destroy.argtypes = [C.c_void_p]
+    L.oalgpu_context_destroy.restype = None
+    L.oalgpu_hrtf_load_mhr.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.oalgpu_hrtf_info_get.argtypes = [C.c_void_p, C.POINTER(HrtfInfo)]
+    L.oalgpu_hrtf_raw.argtypes = [C.c_void_p, f32p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16),
+                                  C.POINTER(C.c_uint16), f32p, C.POINTER(C.c_uint8)]
+    L.oalgpu_hrtf_get_coeffs.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, u32p]
+    L.oalgpu_set_direct_hrtf.argtypes = [C.c_void_p, f32p, f32p, C.c_float, C.c_uint32]
+    L.oalgpu_buffer_register.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_uint32]
+    L.oalgpu_voice_init.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(VoiceDesc)]
+    L.oalgpu_voice_set_params.argtypes = [C.c_void_p, u32p, C.c_void_p, C.c_size_t]
+    L.oalgpu_voice_set_state.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.oalgpu_mix_update.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.oalgpu_mix_voices.argtypes = [C.c_void_p, C.c_uint32]
+    L.oalgpu_post_process.argtypes = [C.c_void_p, C.c_uint32]
+    L.oalgpu_set_carry_accum.argtypes = [C.c_void_p, C.c_int]
+    L.oalgpu_sync.argtypes = [C.c_void_p]
+    L.oalgpu_read_dry.argtypes = [C.c_void_p, f32p]
+    L.oalgpu_read_wet.argtypes = [C.c_void_p, C.c_uint32, f32p]
+    L.oalgpu_read_hrtf_accum.argtypes = [C.c_void_p, f32p]
+    L.oalgpu_bus_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_void_p)]
+    L.oalgpu_voice_readback.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(VoiceState)]
+    L.oalgpu_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.oalgpu_last_update_ms.argtypes = [C.c_void_p, f32p, f32p]
+    return L
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc < 0:
+        raise OalgpuError(f"{what} failed ({rc}): {lib.oalgpu_last_error().decode()}")
+    return rc
+
+
+def device_count():
+    return lib.oalgpu_device_count()
+
+
+class Api:
+    """Per-call mirrors + table access, with the same method names as tests/oracle_lib.OracleLib
+    so the parity tests can drive oracle and product through one code path."""
+    kind = "oalgpu"
+
+    def __init__(self, mode=MATH_EXACT, device=0):
+        self.mode = mode
+        self.device = device
+        self._mhr = None
+
+    # ---- tables (host side) ----
+    def bsinc_table(self, which):
+        t = BsincTable()
+        check(lib.oalgpu_bsinc_table_get(which, C.byref(t)), "bsinc_table_get")
+        tab = np.ctypeslib.as_array(t.tab, shape=(t.tablen,)).copy()
+        return dict(scaleBase=t.scaleBase, scaleRange=t.scaleRange, m=list(t.m),
+                    filterOffset=list(t.filterOffset), tab=tab)
+
+    def cubic_table(self, which):
+        out = np.zeros((32, 8), np.float32)
+        check(lib.oalgpu_cubic_table_get(which, _fp(out)))
+        return out
+
+    def prepare_resampler(self, resampler, increment):
+        st = InterpState()
+        check(lib.oalgpu_prepare_resampler(resampler, increment, C.byref(st)))
+        return st
+
+    # ---- per-call kernels (GPU) ----
+    def resample(self, resampler, increment, src, frac, n):
+        src = np.ascontiguousarray(src, np.float32)
+        dst = np.zeros(n, np.float32)
+        check(lib.oalgpu_resample(self.device, self.mode, resampler, increment, _fp(src), src.size,
+                                  frac, _fp(dst), n), "oalgpu_resample")
+        return dst
+
+    def mix(self, inp, out, cur, tgt, counter, outpos):
+        inp = np.ascontiguousarray(inp, np.float32)
+        tgt = np.ascontiguousarray(tgt, np.float32)
+        check(lib.oalgpu_mix(self.device, _fp(inp), inp.size, _fp(out), out.shape[0], _fp(cur),
+                             _fp(tgt), counter, outpos), "oalgpu_mix")
+
+    def mix_hrtf(self, inp, accum, irsize, coeffs, delay, gain, gainstep, n):
+        inp = np.ascontiguousarray(inp, np.float32)
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        check(lib.oalgpu_mix_hrtf(self.device, self.mode, _fp(inp), _fp(accum), irsize, _fp(coeffs),
+                                  (C.c_uint32 * 2)(*delay), gain, gainstep, n), "oalgpu_mix_hrtf")
+
+    def mix_hrtf_blend(self, inp, accum, irsize, oldc, oldd, oldgain, newc, newd, newstep, n):
+        inp = np.ascontiguousarray(inp, np.float32)
+        oldc = np.ascontiguousarray(oldc, np.float32)
+        newc = np.ascontiguousarray(newc, np.float32)
+        check(lib.oalgpu_mix_hrtf_blend(self.device, self.mode, _fp(inp), _fp(accum), irsize,
+                                        _fp(oldc), (C.c_uint32 * 2)(*oldd), oldgain, _fp(newc),
+                                        (C.c_uint32 * 2)(*newd), newstep, n), "oalgpu_mix_hrtf_blend")
+
+    def mix_direct_hrtf(self, left, right, inp, accum, splitters, hfscales, chan_coeffs, irsize, n):
+        nch = inp.shape[0]
+        sp = (Splitter * nch)()
+        for i, s in enumerate(splitters):
+            sp[i] = Splitter(s.coeff, s.lp_z1, s.lp_z2, s.ap_z1)
+        hf = np.ascontiguousarray(hfscales, np.float32)
+        cc = np.ascontiguousarray(chan_coeffs, np.float32)
+        check(lib.oalgpu_mix_direct_hrtf(self.device, self.mode, _fp(left), _fp(right), _fp(inp), nch,
+                                         _fp(accum), sp, _fp(hf), _fp(cc), irsize, n),
+              "oalgpu_mix_direct_hrtf")
+        return list(sp)
+
+    def biquad_dual_process(self, lp, hp, src):
+        src = np.ascontiguousarray(src, np.float32)
+        dst = np.zeros(src.size, np.float32)
+        check(lib.oalgpu_biquad_dual_process(self.device, C.byref(lp), C.byref(hp), _fp(src),
+                                             _fp(dst), src.size), "oalgpu_biquad_dual_process")
+        return dst
+
+    # ---- HRTF data set: remembered here, loaded into each context created afterwards ----
+    def hrtf_load(self, path):
+        with open(path, "rb") as f:
+            self._mhr = f.read()
+        return None
+
+    def make_scene(self, **kw):
+        return Scene(self, **kw)
+
+
+class Scene:
+    """Batched path: one device context, driven like tests/oracle_lib.Scene."""
+
+    def __init__(self, api, sample_rate=48000, num_dry=3, num_real=0, num_sends=0, num_slots=0,
+                 wet_channels=4, hrtf=False, max_voices=64, max_buffers=64, voices_per_group=0):
+        self.h = None
+        self.api = api
+        self.desc = ContextDesc(api.device, api.mode, sample_rate, num_dry, num_real, num_sends,
+                                num_slots, wet_channels, 1 if hrtf else 0, max_voices, max_buffers,
+                                voices_per_group)
+        h = C.c_void_p()
+        check(lib.oalgpu_context_create(C.byref(self.desc), C.byref(h)), "oalgpu_context_create")
+        self.h = h
+        self.nvoices = 0
+        if hrtf:
+            if api._mhr is None:
+                raise OalgpuError("HRTF scene without a loaded .mhr")
+            check(lib.oalgpu_hrtf_load_mhr(self.h, api._mhr, len(api._mhr)), "oalgpu_hrtf_load_mhr")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.oalgpu_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def hrtf_info(self):
+        info = HrtfInfo()
+        check(lib.oalgpu_hrtf_info_get(self.h, C.byref(info)))
+        return info
+
+    def hrtf_raw(self):
+        info = self.hrtf_info()
+        fd = np.zeros(info.num_fields, np.float32)
+        fe = np.zeros(info.num_fields, np.uint8)
+        az = np.zeros(info.num_elevs, np.uint16)
+        io = np.zeros(info.num_elevs, np.uint16)
+        co = np.zeros((info.num_irs, HRIR_LEN, 2), np.float32)
+        de = np.zeros((info.num_irs, 2), np.uint8)
+        check(lib.oalgpu_hrtf_raw(self.h, _fp(fd), fe.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                  az.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                  io.ctypes.data_as(C.POINTER(C.c_uint16)), _fp(co),
+                                  de.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return dict(info=info, field_distance=fd, field_evcount=fe, elev_azcount=az,
+                    elev_iroffset=io, coeffs=co, delays=de)
+
+    def hrtf_get_coeffs(self, dirs):
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 4)
+        n = dirs.shape[0]
+        co = np.zeros((n, HRIR_LEN, 2), np.float32)
+        de = np.zeros((n, 2), np.uint32)
+        check(lib.oalgpu_hrtf_get_coeffs(self.h, _fp(dirs), n, _fp(co), de.ctypes.data_as(u32p)),
+              "oalgpu_hrtf_get_coeffs")
+        return co, de
+
+    def add_buffer(self, data, fmt, frame_step=1, loop_start=0, loop_end=None):
+        data = np.ascontiguousarray(data, FMT_DTYPES[fmt])
+        n = data.size // frame_step
+        if loop_end is None:
+            loop_end = n
+        return check(lib.oalgpu_buffer_register(self.h, data.ctypes.data_as(C.c_void_p), fmt,
+                                                frame_step, n, loop_start, loop_end),
+                     "oalgpu_buffer_register")
+
+    def add_voice(self, buffer, looping, position=0, frac=0, frequency=44100):
+        d = VoiceDesc(buffer, 1 if looping else 0, position, frac, frequency)
+        v = self.nvoices
+        check(lib.oalgpu_voice_init(self.h, v, C.byref(d)), "oalgpu_voice_init")
+        self.nvoices += 1
+        return v
+
+    def set_params(self, voice, params):
+        """params: any ctypes struct with the oalgpu_voice_params layout."""
+        assert C.sizeof(params) == C.sizeof(VoiceParams)
+        ids = (C.c_uint32 * 1)(voice)
+        check(lib.oalgpu_voice_set_params(self.h, ids, C.byref(params), 1), "oalgpu_voice_set_params")
+
+    def set_params_batch(self, voices, params_array):
+        """voices: uint32 array; params_array: ctypes array of VoiceParams."""
+        voices = np.ascontiguousarray(voices, np.uint32)
+        check(lib.oalgpu_voice_set_params(self.h, voices.ctypes.data_as(u32p),
+                                          C.cast(params_array, C.c_void_p), len(voices)),
+              "oalgpu_voice_set_params")
+
+    def set_state(self, voice, vstate):
+        check(lib.oalgpu_voice_set_state(self.h, voice, vstate), "oalgpu_voice_set_state")
+
+    def set_direct_hrtf(self, chan_coeffs, hfscales, xover_norm, irsize):
+        cc = np.ascontiguousarray(chan_coeffs, np.float32)
+        hf = np.ascontiguousarray(hfscales, np.float32)
+        check(lib.oalgpu_set_direct_hrtf(self.h, _fp(cc), _fp(hf), xover_norm, irsize),
+              "oalgpu_set_direct_hrtf")
+
+    def mix(self, samples_to_do=BUFFER_LINE, post_process=False):
+        check(lib.oalgpu_mix_update(self.h, samples_to_do, 1 if post_process else 0),
+              "oalgpu_mix_update")
+
+    def sync(self):
+        check(lib.oalgpu_sync(self.h), "oalgpu_sync")
+
+    def dry(self):
+        n = self.desc.num_dry_channels + self.desc.num_real_channels
+        out = np.zeros((n, BUFFER_LINE), np.float32)
+        check(lib.oalgpu_read_dry(self.h, _fp(out)), "oalgpu_read_dry")
+        return out
+
+    def wet(self, slot):
+        out = np.zeros((self.desc.wet_channels, BUFFER_LINE), np.float32)
+        check(lib.oalgpu_read_wet(self.h, slot, _fp(out)), "oalgpu_read_wet")
+        return out
+
+    def hrtf_accum(self):
+        out = np.zeros((BUFFER_LINE + HRIR_LEN, 2), np.float32)
+        check(lib.oalgpu_read_hrtf_accum(self.h, _fp(out)), "oalgpu_read_hrtf_accum")
+        return out
+
+    def voice_state(self, voice):
+        st = VoiceState()
+        check(lib.oalgpu_voice_readback(self.h, voice, C.byref(st)), "oalgpu_voice_readback")
+        return st
+
+    def bus_device_ptr(self):
+        p, n, s = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        check(lib.oalgpu_bus_device_ptr(self.h, C.byref(p), C.byref(n), C.byref(s)))
+        return p.value, n.value, s.value
+
+    def set_timing(self, enable=True):
+        check(lib.oalgpu_set_timing(self.h, 1 if enable else 0))
+
+    def last_update_ms(self):
+        a, b = C.c_float(), C.c_float()
+        check(lib.oalgpu_last_update_ms(self.h, C.byref(a), C.byref(b)), "oalgpu_last_update_ms")
+        return a.value, b.value
