@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline path on MI355X: mixed voices/sec at 48 kHz, 1024-sample
+updates, HRTF stereo (BASELINE.json configs[2]: 4096 mono voices, bsinc24 resample, dual-ear
+HRIR FIR, MixDirectHrtf post-process).  One "step" = one update of every voice.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (contract in the task statement; see DESIGN.md "Measurement").
+Inputs (source PCM, voice state, the per-update parameter blocks of the moving voices) are
+resident in HBM before the timed region starts.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+UPDATE_SAMPLES = 1024
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+# algorithmic bytes per voice-update, SURVEY.md 8(d) / DESIGN.md "Algorithmic bytes":
+#   source window (941+48) f32 + mPrevSamples r/w + position r/w + HRTF history r/w + target HRIR
+BYTES_PER_VOICE_UPDATE = {3: 3956 + 384 + 16 + 512 + 512, 2: 3956 + 384 + 16 + 2 * 4 * 5 + 4 * 5}
+
+
+def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, vpg):
+    hrtf = config_id == 3
+    sc = oalgpu.Scene(api, sample_rate=48000, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0,
+                      hrtf=hrtf, max_voices=nvoices, max_buffers=256, voices_per_group=vpg)
+    if hrtf:
+        rng = np.random.default_rng(1234)
+        cc = np.zeros((4, 128, 2), np.float32)
+        cc[:, :64] = rng.uniform(-0.2, 0.2, (4, 64, 2)) * np.exp(-np.arange(64) / 12.0)[None, :, None]
+        sc.set_direct_hrtf(cc, [1.0, 0.8, 0.8, 0.8], 400.0 / 48000.0, 64)
+    bufs = synth.scene_buffers(config_id, nvoices)
+    handles = [sc.add_buffer(b, oalgpu.FMT_FLOAT) for b in bufs]
+    script = synth.SceneScript(config_id, nvoices, voice_base)
+    for v in range(nvoices):
+        sc.add_voice(handles[script.buffer_of(v, len(handles))], True, position=script.start_position(v))
+    return sc, script
+
+
+def param_array(oalgpu, script, voices, update):
+    arr = (oalgpu.VoiceParams * len(voices))()
+    for i, v in enumerate(voices):
+        script.fill(arr[i], v, update)
+    return arr
+
+
+def cpu_baseline(synth, config_id, nvoices, target_seconds=12.0):
+    """The reference CPU mixer (compiled reference if it travelled, else the C restatement) on
+    the same scene, single thread -- the reference's real operating mode."""
+    import oracle_lib as ol
+    which = "ref" if ol.available("ref") else "port"
+    if not ol.available(which):
+        return None
+    L = ol.load(which)
+    L.L.oal_set_simd(1)
+    hrtf = config_id == 3
+    with tempfile.TemporaryDirectory() as td:
+        if hrtf:
+            L.hrtf_load(synth.write_synth_mhr(os.path.join(td, "synth.mhr")))
+        sc = ol.Scene(L, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0, hrtf=hrtf)
+        bufs = synth.scene_buffers(config_id, nvoices)
+        handles = [sc.add_buffer(b, ol.FMT_FLOAT) for b in bufs]
+        script = synth.SceneScript(config_id, nvoices)
+        for v in range(nvoices):
+            sc.add_voice(handles[script.buffer_of(v, len(handles))], True, position=script.start_position(v))
+            sc.set_params(v, script.fill(ol.VoiceParams(), v, 0))
+        moving = [v for v in range(nvoices) if script.is_moving(v)]
+        sc.mix(UPDATE_SAMPLES, post_process=hrtf)          # warm-up (not fading yet)
+        t0 = time.perf_counter()
+        sc.mix(UPDATE_SAMPLES, post_process=hrtf)
+        one = time.perf_counter() - t0
+        updates = int(max(3, min(200, target_seconds / max(one, 1e-6))))
+        mix_time = 0.0
+        for k in range(updates):
+            for v in moving:                               # parameter side is not timed
+                sc.set_params(v, script.fill(ol.VoiceParams(), v, k + 2))
+            t0 = time.perf_counter()
+            sc.mix(UPDATE_SAMPLES, post_process=hrtf)
+            mix_time += time.perf_counter() - t0
+        sc.close()
+    return {"value": nvoices * updates / mix_time, "unit": "voices/s", "cores": 1,
+            "kind": "reference" if L.kind == "reference" else "port",
+            "sample": f"{nvoices} voices x {updates} updates of the same scene, 1 thread, "
+                      f"{mix_time:.1f} s of Voice::mix + MixDirectHrtf"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3))
+    ap.add_argument("--voices", type=int, default=4096, help="voices per GPU")
+    ap.add_argument("--math", default="fast", choices=("fast", "exact"))
+    ap.add_argument("--vpg", type=int, default=0, help="voices per workgroup (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import oalgpu
+    from oalgpu import synth
+
+    if oalgpu.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank)
+    mhr = synth.synth_mhr_bytes()
+    api._mhr = mhr
+    V = args.voices
+    hrtf = args.config == 3
+    sc, script = build_scene(oalgpu, synth, api, args.config, V, rank * V, mhr, args.vpg)
+
+    all_voices = list(range(V))
+    moving = [v for v in all_voices if script.is_moving(v)]
+    sc.set_params_batch(all_voices, param_array(oalgpu, script, all_voices, 0))
+    total_steps = args.warmup + 2 * args.steps
+    blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(total_steps)]
+
+    bus_t = None
+    if world > 1:
+        stream = torch.cuda.current_stream()
+        sc.set_stream(stream.cuda_stream)
+        ptr, nfloats, _ = sc.bus_device_ptr()
+
+        class _Bus:
+            __cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        bus_t = torch.as_tensor(_Bus(), device=f"cuda:{local_rank}")
+        sc.set_carry_accum(rank == 0)
+
+    def step(k):
+        sc.apply_block(blocks[k])
+        if world == 1:
+            sc.mix(UPDATE_SAMPLES, post_process=hrtf)
+        else:
+            sc.mix_voices(UPDATE_SAMPLES)
+            dist.reduce(bus_t, dst=0, op=dist.ReduceOp.SUM)       # one RCCL reduce of the mix buses
+            if rank == 0:
+                sc.post_process(UPDATE_SAMPLES)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        sc.sync()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- instrumented pass: HIP events on the context's stream around each voice-kernel launch
+    sc.set_timing(True)
+    vk = []
+    tot = []
+    for k in range(args.steps):
+        sc.apply_block(blocks[args.warmup + args.steps + k])
+        sc.mix_voices(UPDATE_SAMPLES)
+        a, b = sc.last_update_ms()
+        tot.append(a)
+        vk.append(b)
+        if world == 1 and hrtf:
+            sc.post_process(UPDATE_SAMPLES)
+    sc.sync()
+    sc.set_timing(False)
+    vk_ms = float(np.mean(vk))
+
+    if rank == 0:
+        nvoices_total = V * world
+        bytes_per_launch = BYTES_PER_VOICE_UPDATE[args.config] * V
+        achieved = bytes_per_launch / (vk_ms * 1e-3) / 1e9
+        out = {
+            "metric": "mixed voices/sec @48kHz 1024-sample update, HRTF stereo" if hrtf
+                      else "mixed voices/sec @48kHz 1024-sample update, bsinc24 -> 7.1 dry bus",
+            "value": nvoices_total * args.steps / elapsed,
+            "unit": "voices/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {V} mono f32 voices per GPU "
+                                   f"(44.1k->48k, bsinc24"
+                                   + (", HRTF synthetic .mhr with Default-HRTF geometry irSize 64, "
+                                      "dual-ear FIR + MixDirectHrtf" if hrtf else ", 5-line dry mix")
+                                   + "), 25% filtered, every 4th voice moving",
+                       "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
+                       "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
+                       "parallelism": f"voice-shard x{world}" + (" + RCCL reduce of mix buses" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "VoiceMixKernel", "kernel_ms": vk_ms,
+                         "bytes_per_launch": bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(synth, args.config, V)
+            if cb:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -239,6 +239,13 @@ typedef struct oalgpu_voice_params {
  * the BiquadInterpFilter::setParams state machine run on the GPU. */
 int oalgpu_voice_set_params(oalgpu_context *ctx, const uint32_t *voices,
     const oalgpu_voice_params *params, size_t count);
+/* The same, split so a caller can stage parameter blocks in HBM ahead of time (one block per
+ * update of a scripted scene) and apply them asynchronously on the context's stream. */
+typedef struct oalgpu_param_block oalgpu_param_block;
+int  oalgpu_param_block_create(oalgpu_context *ctx, const uint32_t *voices,
+    const oalgpu_voice_params *params, size_t count, oalgpu_param_block **out);
+int  oalgpu_param_block_apply(oalgpu_context *ctx, oalgpu_param_block *block);
+void oalgpu_param_block_destroy(oalgpu_param_block *block);
 /* ProcessVoiceChanges side (alc/alu.cpp:2057-2151): Playing / Stopping / Stopped. */
 int oalgpu_voice_set_state(oalgpu_context *ctx, uint32_t voice, int play_state);
 
@@ -248,6 +255,9 @@ int oalgpu_voice_set_state(oalgpu_context *ctx, uint32_t voice, int play_state);
  * Asynchronous on the context's stream; oalgpu_sync() or a read-back waits. */
 int oalgpu_mix_update(oalgpu_context *ctx, uint32_t samples_to_do, int post_process);
 int oalgpu_sync(oalgpu_context *ctx);
+/* Run the context on a caller-owned HIP stream (hipStream_t), e.g. the stream an RCCL
+ * collective is ordered on; NULL returns to a private stream. */
+int oalgpu_set_stream(oalgpu_context *ctx, void *hip_stream);
 
 /* Bus read-back (host copies).  dry: (num_dry+num_real) x 1024; wet: wet_channels x 1024;
  * hrtf_accum: (1024+128) x 2. */

@@ -105,6 +105,7 @@ struct oalgpu_context {
     oalgpu_context_desc desc{};
     bool exact{true};
     hipStream_t stream{nullptr};
+    bool ownStream{true};
     hipEvent_t evStart{nullptr}, evVoice{nullptr}, evEnd{nullptr};
     bool timing{false}, timed{false};
     DeviceLayout L{};
@@ -142,7 +143,7 @@ struct oalgpu_context {
         if(evStart) (void)hipEventDestroy(evStart);
         if(evVoice) (void)hipEventDestroy(evVoice);
         if(evEnd) (void)hipEventDestroy(evEnd);
-        if(stream) (void)hipStreamDestroy(stream);
+        if(stream && ownStream) (void)hipStreamDestroy(stream);
     }
 };
 
@@ -544,21 +545,17 @@ int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc
     return OALGPU_OK;
 }
 
-int oalgpu_voice_set_params(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params, size_t count)
+static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params,
+    size_t count, std::vector<ParamRecord> &recs)
 {
-    if(!c || !voices || !params) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(count == 0) return OALGPU_OK;
-    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(int rc = UseDevice(c->desc.device)) return rc;
-    if(int rc = FlushInits(c)) return rc;
     const TableBlob &blob = Blob();
-    c->paramHost.resize(count);
+    recs.resize(count);
     for(size_t i = 0; i < count; ++i)
     {
         const oalgpu_voice_params &p = params[i];
         if(voices[i] >= c->L.numVoices || p.resampler < 0 || p.resampler > OALGPU_RESAMPLER_BSINC48)
-            return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_params: bad voice index or resampler");
-        ParamRecord &r = c->paramHost[i];
+            return Fail(OALGPU_ERR_INVALID, "voice parameters: bad voice index or resampler");
+        ParamRecord &r = recs[i];
         std::memset(&r, 0, sizeof(r));
         r.voice = voices[i];
         r.step = p.step;
@@ -584,11 +581,74 @@ int oalgpu_voice_set_params(oalgpu_context *c, const uint32_t *voices, const oal
         r.hrtfGain = p.hrtf_gain;
         std::memcpy(r.dryGains, p.dry_gains, sizeof(r.dryGains));
     }
+    return OALGPU_OK;
+}
+
+int oalgpu_voice_set_params(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params, size_t count)
+{
+    if(!c || !voices || !params) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(count == 0) return OALGPU_OK;
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(int rc = BuildParamRecords(c, voices, params, count, c->paramHost)) return rc;
     if(c->paramDev.n < count) HIP_TRY(c->paramDev.alloc(count));
     HIP_TRY(hipMemcpyAsync(c->paramDev.p, c->paramHost.data(), count * sizeof(ParamRecord), hipMemcpyHostToDevice, c->stream));
     LaunchApplyParams(c->stream, c->L, c->hrtfDev, c->paramDev.p, uint32_t(count));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));   // paramHost is reused by the next call
+    return OALGPU_OK;
+}
+
+struct oalgpu_param_block {
+    DevBuf<ParamRecord> recs;
+    uint32_t count{0};
+    int device{0};
+};
+
+int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params,
+    size_t count, oalgpu_param_block **out)
+{
+    if(!c || !voices || !params || !out || count == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_param_block_create: bad arguments");
+    *out = nullptr;
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    std::vector<ParamRecord> recs;
+    if(int rc = BuildParamRecords(c, voices, params, count, recs)) return rc;
+    auto b = std::make_unique<oalgpu_param_block>();
+    b->count = uint32_t(count);
+    b->device = c->desc.device;
+    HIP_TRY(b->recs.alloc(count));
+    HIP_TRY(b->recs.upload(recs.data(), count));
+    *out = b.release();
+    return OALGPU_OK;
+}
+
+int oalgpu_param_block_apply(oalgpu_context *c, oalgpu_param_block *b)
+{
+    if(!c || !b) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    LaunchApplyParams(c->stream, c->L, c->hrtfDev, b->recs.p, b->count);
+    HIP_TRY(hipGetLastError());
+    return OALGPU_OK;
+}
+
+void oalgpu_param_block_destroy(oalgpu_param_block *b)
+{
+    if(!b) return;
+    (void)hipSetDevice(b->device);
+    delete b;
+}
+
+int oalgpu_set_stream(oalgpu_context *c, void *hip_stream)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if(c->ownStream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
+    if(hip_stream) { c->stream = static_cast<hipStream_t>(hip_stream); c->ownStream = false; }
+    else { HIP_TRY(hipStreamCreate(&c->stream)); c->ownStream = true; }
     return OALGPU_OK;
 }
 

@@ -148,6 +148,11 @@ def _load():
     L.oalgpu_voice_init.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(VoiceDesc)]
     L.oalgpu_voice_set_params.argtypes = [C.c_void_p, u32p, C.c_void_p, C.c_size_t]
     L.oalgpu_voice_set_state.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.oalgpu_param_block_create.argtypes = [C.c_void_p, u32p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.oalgpu_param_block_apply.argtypes = [C.c_void_p, C.c_void_p]
+    L.oalgpu_param_block_destroy.argtypes = [C.c_void_p]
+    L.oalgpu_param_block_destroy.restype = None
+    L.oalgpu_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.oalgpu_mix_update.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
     L.oalgpu_mix_voices.argtypes = [C.c_void_p, C.c_uint32]
     L.oalgpu_post_process.argtypes = [C.c_void_p, C.c_uint32]
@@ -346,6 +351,29 @@ class Scene:
         check(lib.oalgpu_voice_set_params(self.h, voices.ctypes.data_as(u32p),
                                           C.cast(params_array, C.c_void_p), len(voices)),
               "oalgpu_voice_set_params")
+
+    def param_block(self, voices, params_array):
+        voices = np.ascontiguousarray(voices, np.uint32)
+        h = C.c_void_p()
+        check(lib.oalgpu_param_block_create(self.h, voices.ctypes.data_as(u32p),
+                                            C.cast(params_array, C.c_void_p), len(voices), C.byref(h)),
+              "oalgpu_param_block_create")
+        return h
+
+    def apply_block(self, block):
+        check(lib.oalgpu_param_block_apply(self.h, block), "oalgpu_param_block_apply")
+
+    def set_stream(self, stream_ptr):
+        check(lib.oalgpu_set_stream(self.h, stream_ptr), "oalgpu_set_stream")
+
+    def mix_voices(self, samples_to_do=BUFFER_LINE):
+        check(lib.oalgpu_mix_voices(self.h, samples_to_do), "oalgpu_mix_voices")
+
+    def post_process(self, samples_to_do=BUFFER_LINE):
+        check(lib.oalgpu_post_process(self.h, samples_to_do), "oalgpu_post_process")
+
+    def set_carry_accum(self, enable):
+        check(lib.oalgpu_set_carry_accum(self.h, 1 if enable else 0))
 
     def set_state(self, voice, vstate):
         check(lib.oalgpu_voice_set_state(self.h, voice, vstate), "oalgpu_voice_set_state")

@@ -92,3 +92,86 @@ def write_synth_mhr(path, **kw):
     with open(path, "wb") as f:
         f.write(data)
     return path
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic multi-voice scenes of SURVEY.md section 8(d) (shared by bench.py and the tests)
+# ---------------------------------------------------------------------------------------------
+SRC_RATE = 44100
+DEV_RATE = 48000
+STEP_44K1 = 60211          # fastf2u(44100/48000 * 65536), alc/alu.cpp:1685
+BUFFER_FRAMES = 48000
+
+
+def scene_buffers(config_id, nvoices, fmt="f32"):
+    """min(nvoices, 256) distinct mono buffers, 48000 frames, uniform [-1, 1)."""
+    nbuf = min(nvoices, 256)
+    out = []
+    for b in range(nbuf):
+        x = lcg_block_f32(0x5EED0000 + config_id * 4096 + b, BUFFER_FRAMES)
+        if fmt == "i16":
+            x = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+        out.append(x)
+    return out
+
+
+class SceneScript:
+    """Per-voice parameters for update 0 (all voices) and for every later update (the moving
+    quarter of the voices get a new random direction), config 2 (7.1 dry bus, 5 ambisonic
+    lines) or config 3 (HRTF)."""
+
+    def __init__(self, config_id, nvoices, voice_base=0):
+        self.config_id = config_id
+        self.nvoices = nvoices
+        self.voice_base = voice_base          # global index of local voice 0 (multi-GPU shards)
+        self.hrtf = config_id in (3, 5)
+
+    def _rng(self, gv, update):
+        return Lcg(0x5EED0000 + self.config_id + 7919 * gv + 104729 * update)
+
+    def start_position(self, v):
+        return ((self.voice_base + v) * 7919) % BUFFER_FRAMES
+
+    def buffer_of(self, v, nbuf):
+        return (self.voice_base + v) % nbuf
+
+    def direction(self, v, update):
+        r = self._rng(self.voice_base + v, update if self.is_moving(v) else 0)
+        az = r.uniform(-np.pi, np.pi)
+        ev = float(np.arcsin(r.uniform(-1.0, 1.0)))
+        gain = 10.0 ** (r.uniform(-60.0, -20.0) / 20.0)
+        return ev, az, gain
+
+    def is_moving(self, v):
+        return (self.voice_base + v) % 4 == 0
+
+    def filter_active(self, v):
+        return (self.voice_base + v) % 4 == 1
+
+    def fill(self, p, v, update):
+        """p: a ctypes struct with the oalgpu_voice_params / oal_voice_params layout."""
+        ev, az, gain = self.direction(v, update)
+        p.step = STEP_44K1
+        p.resampler = 7                        # Resampler::BSinc24
+        p.direct_filter.active = 1 if self.filter_active(v) else 0
+        p.direct_filter.gain_hf = 0.5 if self.filter_active(v) else 1.0
+        p.direct_filter.hf_norm = 5000.0 / DEV_RATE
+        p.direct_filter.gain_lf = 1.0
+        p.direct_filter.lf_norm = 250.0 / DEV_RATE
+        for i in range(6):
+            p.send_slot[i] = -1
+            p.send_filter[i].active = 0
+            p.send_filter[i].gain_hf = 1.0
+            p.send_filter[i].hf_norm = 5000.0 / DEV_RATE
+            p.send_filter[i].gain_lf = 1.0
+            p.send_filter[i].lf_norm = 250.0 / DEV_RATE
+        if self.hrtf:
+            p.hrtf_ev, p.hrtf_az, p.hrtf_dist, p.hrtf_spread, p.hrtf_gain = ev, az, 2.0, 0.0, gain
+        else:
+            # 2nd-order 2D ambisonic encode of the direction (W, Y, X, V, U), N3D-like weights
+            x, y = np.cos(az) * np.cos(ev), np.sin(az) * np.cos(ev)
+            coeffs = [1.0, y * 1.7320508, x * 1.7320508, 2.0 * x * y * 1.9364917,
+                      (x * x - y * y) * 1.9364917]
+            for c in range(5):
+                p.dry_gains[c] = gain * coeffs[c]
+        return p
