@@ -25,11 +25,23 @@ struct ResampleSpec {
     const float *filter;   // cubic: float[32][8]; bsinc: BsincState::filter
 };
 
+// Layout of the coefficient rows the kernels read.  In the reference table (HBM) phase row pi
+// of a bsinc filter is [fil(m) | phd(m)] at 2*m*pi and the scale deltas [scd(m) | spd(m)] sit
+// 64*m floats further on (core/bsinc_tables.cpp:255-339); the voice kernel re-stages the rows
+// in LDS with a padded stride (16-byte aligned, bank-spread) and reads them as float4.
+struct TabLayout {
+    uint32_t bsincStride;   // floats between phase rows
+    uint32_t scdBase;       // offset of the scale-delta block
+    uint32_t cubicStride;   // floats between cubic phase rows ({coeffs[4], deltas[4]})
+};
+__host__ __device__ inline TabLayout ReferenceTabLayout(uint32_t m) { return TabLayout{2u * m, 64u * m, 8u}; }
+
 // src: the reference's mResampleData (index 0 = MaxResamplerEdge samples before the position).
 // i: output index inside this call; n: the call's dst size (cubic tail rule).
-template<bool EXACT, typename SrcPtr, typename TabPtr>
+// WIDE: coefficient rows are 16-byte aligned (LDS staging) and are read four taps at a time.
+template<bool EXACT, bool WIDE = false, typename SrcPtr, typename TabPtr>
 __device__ __forceinline__ float ResampleAt(int kind, uint32_t m, uint32_t l, float sf, TabPtr filter,
-    SrcPtr src, uint32_t frac0, uint32_t increment, uint32_t i, uint32_t n)
+    const TabLayout lay, SrcPtr src, uint32_t frac0, uint32_t increment, uint32_t i, uint32_t n)
 {
     const uint32_t t = frac0 + i * increment;
     const uint32_t pos = t >> kFracBits;
@@ -45,11 +57,12 @@ __device__ __forceinline__ float ResampleAt(int kind, uint32_t m, uint32_t l, fl
             const uint32_t pi = frac >> 11;
             const float pf = float(frac & 2047u) * (1.0f / 2048.0f);
             const uint32_t base = kMaxEdge - 1 + pos;
+            const uint32_t row = pi * lay.cubicStride;
             float r[4];
 #pragma unroll
             for(int k = 0; k < 4; ++k)
             {
-                const float f = madd<EXACT>(filter[pi * 8 + k], pf, filter[pi * 8 + 4 + k]);
+                const float f = madd<EXACT>(filter[row + k], pf, filter[row + 4 + k]);
                 r[k] = f * src[base + k];
             }
             if(i < (n & ~3u)) return (r[0] + r[1]) + (r[2] + r[3]);
@@ -60,10 +73,39 @@ __device__ __forceinline__ float ResampleAt(int kind, uint32_t m, uint32_t l, fl
             const uint32_t pi = frac >> 11;
             const float pf = float(frac & 2047u) * (1.0f / 2048.0f);
             const uint32_t base = kMaxEdge - l + pos;
-            const uint32_t fil = 2u * pi * m, phd = fil + m;
-            const uint32_t scd = fil + 64u * m, spd = scd + m;   // BSincPhaseCount*2*m further on
+            const uint32_t fil = pi * lay.bsincStride, phd = fil + m;
+            const uint32_t scd = fil + lay.scdBase, spd = scd + m;
             float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
-            if(kind == 3)
+            if constexpr(WIDE)
+            {
+                if(kind == 3)
+                {
+                    for(uint32_t j = 0; j < m; j += 4)
+                    {
+                        const float4 f = *reinterpret_cast<const float4*>(&filter[fil + j]);
+                        const float4 p = *reinterpret_cast<const float4*>(&filter[phd + j]);
+                        r0 = madd<EXACT>(r0, madd<EXACT>(f.x, pf, p.x), src[base + j + 0]);
+                        r1 = madd<EXACT>(r1, madd<EXACT>(f.y, pf, p.y), src[base + j + 1]);
+                        r2 = madd<EXACT>(r2, madd<EXACT>(f.z, pf, p.z), src[base + j + 2]);
+                        r3 = madd<EXACT>(r3, madd<EXACT>(f.w, pf, p.w), src[base + j + 3]);
+                    }
+                }
+                else
+                {
+                    for(uint32_t j = 0; j < m; j += 4)
+                    {
+                        const float4 f = *reinterpret_cast<const float4*>(&filter[fil + j]);
+                        const float4 p = *reinterpret_cast<const float4*>(&filter[phd + j]);
+                        const float4 sc = *reinterpret_cast<const float4*>(&filter[scd + j]);
+                        const float4 sp = *reinterpret_cast<const float4*>(&filter[spd + j]);
+                        r0 = madd<EXACT>(r0, madd<EXACT>(madd<EXACT>(f.x, sf, sc.x), pf, madd<EXACT>(p.x, sf, sp.x)), src[base + j + 0]);
+                        r1 = madd<EXACT>(r1, madd<EXACT>(madd<EXACT>(f.y, sf, sc.y), pf, madd<EXACT>(p.y, sf, sp.y)), src[base + j + 1]);
+                        r2 = madd<EXACT>(r2, madd<EXACT>(madd<EXACT>(f.z, sf, sc.z), pf, madd<EXACT>(p.z, sf, sp.z)), src[base + j + 2]);
+                        r3 = madd<EXACT>(r3, madd<EXACT>(madd<EXACT>(f.w, sf, sc.w), pf, madd<EXACT>(p.w, sf, sp.w)), src[base + j + 3]);
+                    }
+                }
+            }
+            else if(kind == 3)
             {
                 for(uint32_t j = 0; j < m; j += 4)
                 {

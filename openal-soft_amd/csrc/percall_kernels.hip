@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(256) ResampleKernel(ResampleSpec spec, const f
     uint32_t frac, uint32_t increment, float *__restrict__ dst, uint32_t n)
 {
     for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        dst[i] = ResampleAt<EXACT>(spec.kind, spec.m, spec.l, spec.sf, spec.filter, src, frac, increment, i, n);
+        dst[i] = ResampleAt<EXACT>(spec.kind, spec.m, spec.l, spec.sf, spec.filter, ReferenceTabLayout(spec.m), src, frac, increment, i, n);
 }
 
 __global__ void __launch_bounds__(256) MixKernel(const float *__restrict__ in, uint32_t n, float *__restrict__ out,

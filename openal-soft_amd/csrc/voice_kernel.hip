@@ -28,6 +28,7 @@ constexpr int kInLen = kHist + kLine;          // [History | samples], DoHrtfMix
 constexpr int kXPad = 128;                     // zero padding either side of the x' arrays
 constexpr int kXLen = kXPad + kLine + kXPad;
 constexpr int kXOldLen = kXPad + 256;         // old-filter fade: <= 64 inputs, frames < 256
+constexpr int kTabFloats = 3328;              // fast bsinc up to m=48, full bsinc up to m=24, cubic
 
 // ---- SampleInfo<T>::to_float, core/fmt_traits.h:91-139 (+ the mu-law/A-law tables :12-80 in
 // closed form) ----
@@ -127,7 +128,8 @@ struct alignas(16) SharedMem {
     float filt[kWaves][kInLen];                // filter outputs, one per concurrently running IIR
     float xl[kXLen], xr[kXLen];                // x'_ear[i] = In[64-delay+i]*g(i), zero padded
     float xol[kXOldLen], xor_[kXOldLen];       // old-filter fade-out inputs
-    float stage[(kLine + kHrirLen) * 2];       // end-of-kernel accumulator exchange
+    float tab[kTabFloats];                     // resampler coefficient rows (padded stride)
+    float coT[kHrirLen * 2], coO[kHrirLen * 2];// this voice's Hrtf.Target / Hrtf.Old coefficients
     float gCur[7][32], gTgt[7][32];            // Gains.Current/Target snapshot: [direct | send i][line]
     int32_t sendSlot[8];
     int32_t best;
@@ -239,23 +241,64 @@ void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev 
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// ---- resampler coefficient rows staged in LDS ------------------------------------------------
+// bsinc: phase row pi = [fil(m) | phd(m)] at pi*(2m+4); for the scale-interpolating kernel the
+// [scd(m) | spd(m)] rows follow 32 rows later.  The +4 keeps rows 16-byte aligned for float4
+// reads and spreads consecutive rows over different LDS bank groups.  cubic: 32 rows of 12.
+__device__ __forceinline__ bool TableFitsLds(int kind, uint32_t m)
+{
+    if(kind == 2) return true;
+    if(kind == 3) return 32u * (2u * m + 4u) <= uint32_t(kTabFloats);
+    if(kind == 4) return 64u * (2u * m + 4u) <= uint32_t(kTabFloats);
+    return false;
+}
+
+__device__ __forceinline__ TabLayout LdsTabLayout(uint32_t m) { return TabLayout{2u * m + 4u, 32u * (2u * m + 4u), 12u}; }
+
+__device__ __forceinline__ void StageTable(SharedMem &sm, const float *__restrict__ filter, int kind, uint32_t m)
+{
+    const uint32_t t = threadIdx.x;
+    if(kind == 2)
+    {
+        for(uint32_t k = t; k < 256u; k += kThreads) sm.tab[(k >> 3) * 12u + (k & 7u)] = filter[k];
+    }
+    else
+    {
+        const uint32_t row = 2u * m, stride = row + 4u;
+        const uint32_t blocks = kind == 4 ? 2u : 1u;
+        for(uint32_t b = 0; b < blocks; ++b)
+            for(uint32_t k = t; k < 32u * row; k += kThreads)
+                sm.tab[b * 32u * stride + (k / row) * stride + (k % row)] = filter[b * 32u * row + k];
+    }
+}
+
 // LoadResampledSamples, core/voice.cpp:642-824, for one real channel of a static voice.
 // Produces samplesToLoad resampled samples at sm.in[kHist..]; updates prev[v] when Playing.
 template<bool EXACT>
 __device__ __forceinline__ void LoadResampled(SharedMem &sm, const DeviceLayout &L, uint32_t v, const VoiceCtl &ctl,
     bool playing, int32_t intPos, uint32_t fracPos, uint32_t increment, uint32_t samplesToLoad,
-    uint32_t samplesToMix, int32_t bufferItem, bool looping)
+    uint32_t samplesToMix, int32_t bufferItem, bool looping, uint32_t &stagedTable)
 {
     const uint32_t t = threadIdx.x;
     float *rdata = sm.rdata;
     float *srcBuffer = rdata + kMaxEdge;
     float *mixing = sm.in + kHist;
     if(t < kMaxPad) rdata[t] = L.prev[size_t{v} * kMaxPad + t];
-    __syncthreads();
     const float *filter = L.tables + ctl.rsFilterOffset;
     const int kind = ctl.rsKind;
     const uint32_t rsM = ctl.rsM, rsL = ctl.rsL;
     const float rsSf = ctl.rsSf;
+    const bool resamples = !(increment == kFracOne && fracPos == 0) || samplesToLoad > 1200u;
+    const bool useLds = kind >= 2 && TableFitsLds(kind, rsM);
+    // the staged slice is identified by (offset, kind); most voices of a group share it
+    const uint32_t tableKey = ctl.rsFilterOffset * 8u + uint32_t(kind);
+    if(useLds && resamples && stagedTable != tableKey)
+    {
+        __syncthreads();                 // previous voice may still be reading sm.tab
+        StageTable(sm, filter, kind, rsM);
+        stagedTable = tableKey;
+    }
+    __syncthreads();
 
     for(uint32_t loaded = 0; loaded < samplesToLoad;)
     {
@@ -318,10 +361,17 @@ __device__ __forceinline__ void LoadResampled(SharedMem &sm, const DeviceLayout 
         {
             for(uint32_t k = t; k < bdst; k += kThreads) mixing[loaded + k] = srcBuffer[k];
         }
+        else if(useLds)
+        {
+            const TabLayout lay = LdsTabLayout(rsM);
+            for(uint32_t k = t; k < bdst; k += kThreads)
+                mixing[loaded + k] = ResampleAt<EXACT, true>(kind, rsM, rsL, rsSf, sm.tab, lay, rdata, fracPos, increment, k, bdst);
+        }
         else
         {
+            const TabLayout lay = ReferenceTabLayout(rsM);
             for(uint32_t k = t; k < bdst; k += kThreads)
-                mixing[loaded + k] = ResampleAt<EXACT>(kind, rsM, rsL, rsSf, filter, rdata, fracPos, increment, k, bdst);
+                mixing[loaded + k] = ResampleAt<EXACT, false>(kind, rsM, rsL, rsSf, filter, lay, rdata, fracPos, increment, k, bdst);
         }
 
         // voice.cpp:772-785: history for the next update, taken at the end-of-mix position
@@ -354,36 +404,96 @@ __device__ __forceinline__ void LoadResampled(SharedMem &sm, const DeviceLayout 
     }
 }
 
+// ---- wave-parallel dual biquad (FAST, time-invariant coefficients) ---------------------------
+// The cascade is a linear system with state s = (z01, z02, z11, z12):  s' = A s + B x.
+// Lane L owns samples [L*seg, (L+1)*seg).  (1) every lane measures M = A^seg by running seg
+// zero-input steps from the four unit states; (2) runs its samples from a zero state to get the
+// forced response q_L; (3) the block-start states follow from the 64-step recurrence
+// S_{L+1} = M S_L + q_L; (4) each lane re-runs the true recurrence from S_L over its samples.
+// ~6*seg filter steps per lane instead of 1024 serial ones.  Rounding differs from the serial
+// loop only through the propagated start states (tolerance class of FAST mode).
+struct Dual4 { float a, b, c, d; };
+
+__device__ __forceinline__ float DualStep(Dual4 &s, float x, const BiquadState &f0, const BiquadState &f1)
+{
+    const float y0 = __builtin_fmaf(x, f0.b0, s.a);
+    s.a = __builtin_fmaf(x, f0.b1, __builtin_fmaf(-y0, f0.a1, s.b));
+    s.b = __builtin_fmaf(x, f0.b2, -y0 * f0.a2);
+    const float y1 = __builtin_fmaf(y0, f1.b0, s.c);
+    s.c = __builtin_fmaf(y0, f1.b1, __builtin_fmaf(-y1, f1.a1, s.d));
+    s.d = __builtin_fmaf(y0, f1.b2, -y1 * f1.a2);
+    return y1;
+}
+
+__device__ __forceinline__ void BiquadDualWave(BiquadState &f0, BiquadState &f1, const float *src, float *dst,
+    uint32_t n, uint32_t lane)
+{
+    const uint32_t seg = (n + 63u) / 64u;
+    const uint32_t begin = lane * seg;
+    const uint32_t end = (begin + seg < n) ? begin + seg : n;
+    // (1) M = A^seg, column by column
+    Dual4 m0{1, 0, 0, 0}, m1{0, 1, 0, 0}, m2{0, 0, 1, 0}, m3{0, 0, 0, 1};
+    for(uint32_t i = 0; i < seg; ++i)
+    {
+        DualStep(m0, 0.0f, f0, f1); DualStep(m1, 0.0f, f0, f1);
+        DualStep(m2, 0.0f, f0, f1); DualStep(m3, 0.0f, f0, f1);
+    }
+    // (2) forced response of this lane's block
+    Dual4 q{0, 0, 0, 0};
+    for(uint32_t i = begin; i < end; ++i) DualStep(q, src[i], f0, f1);
+    // (3) block-start states
+    Dual4 cur{f0.z1, f0.z2, f1.z1, f1.z2}, start = cur;
+    for(uint32_t L = 0; L < 64u; ++L)
+    {
+        if(lane == L) start = cur;
+        const float qa = __shfl(q.a, int(L)), qb = __shfl(q.b, int(L)), qc = __shfl(q.c, int(L)), qd = __shfl(q.d, int(L));
+        Dual4 nx;
+        nx.a = m0.a * cur.a + m1.a * cur.b + m2.a * cur.c + m3.a * cur.d + qa;
+        nx.b = m0.b * cur.a + m1.b * cur.b + m2.b * cur.c + m3.b * cur.d + qb;
+        nx.c = m0.c * cur.a + m1.c * cur.b + m2.c * cur.c + m3.c * cur.d + qc;
+        nx.d = m0.d * cur.a + m1.d * cur.b + m2.d * cur.c + m3.d * cur.d + qd;
+        cur = nx;
+    }
+    // (4) the real recurrence from the block-start state
+    for(uint32_t i = begin; i < end; ++i) dst[i] = DualStep(start, src[i], f0, f1);
+    // final state = state after the last sample, held by the lane that owns it
+    const int lastLane = int((n - 1u) / seg);
+    f0.z1 = __shfl(start.a, lastLane); f0.z2 = __shfl(start.b, lastLane);
+    f1.z1 = __shfl(start.c, lastLane); f1.z2 = __shfl(start.d, lastLane);
+}
+
 // Register-tiled dual-ear FIR (FAST): thread t owns output frames 4t..4t+3.  Per 8 taps it
-// needs x'[n0-j0-8 .. n0-j0+3] per ear = three aligned ds_read_b128, against 64 FMAs.
+// reads x'[n0-j0-8 .. n0-j0+3] per ear as three aligned ds_read_b128 and the 8x2 coefficients
+// as four broadcast ds_read_b128, against 64 FMAs.
 __device__ __forceinline__ void FirMain(float (&accL)[4], float (&accR)[4], const float *xl, const float *xr,
-    const float *__restrict__ coeffs, uint32_t irStride, uint32_t n0)
+    const float *coeffs, uint32_t irStride, uint32_t n0)
 {
     for(uint32_t j0 = 0; j0 < irStride; j0 += 8)
     {
         const float4 *pl = reinterpret_cast<const float4*>(xl + kXPad + n0 - j0 - 8);
         const float4 *pr = reinterpret_cast<const float4*>(xr + kXPad + n0 - j0 - 8);
+        const float4 *pc = reinterpret_cast<const float4*>(coeffs + j0 * 2);
         const float4 l0 = pl[0], l1 = pl[1], l2 = pl[2];
         const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2];
+        const float4 c0 = pc[0], c1 = pc[1], c2 = pc[2], c3 = pc[3];
         const float wl[12] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w};
         const float wr[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        const float cf[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
 #pragma unroll
         for(int jj = 0; jj < 8; ++jj)
         {
-            const float cl = coeffs[(j0 + jj) * 2 + 0];
-            const float cr = coeffs[(j0 + jj) * 2 + 1];
 #pragma unroll
             for(int r = 0; r < 4; ++r)
             {
-                accL[r] = __builtin_fmaf(cl, wl[8 + r - jj], accL[r]);
-                accR[r] = __builtin_fmaf(cr, wr[8 + r - jj], accR[r]);
+                accL[r] = __builtin_fmaf(cf[jj * 2 + 0], wl[8 + r - jj], accL[r]);
+                accR[r] = __builtin_fmaf(cf[jj * 2 + 1], wr[8 + r - jj], accR[r]);
             }
         }
     }
 }
 
-// one output frame, one ear, all taps (used for the 128 tail frames and the old-filter fade)
-__device__ __forceinline__ float FirOne(float acc, const float *x /* x'[frame] */, const float *__restrict__ coeffs,
+// one output frame, one ear, all taps (the 128 tail frames and the old-filter fade)
+__device__ __forceinline__ float FirOne(float acc, const float *x /* x'[frame] */, const float *coeffs,
     uint32_t irStride, uint32_t ear)
 {
     for(uint32_t j = 0; j < irStride; ++j)
@@ -439,6 +549,7 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
     for(uint32_t k = t; k < kXOldLen; k += kThreads) { sm.xol[k] = 0.0f; sm.xor_[k] = 0.0f; }
     __syncthreads();
 
+    uint32_t stagedTable = 0xffffffffu;
     const uint32_t vBegin = group * L.voicesPerGroup;
     const uint32_t vEnd = (vBegin + L.voicesPerGroup < L.numVoices) ? vBegin + L.voicesPerGroup : L.numVoices;
     for(uint32_t v = vBegin; v < vEnd; ++v)
@@ -463,9 +574,10 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
         }
         const uint32_t samplesToMix = samplesToDo;          // no delayed start (outPos = 0)
         const uint32_t N = samplesToMix;
+        const bool hasHrtf = (ctl.flags & kFlagHasHrtf) != 0;
 
-        // snapshot of this voice's gain pairs and send slots (read by every thread below while
-        // thread 0 writes the updated Gains.Current back to HBM)
+        // snapshot of this voice's gain pairs, send slots and HRIRs (read by every thread below
+        // while single threads write the updated state back to HBM)
         if(t < 32)
         {
             if(!L.hrtf && t < numDry)
@@ -473,28 +585,33 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
                 sm.gCur[0][t] = L.gainCur[size_t{v} * numDry + t];
                 sm.gTgt[0][t] = L.gainTgt[size_t{v} * numDry + t];
             }
-            if(t < 6) sm.sendSlot[t] = ctl.sendSlot[t];
+            if(t < 6) sm.sendSlot[t] = L.ctl[v].sendSlot[t];
         }
         for(uint32_t k = t; k < numSends * wetCh; k += kThreads)
         {
             sm.gCur[1 + k / wetCh][k % wetCh] = L.sendCur[size_t{v} * numSends * wetCh + k];
             sm.gTgt[1 + k / wetCh][k % wetCh] = L.sendTgt[size_t{v} * numSends * wetCh + k];
         }
+        if(hasHrtf && t < irStride * 2)
+        {
+            sm.coT[t] = L.hrtfTgt[size_t{v} * irStride * 2 + t];
+            sm.coO[t] = L.hrtfOld[size_t{v} * irStride * 2 + t];
+        }
 
-        LoadResampled<EXACT>(sm, L, v, ctl, playing, bufPosInt, bufPosFrac, increment, N, N, bufferItem, loopItem >= 0);
+        LoadResampled<EXACT>(sm, L, v, ctl, playing, bufPosInt, bufPosFrac, increment, N, N, bufferItem, loopItem >= 0,
+            stagedTable);
 
-        const bool hasHrtf = (ctl.flags & kFlagHasHrtf) != 0;
         const uint32_t counter = (ctl.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
 
-        // ---- DoFilters for the direct path and every send (voice.cpp:255-267,945-946,971-973):
-        // each active dual-biquad is a serial recurrence; run up to four at once on lane 0 of
-        // the four waves, each into its own LDS line.  Inactive filters are cleared.
-        // target index 0 = direct, 1+i = send i.
+        // ---- DoFilters for the direct path and every send (voice.cpp:255-267,945-946,971-973).
+        // Up to four filter targets at a time, one per wave, each into its own LDS line.
+        // FAST + settled coefficients: the wave-parallel block method; otherwise the serial
+        // recurrence on lane 0.  Inactive filters are cleared.  target 0 = direct, 1+i = send i.
         const uint32_t numTargets = 1 + numSends;
         for(uint32_t base = 0; base < numTargets; base += kWaves)
         {
             const uint32_t tg = base + wave;
-            if(tg < numTargets && lane == 0)
+            if(tg < numTargets)
             {
                 const bool isDirect = tg == 0;
                 const uint32_t si = tg - 1;
@@ -505,9 +622,18 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
                 if(used)
                 {
                     BiquadState f0 = slots[0].f, f1 = slots[1].f;
-                    if(active) BiquadDualInterp(f0, f1, sm.in + kHist, sm.filt[wave] + kHist, N);
-                    else { BiquadClear(f0); BiquadClear(f1); }
-                    slots[0].f = f0; slots[1].f = f1;
+                    const bool settled = f0.counter <= 0 && f1.counter <= 0;
+                    if(active && !EXACT && settled)
+                    {
+                        BiquadDualWave(f0, f1, sm.in + kHist, sm.filt[wave] + kHist, N, lane);
+                        if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
+                    }
+                    else if(lane == 0)
+                    {
+                        if(active) BiquadDualInterp(f0, f1, sm.in + kHist, sm.filt[wave] + kHist, N);
+                        else { BiquadClear(f0); BiquadClear(f1); }
+                        slots[0].f = f0; slots[1].f = f1;
+                    }
                 }
             }
             __syncthreads();
@@ -551,8 +677,8 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
                     const bool newOn = fademix && newStep * float(fademix) > kGainSilence;
                     const uint32_t odL = ctl.hrtfOldDelay[0], odR = ctl.hrtfOldDelay[1];
                     const uint32_t dL = ctl.hrtfTgtDelay[0], dR = ctl.hrtfTgtDelay[1];
-                    const float *oldCo = L.hrtfOld + size_t{v} * irStride * 2;
-                    const float *tgtCo = L.hrtfTgt + size_t{v} * irStride * 2;
+                    const float *oldCo = sm.coO;
+                    const float *tgtCo = sm.coT;
 
                     if constexpr(EXACT)
                     {
@@ -611,9 +737,8 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
                     }
                     __syncthreads();
                     // voice.cpp:1094-1101 / :869-873,900: Old <- Target, Old.Gain <- reached gain
-                    if(counter == 0 || fademix)
-                        for(uint32_t k = t; k < irStride * 2; k += kThreads)
-                            L.hrtfOld[size_t{v} * irStride * 2 + k] = tgtCo[k];
+                    if((counter == 0 || fademix) && t < irStride * 2)
+                        L.hrtfOld[size_t{v} * irStride * 2 + t] = tgtCo[t];
                     if(t == 0)
                     {
                         VoiceCtl &c = L.ctl[v];
@@ -726,19 +851,19 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
         }
         else
         {
+            float *stage = &sm.filt[0][0];          // the filter lines are dead by now
             __syncthreads();
 #pragma unroll
-            for(int r = 0; r < 4; ++r) { sm.stage[(4 * t + r) * 2] = hL[r]; sm.stage[(4 * t + r) * 2 + 1] = hR[r]; }
-            sm.stage[(kLine + (t & 127)) * 2 + (t >> 7)] = hTail;
+            for(int r = 0; r < 4; ++r) { stage[(4 * t + r) * 2] = hL[r]; stage[(4 * t + r) * 2 + 1] = hR[r]; }
+            stage[(kLine + (t & 127)) * 2 + (t >> 7)] = hTail;
             __syncthreads();
-            sm.stage[(t & 127) * 2 + (t >> 7)] += hOld0;
-            sm.stage[(128 + (t & 127)) * 2 + (t >> 7)] += hOld1;
+            stage[(t & 127) * 2 + (t >> 7)] += hOld0;
+            stage[(128 + (t & 127)) * 2 + (t >> 7)] += hOld1;
             __syncthreads();
-            for(uint32_t k = t; k < (kLine + kHrirLen) * 2; k += kThreads) ph[k] = sm.stage[k];
+            for(uint32_t k = t; k < (kLine + kHrirLen) * 2; k += kThreads) ph[k] = stage[k];
         }
     }
 }
-
 template<bool EXACT, int LINES>
 hipError_t LaunchVoiceMixT(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool carry)
 {
@@ -747,35 +872,65 @@ hipError_t LaunchVoiceMixT(hipStream_t s, const DeviceLayout &L, uint32_t sample
     return hipGetLastError();
 }
 
-// sums the per-group partials in group order; lines without partials (HRTF context: dry/real)
-// are zero-filled (alc/alu.cpp:2417, :2196-2198)
-__global__ void __launch_bounds__(256) BusReduceKernel(DeviceLayout L, uint32_t samplesToDo)
+// Sums the per-group partials into the bus block.  One 1024-thread workgroup per 64 consecutive
+// bus floats: wave w adds its contiguous slice of groups in group order (coalesced 256-byte
+// rows, 8 loads in flight), then the 16 slice sums are added in slice order -- a fixed
+// summation tree, so the result is deterministic.  Lines no voice mixes into (HRTF context:
+// the dry/real lines) are zero-filled, which is the caller-side clear of alc/alu.cpp:2417 and
+// :2196-2198.
+constexpr int kReduceWaves = 16;
+__global__ void __launch_bounds__(kReduceWaves * 64) BusReduceKernel(DeviceLayout L)
 {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float slice[kReduceWaves][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t idx = blockIdx.x * 64u + lane;
     const uint32_t dryLines = L.numDry + L.numReal;
     const uint32_t wetLines = L.numSlots * L.wetChannels;
     const uint32_t lineFloats = (dryLines + wetLines) * kLine;
+    const uint32_t total = lineFloats + (kLine + kHrirLen) * 2;
+
+    const float *src = nullptr;
+    size_t stride = 0;
     if(idx < lineFloats)
     {
         const uint32_t line = idx / kLine, p = idx % kLine;
-        int32_t src = -1;
-        if(line < dryLines) { if(!L.hrtf && line < L.numDry) src = int32_t(line); }
-        else src = int32_t((L.hrtf ? 0u : L.numDry) + (line - dryLines));
-        float sum = 0.0f;
-        if(src >= 0)
-            for(uint32_t g = 0; g < L.numGroups; ++g)
-                sum = sum + L.partLines[(size_t{g} * L.mixLines + uint32_t(src)) * kLine + p];
-        L.bus[idx] = sum;
+        int32_t from = -1;
+        if(line < dryLines) { if(!L.hrtf && line < L.numDry) from = int32_t(line); }
+        else from = int32_t((L.hrtf ? 0u : L.numDry) + (line - dryLines));
+        if(from >= 0) { src = L.partLines + size_t{uint32_t(from)} * kLine + p; stride = size_t{L.mixLines} * kLine; }
     }
-    else if(L.hrtf && idx < lineFloats + (kLine + kHrirLen) * 2)
+    else if(L.hrtf && idx < total)
     {
-        const uint32_t k = idx - lineFloats;
-        float sum = 0.0f;
-        for(uint32_t g = 0; g < L.numGroups; ++g)
-            sum = sum + L.partHrtf[size_t{g} * (kLine + kHrirLen) * 2 + k];
-        L.bus[BusAccumOffset(L) + k] = sum;
+        src = L.partHrtf + (idx - lineFloats);
+        stride = size_t{kLine + kHrirLen} * 2;
     }
-    (void)samplesToDo;
+
+    const uint32_t per = (L.numGroups + kReduceWaves - 1) / kReduceWaves;
+    const uint32_t g0 = wave * per;
+    const uint32_t g1 = (g0 + per < L.numGroups) ? g0 + per : L.numGroups;
+    float sum = 0.0f;
+    if(src)
+    {
+        uint32_t g = g0;
+        for(; g + 8 <= g1; g += 8)
+        {
+            float v[8];
+#pragma unroll
+            for(int k = 0; k < 8; ++k) v[k] = src[size_t{g + uint32_t(k)} * stride];
+#pragma unroll
+            for(int k = 0; k < 8; ++k) sum = sum + v[k];
+        }
+        for(; g < g1; ++g) sum = sum + src[size_t{g} * stride];
+    }
+    slice[wave][lane] = sum;
+    __syncthreads();
+    if(wave == 0 && idx < total)
+    {
+        float t = slice[0][lane];
+#pragma unroll
+        for(int w = 1; w < kReduceWaves; ++w) t = t + slice[w][lane];
+        if(idx < lineFloats || L.hrtf) L.bus[idx] = t;
+    }
 }
 
 } // namespace
@@ -797,7 +952,8 @@ hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint
 void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo)
 {
     const uint32_t total = uint32_t(BusFloats(L));
-    hipLaunchKernelGGL(BusReduceKernel, dim3((total + 255u) / 256u), dim3(256), 0, s, L, samplesToDo);
+    (void)samplesToDo;
+    hipLaunchKernelGGL(BusReduceKernel, dim3((total + 63u) / 64u), dim3(kReduceWaves * 64), 0, s, L);
 }
 
 } // namespace oalgpu
