@@ -113,6 +113,7 @@ struct oalgpu_context {
     HrtfData hrtfHost;
     bool hrtfLoaded{false};
     bool carryAccum{true};
+    bool useWave{false};                   // FAST HRTF contexts without sends: voice_wave.hip
 
     DevBuf<float> tables;
     DevBuf<BufferItem> buffers;
@@ -381,6 +382,16 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     }
     L.voicesPerGroup = vpg;
     L.numGroups = std::max<uint32_t>(1u, (desc->max_voices + vpg - 1u) / vpg);
+    L.waveVoices = 0;
+    c->useWave = WaveKernelApplies(c->exact, L);
+    if(c->useWave)
+    {
+        // one wavefront per voice, 4 wavefronts per workgroup, two workgroups per CU: aim for
+        // ~512 workgroups (2048 wavefronts); voices_per_group is then voices per WORKGROUP
+        L.waveVoices = desc->voices_per_group ? std::max<uint32_t>(1u, (desc->voices_per_group + 3u) / 4u)
+            : std::max<uint32_t>(1u, (desc->max_voices + 2047u) / 2048u);
+        L.numGroups = std::max<uint32_t>(1u, WaveKernelGroups(L));
+    }
 
     const TableBlob &blob = Blob();
     HIP_TRY(c->tables.alloc(blob.data.size())); HIP_TRY(c->tables.upload(blob.data.data(), blob.data.size()));
@@ -443,7 +454,7 @@ int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
 
     DeviceLayout &L = c->L;
     L.irSize = h.irSize;
-    L.irStride = (h.irSize + 7u) & ~7u;
+    L.irStride = (h.irSize + 15u) & ~15u;
     if(L.hrtf)
     {
         const size_t n = size_t{L.numVoices} * L.irStride * 2;
@@ -671,9 +682,11 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
-    HIP_TRY(LaunchVoiceMix(c->stream, c->exact, c->L, samples_to_do, c->carryAccum));
+    if(c->useWave) HIP_TRY(LaunchVoiceWave(c->stream, c->L, samples_to_do));
+    else HIP_TRY(LaunchVoiceMix(c->stream, c->exact, c->L, samples_to_do, c->carryAccum));
     if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
-    LaunchBusReduce(c->stream, c->L, samples_to_do);
+    // the wavefront kernel leaves the carried HRTF accumulator tail to the reduction
+    LaunchBusReduce(c->stream, c->L, samples_to_do, c->useWave && c->carryAccum);
     HIP_TRY(hipGetLastError());
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
     return OALGPU_OK;

@@ -6,6 +6,7 @@
 #include "dev_hrtf.hpp"
 #include "dev_mix.hpp"
 #include "dev_resample.hpp"
+#include "dev_voice.hpp"
 
 namespace oalgpu {
 
@@ -25,6 +26,7 @@ enum VoiceFlagBits : uint32_t {
     kFlagFading = 1u << 0,          // VoiceFlag::IsFading
     kFlagHasHrtf = 1u << 1,         // VoiceFlag::HasHrtf
     kFlagDirectFilter = 1u << 2,    // mDirect.FilterActive
+    kFlagHrtfDirty = 1u << 3,       // Hrtf.Target replaced since the last mix (Old != Target)
     kFlagSendFilterShift = 8        // bits 8..13: mSend[i].FilterActive
 };
 
@@ -49,13 +51,6 @@ struct alignas(16) VoiceCtl {
 };
 static_assert(sizeof(VoiceCtl) == 128, "VoiceCtl is one 128-byte line");
 
-struct alignas(16) BufferItem {     // VoiceBufferItem, core/voice.h:84-98
-    const void *data;
-    int32_t fmt;
-    uint32_t frameStep, sampleLen, loopStart, loopEnd;
-    uint32_t pad;
-};
-
 // a BiquadState padded to 64 bytes so each filter is one aligned segment
 struct alignas(16) BiquadSlot { BiquadState f; uint32_t pad[3]; };
 static_assert(sizeof(BiquadSlot) == 64, "BiquadSlot");
@@ -65,6 +60,7 @@ struct DeviceLayout {
     uint32_t numVoices, numDry, numReal, numSends, numSlots, wetChannels;
     uint32_t hrtf, irSize, irStride;       // irStride: taps stored per voice filter (irSize rounded up to 8)
     uint32_t voicesPerGroup, numGroups;
+    uint32_t waveVoices;                    // voice_wave.hip: voices per wavefront (0 = not used)
     uint32_t mixLines;                      // lines accumulated by the voice kernel
     // tables + buffers
     const float *tables;                    // [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
@@ -130,6 +126,11 @@ void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev 
     uint32_t count);
 // returns hipSuccess or the launch error
 hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum);
-void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo);
+void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry);
+
+// ---- launchers (voice_wave.hip): the FAST HRTF hot path, one wavefront per voice ----
+bool WaveKernelApplies(bool exact, const DeviceLayout &L);
+uint32_t WaveKernelGroups(const DeviceLayout &L);
+hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo);
 
 } // namespace oalgpu

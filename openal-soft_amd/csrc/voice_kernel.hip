@@ -30,98 +30,6 @@ constexpr int kXLen = kXPad + kLine + kXPad;
 constexpr int kXOldLen = kXPad + 256;         // old-filter fade: <= 64 inputs, frames < 256
 constexpr int kTabFloats = 3328;              // fast bsinc up to m=48, full bsinc up to m=24, cubic
 
-// ---- SampleInfo<T>::to_float, core/fmt_traits.h:91-139 (+ the mu-law/A-law tables :12-80 in
-// closed form) ----
-__device__ __forceinline__ float DecodeMulaw(uint32_t u)
-{
-    u = ~u & 0xffu;
-    const int exponent = (u >> 4) & 7, mantissa = u & 15;
-    const int seg = ((33 << exponent) - 33) << 2;             // 0,132,396,924,...
-    const int mag = seg + (mantissa << (exponent + 3));
-    return float((u & 0x80u) ? -mag : mag) * (1.0f / 32768.0f);
-}
-__device__ __forceinline__ float DecodeAlaw(uint32_t a)
-{
-    a = (a ^ 0x55u) & 0xffu;
-    const int exponent = (a >> 4) & 7, mantissa = a & 15;
-    const int mag = (exponent == 0) ? ((mantissa << 4) + 8) : (((mantissa << 4) + 0x108) << (exponent - 1));
-    return float((a & 0x80u) ? mag : -mag) * (1.0f / 32768.0f);
-}
-
-template<int FMT>
-__device__ __forceinline__ float LoadSample(const void *data, size_t idx)
-{
-    if constexpr(FMT == OALGPU_FMT_UBYTE) return (float(static_cast<const uint8_t*>(data)[idx]) - 128.0f) * (1.0f / 128.0f);
-    else if constexpr(FMT == OALGPU_FMT_SHORT) return float(static_cast<const int16_t*>(data)[idx]) * (1.0f / 32768.0f);
-    else if constexpr(FMT == OALGPU_FMT_INT) return float(static_cast<const int32_t*>(data)[idx]) * (1.0f / 2147483648.0f);
-    else if constexpr(FMT == OALGPU_FMT_FLOAT) return static_cast<const float*>(data)[idx];
-    else if constexpr(FMT == OALGPU_FMT_DOUBLE) return float(static_cast<const double*>(data)[idx]);
-    else if constexpr(FMT == OALGPU_FMT_MULAW) return DecodeMulaw(static_cast<const uint8_t*>(data)[idx]);
-    else return DecodeAlaw(static_cast<const uint8_t*>(data)[idx]);
-}
-
-// LoadBufferStatic, core/voice.cpp:500-544: element k of the `count` source samples starting
-// at buffer position dataPos (loop wrap by modulo; past-the-end holds the last sample).
-template<int FMT>
-__device__ __forceinline__ void FillFromStatic(float *dst, uint32_t count, const BufferItem &b, bool looping,
-    uint32_t dataPos)
-{
-    const uint32_t fs = b.frameStep;
-    if(!looping)
-    {
-        const bool any = b.sampleLen > dataPos;
-        const uint32_t avail = any ? b.sampleLen - dataPos : 0u;
-        const float last = any ? LoadSample<FMT>(b.data, size_t{b.sampleLen - 1u} * fs) : 0.0f;
-        for(uint32_t k = threadIdx.x; k < count; k += kThreads)
-            dst[k] = (k < avail) ? LoadSample<FMT>(b.data, size_t{dataPos + k} * fs) : last;
-    }
-    else
-    {
-        const uint32_t ls = b.loopStart, le = b.loopEnd, size = le - ls;
-        const uint32_t intPos = (dataPos < le) ? dataPos : ((dataPos - ls) % size) + ls;
-        const uint32_t first = le - intPos;
-        for(uint32_t k = threadIdx.x; k < count; k += kThreads)
-        {
-            const uint32_t idx = (k < first) ? intPos + k : ls + ((k - first) % size);
-            dst[k] = LoadSample<FMT>(b.data, size_t{idx} * fs);
-        }
-    }
-}
-
-__device__ __forceinline__ void FillFromBuffer(float *dst, uint32_t count, const BufferItem &b, bool looping,
-    uint32_t dataPos)
-{
-    switch(b.fmt)
-    {
-    case OALGPU_FMT_UBYTE: FillFromStatic<OALGPU_FMT_UBYTE>(dst, count, b, looping, dataPos); break;
-    case OALGPU_FMT_SHORT: FillFromStatic<OALGPU_FMT_SHORT>(dst, count, b, looping, dataPos); break;
-    case OALGPU_FMT_INT: FillFromStatic<OALGPU_FMT_INT>(dst, count, b, looping, dataPos); break;
-    case OALGPU_FMT_FLOAT: FillFromStatic<OALGPU_FMT_FLOAT>(dst, count, b, looping, dataPos); break;
-    case OALGPU_FMT_DOUBLE: FillFromStatic<OALGPU_FMT_DOUBLE>(dst, count, b, looping, dataPos); break;
-    case OALGPU_FMT_MULAW: FillFromStatic<OALGPU_FMT_MULAW>(dst, count, b, looping, dataPos); break;
-    default: FillFromStatic<OALGPU_FMT_ALAW>(dst, count, b, looping, dataPos); break;
-    }
-}
-
-// CalculateBufferSize, core/voice.cpp:600-640 (integer, bit-exact).
-__device__ __forceinline__ void CalcBufferSize(uint32_t fracPos, uint32_t increment, uint32_t dstRemaining,
-    uint32_t &dst, uint32_t &src)
-{
-    constexpr uint32_t srcMax = kResampleDataSize - kMaxEdge;
-    const uint32_t ext = increment <= kFracOne ? 1u : 0u;
-    const uint64_t srcSize = ((uint64_t{dstRemaining - ext} * increment + fracPos) >> kFracBits) + ext + kMaxEdge;
-    if(srcSize <= srcMax) { dst = dstRemaining; src = uint32_t(srcSize); return; }
-    const uint64_t dstSize = ((uint64_t{srcMax - kMaxEdge} << kFracBits) - fracPos) / increment;
-    if(dstSize < dstRemaining) { dst = uint32_t(dstSize) & ~3u; src = srcMax; return; }
-    dst = dstRemaining; src = srcMax;
-}
-
-__device__ __forceinline__ int32_t AddSat(int32_t a, int32_t b)
-{
-    const int64_t r = int64_t{a} + b;
-    return r > 2147483647ll ? 2147483647 : (r < -2147483648ll ? int32_t(-2147483647 - 1) : int32_t(r));
-}
-
 struct alignas(16) SharedMem {
     float rdata[kResampleDataSize + 8];        // DeviceBase::mResampleData
     float in[kInLen];                          // [hrtf history | resampled samples]
@@ -152,7 +60,8 @@ __global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfSto
         ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
         ctl.rsFilterOffset = r.rsFilterOffset;
         const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf);
-        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf)) | (L.hrtf ? kFlagHasHrtf : 0u);
+        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty))
+            | (L.hrtf ? (kFlagHasHrtf | kFlagHrtfDirty) : 0u);
         for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
         BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
         BiquadSetTarget(L.dfilt[size_t{v} * 2 + 1].f, r.dirHp);
@@ -352,7 +261,7 @@ __device__ __forceinline__ void LoadResampled(SharedMem &sm, const DeviceLayout 
         else
         {
             const uint32_t upos = intPos < 0 ? 0u : uint32_t(intPos);
-            FillFromBuffer(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos);
+            FillFromBuffer<kThreads>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos, t);
         }
         __syncthreads();
 
@@ -792,7 +701,7 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
         if(t == 0)
         {
             VoiceCtl &c = L.ctl[v];
-            c.flags = ctl.flags | kFlagFading;
+            c.flags = (ctl.flags | kFlagFading) & ~((counter == 0 || N) ? kFlagHrtfDirty : 0u);
             if(!playing) c.playState = OALGPU_VOICE_STOPPED;
             else
             {
@@ -879,7 +788,7 @@ hipError_t LaunchVoiceMixT(hipStream_t s, const DeviceLayout &L, uint32_t sample
 // the dry/real lines) are zero-filled, which is the caller-side clear of alc/alu.cpp:2417 and
 // :2196-2198.
 constexpr int kReduceWaves = 16;
-__global__ void __launch_bounds__(kReduceWaves * 64) BusReduceKernel(DeviceLayout L)
+__global__ void __launch_bounds__(kReduceWaves * 64) BusReduceKernel(DeviceLayout L, uint32_t addCarry)
 {
     __shared__ float slice[kReduceWaves][64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -926,7 +835,8 @@ __global__ void __launch_bounds__(kReduceWaves * 64) BusReduceKernel(DeviceLayou
     __syncthreads();
     if(wave == 0 && idx < total)
     {
-        float t = slice[0][lane];
+        float t = (addCarry && idx >= lineFloats) ? L.bus[idx] : 0.0f;
+        t = t + slice[0][lane];
 #pragma unroll
         for(int w = 1; w < kReduceWaves; ++w) t = t + slice[w][lane];
         if(idx < lineFloats || L.hrtf) L.bus[idx] = t;
@@ -949,11 +859,11 @@ hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint
     return LaunchVoiceMixT<false, 32>(s, L, samplesToDo, carryAccum);
 }
 
-void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo)
+void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry)
 {
     const uint32_t total = uint32_t(BusFloats(L));
     (void)samplesToDo;
-    hipLaunchKernelGGL(BusReduceKernel, dim3((total + 63u) / 64u), dim3(kReduceWaves * 64), 0, s, L);
+    hipLaunchKernelGGL(BusReduceKernel, dim3((total + 63u) / 64u), dim3(kReduceWaves * 64), 0, s, L, addCarry ? 1u : 0u);
 }
 
 } // namespace oalgpu
