@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -317,8 +318,12 @@ int oalgpu_mix_direct_hrtf(int device, int mode, float *left, float *right, cons
     HIP_TRY(dCo.alloc(nch * kHrirLen * 2)); HIP_TRY(dCo.upload(chan_coeffs, nch * kHrirLen * 2));
     HIP_TRY(dTemp.alloc(nch * kLine + accLen));
     HIP_TRY(dSp.alloc(nch)); HIP_TRY(dSp.upload(reinterpret_cast<const SplitterState*>(splitters), nch));
-    LaunchMixDirectHrtf(nullptr, mode == OALGPU_MATH_EXACT, dL.p, dR.p, dIn.p, uint32_t(nch), dAcc.p, dSp.p, dHf.p,
-        dCo.p, uint32_t(irsize), uint32_t(n), dTemp.p);
+    if(mode == OALGPU_MATH_EXACT)
+        LaunchMixDirectHrtf(nullptr, true, dL.p, dR.p, dIn.p, uint32_t(nch), dAcc.p, dSp.p, dHf.p, dCo.p,
+            uint32_t(irsize), uint32_t(n), dTemp.p);
+    else
+        LaunchPostDirectHrtfFast(nullptr, dL.p, dR.p, dIn.p, uint32_t(nch), dAcc.p, dSp.p, dHf.p, dCo.p,
+            uint32_t(irsize), uint32_t(n));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(dL.download(left, kLine)); HIP_TRY(dR.download(right, kLine));
@@ -383,6 +388,8 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.voicesPerGroup = vpg;
     L.numGroups = std::max<uint32_t>(1u, (desc->max_voices + vpg - 1u) / vpg);
     L.waveVoices = 0;
+    L.ablate = 0;
+    if(const char *ab = std::getenv("OALGPU_ABLATE")) L.ablate = uint32_t(std::strtoul(ab, nullptr, 0));
     c->useWave = WaveKernelApplies(c->exact, L);
     if(c->useWave)
     {
@@ -701,8 +708,12 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
     if(L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
     float *left = L.bus + size_t{L.numDry} * kLine;
     float *right = left + kLine;
-    LaunchMixDirectHrtf(c->stream, c->exact, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
-        c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
+    if(c->exact)
+        LaunchMixDirectHrtf(c->stream, true, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
+            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
+    else
+        LaunchPostDirectHrtfFast(c->stream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
+            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do);
     HIP_TRY(hipGetLastError());
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
     return OALGPU_OK;

@@ -1,0 +1,99 @@
+// Helpers of the wavefront-granular kernels (voice_wave.hip, post_wave.hip): packed-fp32 types,
+// scalar-cache (constant address space) views of read-only HBM data, and the compiler-level
+// fence used when the lanes of ONE wavefront exchange data through LDS.
+#pragma once
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace oalgpu {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef const f2 __attribute__((address_space(4))) cf2;        // scalar-cache (constant) loads
+typedef const uint32_t __attribute__((address_space(4))) cu32;
+typedef float f16 __attribute__((ext_vector_type(16)));
+typedef const f16 __attribute__((address_space(4))) cf16;
+
+// The wavefront kernels issue their LDS reads as single ds_read_b64 (2 LDS cycles per wave
+// instruction, 256 B/clk).  Left to itself hipcc pairs them into ds_read2_b64, which the LDS
+// services at half that rate and with 32-bank instead of 64-bank addressing -- measured on the
+// resampler rows: 16 instead of 4 cycles per pair, SQ_LDS_BANK_CONFLICT = 1536 cycles per voice.
+// The pairing is done by the SI load/store optimizer (disabled per kernel by this attribute;
+// device pass only, the host pass does not know the feature) and by the IR load/store
+// vectorizer (disabled for these translation units in the Makefile).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OALGPU_SINGLE_DS_OPS __attribute__((target("no-load-store-opt")))
+#else
+#define OALGPU_SINGLE_DS_OPS
+#endif
+
+__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
+
+// Lanes of a wavefront exchange data through LDS in program order (the LDS executes one wave's
+// operations in order); this only stops the COMPILER from moving memory operations across.
+__device__ __forceinline__ void WaveSync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef const u4 __attribute__((address_space(4))) cu4;
+
+__device__ __forceinline__ VoiceCtl LoadCtlScalar(const VoiceCtl *p)
+{
+    union { VoiceCtl c; u4 q[sizeof(VoiceCtl) / 16]; } u;
+    cu4 *src = (cu4*)(uintptr_t)p;
+#pragma unroll
+    for(size_t k = 0; k < sizeof(VoiceCtl) / 16; ++k) u.q[k] = src[k];
+    return u.c;
+}
+
+
+// ---- dual-ear FIR, packed over the ears -------------------------------------------------------
+// acc[r] = (L,R) of output frame R*lane + r.  xw points at the x' entry of the lane's first
+// frame; co16[b] = taps 8b..8b+7 as (Coeffs[j][0], Coeffs[j][1]) pairs, one s_load_dwordx16
+// through the scalar cache each, fetched one block ahead of its use.  X is f2 (per-ear inputs,
+// MixHrtf) or float (same input for both ears, MixDirectHrtf).
+template<int R, int TAPS, typename X>
+__device__ __forceinline__ void FirMainPk(f2 (&acc)[R], const X *xw, cf16 *co16)
+{
+    static_assert(TAPS % 8 == 0, "taps come in blocks of 8");
+    X w[R + 3];
+#pragma unroll
+    for(int k = 0; k < R + 3; ++k) w[k] = xw[k - 3];
+    f16 cnext = co16[0];
+#pragma unroll
+    for(int b8 = 0; b8 < TAPS / 8; ++b8)
+    {
+        const f16 c16 = cnext;
+        if(b8 + 1 < TAPS / 8) cnext = co16[b8 + 1];
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
+        {
+            const int b = 2 * b8 + h;
+#pragma unroll
+            for(int jj = 0; jj < 4; ++jj)
+            {
+                const f2 c = {c16[(4 * h + jj) * 2], c16[(4 * h + jj) * 2 + 1]};
+#pragma unroll
+                for(int r = 0; r < R; ++r)
+                {
+                    if constexpr(sizeof(X) == sizeof(f2)) acc[r] = pkfma(c, w[r + 3 - jj], acc[r]);
+                    else acc[r] = pkfma(c, splat(w[r + 3 - jj]), acc[r]);
+                }
+            }
+            if(b + 1 < TAPS / 4)
+            {
+#pragma unroll
+                for(int k = R + 2; k >= 4; --k) w[k] = w[k - 4];
+#pragma unroll
+                for(int k = 0; k < 4; ++k) w[k] = xw[-4 * (b + 1) - 3 + k];
+            }
+        }
+    }
+}
+
+} // namespace oalgpu

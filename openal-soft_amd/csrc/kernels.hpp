@@ -61,6 +61,7 @@ struct DeviceLayout {
     uint32_t hrtf, irSize, irStride;       // irStride: taps stored per voice filter (irSize rounded up to 8)
     uint32_t voicesPerGroup, numGroups;
     uint32_t waveVoices;                    // voice_wave.hip: voices per wavefront (0 = not used)
+    uint32_t ablate;                        // profiling aid (env OALGPU_ABLATE): stages to skip, 0 in production
     uint32_t mixLines;                      // lines accumulated by the voice kernel
     // tables + buffers
     const float *tables;                    // [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
@@ -119,6 +120,10 @@ void LaunchMixDirectHrtf(hipStream_t s, bool exact, float *left, float *right, c
 void LaunchBiquadDual(hipStream_t s, BiquadState *f0, BiquadState *f1, const float *src, float *dst, uint32_t n);
 void LaunchGetCoeffs(hipStream_t s, const HrtfStoreDev &st, const float *dirs, uint32_t count, float *coeffs,
     uint32_t *delays);
+
+// ---- launcher (post_wave.hip): FAST MixDirectHrtf, one wavefront per dry channel ----
+void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, float *accum,
+    SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n);
 
 // ---- launchers (voice_kernel.hip) ----
 void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);

@@ -29,43 +29,65 @@
 // the tolerance stated in DESIGN.md; all integer state (positions, loop wrap, play state,
 // delays, fade counters) is bit-exact.  EXACT mode and every other configuration (sends, non-HRTF
 // buses) run voice_kernel.hip.
-#include "kernels.hpp"
+#include "dev_wave.hpp"
 
 #pragma clang fp contract(off)
 
 namespace oalgpu {
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef const f2 __attribute__((address_space(4))) cf2;        // scalar-cache (constant) loads
-typedef const uint32_t __attribute__((address_space(4))) cu32;
-
 constexpr int kWWaves = 4;                    // wavefronts (= concurrent voices) per workgroup
 constexpr int kWThreads = kWWaves * 64;
 constexpr int kTabPairs = 24;                 // staged resampler rows: up to 48 taps
 
-__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
+constexpr int kPre = 17;                      // prefetched source samples per lane (17*64 = 1088)
 
-// Lanes of a wavefront exchange data through LDS in program order (the LDS executes one wave's
-// operations in order); this only stops the COMPILER from moving memory operations across.
-__device__ __forceinline__ void WaveSync()
+// ---- scalar-cache views of the per-voice control block and the buffer table -------------------
+// VoiceCtl (kernels.hpp) in two pieces: the head (bytes 0..47: everything needed to locate and
+// resample the source) is fetched one voice AHEAD so that voice's source window can be
+// requested from HBM while the current voice is still in its FIR; the tail (bytes 64..95: HRTF
+// delays and gains) is fetched at the start of the voice and first needed after resampling.
+struct VoiceHead {
+    int32_t playState, position;
+    uint32_t positionFrac;
+    int32_t curBuffer, loopBuffer;
+    uint32_t step;
+    int32_t rsKind;
+    uint32_t rsM, rsL;
+    float rsSf;
+    uint32_t rsFilterOffset, flags;
+};
+static_assert(sizeof(VoiceHead) == 48 && offsetof(VoiceCtl, flags) == 44, "VoiceHead mirrors the first 48 bytes of VoiceCtl");
+static_assert(offsetof(VoiceCtl, hrtfOldDelay) == 72 && offsetof(VoiceCtl, hrtfTgtGain) == 92, "VoiceCtl tail layout");
+
+__device__ __forceinline__ VoiceHead LoadHeadScalar(const VoiceCtl *p)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    union { VoiceHead h; u4 q[3]; } u;
+    cu4 *src = (cu4*)(uintptr_t)p;
+    u.q[0] = src[0]; u.q[1] = src[1]; u.q[2] = src[2];
+    return u.h;
 }
 
-typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-typedef const u4 __attribute__((address_space(4))) cu4;
-
-__device__ __forceinline__ VoiceCtl LoadCtlScalar(const VoiceCtl *p)
+struct VoiceTail { uint32_t oldDelay[2]; float oldGain; uint32_t tgtDelay[2]; float tgtGain; };
+__device__ __forceinline__ VoiceTail LoadTailScalar(const VoiceCtl *p)
 {
-    union { VoiceCtl c; u4 q[sizeof(VoiceCtl) / 16]; } u;
     cu4 *src = (cu4*)(uintptr_t)p;
-#pragma unroll
-    for(size_t k = 0; k < sizeof(VoiceCtl) / 16; ++k) u.q[k] = src[k];
-    return u.c;
+    const u4 a = src[4], b = src[5];          // bytes 64..95
+    VoiceTail t;
+    t.oldDelay[0] = a.z; t.oldDelay[1] = a.w;
+    t.oldGain = __builtin_bit_cast(float, uint32_t(b.x));
+    t.tgtDelay[0] = b.y; t.tgtDelay[1] = b.z;
+    t.tgtGain = __builtin_bit_cast(float, uint32_t(b.w));
+    return t;
+}
+
+__device__ __forceinline__ BufferItem LoadBufferScalar(const BufferItem *p)
+{
+    static_assert(sizeof(BufferItem) == 32, "BufferItem is two 16-byte words");
+    union { BufferItem b; u4 q[2]; } u;
+    cu4 *src = (cu4*)(uintptr_t)p;
+    u.q[0] = src[0]; u.q[1] = src[1];
+    return u.b;
 }
 
 template<int R, int TAPS>
@@ -80,6 +102,7 @@ struct WaveLds {
     float in[kHist + kLine];                            // [Hrtf.History | resampled, filtered samples]
     f2 cold[TAPS + 128];                                // cold[k] = Hrtf.Old.Coeffs[k - 64], zero padded
     f2 xo[64];                                          // old-filter fade-out inputs (i < 64), both ears
+    float fst[32];                                      // the voice's two BiquadSlots (2 x 16 dwords)
     int32_t best;
     uint32_t pad[3];
 };
@@ -93,66 +116,183 @@ struct WgLds {
     uint32_t pad;
 };
 
-// ---- resampler, staged rows -----------------------------------------------------------------
-// One output sample of Resample_FastBSinc / Resample_Cubic (core/mixer/mixer_c.cpp:52-83,
-// the SSE variants mixer_sse.cpp:199-329 compute the same terms): sum_j (fil[j] + pf*phd[j]) *
-// src[pos + j - l], taps processed two at a time.
-template<int M>
-__device__ __forceinline__ float ResampleStaged(const f2 *tabF, const f2 *tabP, const float *rd, uint32_t l,
-    uint32_t frac0, uint32_t increment, uint32_t i)
+// ---- source window ----------------------------------------------------------------------------
+// The first chunk of LoadBufferStatic (core/voice.cpp:500-544) as a register gather: lane l
+// requests elements l, l+64, ... of the `count` source samples starting at buffer position
+// dataPos (loop wrap; past-the-end holds the last sample).  The loads are issued here and only
+// waited for when the values are stored to LDS, one voice later.
+template<int FMT>
+__device__ __forceinline__ void GatherStaticT(float (&pre)[kPre], uint32_t count, const BufferItem &b, bool looping,
+    uint32_t dataPos, uint32_t lane)
 {
-    const uint32_t t = frac0 + i * increment;
-    const uint32_t pos = t >> kFracBits;
-    const uint32_t frac = t & kFracMask;
-    const uint32_t pi = frac >> 11;
-    const f2 pf = splat(float(frac & 2047u) * (1.0f / 2048.0f));
-    const float *s = rd + (kMaxEdge - l + pos);
-    f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
-#pragma unroll
-    for(int p = 0; p < M / 2; p += 2)
+    const uint32_t fs = b.frameStep;
+    if(!looping)
     {
-        const f2 c0 = pkfma(pf, tabP[p * 32 + pi], tabF[p * 32 + pi]);
-        const f2 s0 = {s[2 * p], s[2 * p + 1]};
-        r0 = pkfma(c0, s0, r0);
-        const f2 c1 = pkfma(pf, tabP[(p + 1) * 32 + pi], tabF[(p + 1) * 32 + pi]);
-        const f2 s1 = {s[2 * p + 2], s[2 * p + 3]};
-        r1 = pkfma(c1, s1, r1);
+        const bool any = b.sampleLen > dataPos;
+        const uint32_t avail = any ? b.sampleLen - dataPos : 0u;
+        const float last = any ? LoadSample<FMT>(b.data, size_t{b.sampleLen - 1u} * fs) : 0.0f;
+#pragma unroll
+        for(int i = 0; i < kPre; ++i)
+        {
+            const uint32_t k = lane + 64u * uint32_t(i);
+            float x = 0.0f;
+            if(k < count) x = (k < avail) ? LoadSample<FMT>(b.data, size_t{dataPos + k} * fs) : last;
+            pre[i] = x;
+        }
     }
-    return (r0.x + r0.y) + (r1.x + r1.y);
+    else
+    {   // GatherWraps() said: at most one wrap inside the window, no division per element
+        const uint32_t ls = b.loopStart, le = b.loopEnd;
+        const uint32_t first = le - dataPos;
+#pragma unroll
+        for(int i = 0; i < kPre; ++i)
+        {
+            const uint32_t k = lane + 64u * uint32_t(i);
+            const uint32_t idx = (k < first) ? dataPos + k : ls + (k - first);
+            pre[i] = (k < count) ? LoadSample<FMT>(b.data, size_t{idx} * fs) : 0.0f;
+        }
+    }
+}
+
+// The register gather covers the formats and loop shapes that matter for throughput; anything
+// else is filled by the generic LoadBufferStatic loop (FillFromBuffer) when the voice starts.
+__device__ __forceinline__ bool GatherCovers(uint32_t count, const BufferItem &b, bool looping, uint32_t dataPos)
+{
+    if(b.fmt != OALGPU_FMT_FLOAT && b.fmt != OALGPU_FMT_SHORT) return false;
+    if(!looping) return true;
+    return dataPos < b.loopEnd && count <= (b.loopEnd - dataPos) + (b.loopEnd - b.loopStart);
+}
+
+__device__ __forceinline__ void GatherStatic(float (&pre)[kPre], uint32_t count, const BufferItem &b, bool looping,
+    uint32_t dataPos, uint32_t lane)
+{
+    if(b.fmt == OALGPU_FMT_FLOAT) GatherStaticT<OALGPU_FMT_FLOAT>(pre, count, b, looping, dataPos, lane);
+    else GatherStaticT<OALGPU_FMT_SHORT>(pre, count, b, looping, dataPos, lane);
+}
+
+// What the first pass of LoadResampledSamples' loop will ask for (core/voice.cpp:600-640,
+// :662-753), decided from the voice head alone.  `prefetch`: the plain case -- the voice mixes,
+// has a buffer, starts at a non-negative position and its first chunk fits kPre*64 samples -- so
+// the chunk can be gathered into registers ahead of time.
+struct SrcPlan { bool prefetch; uint32_t bdst, bsrc; };
+
+__device__ __forceinline__ SrcPlan PlanSource(const VoiceHead &h, uint32_t samplesToLoad)
+{
+    SrcPlan p{false, 0u, 0u};
+    const bool mixes = h.playState == OALGPU_VOICE_PLAYING || h.playState == OALGPU_VOICE_STOPPING;
+    if(!mixes || h.step < 1u) return p;
+    CalcBufferSize(h.positionFrac, h.step, samplesToLoad, p.bdst, p.bsrc);
+    p.prefetch = h.curBuffer >= 0 && h.position >= 0 && p.bsrc <= uint32_t(kPre * 64);
+    return p;
+}
+
+// ---- resampler, staged rows -----------------------------------------------------------------
+// One wavefront's share (outputs lane, lane+64, ...) of a Resample_FastBSinc / Resample_Cubic
+// call (core/mixer/mixer_c.cpp:52-83; the SSE variants mixer_sse.cpp:199-329 compute the same
+// terms): out[k] = sum_j (fil[j] + pf*phd[j]) * src[pos + j - l], taps two at a time in packed
+// FMAs.  The taps of an output are cut into G groups of NP pairs and software-pipelined: the LDS
+// reads of the next group (or of the next output's first group) are in flight while the current
+// group is multiplied.  Every lane runs every pass of the loop (the store is predicated), so the
+// look-ahead reads need no branch; past the last output they read unused words of this wave's
+// own LDS block.  rdb = rd + MaxResamplerEdge - l.
+template<int M>
+__device__ __forceinline__ void ResampleRunStaged(const f2 *tabF, const f2 *tabP, const float *rdb, uint32_t frac0,
+    uint32_t increment, uint32_t bdst, float *out, uint32_t lane)
+{
+    constexpr int NP = M <= 24 ? M / 4 : 6;
+    constexpr int G = (M / 2) / NP;               // 2 (cubic, bsinc12, bsinc24) or 4 (bsinc48)
+    f2 FA[NP], PA[NP], SA[NP], FB[NP], PB[NP], SB[NP];
+    uint32_t t = frac0 + lane * increment;
+    const uint32_t tstep = 64u * increment;
+    const f2 *tf, *tp;
+    const float *s;
+    f2 pf;
+    auto setup = [&]()
+    {
+        const uint32_t pi = (t >> 11) & 31u;
+        pf = splat(float(t & 2047u) * (1.0f / 2048.0f));
+        tf = tabF + pi; tp = tabP + pi;
+        s = rdb + (t >> kFracBits);
+    };
+    auto load = [&](f2 (&F)[NP], f2 (&P)[NP], f2 (&S)[NP], int g)
+    {
+#pragma unroll
+        for(int q = 0; q < NP; ++q)
+        {
+            F[q] = tf[(g * NP + q) * 32];
+            P[q] = tp[(g * NP + q) * 32];
+        }
+#pragma unroll
+        for(int q = 0; q < NP; ++q) S[q] = f2{s[2 * (g * NP + q)], s[2 * (g * NP + q) + 1]};
+    };
+    auto compute = [&](const f2 (&F)[NP], const f2 (&P)[NP], const f2 (&S)[NP], f2 pfc, f2 &r0, f2 &r1)
+    {
+#pragma unroll
+        for(int q = 0; q < NP; ++q)
+        {
+            const f2 c = pkfma(pfc, P[q], F[q]);
+            if(q & 1) r1 = pkfma(c, S[q], r1);
+            else r0 = pkfma(c, S[q], r0);
+        }
+    };
+    setup();
+    load(FA, PA, SA, 0);
+#pragma unroll 1
+    for(uint32_t kb = 0; kb < bdst; kb += 64)
+    {
+        f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
+        const f2 pfc = pf;
+#pragma unroll
+        for(int g = 0; g < G; g += 2)
+        {
+            load(FB, PB, SB, g + 1);
+            compute(FA, PA, SA, pfc, r0, r1);
+            if(g + 2 < G) load(FA, PA, SA, g + 2);
+            else { t += tstep; setup(); load(FA, PA, SA, 0); }
+            compute(FB, PB, SB, pfc, r0, r1);
+        }
+        if(kb + lane < bdst) out[kb + lane] = (r0.x + r0.y) + (r1.x + r1.y);
+    }
 }
 
 template<int R, int TAPS>
-__device__ __forceinline__ float ResampleStagedM(const WgLds<R, TAPS> &sm, const float *rd, uint32_t m, uint32_t l,
-    uint32_t frac0, uint32_t increment, uint32_t i)
+__device__ __forceinline__ void ResampleRunStagedM(const WgLds<R, TAPS> &sm, const float *rdb, uint32_t m,
+    uint32_t frac0, uint32_t increment, uint32_t bdst, float *out, uint32_t lane)
 {
     switch(m)
     {
-    case 4: return ResampleStaged<4>(sm.tabF, sm.tabP, rd, l, frac0, increment, i);
-    case 12: return ResampleStaged<12>(sm.tabF, sm.tabP, rd, l, frac0, increment, i);
-    case 24: return ResampleStaged<24>(sm.tabF, sm.tabP, rd, l, frac0, increment, i);
-    default: return ResampleStaged<48>(sm.tabF, sm.tabP, rd, l, frac0, increment, i);
+    case 4: ResampleRunStaged<4>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, lane); break;
+    case 12: ResampleRunStaged<12>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, lane); break;
+    case 24: ResampleRunStaged<24>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, lane); break;
+    default: ResampleRunStaged<48>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, lane); break;
     }
 }
 
 // LoadResampledSamples, core/voice.cpp:642-824, for one real channel of a static voice, by one
 // wavefront.  Produces samplesToLoad resampled samples at w.in[kHist..]; updates prev[v] when
-// Playing.  Integer logic identical to voice_kernel.hip's LoadResampled.
+// Playing.  Integer logic identical to voice_kernel.hip's LoadResampled.  When plan.prefetch is
+// set the first chunk's source samples are already on their way in `pre` (GatherStatic) and
+// `prevv` holds mPrevSamples[lane].
 template<int R, int TAPS>
 __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R, TAPS> &w, const DeviceLayout &L,
-    uint32_t v, uint32_t lane, int kind, uint32_t rsM, uint32_t rsL, float rsSf, uint32_t filterOffset, bool playing,
-    int32_t intPos, uint32_t fracPos, uint32_t increment, uint32_t samplesToLoad, uint32_t samplesToMix,
-    int32_t bufferItem, bool looping)
+    uint32_t v, uint32_t lane, const VoiceHead &h, bool playing, uint32_t samplesToLoad, uint32_t samplesToMix,
+    int32_t bufferItem, bool looping, const SrcPlan &plan, const float (&pre)[kPre], float prevv)
 {
     float *rdata = w.rd;
     float *srcBuffer = rdata + kMaxEdge;
     float *mixing = w.in + kHist;
-    if(lane < kMaxPad) rdata[lane] = L.prev[size_t{v} * kMaxPad + lane];
-    const float *filter = L.tables + filterOffset;
-    const uint32_t tableKey = filterOffset * 8u + uint32_t(kind);
+    const int kind = h.rsKind;
+    const uint32_t rsM = h.rsM, rsL = h.rsL, increment = h.step;
+    int32_t intPos = h.position;
+    uint32_t fracPos = h.positionFrac;
+    if(lane < kMaxPad) rdata[lane] = prevv;
+    const float *filter = L.tables + h.rsFilterOffset;
+    const uint32_t tableKey = h.rsFilterOffset * 8u + uint32_t(kind);
     const bool staged = (kind == 2 || kind == 3) && sm.tabKey == tableKey;
     const uint32_t sM = kind == 2 ? 4u : rsM, sL = kind == 2 ? 1u : rsL;
     WaveSync();
 
+    bool firstPass = true;
     for(uint32_t loaded = 0; loaded < samplesToLoad;)
     {
         uint32_t bdst, bsrc;
@@ -175,6 +315,7 @@ __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R,
         {
             WaveSync();
             loaded += bdst;
+            firstPass = false;
             if(loaded < samplesToLoad)
             {
                 fracPos += bdst * increment;
@@ -202,28 +343,37 @@ __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R,
             WaveSync();
             for(uint32_t k = best + 1 + lane; k < tofill; k += 64) srcBuffer[k] = hold;
         }
+        else if(firstPass && plan.prefetch)
+        {
+#pragma unroll
+            for(int i = 0; i < kPre; ++i)
+            {
+                const uint32_t k = lane + 64u * uint32_t(i);
+                if(k < bsrc) srcBuffer[k] = pre[i];
+            }
+        }
         else
         {
             const uint32_t upos = intPos < 0 ? 0u : uint32_t(intPos);
             FillFromBuffer<64>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos, lane);
         }
+        firstPass = false;
         WaveSync();
 
         // voice.cpp:764-769
-        if(increment == kFracOne && fracPos == 0)
+        if((increment == kFracOne && fracPos == 0) || (L.ablate & 2u))
         {
             for(uint32_t k = lane; k < bdst; k += 64) mixing[loaded + k] = srcBuffer[k];
         }
         else if(staged)
         {
-            for(uint32_t k = lane; k < bdst; k += 64)
-                mixing[loaded + k] = ResampleStagedM(sm, rdata, sM, sL, fracPos, increment, k);
+            ResampleRunStagedM(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded, lane);
         }
         else
         {
             const TabLayout lay = ReferenceTabLayout(rsM);
             for(uint32_t k = lane; k < bdst; k += 64)
-                mixing[loaded + k] = ResampleAt<false, false>(kind, rsM, rsL, rsSf, filter, lay, rdata, fracPos, increment, k, bdst);
+                mixing[loaded + k] = ResampleAt<false, false>(kind, rsM, rsL, h.rsSf, filter, lay, rdata, fracPos, increment, k, bdst);
         }
 
         // voice.cpp:772-785: history for the next update, taken at the end-of-mix position
@@ -331,37 +481,8 @@ __device__ __forceinline__ void BiquadDualWaveScan(BiquadState &f0, BiquadState 
     f1.z1 = __shfl(start.c, lastLane); f1.z2 = __shfl(start.d, lastLane);
 }
 
-// ---- dual-ear FIR, packed over the ears -------------------------------------------------------
-// acc[r] = (L,R) of output frame R*lane + r.  xw = &x2[TAPS + R*lane] (x' of the lane's first
-// frame).  co[j] = (Coeffs[j][0], Coeffs[j][1]) through the scalar cache.
 template<int R, int TAPS>
-__device__ __forceinline__ void FirMainPk(f2 (&acc)[R], const f2 *xw, cf2 *co)
-{
-    f2 w[R + 3];
-#pragma unroll
-    for(int k = 0; k < R + 3; ++k) w[k] = xw[k - 3];
-#pragma unroll
-    for(int b = 0; b < TAPS / 4; ++b)
-    {
-#pragma unroll
-        for(int jj = 0; jj < 4; ++jj)
-        {
-            const f2 c = co[4 * b + jj];
-#pragma unroll
-            for(int r = 0; r < R; ++r) acc[r] = pkfma(c, w[r + 3 - jj], acc[r]);
-        }
-        if(b + 1 < TAPS / 4)
-        {
-#pragma unroll
-            for(int k = R + 2; k >= 4; --k) w[k] = w[k - 4];
-#pragma unroll
-            for(int k = 0; k < 4; ++k) w[k] = xw[-4 * (b + 1) - 3 + k];
-        }
-    }
-}
-
-template<int R, int TAPS>
-__global__ void __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo)
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo)
 {
     using WL = WaveLds<R, TAPS>;
     __shared__ WgLds<R, TAPS> sm;
@@ -374,50 +495,22 @@ __global__ void __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, 
     WL &w = sm.w[wave];
     const uint32_t N = samplesToDo;
 
-    // ---- workgroup prologue: pick and stage the resampler rows most voices will use
-    {
-        const uint32_t gBegin = group * kWWaves * vpw;
-        if(wave == 0)
-        {
-            const uint32_t cand = gBegin + lane;
-            bool eligible = false;
-            uint32_t off = 0, m = 0, l = 0;
-            int kind = 0;
-            if(lane < kWWaves * vpw && cand < L.numVoices)
-            {
-                const VoiceCtl &c = L.ctl[cand];
-                kind = c.rsKind; off = c.rsFilterOffset; m = c.rsM; l = c.rsL;
-                if(kind == 2) { m = 4; l = 1; }
-                eligible = (kind == 2 || (kind == 3 && (m == 12 || m == 24 || m == 48)))
-                    && (c.playState == OALGPU_VOICE_PLAYING || c.playState == OALGPU_VOICE_STOPPING);
-            }
-            const unsigned long long mask = __ballot(eligible);
-            if(mask)
-            {
-                const int first = __ffsll((long long)mask) - 1;
-                const uint32_t key = uint32_t(__shfl(int(off * 8u + uint32_t(kind)), first));
-                const uint32_t fm = uint32_t(__shfl(int(m), first)), fl = uint32_t(__shfl(int(l), first));
-                if(lane == 0) { sm.tabKey = key; sm.tabM = fm; sm.tabL = fl; }
-            }
-            else if(lane == 0) { sm.tabKey = 0xffffffffu; sm.tabM = 0; sm.tabL = 0; }
-        }
-        __syncthreads();
-        const uint32_t key = sm.tabKey, m = sm.tabM;
-        if(key != 0xffffffffu)
-        {
-            const float *filter = L.tables + (key >> 3);
-            for(uint32_t idx = t; idx < (m / 2u) * 32u; idx += kWThreads)
-            {
-                const uint32_t p = idx >> 5, pi = idx & 31u;
-                const float *row = filter + pi * 2u * m;
-                sm.tabF[idx] = f2{row[2u * p], row[2u * p + 1u]};
-                sm.tabP[idx] = f2{row[m + 2u * p], row[m + 2u * p + 1u]};
-            }
-        }
-        // zero padding of the old-filter coefficient array (never overwritten)
-        for(uint32_t k = lane; k < uint32_t(TAPS + 128); k += 64) w.cold[k] = f2{0.0f, 0.0f};
-        __syncthreads();
-    }
+    const uint32_t vBegin = (group * kWWaves + wave) * vpw;
+    const uint32_t vEnd = (vBegin + vpw < L.numVoices) ? vBegin + vpw : L.numVoices;
+
+    // Voices are processed in passes; pass 0 only requests the first voice's source window and
+    // stages the workgroup's resampler rows.  The request for the NEXT voice's window sits at one
+    // point of the pass -- after this voice's FIR inputs are built, before its FIR runs -- so the
+    // HBM latency of every window but the first is covered by ~1100 packed FMAs.
+    VoiceHead headN{};
+    SrcPlan planN{false, 0u, 0u};
+    BufferItem bufN{};
+    bool loopingN = false;
+    float preN[kPre];
+    float prevN = 0.0f;
+#pragma unroll
+    for(int i = 0; i < kPre; ++i) preN[i] = 0.0f;
+    if(vBegin < vEnd) headN = LoadHeadScalar(L.ctl + vBegin);
 
     f2 acc[R];
 #pragma unroll
@@ -426,189 +519,323 @@ __global__ void __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, 
 #pragma unroll
     for(int q = 0; q < WL::kQ; ++q) accO[q] = f2{0.0f, 0.0f};
 
-    const uint32_t vBegin = (group * kWWaves + wave) * vpw;
-    const uint32_t vEnd = (vBegin + vpw < L.numVoices) ? vBegin + vpw : L.numVoices;
-    for(uint32_t v = vBegin; v < vEnd; ++v)
+    for(uint32_t pass = 0; pass == 0 || vBegin + pass - 1u < vEnd; ++pass)
     {
-        // per-voice control block through the scalar cache (read once, before this wave's own
-        // write-back at the end of the voice; nobody else touches voice v during the launch)
-        const VoiceCtl ctl = LoadCtlScalar(L.ctl + v);
-        const int vstate = ctl.playState;
-        if(vstate != OALGPU_VOICE_PLAYING && vstate != OALGPU_VOICE_STOPPING) continue;
-        const bool playing = vstate == OALGPU_VOICE_PLAYING;
-        const uint32_t increment = ctl.step;
-        if(increment < 1)
-        {   // voice.cpp:1002-1010
-            if(!playing && lane == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
-            continue;
-        }
-        int32_t bufPosInt = ctl.position;
-        uint32_t bufPosFrac = ctl.positionFrac;
-        int32_t bufferItem = ctl.curBuffer;
-        int32_t loopItem = ctl.loopBuffer;
-        if(loopItem >= 0 && bufferItem >= 0)
-        {   // voice.cpp:1015-1019
-            if(bufPosInt >= 0 && uint32_t(bufPosInt) >= L.buffers[bufferItem].loopEnd) loopItem = -1;
-        }
-        const bool dirty = (ctl.flags & kFlagHrtfDirty) != 0;
+        const bool first = pass == 0;
+        const uint32_t v = vBegin + pass - 1u;              // meaningless in pass 0
+        const uint32_t vn = v + 1u;                         // the voice to request (= vBegin in pass 0)
+        const bool haveNext = vn < vEnd;
 
-        LoadResampledWave(sm, w, L, v, lane, ctl.rsKind, ctl.rsM, ctl.rsL, ctl.rsSf, ctl.rsFilterOffset, playing,
-            bufPosInt, bufPosFrac, increment, N, N, bufferItem, loopItem >= 0);
-
-        const uint32_t counter = (ctl.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
-
-        // ---- DoFilters, direct path (voice.cpp:255-267): in place on w.in[kHist..]
+        // ---------------- part 1: this voice up to its FIR inputs ----------------
+        bool active = false;
+        VoiceHead head{};
+        BufferItem buf{};
+        bool looping = false, playing = false, dirty = false, oldPass = false;
+        VoiceTail tail{};
+        uint32_t counter = 0, fademix = 0, todo = 0;
+        float endGain = 0.0f, gainAfterBlend = 0.0f;
+        int32_t bufferItem = -1;
+        if(!first)
         {
-            BiquadSlot *slots = &L.dfilt[size_t{v} * 2];
-            BiquadState f0 = slots[0].f, f1 = slots[1].f;
-            if(ctl.flags & kFlagDirectFilter)
+            // head, plan, buffer and the gathered window were requested one pass ago
+            head = headN;
+            buf = bufN;
+            looping = loopingN;
+            // next voice's head: in flight while this voice resamples
+            if(haveNext) headN = LoadHeadScalar(L.ctl + vn);
+
+            const int vstate = head.playState;
+            const bool mixes = vstate == OALGPU_VOICE_PLAYING || vstate == OALGPU_VOICE_STOPPING;
+            playing = vstate == OALGPU_VOICE_PLAYING;
+            active = mixes && head.step >= 1u;
+            // voice.cpp:1002-1010
+            if(mixes && !active && !playing && lane == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
+        }
+        if(active)
+        {
+            bufferItem = head.curBuffer;
+            dirty = (head.flags & kFlagHrtfDirty) != 0;
+
+            // per-voice state, requested now and first used after the resampler
+            tail = LoadTailScalar(L.ctl + v);
+            const float histv = L.hist[size_t{v} * kHist + lane];
+            const float fstv = (lane < 32u) ? reinterpret_cast<const float*>(L.dfilt + size_t{v} * 2)[lane] : 0.0f;
+            f2 oldv[TAPS / 64];
+#pragma unroll
+            for(int q = 0; q < TAPS / 64; ++q) oldv[q] = f2{0.0f, 0.0f};
+            if(dirty)
             {
-                if(f0.counter <= 0 && f1.counter <= 0)
-                    BiquadDualWaveScan(f0, f1, w.in + kHist, N, lane);
-                else if(lane == 0)
-                    BiquadDualInterp(f0, f1, w.in + kHist, w.in + kHist, N);
-                if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
+                const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{v} * irStride * 2);
+#pragma unroll
+                for(int q = 0; q < TAPS / 64; ++q)
+                    if(lane + 64u * q < irStride) oldv[q] = oc[lane + 64u * q];
             }
-            else if(lane == 0)
+            const SrcPlan plan = planN;
+            const float prevLoaded = plan.prefetch ? prevN : ((lane < kMaxPad) ? L.prev[size_t{v} * kMaxPad + lane] : 0.0f);
+
+            LoadResampledWave(sm, w, L, v, lane, head, playing, N, N, bufferItem, looping, plan, preN, prevLoaded);
+
+            counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
+
+            // ---- DoFilters, direct path (voice.cpp:255-267): in place on w.in[kHist..]
             {
-                BiquadClear(f0); BiquadClear(f1);
-                slots[0].f = f0; slots[1].f = f1;
+                if(lane < 32u) w.fst[lane] = fstv;
+                WaveSync();
+                BiquadState f0, f1;
+                {
+                    const float *a = w.fst, *b = w.fst + 16;
+                    f0 = BiquadState{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], __builtin_bit_cast(int32_t, a[12])};
+                    f1 = BiquadState{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11], __builtin_bit_cast(int32_t, b[12])};
+                }
+                BiquadSlot *slots = &L.dfilt[size_t{v} * 2];
+                if((head.flags & kFlagDirectFilter) && !(L.ablate & 8u))
+                {
+                    if(f0.counter <= 0 && f1.counter <= 0)
+                    {
+                        BiquadDualWaveScan(f0, f1, w.in + kHist, N, lane);
+                        if(lane == 0) { slots[0].f.z1 = f0.z1; slots[0].f.z2 = f0.z2; slots[1].f.z1 = f1.z1; slots[1].f.z2 = f1.z2; }
+                    }
+                    else
+                    {
+                        if(lane == 0) BiquadDualInterp(f0, f1, w.in + kHist, w.in + kHist, N);
+                        if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
+                    }
+                }
+                else
+                {   // an inactive filter is cleared every update (voice.cpp:264-265); skip the
+                    // store when it already is
+                    const bool clean0 = f0.z1 == 0.0f && f0.z2 == 0.0f && f0.counter == 0 && f0.b0 == f0.tb0 && f0.b1 == f0.tb1
+                        && f0.b2 == f0.tb2 && f0.a1 == f0.ta1 && f0.a2 == f0.ta2;
+                    const bool clean1 = f1.z1 == 0.0f && f1.z2 == 0.0f && f1.counter == 0 && f1.b0 == f1.tb0 && f1.b1 == f1.tb1
+                        && f1.b2 == f1.tb2 && f1.a1 == f1.ta1 && f1.a2 == f1.ta2;
+                    if(!(clean0 && clean1) && lane == 0)
+                    {
+                        BiquadClear(f0); BiquadClear(f1);
+                        slots[0].f = f0; slots[1].f = f1;
+                    }
+                }
+                WaveSync();
+            }
+
+            // ---- DoHrtfMix, voice.cpp:827-902
+            w.in[lane] = histv;
+            WaveSync();
+            if(playing) L.hist[size_t{v} * kHist + lane] = w.in[N + lane];
+
+            const float targetGain = tail.tgtGain * (playing ? 1.0f : 0.0f);
+            const float oldGain = counter ? tail.oldGain : tail.tgtGain;   // voice.cpp:1100
+            float blendGain = targetGain;
+            if(counter)
+            {
+                fademix = N < counter ? N : counter;
+                if(counter > fademix)
+                    blendGain = lerpf(oldGain, targetGain, float(fademix) / float(counter));
+            }
+            const float newStep = fademix ? blendGain / float(fademix) : 0.0f;
+            gainAfterBlend = fademix ? blendGain : oldGain;
+            todo = N - fademix;
+            endGain = targetGain;
+            if(todo && counter > N)
+                endGain = lerpf(gainAfterBlend, targetGain, float(todo) / float(counter - fademix));
+            const float mainStep = todo ? (endGain - gainAfterBlend) / float(todo) : 0.0f;
+            const bool oldOn = fademix && oldGain > kGainSilence;
+            const bool newOn = fademix && newStep * float(fademix) > kGainSilence;
+            const uint32_t odL = tail.oldDelay[0], odR = tail.oldDelay[1];
+            const uint32_t dL = tail.tgtDelay[0], dR = tail.tgtDelay[1];
+            const float oldStep = fademix ? oldGain / float(fademix) : 0.0f;
+            // A voice whose target filter was not replaced since its last mix has Old == Target
+            // (coefficients and delays; voice.cpp:869 / :1100), so the old-filter fade-out and
+            // the new-filter fade-in of MixHrtfBlend act on the same taps and their gains are
+            // summed.
+            const bool merged = !dirty;
+
+            // x'[i] = (In[64 - dL + i], In[64 - dR + i]) * g(i); zero pads on both sides
+            w.x2[lane] = f2{0.0f, 0.0f};
+            if(TAPS > 64) w.x2[64 + lane] = f2{0.0f, 0.0f};
+            for(uint32_t k = TAPS + N + lane; k < uint32_t(WL::kX); k += 64) w.x2[k] = f2{0.0f, 0.0f};
+            if(!(L.ablate & 16u))
+            {
+                const float *inL = w.in + (kHist - dL), *inR = w.in + (kHist - dR);
+                if(lane < N)
+                {   // i = lane: the only pass that can touch the fade (fademix <= 64)
+                    const uint32_t i = lane;
+                    float g;
+                    if(i < fademix)
+                    {
+                        g = newOn ? newStep * float(i) : 0.0f;
+                        if(merged && oldOn) g += oldStep * float(fademix - i);
+                    }
+                    else g = gainAfterBlend + mainStep * float(i - fademix);
+                    w.x2[TAPS + i] = f2{inL[i] * g, inR[i] * g};
+                }
+                const float gbase = gainAfterBlend - mainStep * float(fademix);
+#pragma unroll 4
+                for(uint32_t i = lane + 64u; i < N; i += 64)
+                {
+                    const float g = __builtin_fmaf(mainStep, float(i), gbase);
+                    w.x2[TAPS + i] = f2{inL[i] * g, inR[i] * g};
+                }
+            }
+            // old-filter fade-out inputs (one per lane) and coefficients, replaced filters only
+            oldPass = !merged && oldOn;
+            if(oldPass)
+            {
+                f2 xo = {0.0f, 0.0f};
+                if(lane < fademix)
+                {
+                    const float g = oldStep * float(fademix - lane);
+                    xo = f2{w.in[kHist - odL + lane] * g, w.in[kHist - odR + lane] * g};
+                }
+                w.xo[lane] = xo;
+#pragma unroll
+                for(int q = 0; q < TAPS / 64; ++q) w.cold[64 + lane + 64 * q] = oldv[q];
             }
             WaveSync();
         }
 
-        // ---- DoHrtfMix, voice.cpp:827-902
-        w.in[lane] = L.hist[size_t{v} * kHist + lane];
-        WaveSync();
-        if(playing) L.hist[size_t{v} * kHist + lane] = w.in[N + lane];
-
-        const float targetGain = ctl.hrtfTgtGain * (playing ? 1.0f : 0.0f);
-        const float oldGain = counter ? ctl.hrtfOldGain : ctl.hrtfTgtGain;   // voice.cpp:1100
-        uint32_t fademix = 0;
-        float blendGain = targetGain;
-        if(counter)
-        {
-            fademix = N < counter ? N : counter;
-            if(counter > fademix)
-                blendGain = lerpf(oldGain, targetGain, float(fademix) / float(counter));
-        }
-        const float newStep = fademix ? blendGain / float(fademix) : 0.0f;
-        const float gainAfterBlend = fademix ? blendGain : oldGain;
-        const uint32_t todo = N - fademix;
-        float endGain = targetGain;
-        if(todo && counter > N)
-            endGain = lerpf(gainAfterBlend, targetGain, float(todo) / float(counter - fademix));
-        const float mainStep = todo ? (endGain - gainAfterBlend) / float(todo) : 0.0f;
-        const bool oldOn = fademix && oldGain > kGainSilence;
-        const bool newOn = fademix && newStep * float(fademix) > kGainSilence;
-        const uint32_t odL = ctl.hrtfOldDelay[0], odR = ctl.hrtfOldDelay[1];
-        const uint32_t dL = ctl.hrtfTgtDelay[0], dR = ctl.hrtfTgtDelay[1];
-        const float oldStep = fademix ? oldGain / float(fademix) : 0.0f;
-        // A voice whose target filter was not replaced since its last mix has Old == Target
-        // (coefficients and delays; voice.cpp:869 / :1100), so the old-filter fade-out and the
-        // new-filter fade-in of MixHrtfBlend act on the same taps and their gains are summed.
-        const bool merged = !dirty;
-
-        // x'[i] = (In[64 - dL + i], In[64 - dR + i]) * g(i); zero pads on both sides
-        w.x2[lane] = f2{0.0f, 0.0f};
-        if(TAPS > 64) w.x2[64 + lane] = f2{0.0f, 0.0f};
-        for(uint32_t k = TAPS + N + lane; k < uint32_t(WL::kX); k += 64) w.x2[k] = f2{0.0f, 0.0f};
-        for(uint32_t i = lane; i < N; i += 64)
-        {
-            float g;
-            if(i < fademix)
+        // ---------------- the next voice's source window leaves HBM now ----------------
+        if(haveNext)
+        {   // its head is in headN
+            planN = PlanSource(headN, N);
+            loopingN = false;
+            if(headN.curBuffer >= 0)
             {
-                g = newOn ? newStep * float(i) : 0.0f;
-                if(merged && oldOn) g += oldStep * float(fademix - i);
+                bufN = LoadBufferScalar(L.buffers + headN.curBuffer);
+                // voice.cpp:1015-1019: a position at or past the loop end plays on without looping
+                loopingN = headN.loopBuffer >= 0 && !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd);
+                planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
             }
-            else g = gainAfterBlend + mainStep * float(i - fademix);
-            w.x2[TAPS + i] = f2{w.in[kHist - dL + i] * g, w.in[kHist - dR + i] * g};
-        }
-        // old-filter fade-out inputs (one per lane) and coefficients, replaced filters only
-        const bool oldPass = !merged && oldOn;
-        if(oldPass)
-        {
-            f2 xo = {0.0f, 0.0f};
-            if(lane < fademix)
+            if(planN.prefetch)
             {
-                const float g = oldStep * float(fademix - lane);
-                xo = f2{w.in[kHist - odL + lane] * g, w.in[kHist - odR + lane] * g};
-            }
-            w.xo[lane] = xo;
-            const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{v} * irStride * 2);
-            for(uint32_t k = lane; k < uint32_t(TAPS); k += 64) w.cold[64 + k] = (k < irStride) ? oc[k] : f2{0.0f, 0.0f};
-        }
-        WaveSync();
-
-        cf2 *co = (cf2*)(uintptr_t)(L.hrtfTgt + size_t{v} * irStride * 2);
-        if(irStride == uint32_t(TAPS))
-            FirMainPk<R, TAPS>(acc, &w.x2[TAPS + R * lane], co);
-        else
-        {   // other HRIR lengths: 16-tap segments (irStride is a multiple of 16, zero padded)
-            const f2 *xw = &w.x2[TAPS + R * lane];
-            for(uint32_t seg = 0; seg * 16u < irStride; ++seg)
-                FirMainPk<R, 16>(acc, xw - 16 * seg, co + 16 * seg);
-        }
-        if(oldPass)
-        {   // frames lane + 64q receive cOld[lane + 64q - i] * xo[i], i < 64
-#pragma unroll
-            for(int i = 0; i < 64; ++i)
-            {
-                const f2 xi = w.xo[i];               // same address in every lane: LDS broadcast
-#pragma unroll
-                for(int q = 0; q < WL::kQ; ++q) accO[q] = pkfma(w.cold[64 + lane + 64 * q - i], xi, accO[q]);
+                prevN = (lane < kMaxPad) ? L.prev[size_t{vn} * kMaxPad + lane] : 0.0f;
+                GatherStatic(preN, planN.bsrc, bufN, loopingN, uint32_t(headN.position), lane);
             }
         }
 
-        // voice.cpp:1094-1101 / :869-873,900: Old <- Target, Old.Gain <- reached gain
-        if(dirty && (counter == 0 || fademix))
-        {
-            const float *tg = L.hrtfTgt + size_t{v} * irStride * 2;
-            float *od = L.hrtfOld + size_t{v} * irStride * 2;
-            for(uint32_t k = lane; k < irStride * 2; k += 64) od[k] = tg[k];
+        if(first)
+        {   // ---- workgroup prologue: pick and stage the resampler rows most voices will use
+            const uint32_t gBegin = group * kWWaves * vpw;
+            if(wave == 0)
+            {
+                const uint32_t cand = gBegin + lane;
+                bool eligible = false;
+                uint32_t off = 0, m = 0, l = 0;
+                int kind = 0;
+                if(lane < kWWaves * vpw && cand < L.numVoices)
+                {
+                    const VoiceCtl &c = L.ctl[cand];
+                    kind = c.rsKind; off = c.rsFilterOffset; m = c.rsM; l = c.rsL;
+                    if(kind == 2) { m = 4; l = 1; }
+                    eligible = (kind == 2 || (kind == 3 && (m == 12 || m == 24 || m == 48)))
+                        && (c.playState == OALGPU_VOICE_PLAYING || c.playState == OALGPU_VOICE_STOPPING);
+                }
+                const unsigned long long mask = __ballot(eligible);
+                if(mask)
+                {
+                    const int firstLane = __ffsll((long long)mask) - 1;
+                    const uint32_t key = uint32_t(__shfl(int(off * 8u + uint32_t(kind)), firstLane));
+                    const uint32_t fm = uint32_t(__shfl(int(m), firstLane)), fl = uint32_t(__shfl(int(l), firstLane));
+                    if(lane == 0) { sm.tabKey = key; sm.tabM = fm; sm.tabL = fl; }
+                }
+                else if(lane == 0) { sm.tabKey = 0xffffffffu; sm.tabM = 0; sm.tabL = 0; }
+            }
+            __syncthreads();
+            const uint32_t key = sm.tabKey, m = sm.tabM;
+            if(key != 0xffffffffu)
+            {
+                const float *filter = L.tables + (key >> 3);
+                for(uint32_t idx = t; idx < (m / 2u) * 32u; idx += kWThreads)
+                {
+                    const uint32_t p = idx >> 5, pi = idx & 31u;
+                    const float *row = filter + pi * 2u * m;
+                    sm.tabF[idx] = f2{row[2u * p], row[2u * p + 1u]};
+                    sm.tabP[idx] = f2{row[m + 2u * p], row[m + 2u * p + 1u]};
+                }
+            }
+            // zero padding of the old-filter coefficient array (never overwritten)
+            for(uint32_t k = lane; k < uint32_t(TAPS + 128); k += 64) w.cold[k] = f2{0.0f, 0.0f};
+            __syncthreads();
         }
-        // ---- voice.cpp:1116-1232: flags, position, loop wrap / end of buffer ----
-        if(lane == 0)
+
+        // ---------------- part 2: FIR and state write-back ----------------
+        if(active)
         {
-            VoiceCtl &c = L.ctl[v];
-            if(counter == 0 || fademix) { c.hrtfOldDelay[0] = dL; c.hrtfOldDelay[1] = dR; }
-            c.hrtfOldGain = todo ? endGain : gainAfterBlend;
-            uint32_t flags = ctl.flags | kFlagFading;
-            if(counter == 0 || fademix) flags &= ~kFlagHrtfDirty;
-            c.flags = flags;
-            if(!playing) c.playState = OALGPU_VOICE_STOPPED;
+            cf16 *co = (cf16*)(uintptr_t)(L.hrtfTgt + size_t{v} * irStride * 2);
+            if(L.ablate & 1u) {}
+            else if(irStride == uint32_t(TAPS))
+                FirMainPk<R, TAPS>(acc, &w.x2[TAPS + R * lane], co);
             else
-            {
-                bufPosFrac += increment * N;
-                const uint32_t samplesDone = bufPosFrac >> kFracBits;
-                bufPosInt = AddSat(bufPosInt, int32_t(samplesDone));
-                bufPosFrac &= kFracMask;
-                if(bufferItem >= 0 && bufPosInt > 0)
+            {   // other HRIR lengths: 16-tap segments (irStride is a multiple of 16, zero padded)
+                const f2 *xw = &w.x2[TAPS + R * lane];
+                for(uint32_t seg = 0; seg * 16u < irStride; ++seg)
+                    FirMainPk<R, 16>(acc, xw - 16 * seg, co + 2 * seg);
+            }
+            if(oldPass && !(L.ablate & 1u))
+            {   // frames lane + 64q receive cOld[lane + 64q - i] * xo[i], i < 64
+#pragma unroll 1
+                for(int i0 = 0; i0 < 64; i0 += 8)
                 {
-                    const BufferItem &b = L.buffers[bufferItem];
-                    if(loopItem >= 0)
+#pragma unroll
+                    for(int ii = 0; ii < 8; ++ii)
                     {
-                        uint32_t pos = uint32_t(bufPosInt);
-                        if(pos >= b.loopEnd)
-                        {
-                            pos = ((pos - b.loopStart) % (b.loopEnd - b.loopStart)) + b.loopStart;
-                            bufPosInt = int32_t(pos);
-                        }
+                        const int i = i0 + ii;
+                        const f2 xi = w.xo[i];           // same address in every lane: LDS broadcast
+#pragma unroll
+                        for(int q = 0; q < WL::kQ; ++q) accO[q] = pkfma(w.cold[64 + lane + 64 * q - i], xi, accO[q]);
                     }
-                    else if(uint32_t(bufPosInt) >= b.sampleLen)
-                        bufferItem = -1;
-                }
-                c.position = bufPosInt;
-                c.positionFrac = bufPosFrac;
-                c.curBuffer = bufferItem;
-                if(bufferItem < 0)
-                {
-                    c.loopBuffer = -1;
-                    c.playState = OALGPU_VOICE_STOPPING;
                 }
             }
+
+            // voice.cpp:1094-1101 / :869-873,900: Old <- Target, Old.Gain <- reached gain
+            if(dirty && (counter == 0 || fademix))
+            {
+                const float *tg = L.hrtfTgt + size_t{v} * irStride * 2;
+                float *od = L.hrtfOld + size_t{v} * irStride * 2;
+                for(uint32_t k = lane; k < irStride * 2; k += 64) od[k] = tg[k];
+            }
+            // ---- voice.cpp:1116-1232: flags, position, loop wrap / end of buffer ----
+            if(lane == 0)
+            {
+                VoiceCtl &c = L.ctl[v];
+                if(counter == 0 || fademix) { c.hrtfOldDelay[0] = tail.tgtDelay[0]; c.hrtfOldDelay[1] = tail.tgtDelay[1]; }
+                c.hrtfOldGain = todo ? endGain : gainAfterBlend;
+                uint32_t flags = head.flags | kFlagFading;
+                if(counter == 0 || fademix) flags &= ~kFlagHrtfDirty;
+                c.flags = flags;
+                if(!playing) c.playState = OALGPU_VOICE_STOPPED;
+                else
+                {
+                    int32_t bufPosInt = head.position;
+                    uint32_t bufPosFrac = head.positionFrac + head.step * N;
+                    const uint32_t samplesDone = bufPosFrac >> kFracBits;
+                    bufPosInt = AddSat(bufPosInt, int32_t(samplesDone));
+                    bufPosFrac &= kFracMask;
+                    if(bufferItem >= 0 && bufPosInt > 0)
+                    {
+                        if(looping)
+                        {
+                            uint32_t pos = uint32_t(bufPosInt);
+                            if(pos >= buf.loopEnd)
+                            {
+                                pos = ((pos - buf.loopStart) % (buf.loopEnd - buf.loopStart)) + buf.loopStart;
+                                bufPosInt = int32_t(pos);
+                            }
+                        }
+                        else if(uint32_t(bufPosInt) >= buf.sampleLen)
+                            bufferItem = -1;
+                    }
+                    c.position = bufPosInt;
+                    c.positionFrac = bufPosFrac;
+                    c.curBuffer = bufferItem;
+                    if(bufferItem < 0)
+                    {
+                        c.loopBuffer = -1;
+                        c.playState = OALGPU_VOICE_STOPPING;
+                    }
+                }
+            }
+            WaveSync();
         }
-        WaveSync();
     }
 
     // ---- one partial per workgroup: waves dump their accumulators, then a fixed-order sum
