@@ -26,6 +26,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 UPDATE_SAMPLES = 1024
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3         # fp32 dense peak (MFMA f32 = packed vector rate), MI355X_MICROARCH.md
+# algorithmic flops per voice-update, SURVEY.md 8(d) / DESIGN.md 3.4:
+#   config 3: bsinc24 resample 1024*24*4 + dual-ear FIR 1024*64*2*2 + gain 1024*4
+#   config 2: bsinc24 resample + 5-line gain mix 1024*2*5
+FLOPS_PER_VOICE_UPDATE = {3: 1024 * 24 * 4 + 1024 * 64 * 2 * 2 + 1024 * 4, 2: 1024 * 24 * 4 + 1024 * 2 * 5}
 # algorithmic bytes per voice-update, SURVEY.md 8(d) / DESIGN.md "Algorithmic bytes":
 #   source window (941+48) f32 + mPrevSamples r/w + position r/w + HRTF history r/w + target HRIR
 BYTES_PER_VOICE_UPDATE = {3: 3956 + 384 + 16 + 512 + 512, 2: 3956 + 384 + 16 + 2 * 4 * 5 + 4 * 5}
@@ -194,7 +199,19 @@ def main():
     if rank == 0:
         nvoices_total = V * world
         bytes_per_launch = BYTES_PER_VOICE_UPDATE[args.config] * V
-        achieved = bytes_per_launch / (vk_ms * 1e-3) / 1e9
+        flops_per_launch = FLOPS_PER_VOICE_UPDATE[args.config] * V
+        hbm_achieved = bytes_per_launch / (vk_ms * 1e-3) / 1e9
+        achieved = flops_per_launch / (vk_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the voice kernel from the committed rocprofv3 PMC passes
+        # (profiles/voice_kernel_traffic.json: FETCH_SIZE / WRITE_SIZE collected and corrected
+        # as MI355X_MICROARCH.md prescribes); None when the profile was taken on another config
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "voice_kernel_traffic.json")))
+            if tj.get("config") == args.config and tj.get("voices") == V:
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "mixed voices/sec @48kHz 1024-sample update, HRTF stereo" if hrtf
                       else "mixed voices/sec @48kHz 1024-sample update, bsinc24 -> 7.1 dry bus",
@@ -212,10 +229,15 @@ def main():
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
                        "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
                        "parallelism": f"voice-shard x{world}" + (" + RCCL reduce of mix buses" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "VoiceMixKernel", "kernel_ms": vk_ms,
-                         "bytes_per_launch": bytes_per_launch},
+            # 68 flop/B: the path sits above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B), so
+            # the binding roofline is the fp32 FMA rate; the HBM figures BASELINE's metric names are
+            # reported beside it
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": sc.voice_kernel_name(), "kernel_ms": vk_ms,
+                         "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
+                         "hbm_achieved": hbm_achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s",
+                         "hbm_frac": hbm_achieved / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(synth, args.config, V)

@@ -300,6 +300,8 @@ int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_stat
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);
 /* Enables/disables the event timing above (off by default: it adds two event records). */
 int oalgpu_set_timing(oalgpu_context *ctx, int enable);
+/* Name of the HIP kernel oalgpu_mix_voices launches for this context (as a profiler shows it). */
+const char *oalgpu_voice_kernel_name(oalgpu_context *ctx);
 
 #ifdef __cplusplus
 }

@@ -823,6 +823,13 @@ int oalgpu_last_update_ms(oalgpu_context *c, float *total_ms, float *voice_kerne
     return OALGPU_OK;
 }
 
+const char *oalgpu_voice_kernel_name(oalgpu_context *c)
+{
+    if(!c) return "";
+    if(c->useWave) return c->L.irStride <= 64 ? "VoiceWaveKernel<17, 64>" : "VoiceWaveKernel<18, 128>";
+    return c->exact ? "VoiceMixKernel<true, LINES>" : "VoiceMixKernel<false, LINES>";
+}
+
 /* Multi-GPU: whether this context's voice kernel continues the carried HRTF accumulator tail
  * (exactly one rank must, the one that runs the post-process on the reduced buses). */
 int oalgpu_set_carry_accum(oalgpu_context *c, int enable)

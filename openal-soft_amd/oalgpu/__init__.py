@@ -417,6 +417,11 @@ class Scene:
         check(lib.oalgpu_bus_device_ptr(self.h, C.byref(p), C.byref(n), C.byref(s)))
         return p.value, n.value, s.value
 
+    def voice_kernel_name(self):
+        lib.oalgpu_voice_kernel_name.restype = C.c_char_p
+        lib.oalgpu_voice_kernel_name.argtypes = [C.c_void_p]
+        return lib.oalgpu_voice_kernel_name(self.h).decode()
+
     def set_timing(self, enable=True):
         check(lib.oalgpu_set_timing(self.h, 1 if enable else 0))
 
