@@ -108,6 +108,14 @@ struct oalgpu_context {
     hipStream_t stream{nullptr};
     bool ownStream{true};
     hipEvent_t evStart{nullptr}, evVoice{nullptr}, evEnd{nullptr};
+    // oalgpu_mix_update pipelines two streams when the context owns them: the voice kernel of
+    // update k+1 (main stream) overlaps the bus reduction and the post-process of update k
+    // (post stream).  The per-workgroup partial buses are double-buffered for that.
+    hipStream_t postStream{nullptr};
+    hipEvent_t evVoiceDone[2]{nullptr, nullptr}, evReduceDone[2]{nullptr, nullptr}, evPostDone{nullptr};
+    uint32_t parity{0};
+    bool postPending{false};
+    float *partHrtfBuf[2]{nullptr, nullptr};
     bool timing{false}, timed{false};
     DeviceLayout L{};
     HrtfStoreDev hrtfDev{};
@@ -123,7 +131,7 @@ struct oalgpu_context {
     DevBuf<VoiceCtl> ctl;
     DevBuf<float> prev, hrtfOld, hrtfTgt, hist, gainCur, gainTgt, sendCur, sendTgt;
     DevBuf<BiquadSlot> dfilt, sfilt;
-    DevBuf<float> partLines, partHrtf, bus;
+    DevBuf<float> partLines, partHrtf, partHrtf2, bus;
     // HRTF store
     DevBuf<float> hFieldDist, hCoeffs;
     DevBuf<uint8_t> hEvCount, hDelays;
@@ -145,6 +153,9 @@ struct oalgpu_context {
         if(evStart) (void)hipEventDestroy(evStart);
         if(evVoice) (void)hipEventDestroy(evVoice);
         if(evEnd) (void)hipEventDestroy(evEnd);
+        for(hipEvent_t e : {evVoiceDone[0], evVoiceDone[1], evReduceDone[0], evReduceDone[1], evPostDone})
+            if(e) (void)hipEventDestroy(e);
+        if(postStream) (void)hipStreamDestroy(postStream);
         if(stream && ownStream) (void)hipStreamDestroy(stream);
     }
 };
@@ -370,6 +381,9 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     c->exact = desc->math_mode == OALGPU_MATH_EXACT;
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreate(&c->evStart)); HIP_TRY(hipEventCreate(&c->evVoice)); HIP_TRY(hipEventCreate(&c->evEnd));
+    HIP_TRY(hipStreamCreate(&c->postStream));
+    for(hipEvent_t *e : {&c->evVoiceDone[0], &c->evVoiceDone[1], &c->evReduceDone[0], &c->evReduceDone[1], &c->evPostDone})
+        HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
     DeviceLayout &L = c->L;
     L.numVoices = desc->max_voices;
@@ -419,6 +433,8 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->sendTgt.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendTgt.zero()); L.sendTgt = c->sendTgt.p;
     HIP_TRY(c->partLines.alloc(size_t{L.numGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
     HIP_TRY(c->partHrtf.alloc(L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0)); L.partHrtf = c->partHrtf.p;
+    HIP_TRY(c->partHrtf2.alloc(c->useWave ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
+    c->partHrtfBuf[0] = c->partHrtf.p; c->partHrtfBuf[1] = c->partHrtf2.p;
     HIP_TRY(c->bus.alloc(BusFloats(L))); HIP_TRY(c->bus.zero()); L.bus = c->bus.p;
     // HRTF voice filters are sized when the data set is loaded
     L.hrtfOld = nullptr; L.hrtfTgt = nullptr;
@@ -436,6 +452,7 @@ void oalgpu_context_destroy(oalgpu_context *ctx)
     if(!ctx) return;
     (void)hipSetDevice(ctx->desc.device);
     (void)hipStreamSynchronize(ctx->stream);
+    if(ctx->postStream) (void)hipStreamSynchronize(ctx->postStream);
     delete ctx;
 }
 
@@ -664,6 +681,8 @@ int oalgpu_set_stream(oalgpu_context *c, void *hip_stream)
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(int rc = UseDevice(c->desc.device)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if(c->postStream) HIP_TRY(hipStreamSynchronize(c->postStream));
+    c->postPending = false;
     if(c->ownStream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
     if(hip_stream) { c->stream = static_cast<hipStream_t>(hip_stream); c->ownStream = false; }
     else { HIP_TRY(hipStreamCreate(&c->stream)); c->ownStream = true; }
@@ -682,12 +701,22 @@ int oalgpu_voice_set_state(oalgpu_context *c, uint32_t voice, int play_state)
     return OALGPU_OK;
 }
 
+// Orders the main stream behind whatever a pipelined oalgpu_mix_update left on the post stream.
+static int JoinPost(oalgpu_context *c)
+{
+    if(!c->postPending) return OALGPU_OK;
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->evPostDone, 0));
+    c->postPending = false;
+    return OALGPU_OK;
+}
+
 int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
+    if(int rc = JoinPost(c)) return rc;
     if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
     if(c->useWave) HIP_TRY(LaunchVoiceWave(c->stream, c->L, samples_to_do));
     else HIP_TRY(LaunchVoiceMix(c->stream, c->exact, c->L, samples_to_do, c->carryAccum));
@@ -704,6 +733,7 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
     if(!c->L.hrtf) return OALGPU_OK;
     if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = JoinPost(c)) return rc;
     const DeviceLayout &L = c->L;
     if(L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
     float *left = L.bus + size_t{L.numDry} * kLine;
@@ -721,8 +751,46 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
 
 int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_process)
 {
-    if(int rc = oalgpu_mix_voices(c, samples_to_do)) return rc;
-    if(post_process) return oalgpu_post_process(c, samples_to_do);
+    if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
+    if(!(c->useWave && c->ownStream))
+    {   // one stream: the workgroup-per-voice-group kernel reads the carried accumulator itself,
+        // and a caller-owned stream (RCCL ordering) is never forked
+        if(int rc = oalgpu_mix_voices(c, samples_to_do)) return rc;
+        if(post_process) return oalgpu_post_process(c, samples_to_do);
+        return OALGPU_OK;
+    }
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(post_process && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
+    const uint32_t p = c->parity;
+    DeviceLayout L = c->L;
+    L.partHrtf = c->partHrtfBuf[p];
+    // main stream: this update's voices; its partial-bus buffer was last read by the reduction
+    // of two updates ago
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->evReduceDone[p], 0));
+    if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
+    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do));
+    if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
+    HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
+    // post stream: reduction (adds the carried HRTF accumulator tail) and post-process; they
+    // run beside the next update's parameter and voice kernels
+    HIP_TRY(hipStreamWaitEvent(c->postStream, c->evVoiceDone[p], 0));
+    LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->evReduceDone[p], c->postStream));
+    if(post_process && L.hrtf)
+    {
+        float *left = L.bus + size_t{L.numDry} * kLine;
+        float *right = left + kLine;
+        LaunchPostDirectHrtfFast(c->postStream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
+            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do);
+        HIP_TRY(hipGetLastError());
+    }
+    if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->postStream)); c->timed = true; }
+    HIP_TRY(hipEventRecord(c->evPostDone, c->postStream));
+    c->postPending = true;
+    c->parity = p ^ 1u;
     return OALGPU_OK;
 }
 
@@ -731,6 +799,8 @@ int oalgpu_sync(oalgpu_context *c)
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(int rc = UseDevice(c->desc.device)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if(c->postStream) HIP_TRY(hipStreamSynchronize(c->postStream));
+    c->postPending = false;
     return OALGPU_OK;
 }
 
@@ -764,7 +834,7 @@ int oalgpu_bus_device_ptr(oalgpu_context *c, void **ptr, size_t *nfloats, void *
     if(!c || !ptr || !nfloats) return Fail(OALGPU_ERR_INVALID, "null argument");
     *ptr = c->L.bus;
     *nfloats = BusFloats(c->L);
-    if(hip_stream) *hip_stream = c->stream;
+    if(hip_stream) *hip_stream = c->stream;     // serial entry points (mix_voices/post_process) produce the bus here
     return OALGPU_OK;
 }
 
