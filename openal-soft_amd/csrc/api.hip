@@ -132,6 +132,8 @@ struct oalgpu_context {
     DevBuf<float> prev, hrtfOld, hrtfTgt, hist, gainCur, gainTgt, sendCur, sendTgt;
     DevBuf<BiquadSlot> dfilt, sfilt;
     DevBuf<float> partLines, partHrtf, partHrtf2, bus;
+    DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
+    bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
     // HRTF store
     DevBuf<float> hFieldDist, hCoeffs;
     DevBuf<uint8_t> hEvCount, hDelays;
@@ -404,6 +406,8 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.waveVoices = 0;
     L.ablate = 0;
     if(const char *ab = std::getenv("OALGPU_ABLATE")) L.ablate = uint32_t(std::strtoul(ab, nullptr, 0));
+    L.phaseTimes = nullptr;
+    c->serialOnly = std::getenv("OALGPU_SERIAL") != nullptr;
     c->useWave = WaveKernelApplies(c->exact, L);
     if(c->useWave)
     {
@@ -436,6 +440,11 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->partHrtf2.alloc(c->useWave ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
     c->partHrtfBuf[0] = c->partHrtf.p; c->partHrtfBuf[1] = c->partHrtf2.p;
     HIP_TRY(c->bus.alloc(BusFloats(L))); HIP_TRY(c->bus.zero()); L.bus = c->bus.p;
+    if(std::getenv("OALGPU_PHASE_TIMES"))
+    {
+        HIP_TRY(c->phaseTimes.alloc(nv * 8)); HIP_TRY(c->phaseTimes.zero());
+        L.phaseTimes = c->phaseTimes.p;
+    }
     // HRTF voice filters are sized when the data set is loaded
     L.hrtfOld = nullptr; L.hrtfTgt = nullptr;
 
@@ -752,7 +761,7 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
 int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_process)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
-    if(!(c->useWave && c->ownStream))
+    if(!(c->useWave && c->ownStream) || c->serialOnly)
     {   // one stream: the workgroup-per-voice-group kernel reads the carried accumulator itself,
         // and a caller-owned stream (RCCL ordering) is never forked
         if(int rc = oalgpu_mix_voices(c, samples_to_do)) return rc;
@@ -890,6 +899,16 @@ int oalgpu_last_update_ms(oalgpu_context *c, float *total_ms, float *voice_kerne
     if(int rc = oalgpu_sync(c)) return rc;
     if(total_ms) HIP_TRY(hipEventElapsedTime(total_ms, c->evStart, c->evEnd));
     if(voice_kernel_ms) HIP_TRY(hipEventElapsedTime(voice_kernel_ms, c->evStart, c->evVoice));
+    return OALGPU_OK;
+}
+
+/* Profiling aid (not part of the public header): copies the [voice][8] s_memtime stamps the
+ * wavefront kernel recorded when the context was created with OALGPU_PHASE_TIMES set. */
+int oalgpu_debug_phase_times(oalgpu_context *c, unsigned long long *out)
+{
+    if(!c || !out || !c->phaseTimes.p) return Fail(OALGPU_ERR_INVALID, "phase times were not enabled");
+    if(int rc = oalgpu_sync(c)) return rc;
+    HIP_TRY(hipMemcpy(out, c->phaseTimes.p, size_t{c->L.numVoices} * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return OALGPU_OK;
 }
 

@@ -64,6 +64,10 @@ __device__ __forceinline__ void FirMainPk(f2 (&acc)[R], const X *xw, cf16 *co16)
     X w[R + 3];
 #pragma unroll
     for(int k = 0; k < R + 3; ++k) w[k] = xw[k - 3];
+    // the four window entries block b+1 shifts in are read two blocks ahead of their first use
+    X wn[4];
+#pragma unroll
+    for(int k = 0; k < 4; ++k) wn[k] = (TAPS > 4) ? xw[-4 - 3 + k] : w[k];
     f16 cnext = co16[0];
 #pragma unroll
     for(int b8 = 0; b8 < TAPS / 8; ++b8)
@@ -74,6 +78,9 @@ __device__ __forceinline__ void FirMainPk(f2 (&acc)[R], const X *xw, cf16 *co16)
         for(int h = 0; h < 2; ++h)
         {
             const int b = 2 * b8 + h;
+            X wnn[4];
+#pragma unroll
+            for(int k = 0; k < 4; ++k) wnn[k] = (b + 2 < TAPS / 4) ? xw[-4 * (b + 2) - 3 + k] : wn[k];
 #pragma unroll
             for(int jj = 0; jj < 4; ++jj)
             {
@@ -90,7 +97,7 @@ __device__ __forceinline__ void FirMainPk(f2 (&acc)[R], const X *xw, cf16 *co16)
 #pragma unroll
                 for(int k = R + 2; k >= 4; --k) w[k] = w[k - 4];
 #pragma unroll
-                for(int k = 0; k < 4; ++k) w[k] = xw[-4 * (b + 1) - 3 + k];
+                for(int k = 0; k < 4; ++k) { w[k] = wn[k]; wn[k] = wnn[k]; }
             }
         }
     }

@@ -62,6 +62,7 @@ struct DeviceLayout {
     uint32_t voicesPerGroup, numGroups;
     uint32_t waveVoices;                    // voice_wave.hip: voices per wavefront (0 = not used)
     uint32_t ablate;                        // profiling aid (env OALGPU_ABLATE): stages to skip, 0 in production
+    unsigned long long *phaseTimes;         // profiling aid (env OALGPU_PHASE_TIMES): [voice][8] s_memtime stamps, or null
     uint32_t mixLines;                      // lines accumulated by the voice kernel
     // tables + buffers
     const float *tables;                    // [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]

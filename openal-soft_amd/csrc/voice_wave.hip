@@ -197,25 +197,21 @@ __device__ __forceinline__ SrcPlan PlanSource(const VoiceHead &h, uint32_t sampl
 // own LDS block.  rdb = rd + MaxResamplerEdge - l.
 template<int M>
 __device__ __forceinline__ void ResampleRunStaged(const f2 *tabF, const f2 *tabP, const float *rdb, uint32_t frac0,
-    uint32_t increment, uint32_t bdst, float *out, uint32_t lane)
+    uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane)
 {
-    constexpr int NP = M <= 24 ? M / 4 : 6;
-    constexpr int G = (M / 2) / NP;               // 2 (cubic, bsinc12, bsinc24) or 4 (bsinc48)
+    // Two complete outputs are in flight: while the 3*NP LDS reads of one are outstanding
+    // (rows F, P and the source pairs S) the other is multiplied, which covers the LDS latency
+    // at two waves per SIMD.  bsinc48 (24 pairs) takes its outputs in two halves.
+    constexpr int NP = M <= 24 ? M / 2 : 12;
+    constexpr int G = (M / 2) / NP;               // 1, or 2 for bsinc48
     f2 FA[NP], PA[NP], SA[NP], FB[NP], PB[NP], SB[NP];
-    uint32_t t = frac0 + lane * increment;
     const uint32_t tstep = 64u * increment;
-    const f2 *tf, *tp;
-    const float *s;
-    f2 pf;
-    auto setup = [&]()
+    uint32_t t = frac0 + lane * increment;
+    auto load = [&](f2 (&F)[NP], f2 (&P)[NP], f2 (&S)[NP], uint32_t tt, int g)
     {
-        const uint32_t pi = (t >> 11) & 31u;
-        pf = splat(float(t & 2047u) * (1.0f / 2048.0f));
-        tf = tabF + pi; tp = tabP + pi;
-        s = rdb + (t >> kFracBits);
-    };
-    auto load = [&](f2 (&F)[NP], f2 (&P)[NP], f2 (&S)[NP], int g)
-    {
+        const uint32_t pi = (tt >> 11) & 31u;
+        const f2 *tf = tabF + pi, *tp = tabP + pi;
+        const float *s = rdb + (tt >> kFracBits);
 #pragma unroll
         for(int q = 0; q < NP; ++q)
         {
@@ -225,46 +221,68 @@ __device__ __forceinline__ void ResampleRunStaged(const f2 *tabF, const f2 *tabP
 #pragma unroll
         for(int q = 0; q < NP; ++q) S[q] = f2{s[2 * (g * NP + q)], s[2 * (g * NP + q) + 1]};
     };
-    auto compute = [&](const f2 (&F)[NP], const f2 (&P)[NP], const f2 (&S)[NP], f2 pfc, f2 &r0, f2 &r1)
+    auto compute = [&](const f2 (&F)[NP], const f2 (&P)[NP], const f2 (&S)[NP], uint32_t tt, f2 &r0, f2 &r1)
     {
+        const f2 pf = splat(float(tt & 2047u) * (1.0f / 2048.0f));
 #pragma unroll
         for(int q = 0; q < NP; ++q)
         {
-            const f2 c = pkfma(pfc, P[q], F[q]);
+            const f2 c = pkfma(pf, P[q], F[q]);
             if(q & 1) r1 = pkfma(c, S[q], r1);
             else r0 = pkfma(c, S[q], r0);
         }
     };
-    setup();
-    load(FA, PA, SA, 0);
-#pragma unroll 1
-    for(uint32_t kb = 0; kb < bdst; kb += 64)
+    auto store = [&](uint32_t k, f2 r0, f2 r1)
+    {   // lanes past the end write a scratch word instead of branching
+        float *dst = (k < bdst) ? out + k : sink;
+        *dst = (r0.x + r0.y) + (r1.x + r1.y);
+    };
+    if constexpr(G == 1)
     {
-        f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
-        const f2 pfc = pf;
-#pragma unroll
-        for(int g = 0; g < G; g += 2)
+        load(FA, PA, SA, t, 0);
+#pragma unroll 1
+        for(uint32_t kb = 0; kb < bdst; kb += 128)
         {
-            load(FB, PB, SB, g + 1);
-            compute(FA, PA, SA, pfc, r0, r1);
-            if(g + 2 < G) load(FA, PA, SA, g + 2);
-            else { t += tstep; setup(); load(FA, PA, SA, 0); }
-            compute(FB, PB, SB, pfc, r0, r1);
+            const uint32_t t0 = t, t1 = t + tstep;
+            t = t1 + tstep;
+            load(FB, PB, SB, t1, 0);
+            f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
+            compute(FA, PA, SA, t0, r0, r1);
+            store(kb + lane, r0, r1);
+            load(FA, PA, SA, t, 0);
+            f2 u0 = {0.0f, 0.0f}, u1 = {0.0f, 0.0f};
+            compute(FB, PB, SB, t1, u0, u1);
+            store(kb + 64u + lane, u0, u1);
         }
-        if(kb + lane < bdst) out[kb + lane] = (r0.x + r0.y) + (r1.x + r1.y);
+    }
+    else
+    {
+        load(FA, PA, SA, t, 0);
+#pragma unroll 1
+        for(uint32_t kb = 0; kb < bdst; kb += 64)
+        {
+            const uint32_t t0 = t;
+            t += tstep;
+            load(FB, PB, SB, t0, 1);
+            f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
+            compute(FA, PA, SA, t0, r0, r1);
+            load(FA, PA, SA, t, 0);
+            compute(FB, PB, SB, t0, r0, r1);
+            store(kb + lane, r0, r1);
+        }
     }
 }
 
 template<int R, int TAPS>
 __device__ __forceinline__ void ResampleRunStagedM(const WgLds<R, TAPS> &sm, const float *rdb, uint32_t m,
-    uint32_t frac0, uint32_t increment, uint32_t bdst, float *out, uint32_t lane)
+    uint32_t frac0, uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane)
 {
     switch(m)
     {
-    case 4: ResampleRunStaged<4>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, lane); break;
-    case 12: ResampleRunStaged<12>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, lane); break;
-    case 24: ResampleRunStaged<24>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, lane); break;
-    default: ResampleRunStaged<48>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, lane); break;
+    case 4: ResampleRunStaged<4>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
+    case 12: ResampleRunStaged<12>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
+    case 24: ResampleRunStaged<24>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
+    default: ResampleRunStaged<48>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
     }
 }
 
@@ -359,6 +377,7 @@ __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R,
         }
         firstPass = false;
         WaveSync();
+        if(L.phaseTimes && lane == 0 && loaded == 0) L.phaseTimes[size_t{v} * 8 + 7] = __builtin_readcyclecounter();
 
         // voice.cpp:764-769
         if((increment == kFracOne && fracPos == 0) || (L.ablate & 2u))
@@ -367,7 +386,8 @@ __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R,
         }
         else if(staged)
         {
-            ResampleRunStagedM(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded, lane);
+            ResampleRunStagedM(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded,
+                reinterpret_cast<float*>(&w.pad[0]), lane);
         }
         else
         {
@@ -407,78 +427,78 @@ __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R,
 }
 
 // ---- wave-parallel dual biquad (time-invariant coefficients) ---------------------------------
-// The cascade is linear in its state s = (z01, z02, z11, z12): s' = A s + B x.  Lane l owns
-// samples [l*seg, (l+1)*seg).  (1) M = A^seg (the same for every lane) from seg zero-input steps
-// of the four unit states; (2) forced response q_l of the lane's block from a zero state;
-// (3) block-start states by a 6-step Kogge-Stone scan of S_l = M^(l) S_0 + sum M^(l-1-k) q_k
-// using M, M^2, ... M^32; (4) each lane re-runs the true recurrence from its start state.
-// seg is odd so that lanes reading sample l*seg + r hit distinct LDS banks.
-struct Dual4 { float a, b, c, d; };
+// BiquadFilter::dualProcess (core/filters/biquad.cpp:254-282) is two transposed-direct-form-II
+// sections in cascade; each is linear in its state s = (z1, z2): s' = A s + B x with
+// A = [[-a1, 1], [-a2, 0]].  Lane l owns the run of samples [l*seg, (l+1)*seg) -- seg odd, so
+// the per-lane runs hit distinct LDS banks -- and keeps it in registers for both sections:
+//   (1) M = A^seg;  (2) forced response q_l of the run from a zero state;  (3) run-start states
+//   S_l = M^l S_0 + sum_{k<l} M^(l-1-k) q_k by a 6-step Kogge-Stone scan with M, M^2, .. M^32;
+//   (4) the true recurrence from S_l.  Lanes past the last sample only produce values nobody
+// reads.  The serial loop of the reference differs from this by rounding only.
+constexpr int kBqSeg = 17;                    // ceil(1024 / 64) | 1
+struct S2 { float a, b; };
 
-__device__ __forceinline__ float DualStepF(Dual4 &s, float x, const BiquadState &f0, const BiquadState &f1)
+__device__ __forceinline__ float BqStep(S2 &s, float x, float b0, float b1, float b2, float a1, float a2)
 {
-    const float y0 = __builtin_fmaf(x, f0.b0, s.a);
-    s.a = __builtin_fmaf(x, f0.b1, __builtin_fmaf(-y0, f0.a1, s.b));
-    s.b = __builtin_fmaf(x, f0.b2, -y0 * f0.a2);
-    const float y1 = __builtin_fmaf(y0, f1.b0, s.c);
-    s.c = __builtin_fmaf(y0, f1.b1, __builtin_fmaf(-y1, f1.a1, s.d));
-    s.d = __builtin_fmaf(y0, f1.b2, -y1 * f1.a2);
-    return y1;
+    const float y = __builtin_fmaf(x, b0, s.a);
+    s.a = __builtin_fmaf(x, b1, __builtin_fmaf(-y, a1, s.b));
+    s.b = __builtin_fmaf(x, b2, -y * a2);
+    return y;
 }
+__device__ __forceinline__ S2 Mv2(S2 c0, S2 c1, S2 v)          // [c0 c1] * v
+{ return S2{__builtin_fmaf(c1.a, v.b, c0.a * v.a), __builtin_fmaf(c1.b, v.b, c0.b * v.a)}; }
 
-struct Mat4 { Dual4 c0, c1, c2, c3; };    // columns
-
-__device__ __forceinline__ Dual4 MatVec(const Mat4 &m, const Dual4 &v)
+// one section over the lane's run x[0..cnt); z1/z2: state in, state after the last sample out
+__device__ __forceinline__ void BiquadWaveScan(float (&x)[kBqSeg], uint32_t cnt, uint32_t seg, const BiquadState &f,
+    float &z1, float &z2, uint32_t lane, int lastLane)
 {
-    Dual4 r;
-    r.a = __builtin_fmaf(m.c3.a, v.d, __builtin_fmaf(m.c2.a, v.c, __builtin_fmaf(m.c1.a, v.b, m.c0.a * v.a)));
-    r.b = __builtin_fmaf(m.c3.b, v.d, __builtin_fmaf(m.c2.b, v.c, __builtin_fmaf(m.c1.b, v.b, m.c0.b * v.a)));
-    r.c = __builtin_fmaf(m.c3.c, v.d, __builtin_fmaf(m.c2.c, v.c, __builtin_fmaf(m.c1.c, v.b, m.c0.c * v.a)));
-    r.d = __builtin_fmaf(m.c3.d, v.d, __builtin_fmaf(m.c2.d, v.c, __builtin_fmaf(m.c1.d, v.b, m.c0.d * v.a)));
-    return r;
-}
-__device__ __forceinline__ Mat4 MatMul(const Mat4 &a, const Mat4 &b)
-{ return Mat4{MatVec(a, b.c0), MatVec(a, b.c1), MatVec(a, b.c2), MatVec(a, b.c3)}; }
-
-__device__ __forceinline__ void BiquadDualWaveScan(BiquadState &f0, BiquadState &f1, float *buf /* in place */,
-    uint32_t n, uint32_t lane)
-{
-    const uint32_t seg = ((n + 63u) / 64u) | 1u;
-    const uint32_t begin = lane * seg < n ? lane * seg : n;
-    const uint32_t end = (begin + seg < n) ? begin + seg : n;
-    Mat4 M{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    const float b0 = f.b0, b1 = f.b1, b2 = f.b2, a1 = f.a1, a2 = f.a2;
+    S2 m0{1.0f, 0.0f}, m1{0.0f, 1.0f};                 // columns of M = A^seg
     for(uint32_t i = 0; i < seg; ++i)
     {
-        DualStepF(M.c0, 0.0f, f0, f1); DualStepF(M.c1, 0.0f, f0, f1);
-        DualStepF(M.c2, 0.0f, f0, f1); DualStepF(M.c3, 0.0f, f0, f1);
+        m0 = S2{__builtin_fmaf(-a1, m0.a, m0.b), -a2 * m0.a};
+        m1 = S2{__builtin_fmaf(-a1, m1.a, m1.b), -a2 * m1.a};
     }
-    Dual4 q{0, 0, 0, 0};
-    for(uint32_t i = begin; i < end; ++i) DualStepF(q, buf[i], f0, f1);
-    // inclusive scan: after it, lane l holds E_l = sum_{k<=l} M^(l-k) q_k  (state at the END of
-    // block l for a zero initial state); P_l = M^(l+1) applied to S_0 is added below.
-    Dual4 e = q;
-    Dual4 s0{f0.z1, f0.z2, f1.z1, f1.z2};        // becomes M^lane S_0 (binary powers of M)
-    Mat4 P = M;                                  // M^(2^step)
+    S2 e{0.0f, 0.0f};
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < seg) BqStep(e, x[i], b0, b1, b2, a1, a2);
+    S2 s0{z1, z2};                                    // -> M^lane S_0
+    S2 p0 = m0, p1 = m1;                              // M^(2^step)
 #pragma unroll
     for(int step = 0; step < 6; ++step)
     {
         const int d = 1 << step;
-        Dual4 o;
-        o.a = __shfl_up(e.a, d); o.b = __shfl_up(e.b, d); o.c = __shfl_up(e.c, d); o.d = __shfl_up(e.d, d);
-        const Dual4 mo = MatVec(P, o);
-        if(int(lane) >= d) { e.a += mo.a; e.b += mo.b; e.c += mo.c; e.d += mo.d; }
-        const Dual4 ms = MatVec(P, s0);
+        const S2 o{__shfl_up(e.a, d), __shfl_up(e.b, d)};
+        const S2 mo = Mv2(p0, p1, o);
+        if(int(lane) >= d) { e.a += mo.a; e.b += mo.b; }
+        const S2 ms = Mv2(p0, p1, s0);
         if(lane & uint32_t(d)) s0 = ms;
-        if(step < 5) P = MatMul(P, P);
+        if(step < 5) { const S2 n0 = Mv2(p0, p1, p0), n1 = Mv2(p0, p1, p1); p0 = n0; p1 = n1; }
     }
-    Dual4 prevE;
-    prevE.a = __shfl_up(e.a, 1); prevE.b = __shfl_up(e.b, 1); prevE.c = __shfl_up(e.c, 1); prevE.d = __shfl_up(e.d, 1);
-    Dual4 start = s0;
-    if(lane > 0) { start.a += prevE.a; start.b += prevE.b; start.c += prevE.c; start.d += prevE.d; }
-    for(uint32_t i = begin; i < end; ++i) buf[i] = DualStepF(start, buf[i], f0, f1);
+    const S2 prevE{__shfl_up(e.a, 1), __shfl_up(e.b, 1)};
+    S2 st = s0;
+    if(lane > 0) { st.a += prevE.a; st.b += prevE.b; }
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i)
+        if(uint32_t(i) < cnt) x[i] = BqStep(st, x[i], b0, b1, b2, a1, a2);
+    z1 = __shfl(st.a, lastLane);
+    z2 = __shfl(st.b, lastLane);
+}
+
+__device__ __forceinline__ void BiquadDualWaveScan(BiquadState &f0, BiquadState &f1, float *buf /* in place */,
+    uint32_t n, uint32_t lane)
+{
+    const uint32_t seg = ((n + 63u) / 64u) | 1u;      // <= kBqSeg for n <= 1024
+    const uint32_t begin = lane * seg < n ? lane * seg : n;
+    const uint32_t cnt = (begin + seg < n) ? seg : n - begin;
     const int lastLane = int((n - 1u) / seg);
-    f0.z1 = __shfl(start.a, lastLane); f0.z2 = __shfl(start.b, lastLane);
-    f1.z1 = __shfl(start.c, lastLane); f1.z2 = __shfl(start.d, lastLane);
+    float x[kBqSeg];
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) x[i] = (uint32_t(i) < cnt) ? buf[begin + i] : 0.0f;
+    BiquadWaveScan(x, cnt, seg, f0, f0.z1, f0.z2, lane, lastLane);
+    BiquadWaveScan(x, cnt, seg, f1, f1.z1, f1.z2, lane, lastLane);
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < cnt) buf[begin + i] = x[i];
 }
 
 template<int R, int TAPS>
@@ -527,7 +547,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         const bool haveNext = vn < vEnd;
 
         // ---------------- part 1: this voice up to its FIR inputs ----------------
-        bool active = false;
+        bool active = false, planned = false;
         VoiceHead head{};
         BufferItem buf{};
         bool looping = false, playing = false, dirty = false, oldPass = false;
@@ -551,8 +571,13 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             // voice.cpp:1002-1010
             if(mixes && !active && !playing && lane == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
         }
+        auto stamp = [&](int slot)
+        {
+            if(L.phaseTimes && lane == 0) L.phaseTimes[size_t{v} * 8 + slot] = __builtin_readcyclecounter();
+        };
         if(active)
         {
+            stamp(0);
             bufferItem = head.curBuffer;
             dirty = (head.flags & kFlagHrtfDirty) != 0;
 
@@ -575,6 +600,15 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 
             LoadResampledWave(sm, w, L, v, lane, head, playing, N, N, bufferItem, looping, plan, preN, prevLoaded);
 
+            // the next voice's head has arrived by now: plan its window and fetch its buffer
+            // descriptor, so that only the gather itself is left for the request point below
+            if(haveNext)
+            {
+                planN = PlanSource(headN, N);
+                if(headN.curBuffer >= 0) bufN = LoadBufferScalar(L.buffers + headN.curBuffer);
+                planned = true;
+            }
+            stamp(1);
             counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
 
             // ---- DoFilters, direct path (voice.cpp:255-267): in place on w.in[kHist..]
@@ -617,6 +651,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 WaveSync();
             }
 
+            stamp(2);
             // ---- DoHrtfMix, voice.cpp:827-902
             w.in[lane] = histv;
             WaveSync();
@@ -691,16 +726,20 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 for(int q = 0; q < TAPS / 64; ++q) w.cold[64 + lane + 64 * q] = oldv[q];
             }
             WaveSync();
+            stamp(3);
         }
 
         // ---------------- the next voice's source window leaves HBM now ----------------
         if(haveNext)
         {   // its head is in headN
-            planN = PlanSource(headN, N);
+            if(!planned)
+            {
+                planN = PlanSource(headN, N);
+                if(headN.curBuffer >= 0) bufN = LoadBufferScalar(L.buffers + headN.curBuffer);
+            }
             loopingN = false;
             if(headN.curBuffer >= 0)
             {
-                bufN = LoadBufferScalar(L.buffers + headN.curBuffer);
                 // voice.cpp:1015-1019: a position at or past the loop end plays on without looping
                 loopingN = headN.loopBuffer >= 0 && !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd);
                 planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
@@ -760,6 +799,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         // ---------------- part 2: FIR and state write-back ----------------
         if(active)
         {
+            stamp(4);
             cf16 *co = (cf16*)(uintptr_t)(L.hrtfTgt + size_t{v} * irStride * 2);
             if(L.ablate & 1u) {}
             else if(irStride == uint32_t(TAPS))
@@ -786,6 +826,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 }
             }
 
+            stamp(5);
             // voice.cpp:1094-1101 / :869-873,900: Old <- Target, Old.Gain <- reached gain
             if(dirty && (counter == 0 || fademix))
             {
@@ -835,6 +876,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 }
             }
             WaveSync();
+            stamp(6);
         }
     }
 
