@@ -303,6 +303,32 @@ int oalgpu_set_timing(oalgpu_context *ctx, int enable);
 /* Name of the HIP kernel oalgpu_mix_voices launches for this context (as a profiler shows it). */
 const char *oalgpu_voice_kernel_name(oalgpu_context *ctx);
 
+/* ------------------------------------------------------------------------------------------
+ * Convolution reverb: ConvolutionState (alc/effects/convolution.cpp:253-716) behind
+ * EffectState::deviceUpdate / update / process (core/effects/base.h:197-209), for a mono float
+ * impulse response at the device rate.  The first 128 taps run as a time-domain FIR, the rest
+ * as 128-tap segments in the frequency domain (LDS FFT in place of common/pffft.cpp).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct oalgpu_convolution oalgpu_convolution;
+/* deviceUpdate(device, buffer), convolution.cpp:318-471: num_out_lines = lines of the target
+ * bus (EffectTarget::Main, <= 32). */
+int  oalgpu_convolution_create(int device, uint32_t num_out_lines, const float *ir, uint32_t ir_len,
+    oalgpu_convolution **out);
+void oalgpu_convolution_destroy(oalgpu_convolution *conv);
+/* The result of update(), convolution.cpp:474-621: mChans[0].Target (ComputePanGains of the
+ * response's direction times the slot gain, computed by the caller). */
+int  oalgpu_convolution_set_target_gains(oalgpu_convolution *conv, const float *gains);
+/* process(samplesToDo, samplesIn, samplesOut), convolution.cpp:623-716, host buffers: wet_in =
+ * channel 0 of the slot's wet bus (n samples), out_lines = num_out_lines x 1024, added to. */
+int  oalgpu_convolution_process(oalgpu_convolution *conv, const float *wet_in, float *out_lines, uint32_t n);
+/* The same on device memory, asynchronous on `hip_stream` (NULL = the default stream). */
+int  oalgpu_convolution_process_device(oalgpu_convolution *conv, void *hip_stream, const float *wet_in_dev,
+    float *out_lines_dev, uint32_t n);
+/* Attach to effect slot `slot` of a context: oalgpu_mix_update / oalgpu_post_process then run it
+ * between the bus reduction and the HRTF post-process, from the slot's wet bus (channel 0) into
+ * the dry lines (alc/alu.cpp:2209-2257).  NULL detaches. */
+int  oalgpu_slot_set_convolution(oalgpu_context *ctx, uint32_t slot, oalgpu_convolution *conv);
+
 #ifdef __cplusplus
 }
 #endif

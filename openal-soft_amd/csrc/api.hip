@@ -17,11 +17,12 @@
 #include "../host/mhr.hpp"
 #include "../host/params.hpp"
 #include "../host/tables.hpp"
+#include "api_util.hpp"
 #include "kernels.hpp"
 
 using namespace oalgpu;
 
-namespace {
+namespace oalgpu {
 
 thread_local std::string gLastError;
 
@@ -30,12 +31,6 @@ int Fail(int code, const std::string &msg)
     gLastError = msg;
     return code;
 }
-
-#define HIP_TRY(expr) do { \
-    const hipError_t err_ = (expr); \
-    if(err_ != hipSuccess) \
-        return Fail(OALGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err_)); \
-} while(0)
 
 int UseDevice(int device)
 {
@@ -47,25 +42,9 @@ int UseDevice(int device)
     return OALGPU_OK;
 }
 
-// device scratch that frees itself
-template<typename T>
-struct DevBuf {
-    T *p{nullptr};
-    size_t n{0};
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf &operator=(const DevBuf&) = delete;
-    ~DevBuf() { if(p) (void)hipFree(p); }
-    hipError_t alloc(size_t count)
-    {
-        if(p) { (void)hipFree(p); p = nullptr; }
-        n = count;
-        return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
-    }
-    hipError_t upload(const T *src, size_t count) { return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice); }
-    hipError_t download(T *dst, size_t count) const { return hipMemcpy(dst, p, count * sizeof(T), hipMemcpyDeviceToHost); }
-    hipError_t zero() { return hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)); }
-};
+} // namespace oalgpu
+
+namespace {
 
 // One blob with every resampler table: [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
 struct TableBlob {
@@ -123,6 +102,7 @@ struct oalgpu_context {
     bool hrtfLoaded{false};
     bool carryAccum{true};
     bool useWave{false};                   // FAST HRTF contexts without sends: voice_wave.hip
+    std::vector<oalgpu_convolution*> slotConv;   // per effect slot: attached convolution reverb (not owned)
 
     DevBuf<float> tables;
     DevBuf<BufferItem> buffers;
@@ -394,6 +374,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.hrtf = desc->hrtf ? 1u : 0u;
     L.irSize = 0; L.irStride = 8;
     L.mixLines = mixLines;
+    c->slotConv.assign(desc->num_slots, nullptr);
     uint32_t vpg = desc->voices_per_group;
     if(vpg == 0)
     {
@@ -710,6 +691,21 @@ int oalgpu_voice_set_state(oalgpu_context *c, uint32_t voice, int play_state)
     return OALGPU_OK;
 }
 
+// EffectState::process of every slot that has an effect attached (alc/alu.cpp:2209-2257): from
+// channel 0 of the slot's wet bus into the dry lines, on stream `s`, after the buses are final.
+static int RunEffects(oalgpu_context *c, hipStream_t s, uint32_t samples_to_do)
+{
+    const DeviceLayout &L = c->L;
+    for(uint32_t slot = 0; slot < L.numSlots; ++slot)
+    {
+        oalgpu_convolution *conv = c->slotConv[slot];
+        if(!conv) continue;
+        const float *wet = L.bus + BusWetOffset(L) + size_t{slot} * L.wetChannels * kLine;
+        if(int rc = oalgpu_convolution_process_device(conv, s, wet, L.bus, samples_to_do)) return rc;
+    }
+    return OALGPU_OK;
+}
+
 // Orders the main stream behind whatever a pipelined oalgpu_mix_update left on the post stream.
 static int JoinPost(oalgpu_context *c)
 {
@@ -740,9 +736,10 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
 int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
-    if(!c->L.hrtf) return OALGPU_OK;
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = JoinPost(c)) return rc;
+    if(int rc = RunEffects(c, c->stream, samples_to_do)) return rc;
+    if(!c->L.hrtf) return OALGPU_OK;
     const DeviceLayout &L = c->L;
     if(L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
     float *left = L.bus + size_t{L.numDry} * kLine;
@@ -788,6 +785,7 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
     LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->evReduceDone[p], c->postStream));
+    if(post_process) { if(int rc = RunEffects(c, c->postStream, samples_to_do)) return rc; }
     if(post_process && L.hrtf)
     {
         float *left = L.bus + size_t{L.numDry} * kLine;
@@ -909,6 +907,14 @@ int oalgpu_debug_phase_times(oalgpu_context *c, unsigned long long *out)
     if(!c || !out || !c->phaseTimes.p) return Fail(OALGPU_ERR_INVALID, "phase times were not enabled");
     if(int rc = oalgpu_sync(c)) return rc;
     HIP_TRY(hipMemcpy(out, c->phaseTimes.p, size_t{c->L.numVoices} * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return OALGPU_OK;
+}
+
+int oalgpu_slot_set_convolution(oalgpu_context *c, uint32_t slot, oalgpu_convolution *conv)
+{
+    if(!c || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_convolution: bad slot");
+    if(int rc = oalgpu_sync(c)) return rc;
+    c->slotConv[slot] = conv;
     return OALGPU_OK;
 }
 

@@ -126,6 +126,19 @@ void LaunchGetCoeffs(hipStream_t s, const HrtfStoreDev &st, const float *dirs, u
 void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, float *accum,
     SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n);
 
+// ---- launcher (conv_kernels.hip): ConvolutionState::process for a mono response ----
+struct ConvLayoutHost {
+    uint32_t numSegs, ringSlots, nlines, n, fifoPos, curSeg, numBlocks, numChunks, segsPerChunk;
+    const float *wetIn;
+    float *xhist, *ring;
+    const float *filt, *fir;
+    float *outFifo, *partial, *cur;
+    const float *tgt;
+    float *outLines;
+    const float *tw128, *tw256;
+};
+void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
+
 // ---- launchers (voice_kernel.hip) ----
 void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);
 void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev &st, const ParamRecord *recs,

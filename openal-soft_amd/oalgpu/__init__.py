@@ -429,3 +429,37 @@ class Scene:
         a, b = C.c_float(), C.c_float()
         check(lib.oalgpu_last_update_ms(self.h, C.byref(a), C.byref(b)), "oalgpu_last_update_ms")
         return a.value, b.value
+
+
+class Convolution:
+    """oalgpu_convolution: ConvolutionState (alc/effects/convolution.cpp) for a mono response."""
+
+    def __init__(self, num_out_lines, ir, device=0):
+        lib.oalgpu_convolution_create.argtypes = [C.c_int, C.c_uint32, f32p, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.oalgpu_convolution_destroy.argtypes = [C.c_void_p]
+        lib.oalgpu_convolution_destroy.restype = None
+        lib.oalgpu_convolution_set_target_gains.argtypes = [C.c_void_p, f32p]
+        lib.oalgpu_convolution_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
+        lib.oalgpu_slot_set_convolution.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        self.nlines = num_out_lines
+        ir = np.ascontiguousarray(ir, np.float32)
+        h = C.c_void_p()
+        check(lib.oalgpu_convolution_create(device, num_out_lines, _fp(ir), ir.size, C.byref(h)),
+              "oalgpu_convolution_create")
+        self.h = h
+
+    def set_target_gains(self, gains):
+        g = np.zeros(MAX_OUT, np.float32)
+        g[:len(gains)] = gains
+        check(lib.oalgpu_convolution_set_target_gains(self.h, _fp(g)))
+
+    def process(self, wet_in, out_lines):
+        wet_in = np.ascontiguousarray(wet_in, np.float32)
+        assert out_lines.dtype == np.float32 and out_lines.shape == (self.nlines, BUFFER_LINE)
+        check(lib.oalgpu_convolution_process(self.h, _fp(wet_in), _fp(out_lines), wet_in.size),
+              "oalgpu_convolution_process")
+
+    def close(self):
+        if self.h:
+            lib.oalgpu_convolution_destroy(self.h)
+            self.h = None

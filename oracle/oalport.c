@@ -1574,3 +1574,105 @@ int oal_scene_set_direct_hrtf(oal_scene *s, const float *chan_coeffs, const floa
     memcpy(s->dcoeffs, chan_coeffs, (size_t)s->desc.num_dry_channels * HRIR_LEN * 2 * sizeof(float));
     return 0;
 }
+
+/* ======================================================================== *
+ * Convolution reverb  (ConvolutionState, alc/effects/convolution.cpp:253-716)
+ *
+ * The reference splits the impulse response into 128-tap segments: segment 0 is
+ * applied in the time domain (apply_fir :205-250, over mInput :260), segments
+ * 1.. in the frequency domain (256-point pffft, spectra pre-scaled and
+ * z-reordered at setup :411-470, accumulated per completed 128-sample input
+ * block :672-709), whose result is overlap-added one block later (:644-652,
+ * :701-707).  The sum of all of it is the linear convolution of the wet input
+ * with the impulse response, sample for sample; this restatement keeps segment 0
+ * as the float dot product of apply_fir's scalar variant and evaluates the other
+ * segments as one double-precision dot product per output sample, so it agrees
+ * with the compiled reference to float rounding (pinned with a tolerance in
+ * tests/test_oracle_pin.py, not bit-for-bit: the FFT order is not restated).
+ * update (:474-621) for a mono response: the channel is panned straight ahead,
+ * Target[i] = AmbiMap[i].Scale * coeffs[AmbiMap[i].Index] * slot gain
+ * (ComputePanGains core/mixer.cpp:103-112) with an identity map; process ends
+ * with MixSamples(chan buffer, out, Current, Target, Counter = samplesToDo)
+ * (NormalMix :298-304).  Same-rate responses only (the polyphase resampler of
+ * :356-362,419-426 is a setup step this restatement leaves to the reference).
+ * ======================================================================== */
+#define CONV_SEG 128
+struct oal_conv {
+    unsigned nlines, irlen;
+    float *ir;              /* device-rate impulse response */
+    float *hist;            /* the last irlen input samples, oldest first */
+    float cur[OAL_MAX_AMBI_CHANNELS], tgt[OAL_MAX_AMBI_CHANNELS];
+};
+
+/* CalcAmbiCoeffs(y, z, x) up to first order (core/ambidefs.h: ACN order, N3D scaling);
+ * the callers in scope pan into first-order buses. */
+void oal_calc_direction_coeffs(const float dir[3], float spread, float *out25)
+{
+    const float y = -dir[0], z = dir[1], x = -dir[2];   /* CalcDirectionCoeffs, core/mixer.h:68-73 */
+    memset(out25, 0, 25 * sizeof(float));
+    out25[0] = 1.0f;
+    out25[1] = 1.732050808f * y;
+    out25[2] = 1.732050808f * z;
+    out25[3] = 1.732050808f * x;
+    if(spread > 0.0f)
+    {   /* core/mixer.cpp:20-62 */
+        const float ca = cosf(spread * 0.5f);
+        const float scale = sqrtf(1.0f + 0.318309886183790671538f * 0.5f * spread);
+        const float zh1 = scale * 0.5f * (ca + 1.0f);
+        out25[0] *= scale; out25[1] *= zh1; out25[2] *= zh1; out25[3] *= zh1;
+    }
+}
+
+oal_conv *oal_conv_create(uint32_t sample_rate, uint32_t num_out_lines, const float *ir,
+    uint32_t ir_len, uint32_t ir_rate)
+{
+    if(sample_rate != ir_rate || ir_len < 1 || num_out_lines > OAL_MAX_AMBI_CHANNELS) return NULL;
+    oal_conv *c = (oal_conv*)calloc(1, sizeof(*c));
+    c->nlines = num_out_lines;
+    c->irlen = ir_len;
+    c->ir = (float*)malloc(ir_len * sizeof(float));
+    memcpy(c->ir, ir, ir_len * sizeof(float));
+    c->hist = (float*)calloc(ir_len, sizeof(float));
+    return c;
+}
+
+void oal_conv_update(oal_conv *c, float slot_gain)
+{
+    static const float front[3] = {0.0f, 0.0f, -1.0f};  /* MonoMap, convolution.cpp:153 */
+    float coeffs[25];
+    oal_calc_direction_coeffs(front, 0.0f, coeffs);
+    memset(c->tgt, 0, sizeof(c->tgt));
+    for(unsigned i = 0; i < c->nlines; ++i) c->tgt[i] = 1.0f * coeffs[i] * slot_gain;
+}
+
+void oal_conv_process(oal_conv *c, const float *wet_in, float *out_lines, uint32_t n)
+{
+    const unsigned csr = fpu_enter();
+    float buf[LINE];
+    const unsigned L = c->irlen;
+    /* timeline = [hist (L samples) | wet_in (n samples)] */
+    float *tl = (float*)malloc((L + n) * sizeof(float));
+    memcpy(tl, c->hist, L * sizeof(float));
+    memcpy(tl + L, wet_in, n * sizeof(float));
+    for(uint32_t i = 0; i < n; ++i)
+    {
+        const float *x = tl + L + i;                 /* x[0] = current sample, x[-k] = k samples ago */
+        float fir = 0.0f;                            /* apply_fir, convolution.cpp:240-248 */
+        const unsigned first = L < CONV_SEG ? L : CONV_SEG;
+        for(unsigned j = CONV_SEG - first; j < CONV_SEG; ++j)   /* filter[j] = ir[127-j], input[j] = x[j-127] */
+            fir += x[(int)j - (CONV_SEG - 1)] * c->ir[CONV_SEG - 1 - j];
+        double tail = 0.0;
+        for(unsigned k = CONV_SEG; k < L; ++k) tail += (double)c->ir[k] * (double)x[-(int)k];
+        buf[i] = fir + (float)tail;
+    }
+    memcpy(c->hist, tl + n, L * sizeof(float));
+    free(tl);
+    mix_lines(buf, n, out_lines, c->nlines, c->cur, c->tgt, n, 0);   /* NormalMix :298-304 */
+    fpu_leave(csr);
+}
+
+void oal_conv_destroy(oal_conv *c)
+{
+    if(!c) return;
+    free(c->ir); free(c->hist); free(c);
+}

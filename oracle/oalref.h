@@ -214,6 +214,21 @@ int oal_scene_voice_state(oal_scene *s, int voice, oal_voice_state *out);
 int oal_scene_set_direct_hrtf(oal_scene *s, const float *chan_coeffs, const float *hfscales,
     float xover_norm, uint32_t irsize);
 
+/* ---- convolution reverb: ConvolutionState, alc/effects/convolution.cpp:253-716 ----
+ * A mono float impulse response at ir_rate is installed with deviceUpdate (:318-471: resampled
+ * to the device rate when the rates differ, first 128 taps kept as a time-domain FIR, the rest as
+ * 128-tap segments in the frequency domain); update (:474-621) pans the mono channel straight
+ * ahead into `num_out_lines` ambisonic lines (identity AmbiMap) with the slot gain; process
+ * (:623-716) consumes channel 0 of the wet bus and ADDS into out_lines (num_out_lines x 1024). */
+typedef struct oal_conv oal_conv;
+oal_conv *oal_conv_create(uint32_t sample_rate, uint32_t num_out_lines, const float *ir,
+    uint32_t ir_len, uint32_t ir_rate);
+void oal_conv_update(oal_conv *c, float slot_gain);
+void oal_conv_process(oal_conv *c, const float *wet_in, float *out_lines, uint32_t n);
+void oal_conv_destroy(oal_conv *c);
+/* CalcDirectionCoeffs(dir, spread), core/mixer.h:68: ambisonic coefficients (ACN/N3D, 25). */
+void oal_calc_direction_coeffs(const float dir[3], float spread, float *out25);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@
 #include "oalref.h"
 
 #include "alc/alu.h"
+#include "alc/effects/base.h"
+#include "core/effects/base.h"
 
 namespace {
 
@@ -672,6 +674,77 @@ int oal_scene_set_direct_hrtf(oal_scene *s, const float *chan_coeffs, const floa
             sizeof(HrirArray));
     }
     return 0;
+}
+
+/* ---- convolution reverb ---- */
+} // extern "C" (reopened below)
+
+struct oal_conv {
+    std::unique_ptr<Dev> dev;
+    std::unique_ptr<Ctx> ctx;
+    EffectSlotBase slot;
+    al::intrusive_ptr<EffectState> state;
+    std::vector<float> ir;
+    BufferStorage storage;
+    EffectProps props;
+    std::array<FloatBufferLine, 1> wet{};
+};
+
+extern "C" {
+
+oal_conv *oal_conv_create(uint32_t sample_rate, uint32_t num_out_lines, const float *ir,
+    uint32_t ir_len, uint32_t ir_rate)
+{
+    ApplySimd();
+    auto c = std::make_unique<oal_conv>();
+    c->dev = std::make_unique<Dev>();
+    auto &dev = *c->dev;
+    dev.mSampleRate = sample_rate;
+    dev.mUpdateSize = BufferLineSize;
+    dev.mBufferSize = BufferLineSize;
+    dev.FmtType = DevFmtFloat;
+    dev.mAmbiOrder = 1;
+    dev.MixBuffer.resize(num_out_lines);
+    dev.Dry.Buffer = std::span{dev.MixBuffer};
+    dev.RealOut.Buffer = dev.Dry.Buffer;
+    for(uint32_t i{0};i < num_out_lines;++i) dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, i};
+    c->ctx = std::make_unique<Ctx>(c->dev.get());
+    c->ir.assign(ir, ir + ir_len);
+    c->storage.mData = std::span<f32>{reinterpret_cast<f32*>(c->ir.data()), c->ir.size()};
+    c->storage.mSampleRate = ir_rate;
+    c->storage.mChannels = FmtMono;
+    c->storage.mType = FmtFloat;
+    c->storage.mSampleLen = ir_len;
+    c->state = ConvolutionStateFactory_getFactory()->create();
+    c->state->deviceUpdate(c->dev.get(), &c->storage);
+    c->props = ConvolutionProps{{0.0f, 0.0f, -1.0f}, {0.0f, 1.0f, 0.0f}};
+    return c.release();
+}
+
+void oal_conv_update(oal_conv *c, float slot_gain)
+{
+    c->slot.Gain = slot_gain;
+    c->state->update(c->ctx.get(), &c->slot, &c->props, EffectTarget{&c->dev->Dry, &c->dev->RealOut});
+}
+
+void oal_conv_process(oal_conv *c, const float *wet_in, float *out_lines, uint32_t n)
+{
+    auto const fpuctl = FPUCtl{};
+    auto &dev = *c->dev;
+    std::copy_n(wet_in, n, c->wet[0].begin());
+    for(size_t l{0};l < dev.MixBuffer.size();++l)
+        std::copy_n(out_lines + l*BufferLineSize, BufferLineSize, dev.MixBuffer[l].begin());
+    c->state->process(n, c->wet, c->state->mOutTarget);
+    for(size_t l{0};l < dev.MixBuffer.size();++l)
+        std::copy_n(dev.MixBuffer[l].begin(), BufferLineSize, out_lines + l*BufferLineSize);
+}
+
+void oal_conv_destroy(oal_conv *c) { delete c; }
+
+void oal_calc_direction_coeffs(const float dir[3], float spread, float *out25)
+{
+    auto const coeffs = CalcDirectionCoeffs(std::span<const float,3>{dir, 3}, spread);
+    std::copy(coeffs.begin(), coeffs.end(), out25);
 }
 
 } // extern "C"

@@ -183,10 +183,26 @@ class OracleLib:
         L.oal_scene_wet.restype = f32p
         L.oal_scene_voice_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(VoiceState)]
         L.oal_scene_set_direct_hrtf.argtypes = [C.c_void_p, f32p, f32p, C.c_float, C.c_uint32]
+        L.oal_conv_create.restype = C.c_void_p
+        L.oal_conv_create.argtypes = [C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_uint32]
+        L.oal_conv_update.argtypes = [C.c_void_p, C.c_float]
+        L.oal_conv_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
+        L.oal_conv_destroy.argtypes = [C.c_void_p]
+        L.oal_calc_direction_coeffs.argtypes = [f32p, C.c_float, f32p]
         self.kind = L.oal_kind().decode()
 
     def make_scene(self, **kw):
         return Scene(self, **kw)
+
+    # ---- convolution reverb (ConvolutionState, alc/effects/convolution.cpp) ----
+    def make_convolution(self, num_out_lines, ir, sample_rate=48000, ir_rate=None):
+        return Convolution(self, num_out_lines, ir, sample_rate, ir_rate or sample_rate)
+
+    def direction_coeffs(self, direction, spread=0.0):
+        d = np.ascontiguousarray(direction, np.float32)
+        out = np.zeros(25, np.float32)
+        self.L.oal_calc_direction_coeffs(_fp(d), spread, _fp(out))
+        return out
 
     # ---- tables ----
     def bsinc_table(self, which):
@@ -339,6 +355,30 @@ class Scene:
         st = VoiceState()
         assert self.lib.L.oal_scene_voice_state(self.h, voice, C.byref(st)) == 0
         return st
+
+
+class Convolution:
+    """EffectState-shaped handle: update(slot_gain) then process(wet_in, out_lines)."""
+
+    def __init__(self, lib, num_out_lines, ir, sample_rate, ir_rate):
+        self.lib = lib
+        self.nlines = num_out_lines
+        ir = np.ascontiguousarray(ir, np.float32)
+        self.h = lib.L.oal_conv_create(sample_rate, num_out_lines, _fp(ir), ir.size, ir_rate)
+        assert self.h, "oal_conv_create failed"
+
+    def update(self, slot_gain):
+        self.lib.L.oal_conv_update(self.h, slot_gain)
+
+    def process(self, wet_in, out_lines):
+        wet_in = np.ascontiguousarray(wet_in, np.float32)
+        assert out_lines.dtype == np.float32 and out_lines.shape == (self.nlines, BUFFER_LINE)
+        self.lib.L.oal_conv_process(self.h, _fp(wet_in), _fp(out_lines), wet_in.size)
+
+    def close(self):
+        if self.h:
+            self.lib.L.oal_conv_destroy(self.h)
+            self.h = None
 
 
 REF_PATH = os.path.join(ROOT, "oracle", "_ref", "liboalref.so")
