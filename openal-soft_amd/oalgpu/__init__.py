@@ -384,6 +384,10 @@ class Scene:
         check(lib.oalgpu_set_direct_hrtf(self.h, _fp(cc), _fp(hf), xover_norm, irsize),
               "oalgpu_set_direct_hrtf")
 
+    def set_slot_convolution(self, slot, conv):
+        lib.oalgpu_slot_set_convolution.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        check(lib.oalgpu_slot_set_convolution(self.h, slot, conv.h if conv is not None else None))
+
     def mix(self, samples_to_do=BUFFER_LINE, post_process=False):
         check(lib.oalgpu_mix_update(self.h, samples_to_do, 1 if post_process else 0),
               "oalgpu_mix_update")

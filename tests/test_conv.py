@@ -107,3 +107,49 @@ def test_gpu_matches_reference_golden(golden):
         assert np.all(y[[1, 2]] == 0.125)
     y = conv_cases.run_case(lambda nl, ir: oalgpu.Convolution(nl, ir), front, conv_cases.BIG_CASE, is_product=True)
     close(y[0, -1024:], golden[conv_cases.BIG_CASE[0]], "gpu vs golden 65536 taps")
+
+
+@pytest.mark.gpu
+def test_gpu_slot_convolution_in_scene(synth_mhr):
+    """A convolution attached to an effect slot: oalgpu_mix_update feeds it channel 0 of the
+    slot's wet bus and it adds into the dry lines (alc/alu.cpp:2209-2257).  Expected = the oracle
+    scene's wet bus pushed through the oracle's ConvolutionState into the oracle's dry bus."""
+    oalgpu = _gpu()
+    from scenes import SCENES
+    which = "ref" if ol.available("ref") else "port"
+    L = ol.load(which)
+    L.L.oal_set_simd(1)
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    rng = np.random.default_rng(77)
+    ir = (rng.standard_normal(3000) * np.exp(-np.arange(3000) / 500.0) * 0.1).astype(np.float32)
+    front = L.direction_coeffs([0.0, 0.0, -1.0])
+    nlines = 5
+
+    def build(lib):
+        sc = lib.make_scene(num_dry=nlines, num_real=0, num_sends=1, num_slots=1, wet_channels=4, hrtf=False)
+        r = np.random.default_rng(5)
+        buf = sc.add_buffer(r.uniform(-1, 1, 9000).astype(np.float32), ol.FMT_FLOAT, loop_start=0, loop_end=9000)
+        for v in range(6):
+            sc.add_voice(buf, looping=True, position=(v * 977) % 8000, frac=0)
+            snd = [(0, r.uniform(0.05, 0.3, 4), ol.default_filter(active=0))]
+            sc.set_params(v, ol.make_voice_params(60211, ol.RS_BSINC24, dry_gains=r.uniform(0, 0.1, nlines),
+                                                  direct_filter=ol.default_filter(active=0), sends=snd))
+        return sc
+
+    gsc = build(api)
+    conv = oalgpu.Convolution(nlines, ir)
+    conv.set_target_gains(front[:nlines] * 0.8)
+    gsc.set_slot_convolution(0, conv)
+    osc = build(L)
+    oconv = L.make_convolution(nlines, ir)
+    oconv.update(0.8)
+    for k in range(4):
+        n = (1024, 1000, 1024, 300)[k]
+        gsc.mix(n, post_process=True)
+        got = gsc.dry()
+        osc.mix(n, post_process=False)
+        want = osc.dry().copy()
+        oconv.process(osc.wet(0)[0, :n], want)
+        close(got[:, :n], want[:, :n], f"scene + slot convolution, update {k}")
+    gsc.set_slot_convolution(0, None)
+    conv.close(); oconv.close(); gsc.close(); osc.close()
