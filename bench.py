@@ -140,26 +140,17 @@ def main():
     total_steps = args.warmup + 2 * args.steps
     blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(total_steps)]
 
-    bus_t = None
+    mixer = None
     if world > 1:
-        stream = torch.cuda.current_stream()
-        sc.set_stream(stream.cuda_stream)
-        ptr, nfloats, _ = sc.bus_device_ptr()
-
-        class _Bus:
-            __cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-        bus_t = torch.as_tensor(_Bus(), device=f"cuda:{local_rank}")
-        sc.set_carry_accum(rank == 0)
+        from oalgpu.shard import GpuEngine, ShardedMixer
+        mixer = ShardedMixer(GpuEngine(sc, torch, local_rank, torch.cuda.current_stream()), dist, rank, world)
 
     def step(k):
         sc.apply_block(blocks[k])
-        if world == 1:
+        if mixer is None:
             sc.mix(UPDATE_SAMPLES, post_process=hrtf)
         else:
-            sc.mix_voices(UPDATE_SAMPLES)
-            dist.reduce(bus_t, dst=0, op=dist.ReduceOp.SUM)       # one RCCL reduce of the mix buses
-            if rank == 0:
-                sc.post_process(UPDATE_SAMPLES)
+            mixer.update(UPDATE_SAMPLES)          # partial buses, one RCCL reduce, post-process on rank 0
 
     def fence():
         if dist is not None:

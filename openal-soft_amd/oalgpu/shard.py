@@ -1,0 +1,59 @@
+"""Voice sharding across the GPUs of one node: voices are independent given
+their parameters, so every rank owns a contiguous shard of them and mixes it into PARTIAL buses;
+the only exchange is one sum-reduce of the bus block [dry+real lines | wet buses | HrtfAccumData]
+to rank 0 per update (RCCL over xGMI on the GPU box, ~41 KB), after which rank 0 -- the only rank
+that carries the HRTF accumulator tail between updates -- runs the effects and the HRTF
+post-process (alc/alu.cpp:2209-2257, :289-298) on the summed buses.
+
+The orchestration is backend-agnostic: ``engine`` is anything with
+    set_carry(bool) / mix_voices(n) / bus_tensor() -> torch tensor aliasing the bus block /
+    post_process(n)
+bench.py passes the HIP context (GpuEngine, nccl); tests/test_multi_rank.py passes the CPU oracle
+(gloo, world_size 2) to check the scheme itself against an unsharded scene."""
+
+
+def shard_range(total_voices, rank, world):
+    """Contiguous, near-equal shards: rank r owns [lo, hi)."""
+    base, extra = divmod(total_voices, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardedMixer:
+    def __init__(self, engine, dist=None, rank=0, world=1):
+        self.engine, self.dist, self.rank, self.world = engine, dist, rank, world
+        engine.set_carry(rank == 0)
+
+    def update(self, samples_to_do):
+        e = self.engine
+        e.mix_voices(samples_to_do)
+        if self.world > 1:
+            self.dist.reduce(e.bus_tensor(), dst=0, op=self.dist.ReduceOp.SUM)
+        if self.rank == 0:
+            e.post_process(samples_to_do)
+
+
+class GpuEngine:
+    """The HIP context behind the ShardedMixer interface.  ``torch_stream`` is the stream RCCL is
+    ordered on; the context runs on it too (oalgpu_set_stream), so no extra synchronisation."""
+
+    def __init__(self, scene, torch, device_index, torch_stream):
+        self.sc = scene
+        scene.set_stream(torch_stream.cuda_stream)
+        ptr, nfloats, _ = scene.bus_device_ptr()
+
+        class _Bus:
+            __cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        self._bus = torch.as_tensor(_Bus(), device=f"cuda:{device_index}")
+
+    def set_carry(self, on):
+        self.sc.set_carry_accum(on)
+
+    def mix_voices(self, n):
+        self.sc.mix_voices(n)
+
+    def bus_tensor(self):
+        return self._bus
+
+    def post_process(self, n):
+        self.sc.post_process(n)

@@ -1,0 +1,58 @@
+"""Voice sharding over ranks on CPU: two gloo processes run the
+orchestration bench.py uses on GPUs (oalgpu.shard.ShardedMixer: partial buses per rank, ONE
+sum-reduce of the bus block, effects + HRTF post-process on rank 0 which alone carries the
+accumulator tail) with the CPU oracle as each rank's mixer, and rank 0 checks the result against
+the same scene mixed unsharded.  Also the shard arithmetic itself."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "openal-soft_amd"))
+
+
+def test_shard_range_partitions_voices():
+    from oalgpu.shard import shard_range
+    for total in (0, 1, 7, 22, 4096, 32768):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_scene_matches_unsharded(synth_mhr, world):
+    if not ol.available("port"):
+        pytest.skip("oracle/liboalport.so not built")
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OAL_TEST_MHR=synth_mhr, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "multi_rank_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out}"
+    assert "update 3" in outs[0]
