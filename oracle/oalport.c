@@ -1676,3 +1676,495 @@ void oal_conv_destroy(oal_conv *c)
     if(!c) return;
     free(c->ir); free(c->hist); free(c);
 }
+
+/* ======================================================================== *
+ * EAX reverb: ReverbState::process and what it calls, alc/effects/reverb.cpp.
+ * The parameter side (ReverbState::update) is NOT restated here: the block the compiled
+ * reference computed (oal_reverb_get_params) -- or the product host's -- is installed with
+ * oal_reverb_set_params, following which fields update() touches (:1263-1350).
+ * ======================================================================== */
+#define RV_LINES 4
+#define RV_MAX_UPDATE 256            /* MAX_UPDATE_SAMPLES, reverb.cpp:68 */
+#define RV_MOD_FRACBITS 24
+#define RV_MOD_FRACONE (1u << RV_MOD_FRACBITS)
+#define RV_MOD_FRACMASK (RV_MOD_FRACONE - 1u)
+#define RV_CUBIC_BITS 8              /* CubicFilter::sTableBits, core/cubic_tables.h:23-25 */
+#define RV_CUBIC_STEPS (1u << RV_CUBIC_BITS)
+#define RV_CUBIC_MASK (RV_CUBIC_STEPS - 1u)
+enum { RV_DEVICE_CLEAR, RV_START_FADE, RV_FADING, RV_CLEANUP, RV_NORMAL };   /* reverb.cpp:589-595 */
+
+static float g_rv_cubic[RV_CUBIC_STEPS * 2 + 1];
+static int g_rv_cubic_ready;
+static void rv_cubic_build(void) /* CubicFilter::CubicFilter, core/cubic_tables.cpp:109-128 */
+{
+    if(g_rv_cubic_ready) return;
+    const double index_scale = 512.0 / (double)(RV_CUBIC_STEPS * 2);
+    for(unsigned i = 0; i < RV_CUBIC_STEPS / 2 + 1; ++i)
+    {
+        const double c0 = gauss_coeff((double)(RV_CUBIC_STEPS + i) * index_scale);
+        const double c1 = gauss_coeff((double)i * index_scale);
+        const double c2 = gauss_coeff((double)(RV_CUBIC_STEPS - i) * index_scale);
+        const double c3 = gauss_coeff((double)(RV_CUBIC_STEPS * 2 - i) * index_scale);
+        const double scale = 1.0 / (c0 + c1 + c2 + c3);
+        g_rv_cubic[RV_CUBIC_STEPS + i] = (float)(c0 * scale);
+        g_rv_cubic[i] = (float)(c1 * scale);
+        g_rv_cubic[RV_CUBIC_STEPS - i] = (float)(c2 * scale);
+        g_rv_cubic[RV_CUBIC_STEPS * 2 - i] = (float)(c3 * scale);
+    }
+    g_rv_cubic_ready = 1;
+}
+int oal_reverb_cubic_table(float *out513)
+{
+    rv_cubic_build();
+    memcpy(out513, g_rv_cubic, sizeof(g_rv_cubic));
+    return 0;
+}
+
+typedef struct rv_line { float *buf; size_t stride; } rv_line;     /* DelayLineU / DelayLineI: 4 lines */
+typedef struct rv_bq { oal_bq c; float z1, z2; } rv_bq;            /* BiquadFilter */
+typedef struct rv_gains { float cur[OAL_MAX_AMBI_CHANNELS], tgt[OAL_MAX_AMBI_CHANNELS]; } rv_gains;
+
+typedef struct rv_pipeline {                                       /* ReverbPipeline, reverb.cpp:502-565 */
+    rv_bq lp[RV_LINES], hp[RV_LINES];
+    rv_line late_in;
+    size_t early_tap[RV_LINES][2]; float early_coeff[2];
+    size_t late_tap[RV_LINES][2];
+    float mix_x, mix_y;
+    rv_line eap; float eap_coeff; size_t eap_off[RV_LINES];        /* mEarly.Allpass */
+    rv_line edelay; size_t e_off[RV_LINES]; float e_coeff;         /* mEarly.Delay/Offset/Coeff */
+    rv_gains egains[RV_LINES];
+    rv_line ldelay; size_t l_off[RV_LINES]; float density_gain;    /* mLate */
+    float mid_gain[RV_LINES]; rv_bq t60hf[RV_LINES], t60lf[RV_LINES];
+    unsigned mod_index, mod_step; float mod_depth;
+    unsigned mod_delays[RV_MAX_UPDATE];
+    rv_line vap; float vap_coeff; size_t vap_off[RV_LINES];        /* mLate.VecAp (interleaved line) */
+    rv_gains lgains[RV_LINES];
+    size_t fade_count;
+} rv_pipeline;
+
+struct oal_reverb {
+    unsigned nlines;
+    float *samples; size_t total;
+    uint32_t lengths[11];
+    int state, current;
+    rv_line main_delay;
+    rv_pipeline pipe[2];
+    size_t offset;
+    float temp[RV_LINES][RV_MAX_UPDATE];
+    float early[RV_LINES][LINE], late[RV_LINES][LINE];
+};
+
+static unsigned rv_next_pow2(unsigned v) /* NextPowerOf2, common/alnumeric.h */
+{
+    if(v > 0) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; }
+    return v + 1;
+}
+static size_t rv_line_length(float length, float frequency, unsigned extra) /* calcLineLength :273-284 */
+{ return (size_t)rv_next_pow2(float2uint(ceilf(length * frequency)) + extra) * RV_LINES; }
+
+static const float RV_EARLY_TAP[4] = {0.000000e+0f, 1.010676e-3f, 2.126553e-3f, 3.358580e-3f};
+static const float RV_EARLY_AP[4] = {4.854840e-4f, 5.360178e-4f, 5.918117e-4f, 6.534130e-4f};
+static const float RV_EARLY_LINE[4] = {2.992520e-3f, 5.456575e-3f, 7.688329e-3f, 9.709681e-3f};
+static const float RV_LATE_AP[4] = {8.091400e-4f, 1.019453e-3f, 1.407968e-3f, 1.618280e-3f};
+static const float RV_LATE_LINE[4] = {9.709681e-3f, 1.223343e-2f, 1.689561e-2f, 1.941936e-2f};
+
+static void rv_pipeline_clear(rv_pipeline *p) /* ReverbPipeline::clear :550-564 */
+{
+    memset(p->late_in.buf, 0, p->late_in.stride * RV_LINES * sizeof(float));
+    for(int j = 0; j < RV_LINES; ++j) { p->lp[j].z1 = p->lp[j].z2 = p->hp[j].z1 = p->hp[j].z2 = 0.0f; }
+    memset(p->early_tap, 0, sizeof(p->early_tap));
+    p->early_coeff[0] = p->early_coeff[1] = 0.0f;
+    memset(p->late_tap, 0, sizeof(p->late_tap));
+    memset(p->eap.buf, 0, p->eap.stride * RV_LINES * sizeof(float));
+    memset(p->edelay.buf, 0, p->edelay.stride * RV_LINES * sizeof(float));
+    memset(p->egains, 0, sizeof(p->egains));
+    memset(p->vap.buf, 0, p->vap.stride * RV_LINES * sizeof(float));
+    memset(p->ldelay.buf, 0, p->ldelay.stride * RV_LINES * sizeof(float));
+    for(int j = 0; j < RV_LINES; ++j) { p->t60hf[j].z1 = p->t60hf[j].z2 = p->t60lf[j].z1 = p->t60lf[j].z2 = 0.0f; }
+    p->mod_index = 0u; p->mod_step = 1u; p->mod_depth = 0.0f;
+    memset(p->lgains, 0, sizeof(p->lgains));
+}
+
+oal_reverb *oal_reverb_create(uint32_t sample_rate, uint32_t num_out_lines)
+{
+    if(num_out_lines > OAL_MAX_AMBI_CHANNELS) return NULL;
+    rv_cubic_build();
+    oal_reverb *r = (oal_reverb*)calloc(1, sizeof(*r));
+    r->nlines = num_out_lines;
+    /* allocLines, reverb.cpp:728-820 */
+    const float frequency = (float)sample_rate;
+    const float multiplier = fmaxf(1.0f, cbrtf(1.0f * 1000.0f));
+    const float max_mod_delay = 4.0f * 0.05f / 2.0f;
+    const unsigned late_vecap_extra = float2uint(ceilf(RV_LATE_AP[0] * multiplier * frequency));
+    const float late_diff_avg = (RV_LATE_LINE[3] - RV_LATE_LINE[0]) / 4.0f;
+    size_t k = 0;
+    r->lengths[k++] = (uint32_t)rv_line_length(0.3f + RV_EARLY_TAP[3] * multiplier, frequency, LINE);
+    for(int p = 0; p < 2; ++p)
+    {
+        r->lengths[k++] = (uint32_t)rv_line_length(0.1f + late_diff_avg * multiplier, frequency, LINE);
+        r->lengths[k++] = (uint32_t)rv_line_length(RV_EARLY_AP[3] * multiplier, frequency, 0);
+        r->lengths[k++] = (uint32_t)rv_line_length(RV_EARLY_LINE[3] * multiplier, frequency, RV_MAX_UPDATE);
+        r->lengths[k++] = (uint32_t)rv_line_length(RV_LATE_AP[3] * multiplier, frequency, late_vecap_extra);
+        r->lengths[k++] = (uint32_t)rv_line_length(RV_LATE_LINE[3] * multiplier + max_mod_delay, frequency, 4);
+    }
+    for(k = 0; k < 11; ++k) r->total += r->lengths[k];
+    r->samples = (float*)calloc(r->total, sizeof(float));
+    float *at = r->samples;
+    k = 0;
+#define RV_TAKE(line) do { (line).buf = at; (line).stride = r->lengths[k] / RV_LINES; at += r->lengths[k++]; } while(0)
+    RV_TAKE(r->main_delay);
+    for(int p = 0; p < 2; ++p)
+    {
+        RV_TAKE(r->pipe[p].late_in); RV_TAKE(r->pipe[p].eap); RV_TAKE(r->pipe[p].edelay);
+        RV_TAKE(r->pipe[p].vap); RV_TAKE(r->pipe[p].ldelay);
+    }
+#undef RV_TAKE
+    /* deviceUpdate :829-833; constructor defaults of ReverbPipeline (:526-535) and BiquadFilter */
+    for(int p = 0; p < 2; ++p)
+    {
+        rv_pipeline *P = &r->pipe[p];
+        rv_pipeline_clear(P);
+        P->mix_x = 1.0f; P->mix_y = 0.0f; P->fade_count = 1;
+        for(int j = 0; j < RV_LINES; ++j)
+            P->lp[j].c.b0 = P->hp[j].c.b0 = P->t60hf[j].c.b0 = P->t60lf[j].c.b0 = 1.0f;
+    }
+    r->state = RV_DEVICE_CLEAR;
+    r->current = 0;
+    return r;
+}
+
+void oal_reverb_destroy(oal_reverb *r) { if(r) { free(r->samples); free(r); } }
+
+int oal_reverb_update(oal_reverb *r, const oal_reverb_props *props, float slot_gain)
+{ (void)r; (void)props; (void)slot_gain; return -1; }
+
+int oal_reverb_get_params(oal_reverb *r, oal_reverb_params *out) { (void)r; (void)out; return -1; }
+
+int oal_reverb_line_lengths(oal_reverb *r, uint32_t *lengths11)
+{
+    memcpy(lengths11, r->lengths, sizeof(r->lengths));
+    return (int)r->total;
+}
+
+/* What ReverbState::update writes (:1263-1350).  A toggled current_pipeline means the update was
+ * a full one: the state becomes StartFade/Normal and the old pipeline's early coefficient target
+ * drops to 0 (:1275-1279).  Only the current pipeline's parameters are replaced; everything
+ * process() itself mutates (taps[.][0], gains.Current, the old pipeline's targets and fade count)
+ * is left alone. */
+int oal_reverb_set_params(oal_reverb *r, const oal_reverb_params *q)
+{
+    if(q->current_pipeline != r->current)
+    {
+        r->state = q->pipeline_state;
+        r->current = q->current_pipeline;
+        r->pipe[!r->current].early_coeff[1] = 0.0f;
+    }
+    rv_pipeline *P = &r->pipe[r->current];
+    const oal_reverb_pipeline *s = &q->pipe[r->current];
+    for(int j = 0; j < RV_LINES; ++j)
+    {
+        P->lp[j].c = s->filter_lp; P->hp[j].c = s->filter_hp;
+        P->early_tap[j][1] = s->early_delay_tap[j][1];
+        P->late_tap[j][1] = s->late_delay_tap[j][1];
+        P->eap_off[j] = s->early_ap_offset[j];
+        P->e_off[j] = s->early_offset[j];
+        P->l_off[j] = s->late_offset[j];
+        P->vap_off[j] = s->late_ap_offset[j];
+        P->mid_gain[j] = s->t60_mid_gain[j];
+        P->t60hf[j].c = s->t60_hf[j]; P->t60lf[j].c = s->t60_lf[j];
+        memcpy(P->egains[j].tgt, s->early_gains_target[j], sizeof(P->egains[j].tgt));
+        memcpy(P->lgains[j].tgt, s->late_gains_target[j], sizeof(P->lgains[j].tgt));
+    }
+    P->early_coeff[1] = s->early_delay_coeff[1];
+    P->mix_x = s->mix_x; P->mix_y = s->mix_y;
+    P->eap_coeff = s->early_ap_coeff; P->e_coeff = s->early_coeff;
+    P->density_gain = s->late_density_gain;
+    P->mod_step = s->mod_step; P->mod_depth = s->mod_depth;
+    P->vap_coeff = s->late_ap_coeff;
+    P->fade_count = s->fade_sample_count;
+    return 0;
+}
+
+static void rv_dual_biquad(rv_bq *f0, rv_bq *f1, const float *src, float *dst, size_t n)
+{   /* DualBiquad{f0,f1}.process -> BiquadFilter::dualProcess, core/filters/biquad.cpp:254-282 */
+    float z01 = f0->z1, z02 = f0->z2, z11 = f1->z1, z12 = f1->z2;
+    for(size_t i = 0; i < n; ++i)
+    {
+        const float x0 = src[i];
+        const float y0 = x0 * f0->c.b0 + z01;
+        z01 = x0 * f0->c.b1 - y0 * f0->c.a1 + z02;
+        z02 = x0 * f0->c.b2 - y0 * f0->c.a2;
+        const float y1 = y0 * f1->c.b0 + z11;
+        z11 = y0 * f1->c.b1 - y1 * f1->c.a1 + z12;
+        z12 = y0 * f1->c.b2 - y1 * f1->c.a2;
+        dst[i] = y1;
+    }
+    f0->z1 = z01; f0->z2 = z02; f1->z1 = z11; f1->z2 = z12;
+}
+
+static void rv_partial_scatter(float out[4], const float in[4], float x, float y) /* :1396-1405 */
+{
+    const float o0 = x * in[0] + y * (in[1] + -in[2] + in[3]);
+    const float o1 = x * in[1] + y * (-in[0] + in[2] + in[3]);
+    const float o2 = x * in[2] + y * (in[0] + -in[1] + in[3]);
+    const float o3 = x * in[3] + y * (-in[0] + -in[1] + -in[2]);
+    out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3;
+}
+
+static void rv_line_write(const rv_line *l, size_t offset, size_t c, const float *in, size_t n) /* DelayLineU::write :312-326 */
+{
+    float *out = l->buf + c * l->stride;
+    for(size_t i = 0; i < n; ++i) out[(offset + i) & (l->stride - 1)] = in[i];
+}
+
+static void rv_allpass4(rv_pipeline *P, float (*samples)[RV_MAX_UPDATE], size_t offset, size_t todo)
+{   /* Allpass4::process :1508-1540 */
+    const float feed = P->eap_coeff;
+    const size_t mask = P->eap.stride - 1;
+    for(size_t j = 0; j < RV_LINES; ++j)
+    {
+        float *buf = P->eap.buf + j * P->eap.stride;
+        size_t dst = offset, tap = offset - P->eap_off[j];
+        for(size_t i = 0; i < todo; ++i)
+        {
+            const float x = samples[j][i];
+            const float y = buf[(tap++) & mask] - feed * x;
+            buf[(dst++) & mask] = x + feed * y;
+            samples[j][i] = y;
+        }
+    }
+}
+
+static void rv_vec_allpass(rv_pipeline *P, float (*samples)[RV_MAX_UPDATE], size_t offset, float xc, float yc,
+    size_t todo)
+{   /* VecAllpass::process :1452-1503 */
+    const size_t mask = P->vap.stride - 1;
+    float *buf = P->vap.buf;
+    const float feed = P->vap_coeff;
+    for(size_t base = 0; base < todo;)
+    {
+        size_t vo[RV_LINES], maxoff;
+        for(int c = 0; c < RV_LINES; ++c) vo[c] = (offset - P->vap_off[c]) & mask;
+        offset &= mask;
+        maxoff = offset;
+        for(int c = 0; c < RV_LINES; ++c) if(vo[c] > maxoff) maxoff = vo[c];
+        size_t td = mask + 1 - maxoff;
+        if(todo - base < td) td = todo - base;
+        if(P->vap_off[0] < td) td = P->vap_off[0];
+        for(int c = 0; c < RV_LINES; ++c)
+        {
+            size_t out_off = vo[c], in_off = offset;
+            for(size_t i = 0; i < td; ++i)
+            {
+                const float input = samples[c][base + i];
+                const float out = buf[(out_off++) * RV_LINES + (size_t)c] - feed * input;
+                buf[(in_off++) * RV_LINES + (size_t)c] = input + feed * out;
+                samples[c][base + i] = out;
+            }
+        }
+        for(size_t j = 0; j < td; ++j)
+        {
+            float *d = buf + (offset + j) * RV_LINES;
+            rv_partial_scatter(d, d, xc, yc);
+        }
+        offset += td;
+        base += td;
+    }
+}
+
+static void rv_process_early(oal_reverb *r, rv_pipeline *P, size_t offset, size_t samplesToDo)
+{   /* ReverbPipeline::processEarly :1558-1660 */
+    const rv_line *in_delay = &r->main_delay;
+    const size_t inmask = in_delay->stride - 1;
+    for(size_t base = 0; base < samplesToDo;)
+    {
+        const size_t todo = (samplesToDo - base < RV_MAX_UPDATE) ? samplesToDo - base : RV_MAX_UPDATE;
+        const float fadeStep = 1.0f / (float)todo;
+        const float c0 = P->early_coeff[0], c1 = P->early_coeff[1];
+        P->early_coeff[0] = P->early_coeff[1];
+        for(size_t j = 0; j < RV_LINES; ++j)
+        {
+            const float *input = in_delay->buf + j * in_delay->stride;
+            size_t tap0 = offset - P->early_tap[j][0], tap1 = offset - P->early_tap[j][1];
+            P->early_tap[j][0] = P->early_tap[j][1];
+            float fadeCount = 0.0f;
+            for(size_t i = 0; i < todo; ++i)
+            {
+                const float in0 = input[(tap0++) & inmask], in1 = input[(tap1++) & inmask];
+                r->temp[j][i] = lerpf(in0 * c0, in1 * c1, fadeStep * fadeCount);
+                fadeCount += 1.0f;
+            }
+            rv_dual_biquad(&P->lp[j], &P->hp[j], r->temp[j], r->temp[j], todo);
+        }
+        rv_allpass4(P, r->temp, offset, todo);
+        /* DelayLineU::writeReflected :340-365 */
+        {
+            const size_t mask = P->edelay.stride - 1;
+            float *b = P->edelay.buf;
+            const size_t st = P->edelay.stride;
+            for(size_t i = 0; i < todo; ++i)
+            {
+                const float s0 = r->temp[0][i], s1 = r->temp[1][i], s2 = r->temp[2][i], s3 = r->temp[3][i];
+                const size_t o = (offset + i) & mask;
+                b[0 * st + o] = (s0 - s1 - s2 - s3) * 0.5f;
+                b[1 * st + o] = (s1 - s0 - s2 - s3) * 0.5f;
+                b[2 * st + o] = (s2 - s0 - s1 - s3) * 0.5f;
+                b[3 * st + o] = (s3 - s0 - s1 - s2) * 0.5f;
+            }
+        }
+        for(size_t j = 0; j < RV_LINES; ++j)
+        {
+            const float *buf = P->edelay.buf + j * P->edelay.stride;
+            const size_t mask = P->edelay.stride - 1;
+            size_t tap = offset - P->e_off[j];
+            for(size_t i = 0; i < todo; ++i)
+                r->early[j][base + i] = buf[(tap++) & mask] * P->e_coeff + r->temp[j][i];
+        }
+        for(size_t i = 0; i < todo; ++i)                      /* VectorScatter :1408-1423 */
+        {
+            float v[4] = {r->temp[0][i], r->temp[1][i], r->temp[2][i], r->temp[3][i]};
+            rv_partial_scatter(v, v, P->mix_x, P->mix_y);
+            r->temp[0][i] = v[0]; r->temp[1][i] = v[1]; r->temp[2][i] = v[2]; r->temp[3][i] = v[3];
+        }
+        for(size_t j = 0; j < RV_LINES; ++j) rv_line_write(&P->late_in, offset, j, r->temp[j], todo);
+        base += todo;
+        offset += todo;
+    }
+}
+
+static void rv_calc_delays(rv_pipeline *P, size_t todo) /* Modulation::calcDelays :1662-1682 */
+{
+    unsigned idx = P->mod_index;
+    const unsigned step = P->mod_step;
+    const float depth = P->mod_depth * (float)RV_CUBIC_STEPS;
+    for(size_t i = 0; i < todo; ++i)
+    {
+        const float x = (float)(idx & RV_MOD_FRACMASK) * (1.0f / (float)RV_MOD_FRACONE);
+        const float lfo = !(idx & (RV_MOD_FRACONE >> 1))
+            ? ((-16.0f * x * x) + (8.0f * x))
+            : ((16.0f * x * x) + (-8.0f * x) + (-16.0f * x) + 8.0f);
+        idx += step;
+        P->mod_delays[i] = float2uint((lfo + 1.0f) * depth);
+    }
+    P->mod_index = idx;
+}
+
+static void rv_process_late(oal_reverb *r, rv_pipeline *P, size_t offset, size_t samplesToDo)
+{   /* ReverbPipeline::processLate :1696-1811 */
+    for(size_t base = 0; base < samplesToDo;)
+    {
+        size_t todo = P->l_off[0] < RV_MAX_UPDATE ? P->l_off[0] : RV_MAX_UPDATE;
+        if(samplesToDo - base < todo) todo = samplesToDo - base;
+        rv_calc_delays(P, todo);
+        for(size_t j = 0; j < RV_LINES; ++j)
+        {
+            const float *input = P->ldelay.buf + j * P->ldelay.stride;
+            const size_t mask = P->ldelay.stride - 1;
+            const float midGain = P->mid_gain[j];
+            size_t tap = offset - P->l_off[j];
+            for(size_t i = 0; i < todo; ++i)
+            {
+                const size_t idelay = P->mod_delays[i];
+                const size_t delay = tap - (idelay >> RV_CUBIC_BITS);
+                const size_t doff = idelay & RV_CUBIC_MASK;
+                ++tap;
+                const float out0 = input[(delay) & mask], out1 = input[(delay - 1) & mask];
+                const float out2 = input[(delay - 2) & mask], out3 = input[(delay - 3) & mask];
+                const float out = out0 * g_rv_cubic[RV_CUBIC_STEPS + doff] + out1 * g_rv_cubic[doff]
+                    + out2 * g_rv_cubic[RV_CUBIC_STEPS - doff] + out3 * g_rv_cubic[RV_CUBIC_STEPS * 2 - doff];
+                r->temp[j][i] = out * midGain;
+            }
+            rv_dual_biquad(&P->t60hf[j], &P->t60lf[j], r->temp[j], r->temp[j], todo);
+        }
+        const float fadeStep = 1.0f / (float)todo;
+        for(size_t j = 0; j < RV_LINES; ++j)
+        {
+            const float *input = P->late_in.buf + j * P->late_in.stride;
+            const size_t mask = P->late_in.stride - 1;
+            size_t tap0 = offset - P->late_tap[j][0], tap1 = offset - P->late_tap[j][1];
+            P->late_tap[j][0] = P->late_tap[j][1];
+            const float densityGain = P->density_gain;
+            const float densityStep = (tap0 != tap1) ? densityGain * fadeStep : 0.0f;
+            float fadeCount = 0.0f;
+            for(size_t i = 0; i < todo; ++i)
+            {
+                const float fade0 = densityGain - densityStep * fadeCount;
+                const float fade1 = densityStep * fadeCount;
+                fadeCount += 1.0f;
+                r->temp[j][i] = input[(tap0++) & mask] * fade0 + input[(tap1++) & mask] * fade1 + r->temp[j][i];
+            }
+        }
+        rv_vec_allpass(P, r->temp, offset, P->mix_x, P->mix_y, todo);
+        for(size_t j = 0; j < RV_LINES; ++j) memcpy(&r->late[j][base], r->temp[j], todo * sizeof(float));
+        for(size_t i = 0; i < todo; ++i)                      /* VectorScatterRev :1428-1443 */
+        {
+            const float v[4] = {r->temp[3][i], r->temp[2][i], r->temp[1][i], r->temp[0][i]};
+            float o[4];
+            rv_partial_scatter(o, v, P->mix_x, P->mix_y);
+            r->temp[0][i] = o[0]; r->temp[1][i] = o[1]; r->temp[2][i] = o[2]; r->temp[3][i] = o[3];
+        }
+        for(size_t j = 0; j < RV_LINES; ++j) rv_line_write(&P->ldelay, offset, j, r->temp[j], todo);
+        base += todo;
+        offset += todo;
+    }
+}
+
+static void rv_mix_out(oal_reverb *r, rv_pipeline *P, float *out_lines, size_t todo) /* MixOutPlain :637-656 */
+{
+    for(int j = 0; j < RV_LINES; ++j)
+        mix_lines(r->early[j], todo, out_lines, r->nlines, P->egains[j].cur, P->egains[j].tgt, todo, 0);
+    for(int j = 0; j < RV_LINES; ++j)
+        mix_lines(r->late[j], todo, out_lines, r->nlines, P->lgains[j].cur, P->lgains[j].tgt, todo, 0);
+}
+
+void oal_reverb_process(oal_reverb *r, const float *wet_in, float *out_lines, uint32_t n)
+{   /* ReverbState::process :1813-1883 */
+    static const float B2A[4][4] = {{0.5f, 0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, -0.5f, 0.5f},
+        {0.5f, 0.5f, -0.5f, -0.5f}, {0.5f, -0.5f, 0.5f, -0.5f}};      /* :91-97 */
+    const unsigned csr = fpu_enter();
+    const size_t offset = r->offset;
+    rv_pipeline *oldp = &r->pipe[!r->current], *curp = &r->pipe[r->current];
+    float tmp[LINE];
+    for(size_t c = 0; c < RV_LINES; ++c)
+    {
+        for(size_t i = 0; i < n; ++i) tmp[i] = 0.0f;
+        for(size_t k = 0; k < 4; ++k)
+        {
+            const float gain = B2A[c][k];
+            for(size_t i = 0; i < n; ++i) tmp[i] = tmp[i] + wet_in[k * LINE + i] * gain;
+        }
+        rv_line_write(&r->main_delay, offset, c, tmp, n);
+    }
+    if(r->state < RV_FADING) r->state = RV_FADING;
+    rv_process_early(r, curp, offset, n);
+    rv_process_late(r, curp, offset, n);
+    rv_mix_out(r, curp, out_lines, n);
+    if(r->state != RV_NORMAL)
+    {
+        if(r->state == RV_CLEANUP)
+        {
+            rv_pipeline_clear(oldp);
+            r->state = RV_NORMAL;
+        }
+        else
+        {
+            if(n >= oldp->fade_count)
+            {
+                for(int j = 0; j < RV_LINES; ++j)
+                {
+                    memset(oldp->egains[j].tgt, 0, sizeof(oldp->egains[j].tgt));
+                    memset(oldp->lgains[j].tgt, 0, sizeof(oldp->lgains[j].tgt));
+                }
+                oldp->fade_count = 0;
+                r->state = RV_CLEANUP;
+            }
+            else
+                oldp->fade_count -= n;
+            rv_process_early(r, oldp, offset, n);
+            rv_process_late(r, oldp, offset, n);
+            rv_mix_out(r, oldp, out_lines, n);
+        }
+    }
+    r->offset = offset + n;
+    fpu_leave(csr);
+}

@@ -229,6 +229,61 @@ void oal_conv_destroy(oal_conv *c);
 /* CalcDirectionCoeffs(dir, spread), core/mixer.h:68: ambisonic coefficients (ACN/N3D, 25). */
 void oal_calc_direction_coeffs(const float dir[3], float spread, float *out25);
 
+/* ---- EAX reverb: ReverbState, alc/effects/reverb.cpp:567-1883 ----
+ * create = deviceUpdate (:822-852, allocLines :728-820) for a first-order target bus of
+ * `num_out_lines` lines (identity AmbiMap, no up-mix); update = ReverbState::update (:1222-1395);
+ * process (:1813-1883) consumes the slot's 4-line B-Format wet bus and ADDS into out_lines.
+ * The parameter block is what update() leaves behind for process(); the compiled reference
+ * fills it (oal_reverb_get_params), the restatement and the product consume it. */
+typedef struct oal_bq { float b0, b1, b2, a1, a2; } oal_bq;
+typedef struct oal_reverb_pipeline {
+    oal_bq filter_lp, filter_hp;              /* mFilter[*].Lp / .Hp (all four lines alike) */
+    uint32_t early_delay_tap[4][2];           /* mEarlyDelayTap: [0] current, [1] target */
+    float early_delay_coeff[2];               /* mEarlyDelayCoeff */
+    uint32_t late_delay_tap[4][2];            /* mLateDelayTap */
+    float mix_x, mix_y;                       /* mMixX, mMixY */
+    float early_ap_coeff;                     /* mEarly.Allpass.Coeff */
+    uint32_t early_ap_offset[4];              /* mEarly.Allpass.Offset */
+    uint32_t early_offset[4];                 /* mEarly.Offset */
+    float early_coeff;                        /* mEarly.Coeff */
+    float early_gains_target[4][25];          /* mEarly.Gains[j].Target */
+    uint32_t late_offset[4];                  /* mLate.Offset */
+    float late_density_gain;                  /* mLate.DensityGain */
+    float t60_mid_gain[4];                    /* mLate.T60[j].mMidGain */
+    oal_bq t60_hf[4], t60_lf[4];              /* mLate.T60[j].mHFFilter / mLFFilter */
+    uint32_t mod_step;                        /* mLate.Mod.Step */
+    float mod_depth;                          /* mLate.Mod.Depth */
+    float late_ap_coeff;                      /* mLate.VecAp.Coeff */
+    uint32_t late_ap_offset[4];               /* mLate.VecAp.Offset */
+    float late_gains_target[4][25];           /* mLate.Gains[j].Target */
+    uint32_t fade_sample_count;               /* mFadeSampleCount */
+} oal_reverb_pipeline;
+typedef struct oal_reverb_params {
+    int32_t pipeline_state;                   /* ReverbState::PipelineState: 0 DeviceClear .. 4 Normal */
+    int32_t current_pipeline;                 /* mCurrentPipeline */
+    oal_reverb_pipeline pipe[2];
+} oal_reverb_params;
+typedef struct oal_reverb_props {             /* ReverbProps, core/effects/base.h:62-86 */
+    float density, diffusion, gain, gain_hf, gain_lf, decay_time, decay_hf_ratio, decay_lf_ratio;
+    float reflections_gain, reflections_delay, reflections_pan[3];
+    float late_reverb_gain, late_reverb_delay, late_reverb_pan[3];
+    float echo_time, echo_depth, modulation_time, modulation_depth, air_absorption_gain_hf;
+    float hf_reference, lf_reference, room_rolloff_factor;
+    int32_t decay_hf_limit;
+} oal_reverb_props;
+typedef struct oal_reverb oal_reverb;
+oal_reverb *oal_reverb_create(uint32_t sample_rate, uint32_t num_out_lines);
+void oal_reverb_destroy(oal_reverb *r);
+/* compiled reference only (the restatement returns -1): ReverbState::update, then the block */
+int oal_reverb_update(oal_reverb *r, const oal_reverb_props *props, float slot_gain);
+int oal_reverb_get_params(oal_reverb *r, oal_reverb_params *out);
+/* restatement only (the reference returns -1): install what update() computed */
+int oal_reverb_set_params(oal_reverb *r, const oal_reverb_params *params);
+/* wet_in: 4 x 1024 (W, Y, Z, X lines of the slot's wet bus); out_lines: num_out_lines x 1024 */
+void oal_reverb_process(oal_reverb *r, const float *wet_in, float *out_lines, uint32_t n);
+/* total floats of the delay-line buffer and the 11 line lengths allocLines computed */
+int oal_reverb_line_lengths(oal_reverb *r, uint32_t *lengths11);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,6 +188,15 @@ class OracleLib:
         L.oal_conv_update.argtypes = [C.c_void_p, C.c_float]
         L.oal_conv_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
         L.oal_conv_destroy.argtypes = [C.c_void_p]
+        if hasattr(L, "oal_reverb_create"):
+            L.oal_reverb_create.restype = C.c_void_p
+            L.oal_reverb_create.argtypes = [C.c_uint32, C.c_uint32]
+            L.oal_reverb_destroy.argtypes = [C.c_void_p]
+            L.oal_reverb_update.argtypes = [C.c_void_p, C.POINTER(ReverbProps), C.c_float]
+            L.oal_reverb_get_params.argtypes = [C.c_void_p, C.POINTER(ReverbParams)]
+            L.oal_reverb_set_params.argtypes = [C.c_void_p, C.POINTER(ReverbParams)]
+            L.oal_reverb_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
+            L.oal_reverb_line_lengths.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.oal_calc_direction_coeffs.argtypes = [f32p, C.c_float, f32p]
         self.kind = L.oal_kind().decode()
 
@@ -197,6 +206,9 @@ class OracleLib:
     # ---- convolution reverb (ConvolutionState, alc/effects/convolution.cpp) ----
     def make_convolution(self, num_out_lines, ir, sample_rate=48000, ir_rate=None):
         return Convolution(self, num_out_lines, ir, sample_rate, ir_rate or sample_rate)
+
+    def make_reverb(self, num_out_lines, sample_rate=48000):
+        return Reverb(self, num_out_lines, sample_rate)
 
     def direction_coeffs(self, direction, spread=0.0):
         d = np.ascontiguousarray(direction, np.float32)
@@ -355,6 +367,113 @@ class Scene:
         st = VoiceState()
         assert self.lib.L.oal_scene_voice_state(self.h, voice, C.byref(st)) == 0
         return st
+
+
+class BqCoeffs(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("b0", "b1", "b2", "a1", "a2")]
+
+
+class ReverbPipelineParams(C.Structure):
+    """oal_reverb_pipeline of oracle/oalref.h."""
+    _fields_ = [
+        ("filter_lp", BqCoeffs), ("filter_hp", BqCoeffs),
+        ("early_delay_tap", (C.c_uint32 * 2) * 4), ("early_delay_coeff", C.c_float * 2),
+        ("late_delay_tap", (C.c_uint32 * 2) * 4),
+        ("mix_x", C.c_float), ("mix_y", C.c_float),
+        ("early_ap_coeff", C.c_float), ("early_ap_offset", C.c_uint32 * 4),
+        ("early_offset", C.c_uint32 * 4), ("early_coeff", C.c_float),
+        ("early_gains_target", (C.c_float * 25) * 4),
+        ("late_offset", C.c_uint32 * 4), ("late_density_gain", C.c_float),
+        ("t60_mid_gain", C.c_float * 4), ("t60_hf", BqCoeffs * 4), ("t60_lf", BqCoeffs * 4),
+        ("mod_step", C.c_uint32), ("mod_depth", C.c_float),
+        ("late_ap_coeff", C.c_float), ("late_ap_offset", C.c_uint32 * 4),
+        ("late_gains_target", (C.c_float * 25) * 4),
+        ("fade_sample_count", C.c_uint32),
+    ]
+
+
+class ReverbParams(C.Structure):
+    _fields_ = [("pipeline_state", C.c_int32), ("current_pipeline", C.c_int32),
+                ("pipe", ReverbPipelineParams * 2)]
+
+    def as_bytes(self):
+        return bytes(memoryview(self))
+
+
+class ReverbProps(C.Structure):
+    """oal_reverb_props (ReverbProps, core/effects/base.h:62-86); defaults = AL_EAXREVERB_DEFAULT_*."""
+    _fields_ = [(k, C.c_float) for k in ("density", "diffusion", "gain", "gain_hf", "gain_lf", "decay_time",
+                                         "decay_hf_ratio", "decay_lf_ratio", "reflections_gain",
+                                         "reflections_delay")] + [
+        ("reflections_pan", C.c_float * 3), ("late_reverb_gain", C.c_float), ("late_reverb_delay", C.c_float),
+        ("late_reverb_pan", C.c_float * 3)] + [(k, C.c_float) for k in (
+            "echo_time", "echo_depth", "modulation_time", "modulation_depth", "air_absorption_gain_hf",
+            "hf_reference", "lf_reference", "room_rolloff_factor")] + [("decay_hf_limit", C.c_int32)]
+
+    DEFAULTS = dict(density=1.0, diffusion=1.0, gain=0.32, gain_hf=0.89, gain_lf=1.0, decay_time=1.49,
+                    decay_hf_ratio=0.83, decay_lf_ratio=1.0, reflections_gain=0.05, reflections_delay=0.007,
+                    reflections_pan=(0.0, 0.0, 0.0), late_reverb_gain=1.26, late_reverb_delay=0.011,
+                    late_reverb_pan=(0.0, 0.0, 0.0), echo_time=0.25, echo_depth=0.0, modulation_time=0.25,
+                    modulation_depth=0.0, air_absorption_gain_hf=0.994, hf_reference=5000.0,
+                    lf_reference=250.0, room_rolloff_factor=0.0, decay_hf_limit=1)
+
+    @classmethod
+    def make(cls, **kw):
+        d = dict(cls.DEFAULTS)
+        unknown = set(kw) - set(d)
+        assert not unknown, unknown
+        d.update(kw)
+        p = cls()
+        for k, v in d.items():
+            if isinstance(v, (tuple, list)):
+                setattr(p, k, (C.c_float * 3)(*v))
+            else:
+                setattr(p, k, v)
+        return p
+
+
+class Reverb:
+    """ReverbState-shaped handle.  The compiled reference implements update()/get_params(); the
+    restatement implements set_params() (fed with the reference's block, or the product host's)."""
+
+    def __init__(self, lib, num_out_lines, sample_rate):
+        self.lib = lib
+        self.nlines = num_out_lines
+        self.h = lib.L.oal_reverb_create(sample_rate, num_out_lines)
+        assert self.h, "oal_reverb_create failed"
+
+    def update(self, props, slot_gain=1.0):
+        rc = self.lib.L.oal_reverb_update(self.h, C.byref(props), slot_gain)
+        assert rc == 0, "oal_reverb_update is reference-only"
+
+    def get_params(self):
+        out = ReverbParams()
+        rc = self.lib.L.oal_reverb_get_params(self.h, C.byref(out))
+        assert rc == 0
+        return out
+
+    def set_params(self, params):
+        rc = self.lib.L.oal_reverb_set_params(self.h, C.byref(params))
+        assert rc == 0, "oal_reverb_set_params is restatement-only"
+
+    def process(self, wet_in, out_lines):
+        wet_in = np.ascontiguousarray(wet_in, np.float32)
+        assert wet_in.shape == (4, BUFFER_LINE)
+        assert out_lines.dtype == np.float32 and out_lines.shape == (self.nlines, BUFFER_LINE)
+        self.lib.L.oal_reverb_process(self.h, _fp(wet_in), _fp(out_lines), BUFFER_LINE)
+
+    def process_n(self, wet_in, out_lines, n):
+        self.lib.L.oal_reverb_process(self.h, _fp(wet_in), _fp(out_lines), n)
+
+    def line_lengths(self):
+        out = (C.c_uint32 * 11)()
+        total = self.lib.L.oal_reverb_line_lengths(self.h, out)
+        return total, list(out)
+
+    def close(self):
+        if self.h:
+            self.lib.L.oal_reverb_destroy(self.h)
+            self.h = None
 
 
 class Convolution:
