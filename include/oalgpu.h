@@ -329,6 +329,91 @@ int  oalgpu_convolution_process_device(oalgpu_convolution *conv, void *hip_strea
  * the dry lines (alc/alu.cpp:2209-2257).  NULL detaches. */
 int  oalgpu_slot_set_convolution(oalgpu_context *ctx, uint32_t slot, oalgpu_convolution *conv);
 
+/* ------------------------------------------------------------------------------------------
+ * EAX / standard reverb: ReverbState (alc/effects/reverb.cpp:567-1883) behind
+ * EffectState::deviceUpdate / update / process, for a first-order (<= 4 line up-mix-free) or
+ * wider target bus without ambisonic up-mixing (mUpmixOutput == false, :835-844).
+ *   - update() is host work (libm parameter design, :858-1351) and runs on the CPU here too;
+ *     the block it leaves behind is oalgpu_reverb_params.
+ *   - process() -- B-Format -> A-Format, early reflections, the modulated feedback delay
+ *     network, T60 filters, the vector all-pass, the pipeline cross-fade and the panned mix-out
+ *     (:1396-1883) -- is one HIP launch; the delay lines stay resident in HBM.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct oalgpu_reverb_props {             /* ReverbProps, core/effects/base.h:62-86 */
+    float density, diffusion, gain, gain_hf, gain_lf, decay_time, decay_hf_ratio, decay_lf_ratio;
+    float reflections_gain, reflections_delay, reflections_pan[3];
+    float late_reverb_gain, late_reverb_delay, late_reverb_pan[3];
+    float echo_time, echo_depth, modulation_time, modulation_depth, air_absorption_gain_hf;
+    float hf_reference, lf_reference, room_rolloff_factor;
+    int32_t decay_hf_limit;
+} oalgpu_reverb_props;
+
+typedef struct oalgpu_bq_coeffs { float b0, b1, b2, a1, a2; } oalgpu_bq_coeffs;  /* BiquadFilter::mCoeffs */
+typedef struct oalgpu_reverb_pipeline {          /* ReverbPipeline fields update() computes, :502-548 */
+    oalgpu_bq_coeffs filter_lp, filter_hp;       /* mFilter[*].Lp / .Hp */
+    uint32_t early_delay_tap[4][2];              /* mEarlyDelayTap: [0] current, [1] target */
+    float    early_delay_coeff[2];               /* mEarlyDelayCoeff */
+    uint32_t late_delay_tap[4][2];               /* mLateDelayTap */
+    float    mix_x, mix_y;                       /* mMixX, mMixY */
+    float    early_ap_coeff;                     /* mEarly.Allpass.Coeff */
+    uint32_t early_ap_offset[4];                 /* mEarly.Allpass.Offset */
+    uint32_t early_offset[4];                    /* mEarly.Offset */
+    float    early_coeff;                        /* mEarly.Coeff */
+    float    early_gains_target[4][OALGPU_MAX_AMBI_CHANNELS];   /* mEarly.Gains[j].Target */
+    uint32_t late_offset[4];                     /* mLate.Offset */
+    float    late_density_gain;                  /* mLate.DensityGain */
+    float    t60_mid_gain[4];                    /* mLate.T60[j].mMidGain */
+    oalgpu_bq_coeffs t60_hf[4], t60_lf[4];       /* mLate.T60[j].mHFFilter / mLFFilter */
+    uint32_t mod_step;                           /* mLate.Mod.Step */
+    float    mod_depth;                          /* mLate.Mod.Depth */
+    float    late_ap_coeff;                      /* mLate.VecAp.Coeff */
+    uint32_t late_ap_offset[4];                  /* mLate.VecAp.Offset */
+    float    late_gains_target[4][OALGPU_MAX_AMBI_CHANNELS];    /* mLate.Gains[j].Target */
+    uint32_t fade_sample_count;                  /* mFadeSampleCount */
+} oalgpu_reverb_pipeline;
+typedef struct oalgpu_reverb_params {
+    int32_t pipeline_state;                      /* ReverbState::PipelineState, :589-596 */
+    int32_t current_pipeline;                    /* mCurrentPipeline */
+    oalgpu_reverb_pipeline pipe[2];
+} oalgpu_reverb_params;
+enum oalgpu_reverb_pipeline_state {
+    OALGPU_REVERB_DEVICE_CLEAR = 0, OALGPU_REVERB_START_FADE = 1, OALGPU_REVERB_FADING = 2,
+    OALGPU_REVERB_CLEANUP = 3, OALGPU_REVERB_NORMAL = 4
+};
+
+typedef struct oalgpu_reverb oalgpu_reverb;
+/* deviceUpdate, :822-852 (allocLines :728-820).  device < 0 creates a parameter-only instance
+ * (update / get_params / line_lengths work, process fails with OALGPU_ERR_NO_DEVICE): the host
+ * half can be exercised without a GPU. */
+int  oalgpu_reverb_create(int device, uint32_t sample_rate, uint32_t num_out_lines, oalgpu_reverb **out);
+void oalgpu_reverb_destroy(oalgpu_reverb *rev);
+/* The stream update() and process() enqueue on (NULL = the default stream).  A reverb attached
+ * to a context slot uses the context's effect stream. */
+int  oalgpu_reverb_set_stream(oalgpu_reverb *rev, void *hip_stream);
+/* ReverbState::update, :1222-1351, for an identity first-order target map
+ * (ComputePanGains with AmbiMap[i] = {1, i}, core/mixer.cpp:93-103). */
+int  oalgpu_reverb_update(oalgpu_reverb *rev, const oalgpu_reverb_props *props, float slot_gain);
+/* The block as the host mirror holds it (what update() wrote, and what process() has since
+ * advanced: taps, coefficients, fade count, pipeline state). */
+int  oalgpu_reverb_get_params(oalgpu_reverb *rev, oalgpu_reverb_params *out);
+/* Installs a block computed elsewhere (a host that keeps its own ReverbState::update): only the
+ * fields update() writes are taken, as after one update() call. */
+int  oalgpu_reverb_set_params(oalgpu_reverb *rev, const oalgpu_reverb_params *params);
+/* The 11 delay-line lengths of allocLines (in floats, 4 lines each); returns their sum. */
+int  oalgpu_reverb_line_lengths(oalgpu_reverb *rev, uint32_t lengths[11]);
+/* process(samplesToDo, samplesIn, samplesOut), :1813-1883, host buffers: wet_in = 4 x 1024 (the
+ * slot's B-Format wet bus), out_lines = num_out_lines x 1024, added to. */
+int  oalgpu_reverb_process(oalgpu_reverb *rev, const float *wet_in, float *out_lines, uint32_t n);
+/* The same on device memory, asynchronous on the reverb's stream. */
+int  oalgpu_reverb_process_device(oalgpu_reverb *rev, const float *wet_in_dev, float *out_lines_dev, uint32_t n);
+/* Parameter-only instances: the scalar bookkeeping of one process(n) call (tap and coefficient
+ * hand-over, fade countdown, pipeline state machine, :1840-1882) without any audio, so that the
+ * host half can be followed through a schedule of updates on a machine without a GPU. */
+int  oalgpu_reverb_skip(oalgpu_reverb *rev, uint32_t n);
+/* Attach to effect slot `slot` of a context (like oalgpu_slot_set_convolution): wet bus lines
+ * 0..3 in, dry lines out.  NULL detaches. */
+int  oalgpu_slot_set_reverb(oalgpu_context *ctx, uint32_t slot, oalgpu_reverb *rev);
+
 #ifdef __cplusplus
 }
 #endif

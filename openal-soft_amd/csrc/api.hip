@@ -103,6 +103,7 @@ struct oalgpu_context {
     bool carryAccum{true};
     bool useWave{false};                   // FAST HRTF contexts without sends: voice_wave.hip
     std::vector<oalgpu_convolution*> slotConv;   // per effect slot: attached convolution reverb (not owned)
+    std::vector<oalgpu_reverb*> slotReverb;      // per effect slot: attached EAX reverb (not owned)
 
     DevBuf<float> tables;
     DevBuf<BufferItem> buffers;
@@ -375,6 +376,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.irSize = 0; L.irStride = 8;
     L.mixLines = mixLines;
     c->slotConv.assign(desc->num_slots, nullptr);
+    c->slotReverb.assign(desc->num_slots, nullptr);
     uint32_t vpg = desc->voices_per_group;
     if(vpg == 0)
     {
@@ -698,10 +700,16 @@ static int RunEffects(oalgpu_context *c, hipStream_t s, uint32_t samples_to_do)
     const DeviceLayout &L = c->L;
     for(uint32_t slot = 0; slot < L.numSlots; ++slot)
     {
-        oalgpu_convolution *conv = c->slotConv[slot];
-        if(!conv) continue;
         const float *wet = L.bus + BusWetOffset(L) + size_t{slot} * L.wetChannels * kLine;
-        if(int rc = oalgpu_convolution_process_device(conv, s, wet, L.bus, samples_to_do)) return rc;
+        if(oalgpu_convolution *conv = c->slotConv[slot])
+        {
+            if(int rc = oalgpu_convolution_process_device(conv, s, wet, L.bus, samples_to_do)) return rc;
+        }
+        if(oalgpu_reverb *rev = c->slotReverb[slot])
+        {
+            if(int rc = oalgpu_reverb_set_stream(rev, s)) return rc;
+            if(int rc = oalgpu_reverb_process_device(rev, wet, L.bus, samples_to_do)) return rc;
+        }
     }
     return OALGPU_OK;
 }
@@ -915,6 +923,16 @@ int oalgpu_slot_set_convolution(oalgpu_context *c, uint32_t slot, oalgpu_convolu
     if(!c || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_convolution: bad slot");
     if(int rc = oalgpu_sync(c)) return rc;
     c->slotConv[slot] = conv;
+    return OALGPU_OK;
+}
+
+int oalgpu_slot_set_reverb(oalgpu_context *c, uint32_t slot, oalgpu_reverb *rev)
+{
+    if(!c || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_reverb: bad slot");
+    if(rev && c->L.wetChannels < 4)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_reverb: the reverb reads a 4-line B-Format wet bus");
+    if(int rc = oalgpu_sync(c)) return rc;
+    c->slotReverb[slot] = rev;
     return OALGPU_OK;
 }
 

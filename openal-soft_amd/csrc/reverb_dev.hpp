@@ -1,0 +1,49 @@
+// Device-side layout of one EAX reverb instance, shared by reverb_kernels.hip and reverb_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/oalgpu.h"
+
+namespace oalgpu {
+
+// The all-pass stages run in LDS windows sized for sample rates up to 48 kHz: the longest early
+// all-pass delay is 6.534130e-4 s x 10 (density multiplier) x 48000 = 313 samples, the longest
+// late vector all-pass delay 1.618280e-3 x 10 x 48000 = 776 (reverb.cpp:195-197,229-231).
+constexpr uint32_t kRvMaxSampleRate = 48000;
+constexpr uint32_t kRvMaxEarlyApOffset = 320;
+constexpr uint32_t kRvMaxLateApOffset = 784;
+
+// what process() keeps per pipeline besides the delay lines and the scalars of
+// oalgpu_reverb_pipeline: Gains[j].Current and the biquad delay elements
+struct RvPipeState {
+    float earlyCur[4][OALGPU_MAX_AMBI_CHANNELS];
+    float lateCur[4][OALGPU_MAX_AMBI_CHANNELS];
+    float z[4][8];                 // per line: mFilter Lp z1,z2 / Hp z1,z2, T60 HF z1,z2 / LF z1,z2
+};
+
+struct RvLines {                   // per pipeline; strides = samples per line (powers of two)
+    float *lateIn, *eap, *edelay, *vap, *ldelay;
+    uint32_t lateInStride, eapStride, edelayStride, vapStride, ldelayStride;
+};
+
+struct RvLayout {
+    oalgpu_reverb_pipeline *pipe;  // [2]
+    RvPipeState *state;            // [2]
+    float *mainDelay;
+    uint32_t mainStride;
+    RvLines lines[2];
+    float *earlyOut, *lateOut;     // [2][4][1024] scratch: mEarlySamples / mLateSamples per pipeline
+    const float *cubic;            // gCubicTable, 513 floats
+    const float *wetIn;            // 4 x 1024
+    float *outLines;               // nlines x 1024
+    uint32_t nlines, n;
+    uint32_t offset;               // mOffset (low 32 bits: every line length is a power of two)
+    uint32_t modIndex[2];          // mLate.Mod.Index at the start of this block
+    int current;                   // mCurrentPipeline
+    int oldMode;                   // ReverbHost::Step::oldMode
+};
+
+void LaunchReverbProcess(hipStream_t s, const RvLayout &L);
+void LaunchReverbInstall(hipStream_t s, oalgpu_reverb_pipeline *dst, const oalgpu_reverb_pipeline &src);
+
+} // namespace oalgpu

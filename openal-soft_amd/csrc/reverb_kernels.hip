@@ -1,0 +1,452 @@
+// EAX reverb, ReverbState::process and what it calls (alc/effects/reverb.cpp:1396-1883), as ONE
+// launch of ONE workgroup per reverb instance.
+//
+// The network is a feedback structure: every 256-sample sub-block of the late reverb reads what
+// the previous one wrote, and inside a sub-block four things are true recurrences -- the two
+// dual-biquad sections (master band-pass, T60 damping) and the two all-pass stages (per-line
+// comb all-pass, Gerzon vector all-pass with its scattering matrix).  Everything else (tap reads,
+// cross-fades, cubic interpolation of the modulated feedback taps, reflections, scatters,
+// delay-line writes) is data parallel over 4 lines x 256 samples.  So the parallelism on offer
+// is: 4 lines, up to 256 samples in the parallel phases, early/late sections of consecutive
+// sub-blocks, and the two pipelines while a parameter change cross-fades.  The workgroup has four
+// wavefronts with fixed roles:
+//     wave 0  early reflections of the current pipeline   (processEarly, :1558-1660)
+//     wave 1  late reverb of the current pipeline         (processLate, :1696-1811)
+//     wave 2  early reflections of the old pipeline        } only while fading
+//     wave 3  late reverb of the old pipeline              }
+// A late wave waits for its early wave through a progress word in LDS (the late input line taps
+// may be zero samples behind).  Inside a wave: parallel phases run over the 64 lanes, the biquad
+// recurrences run one line per lane (4 lanes) in the reference's operation order, the all-pass
+// recurrences run in LDS windows in chunks of the shortest delay (within which they are
+// parallel).  All arithmetic keeps the reference's order (-ffp-contract=off, FTZ), so the output
+// is bit-identical to the CPU reference; the mix-out (MixOutPlain :637-656) is done last, by all
+// 256 threads, adding the 8 (16 while fading) inputs per output sample in the reference's order.
+//
+// Delay lines stay in HBM (1.6 MB per instance, L2 resident); per launch the algorithmic traffic
+// is ~100 KB, so this kernel is latency-bound by construction, not bandwidth-bound.
+#include "dev_wave.hpp"
+#include "reverb_dev.hpp"
+
+#pragma clang fp contract(off)
+
+namespace oalgpu {
+namespace {
+
+constexpr uint32_t kSub = 256;                   // MAX_UPDATE_SAMPLES, reverb.cpp:68
+constexpr uint32_t kRow = kSub + 1;              // LDS row pitch of the 4-line scratch (odd: the
+                                                 // four biquad lanes hit different banks)
+constexpr uint32_t kModFracOne = 1u << 24, kModFracMask = kModFracOne - 1u;   // :60-62
+constexpr uint32_t kCubicBits = 8, kCubicSteps = 1u << kCubicBits, kCubicMask = kCubicSteps - 1u;
+
+struct alignas(16) RoleLds {
+    float temp[4 * kRow];                        // tempSamples[4][256]
+    union alignas(16) {
+        float eap[4 * (kRvMaxEarlyApOffset + kSub)];      // early wave: per-line all-pass windows
+        float vap[4 * (kRvMaxLateApOffset + kSub)];       // late wave: interleaved vector all-pass window
+    };
+    uint32_t modDelays[kSub];
+};
+
+struct RvLds {
+    RoleLds role[4];
+    uint32_t progress[2];                        // samples of this block the early wave has finished
+};
+
+__device__ __forceinline__ float Lerp(float a, float b, float mu) { return a + (b - a) * mu; }
+
+// VectorPartialScatter, :1396-1405
+__device__ __forceinline__ void PartialScatter(float (&o)[4], const float (&in)[4], float x, float y)
+{
+    const float o0 = x * in[0] + y * (in[1] + -in[2] + in[3]);
+    const float o1 = x * in[1] + y * (-in[0] + in[2] + in[3]);
+    const float o2 = x * in[2] + y * (in[0] + -in[1] + in[3]);
+    const float o3 = x * in[3] + y * (-in[0] + -in[1] + -in[2]);
+    o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+}
+
+// DualBiquad{f0,f1}.process in place over row[0..todo) -- BiquadFilter::dualProcess,
+// core/filters/biquad.cpp:254-282.  One lane, serial.
+__device__ __forceinline__ void DualBiquadSerial(float *row, uint32_t todo, const oalgpu_bq_coeffs &c0,
+    const oalgpu_bq_coeffs &c1, float *z)
+{
+    float z01 = z[0], z02 = z[1], z11 = z[2], z12 = z[3];
+    const float b00 = c0.b0, b01 = c0.b1, b02 = c0.b2, a01 = c0.a1, a02 = c0.a2;
+    const float b10 = c1.b0, b11 = c1.b1, b12 = c1.b2, a11 = c1.a1, a12 = c1.a2;
+#pragma unroll 4
+    for(uint32_t i = 0; i < todo; ++i)
+    {
+        const float x0 = row[i];
+        const float y0 = x0 * b00 + z01;
+        z01 = x0 * b01 - y0 * a01 + z02;
+        z02 = x0 * b02 - y0 * a02;
+        const float y1 = y0 * b10 + z11;
+        z11 = y0 * b11 - y1 * a11 + z12;
+        z12 = y0 * b12 - y1 * a12;
+        row[i] = y1;
+    }
+    z[0] = z01; z[1] = z02; z[2] = z11; z[3] = z12;
+}
+
+// ---- early reflections: ReverbPipeline::processEarly, :1558-1660 -------------------------------
+__device__ void EarlyWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *progress, const uint32_t lane)
+{
+    const oalgpu_reverb_pipeline &P = L.pipe[p];
+    RvPipeState &S = L.state[p];
+    const RvLines &ln = L.lines[p];
+    const uint32_t n = L.n;
+    const uint32_t mainMask = L.mainStride - 1u, eapMask = ln.eapStride - 1u, edMask = ln.edelayStride - 1u,
+        liMask = ln.lateInStride - 1u;
+    const float mixX = P.mix_x, mixY = P.mix_y, feed = P.early_ap_coeff, delayCoeff = P.early_coeff;
+    float *earlyOut = L.earlyOut + size_t(p) * 4u * kLine;
+
+    uint32_t offset = L.offset;
+    for(uint32_t base = 0; base < n;)
+    {
+        const uint32_t todo = (n - base < kSub) ? n - base : kSub;
+        const float fadeStep = 1.0f / float(todo);
+        // the hand-over to the target taps happens after the first sub-block (:1579,1585)
+        const float c0 = base ? P.early_delay_coeff[1] : P.early_delay_coeff[0];
+        const float c1 = P.early_delay_coeff[1];
+        for(uint32_t j = 0; j < 4; ++j)
+        {
+            const float *input = L.mainDelay + size_t{j} * L.mainStride;
+            const uint32_t tap0 = offset - (base ? P.early_delay_tap[j][1] : P.early_delay_tap[j][0]);
+            const uint32_t tap1 = offset - P.early_delay_tap[j][1];
+            for(uint32_t i = lane; i < todo; i += 64)
+            {
+                const float in0 = input[(tap0 + i) & mainMask], in1 = input[(tap1 + i) & mainMask];
+                w.temp[j * kRow + i] = Lerp(in0 * c0, in1 * c1, fadeStep * float(i));
+            }
+        }
+        WaveSync();
+        if(lane < 4)                                            // mFilter[j].process, :1611
+            DualBiquadSerial(&w.temp[lane * kRow], todo, P.filter_lp, P.filter_hp, &S.z[lane][0]);
+        WaveSync();
+
+        // Allpass4::process, :1508-1540, in an LDS window per line: win[k] = line sample at
+        // position offset - Offset[j] + k.  16 lanes per line; a chunk of Offset[j] samples has
+        // no dependency inside it.
+        {
+            const uint32_t j = lane >> 4, l = lane & 15u;
+            const uint32_t off = P.early_ap_offset[j];
+            float *win = &w.eap[j * (kRvMaxEarlyApOffset + kSub)];
+            float *line = ln.eap + size_t{j} * ln.eapStride;
+            for(uint32_t k = l; k < off; k += 16) win[k] = line[(offset - off + k) & eapMask];
+            WaveSync();
+            float *row = &w.temp[j * kRow];
+            for(uint32_t cb = 0; cb < todo; cb += off)
+            {
+                const uint32_t cnt = (todo - cb < off) ? todo - cb : off;
+                for(uint32_t i = l; i < cnt; i += 16)
+                {
+                    const float x = row[cb + i];
+                    const float y = win[cb + i] - feed * x;
+                    win[off + cb + i] = x + feed * y;
+                    row[cb + i] = y;
+                }
+                WaveSync();
+            }
+            for(uint32_t i = l; i < todo; i += 16) line[(offset + i) & eapMask] = win[off + i];
+        }
+        WaveSync();
+
+        // DelayLineU::writeReflected, :340-365
+        for(uint32_t i = lane; i < todo; i += 64)
+        {
+            const float s0 = w.temp[0 * kRow + i], s1 = w.temp[1 * kRow + i], s2 = w.temp[2 * kRow + i],
+                s3 = w.temp[3 * kRow + i];
+            const uint32_t o = (offset + i) & edMask;
+            ln.edelay[0 * size_t{ln.edelayStride} + o] = (s0 - s1 - s2 - s3) * 0.5f;
+            ln.edelay[1 * size_t{ln.edelayStride} + o] = (s1 - s0 - s2 - s3) * 0.5f;
+            ln.edelay[2 * size_t{ln.edelayStride} + o] = (s2 - s0 - s1 - s3) * 0.5f;
+            ln.edelay[3 * size_t{ln.edelayStride} + o] = (s3 - s0 - s1 - s2) * 0.5f;
+        }
+        // the taps below may land on samples this wave has just stored
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        WaveSync();
+        for(uint32_t j = 0; j < 4; ++j)                         // :1619-1643
+        {
+            const float *buf = ln.edelay + size_t{j} * ln.edelayStride;
+            const uint32_t tap = offset - P.early_offset[j];
+            for(uint32_t i = lane; i < todo; i += 64)
+                earlyOut[j * kLine + base + i] = buf[(tap + i) & edMask] * delayCoeff + w.temp[j * kRow + i];
+        }
+        // VectorScatter (:1408-1423) into the late input line (:1649-1655)
+        for(uint32_t i = lane; i < todo; i += 64)
+        {
+            const float v[4] = {w.temp[0 * kRow + i], w.temp[1 * kRow + i], w.temp[2 * kRow + i], w.temp[3 * kRow + i]};
+            float o[4];
+            PartialScatter(o, v, mixX, mixY);
+            const uint32_t pos = (offset + i) & liMask;
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j) ln.lateIn[size_t{j} * ln.lateInStride + pos] = o[j];
+        }
+        base += todo;
+        offset += todo;
+        WaveSync();
+        // publish: the late wave of this pipeline may now read late-input samples < base
+        __hip_atomic_store(progress, base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// ---- late reverb: ReverbPipeline::processLate, :1696-1811 --------------------------------------
+__device__ void LateWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *progress, const uint32_t lane)
+{
+    const oalgpu_reverb_pipeline &P = L.pipe[p];
+    RvPipeState &S = L.state[p];
+    const RvLines &ln = L.lines[p];
+    const uint32_t n = L.n;
+    const uint32_t ldMask = ln.ldelayStride - 1u, liMask = ln.lateInStride - 1u, vapMask = ln.vapStride - 1u;
+    const float mixX = P.mix_x, mixY = P.mix_y, feed = P.late_ap_coeff;
+    const float depth = P.mod_depth * float(kCubicSteps);
+    const uint32_t step = P.mod_step;
+    float *lateOut = L.lateOut + size_t(p) * 4u * kLine;
+    uint32_t vapMax = 0;
+    for(uint32_t c = 0; c < 4; ++c) vapMax = P.late_ap_offset[c] > vapMax ? P.late_ap_offset[c] : vapMax;
+
+    uint32_t offset = L.offset;
+    for(uint32_t base = 0; base < n;)
+    {
+        uint32_t todo = P.late_offset[0] < kSub ? P.late_offset[0] : kSub;
+        todo = (n - base < todo) ? n - base : todo;
+
+        // Modulation::calcDelays, :1662-1682
+        for(uint32_t i = lane; i < todo; i += 64)
+        {
+            const uint32_t idx = L.modIndex[p] + (base + i) * step;
+            const float x = float(idx & kModFracMask) * (1.0f / float(kModFracOne));
+            const float lfo = !(idx & (kModFracOne >> 1))
+                ? ((-16.0f * x * x) + (8.0f * x))
+                : ((16.0f * x * x) + (-8.0f * x) + (-16.0f * x) + 8.0f);
+            w.modDelays[i] = uint32_t((lfo + 1.0f) * depth);
+        }
+        WaveSync();
+        // modulated feedback taps, cubic-interpolated (:1718-1747)
+        for(uint32_t j = 0; j < 4; ++j)
+        {
+            const float *input = ln.ldelay + size_t{j} * ln.ldelayStride;
+            const float midGain = P.t60_mid_gain[j];
+            const uint32_t tap = offset - P.late_offset[j];
+            for(uint32_t i = lane; i < todo; i += 64)
+            {
+                const uint32_t idelay = w.modDelays[i];
+                const uint32_t delay = tap + i - (idelay >> kCubicBits);
+                const uint32_t doff = idelay & kCubicMask;
+                const float out0 = input[delay & ldMask], out1 = input[(delay - 1u) & ldMask];
+                const float out2 = input[(delay - 2u) & ldMask], out3 = input[(delay - 3u) & ldMask];
+                const float out = out0 * L.cubic[kCubicSteps + doff] + out1 * L.cubic[doff]
+                    + out2 * L.cubic[kCubicSteps - doff] + out3 * L.cubic[kCubicSteps * 2u - doff];
+                w.temp[j * kRow + i] = out * midGain;
+            }
+        }
+        WaveSync();
+        if(lane < 4)                                            // mLate.T60[j].process, :1749
+            DualBiquadSerial(&w.temp[lane * kRow], todo, P.t60_hf[lane], P.t60_lf[lane], &S.z[lane][4]);
+        WaveSync();
+
+        // the late input line must hold this pipeline's early output up to base + todo
+        while(__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < base + todo)
+            __builtin_amdgcn_s_sleep(2);
+        const float fadeStep = 1.0f / float(todo);
+        for(uint32_t j = 0; j < 4; ++j)                         // :1753-1785
+        {
+            const float *input = ln.lateIn + size_t{j} * ln.lateInStride;
+            const uint32_t tap0 = offset - (base ? P.late_delay_tap[j][1] : P.late_delay_tap[j][0]);
+            const uint32_t tap1 = offset - P.late_delay_tap[j][1];
+            const float densityGain = P.late_density_gain;
+            const float densityStep = (tap0 != tap1) ? densityGain * fadeStep : 0.0f;
+            for(uint32_t i = lane; i < todo; i += 64)
+            {
+                const float fadeCount = float(i);
+                const float fade0 = densityGain - densityStep * fadeCount;
+                const float fade1 = densityStep * fadeCount;
+                w.temp[j * kRow + i] = input[(tap0 + i) & liMask] * fade0 + input[(tap1 + i) & liMask] * fade1
+                    + w.temp[j * kRow + i];
+            }
+        }
+        WaveSync();
+
+        // VecAllpass::process, :1452-1503, in an LDS window: vap[(k)*4 + c] = interleaved line
+        // sample at position offset - vapMax + k.  Chunks of Offset[0] (the shortest delay).
+        {
+            float4 *win4 = reinterpret_cast<float4*>(w.vap);
+            const float4 *line4 = reinterpret_cast<const float4*>(ln.vap);
+            for(uint32_t k = lane; k < vapMax; k += 64) win4[k] = line4[(offset - vapMax + k) & vapMask];
+            WaveSync();
+            const uint32_t minOff = P.late_ap_offset[0];
+            for(uint32_t cb = 0; cb < todo;)
+            {
+                const uint32_t td = (todo - cb < minOff) ? todo - cb : minOff;
+                for(uint32_t e = lane; e < td * 4u; e += 64)
+                {
+                    const uint32_t c = e & 3u, i = cb + (e >> 2);
+                    const float input = w.temp[c * kRow + i];
+                    const float out = w.vap[(vapMax + i - P.late_ap_offset[c]) * 4u + c] - feed * input;
+                    w.vap[(vapMax + i) * 4u + c] = input + feed * out;
+                    w.temp[c * kRow + i] = out;
+                }
+                WaveSync();
+                for(uint32_t i = lane; i < td; i += 64)
+                {
+                    const float4 d = win4[vapMax + cb + i];
+                    const float v[4] = {d.x, d.y, d.z, d.w};
+                    float o[4];
+                    PartialScatter(o, v, mixX, mixY);
+                    win4[vapMax + cb + i] = make_float4(o[0], o[1], o[2], o[3]);
+                }
+                WaveSync();
+                cb += td;
+            }
+            float4 *out4 = reinterpret_cast<float4*>(ln.vap);
+            for(uint32_t i = lane; i < todo; i += 64) out4[(offset + i) & vapMask] = win4[vapMax + i];
+        }
+        // out for mixing (:1791-1797), then VectorScatterRev into the feedback lines (:1800-1806)
+        for(uint32_t i = lane; i < todo; i += 64)
+        {
+            const float t0 = w.temp[0 * kRow + i], t1 = w.temp[1 * kRow + i], t2 = w.temp[2 * kRow + i],
+                t3 = w.temp[3 * kRow + i];
+            lateOut[0 * kLine + base + i] = t0; lateOut[1 * kLine + base + i] = t1;
+            lateOut[2 * kLine + base + i] = t2; lateOut[3 * kLine + base + i] = t3;
+            const float v[4] = {t3, t2, t1, t0};
+            float o[4];
+            PartialScatter(o, v, mixX, mixY);
+            const uint32_t pos = (offset + i) & ldMask;
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j) ln.ldelay[size_t{j} * ln.ldelayStride + pos] = o[j];
+        }
+        // the next sub-block's feedback taps may land on samples this wave has just stored
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        WaveSync();
+        base += todo;
+        offset += todo;
+    }
+}
+
+// MixLine with Counter == n (core/mixer/mixer_c.cpp:150-186): one input sample into one output
+__device__ __forceinline__ float MixTerm(float acc, float in, float cur, float tgt, float delta, uint32_t i)
+{
+    const float step = (tgt - cur) * delta;
+    if(fabsf(step) > 1.1920928955078125e-07f) return acc + in * (cur + step * float(i));
+    if(fabsf(tgt) > 0.00001f) return acc + in * tgt;
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
+{
+    __shared__ RvLds sm;
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t n = L.n;
+    const int cur = L.current, old = !L.current;
+    const bool oldRuns = (L.oldMode == 1 || L.oldMode == 2);
+
+    // B-Format -> A-Format into the main delay line (:1824-1838)
+    {
+        constexpr float B2A[4][4] = {{0.5f, 0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, -0.5f, 0.5f},
+            {0.5f, 0.5f, -0.5f, -0.5f}, {0.5f, -0.5f, 0.5f, -0.5f}};
+        const uint32_t mask = L.mainStride - 1u;
+        for(uint32_t i = t; i < n; i += 256)
+        {
+            float in[4];
+#pragma unroll
+            for(int k = 0; k < 4; ++k) in[k] = L.wetIn[k * kLine + i];
+#pragma unroll
+            for(int c = 0; c < 4; ++c)
+            {
+                float tmp = 0.0f;
+#pragma unroll
+                for(int k = 0; k < 4; ++k) tmp = tmp + in[k] * B2A[c][k];
+                L.mainDelay[size_t(c) * L.mainStride + ((L.offset + i) & mask)] = tmp;
+            }
+        }
+    }
+    if(L.oldMode == 3)
+    {   // ReverbPipeline::clear, :550-564 (the scalar fields were cleared by the host)
+        const RvLines &ln = L.lines[old];
+        float4 *lines[5] = {reinterpret_cast<float4*>(ln.lateIn), reinterpret_cast<float4*>(ln.eap),
+            reinterpret_cast<float4*>(ln.edelay), reinterpret_cast<float4*>(ln.vap), reinterpret_cast<float4*>(ln.ldelay)};
+        const uint32_t counts[5] = {ln.lateInStride, ln.eapStride, ln.edelayStride, ln.vapStride, ln.ldelayStride};
+        for(int k = 0; k < 5; ++k)
+            for(uint32_t i = t; i < counts[k]; i += 256) lines[k][i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float *st = reinterpret_cast<float*>(&L.state[old]);
+        for(uint32_t i = t; i < sizeof(RvPipeState) / sizeof(float); i += 256) st[i] = 0.0f;
+    }
+    if(t < 2) sm.progress[t] = 0u;
+    __syncthreads();
+
+    {
+        const int p = (wave >> 1) ? old : cur;
+        if(wave < 2 || oldRuns)
+        {
+            if(!(wave & 1u)) EarlyWave(L, p, sm.role[wave], &sm.progress[wave >> 1], lane);
+            else LateWave(L, p, sm.role[wave], &sm.progress[wave >> 1], lane);
+        }
+    }
+    __syncthreads();
+
+    // MixOutPlain, :637-656: current pipeline first, then the old one (:1845,1878)
+    {
+        const float delta = 1.0f / float(n);
+        const int npipes = oldRuns ? 2 : 1;
+        for(uint32_t c = 0; c < L.nlines; ++c)
+        {
+            for(uint32_t i = t; i < n; i += 256)
+            {
+                float acc = L.outLines[c * kLine + i];
+                for(int q = 0; q < npipes; ++q)
+                {
+                    const int p = q ? old : cur;
+                    const oalgpu_reverb_pipeline &P = L.pipe[p];
+                    const RvPipeState &S = L.state[p];
+                    const float *eo = L.earlyOut + size_t(p) * 4u * kLine, *lo = L.lateOut + size_t(p) * 4u * kLine;
+#pragma unroll
+                    for(int j = 0; j < 4; ++j)
+                        acc = MixTerm(acc, eo[j * kLine + i], S.earlyCur[j][c], P.early_gains_target[j][c], delta, i);
+#pragma unroll
+                    for(int j = 0; j < 4; ++j)
+                        acc = MixTerm(acc, lo[j * kLine + i], S.lateCur[j][c], P.late_gains_target[j][c], delta, i);
+                }
+                L.outLines[c * kLine + i] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    // what process() leaves in the pipelines: Current = Target (MixLine with Counter == n), the
+    // taps and the early coefficient handed over (:1579,1585,1759)
+    for(int q = 0; q < (oldRuns ? 2 : 1); ++q)
+    {
+        const int p = q ? old : cur;
+        oalgpu_reverb_pipeline &P = L.pipe[p];
+        RvPipeState &S = L.state[p];
+        for(uint32_t k = t; k < 4u * OALGPU_MAX_AMBI_CHANNELS; k += 256)
+        {
+            const uint32_t j = k / OALGPU_MAX_AMBI_CHANNELS, c = k % OALGPU_MAX_AMBI_CHANNELS;
+            S.earlyCur[j][c] = P.early_gains_target[j][c];
+            S.lateCur[j][c] = P.late_gains_target[j][c];
+        }
+        if(t < 4)
+        {
+            P.early_delay_tap[t][0] = P.early_delay_tap[t][1];
+            P.late_delay_tap[t][0] = P.late_delay_tap[t][1];
+        }
+        if(t == 4) P.early_delay_coeff[0] = P.early_delay_coeff[1];
+    }
+}
+
+// installs one pipeline's parameter block (passed by value) into device memory
+__global__ void __launch_bounds__(256) ReverbInstallKernel(oalgpu_reverb_pipeline *dst, const oalgpu_reverb_pipeline src)
+{
+    const uint32_t *s = reinterpret_cast<const uint32_t*>(&src);
+    uint32_t *d = reinterpret_cast<uint32_t*>(dst);
+    for(uint32_t k = threadIdx.x; k < sizeof(oalgpu_reverb_pipeline) / 4u; k += blockDim.x) d[k] = s[k];
+}
+
+} // namespace
+
+void LaunchReverbProcess(hipStream_t s, const RvLayout &L)
+{ hipLaunchKernelGGL(ReverbProcessKernel, dim3(1), dim3(256), 0, s, L); }
+
+void LaunchReverbInstall(hipStream_t s, oalgpu_reverb_pipeline *dst, const oalgpu_reverb_pipeline &src)
+{ hipLaunchKernelGGL(ReverbInstallKernel, dim3(1), dim3(256), 0, s, dst, src); }
+
+} // namespace oalgpu

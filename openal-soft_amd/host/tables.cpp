@@ -227,6 +227,28 @@ const AllTables &Tables()
     return t;
 }
 
+// CubicFilter::CubicFilter, core/cubic_tables.cpp:109-128: the 256-step gaussian the reverb's
+// modulated feedback taps interpolate with (getCoeff0..3 index one 513-entry array)
+struct FineCubic {
+    float f[kFineCubicSteps * 2 + 1]{};
+    FineCubic()
+    {
+        const double indexScale = 512.0 / double(kFineCubicSteps * 2);
+        for(unsigned i = 0; i < kFineCubicSteps / 2 + 1; ++i)
+        {
+            const double c0 = GaussCoeff(double(kFineCubicSteps + i) * indexScale);
+            const double c1 = GaussCoeff(double(i) * indexScale);
+            const double c2 = GaussCoeff(double(kFineCubicSteps - i) * indexScale);
+            const double c3 = GaussCoeff(double(kFineCubicSteps * 2 - i) * indexScale);
+            const double norm = 1.0 / (c0 + c1 + c2 + c3);
+            f[kFineCubicSteps + i] = float(c0 * norm);
+            f[i] = float(c1 * norm);
+            f[kFineCubicSteps - i] = float(c2 * norm);
+            f[kFineCubicSteps * 2 - i] = float(c3 * norm);
+        }
+    }
+};
+
 } // namespace
 
 const BsincTable *GetBsincTable(int which)
@@ -244,6 +266,12 @@ const CubicTable *GetCubicTable(int which)
 {
     if(which < 0 || which > 1) return nullptr;
     return &Tables().cubic[which];
+}
+
+const float *GetFineCubicFilter()
+{
+    static const FineCubic t;
+    return t.f;
 }
 
 } // namespace oalgpu

@@ -20,4 +20,8 @@ struct CubicTable {            // CubicCoefficients[32], core/cubic_defs.h:10-13
 const BsincTable *GetBsincTable(int which);   // 12, 24, 48
 const CubicTable *GetCubicTable(int which);   // 0 spline, 1 gaussian
 
+// gCubicTable (CubicFilter, core/cubic_tables.h:22-40): 2*256+1 floats
+constexpr unsigned kFineCubicSteps = 256;
+const float *GetFineCubicFilter();
+
 } // namespace oalgpu

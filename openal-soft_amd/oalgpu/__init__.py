@@ -388,6 +388,10 @@ class Scene:
         lib.oalgpu_slot_set_convolution.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         check(lib.oalgpu_slot_set_convolution(self.h, slot, conv.h if conv is not None else None))
 
+    def set_slot_reverb(self, slot, rev):
+        lib.oalgpu_slot_set_reverb.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        check(lib.oalgpu_slot_set_reverb(self.h, slot, rev.h if rev is not None else None))
+
     def mix(self, samples_to_do=BUFFER_LINE, post_process=False):
         check(lib.oalgpu_mix_update(self.h, samples_to_do, 1 if post_process else 0),
               "oalgpu_mix_update")
@@ -466,4 +470,121 @@ class Convolution:
     def close(self):
         if self.h:
             lib.oalgpu_convolution_destroy(self.h)
+            self.h = None
+
+
+class BqCoeffs(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("b0", "b1", "b2", "a1", "a2")]
+
+
+class ReverbPipelineParams(C.Structure):
+    """oalgpu_reverb_pipeline."""
+    _fields_ = [
+        ("filter_lp", BqCoeffs), ("filter_hp", BqCoeffs),
+        ("early_delay_tap", (C.c_uint32 * 2) * 4), ("early_delay_coeff", C.c_float * 2),
+        ("late_delay_tap", (C.c_uint32 * 2) * 4),
+        ("mix_x", C.c_float), ("mix_y", C.c_float),
+        ("early_ap_coeff", C.c_float), ("early_ap_offset", C.c_uint32 * 4),
+        ("early_offset", C.c_uint32 * 4), ("early_coeff", C.c_float),
+        ("early_gains_target", (C.c_float * 25) * 4),
+        ("late_offset", C.c_uint32 * 4), ("late_density_gain", C.c_float),
+        ("t60_mid_gain", C.c_float * 4), ("t60_hf", BqCoeffs * 4), ("t60_lf", BqCoeffs * 4),
+        ("mod_step", C.c_uint32), ("mod_depth", C.c_float),
+        ("late_ap_coeff", C.c_float), ("late_ap_offset", C.c_uint32 * 4),
+        ("late_gains_target", (C.c_float * 25) * 4),
+        ("fade_sample_count", C.c_uint32),
+    ]
+
+
+class ReverbParams(C.Structure):
+    """oalgpu_reverb_params."""
+    _fields_ = [("pipeline_state", C.c_int32), ("current_pipeline", C.c_int32),
+                ("pipe", ReverbPipelineParams * 2)]
+
+
+class ReverbProps(C.Structure):
+    """oalgpu_reverb_props (ReverbProps, core/effects/base.h:62-86); make() fills the
+    AL_EAXREVERB_DEFAULT_* values (include/AL/efx.h:317-401)."""
+    _fields_ = [(k, C.c_float) for k in ("density", "diffusion", "gain", "gain_hf", "gain_lf", "decay_time",
+                                         "decay_hf_ratio", "decay_lf_ratio", "reflections_gain",
+                                         "reflections_delay")] + [
+        ("reflections_pan", C.c_float * 3), ("late_reverb_gain", C.c_float), ("late_reverb_delay", C.c_float),
+        ("late_reverb_pan", C.c_float * 3)] + [(k, C.c_float) for k in (
+            "echo_time", "echo_depth", "modulation_time", "modulation_depth", "air_absorption_gain_hf",
+            "hf_reference", "lf_reference", "room_rolloff_factor")] + [("decay_hf_limit", C.c_int32)]
+
+    DEFAULTS = dict(density=1.0, diffusion=1.0, gain=0.32, gain_hf=0.89, gain_lf=1.0, decay_time=1.49,
+                    decay_hf_ratio=0.83, decay_lf_ratio=1.0, reflections_gain=0.05, reflections_delay=0.007,
+                    reflections_pan=(0.0, 0.0, 0.0), late_reverb_gain=1.26, late_reverb_delay=0.011,
+                    late_reverb_pan=(0.0, 0.0, 0.0), echo_time=0.25, echo_depth=0.0, modulation_time=0.25,
+                    modulation_depth=0.0, air_absorption_gain_hf=0.994, hf_reference=5000.0,
+                    lf_reference=250.0, room_rolloff_factor=0.0, decay_hf_limit=1)
+
+    @classmethod
+    def make(cls, **kw):
+        d = dict(cls.DEFAULTS)
+        unknown = set(kw) - set(d)
+        if unknown:
+            raise KeyError(sorted(unknown))
+        d.update(kw)
+        p = cls()
+        for k, v in d.items():
+            setattr(p, k, (C.c_float * 3)(*v) if isinstance(v, (tuple, list)) else v)
+        return p
+
+
+class Reverb:
+    """oalgpu_reverb: ReverbState (alc/effects/reverb.cpp).  device=-1 makes a parameter-only
+    instance (update/get_params work without a GPU; process raises)."""
+
+    def __init__(self, num_out_lines, sample_rate=48000, device=0):
+        lib.oalgpu_reverb_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.oalgpu_reverb_destroy.argtypes = [C.c_void_p]
+        lib.oalgpu_reverb_destroy.restype = None
+        lib.oalgpu_reverb_update.argtypes = [C.c_void_p, C.POINTER(ReverbProps), C.c_float]
+        lib.oalgpu_reverb_get_params.argtypes = [C.c_void_p, C.POINTER(ReverbParams)]
+        lib.oalgpu_reverb_set_params.argtypes = [C.c_void_p, C.POINTER(ReverbParams)]
+        lib.oalgpu_reverb_line_lengths.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        lib.oalgpu_reverb_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
+        lib.oalgpu_slot_set_reverb.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        self.nlines = num_out_lines
+        h = C.c_void_p()
+        check(lib.oalgpu_reverb_create(device, sample_rate, num_out_lines, C.byref(h)), "oalgpu_reverb_create")
+        self.h = h
+
+    def update(self, props, slot_gain=1.0):
+        check(lib.oalgpu_reverb_update(self.h, C.byref(props), slot_gain), "oalgpu_reverb_update")
+
+    def get_params(self):
+        out = ReverbParams()
+        check(lib.oalgpu_reverb_get_params(self.h, C.byref(out)), "oalgpu_reverb_get_params")
+        return out
+
+    def set_params(self, params):
+        """`params`: a ReverbParams, or any ctypes structure of the same layout."""
+        assert C.sizeof(params) == C.sizeof(ReverbParams)
+        check(lib.oalgpu_reverb_set_params(self.h, C.cast(C.byref(params), C.POINTER(ReverbParams))),
+              "oalgpu_reverb_set_params")
+
+    def line_lengths(self):
+        out = (C.c_uint32 * 11)()
+        total = lib.oalgpu_reverb_line_lengths(self.h, out)
+        return total, list(out)
+
+    def skip(self, n):
+        lib.oalgpu_reverb_skip.argtypes = [C.c_void_p, C.c_uint32]
+        check(lib.oalgpu_reverb_skip(self.h, n), "oalgpu_reverb_skip")
+
+    def process_n(self, wet_in, out_lines, n):
+        wet_in = np.ascontiguousarray(wet_in, np.float32)
+        assert wet_in.shape == (4, BUFFER_LINE)
+        assert out_lines.dtype == np.float32 and out_lines.shape == (self.nlines, BUFFER_LINE)
+        check(lib.oalgpu_reverb_process(self.h, _fp(wet_in), _fp(out_lines), n), "oalgpu_reverb_process")
+
+    def process(self, wet_in, out_lines):
+        self.process_n(wet_in, out_lines, BUFFER_LINE)
+
+    def close(self):
+        if self.h:
+            lib.oalgpu_reverb_destroy(self.h)
             self.h = None

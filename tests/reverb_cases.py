@@ -1,9 +1,18 @@
 """Shared EAX-reverb scenarios: a list of (name, schedule) where a schedule is a list of
 per-update steps {props: kwargs for ReverbProps.make, slot_gain, n} -- None props = no update()
 before that process() call.  Input is seeded noise bursts on the 4-line wet bus."""
+import zlib
+
 import numpy as np
 
 BUFFER_LINE = 1024
+
+
+def out_init(nlines):
+    """process() ADDS into the target lines: start them from a recognisable non-zero pattern."""
+    o = np.zeros((nlines, BUFFER_LINE), np.float32)
+    o[:, :7] = 0.125
+    return o
 
 
 def wet_input(seed, updates, burst_every=3):
@@ -49,3 +58,6 @@ CASES = [
                 dict(props=None, slot_gain=0.8, n=1024), dict(props=None, slot_gain=0.8, n=257),
                 dict(props=None, slot_gain=0.8, n=1024), dict(props=None, slot_gain=0.8, n=1024)]),
 ]
+
+SEED = {name: zlib.crc32(name.encode()) % 1000 for name, _ in CASES}
+FULL_CASES = ("default", "ragged")      # cases whose golden fixture holds the lines, not only CRCs
