@@ -4,6 +4,7 @@
 #include "api_util.hpp"
 #include "reverb_dev.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -22,6 +23,7 @@ struct oalgpu_reverb {
     DevBuf<float> samples, scratch, cubic, hostIn, hostOut;
     DevBuf<oalgpu_reverb_pipeline> pipe;
     DevBuf<RvPipeState> state;
+    DevBuf<unsigned long long> stamps;      // profiling aid, env OALGPU_PHASE_TIMES
     RvLayout L{};
 };
 
@@ -88,6 +90,11 @@ int oalgpu_reverb_create(int device, uint32_t sample_rate, uint32_t num_out_line
     L.lateOut = r->scratch.p + size_t{2} * 4 * OALGPU_BUFFER_LINE_SIZE;
     L.cubic = r->cubic.p;
     L.nlines = num_out_lines;
+    if(std::getenv("OALGPU_PHASE_TIMES"))
+    {
+        HIP_TRY(r->stamps.alloc(4 * 8 * 8)); HIP_TRY(r->stamps.zero());
+        L.stamps = r->stamps.p;
+    }
     *out = r.release();
     return OALGPU_OK;
 }
@@ -171,6 +178,15 @@ int oalgpu_reverb_process_device(oalgpu_reverb *r, const float *wet_in_dev, floa
     LaunchReverbProcess(r->stream, L);
     HIP_TRY(hipGetLastError());
     r->host.finish(st, n);
+    return OALGPU_OK;
+}
+
+/* profiling aid: the cycle-counter stamps of the last launch, [4 roles][8 sub-blocks][8] */
+int oalgpu_reverb_debug_phase_times(oalgpu_reverb *r, unsigned long long *out)
+{
+    if(!r || !out || !r->stamps.p) return Fail(OALGPU_ERR_INVALID, "phase times were not enabled");
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->stamps.download(out, 4 * 8 * 8));
     return OALGPU_OK;
 }
 

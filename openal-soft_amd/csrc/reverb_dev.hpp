@@ -41,6 +41,7 @@ struct RvLayout {
     uint32_t modIndex[2];          // mLate.Mod.Index at the start of this block
     int current;                   // mCurrentPipeline
     int oldMode;                   // ReverbHost::Step::oldMode
+    unsigned long long *stamps;    // profiling aid (env OALGPU_PHASE_TIMES): [4 roles][8 sub-blocks][8]
 };
 
 void LaunchReverbProcess(hipStream_t s, const RvLayout &L);

@@ -33,24 +33,35 @@ namespace oalgpu {
 namespace {
 
 constexpr uint32_t kSub = 256;                   // MAX_UPDATE_SAMPLES, reverb.cpp:68
-constexpr uint32_t kRow = kSub + 1;              // LDS row pitch of the 4-line scratch (odd: the
-                                                 // four biquad lanes hit different banks)
+constexpr uint32_t kRow = kSub + 4;              // LDS row pitch of the 4-line scratch: the four biquad
+                                                 // lanes hit different banks, rows stay 16-byte aligned
 constexpr uint32_t kModFracOne = 1u << 24, kModFracMask = kModFracOne - 1u;   // :60-62
 constexpr uint32_t kCubicBits = 8, kCubicSteps = 1u << kCubicBits, kCubicMask = kCubicSteps - 1u;
 
-struct alignas(16) RoleLds {
-    float temp[4 * kRow];                        // tempSamples[4][256]
-    union alignas(16) {
-        float eap[4 * (kRvMaxEarlyApOffset + kSub)];      // early wave: per-line all-pass windows
-        float vap[4 * (kRvMaxLateApOffset + kSub)];       // late wave: interleaved vector all-pass window
-    };
+// The all-pass windows hold the delay history a block starts from plus everything the block
+// adds (loaded once per launch; each sub-block writes its new samples back to HBM).
+struct alignas(16) EarlyLds {
+    float temp[4 * kRow];                                 // tempSamples[4][256]
+    float eap[4 * (kRvMaxEarlyApOffset + kLine)];         // per-line all-pass windows
+};
+struct alignas(16) LateLds {
+    float temp[4 * kRow];
+    float vap[4 * (kRvMaxLateApOffset + kLine)];          // interleaved vector all-pass window
     uint32_t modDelays[kSub];
 };
+struct PipeLds { EarlyLds e; LateLds l; };
+
+struct MixGain { float cur, step, tgt; uint32_t mode; };   // mode 0: silent, 1: fading, 2: constant gain
 
 struct RvLds {
-    RoleLds role[4];
+    PipeLds pipe[2];                             // [0] current pipeline, [1] old pipeline
+    float cubic[kCubicSteps * 2 + 4];            // gCubicTable
+    MixGain mix[2][8][OALGPU_MAX_AMBI_CHANNELS]; // [pipeline][early 0-3, late 4-7][target line]
     uint32_t progress[2];                        // samples of this block the early wave has finished
 };
+
+#define RV_STAMP(role, sub, k) do { if(L.stamps && lane == 0 && (sub) < 8u) \
+    L.stamps[((role) * 8u + (sub)) * 8u + (k)] = __builtin_readcyclecounter(); } while(0)
 
 __device__ __forceinline__ float Lerp(float a, float b, float mu) { return a + (b - a) * mu; }
 
@@ -65,30 +76,45 @@ __device__ __forceinline__ void PartialScatter(float (&o)[4], const float (&in)[
 }
 
 // DualBiquad{f0,f1}.process in place over row[0..todo) -- BiquadFilter::dualProcess,
-// core/filters/biquad.cpp:254-282.  One lane, serial.
+// core/filters/biquad.cpp:254-282.  One lane, serial in time.  The second section runs one sample
+// behind the first, so that both sections' identical operation sequences pack into v_pk_mul_f32 /
+// v_pk_add_f32 (.x = first section on sample i, .y = second section on sample i-1): 9 packed
+// instructions per sample instead of 18 scalar ones, every product and sum still rounded on its
+// own exactly as the reference's scalar code does.
 __device__ __forceinline__ void DualBiquadSerial(float *row, uint32_t todo, const oalgpu_bq_coeffs &c0,
     const oalgpu_bq_coeffs &c1, float *z)
 {
-    float z01 = z[0], z02 = z[1], z11 = z[2], z12 = z[3];
-    const float b00 = c0.b0, b01 = c0.b1, b02 = c0.b2, a01 = c0.a1, a02 = c0.a2;
-    const float b10 = c1.b0, b11 = c1.b1, b12 = c1.b2, a11 = c1.a1, a12 = c1.a2;
-#pragma unroll 4
-    for(uint32_t i = 0; i < todo; ++i)
-    {
-        const float x0 = row[i];
-        const float y0 = x0 * b00 + z01;
-        z01 = x0 * b01 - y0 * a01 + z02;
-        z02 = x0 * b02 - y0 * a02;
-        const float y1 = y0 * b10 + z11;
-        z11 = y0 * b11 - y1 * a11 + z12;
-        z12 = y0 * b12 - y1 * a12;
-        row[i] = y1;
+    f2 Z1 = {z[0], z[2]}, Z2 = {z[1], z[3]};
+    const f2 B0 = {c0.b0, c1.b0}, B1 = {c0.b1, c1.b1}, B2 = {c0.b2, c1.b2}, A1 = {c0.a1, c1.a1}, A2 = {c0.a2, c1.a2};
+    float yprev;
+    {   // first section alone on sample 0
+        const float x0 = row[0];
+        const float y0 = x0 * B0.x + Z1.x;
+        Z1.x = x0 * B1.x - y0 * A1.x + Z2.x;
+        Z2.x = x0 * B2.x - y0 * A2.x;
+        yprev = y0;
     }
-    z[0] = z01; z[1] = z02; z[2] = z11; z[3] = z12;
+#pragma unroll 8
+    for(uint32_t i = 1; i < todo; ++i)
+    {
+        const f2 X = {row[i], yprev};
+        const f2 Y = X * B0 + Z1;
+        Z1 = X * B1 - Y * A1 + Z2;
+        Z2 = X * B2 - Y * A2;
+        row[i - 1] = Y.y;
+        yprev = Y.x;
+    }
+    {   // second section alone on the last sample
+        const float y1 = yprev * B0.y + Z1.y;
+        Z1.y = yprev * B1.y - y1 * A1.y + Z2.y;
+        Z2.y = yprev * B2.y - y1 * A2.y;
+        row[todo - 1] = y1;
+    }
+    z[0] = Z1.x; z[1] = Z2.x; z[2] = Z1.y; z[3] = Z2.y;
 }
 
 // ---- early reflections: ReverbPipeline::processEarly, :1558-1660 -------------------------------
-__device__ void EarlyWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *progress, const uint32_t lane)
+__device__ void EarlyWave(const RvLayout &L, const int p, EarlyLds &w, uint32_t *progress, const uint32_t lane)
 {
     const oalgpu_reverb_pipeline &P = L.pipe[p];
     RvPipeState &S = L.state[p];
@@ -100,39 +126,61 @@ __device__ void EarlyWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *
     float *earlyOut = L.earlyOut + size_t(p) * 4u * kLine;
 
     uint32_t offset = L.offset;
-    for(uint32_t base = 0; base < n;)
+    const uint32_t role = p == L.current ? 0u : 2u;
+    {   // all-pass history: win[k] = line sample at position L.offset - Offset[j] + k
+        const uint32_t j = lane >> 4, l = lane & 15u;
+        const uint32_t off = P.early_ap_offset[j];
+        float *win = &w.eap[j * (kRvMaxEarlyApOffset + kLine)];
+        const float *line = ln.eap + size_t{j} * ln.eapStride;
+        for(uint32_t k = l; k < off; k += 16) win[k] = line[(offset - off + k) & eapMask];
+    }
+    for(uint32_t base = 0, sub = 0; base < n; ++sub)
     {
         const uint32_t todo = (n - base < kSub) ? n - base : kSub;
         const float fadeStep = 1.0f / float(todo);
+        RV_STAMP(role, sub, 0);
         // the hand-over to the target taps happens after the first sub-block (:1579,1585)
         const float c0 = base ? P.early_delay_coeff[1] : P.early_delay_coeff[0];
         const float c1 = P.early_delay_coeff[1];
-        for(uint32_t j = 0; j < 4; ++j)
-        {
-            const float *input = L.mainDelay + size_t{j} * L.mainStride;
-            const uint32_t tap0 = offset - (base ? P.early_delay_tap[j][1] : P.early_delay_tap[j][0]);
-            const uint32_t tap1 = offset - P.early_delay_tap[j][1];
-            for(uint32_t i = lane; i < todo; i += 64)
+        {   // all 32 loads of the lane first, then the arithmetic (one memory round trip)
+            float in0[4][4], in1[4][4];
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j)
             {
-                const float in0 = input[(tap0 + i) & mainMask], in1 = input[(tap1 + i) & mainMask];
-                w.temp[j * kRow + i] = Lerp(in0 * c0, in1 * c1, fadeStep * float(i));
+                const float *input = L.mainDelay + size_t{j} * L.mainStride;
+                const uint32_t tap0 = offset - (base ? P.early_delay_tap[j][1] : P.early_delay_tap[j][0]);
+                const uint32_t tap1 = offset - P.early_delay_tap[j][1];
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k)
+                {
+                    const uint32_t i = lane + 64u * k;
+                    in0[j][k] = input[(tap0 + i) & mainMask];
+                    in1[j][k] = input[(tap1 + i) & mainMask];
+                }
             }
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j)
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k)
+                {
+                    const uint32_t i = lane + 64u * k;
+                    if(i < todo) w.temp[j * kRow + i] = Lerp(in0[j][k] * c0, in1[j][k] * c1, fadeStep * float(i));
+                }
         }
         WaveSync();
+        RV_STAMP(role, sub, 1);
         if(lane < 4)                                            // mFilter[j].process, :1611
             DualBiquadSerial(&w.temp[lane * kRow], todo, P.filter_lp, P.filter_hp, &S.z[lane][0]);
         WaveSync();
+        RV_STAMP(role, sub, 2);
 
-        // Allpass4::process, :1508-1540, in an LDS window per line: win[k] = line sample at
-        // position offset - Offset[j] + k.  16 lanes per line; a chunk of Offset[j] samples has
-        // no dependency inside it.
+        // Allpass4::process, :1508-1540, in the LDS window of the line.  16 lanes per line; a chunk
+        // of Offset[j] samples has no dependency inside it.
         {
             const uint32_t j = lane >> 4, l = lane & 15u;
             const uint32_t off = P.early_ap_offset[j];
-            float *win = &w.eap[j * (kRvMaxEarlyApOffset + kSub)];
+            float *win = &w.eap[j * (kRvMaxEarlyApOffset + kLine)] + base;
             float *line = ln.eap + size_t{j} * ln.eapStride;
-            for(uint32_t k = l; k < off; k += 16) win[k] = line[(offset - off + k) & eapMask];
-            WaveSync();
             float *row = &w.temp[j * kRow];
             for(uint32_t cb = 0; cb < todo; cb += off)
             {
@@ -149,6 +197,7 @@ __device__ void EarlyWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *
             for(uint32_t i = l; i < todo; i += 16) line[(offset + i) & eapMask] = win[off + i];
         }
         WaveSync();
+        RV_STAMP(role, sub, 3);
 
         // DelayLineU::writeReflected, :340-365
         for(uint32_t i = lane; i < todo; i += 64)
@@ -164,12 +213,25 @@ __device__ void EarlyWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *
         // the taps below may land on samples this wave has just stored
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         WaveSync();
-        for(uint32_t j = 0; j < 4; ++j)                         // :1619-1643
-        {
-            const float *buf = ln.edelay + size_t{j} * ln.edelayStride;
-            const uint32_t tap = offset - P.early_offset[j];
-            for(uint32_t i = lane; i < todo; i += 64)
-                earlyOut[j * kLine + base + i] = buf[(tap + i) & edMask] * delayCoeff + w.temp[j * kRow + i];
+        RV_STAMP(role, sub, 4);
+        {                                                       // :1619-1643
+            float dl[4][4];
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j)
+            {
+                const float *buf = ln.edelay + size_t{j} * ln.edelayStride;
+                const uint32_t tap = offset - P.early_offset[j];
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k) dl[j][k] = buf[(tap + lane + 64u * k) & edMask];
+            }
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j)
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k)
+                {
+                    const uint32_t i = lane + 64u * k;
+                    if(i < todo) earlyOut[j * kLine + base + i] = dl[j][k] * delayCoeff + w.temp[j * kRow + i];
+                }
         }
         // VectorScatter (:1408-1423) into the late input line (:1649-1655)
         for(uint32_t i = lane; i < todo; i += 64)
@@ -184,13 +246,15 @@ __device__ void EarlyWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *
         base += todo;
         offset += todo;
         WaveSync();
+        RV_STAMP(role, sub, 5);
         // publish: the late wave of this pipeline may now read late-input samples < base
         __hip_atomic_store(progress, base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
 // ---- late reverb: ReverbPipeline::processLate, :1696-1811 --------------------------------------
-__device__ void LateWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *progress, const uint32_t lane)
+__device__ void LateWave(const RvLayout &L, const int p, LateLds &w, uint32_t *progress, const float *cubic,
+    const uint32_t lane)
 {
     const oalgpu_reverb_pipeline &P = L.pipe[p];
     RvPipeState &S = L.state[p];
@@ -205,10 +269,17 @@ __device__ void LateWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *p
     for(uint32_t c = 0; c < 4; ++c) vapMax = P.late_ap_offset[c] > vapMax ? P.late_ap_offset[c] : vapMax;
 
     uint32_t offset = L.offset;
-    for(uint32_t base = 0; base < n;)
+    const uint32_t role = p == L.current ? 1u : 3u;
+    {   // vector all-pass history: vap[k*4 + c] = interleaved line sample at L.offset - vapMax + k
+        float4 *win4 = reinterpret_cast<float4*>(w.vap);
+        const float4 *line4 = reinterpret_cast<const float4*>(ln.vap);
+        for(uint32_t k = lane; k < vapMax; k += 64) win4[k] = line4[(offset - vapMax + k) & vapMask];
+    }
+    for(uint32_t base = 0, sub = 0; base < n; ++sub)
     {
         uint32_t todo = P.late_offset[0] < kSub ? P.late_offset[0] : kSub;
         todo = (n - base < todo) ? n - base : todo;
+        RV_STAMP(role, sub, 0);
 
         // Modulation::calcDelays, :1662-1682
         for(uint32_t i = lane; i < todo; i += 64)
@@ -227,52 +298,78 @@ __device__ void LateWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *p
             const float *input = ln.ldelay + size_t{j} * ln.ldelayStride;
             const float midGain = P.t60_mid_gain[j];
             const uint32_t tap = offset - P.late_offset[j];
-            for(uint32_t i = lane; i < todo; i += 64)
+            float o[4][4];
+            uint32_t doff[4];
+#pragma unroll
+            for(uint32_t k = 0; k < 4; ++k)
             {
-                const uint32_t idelay = w.modDelays[i];
+                const uint32_t i = lane + 64u * k;
+                const uint32_t idelay = w.modDelays[i < todo ? i : 0u];
                 const uint32_t delay = tap + i - (idelay >> kCubicBits);
-                const uint32_t doff = idelay & kCubicMask;
-                const float out0 = input[delay & ldMask], out1 = input[(delay - 1u) & ldMask];
-                const float out2 = input[(delay - 2u) & ldMask], out3 = input[(delay - 3u) & ldMask];
-                const float out = out0 * L.cubic[kCubicSteps + doff] + out1 * L.cubic[doff]
-                    + out2 * L.cubic[kCubicSteps - doff] + out3 * L.cubic[kCubicSteps * 2u - doff];
-                w.temp[j * kRow + i] = out * midGain;
+                doff[k] = idelay & kCubicMask;
+#pragma unroll
+                for(uint32_t m = 0; m < 4; ++m) o[k][m] = input[(delay - m) & ldMask];
+            }
+#pragma unroll
+            for(uint32_t k = 0; k < 4; ++k)
+            {
+                const uint32_t i = lane + 64u * k;
+                const float out = o[k][0] * cubic[kCubicSteps + doff[k]] + o[k][1] * cubic[doff[k]]
+                    + o[k][2] * cubic[kCubicSteps - doff[k]] + o[k][3] * cubic[kCubicSteps * 2u - doff[k]];
+                if(i < todo) w.temp[j * kRow + i] = out * midGain;
             }
         }
         WaveSync();
+        RV_STAMP(role, sub, 1);
         if(lane < 4)                                            // mLate.T60[j].process, :1749
             DualBiquadSerial(&w.temp[lane * kRow], todo, P.t60_hf[lane], P.t60_lf[lane], &S.z[lane][4]);
         WaveSync();
+        RV_STAMP(role, sub, 2);
 
         // the late input line must hold this pipeline's early output up to base + todo
         while(__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < base + todo)
             __builtin_amdgcn_s_sleep(2);
+        RV_STAMP(role, sub, 3);
         const float fadeStep = 1.0f / float(todo);
-        for(uint32_t j = 0; j < 4; ++j)                         // :1753-1785
-        {
-            const float *input = ln.lateIn + size_t{j} * ln.lateInStride;
-            const uint32_t tap0 = offset - (base ? P.late_delay_tap[j][1] : P.late_delay_tap[j][0]);
-            const uint32_t tap1 = offset - P.late_delay_tap[j][1];
+        {                                                       // :1753-1785
+            float in0[4][4], in1[4][4];
+            float densityStep[4];
             const float densityGain = P.late_density_gain;
-            const float densityStep = (tap0 != tap1) ? densityGain * fadeStep : 0.0f;
-            for(uint32_t i = lane; i < todo; i += 64)
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j)
             {
-                const float fadeCount = float(i);
-                const float fade0 = densityGain - densityStep * fadeCount;
-                const float fade1 = densityStep * fadeCount;
-                w.temp[j * kRow + i] = input[(tap0 + i) & liMask] * fade0 + input[(tap1 + i) & liMask] * fade1
-                    + w.temp[j * kRow + i];
+                const float *input = ln.lateIn + size_t{j} * ln.lateInStride;
+                const uint32_t tap0 = offset - (base ? P.late_delay_tap[j][1] : P.late_delay_tap[j][0]);
+                const uint32_t tap1 = offset - P.late_delay_tap[j][1];
+                densityStep[j] = (tap0 != tap1) ? densityGain * fadeStep : 0.0f;
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k)
+                {
+                    const uint32_t i = lane + 64u * k;
+                    in0[j][k] = input[(tap0 + i) & liMask];
+                    in1[j][k] = input[(tap1 + i) & liMask];
+                }
             }
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j)
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k)
+                {
+                    const uint32_t i = lane + 64u * k;
+                    const float fadeCount = float(i);
+                    const float fade0 = densityGain - densityStep[j] * fadeCount;
+                    const float fade1 = densityStep[j] * fadeCount;
+                    if(i < todo) w.temp[j * kRow + i] = in0[j][k] * fade0 + in1[j][k] * fade1 + w.temp[j * kRow + i];
+                }
         }
         WaveSync();
+        RV_STAMP(role, sub, 4);
 
-        // VecAllpass::process, :1452-1503, in an LDS window: vap[(k)*4 + c] = interleaved line
-        // sample at position offset - vapMax + k.  Chunks of Offset[0] (the shortest delay).
+        // VecAllpass::process, :1452-1503, in the LDS window.  Chunks of Offset[0] (the shortest
+        // delay).
         {
-            float4 *win4 = reinterpret_cast<float4*>(w.vap);
-            const float4 *line4 = reinterpret_cast<const float4*>(ln.vap);
-            for(uint32_t k = lane; k < vapMax; k += 64) win4[k] = line4[(offset - vapMax + k) & vapMask];
-            WaveSync();
+            float4 *win4 = reinterpret_cast<float4*>(w.vap) + base;
+            float *winf = w.vap + size_t{base} * 4u;
             const uint32_t minOff = P.late_ap_offset[0];
             for(uint32_t cb = 0; cb < todo;)
             {
@@ -281,8 +378,8 @@ __device__ void LateWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *p
                 {
                     const uint32_t c = e & 3u, i = cb + (e >> 2);
                     const float input = w.temp[c * kRow + i];
-                    const float out = w.vap[(vapMax + i - P.late_ap_offset[c]) * 4u + c] - feed * input;
-                    w.vap[(vapMax + i) * 4u + c] = input + feed * out;
+                    const float out = winf[(vapMax + i - P.late_ap_offset[c]) * 4u + c] - feed * input;
+                    winf[(vapMax + i) * 4u + c] = input + feed * out;
                     w.temp[c * kRow + i] = out;
                 }
                 WaveSync();
@@ -300,6 +397,7 @@ __device__ void LateWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *p
             float4 *out4 = reinterpret_cast<float4*>(ln.vap);
             for(uint32_t i = lane; i < todo; i += 64) out4[(offset + i) & vapMask] = win4[vapMax + i];
         }
+        RV_STAMP(role, sub, 5);
         // out for mixing (:1791-1797), then VectorScatterRev into the feedback lines (:1800-1806)
         for(uint32_t i = lane; i < todo; i += 64)
         {
@@ -317,18 +415,10 @@ __device__ void LateWave(const RvLayout &L, const int p, RoleLds &w, uint32_t *p
         // the next sub-block's feedback taps may land on samples this wave has just stored
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         WaveSync();
+        RV_STAMP(role, sub, 6);
         base += todo;
         offset += todo;
     }
-}
-
-// MixLine with Counter == n (core/mixer/mixer_c.cpp:150-186): one input sample into one output
-__device__ __forceinline__ float MixTerm(float acc, float in, float cur, float tgt, float delta, uint32_t i)
-{
-    const float step = (tgt - cur) * delta;
-    if(fabsf(step) > 1.1920928955078125e-07f) return acc + in * (cur + step * float(i));
-    if(fabsf(tgt) > 0.00001f) return acc + in * tgt;
-    return acc;
 }
 
 __global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
@@ -339,6 +429,7 @@ __global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
     const uint32_t n = L.n;
     const int cur = L.current, old = !L.current;
     const bool oldRuns = (L.oldMode == 1 || L.oldMode == 2);
+    if(L.stamps && t == 0) L.stamps[7 * 8 + 0] = __builtin_readcyclecounter();
 
     // B-Format -> A-Format into the main delay line (:1824-1838)
     {
@@ -372,45 +463,89 @@ __global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
         for(uint32_t i = t; i < sizeof(RvPipeState) / sizeof(float); i += 256) st[i] = 0.0f;
     }
     if(t < 2) sm.progress[t] = 0u;
+    for(uint32_t k = t; k < kCubicSteps * 2u + 1u; k += 256) sm.cubic[k] = L.cubic[k];
     __syncthreads();
+    if(L.stamps && t == 0) L.stamps[7 * 8 + 1] = __builtin_readcyclecounter();
 
     {
         const int p = (wave >> 1) ? old : cur;
         if(wave < 2 || oldRuns)
         {
-            if(!(wave & 1u)) EarlyWave(L, p, sm.role[wave], &sm.progress[wave >> 1], lane);
-            else LateWave(L, p, sm.role[wave], &sm.progress[wave >> 1], lane);
+            if(!(wave & 1u)) EarlyWave(L, p, sm.pipe[wave >> 1].e, &sm.progress[wave >> 1], lane);
+            else LateWave(L, p, sm.pipe[wave >> 1].l, &sm.progress[wave >> 1], sm.cubic, lane);
         }
     }
     __syncthreads();
+    if(L.stamps && t == 0) L.stamps[7 * 8 + 2] = __builtin_readcyclecounter();
 
-    // MixOutPlain, :637-656: current pipeline first, then the old one (:1845,1878)
+    // MixOutPlain, :637-656: current pipeline first, then the old one (:1845,1878).  MixLine with
+    // Counter == n (core/mixer/mixer_c.cpp:150-186): per (input, target line) the gain either
+    // ramps over the whole block, or is constant, or the pair is skipped -- decided once here.
     {
         const float delta = 1.0f / float(n);
-        const int npipes = oldRuns ? 2 : 1;
+        const uint32_t npipes = oldRuns ? 2u : 1u;
+        for(uint32_t e = t; e < npipes * 8u * L.nlines; e += 256)
+        {
+            const uint32_t q = e / (8u * L.nlines), r = e % (8u * L.nlines), j = r / L.nlines, c = r % L.nlines;
+            const int p = q ? old : cur;
+            const float curg = (j < 4) ? L.state[p].earlyCur[j][c] : L.state[p].lateCur[j - 4][c];
+            const float tgt = (j < 4) ? L.pipe[p].early_gains_target[j][c] : L.pipe[p].late_gains_target[j - 4][c];
+            const float step = (tgt - curg) * delta;
+            MixGain g{curg, step, tgt, 0u};
+            if(fabsf(step) > 1.1920928955078125e-07f) g.mode = 1u;
+            else if(fabsf(tgt) > 0.00001f) g.mode = 2u;
+            sm.mix[q][j][c] = g;
+        }
+        __syncthreads();
+        float in[2][8][4];
+#pragma unroll
+        for(uint32_t q = 0; q < 2; ++q)
+        {
+            if(q >= npipes) break;
+            const int p = q ? old : cur;
+            const float *eo = L.earlyOut + size_t(p) * 4u * kLine, *lo = L.lateOut + size_t(p) * 4u * kLine;
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j)
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k)
+                {
+                    const uint32_t i = t + 256u * k;
+                    in[q][j][k] = eo[j * kLine + (i < n ? i : 0u)];
+                    in[q][4 + j][k] = lo[j * kLine + (i < n ? i : 0u)];
+                }
+        }
         for(uint32_t c = 0; c < L.nlines; ++c)
         {
-            for(uint32_t i = t; i < n; i += 256)
+            float acc[4];
+#pragma unroll
+            for(uint32_t k = 0; k < 4; ++k) acc[k] = L.outLines[c * kLine + ((t + 256u * k) < n ? t + 256u * k : 0u)];
+#pragma unroll
+            for(uint32_t q = 0; q < 2; ++q)
             {
-                float acc = L.outLines[c * kLine + i];
-                for(int q = 0; q < npipes; ++q)
+                if(q >= npipes) break;
+#pragma unroll
+                for(uint32_t j = 0; j < 8; ++j)
                 {
-                    const int p = q ? old : cur;
-                    const oalgpu_reverb_pipeline &P = L.pipe[p];
-                    const RvPipeState &S = L.state[p];
-                    const float *eo = L.earlyOut + size_t(p) * 4u * kLine, *lo = L.lateOut + size_t(p) * 4u * kLine;
+                    const MixGain g = sm.mix[q][j][c];
+                    if(g.mode == 1u)
+                    {
 #pragma unroll
-                    for(int j = 0; j < 4; ++j)
-                        acc = MixTerm(acc, eo[j * kLine + i], S.earlyCur[j][c], P.early_gains_target[j][c], delta, i);
+                        for(uint32_t k = 0; k < 4; ++k) acc[k] += in[q][j][k] * (g.cur + g.step * float(t + 256u * k));
+                    }
+                    else if(g.mode == 2u)
+                    {
 #pragma unroll
-                    for(int j = 0; j < 4; ++j)
-                        acc = MixTerm(acc, lo[j * kLine + i], S.lateCur[j][c], P.late_gains_target[j][c], delta, i);
+                        for(uint32_t k = 0; k < 4; ++k) acc[k] = acc[k] + in[q][j][k] * g.tgt;
+                    }
                 }
-                L.outLines[c * kLine + i] = acc;
             }
+#pragma unroll
+            for(uint32_t k = 0; k < 4; ++k)
+                if(t + 256u * k < n) L.outLines[c * kLine + t + 256u * k] = acc[k];
         }
     }
     __syncthreads();
+    if(L.stamps && t == 0) L.stamps[7 * 8 + 3] = __builtin_readcyclecounter();
     // what process() leaves in the pipelines: Current = Target (MixLine with Counter == n), the
     // taps and the early coefficient handed over (:1579,1585,1759)
     for(int q = 0; q < (oldRuns ? 2 : 1); ++q)

@@ -314,9 +314,10 @@ def test_gpu_wide_target_and_long_run():
 def test_gpu_slot_reverb_in_scene(synth_mhr):
     """A reverb attached to an effect slot: oalgpu_mix_update feeds it the slot's 4-line wet bus
     and it adds into the dry lines (alc/alu.cpp:2209-2257).  Expected = the oracle scene's wet
-    bus through the oracle's ReverbState into the oracle's dry bus; the scene itself is compared
-    with the FAST-mode tolerance of the voice path, the reverb adds no error of its own beyond
-    what its input carries."""
+    bus through the oracle's ReverbState into the oracle's dry bus.  The voice side sums its
+    partial buses in a different order than the serial CPU loop (tests/test_gpu_parity.py), so
+    the reverb's INPUT already differs in the last bit; the tolerance is that of the multi-voice
+    bus tests, |a - b| <= 2e-5 * max|want| + 1e-7 (the reverb alone is bit-exact, see above)."""
     oalgpu = _gpu()
     if not ol.available("ref"):
         pytest.skip("needs the compiled reference")
@@ -350,6 +351,7 @@ def test_gpu_slot_reverb_in_scene(synth_mhr):
         osc.mix(n, post_process=False)
         want = osc.dry().copy()
         orev.process_n(np.ascontiguousarray(osc.wet(0)[:4]), want, n)
-        assert np.array_equal(bits(got[:, :n]), bits(want[:, :n])), (k, float(np.abs(got[:, :n] - want[:, :n]).max()))
+        err = float(np.abs(got[:, :n].astype(np.float64) - want[:, :n]).max())
+        assert err <= 2e-5 * float(np.abs(want[:, :n]).max()) + 1e-7, (k, err)
     gsc.set_slot_reverb(0, None)
     rev.close(); orev.close(); gsc.close(); osc.close()
