@@ -101,7 +101,7 @@ struct oalgpu_context {
     HrtfData hrtfHost;
     bool hrtfLoaded{false};
     bool carryAccum{true};
-    bool useWave{false};                   // FAST HRTF contexts without sends: voice_wave.hip
+    bool useWave{false};                   // FAST contexts without sends (HRTF, or <= 8 dry lines): voice_wave.hip
     std::vector<oalgpu_convolution*> slotConv;   // per effect slot: attached convolution reverb (not owned)
     std::vector<oalgpu_reverb*> slotReverb;      // per effect slot: attached EAX reverb (not owned)
 
@@ -112,7 +112,8 @@ struct oalgpu_context {
     DevBuf<VoiceCtl> ctl;
     DevBuf<float> prev, hrtfOld, hrtfTgt, hist, gainCur, gainTgt, sendCur, sendTgt;
     DevBuf<BiquadSlot> dfilt, sfilt;
-    DevBuf<float> partLines, partHrtf, partHrtf2, bus;
+    DevBuf<float> partLines, partHrtf, partHrtf2, bus, streams;
+    DevBuf<uint32_t> lineGains;
     DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
     bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
     // HRTF store
@@ -418,9 +419,19 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->sfilt.alloc(nv * L.numSends * 2)); HIP_TRY(c->sfilt.zero()); L.sfilt = c->sfilt.p;
     HIP_TRY(c->sendCur.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendCur.zero()); L.sendCur = c->sendCur.p;
     HIP_TRY(c->sendTgt.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendTgt.zero()); L.sendTgt = c->sendTgt.p;
-    HIP_TRY(c->partLines.alloc(size_t{L.numGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
+    L.numLineGroups = L.numGroups;
+    L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0;
+    if(c->useWave && !L.hrtf)
+    {   // LinesMixKernel: at most 64 voices per partial bus, at least 128 partials when there
+        // are that many voices (4 x 128 workgroups)
+        L.numLineGroups = std::max<uint32_t>(std::min<uint32_t>(256u, desc->max_voices), (desc->max_voices + 63u) / 64u);
+        HIP_TRY(c->streams.alloc(nv * kLine)); HIP_TRY(c->streams.zero()); L.streams = c->streams.p;
+        L.lineStride = L.numDry <= 8 ? 8u : (L.numDry <= 16 ? 16u : 32u);
+        HIP_TRY(c->lineGains.alloc(nv * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero()); L.lineGains = c->lineGains.p;
+    }
+    HIP_TRY(c->partLines.alloc(size_t{L.numLineGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
     HIP_TRY(c->partHrtf.alloc(L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0)); L.partHrtf = c->partHrtf.p;
-    HIP_TRY(c->partHrtf2.alloc(c->useWave ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
+    HIP_TRY(c->partHrtf2.alloc(c->useWave && L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
     c->partHrtfBuf[0] = c->partHrtf.p; c->partHrtfBuf[1] = c->partHrtf2.p;
     HIP_TRY(c->bus.alloc(BusFloats(L))); HIP_TRY(c->bus.zero()); L.bus = c->bus.p;
     if(std::getenv("OALGPU_PHASE_TIMES"))
@@ -766,7 +777,7 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
 int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_process)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
-    if(!(c->useWave && c->ownStream) || c->serialOnly)
+    if(!(c->useWave && c->L.hrtf && c->ownStream) || c->serialOnly)
     {   // one stream: the workgroup-per-voice-group kernel reads the carried accumulator itself,
         // and a caller-owned stream (RCCL ordering) is never forked
         if(int rc = oalgpu_mix_voices(c, samples_to_do)) return rc;
@@ -939,7 +950,7 @@ int oalgpu_slot_set_reverb(oalgpu_context *c, uint32_t slot, oalgpu_reverb *rev)
 const char *oalgpu_voice_kernel_name(oalgpu_context *c)
 {
     if(!c) return "";
-    if(c->useWave) return c->L.irStride <= 64 ? "VoiceWaveKernel<17, 64>" : "VoiceWaveKernel<18, 128>";
+    if(c->useWave) return WaveKernelName(c->L);
     return c->exact ? "VoiceMixKernel<true, LINES>" : "VoiceMixKernel<false, LINES>";
 }
 

@@ -55,6 +55,13 @@ static_assert(sizeof(VoiceCtl) == 128, "VoiceCtl is one 128-byte line");
 struct alignas(16) BiquadSlot { BiquadState f; uint32_t pad[3]; };
 static_assert(sizeof(BiquadSlot) == 64, "BiquadSlot");
 
+// The resolved MixLine gains (dev_mix.hpp MixLineGain) of one voice's lines, as LinesMixKernel
+// consumes them: a block of 4*S + 8 dwords per voice, S = lineStride (numDry padded to 8/16/32),
+//   [gain[S] | cur[S] | step[S] | fadeLen[S] | live, maxFadeLen, 0...]
+// frames below fadeLen[c] use cur[c] + step[c]*frame, the others gain[c] (0 when the line's
+// constant part is not mixed); live == 0: the voice did not mix in this update.
+__host__ __device__ inline uint32_t LineBlockDwords(uint32_t lineStride) { return 4u * lineStride + 8u; }
+
 struct DeviceLayout {
     // configuration
     uint32_t numVoices, numDry, numReal, numSends, numSlots, wetChannels;
@@ -77,6 +84,12 @@ struct DeviceLayout {
     float *sendCur, *sendTgt;
     // partial buses written by the voice kernel: [group][mixLines][1024], [group][1152][2]
     float *partLines, *partHrtf;
+    // dry-line contexts on the wavefront kernel: per-voice filtered samples [voice][1024] and
+    // line gains [voice][numDry], consumed by LinesMixKernel, which writes numLineGroups partials
+    float *streams;
+    uint32_t *lineGains;
+    uint32_t numLineGroups;                 // groups of partLines (== numGroups unless LinesMixKernel runs)
+    uint32_t lineStride;                    // records per voice in lineGains: numDry rounded up to 8 / 16 / 32
     // final bus block: [(numDry+numReal) x 1024 | numSlots*wetChannels x 1024 | 1152 x 2]
     float *bus;
 };
@@ -149,6 +162,7 @@ void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo,
 
 // ---- launchers (voice_wave.hip): the FAST HRTF hot path, one wavefront per voice ----
 bool WaveKernelApplies(bool exact, const DeviceLayout &L);
+const char *WaveKernelName(const DeviceLayout &L);
 uint32_t WaveKernelGroups(const DeviceLayout &L);
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo);
 

@@ -814,9 +814,10 @@ __global__ void __launch_bounds__(kReduceWaves * 64) BusReduceKernel(DeviceLayou
         stride = size_t{kLine + kHrirLen} * 2;
     }
 
-    const uint32_t per = (L.numGroups + kReduceWaves - 1) / kReduceWaves;
-    const uint32_t g0 = wave * per;
-    const uint32_t g1 = (g0 + per < L.numGroups) ? g0 + per : L.numGroups;
+    const uint32_t ngroups = (idx < lineFloats) ? L.numLineGroups : L.numGroups;
+    const uint32_t per = (ngroups + kReduceWaves - 1) / kReduceWaves;
+    const uint32_t g0 = wave * per < ngroups ? wave * per : ngroups;
+    const uint32_t g1 = (g0 + per < ngroups) ? g0 + per : ngroups;
     float sum = 0.0f;
     if(src)
     {

@@ -501,7 +501,14 @@ __device__ __forceinline__ void BiquadDualWaveScan(BiquadState &f0, BiquadState 
     for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < cnt) buf[begin + i] = x[i];
 }
 
-template<int R, int TAPS>
+// NL == 0: HRTF voices (DoHrtfMix into the wave's register accumulator).
+// NL == 1: voices panned onto dry lines (MixSamples, voice.cpp:962-963).  Holding N lines x 1024
+// frames of accumulator per wavefront would take 16 N VGPRs per lane on top of the resampler's
+// ~230 (measured: 209 spilled registers at 2 waves/SIMD, or 1 wave/SIMD and a latency-bound
+// resampler), so this variant stops after DoFilters: it leaves the voice's 1024 filtered
+// samples in HBM (L.streams, 4 KB per voice) together with the resolved MixLine gain of every
+// line (L.lineGains), and LinesMixKernel below turns those into partial buses.
+template<int R, int TAPS, int NL>
 __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo)
 {
     using WL = WaveLds<R, TAPS>;
@@ -570,6 +577,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             active = mixes && head.step >= 1u;
             // voice.cpp:1002-1010
             if(mixes && !active && !playing && lane == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
+            if constexpr (NL > 0)
+            {   // nothing to mix for this voice in this update
+                if(!active && lane == 0) L.lineGains[size_t{v} * LineBlockDwords(L.lineStride) + 4u * L.lineStride] = 0u;
+            }
         }
         auto stamp = [&](int slot)
         {
@@ -582,13 +593,13 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             dirty = (head.flags & kFlagHrtfDirty) != 0;
 
             // per-voice state, requested now and first used after the resampler
-            tail = LoadTailScalar(L.ctl + v);
-            const float histv = L.hist[size_t{v} * kHist + lane];
+            if constexpr (NL == 0) tail = LoadTailScalar(L.ctl + v);
+            const float histv = NL == 0 ? L.hist[size_t{v} * kHist + lane] : 0.0f;
             const float fstv = (lane < 32u) ? reinterpret_cast<const float*>(L.dfilt + size_t{v} * 2)[lane] : 0.0f;
             f2 oldv[TAPS / 64];
 #pragma unroll
             for(int q = 0; q < TAPS / 64; ++q) oldv[q] = f2{0.0f, 0.0f};
-            if(dirty)
+            if(NL == 0 && dirty)
             {
                 const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{v} * irStride * 2);
 #pragma unroll
@@ -652,6 +663,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             }
 
             stamp(2);
+            if constexpr (NL == 0)
+            {
             // ---- DoHrtfMix, voice.cpp:827-902
             w.in[lane] = histv;
             WaveSync();
@@ -726,6 +739,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 for(int q = 0; q < TAPS / 64; ++q) w.cold[64 + lane + 64 * q] = oldv[q];
             }
             WaveSync();
+            }
             stamp(3);
         }
 
@@ -800,8 +814,43 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         if(active)
         {
             stamp(4);
+            if constexpr (NL > 0)
+            {   // ---- MixSamples onto the dry lines, voice.cpp:962-963: samples and resolved gains
+                // (MixLine, mixer_c.cpp:150-186) for LinesMixKernel
+                const uint32_t nd = L.numDry;
+                float *st = L.streams + size_t{v} * kLine;
+#pragma unroll
+                for(uint32_t k = 0; k < uint32_t(kLine / 64); ++k)
+                {
+                    const uint32_t p = lane + 64u * k;
+                    st[p] = (p < N) ? w.in[kHist + p] : 0.0f;
+                }
+                const uint32_t ls = L.lineStride;
+                float tg = 0.0f, cu = 0.0f;
+                if(lane < nd)
+                {
+                    tg = playing ? L.gainTgt[size_t{v} * nd + lane] : 0.0f;       // SilentCoeffs when Stopping
+                    cu = counter ? L.gainCur[size_t{v} * nd + lane] : tg;         // voice.cpp:1094-1112
+                }
+                const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+                if(lane < nd) L.gainCur[size_t{v} * nd + lane] = g.newCur;
+                // the block is padded to the mix kernel's line count with zero gains
+                uint32_t *blk = L.lineGains + size_t{v} * LineBlockDwords(ls);
+                const bool mine = lane < nd;
+                uint32_t maxFade = mine ? g.fadeLen : 0u;
+#pragma unroll
+                for(int d = 32; d >= 1; d >>= 1) { const uint32_t o = uint32_t(__shfl_xor(int(maxFade), d)); maxFade = o > maxFade ? o : maxFade; }
+                if(lane < ls)
+                {
+                    blk[lane] = __builtin_bit_cast(uint32_t, (mine && g.steady) ? g.tgt : 0.0f);
+                    blk[ls + lane] = __builtin_bit_cast(uint32_t, mine ? g.cur : 0.0f);
+                    blk[2u * ls + lane] = __builtin_bit_cast(uint32_t, mine ? g.step : 0.0f);
+                    blk[3u * ls + lane] = mine ? g.fadeLen : 0u;
+                }
+                if(lane < 8u) blk[4u * ls + lane] = lane == 0u ? 1u : (lane == 1u ? maxFade : 0u);
+            }
             cf16 *co = (cf16*)(uintptr_t)(L.hrtfTgt + size_t{v} * irStride * 2);
-            if(L.ablate & 1u) {}
+            if(NL > 0 || (L.ablate & 1u)) {}
             else if(irStride == uint32_t(TAPS))
                 FirMainPk<R, TAPS>(acc, &w.x2[TAPS + R * lane], co);
             else
@@ -810,7 +859,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 for(uint32_t seg = 0; seg * 16u < irStride; ++seg)
                     FirMainPk<R, 16>(acc, xw - 16 * seg, co + 2 * seg);
             }
-            if(oldPass && !(L.ablate & 1u))
+            if(NL == 0 && oldPass && !(L.ablate & 1u))
             {   // frames lane + 64q receive cOld[lane + 64q - i] * xo[i], i < 64
 #pragma unroll 1
                 for(int i0 = 0; i0 < 64; i0 += 8)
@@ -828,7 +877,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 
             stamp(5);
             // voice.cpp:1094-1101 / :869-873,900: Old <- Target, Old.Gain <- reached gain
-            if(dirty && (counter == 0 || fademix))
+            if(NL == 0 && dirty && (counter == 0 || fademix))
             {
                 const float *tg = L.hrtfTgt + size_t{v} * irStride * 2;
                 float *od = L.hrtfOld + size_t{v} * irStride * 2;
@@ -838,10 +887,13 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             if(lane == 0)
             {
                 VoiceCtl &c = L.ctl[v];
-                if(counter == 0 || fademix) { c.hrtfOldDelay[0] = tail.tgtDelay[0]; c.hrtfOldDelay[1] = tail.tgtDelay[1]; }
-                c.hrtfOldGain = todo ? endGain : gainAfterBlend;
+                if(NL == 0)
+                {
+                    if(counter == 0 || fademix) { c.hrtfOldDelay[0] = tail.tgtDelay[0]; c.hrtfOldDelay[1] = tail.tgtDelay[1]; }
+                    c.hrtfOldGain = todo ? endGain : gainAfterBlend;
+                }
                 uint32_t flags = head.flags | kFlagFading;
-                if(counter == 0 || fademix) flags &= ~kFlagHrtfDirty;
+                if(NL > 0 || counter == 0 || fademix) flags &= ~kFlagHrtfDirty;
                 c.flags = flags;
                 if(!playing) c.playState = OALGPU_VOICE_STOPPED;
                 else
@@ -880,6 +932,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
     }
 
+    if constexpr (NL > 0) return;
     // ---- one partial per workgroup: waves dump their accumulators, then a fixed-order sum
     {
         f2 *dump = w.x2;                     // [frame] = (L, R), frames < 64R
@@ -909,10 +962,140 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     }
 }
 
+// ---- MixSamples of every voice onto the dry lines ------------------------------------------------
+// out[c][f] += stream_v[f] * gain_{v,c}(f) over the voices of one group, in voice order: thread t
+// owns frame 256*blockIdx.x + t of every line, blockIdx.y is the voice group.  The stream rows
+// are read once, coalesced, and together with the gain blocks a whole batch ahead of use.  A gain ramp
+// (MixLine with Counter <= 64, voice.cpp:1093) only ever covers the first 64 frames: the first
+// wavefront of the first frame block adds s * (ramp(f) - constant) for those.  One partial bus
+// per group, summed by BusReduceKernel in group order: deterministic.
+constexpr uint32_t kMixBatch = 16;                // stream rows in flight per thread
+template<int NLMAX>
+__global__ void __launch_bounds__(256) LinesMixKernel(DeviceLayout L, uint32_t samplesToDo)
+{
+    constexpr uint32_t kBlk = 4u * NLMAX + 8u;     // LineBlockDwords(NLMAX)
+    const uint32_t t = threadIdx.x;
+    const uint32_t f = blockIdx.x * 256u + t;
+    const uint32_t g = blockIdx.y;
+    const uint32_t nd = L.numDry;
+    const uint32_t per = (L.numVoices + L.numLineGroups - 1u) / L.numLineGroups;
+    const uint32_t v0 = g * per;
+    const uint32_t cnt = (v0 < L.numVoices) ? ((v0 + per < L.numVoices) ? per : L.numVoices - v0) : 0u;
+    float acc[NLMAX];
+#pragma unroll
+    for(int c = 0; c < NLMAX; ++c) acc[c] = 0.0f;
+    const float *rows = L.streams + size_t{v0} * kLine + f;
+    // gain ramps end within the first 64 frames: only this wavefront ever evaluates them
+    const bool rampWave = blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(t >> 6) == 0u;
+    const float ff = float(f);
+    const uint32_t *blk = L.lineGains + size_t{v0} * kBlk;
+    unsigned long long rampMask = 0ull;           // voices of the group (<= 64) with a gain ramp
+    for(uint32_t b = 0; b < cnt; b += kMixBatch)
+    {
+        // every load of the batch -- stream rows, gain blocks (same address in all lanes: one
+        // request each), flags -- is issued before the first use; rows past the group's end
+        // re-read its last voice and contribute nothing
+        float s[kMixBatch];
+        float4 gq[kMixBatch][NLMAX / 4];
+        uint2 fl[kMixBatch];
+#pragma unroll
+        for(uint32_t k = 0; k < kMixBatch; ++k)
+        {
+            const uint32_t vi = (b + k < cnt) ? b + k : cnt - 1u;
+            s[k] = rows[size_t{vi} * kLine];
+#pragma unroll
+            for(int q = 0; q < NLMAX / 4; ++q) gq[k][q] = reinterpret_cast<const float4*>(blk + vi * kBlk)[q];
+            fl[k] = *reinterpret_cast<const uint2*>(blk + vi * kBlk + 4u * NLMAX);
+        }
+#pragma unroll
+        for(uint32_t k = 0; k < kMixBatch; ++k)
+        {
+            const bool in = b + k < cnt;
+            // a voice that did not mix keeps a stale row: make its contribution an exact zero
+            const bool livev = in && fl[k].x != 0u;
+            const float sk = livev ? s[k] : 0.0f;
+#pragma unroll
+            for(int q = 0; q < NLMAX / 4; ++q)
+            {
+                acc[4 * q] = __builtin_fmaf(sk, gq[k][q].x, acc[4 * q]);
+                acc[4 * q + 1] = __builtin_fmaf(sk, gq[k][q].y, acc[4 * q + 1]);
+                acc[4 * q + 2] = __builtin_fmaf(sk, gq[k][q].z, acc[4 * q + 2]);
+                acc[4 * q + 3] = __builtin_fmaf(sk, gq[k][q].w, acc[4 * q + 3]);
+            }
+            if(rampWave && livev && __builtin_amdgcn_readfirstlane(fl[k].y) != 0u) rampMask |= 1ull << (b + k);
+        }
+    }
+    // s * (ramp(f) - constant) on the frames a ramp covers, for the voices that have one: their
+    // indices are compacted so that up to kRampBatch rows and ramp blocks are in flight together
+    while(rampMask)
+    {
+        constexpr int kRampBatch = 8;
+        uint32_t idx[kRampBatch];
+        bool on[kRampBatch];
+#pragma unroll
+        for(int j = 0; j < kRampBatch; ++j)
+        {
+            on[j] = rampMask != 0ull;
+            idx[j] = on[j] ? uint32_t(__builtin_ctzll(rampMask)) : 0u;
+            if(on[j]) rampMask &= rampMask - 1ull;
+        }
+        float sv[kRampBatch];
+        float4 gq[kRampBatch][NLMAX / 4], cq[kRampBatch][NLMAX / 4], sq[kRampBatch][NLMAX / 4];
+        uint4 fq[kRampBatch][NLMAX / 4];
+#pragma unroll
+        for(int j = 0; j < kRampBatch; ++j)
+        {
+            const uint32_t *vb = blk + idx[j] * kBlk;
+            sv[j] = rows[size_t{idx[j]} * kLine];
+#pragma unroll
+            for(int q = 0; q < NLMAX / 4; ++q)
+            {
+                gq[j][q] = reinterpret_cast<const float4*>(vb)[q];
+                cq[j][q] = reinterpret_cast<const float4*>(vb + NLMAX)[q];
+                sq[j][q] = reinterpret_cast<const float4*>(vb + 2 * NLMAX)[q];
+                fq[j][q] = reinterpret_cast<const uint4*>(vb + 3 * NLMAX)[q];
+            }
+        }
+#pragma unroll
+        for(int j = 0; j < kRampBatch; ++j)
+        {
+            const float sk = on[j] ? sv[j] : 0.0f;
+#pragma unroll
+            for(int q = 0; q < NLMAX / 4; ++q)
+            {
+                const float d0 = (f < fq[j][q].x) ? (cq[j][q].x + sq[j][q].x * ff) - gq[j][q].x : 0.0f;
+                const float d1 = (f < fq[j][q].y) ? (cq[j][q].y + sq[j][q].y * ff) - gq[j][q].y : 0.0f;
+                const float d2 = (f < fq[j][q].z) ? (cq[j][q].z + sq[j][q].z * ff) - gq[j][q].z : 0.0f;
+                const float d3 = (f < fq[j][q].w) ? (cq[j][q].w + sq[j][q].w * ff) - gq[j][q].w : 0.0f;
+                acc[4 * q] = __builtin_fmaf(sk, d0, acc[4 * q]);
+                acc[4 * q + 1] = __builtin_fmaf(sk, d1, acc[4 * q + 1]);
+                acc[4 * q + 2] = __builtin_fmaf(sk, d2, acc[4 * q + 2]);
+                acc[4 * q + 3] = __builtin_fmaf(sk, d3, acc[4 * q + 3]);
+            }
+        }
+    }
+    float *pl = L.partLines + size_t{g} * L.mixLines * kLine;
+#pragma unroll
+    for(int c = 0; c < NLMAX; ++c)
+        if(uint32_t(c) < nd) pl[size_t(c) * kLine + f] = (f < samplesToDo) ? acc[c] : 0.0f;
+    // lines no voice of this context mixes into (wet buses without sends) stay zero
+    for(uint32_t c = nd; c < L.mixLines; ++c) pl[size_t{c} * kLine + f] = 0.0f;
+}
+
 } // namespace
 
 bool WaveKernelApplies(bool exact, const DeviceLayout &L)
-{ return !exact && L.hrtf && L.numSends == 0 && L.irStride >= 8 && L.irStride <= 128; }
+{
+    if(exact || L.numSends != 0) return false;
+    if(L.hrtf) return L.irStride >= 8 && L.irStride <= 128;
+    return L.numDry >= 1 && L.numDry <= 32;
+}
+
+const char *WaveKernelName(const DeviceLayout &L)
+{
+    if(!L.hrtf) return "VoiceWaveKernel<17, 64, 1>";
+    return L.irStride <= 64 ? "VoiceWaveKernel<17, 64, 0>" : "VoiceWaveKernel<18, 128, 0>";
+}
 
 uint32_t WaveKernelGroups(const DeviceLayout &L)
 { return (L.numVoices + kWWaves * L.waveVoices - 1u) / (kWWaves * L.waveVoices); }
@@ -920,10 +1103,18 @@ uint32_t WaveKernelGroups(const DeviceLayout &L)
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo)
 {
     const uint32_t groups = WaveKernelGroups(L);
-    if(L.irStride <= 64)
-        hipLaunchKernelGGL((VoiceWaveKernel<17, 64>), dim3(groups), dim3(kWThreads), 0, s, L, samplesToDo);
+    if(!L.hrtf)
+    {
+        hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1>), dim3(groups), dim3(kWThreads), 0, s, L, samplesToDo);
+        const dim3 grid(kLine / 256, L.numLineGroups);
+        if(L.numDry <= 8) hipLaunchKernelGGL(LinesMixKernel<8>, grid, dim3(256), 0, s, L, samplesToDo);
+        else if(L.numDry <= 16) hipLaunchKernelGGL(LinesMixKernel<16>, grid, dim3(256), 0, s, L, samplesToDo);
+        else hipLaunchKernelGGL(LinesMixKernel<32>, grid, dim3(256), 0, s, L, samplesToDo);
+    }
+    else if(L.irStride <= 64)
+        hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0>), dim3(groups), dim3(kWThreads), 0, s, L, samplesToDo);
     else
-        hipLaunchKernelGGL((VoiceWaveKernel<18, 128>), dim3(groups), dim3(kWThreads), 0, s, L, samplesToDo);
+        hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0>), dim3(groups), dim3(kWThreads), 0, s, L, samplesToDo);
     return hipGetLastError();
 }
 
