@@ -30,16 +30,38 @@ FP32_PEAK_TFLOPS = 157.3         # fp32 dense peak (MFMA f32 = packed vector rat
 # algorithmic flops per voice-update, SURVEY.md 8(d) / DESIGN.md 3.4:
 #   config 3: bsinc24 resample 1024*24*4 + dual-ear FIR 1024*64*2*2 + gain 1024*4
 #   config 2: bsinc24 resample + 5-line gain mix 1024*2*5
-FLOPS_PER_VOICE_UPDATE = {3: 1024 * 24 * 4 + 1024 * 64 * 2 * 2 + 1024 * 4, 2: 1024 * 24 * 4 + 1024 * 2 * 5}
+#   config 4: config 2 + on average 2 sends (4-line gain mix each, every third through a biquad pair)
+#   config 5: config 3 + one send
+FLOPS_PER_VOICE_UPDATE = {3: 1024 * 24 * 4 + 1024 * 64 * 2 * 2 + 1024 * 4, 2: 1024 * 24 * 4 + 1024 * 2 * 5,
+                          4: 1024 * 24 * 4 + 1024 * 2 * 5 + 2 * (1024 * 2 * 4) + 2 * 1024 * 18 // 3,
+                          5: 1024 * 24 * 4 + 1024 * 64 * 2 * 2 + 1024 * 4 + 1024 * 2 * 4}
 # algorithmic bytes per voice-update, SURVEY.md 8(d) / DESIGN.md "Algorithmic bytes":
 #   source window (941+48) f32 + mPrevSamples r/w + position r/w + HRTF history r/w + target HRIR
-BYTES_PER_VOICE_UPDATE = {3: 3956 + 384 + 16 + 512 + 512, 2: 3956 + 384 + 16 + 2 * 4 * 5 + 4 * 5}
+BYTES_PER_VOICE_UPDATE = {3: 3956 + 384 + 16 + 512 + 512, 2: 3956 + 384 + 16 + 2 * 4 * 5 + 4 * 5,
+                          4: 3956 + 384 + 16 + 3 * 4 * 5 + 2 * 3 * 4 * 4, 5: 3956 + 384 + 16 + 512 + 512 + 3 * 4 * 4}
 
 
 def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, vpg):
-    hrtf = config_id == 3
+    hrtf = config_id in (3, 5)
+    nsends = {4: 4, 5: 1}.get(config_id, 0)
     sc = oalgpu.Scene(api, sample_rate=48000, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0,
+                      num_sends=nsends, num_slots=nsends, wet_channels=4,
                       hrtf=hrtf, max_voices=nvoices, max_buffers=256, voices_per_group=vpg)
+    sc.effects = []
+    if config_id == 4:                  # EAX reverb, default preset, in every slot
+        for slot in range(4):
+            rev = oalgpu.Reverb(5)
+            rev.update(oalgpu.ReverbProps.make(), 1.0)
+            sc.set_slot_reverb(slot, rev)
+            sc.effects.append(rev)
+    if config_id == 5:                  # 65 536-tap exponentially decaying noise, BASELINE configs[4]
+        lcg = synth.Lcg(0x5EED0005)
+        ir = np.array([lcg.uniform(-1.0, 1.0) for _ in range(65536)], np.float32)
+        ir *= np.exp(-np.arange(65536) / 12000.0).astype(np.float32) * 0.05
+        conv = oalgpu.Convolution(4, ir)
+        conv.set_target_gains([1.0, 0.0, 0.0, 0.0])
+        sc.set_slot_convolution(0, conv)
+        sc.effects.append(conv)
     if hrtf:
         rng = np.random.default_rng(1234)
         cc = np.zeros((4, 128, 2), np.float32)
@@ -105,8 +127,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=3, choices=(2, 3))
-    ap.add_argument("--voices", type=int, default=4096, help="voices per GPU")
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
+    ap.add_argument("--voices", type=int, default=None, help="voices per GPU (default 4096; 8192 for config 4)")
     ap.add_argument("--math", default="fast", choices=("fast", "exact"))
     ap.add_argument("--vpg", type=int, default=0, help="voices per workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,8 +152,9 @@ def main():
     api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank)
     mhr = synth.synth_mhr_bytes()
     api._mhr = mhr
-    V = args.voices
-    hrtf = args.config == 3
+    V = args.voices if args.voices else (8192 if args.config == 4 else 4096)
+    hrtf = args.config in (3, 5)
+    post = hrtf or args.config == 4          # effect slots run with the post-process
     sc, script = build_scene(oalgpu, synth, api, args.config, V, rank * V, mhr, args.vpg)
 
     all_voices = list(range(V))
@@ -148,7 +171,7 @@ def main():
     def step(k):
         sc.apply_block(blocks[k])
         if mixer is None:
-            sc.mix(UPDATE_SAMPLES, post_process=hrtf)
+            sc.mix(UPDATE_SAMPLES, post_process=post)
         else:
             mixer.update(UPDATE_SAMPLES)          # partial buses, one RCCL reduce, post-process on rank 0
 
@@ -181,7 +204,7 @@ def main():
         a, b = sc.last_update_ms()
         tot.append(a)
         vk.append(b)
-        if world == 1 and hrtf:
+        if world == 1 and post:
             sc.post_process(UPDATE_SAMPLES)
     sc.sync()
     sc.set_timing(False)
@@ -204,8 +227,10 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "mixed voices/sec @48kHz 1024-sample update, HRTF stereo" if hrtf
-                      else "mixed voices/sec @48kHz 1024-sample update, bsinc24 -> 7.1 dry bus",
+            "metric": {3: "mixed voices/sec @48kHz 1024-sample update, HRTF stereo",
+                       2: "mixed voices/sec @48kHz 1024-sample update, bsinc24 -> 7.1 dry bus",
+                       4: "mixed voices/sec @48kHz 1024-sample update, 7.1 dry bus + 4 EAX reverb slots",
+                       5: "mixed voices/sec @48kHz 1024-sample update, HRTF stereo + convolution slot"}[args.config],
             "value": nvoices_total * args.steps / elapsed,
             "unit": "voices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,6 +241,7 @@ def main():
                                    f"(44.1k->48k, bsinc24"
                                    + (", HRTF synthetic .mhr with Default-HRTF geometry irSize 64, "
                                       "dual-ear FIR + MixDirectHrtf" if hrtf else ", 5-line dry mix")
+                                   + {4: ", v%5 sends into 4 reverb slots", 5: ", one send into a 65536-tap convolution slot"}.get(args.config, "")
                                    + "), 25% filtered, every 4th voice moving",
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
                        "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
@@ -230,7 +256,7 @@ def main():
                          "hbm_achieved": hbm_achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s",
                          "hbm_frac": hbm_achieved / HBM_PEAK_GBS},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config in (2, 3):
             cb = cpu_baseline(synth, args.config, V)
             if cb:
                 out["cpu_baseline"] = cb

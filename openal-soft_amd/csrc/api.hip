@@ -95,6 +95,7 @@ struct oalgpu_context {
     uint32_t parity{0};
     bool postPending{false};
     float *partHrtfBuf[2]{nullptr, nullptr};
+    float *partLinesBuf[2]{nullptr, nullptr};
     bool timing{false}, timed{false};
     DeviceLayout L{};
     HrtfStoreDev hrtfDev{};
@@ -112,7 +113,7 @@ struct oalgpu_context {
     DevBuf<VoiceCtl> ctl;
     DevBuf<float> prev, hrtfOld, hrtfTgt, hist, gainCur, gainTgt, sendCur, sendTgt;
     DevBuf<BiquadSlot> dfilt, sfilt;
-    DevBuf<float> partLines, partHrtf, partHrtf2, bus, streams;
+    DevBuf<float> partLines, partLines2, partHrtf, partHrtf2, bus, streams;
     DevBuf<uint32_t> lineGains;
     DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
     bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
@@ -420,16 +421,25 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->sendCur.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendCur.zero()); L.sendCur = c->sendCur.p;
     HIP_TRY(c->sendTgt.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendTgt.zero()); L.sendTgt = c->sendTgt.p;
     L.numLineGroups = L.numGroups;
-    L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0;
-    if(c->useWave && !L.hrtf)
-    {   // LinesMixKernel: at most 64 voices per partial bus, at least 128 partials when there
-        // are that many voices (4 x 128 workgroups)
-        L.numLineGroups = std::max<uint32_t>(std::min<uint32_t>(256u, desc->max_voices), (desc->max_voices + 63u) / 64u);
-        HIP_TRY(c->streams.alloc(nv * kLine)); HIP_TRY(c->streams.zero()); L.streams = c->streams.p;
-        L.lineStride = L.numDry <= 8 ? 8u : (L.numDry <= 16 ? 16u : 32u);
-        HIP_TRY(c->lineGains.alloc(nv * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero()); L.lineGains = c->lineGains.p;
+    L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0; L.streamsPerVoice = 0;
+    if(c->useWave && (!L.hrtf || L.numSends))
+    {   // LinesMixKernel: at most 64 voices per partial bus; 256 partials while the buses are
+        // narrow, 128 when they are wide (the partials are HBM traffic for the reduction)
+        L.lineStride = L.mixLines <= 8 ? 8u : (L.mixLines <= 16 ? 16u : 32u);
+        L.streamsPerVoice = 2u + L.numSends;
+        // its LDS row list (1 + lineStride dwords per potential row) stays under 60 KB
+        const uint32_t maxRows = 60000u / (4u * (1u + L.lineStride));
+        const uint32_t maxPer = std::max<uint32_t>(1u, std::min<uint32_t>(64u, maxRows / L.streamsPerVoice));
+        const uint32_t want = L.mixLines <= 8 ? 256u : 128u;
+        L.numLineGroups = std::max<uint32_t>(std::min<uint32_t>(want, desc->max_voices), (desc->max_voices + maxPer - 1u) / maxPer);
+        HIP_TRY(c->streams.alloc(nv * L.streamsPerVoice * kLine)); HIP_TRY(c->streams.zero()); L.streams = c->streams.p;
+        HIP_TRY(c->lineGains.alloc(nv * L.streamsPerVoice * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
+        L.lineGains = c->lineGains.p;
     }
     HIP_TRY(c->partLines.alloc(size_t{L.numLineGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
+    // the two-stream pipeline of oalgpu_mix_update alternates between two sets of partial buses
+    HIP_TRY(c->partLines2.alloc(c->useWave && L.hrtf && L.streams ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
+    c->partLinesBuf[0] = c->partLines.p; c->partLinesBuf[1] = c->partLines2.p;
     HIP_TRY(c->partHrtf.alloc(L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0)); L.partHrtf = c->partHrtf.p;
     HIP_TRY(c->partHrtf2.alloc(c->useWave && L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
     c->partHrtfBuf[0] = c->partHrtf.p; c->partHrtfBuf[1] = c->partHrtf2.p;
@@ -791,6 +801,7 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
     const uint32_t p = c->parity;
     DeviceLayout L = c->L;
     L.partHrtf = c->partHrtfBuf[p];
+    if(L.streams) L.partLines = c->partLinesBuf[p];
     // main stream: this update's voices; its partial-bus buffer was last read by the reduction
     // of two updates ago
     HIP_TRY(hipStreamWaitEvent(c->stream, c->evReduceDone[p], 0));

@@ -55,12 +55,13 @@ static_assert(sizeof(VoiceCtl) == 128, "VoiceCtl is one 128-byte line");
 struct alignas(16) BiquadSlot { BiquadState f; uint32_t pad[3]; };
 static_assert(sizeof(BiquadSlot) == 64, "BiquadSlot");
 
-// The resolved MixLine gains (dev_mix.hpp MixLineGain) of one voice's lines, as LinesMixKernel
-// consumes them: a block of 4*S + 8 dwords per voice, S = lineStride (numDry padded to 8/16/32),
-//   [gain[S] | cur[S] | step[S] | fadeLen[S] | live, maxFadeLen, 0...]
-// frames below fadeLen[c] use cur[c] + step[c]*frame, the others gain[c] (0 when the line's
-// constant part is not mixed); live == 0: the voice did not mix in this update.
-__host__ __device__ inline uint32_t LineBlockDwords(uint32_t lineStride) { return 4u * lineStride + 8u; }
+// The resolved MixLine gains (dev_mix.hpp MixLineGain) of one stream row over the mix lines, as
+// LinesMixKernel consumes them: a block of 3*S + 8 dwords per row, S = lineStride,
+//   [gain[S] | rampA[S] | rampB[S] | live, rampLen, 0...]
+// every frame uses gain[c] (0 when the line's constant part is not mixed); frames below rampLen
+// add rampA[c] + rampB[c]*frame, the ramp's distance from the constant (0 for lines without a
+// ramp).  live == 0: nothing to mix from this row in this update.
+__host__ __device__ inline uint32_t LineBlockDwords(uint32_t lineStride) { return 3u * lineStride + 8u; }
 
 struct DeviceLayout {
     // configuration
@@ -84,12 +85,13 @@ struct DeviceLayout {
     float *sendCur, *sendTgt;
     // partial buses written by the voice kernel: [group][mixLines][1024], [group][1152][2]
     float *partLines, *partHrtf;
-    // dry-line contexts on the wavefront kernel: per-voice filtered samples [voice][1024] and
-    // line gains [voice][numDry], consumed by LinesMixKernel, which writes numLineGroups partials
+    // wavefront kernel, dry-line and send mixing: stream rows [voice][streamsPerVoice][1024] and
+    // their gain blocks, consumed by LinesMixKernel, which writes numLineGroups partial buses
     float *streams;
     uint32_t *lineGains;
     uint32_t numLineGroups;                 // groups of partLines (== numGroups unless LinesMixKernel runs)
-    uint32_t lineStride;                    // records per voice in lineGains: numDry rounded up to 8 / 16 / 32
+    uint32_t lineStride;                    // gain vector width of a stream row: mixLines rounded up to 8 / 16 / 32
+    uint32_t streamsPerVoice;               // stream rows per voice: 2 + numSends (see voice_wave.hip)
     // final bus block: [(numDry+numReal) x 1024 | numSlots*wetChannels x 1024 | 1152 x 2]
     float *bus;
 };

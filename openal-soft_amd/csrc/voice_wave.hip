@@ -501,6 +501,74 @@ __device__ __forceinline__ void BiquadDualWaveScan(BiquadState &f0, BiquadState 
     for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < cnt) buf[begin + i] = x[i];
 }
 
+// DoFilters (voice.cpp:255-267) for one filter pair of a voice, in place over buf[0..n):
+// settled coefficients run the wave-parallel block scan, an interpolating filter the serial
+// reference loop on lane 0; an inactive pair is cleared (voice.cpp:264-265).  `fst` = this
+// wave's 32-dword LDS scratch holding the two BiquadSlots' first 16 dwords each.
+__device__ __forceinline__ void WaveDoFilters(float *fst, BiquadSlot *slots, bool filterActive, float *buf, uint32_t n,
+    uint32_t lane)
+{
+    BiquadState f0, f1;
+    {
+        const float *a = fst, *b = fst + 16;
+        f0 = BiquadState{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], __builtin_bit_cast(int32_t, a[12])};
+        f1 = BiquadState{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11], __builtin_bit_cast(int32_t, b[12])};
+    }
+    if(filterActive)
+    {
+        if(f0.counter <= 0 && f1.counter <= 0)
+        {
+            BiquadDualWaveScan(f0, f1, buf, n, lane);
+            if(lane == 0) { slots[0].f.z1 = f0.z1; slots[0].f.z2 = f0.z2; slots[1].f.z1 = f1.z1; slots[1].f.z2 = f1.z2; }
+        }
+        else
+        {
+            if(lane == 0) BiquadDualInterp(f0, f1, buf, buf, n);
+            if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
+        }
+    }
+    else
+    {   // skip the store when the pair already is clear
+        const bool clean0 = f0.z1 == 0.0f && f0.z2 == 0.0f && f0.counter == 0 && f0.b0 == f0.tb0 && f0.b1 == f0.tb1
+            && f0.b2 == f0.tb2 && f0.a1 == f0.ta1 && f0.a2 == f0.ta2;
+        const bool clean1 = f1.z1 == 0.0f && f1.z2 == 0.0f && f1.counter == 0 && f1.b0 == f1.tb0 && f1.b1 == f1.tb1
+            && f1.b2 == f1.tb2 && f1.a1 == f1.ta1 && f1.a2 == f1.ta2;
+        if(!(clean0 && clean1) && lane == 0)
+        {
+            BiquadClear(f0); BiquadClear(f1);
+            slots[0].f = f0; slots[1].f = f1;
+        }
+    }
+}
+
+// One line's share of a stream row's gain block (kernels.hpp LineBlockDwords): contributions of
+// several MixSamples calls onto the same row and line add up -- the constant gains, and for
+// the ramped frames the per-frame values (a contribution without a ramp adds its constant there)
+struct RowLineGain {
+    float gain{0.0f}, cur{0.0f}, step{0.0f};
+    uint32_t fadeLen{0};
+    __device__ __forceinline__ void add(const MixLineGain &g)
+    {
+        const float constant = g.steady ? g.tgt : 0.0f;
+        gain += constant;
+        if(g.fadeLen) { cur += g.cur; step += g.step; fadeLen = g.fadeLen; }
+        else cur += constant;
+    }
+};
+__device__ __forceinline__ void StoreRowBlock(uint32_t *blk, uint32_t ls, uint32_t lane, const RowLineGain &r, bool live)
+{
+    uint32_t maxFade = r.fadeLen;
+#pragma unroll
+    for(int d = 32; d >= 1; d >>= 1) { const uint32_t o = uint32_t(__shfl_xor(int(maxFade), d)); maxFade = o > maxFade ? o : maxFade; }
+    if(lane < ls)
+    {
+        blk[lane] = __builtin_bit_cast(uint32_t, r.gain);
+        blk[ls + lane] = __builtin_bit_cast(uint32_t, r.fadeLen ? r.cur - r.gain : 0.0f);
+        blk[2u * ls + lane] = __builtin_bit_cast(uint32_t, r.fadeLen ? r.step : 0.0f);
+    }
+    if(lane < 8u) blk[3u * ls + lane] = lane == 0u ? (live ? 1u : 0u) : (lane == 1u ? maxFade : 0u);
+}
+
 // NL == 0: HRTF voices (DoHrtfMix into the wave's register accumulator).
 // NL == 1: voices panned onto dry lines (MixSamples, voice.cpp:962-963).  Holding N lines x 1024
 // frames of accumulator per wavefront would take 16 N VGPRs per lane on top of the resampler's
@@ -508,7 +576,11 @@ __device__ __forceinline__ void BiquadDualWaveScan(BiquadState &f0, BiquadState 
 // resampler), so this variant stops after DoFilters: it leaves the voice's 1024 filtered
 // samples in HBM (L.streams, 4 KB per voice) together with the resolved MixLine gain of every
 // line (L.lineGains), and LinesMixKernel below turns those into partial buses.
-template<int R, int TAPS, int NL>
+// SENDS: the context has auxiliary sends (voice.cpp:966-983): every send with a slot leaves a
+// stream row too -- the unfiltered resampled samples shared by all sends (and the direct path)
+// whose filter is inactive, or its own filtered copy -- with a gain block over the wet lines.
+// Stream rows of a voice: [0] unfiltered, [1] direct-filtered (dry-line contexts), [2+i] send i filtered.
+template<int R, int TAPS, int NL, bool SENDS>
 __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo)
 {
     using WL = WaveLds<R, TAPS>;
@@ -577,9 +649,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             active = mixes && head.step >= 1u;
             // voice.cpp:1002-1010
             if(mixes && !active && !playing && lane == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
-            if constexpr (NL > 0)
+            if constexpr (SENDS || NL > 0)
             {   // nothing to mix for this voice in this update
-                if(!active && lane == 0) L.lineGains[size_t{v} * LineBlockDwords(L.lineStride) + 4u * L.lineStride] = 0u;
+                if(!active && lane < L.streamsPerVoice)
+                    L.lineGains[(size_t{v} * L.streamsPerVoice + lane) * LineBlockDwords(L.lineStride) + 3u * L.lineStride] = 0u;
             }
         }
         auto stamp = [&](int slot)
@@ -622,44 +695,111 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             stamp(1);
             counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
 
+            const bool directFilter = (head.flags & kFlagDirectFilter) && !(L.ablate & 8u);
+            if constexpr (SENDS || NL > 0)
+            {   // ---- stream rows that must leave before the direct filter overwrites w.in
+                const uint32_t ls = L.lineStride, spv = L.streamsPerVoice, numSends = L.numSends, wetCh = L.wetChannels;
+                const uint32_t wetBase = L.hrtf ? 0u : L.numDry;
+                float *rowsV = L.streams + size_t{v} * spv * kLine;
+                uint32_t *blkV = L.lineGains + size_t{v} * spv * LineBlockDwords(ls);
+                RowLineGain row0;                       // the unfiltered row's merged gains, line = lane
+                bool row0Live = false;
+                if constexpr (NL > 0)
+                {
+                    if(!directFilter)
+                    {   // MixSamples onto the dry lines rides on the unfiltered row
+                        const uint32_t nd = L.numDry;
+                        float tg = 0.0f, cu = 0.0f;
+                        if(lane < nd)
+                        {
+                            tg = playing ? L.gainTgt[size_t{v} * nd + lane] : 0.0f;       // SilentCoeffs when Stopping
+                            cu = counter ? L.gainCur[size_t{v} * nd + lane] : tg;         // voice.cpp:1094-1112
+                        }
+                        const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+                        if(lane < nd) { L.gainCur[size_t{v} * nd + lane] = g.newCur; row0.add(g); }
+                        row0Live = true;
+                    }
+                }
+                if constexpr (SENDS)
+                {
+                    for(uint32_t si = 0; si < numSends; ++si)
+                    {
+                        const int32_t slot = L.ctl[v].sendSlot[si];
+                        uint32_t *blkS = blkV + size_t{2u + si} * LineBlockDwords(ls);
+                        if(slot < 0) { if(lane == 0) blkS[3u * ls] = 0u; continue; }
+                        const bool sendFilter = (head.flags >> (kFlagSendFilterShift + si)) & 1u;
+                        // the send's gains onto its slot's wet lines (voice.cpp:978-979)
+                        const uint32_t base = wetBase + uint32_t(slot) * wetCh;
+                        const bool mine = lane >= base && lane < base + wetCh;
+                        float tg = 0.0f, cu = 0.0f;
+                        float *curp = L.sendCur + (size_t{v} * numSends + si) * wetCh + (lane - base);
+                        if(mine)
+                        {
+                            tg = playing ? L.sendTgt[(size_t{v} * numSends + si) * wetCh + (lane - base)] : 0.0f;
+                            cu = counter ? *curp : tg;
+                        }
+                        const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+                        if(mine) *curp = g.newCur;
+                        // filter state of this send
+                        BiquadSlot *slots = &L.sfilt[(size_t{v} * numSends + si) * 2];
+                        WaveSync();
+                        if(lane < 32u) w.fst[lane] = reinterpret_cast<const float*>(slots)[lane];
+                        WaveSync();
+                        if(sendFilter)
+                        {   // its own filtered copy, built in the (currently unused) resampler scratch
+                            float *tmp = w.rd;
+                            for(uint32_t k = lane; k < N; k += 64) tmp[k] = w.in[kHist + k];
+                            WaveSync();
+                            WaveDoFilters(w.fst, slots, true, tmp, N, lane);
+                            WaveSync();
+                            float *dst = rowsV + size_t{2u + si} * kLine;
+                            for(uint32_t k = lane; k < uint32_t(kLine); k += 64) dst[k] = (k < N) ? tmp[k] : 0.0f;
+                            RowLineGain r;
+                            if(mine) r.add(g);
+                            StoreRowBlock(blkS, ls, lane, r, true);
+                        }
+                        else
+                        {
+                            WaveDoFilters(w.fst, slots, false, w.in + kHist, N, lane);
+                            if(mine) row0.add(g);
+                            row0Live = true;
+                            if(lane == 0) blkS[3u * ls] = 0u;
+                        }
+                    }
+                }
+                if(row0Live)
+                    for(uint32_t k = lane; k < uint32_t(kLine); k += 64) rowsV[k] = (k < N) ? w.in[kHist + k] : 0.0f;
+                StoreRowBlock(blkV, ls, lane, row0, row0Live);
+                WaveSync();
+            }
+
             // ---- DoFilters, direct path (voice.cpp:255-267): in place on w.in[kHist..]
             {
                 if(lane < 32u) w.fst[lane] = fstv;
                 WaveSync();
-                BiquadState f0, f1;
-                {
-                    const float *a = w.fst, *b = w.fst + 16;
-                    f0 = BiquadState{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], __builtin_bit_cast(int32_t, a[12])};
-                    f1 = BiquadState{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11], __builtin_bit_cast(int32_t, b[12])};
-                }
-                BiquadSlot *slots = &L.dfilt[size_t{v} * 2];
-                if((head.flags & kFlagDirectFilter) && !(L.ablate & 8u))
-                {
-                    if(f0.counter <= 0 && f1.counter <= 0)
-                    {
-                        BiquadDualWaveScan(f0, f1, w.in + kHist, N, lane);
-                        if(lane == 0) { slots[0].f.z1 = f0.z1; slots[0].f.z2 = f0.z2; slots[1].f.z1 = f1.z1; slots[1].f.z2 = f1.z2; }
-                    }
-                    else
-                    {
-                        if(lane == 0) BiquadDualInterp(f0, f1, w.in + kHist, w.in + kHist, N);
-                        if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
-                    }
-                }
-                else
-                {   // an inactive filter is cleared every update (voice.cpp:264-265); skip the
-                    // store when it already is
-                    const bool clean0 = f0.z1 == 0.0f && f0.z2 == 0.0f && f0.counter == 0 && f0.b0 == f0.tb0 && f0.b1 == f0.tb1
-                        && f0.b2 == f0.tb2 && f0.a1 == f0.ta1 && f0.a2 == f0.ta2;
-                    const bool clean1 = f1.z1 == 0.0f && f1.z2 == 0.0f && f1.counter == 0 && f1.b0 == f1.tb0 && f1.b1 == f1.tb1
-                        && f1.b2 == f1.tb2 && f1.a1 == f1.ta1 && f1.a2 == f1.ta2;
-                    if(!(clean0 && clean1) && lane == 0)
-                    {
-                        BiquadClear(f0); BiquadClear(f1);
-                        slots[0].f = f0; slots[1].f = f1;
-                    }
-                }
+                WaveDoFilters(w.fst, &L.dfilt[size_t{v} * 2], directFilter, w.in + kHist, N, lane);
                 WaveSync();
+            }
+            if constexpr (NL > 0)
+            {   // the direct-filtered row (voice.cpp:962-963 after an active DoFilters)
+                const uint32_t ls = L.lineStride, spv = L.streamsPerVoice, nd = L.numDry;
+                uint32_t *blk1 = L.lineGains + (size_t{v} * spv + 1u) * LineBlockDwords(ls);
+                if(directFilter)
+                {
+                    float *dst = L.streams + (size_t{v} * spv + 1u) * kLine;
+                    for(uint32_t k = lane; k < uint32_t(kLine); k += 64) dst[k] = (k < N) ? w.in[kHist + k] : 0.0f;
+                    float tg = 0.0f, cu = 0.0f;
+                    if(lane < nd)
+                    {
+                        tg = playing ? L.gainTgt[size_t{v} * nd + lane] : 0.0f;
+                        cu = counter ? L.gainCur[size_t{v} * nd + lane] : tg;
+                    }
+                    const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+                    RowLineGain r;
+                    if(lane < nd) { L.gainCur[size_t{v} * nd + lane] = g.newCur; r.add(g); }
+                    StoreRowBlock(blk1, ls, lane, r, true);
+                }
+                else if(lane == 0) blk1[3u * ls] = 0u;
             }
 
             stamp(2);
@@ -814,41 +954,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         if(active)
         {
             stamp(4);
-            if constexpr (NL > 0)
-            {   // ---- MixSamples onto the dry lines, voice.cpp:962-963: samples and resolved gains
-                // (MixLine, mixer_c.cpp:150-186) for LinesMixKernel
-                const uint32_t nd = L.numDry;
-                float *st = L.streams + size_t{v} * kLine;
-#pragma unroll
-                for(uint32_t k = 0; k < uint32_t(kLine / 64); ++k)
-                {
-                    const uint32_t p = lane + 64u * k;
-                    st[p] = (p < N) ? w.in[kHist + p] : 0.0f;
-                }
-                const uint32_t ls = L.lineStride;
-                float tg = 0.0f, cu = 0.0f;
-                if(lane < nd)
-                {
-                    tg = playing ? L.gainTgt[size_t{v} * nd + lane] : 0.0f;       // SilentCoeffs when Stopping
-                    cu = counter ? L.gainCur[size_t{v} * nd + lane] : tg;         // voice.cpp:1094-1112
-                }
-                const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
-                if(lane < nd) L.gainCur[size_t{v} * nd + lane] = g.newCur;
-                // the block is padded to the mix kernel's line count with zero gains
-                uint32_t *blk = L.lineGains + size_t{v} * LineBlockDwords(ls);
-                const bool mine = lane < nd;
-                uint32_t maxFade = mine ? g.fadeLen : 0u;
-#pragma unroll
-                for(int d = 32; d >= 1; d >>= 1) { const uint32_t o = uint32_t(__shfl_xor(int(maxFade), d)); maxFade = o > maxFade ? o : maxFade; }
-                if(lane < ls)
-                {
-                    blk[lane] = __builtin_bit_cast(uint32_t, (mine && g.steady) ? g.tgt : 0.0f);
-                    blk[ls + lane] = __builtin_bit_cast(uint32_t, mine ? g.cur : 0.0f);
-                    blk[2u * ls + lane] = __builtin_bit_cast(uint32_t, mine ? g.step : 0.0f);
-                    blk[3u * ls + lane] = mine ? g.fadeLen : 0u;
-                }
-                if(lane < 8u) blk[4u * ls + lane] = lane == 0u ? 1u : (lane == 1u ? maxFade : 0u);
-            }
             cf16 *co = (cf16*)(uintptr_t)(L.hrtfTgt + size_t{v} * irStride * 2);
             if(NL > 0 || (L.ablate & 1u)) {}
             else if(irStride == uint32_t(TAPS))
@@ -962,139 +1067,184 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     }
 }
 
-// ---- MixSamples of every voice onto the dry lines ------------------------------------------------
-// out[c][f] += stream_v[f] * gain_{v,c}(f) over the voices of one group, in voice order: thread t
-// owns frame 256*blockIdx.x + t of every line, blockIdx.y is the voice group.  The stream rows
-// are read once, coalesced, and together with the gain blocks a whole batch ahead of use.  A gain ramp
-// (MixLine with Counter <= 64, voice.cpp:1093) only ever covers the first 64 frames: the first
-// wavefront of the first frame block adds s * (ramp(f) - constant) for those.  One partial bus
-// per group, summed by BusReduceKernel in group order: deterministic.
-constexpr uint32_t kMixBatch = 16;                // stream rows in flight per thread
-template<int NLMAX>
+// ---- MixSamples of every stream row onto the mix lines -------------------------------------------
+// out[c][f] += row_r[f] * gain_{r,c}(f) over the live rows of one voice group, in row order:
+// thread t owns frame 256*blockIdx.x + t of every line, blockIdx.y is the voice group.  The
+// group's live rows are compacted into an LDS list first (dead rows -- idle voices, rows a voice
+// does not use -- cost one flag read, not 4 KB); the rows are then read once, coalesced, a batch
+// in flight, and multiplied by their constant gain vectors (LDS, same address in all lanes).
+// One partial bus per group, summed by BusReduceKernel in group order: deterministic.
+// A gain ramp (MixLine with Counter <= 64, voice.cpp:1093) only ever covers the first 64 frames:
+// LinesRampKernel adds s * (ramp(f) - constant) to those frames of the partial bus afterwards.
+template<int S>                                   // gain vector width: mix lines padded to 8 / 16 / 32
 __global__ void __launch_bounds__(256) LinesMixKernel(DeviceLayout L, uint32_t samplesToDo)
 {
-    constexpr uint32_t kBlk = 4u * NLMAX + 8u;     // LineBlockDwords(NLMAX)
-    const uint32_t t = threadIdx.x;
+    constexpr uint32_t kBlk = 3u * S + 8u;         // LineBlockDwords(S)
+    constexpr uint32_t kMixBatch = 16u;            // stream rows in flight per thread
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    // dyn: gains[maxRows][S] | rowIdx[maxRows]
+    __shared__ uint32_t waveBase[4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t f = blockIdx.x * 256u + t;
     const uint32_t g = blockIdx.y;
-    const uint32_t nd = L.numDry;
+    const uint32_t spv = L.streamsPerVoice;
     const uint32_t per = (L.numVoices + L.numLineGroups - 1u) / L.numLineGroups;
     const uint32_t v0 = g * per;
-    const uint32_t cnt = (v0 < L.numVoices) ? ((v0 + per < L.numVoices) ? per : L.numVoices - v0) : 0u;
-    float acc[NLMAX];
-#pragma unroll
-    for(int c = 0; c < NLMAX; ++c) acc[c] = 0.0f;
-    const float *rows = L.streams + size_t{v0} * kLine + f;
-    // gain ramps end within the first 64 frames: only this wavefront ever evaluates them
-    const bool rampWave = blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(t >> 6) == 0u;
-    const float ff = float(f);
-    const uint32_t *blk = L.lineGains + size_t{v0} * kBlk;
-    unsigned long long rampMask = 0ull;           // voices of the group (<= 64) with a gain ramp
-    for(uint32_t b = 0; b < cnt; b += kMixBatch)
+    const uint32_t nv = (v0 < L.numVoices) ? ((v0 + per < L.numVoices) ? per : L.numVoices - v0) : 0u;
+    const uint32_t maxRows = per * spv;
+    float *gains = reinterpret_cast<float*>(dyn);
+    uint32_t *rowIdx = dyn + size_t{maxRows} * S;
+    const uint32_t *blk0 = L.lineGains + size_t{v0} * spv * kBlk;
+
+    // ---- compact the live rows in row order: ballot + prefix per pass of 256 potential rows
+    uint32_t nLive = 0;
+    for(uint32_t r0 = 0; r0 < nv * spv; r0 += 256)
     {
-        // every load of the batch -- stream rows, gain blocks (same address in all lanes: one
-        // request each), flags -- is issued before the first use; rows past the group's end
-        // re-read its last voice and contribute nothing
-        float s[kMixBatch];
-        float4 gq[kMixBatch][NLMAX / 4];
-        uint2 fl[kMixBatch];
-#pragma unroll
-        for(uint32_t k = 0; k < kMixBatch; ++k)
-        {
-            const uint32_t vi = (b + k < cnt) ? b + k : cnt - 1u;
-            s[k] = rows[size_t{vi} * kLine];
-#pragma unroll
-            for(int q = 0; q < NLMAX / 4; ++q) gq[k][q] = reinterpret_cast<const float4*>(blk + vi * kBlk)[q];
-            fl[k] = *reinterpret_cast<const uint2*>(blk + vi * kBlk + 4u * NLMAX);
-        }
-#pragma unroll
-        for(uint32_t k = 0; k < kMixBatch; ++k)
-        {
-            const bool in = b + k < cnt;
-            // a voice that did not mix keeps a stale row: make its contribution an exact zero
-            const bool livev = in && fl[k].x != 0u;
-            const float sk = livev ? s[k] : 0.0f;
-#pragma unroll
-            for(int q = 0; q < NLMAX / 4; ++q)
-            {
-                acc[4 * q] = __builtin_fmaf(sk, gq[k][q].x, acc[4 * q]);
-                acc[4 * q + 1] = __builtin_fmaf(sk, gq[k][q].y, acc[4 * q + 1]);
-                acc[4 * q + 2] = __builtin_fmaf(sk, gq[k][q].z, acc[4 * q + 2]);
-                acc[4 * q + 3] = __builtin_fmaf(sk, gq[k][q].w, acc[4 * q + 3]);
-            }
-            if(rampWave && livev && __builtin_amdgcn_readfirstlane(fl[k].y) != 0u) rampMask |= 1ull << (b + k);
-        }
+        const uint32_t r = r0 + t;
+        const bool live = r < nv * spv && blk0[size_t{r} * kBlk + 3u * S] != 0u;
+        const unsigned long long ml = __ballot(live);
+        if(lane == 0) waveBase[wave] = uint32_t(__popcll(ml));
+        __syncthreads();
+        uint32_t bl = nLive, tl = 0;
+        for(uint32_t w = 0; w < 4; ++w) { if(w < wave) bl += waveBase[w]; tl += waveBase[w]; }
+        if(live) rowIdx[bl + uint32_t(__popcll(ml & ((1ull << lane) - 1ull)))] = r;
+        nLive += tl;
+        __syncthreads();
     }
-    // s * (ramp(f) - constant) on the frames a ramp covers, for the voices that have one: their
-    // indices are compacted so that up to kRampBatch rows and ramp blocks are in flight together
-    while(rampMask)
+    // ---- their gain vectors
+    for(uint32_t k = t; k < nLive * S; k += 256)
+        gains[k] = __builtin_bit_cast(float, blk0[size_t{rowIdx[k / S]} * kBlk + (k % S)]);
+    __syncthreads();
+
+    float acc[S];
+#pragma unroll
+    for(int c = 0; c < S; ++c) acc[c] = 0.0f;
+    const float *rows = L.streams + size_t{v0} * spv * kLine + f;
+    for(uint32_t b = 0; b < nLive; b += kMixBatch)
     {
-        constexpr int kRampBatch = 8;
-        uint32_t idx[kRampBatch];
-        bool on[kRampBatch];
+        float s[kMixBatch];
 #pragma unroll
-        for(int j = 0; j < kRampBatch; ++j)
+        for(uint32_t k = 0; k < kMixBatch; ++k)
+            s[k] = rows[size_t{rowIdx[(b + k < nLive) ? b + k : nLive - 1u]} * kLine];
+#pragma unroll
+        for(uint32_t k = 0; k < kMixBatch; ++k)
         {
-            on[j] = rampMask != 0ull;
-            idx[j] = on[j] ? uint32_t(__builtin_ctzll(rampMask)) : 0u;
-            if(on[j]) rampMask &= rampMask - 1ull;
-        }
-        float sv[kRampBatch];
-        float4 gq[kRampBatch][NLMAX / 4], cq[kRampBatch][NLMAX / 4], sq[kRampBatch][NLMAX / 4];
-        uint4 fq[kRampBatch][NLMAX / 4];
+            const bool in = b + k < nLive;
+            const float sk = in ? s[k] : 0.0f;
+            const float4 *g4 = reinterpret_cast<const float4*>(gains + size_t{in ? b + k : nLive - 1u} * S);
 #pragma unroll
-        for(int j = 0; j < kRampBatch; ++j)
-        {
-            const uint32_t *vb = blk + idx[j] * kBlk;
-            sv[j] = rows[size_t{idx[j]} * kLine];
-#pragma unroll
-            for(int q = 0; q < NLMAX / 4; ++q)
+            for(int q = 0; q < S / 4; ++q)
             {
-                gq[j][q] = reinterpret_cast<const float4*>(vb)[q];
-                cq[j][q] = reinterpret_cast<const float4*>(vb + NLMAX)[q];
-                sq[j][q] = reinterpret_cast<const float4*>(vb + 2 * NLMAX)[q];
-                fq[j][q] = reinterpret_cast<const uint4*>(vb + 3 * NLMAX)[q];
+                const float4 x = g4[q];
+                acc[4 * q] = __builtin_fmaf(sk, x.x, acc[4 * q]);
+                acc[4 * q + 1] = __builtin_fmaf(sk, x.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = __builtin_fmaf(sk, x.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = __builtin_fmaf(sk, x.w, acc[4 * q + 3]);
             }
-        }
-#pragma unroll
-        for(int j = 0; j < kRampBatch; ++j)
-        {
-            const float sk = on[j] ? sv[j] : 0.0f;
-#pragma unroll
-            for(int q = 0; q < NLMAX / 4; ++q)
-            {
-                const float d0 = (f < fq[j][q].x) ? (cq[j][q].x + sq[j][q].x * ff) - gq[j][q].x : 0.0f;
-                const float d1 = (f < fq[j][q].y) ? (cq[j][q].y + sq[j][q].y * ff) - gq[j][q].y : 0.0f;
-                const float d2 = (f < fq[j][q].z) ? (cq[j][q].z + sq[j][q].z * ff) - gq[j][q].z : 0.0f;
-                const float d3 = (f < fq[j][q].w) ? (cq[j][q].w + sq[j][q].w * ff) - gq[j][q].w : 0.0f;
-                acc[4 * q] = __builtin_fmaf(sk, d0, acc[4 * q]);
-                acc[4 * q + 1] = __builtin_fmaf(sk, d1, acc[4 * q + 1]);
-                acc[4 * q + 2] = __builtin_fmaf(sk, d2, acc[4 * q + 2]);
-                acc[4 * q + 3] = __builtin_fmaf(sk, d3, acc[4 * q + 3]);
-            }
+            // keep the gain reads of later rows from being hoisted above (register pressure)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     float *pl = L.partLines + size_t{g} * L.mixLines * kLine;
 #pragma unroll
-    for(int c = 0; c < NLMAX; ++c)
-        if(uint32_t(c) < nd) pl[size_t(c) * kLine + f] = (f < samplesToDo) ? acc[c] : 0.0f;
-    // lines no voice of this context mixes into (wet buses without sends) stay zero
-    for(uint32_t c = nd; c < L.mixLines; ++c) pl[size_t{c} * kLine + f] = 0.0f;
+    for(int c = 0; c < S; ++c)
+        if(uint32_t(c) < L.mixLines) pl[size_t(c) * kLine + f] = (f < samplesToDo) ? acc[c] : 0.0f;
+}
+
+// One wavefront per voice group: lane = frame (< 64).  The group's rows with a ramp are listed
+// first (64 potential rows per ballot); then 16 of them at a time have their sample and their
+// ramp vectors (A | B, 2S <= 64 floats: one coalesced load per row) in flight together, the
+// vectors go through LDS so that every lane can read every line's pair.
+constexpr uint32_t kRampListMax = 2048;           // >= 60000 / (4 * (1 + 8)) potential rows per group
+template<int S>
+__global__ void __launch_bounds__(64) LinesRampKernel(DeviceLayout L, uint32_t samplesToDo)
+{
+    constexpr uint32_t kBlk = 3u * S + 8u;
+    constexpr uint32_t kChunk = 16;
+    __shared__ __attribute__((aligned(16))) float ab[kChunk][2 * S];
+    __shared__ uint32_t rampIdx[kRampListMax];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    const uint32_t spv = L.streamsPerVoice;
+    const uint32_t per = (L.numVoices + L.numLineGroups - 1u) / L.numLineGroups;
+    const uint32_t v0 = g * per;
+    const uint32_t nv = (v0 < L.numVoices) ? ((v0 + per < L.numVoices) ? per : L.numVoices - v0) : 0u;
+    const uint32_t *blk0 = L.lineGains + size_t{v0} * spv * kBlk;
+    const float *rows = L.streams + size_t{v0} * spv * kLine + lane;
+    const float ff = float(lane);
+    uint32_t n = 0;
+    for(uint32_t r0 = 0; r0 < nv * spv; r0 += 64)
+    {
+        const uint32_t r = r0 + lane;
+        uint2 fl = make_uint2(0u, 0u);
+        if(r < nv * spv) fl = *reinterpret_cast<const uint2*>(blk0 + size_t{r} * kBlk + 3u * S);
+        const bool ramp = fl.x != 0u && fl.y != 0u;
+        const unsigned long long mr = __ballot(ramp);
+        if(ramp) rampIdx[n + uint32_t(__popcll(mr & ((1ull << lane) - 1ull)))] = r;
+        n += uint32_t(__popcll(mr));
+    }
+    if(n == 0u) return;
+    WaveSync();
+    float acc[S];
+#pragma unroll
+    for(int c = 0; c < S; ++c) acc[c] = 0.0f;
+    for(uint32_t b = 0; b < n; b += kChunk)
+    {
+        const uint32_t m = (n - b < kChunk) ? n - b : kChunk;
+        float sv[kChunk], abv[kChunk];
+        uint32_t len[kChunk];
+#pragma unroll
+        for(uint32_t j = 0; j < kChunk; ++j)
+        {
+            const uint32_t rr = rampIdx[b + ((j < m) ? j : m - 1u)];
+            sv[j] = rows[size_t{rr} * kLine];
+            abv[j] = (lane < 2u * S) ? __builtin_bit_cast(float, blk0[size_t{rr} * kBlk + S + lane]) : 0.0f;
+            len[j] = blk0[size_t{rr} * kBlk + 3u * S + 1u];
+        }
+        WaveSync();
+#pragma unroll
+        for(uint32_t j = 0; j < kChunk; ++j) if(lane < 2u * S) ab[j][lane] = abv[j];
+        WaveSync();
+#pragma unroll
+        for(uint32_t j = 0; j < kChunk; ++j)
+        {
+            if(j >= m) continue;
+            const float sk = (lane < len[j]) ? sv[j] : 0.0f;
+            const float4 *a4 = reinterpret_cast<const float4*>(&ab[j][0]);
+            const float4 *b4 = reinterpret_cast<const float4*>(&ab[j][S]);
+#pragma unroll
+            for(int q = 0; q < S / 4; ++q)
+            {
+                const float4 a = a4[q], bb = b4[q];
+                acc[4 * q] = __builtin_fmaf(sk, a.x + bb.x * ff, acc[4 * q]);
+                acc[4 * q + 1] = __builtin_fmaf(sk, a.y + bb.y * ff, acc[4 * q + 1]);
+                acc[4 * q + 2] = __builtin_fmaf(sk, a.z + bb.z * ff, acc[4 * q + 2]);
+                acc[4 * q + 3] = __builtin_fmaf(sk, a.w + bb.w * ff, acc[4 * q + 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float *pl = L.partLines + size_t{g} * L.mixLines * kLine;
+#pragma unroll
+    for(int c = 0; c < S; ++c)
+        if(uint32_t(c) < L.mixLines && lane < samplesToDo) pl[size_t(c) * kLine + lane] += acc[c];
 }
 
 } // namespace
 
 bool WaveKernelApplies(bool exact, const DeviceLayout &L)
 {
-    if(exact || L.numSends != 0) return false;
+    if(exact || L.mixLines > 32 || L.numSends > 6) return false;
     if(L.hrtf) return L.irStride >= 8 && L.irStride <= 128;
-    return L.numDry >= 1 && L.numDry <= 32;
+    return L.numDry >= 1;
 }
 
 const char *WaveKernelName(const DeviceLayout &L)
 {
-    if(!L.hrtf) return "VoiceWaveKernel<17, 64, 1>";
-    return L.irStride <= 64 ? "VoiceWaveKernel<17, 64, 0>" : "VoiceWaveKernel<18, 128, 0>";
+    const bool sends = L.numSends != 0;
+    if(!L.hrtf) return sends ? "VoiceWaveKernel<17, 64, 1, true>" : "VoiceWaveKernel<17, 64, 1, false>";
+    if(L.irStride <= 64) return sends ? "VoiceWaveKernel<17, 64, 0, true>" : "VoiceWaveKernel<17, 64, 0, false>";
+    return sends ? "VoiceWaveKernel<18, 128, 0, true>" : "VoiceWaveKernel<18, 128, 0, false>";
 }
 
 uint32_t WaveKernelGroups(const DeviceLayout &L)
@@ -1103,18 +1253,46 @@ uint32_t WaveKernelGroups(const DeviceLayout &L)
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo)
 {
     const uint32_t groups = WaveKernelGroups(L);
+    const bool sends = L.numSends != 0;
+    const dim3 grid(groups), block(kWThreads);
     if(!L.hrtf)
     {
-        hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1>), dim3(groups), dim3(kWThreads), 0, s, L, samplesToDo);
-        const dim3 grid(kLine / 256, L.numLineGroups);
-        if(L.numDry <= 8) hipLaunchKernelGGL(LinesMixKernel<8>, grid, dim3(256), 0, s, L, samplesToDo);
-        else if(L.numDry <= 16) hipLaunchKernelGGL(LinesMixKernel<16>, grid, dim3(256), 0, s, L, samplesToDo);
-        else hipLaunchKernelGGL(LinesMixKernel<32>, grid, dim3(256), 0, s, L, samplesToDo);
+        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, L, samplesToDo);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false>), grid, block, 0, s, L, samplesToDo);
     }
     else if(L.irStride <= 64)
-        hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0>), dim3(groups), dim3(kWThreads), 0, s, L, samplesToDo);
+    {
+        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, L, samplesToDo);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false>), grid, block, 0, s, L, samplesToDo);
+    }
     else
-        hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0>), dim3(groups), dim3(kWThreads), 0, s, L, samplesToDo);
+    {
+        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, L, samplesToDo);
+        else hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false>), grid, block, 0, s, L, samplesToDo);
+    }
+    if(L.streams)
+    {   // stream rows -> partial mix-line buses
+        const uint32_t per = (L.numVoices + L.numLineGroups - 1u) / L.numLineGroups;
+        const uint32_t maxRows = per * L.streamsPerVoice;
+        const dim3 mgrid(kLine / 256, L.numLineGroups);
+        const size_t lds = (size_t{maxRows} + size_t{maxRows} * L.lineStride) * sizeof(uint32_t);
+        const dim3 rgrid(L.numLineGroups);
+        if(L.lineStride <= 8)
+        {
+            hipLaunchKernelGGL(LinesMixKernel<8>, mgrid, dim3(256), lds, s, L, samplesToDo);
+            hipLaunchKernelGGL(LinesRampKernel<8>, rgrid, dim3(64), 0, s, L, samplesToDo);
+        }
+        else if(L.lineStride <= 16)
+        {
+            hipLaunchKernelGGL(LinesMixKernel<16>, mgrid, dim3(256), lds, s, L, samplesToDo);
+            hipLaunchKernelGGL(LinesRampKernel<16>, rgrid, dim3(64), 0, s, L, samplesToDo);
+        }
+        else
+        {
+            hipLaunchKernelGGL(LinesMixKernel<32>, mgrid, dim3(256), lds, s, L, samplesToDo);
+            hipLaunchKernelGGL(LinesRampKernel<32>, rgrid, dim3(64), 0, s, L, samplesToDo);
+        }
+    }
     return hipGetLastError();
 }
 

@@ -117,8 +117,10 @@ def scene_buffers(config_id, nvoices, fmt="f32"):
 
 class SceneScript:
     """Per-voice parameters for update 0 (all voices) and for every later update (the moving
-    quarter of the voices get a new random direction), config 2 (7.1 dry bus, 5 ambisonic
-    lines) or config 3 (HRTF)."""
+    quarter of the voices get a new random direction): config 2 (7.1 dry bus, 5 ambisonic
+    lines), config 3 (HRTF), config 4 (config 2 voices with v % 5 active sends into 4 reverb
+    slots, every third send low-passed) or config 5 (config 3 voices with one send into a
+    convolution slot)."""
 
     def __init__(self, config_id, nvoices, voice_base=0):
         self.config_id = config_id
@@ -165,6 +167,18 @@ class SceneScript:
             p.send_filter[i].hf_norm = 5000.0 / DEV_RATE
             p.send_filter[i].gain_lf = 1.0
             p.send_filter[i].lf_norm = 250.0 / DEV_RATE
+        nsends = {4: (self.voice_base + v) % 5, 5: 1}.get(self.config_id, 0)
+        if nsends:
+            # first-order encode of the direction onto the slot's 4-line wet bus, -10 dB
+            x, y, z = np.cos(az) * np.cos(ev), np.sin(az) * np.cos(ev), np.sin(ev)
+            wet = [1.0, y * 1.7320508, z * 1.7320508, x * 1.7320508]
+            for i in range(nsends):
+                p.send_slot[i] = i
+                if (self.voice_base + v + i) % 3 == 0 and self.config_id == 4:
+                    p.send_filter[i].active = 1
+                    p.send_filter[i].gain_hf = 0.7
+                for c in range(4):
+                    p.send_gains[i][c] = 0.316 * gain * wet[c]
         if self.hrtf:
             p.hrtf_ev, p.hrtf_az, p.hrtf_dist, p.hrtf_spread, p.hrtf_gain = ev, az, 2.0, 0.0, gain
         else:

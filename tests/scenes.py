@@ -97,6 +97,12 @@ SCENES = [
     dict(hrtf=False, fmt=ol.FMT_MULAW, resampler=ol.RS_BSINC48, steps=[70000], n_updates=2, nvoices=4),
     dict(hrtf=False, fmt=ol.FMT_ALAW, resampler=ol.RS_POINT, steps=[65536, 1], n_updates=2, nvoices=4,
          todo=37),
+    # three sends, sends 0 and 2 into the SAME slot, filtered and unfiltered sends side by side,
+    # voices stopping on the way: the stream-row path of the wavefront kernel
+    dict(hrtf=False, fmt=ol.FMT_FLOAT, resampler=ol.RS_BSINC24, steps=[60211, 48000], n_updates=4, nvoices=40,
+         sends=3, stop_at=1, todo=700),
+    dict(hrtf=True, fmt=ol.FMT_SHORT, resampler=ol.RS_BSINC24, steps=[60211, 70000], n_updates=4, nvoices=36,
+         sends=3, stop_at=2, nonloop=True),
 ]
 
 
