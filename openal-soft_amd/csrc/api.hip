@@ -19,6 +19,7 @@
 #include "../host/tables.hpp"
 #include "api_util.hpp"
 #include "kernels.hpp"
+#include "reverb_dev.hpp"
 
 using namespace oalgpu;
 
@@ -105,6 +106,7 @@ struct oalgpu_context {
     bool useWave{false};                   // FAST contexts without sends (HRTF, or <= 8 dry lines): voice_wave.hip
     std::vector<oalgpu_convolution*> slotConv;   // per effect slot: attached convolution reverb (not owned)
     std::vector<oalgpu_reverb*> slotReverb;      // per effect slot: attached EAX reverb (not owned)
+    DevBuf<uint32_t> reverbTicket;               // mix-out order word of a reverb batch launch
 
     DevBuf<float> tables;
     DevBuf<BufferItem> buffers;
@@ -379,6 +381,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.mixLines = mixLines;
     c->slotConv.assign(desc->num_slots, nullptr);
     c->slotReverb.assign(desc->num_slots, nullptr);
+    HIP_TRY(c->reverbTicket.alloc(1)); HIP_TRY(c->reverbTicket.zero());
     uint32_t vpg = desc->voices_per_group;
     if(vpg == 0)
     {
@@ -726,12 +729,26 @@ static int RunEffects(oalgpu_context *c, hipStream_t s, uint32_t samples_to_do)
         {
             if(int rc = oalgpu_convolution_process_device(conv, s, wet, L.bus, samples_to_do)) return rc;
         }
-        if(oalgpu_reverb *rev = c->slotReverb[slot])
-        {
-            if(int rc = oalgpu_reverb_set_stream(rev, s)) return rc;
-            if(int rc = oalgpu_reverb_process_device(rev, wet, L.bus, samples_to_do)) return rc;
-        }
     }
+    // the EAX reverbs of all slots: one launch, instances side by side, mix-out in slot order
+    oalgpu_reverb *revs[kRvBatchMax];
+    const float *wets[kRvBatchMax];
+    uint32_t count = 0;
+    auto flush = [&]() -> int
+    {
+        if(!count) return OALGPU_OK;
+        const int rc = oalgpu_reverb_process_batch_device(revs, wets, count, L.bus, samples_to_do, s, c->reverbTicket.p);
+        count = 0;
+        return rc;
+    };
+    for(uint32_t slot = 0; slot < L.numSlots; ++slot)
+    {
+        if(!c->slotReverb[slot]) continue;
+        revs[count] = c->slotReverb[slot];
+        wets[count] = L.bus + BusWetOffset(L) + size_t{slot} * L.wetChannels * kLine;
+        if(++count == kRvBatchMax) { if(int rc = flush()) return rc; }
+    }
+    if(int rc = flush()) return rc;
     return OALGPU_OK;
 }
 

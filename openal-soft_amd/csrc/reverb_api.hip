@@ -153,7 +153,11 @@ int oalgpu_reverb_line_lengths(oalgpu_reverb *r, uint32_t lengths[11])
     return static_cast<int>(r->total);
 }
 
-int oalgpu_reverb_process_device(oalgpu_reverb *r, const float *wet_in_dev, float *out_lines_dev, uint32_t n)
+} // extern "C"
+
+// validates, advances the host mirror by one block, installs what changed, and returns the launch
+// layout of this block
+static int PrepareBlock(oalgpu_reverb *r, const float *wet_in_dev, float *out_lines_dev, uint32_t n, RvLayout *out)
 {
     if(!r || !wet_in_dev || !out_lines_dev || n == 0 || n > OALGPU_BUFFER_LINE_SIZE)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_process: bad arguments");
@@ -175,9 +179,38 @@ int oalgpu_reverb_process_device(oalgpu_reverb *r, const float *wet_in_dev, floa
     L.offset = static_cast<uint32_t>(st.offset);
     L.modIndex[0] = st.modIndex[0]; L.modIndex[1] = st.modIndex[1];
     L.current = st.current; L.oldMode = st.oldMode;
+    r->host.finish(st, n);
+    *out = L;
+    return OALGPU_OK;
+}
+
+int oalgpu_reverb_process_batch_device(oalgpu_reverb *const *revs, const float *const *wet_in_dev, uint32_t count,
+    float *out_lines_dev, uint32_t n, void *hip_stream, uint32_t *ticket_dev)
+{
+    if(!revs || !wet_in_dev || count == 0 || count > kRvBatchMax || (count > 1 && !ticket_dev))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_process_batch: bad arguments");
+    RvBatch B{};
+    B.count = count;
+    B.ticket = ticket_dev;
+    for(uint32_t i = 0; i < count; ++i)
+    {
+        if(!revs[i]) return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_process_batch: null instance");
+        revs[i]->stream = static_cast<hipStream_t>(hip_stream);
+        if(int rc = PrepareBlock(revs[i], wet_in_dev[i], out_lines_dev, n, &B.r[i])) return rc;
+    }
+    LaunchReverbBatch(static_cast<hipStream_t>(hip_stream), B);
+    HIP_TRY(hipGetLastError());
+    return OALGPU_OK;
+}
+
+extern "C" {
+
+int oalgpu_reverb_process_device(oalgpu_reverb *r, const float *wet_in_dev, float *out_lines_dev, uint32_t n)
+{
+    RvLayout L{};
+    if(int rc = PrepareBlock(r, wet_in_dev, out_lines_dev, n, &L)) return rc;
     LaunchReverbProcess(r->stream, L);
     HIP_TRY(hipGetLastError());
-    r->host.finish(st, n);
     return OALGPU_OK;
 }
 

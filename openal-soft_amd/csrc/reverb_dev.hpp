@@ -44,7 +44,22 @@ struct RvLayout {
     unsigned long long *stamps;    // profiling aid (env OALGPU_PHASE_TIMES): [4 roles][8 sub-blocks][8]
 };
 
+// several instances adding into the same target lines in one launch (see ReverbProcessBody)
+constexpr uint32_t kRvBatchMax = 8;
+struct RvBatch {
+    RvLayout r[kRvBatchMax];
+    uint32_t count;
+    uint32_t *ticket;              // device word, 0 between launches
+};
+static_assert(sizeof(RvBatch) <= 3800, "RvBatch travels as a kernel argument");
+
 void LaunchReverbProcess(hipStream_t s, const RvLayout &L);
+void LaunchReverbBatch(hipStream_t s, const RvBatch &B);
 void LaunchReverbInstall(hipStream_t s, oalgpu_reverb_pipeline *dst, const oalgpu_reverb_pipeline &src);
 
 } // namespace oalgpu
+
+// api.hip: process `count` reverbs (<= kRvBatchMax) that share `out_lines_dev` and a stream as one
+// launch; `ticket_dev` is a zeroed device word owned by the caller
+int oalgpu_reverb_process_batch_device(oalgpu_reverb *const *revs, const float *const *wet_in_dev, uint32_t count,
+    float *out_lines_dev, uint32_t n, void *hip_stream, uint32_t *ticket_dev);

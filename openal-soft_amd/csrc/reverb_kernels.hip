@@ -421,9 +421,13 @@ __device__ void LateWave(const RvLayout &L, const int p, LateLds &w, uint32_t *p
     }
 }
 
-__global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
+// One workgroup = one reverb instance.  `ticket` (null for a lone instance): several instances
+// that add into the SAME target lines run side by side up to their mix-out, which they then
+// perform one after the other in launch order -- instance `order` waits until the ticket word
+// reaches its number -- so that the sums come out in the order a serial loop over the slots
+// (alc/alu.cpp:2209-2257) would produce.
+__device__ __forceinline__ void ReverbProcessBody(const RvLayout &L, RvLds &sm, uint32_t *ticket, uint32_t order, uint32_t count)
 {
-    __shared__ RvLds sm;
     const uint32_t t = threadIdx.x, lane = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t n = L.n;
@@ -477,6 +481,13 @@ __global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
     }
     __syncthreads();
     if(L.stamps && t == 0) L.stamps[7 * 8 + 2] = __builtin_readcyclecounter();
+    if(ticket)
+    {
+        if(t == 0)
+            while(__hip_atomic_load(ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != order) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every wave drops what it may hold of the lines
+    }
 
     // MixOutPlain, :637-656: current pipeline first, then the old one (:1845,1878).  MixLine with
     // Counter == n (core/mixer/mixer_c.cpp:150-186): per (input, target line) the gain either
@@ -544,7 +555,10 @@ __global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
                 if(t + 256u * k < n) L.outLines[c * kLine + t + 256u * k] = acc[k];
         }
     }
+    if(ticket) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this wave's line stores are out
     __syncthreads();
+    if(ticket && t == 0)
+        __hip_atomic_store(ticket, (order + 1u == count) ? 0u : order + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if(L.stamps && t == 0) L.stamps[7 * 8 + 3] = __builtin_readcyclecounter();
     // what process() leaves in the pipelines: Current = Target (MixLine with Counter == n), the
     // taps and the early coefficient handed over (:1579,1585,1759)
@@ -568,6 +582,18 @@ __global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
     }
 }
 
+__global__ void __launch_bounds__(256) ReverbProcessKernel(RvLayout L)
+{
+    __shared__ RvLds sm;
+    ReverbProcessBody(L, sm, nullptr, 0u, 1u);
+}
+
+__global__ void __launch_bounds__(256) ReverbProcessBatchKernel(RvBatch B)
+{
+    __shared__ RvLds sm;
+    ReverbProcessBody(B.r[blockIdx.x], sm, B.count > 1u ? B.ticket : nullptr, blockIdx.x, B.count);
+}
+
 // installs one pipeline's parameter block (passed by value) into device memory
 __global__ void __launch_bounds__(256) ReverbInstallKernel(oalgpu_reverb_pipeline *dst, const oalgpu_reverb_pipeline src)
 {
@@ -580,6 +606,9 @@ __global__ void __launch_bounds__(256) ReverbInstallKernel(oalgpu_reverb_pipelin
 
 void LaunchReverbProcess(hipStream_t s, const RvLayout &L)
 { hipLaunchKernelGGL(ReverbProcessKernel, dim3(1), dim3(256), 0, s, L); }
+
+void LaunchReverbBatch(hipStream_t s, const RvBatch &B)
+{ hipLaunchKernelGGL(ReverbProcessBatchKernel, dim3(B.count), dim3(256), 0, s, B); }
 
 void LaunchReverbInstall(hipStream_t s, oalgpu_reverb_pipeline *dst, const oalgpu_reverb_pipeline &src)
 { hipLaunchKernelGGL(ReverbInstallKernel, dim3(1), dim3(256), 0, s, dst, src); }

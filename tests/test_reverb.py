@@ -355,3 +355,61 @@ def test_gpu_slot_reverb_in_scene(synth_mhr):
         assert err <= 2e-5 * float(np.abs(want[:, :n]).max()) + 1e-7, (k, err)
     gsc.set_slot_reverb(0, None)
     rev.close(); orev.close(); gsc.close(); osc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_four_reverb_slots_in_scene(synth_mhr):
+    """BASELINE configs[3] in small: voices with sends into FOUR reverb slots.  The four
+    instances run as one launch side by side and mix out in slot order; expected = the oracle
+    scene's wet buses through four oracle ReverbStates, slot after slot, into its dry bus
+    (tolerance of the multi-voice bus tests: the reverb inputs already differ in the last bit)."""
+    oalgpu = _gpu()
+    if not ol.available("ref"):
+        pytest.skip("needs the compiled reference")
+    L = ol.load("ref")
+    L.L.oal_set_simd(1)
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    nlines = 5
+
+    def build(lib):
+        sc = lib.make_scene(num_dry=nlines, num_real=0, num_sends=4, num_slots=4, wet_channels=4, hrtf=False)
+        r = np.random.default_rng(11)
+        buf = sc.add_buffer(r.uniform(-1, 1, 9000).astype(np.float32), ol.FMT_FLOAT, loop_start=0, loop_end=9000)
+        for v in range(24):
+            sc.add_voice(buf, looping=True, position=(v * 977) % 8000, frac=0)
+            snd = [(i, r.uniform(0.05, 0.3, 4), ol.default_filter(active=1 if (v + i) % 3 == 0 else 0, gain_hf=0.6))
+                   for i in range(v % 5)]
+            sc.set_params(v, ol.make_voice_params(60211, ol.RS_BSINC24, dry_gains=r.uniform(0, 0.1, nlines),
+                                                  direct_filter=ol.default_filter(active=v % 2, gain_hf=0.5), sends=snd))
+        return sc
+
+    presets = [dict(), dict(decay_time=3.0, modulation_depth=0.4), dict(density=0.3, diffusion=0.5),
+               dict(late_reverb_pan=(0.3, 0.0, -0.6), decay_time=0.8)]
+    gsc, osc = build(api), build(L)
+    grev, orev = [], []
+    for slot, kw in enumerate(presets):
+        g = oalgpu.Reverb(nlines)
+        g.update(oalgpu.ReverbProps.make(**kw), 0.5 + 0.1 * slot)
+        gsc.set_slot_reverb(slot, g)
+        o = L.make_reverb(nlines)
+        o.update(ol.ReverbProps.make(**kw), 0.5 + 0.1 * slot)
+        grev.append(g); orev.append(o)
+    for k in range(6):
+        n = (1024, 1024, 700, 1024, 1024, 1024)[k]
+        if k == 3:          # a parameter change that cross-fades two of the instances
+            for slot in (1, 2):
+                grev[slot].update(oalgpu.ReverbProps.make(decay_time=1.2 + slot), 0.6)
+                orev[slot].update(ol.ReverbProps.make(decay_time=1.2 + slot), 0.6)
+        gsc.mix(n, post_process=True)
+        got = gsc.dry()
+        osc.mix(n, post_process=False)
+        want = osc.dry().copy()
+        for slot in range(4):
+            orev[slot].process_n(np.ascontiguousarray(osc.wet(slot)[:4]), want, n)
+        err = float(np.abs(got[:, :n].astype(np.float64) - want[:, :n]).max())
+        assert err <= 2e-5 * float(np.abs(want[:, :n]).max()) + 1e-7, (k, err)
+    for slot in range(4):
+        gsc.set_slot_reverb(slot, None)
+    for x in grev + orev:
+        x.close()
+    gsc.close(); osc.close()
