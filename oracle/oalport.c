@@ -633,9 +633,8 @@ void oal_splitter_process_hfscale(oal_splitter *s, const float *in, float *out, 
     fpu_leave(csr);
 }
 
-void oal_splitter_process_scale(oal_splitter *s, float *samples, size_t n, float hfscale, float lfscale)
+static void splitter_scale(oal_splitter *s, float *samples, size_t n, float hfscale, float lfscale)
 {   /* processScale splitter.cpp:133-161 */
-    const unsigned csr = fpu_enter();
     const float ap_coeff = s->coeff;
     const float lp_coeff = s->coeff * 0.5f + 0.5f;
     float lp_z1 = s->lp_z1, lp_z2 = s->lp_z2, ap_z1 = s->ap_z1;
@@ -653,6 +652,12 @@ void oal_splitter_process_scale(oal_splitter *s, float *samples, size_t n, float
         samples[i] = (ap_y - lp_y1) * hfscale + lp_y1 * lfscale;
     }
     s->lp_z1 = lp_z1; s->lp_z2 = lp_z2; s->ap_z1 = ap_z1;
+}
+
+void oal_splitter_process_scale(oal_splitter *s, float *samples, size_t n, float hfscale, float lfscale)
+{
+    const unsigned csr = fpu_enter();
+    splitter_scale(s, samples, n, hfscale, lfscale);
     fpu_leave(csr);
 }
 
@@ -1055,6 +1060,7 @@ void oal_hrtf_get_coeffs(float elevation, float azimuth, float distance, float s
  * ======================================================================== */
 typedef struct buffer_item { /* VoiceBufferItem core/voice.h:84-98 */
     void *data; int fmt; uint32_t frame_step, sample_len, loop_start, loop_end;
+    int view;   /* data points into another item's storage (one channel of an interleaved buffer) */
 } buffer_item;
 
 typedef struct send_params { /* SendParams core/voice.h:73-82 */
@@ -1076,6 +1082,8 @@ typedef struct voice { /* Voice core/voice.h:176-270 (mono, static sources) */
     float hrtf_history[HIST];
     float gains_cur[OAL_MAX_OUTPUT_CHANNELS], gains_tgt[OAL_MAX_OUTPUT_CHANNELS];
     send_params send[OAL_MAX_SENDS];
+    /* ChannelData::mAmbiSplitter / mAmbiHFScale / mAmbiLFScale + VoiceFlag::IsAmbisonic */
+    int is_ambisonic; oal_splitter ambi_splitter; float ambi_hf_scale, ambi_lf_scale;
 } voice;
 
 struct oal_scene {
@@ -1113,7 +1121,7 @@ oal_scene *oal_scene_create(const oal_device_desc *desc)
 void oal_scene_destroy(oal_scene *s)
 {
     if(!s) return;
-    for(size_t i = 0; i < s->nbuffers; ++i) free(s->buffers[i].data);
+    for(size_t i = 0; i < s->nbuffers; ++i) if(!s->buffers[i].view) free(s->buffers[i].data);
     free(s->buffers); free(s->voices); free(s->mix); free(s->wet);
     free(s->dsplit); free(s->dhfscale); free(s->dcoeffs);
     free(s);
@@ -1132,6 +1140,18 @@ int oal_scene_add_buffer(oal_scene *s, const void *data, int fmt_type, uint32_t 
     memcpy(b->data, data, nbytes);
     b->fmt = fmt_type; b->frame_step = frame_step; b->sample_len = sample_len;
     b->loop_start = loop_start; b->loop_end = loop_end;
+    b->view = 0;
+    return (int)s->nbuffers++;
+}
+
+/* channel `channel` of an interleaved buffer as a buffer of its own (same frames and loop points) */
+static int add_buffer_view(oal_scene *s, int buffer, uint32_t channel)
+{
+    s->buffers = (buffer_item *)realloc(s->buffers, (s->nbuffers + 1) * sizeof(buffer_item));
+    buffer_item *b = &s->buffers[s->nbuffers];
+    *b = s->buffers[buffer];
+    b->data = (char*)b->data + (size_t)channel * g_fmt_bytes[b->fmt];
+    b->view = 1;
     return (int)s->nbuffers++;
 }
 
@@ -1186,6 +1206,34 @@ int oal_scene_set_voice_params(oal_scene *s, int vi, const oal_voice_params *p)
         set_filter_pair(&v->send[i].lp, &v->send[i].hp, &p->send_filter[i]);
     }
     fpu_leave(csr);
+    return 0;
+}
+
+int oal_scene_add_voice_multi(oal_scene *s, const oal_voice_desc *desc, uint32_t num_channels)
+{   /* one mono voice per channel, in channel order: DoMix (voice.cpp:934-984) walks the channels
+     * of a voice in that order too, so the buses accumulate identically */
+    if(num_channels != s->buffers[desc->buffer].frame_step) return -1;
+    int first = -1;
+    for(uint32_t c = 0; c < num_channels; ++c)
+    {
+        oal_voice_desc d = *desc;
+        d.buffer = add_buffer_view(s, desc->buffer, c);
+        const int vi = oal_scene_add_voice(s, &d);
+        if(c == 0) first = vi;
+    }
+    return first;
+}
+
+int oal_scene_set_channel_params(oal_scene *s, int voice, uint32_t channel, const oal_voice_params *p)
+{ return oal_scene_set_voice_params(s, voice + (int)channel, p); }
+
+int oal_scene_set_channel_ambi_scale(oal_scene *s, int voice, uint32_t channel, float xover_norm,
+    float hf_scale, float lf_scale)
+{
+    struct voice *v = &s->voices[voice + (int)channel];
+    oal_splitter_init(&v->ambi_splitter, xover_norm);
+    v->ambi_hf_scale = hf_scale; v->ambi_lf_scale = lf_scale;
+    v->is_ambisonic = 1;
     return 0;
 }
 
@@ -1438,6 +1486,9 @@ static void voice_mix(oal_scene *s, voice *v, int vstate, unsigned samplesToDo)
 
     load_resampled(s, v, vstate, bufPosInt, bufPosFrac, increment, samplesToLoad, samplesToMix,
         bufferListItem, bufferLoopItem, mixing);
+
+    if(v->is_ambisonic) /* :1082-1091 */
+        splitter_scale(&v->ambi_splitter, mixing, samplesToMix, v->ambi_hf_scale, v->ambi_lf_scale);
 
     const unsigned counter = v->is_fading ? (samplesToMix < 64u ? samplesToMix : 64u) : 0u; /* :1093 */
     if(!counter)

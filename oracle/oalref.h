@@ -229,6 +229,22 @@ void oal_conv_destroy(oal_conv *c);
 /* CalcDirectionCoeffs(dir, spread), core/mixer.h:68: ambisonic coefficients (ACN/N3D, 25). */
 void oal_calc_direction_coeffs(const float dir[3], float spread, float *out25);
 
+/* ---- B-Format (ambisonic) sources: VoiceFlag::IsAmbisonic, core/voice.cpp:1082-1091 ----
+ * A static voice over all `num_channels` interleaved channels of desc->buffer (FmtBFormat3D,
+ * one ChannelData each; Voice::prepare, voice.cpp:1235-1397).  Returns the voice index.  The
+ * restatement models it the way the GPU product does -- num_channels consecutive mono voices over
+ * channel views of the buffer -- and returns the index of the first; the two functions below
+ * address channels the same way in both. */
+int oal_scene_add_voice_multi(oal_scene *s, const oal_voice_desc *desc, uint32_t num_channels);
+/* Channel `channel`'s share of oal_scene_set_voice_params: its gains and filters.  step,
+ * resampler and the send slots are voice-wide and are taken from every call. */
+int oal_scene_set_channel_params(oal_scene *s, int voice, uint32_t channel, const oal_voice_params *p);
+/* mAmbiSplitter.init(xover_norm), mAmbiHFScale, mAmbiLFScale of the channel and the voice's
+ * IsAmbisonic flag (what Voice::prepare sets up when the device's ambisonic order is higher
+ * than the source's, voice.cpp:1353-1380) */
+int oal_scene_set_channel_ambi_scale(oal_scene *s, int voice, uint32_t channel, float xover_norm,
+    float hf_scale, float lf_scale);
+
 /* ---- EAX reverb: ReverbState, alc/effects/reverb.cpp:567-1883 ----
  * create = deviceUpdate (:822-852, allocLines :728-820) for a first-order target bus of
  * `num_out_lines` lines (identity AmbiMap, no up-mix); update = ReverbState::update (:1222-1395);

@@ -594,6 +594,72 @@ int oal_scene_set_voice_params(oal_scene *s, int voice, const oal_voice_params *
     return 0;
 }
 
+int oal_scene_add_voice_multi(oal_scene *s, const oal_voice_desc *desc, uint32_t num_channels)
+{
+    auto const vi = oal_scene_add_voice(s, desc);
+    auto &v = s->voices.at(static_cast<size_t>(vi));
+    if(num_channels != 4 || v.mFrameStep != 4) return -1;
+    /* a first-order B-Format source; the device has to be at least first order for prepare()
+     * to keep all four channels (voice.cpp:1247-1249) */
+    if(s->dev->mAmbiOrder < 1) s->dev->mAmbiOrder = 1;
+    v.mFmtChannels = FmtBFormat3D;
+    v.mAmbiOrder = 1;
+    auto const pos = v.mPosition.load(std::memory_order_relaxed);
+    auto const frac = v.mPositionFrac.load(std::memory_order_relaxed);
+    v.prepare(s->dev.get());
+    v.mPosition.store(pos, std::memory_order_relaxed);
+    v.mPositionFrac.store(frac, std::memory_order_relaxed);
+    if(v.mChans.size() != 4) return -1;
+    return vi;
+}
+
+int oal_scene_set_channel_params(oal_scene *s, int voice, uint32_t channel, const oal_voice_params *p)
+{
+    auto &v = s->voices.at(static_cast<size_t>(voice));
+    auto &dev = *s->dev;
+    auto const fpuctl = FPUCtl{};
+    if(channel >= v.mChans.size() || s->desc.hrtf) return -1;
+    v.mDirect.Buffer = dev.Dry.Buffer;
+    for(size_t i{0};i < dev.NumAuxSends;++i)
+    {
+        if(p->send_slot[i] < 0) v.mSend[i].Buffer = {};
+        else v.mSend[i].Buffer = s->slots.at(static_cast<size_t>(p->send_slot[i])).Wet.Buffer;
+    }
+    v.mStep = p->step;
+    v.mResampler = PrepareResampler(static_cast<Resampler>(p->resampler), v.mStep, &v.mResampleState);
+    auto &chan = v.mChans[channel];
+    std::copy_n(p->dry_gains, MaxOutputChannels, chan.mDryParams.Gains.Target.begin());
+    for(size_t i{0};i < dev.NumAuxSends;++i)
+        std::copy_n(p->send_gains[i], MaxAmbiChannels, chan.mWetParams[i].Gains.Target.begin());
+    v.mDirect.FilterActive = p->direct_filter.active != 0;
+    chan.mDryParams.LowPass.setParamsFromSlope(BiquadType::HighShelf, p->direct_filter.hf_norm,
+        p->direct_filter.gain_hf, 1.0f);
+    chan.mDryParams.HighPass.setParamsFromSlope(BiquadType::LowShelf, p->direct_filter.lf_norm,
+        p->direct_filter.gain_lf, 1.0f);
+    for(size_t i{0};i < dev.NumAuxSends;++i)
+    {
+        v.mSend[i].FilterActive = p->send_filter[i].active != 0;
+        chan.mWetParams[i].LowPass.setParamsFromSlope(BiquadType::HighShelf,
+            p->send_filter[i].hf_norm, p->send_filter[i].gain_hf, 1.0f);
+        chan.mWetParams[i].HighPass.setParamsFromSlope(BiquadType::LowShelf,
+            p->send_filter[i].lf_norm, p->send_filter[i].gain_lf, 1.0f);
+    }
+    return 0;
+}
+
+int oal_scene_set_channel_ambi_scale(oal_scene *s, int voice, uint32_t channel, float xover_norm,
+    float hf_scale, float lf_scale)
+{
+    auto &v = s->voices.at(static_cast<size_t>(voice));
+    if(channel >= v.mChans.size()) return -1;
+    auto &chan = v.mChans[channel];
+    chan.mAmbiSplitter.init(xover_norm);
+    chan.mAmbiHFScale = hf_scale;
+    chan.mAmbiLFScale = lf_scale;
+    v.mFlags.set(VoiceFlag::IsAmbisonic);
+    return 0;
+}
+
 int oal_scene_set_voice_state(oal_scene *s, int voice, int vstate)
 {
     s->vstate.at(static_cast<size_t>(voice)) = vstate;

@@ -174,6 +174,11 @@ class OracleLib:
                                            C.c_uint32, C.c_uint32, C.c_uint32]
         L.oal_scene_add_voice.argtypes = [C.c_void_p, C.POINTER(VoiceDesc)]
         L.oal_scene_set_voice_params.argtypes = [C.c_void_p, C.c_int, C.POINTER(VoiceParams)]
+        if hasattr(L, "oal_scene_add_voice_multi"):
+            L.oal_scene_add_voice_multi.argtypes = [C.c_void_p, C.POINTER(VoiceDesc), C.c_uint32]
+            L.oal_scene_set_channel_params.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(VoiceParams)]
+            L.oal_scene_set_channel_ambi_scale.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_float,
+                                                           C.c_float]
         L.oal_scene_set_voice_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.oal_scene_mix.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         for n in ("oal_scene_dry", "oal_scene_hrtf_accum"):
@@ -338,6 +343,21 @@ class Scene:
 
     def set_params(self, voice, params):
         assert self.lib.L.oal_scene_set_voice_params(self.h, voice, C.byref(params)) == 0
+
+    # B-Format sources: `voice` = what add_ambi_voice returned, `channel` = 0..nch-1
+    def add_ambi_voice(self, buffer, nch, looping, position=0, frac=0, frequency=44100):
+        d = VoiceDesc(buffer, 1 if looping else 0, position, frac, frequency)
+        v = self.lib.L.oal_scene_add_voice_multi(self.h, C.byref(d), nch)
+        assert v >= 0
+        self.nvoices += 1
+        return v
+
+    def set_channel_params(self, voice, channel, params):
+        assert self.lib.L.oal_scene_set_channel_params(self.h, voice, channel, C.byref(params)) == 0
+
+    def set_channel_ambi_scale(self, voice, channel, xover_norm, hf_scale, lf_scale):
+        assert self.lib.L.oal_scene_set_channel_ambi_scale(self.h, voice, channel, xover_norm, hf_scale,
+                                                           lf_scale) == 0
 
     def set_state(self, voice, vstate):
         assert self.lib.L.oal_scene_set_voice_state(self.h, voice, vstate) == 0
