@@ -206,6 +206,12 @@ int oalgpu_set_direct_hrtf(oalgpu_context *ctx, const float *chan_coeffs /* ndry
 int oalgpu_buffer_register(oalgpu_context *ctx, const void *data, int fmt_type,
     uint32_t frame_step, uint32_t sample_len, uint32_t loop_start, uint32_t loop_end);
 
+/* One channel of an interleaved multi-channel buffer as a buffer of its own (same frames and
+ * loop points, no copy): multi-channel sources -- B-Format in particular -- are mixed as one
+ * voice per channel, which is what Voice::mix's per-ChannelData loop does (DoMix,
+ * core/voice.cpp:934-984).  Returns the new handle. */
+int oalgpu_buffer_channel_view(oalgpu_context *ctx, int buffer, uint32_t channel);
+
 /* Voice::prepare + the source attach of InitVoice (al/source.cpp:639-670) for a static mono
  * voice: mixing state cleared, position set, state Playing, not fading. */
 typedef struct oalgpu_voice_desc {
@@ -216,6 +222,13 @@ typedef struct oalgpu_voice_desc {
     uint32_t frequency;           /* mFrequency */
 } oalgpu_voice_desc;
 int oalgpu_voice_init(oalgpu_context *ctx, uint32_t voice, const oalgpu_voice_desc *desc);
+/* VoiceFlag::IsAmbisonic for this (channel) voice: ChannelData::mAmbiSplitter.init(xover_norm),
+ * mAmbiHFScale, mAmbiLFScale as Voice::prepare sets them up for a B-Format source on a
+ * higher-order device (core/voice.cpp:1353-1380); every mix then runs
+ * BandSplitter::processScale over the resampled samples ahead of DoFilters (:1082-1091).
+ * Call after oalgpu_voice_init (which clears it). */
+int oalgpu_voice_set_ambi_scale(oalgpu_context *ctx, uint32_t voice, float xover_norm, float hf_scale,
+    float lf_scale);
 
 typedef struct oalgpu_filter_params {
     int32_t active;               /* TargetData::FilterActive */

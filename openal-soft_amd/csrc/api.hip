@@ -117,6 +117,7 @@ struct oalgpu_context {
     DevBuf<BiquadSlot> dfilt, sfilt;
     DevBuf<float> partLines, partLines2, partHrtf, partHrtf2, bus, streams;
     DevBuf<uint32_t> lineGains;
+    DevBuf<AmbiScaleState> ambi;
     DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
     bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
     // HRTF store
@@ -423,6 +424,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->sfilt.alloc(nv * L.numSends * 2)); HIP_TRY(c->sfilt.zero()); L.sfilt = c->sfilt.p;
     HIP_TRY(c->sendCur.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendCur.zero()); L.sendCur = c->sendCur.p;
     HIP_TRY(c->sendTgt.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendTgt.zero()); L.sendTgt = c->sendTgt.p;
+    HIP_TRY(c->ambi.alloc(nv)); HIP_TRY(c->ambi.zero()); L.ambi = c->ambi.p;
     L.numLineGroups = L.numGroups;
     L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0; L.streamsPerVoice = 0;
     if(c->useWave && (!L.hrtf || L.numSends))
@@ -594,6 +596,35 @@ int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     c->initPending.push_back(VoiceInitRecord{voice, d->buffer, d->looping ? 1 : 0, d->position, d->position_frac});
     return OALGPU_OK;
+}
+
+int oalgpu_voice_set_ambi_scale(oalgpu_context *c, uint32_t voice, float xover_norm, float hf_scale, float lf_scale)
+{
+    if(!c || voice >= c->L.numVoices || !(xover_norm > 0.0f) || !(xover_norm < 0.5f))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_ambi_scale: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    AmbiScaleState st{};
+    st.coeff = SplitterCoeff(xover_norm);
+    st.hfScale = hf_scale; st.lfScale = lf_scale;
+    LaunchSetAmbiScale(c->stream, c->L, voice, st);
+    HIP_TRY(hipGetLastError());
+    return OALGPU_OK;
+}
+
+int oalgpu_buffer_channel_view(oalgpu_context *c, int buffer, uint32_t channel)
+{
+    if(!c || buffer < 0 || uint32_t(buffer) >= c->numBuffers) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_channel_view: bad buffer");
+    if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    static const size_t bytesPer[7] = {1, 2, 4, 4, 8, 1, 1};
+    BufferItem item{};
+    HIP_TRY(hipMemcpy(&item, c->buffers.p + buffer, sizeof(item), hipMemcpyDeviceToHost));
+    if(channel >= item.frameStep) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_channel_view: channel >= frame_step");
+    item.data = static_cast<const char*>(item.data) + size_t{channel} * bytesPer[item.fmt];
+    HIP_TRY(hipMemcpy(c->buffers.p + c->numBuffers, &item, sizeof(item), hipMemcpyHostToDevice));
+    c->bufferData[c->numBuffers] = nullptr;               // the storage belongs to `buffer`
+    return int(c->numBuffers++);
 }
 
 static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params,

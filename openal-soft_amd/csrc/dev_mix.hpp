@@ -176,4 +176,27 @@ __device__ __forceinline__ void SplitterHfScale(SplitterState &s, SrcPtr in, Dst
     s.lpZ1 = lpZ1; s.lpZ2 = lpZ2; s.apZ1 = apZ1;
 }
 
+// ---- BandSplitter::processScale(samples, hfscale, lfscale), splitter.cpp:133-161, in place ---
+template<typename Ptr>
+__device__ __forceinline__ void SplitterScale(SplitterState &s, Ptr buf, uint32_t n, float hfscale, float lfscale)
+{
+    const float apCoeff = s.coeff;
+    const float lpCoeff = s.coeff * 0.5f + 0.5f;
+    float lpZ1 = s.lpZ1, lpZ2 = s.lpZ2, apZ1 = s.apZ1;
+    for(uint32_t i = 0; i < n; ++i)
+    {
+        const float x = buf[i];
+        const float d0 = (x - lpZ1) * lpCoeff;
+        const float lpY0 = lpZ1 + d0;
+        lpZ1 = lpY0 + d0;
+        const float d1 = (lpY0 - lpZ2) * lpCoeff;
+        const float lpY1 = lpZ2 + d1;
+        lpZ2 = lpY1 + d1;
+        const float apY = x * apCoeff + apZ1;
+        apZ1 = x - apY * apCoeff;
+        buf[i] = (apY - lpY1) * hfscale + lpY1 * lfscale;
+    }
+    s.lpZ1 = lpZ1; s.lpZ2 = lpZ2; s.apZ1 = apZ1;
+}
+
 } // namespace oalgpu

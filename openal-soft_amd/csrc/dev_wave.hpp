@@ -52,6 +52,81 @@ __device__ __forceinline__ VoiceCtl LoadCtlScalar(const VoiceCtl *p)
 }
 
 
+// ---- BandSplitter as a wavefront block scan ----------------------------------------------------
+// BandSplitter::processHfScale / processScale (core/filters/splitter.cpp:65-97, :133-161) is a
+// 3-state linear recurrence (lpZ1, lpZ2, apZ1); the wavefront runs it as a block scan -- each lane
+// owns a run of samples, block start states by a 6-step Kogge-Stone scan over the lanes with powers
+// of the run's transition matrix -- instead of n serial steps.  HFONLY: processHfScale (its first
+// low-pass state update carries an extra coefficient, splitter.cpp:79, and there is no LF scale).
+struct Sp3 { float a, b, c; };                              // (lpZ1, lpZ2, apZ1)
+
+// one sample on state s; returns the output
+template<bool HFONLY>
+__device__ __forceinline__ float SplitStep(Sp3 &s, float x, float apCoeff, float lpCoeff, float hf, float lf)
+{
+    const float d0 = (x - s.a) * lpCoeff;
+    const float lpY0 = s.a + d0;
+    s.a = HFONLY ? __builtin_fmaf(d0, lpCoeff, lpY0) : lpY0 + d0;   // splitter.cpp:79 vs :146
+    const float d1 = (lpY0 - s.b) * lpCoeff;
+    const float lpY1 = s.b + d1;
+    s.b = lpY1 + d1;
+    const float apY = __builtin_fmaf(x, apCoeff, s.c);
+    s.c = __builtin_fmaf(-apY, apCoeff, x);
+    return __builtin_fmaf(apY - lpY1, hf, HFONLY ? lpY1 : lpY1 * lf);
+}
+
+struct Mat3 { Sp3 c0, c1, c2; };
+__device__ __forceinline__ Sp3 MatVec3(const Mat3 &m, const Sp3 &v)
+{
+    Sp3 r;
+    r.a = __builtin_fmaf(m.c2.a, v.c, __builtin_fmaf(m.c1.a, v.b, m.c0.a * v.a));
+    r.b = __builtin_fmaf(m.c2.b, v.c, __builtin_fmaf(m.c1.b, v.b, m.c0.b * v.a));
+    r.c = __builtin_fmaf(m.c2.c, v.c, __builtin_fmaf(m.c1.c, v.b, m.c0.c * v.a));
+    return r;
+}
+__device__ __forceinline__ Mat3 MatMul3(const Mat3 &a, const Mat3 &b)
+{ return Mat3{MatVec3(a, b.c0), MatVec3(a, b.c1), MatVec3(a, b.c2)}; }
+
+// in place over buf[0..n); the lane stride (seg) is odd so the per-lane runs hit distinct banks
+template<bool HFONLY>
+__device__ __forceinline__ void SplitterScan(SplitterState &st, float *buf, uint32_t n, float hf, float lf, uint32_t lane)
+{
+    const float apCoeff = st.coeff, lpCoeff = st.coeff * 0.5f + 0.5f;
+    const uint32_t seg = ((n + 63u) / 64u) | 1u;
+    const uint32_t begin = lane * seg < n ? lane * seg : n;
+    const uint32_t end = (begin + seg < n) ? begin + seg : n;
+    Mat3 M{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for(uint32_t i = 0; i < seg; ++i)
+    {
+        SplitStep<HFONLY>(M.c0, 0.0f, apCoeff, lpCoeff, hf, lf); SplitStep<HFONLY>(M.c1, 0.0f, apCoeff, lpCoeff, hf, lf);
+        SplitStep<HFONLY>(M.c2, 0.0f, apCoeff, lpCoeff, hf, lf);
+    }
+    Sp3 q{0, 0, 0};
+    for(uint32_t i = begin; i < end; ++i) SplitStep<HFONLY>(q, buf[i], apCoeff, lpCoeff, hf, lf);
+    Sp3 e = q;                                   // -> sum_{k<=l} M^(l-k) q_k
+    Sp3 s0{st.lpZ1, st.lpZ2, st.apZ1};           // -> M^lane S_0
+    Mat3 P = M;
+#pragma unroll
+    for(int step = 0; step < 6; ++step)
+    {
+        const int d = 1 << step;
+        Sp3 o;
+        o.a = __shfl_up(e.a, d); o.b = __shfl_up(e.b, d); o.c = __shfl_up(e.c, d);
+        const Sp3 mo = MatVec3(P, o);
+        if(int(lane) >= d) { e.a += mo.a; e.b += mo.b; e.c += mo.c; }
+        const Sp3 ms = MatVec3(P, s0);
+        if(lane & uint32_t(d)) s0 = ms;
+        if(step < 5) P = MatMul3(P, P);
+    }
+    Sp3 prevE;
+    prevE.a = __shfl_up(e.a, 1); prevE.b = __shfl_up(e.b, 1); prevE.c = __shfl_up(e.c, 1);
+    Sp3 start = s0;
+    if(lane > 0) { start.a += prevE.a; start.b += prevE.b; start.c += prevE.c; }
+    for(uint32_t i = begin; i < end; ++i) buf[i] = SplitStep<HFONLY>(start, buf[i], apCoeff, lpCoeff, hf, lf);
+    const int lastLane = int((n - 1u) / seg);
+    st.lpZ1 = __shfl(start.a, lastLane); st.lpZ2 = __shfl(start.b, lastLane); st.apZ1 = __shfl(start.c, lastLane);
+}
+
 // ---- dual-ear FIR, packed over the ears -------------------------------------------------------
 // acc[r] = (L,R) of output frame R*lane + r.  xw points at the x' entry of the lane's first
 // frame; co16[b] = taps 8b..8b+7 as (Coeffs[j][0], Coeffs[j][1]) pairs, one s_load_dwordx16

@@ -27,6 +27,7 @@ enum VoiceFlagBits : uint32_t {
     kFlagHasHrtf = 1u << 1,         // VoiceFlag::HasHrtf
     kFlagDirectFilter = 1u << 2,    // mDirect.FilterActive
     kFlagHrtfDirty = 1u << 3,       // Hrtf.Target replaced since the last mix (Old != Target)
+    kFlagAmbiScale = 1u << 4,       // VoiceFlag::IsAmbisonic: ambi[v] holds the channel's splitter and scales
     kFlagSendFilterShift = 8        // bits 8..13: mSend[i].FilterActive
 };
 
@@ -50,6 +51,10 @@ struct alignas(16) VoiceCtl {
     uint32_t pad[8];
 };
 static_assert(sizeof(VoiceCtl) == 128, "VoiceCtl is one 128-byte line");
+
+// ChannelData::mAmbiSplitter (BandSplitter: coefficient + three delay elements), mAmbiHFScale,
+// mAmbiLFScale of a B-Format channel voice
+struct alignas(16) AmbiScaleState { float coeff, lpZ1, lpZ2, apZ1, hfScale, lfScale; uint32_t pad[2]; };
 
 // a BiquadState padded to 64 bytes so each filter is one aligned segment
 struct alignas(16) BiquadSlot { BiquadState f; uint32_t pad[3]; };
@@ -83,6 +88,7 @@ struct DeviceLayout {
     float *gainCur, *gainTgt;
     BiquadSlot *sfilt;
     float *sendCur, *sendTgt;
+    AmbiScaleState *ambi;                   // [voice]
     // partial buses written by the voice kernel: [group][mixLines][1024], [group][1152][2]
     float *partLines, *partHrtf;
     // wavefront kernel, dry-line and send mixing: stream rows [voice][streamsPerVoice][1024] and
@@ -163,6 +169,7 @@ hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint
 void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry);
 
 // ---- launchers (voice_wave.hip): the FAST HRTF hot path, one wavefront per voice ----
+void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st);
 bool WaveKernelApplies(bool exact, const DeviceLayout &L);
 const char *WaveKernelName(const DeviceLayout &L);
 uint32_t WaveKernelGroups(const DeviceLayout &L);

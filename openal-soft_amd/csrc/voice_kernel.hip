@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfSto
         ctl.step = r.step;
         ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
         ctl.rsFilterOffset = r.rsFilterOffset;
-        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf);
-        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty))
+        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale);
+        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale))
             | (L.hrtf ? (kFlagHasHrtf | kFlagHrtfDirty) : 0u);
         for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
         BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
@@ -88,6 +88,16 @@ __global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfSto
     for(uint32_t k = t; k < L.numSends * L.wetChannels; k += blockDim.x)
         L.sendTgt[size_t{v} * L.numSends * L.wetChannels + k] = r.sendGains[k / L.wetChannels][k % L.wetChannels];
 }
+
+// VoiceFlag::IsAmbisonic + the channel's splitter and scales (Voice::prepare, voice.cpp:1353-1380)
+__global__ void SetAmbiScaleKernel(DeviceLayout L, uint32_t v, AmbiScaleState st)
+{
+    L.ambi[v] = st;
+    L.ctl[v].flags |= kFlagAmbiScale;
+}
+
+void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st)
+{ hipLaunchKernelGGL(SetAmbiScaleKernel, dim3(1), dim3(1), 0, s, L, voice, st); }
 
 // Voice::prepare (core/voice.cpp:1235-1397) + InitVoice's source attach (al/source.cpp:639-670)
 // for `count` static mono voices: mixing state cleared, filters default-constructed
@@ -509,6 +519,18 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
 
         LoadResampled<EXACT>(sm, L, v, ctl, playing, bufPosInt, bufPosFrac, increment, N, N, bufferItem, loopItem >= 0,
             stagedTable);
+
+        if(ctl.flags & kFlagAmbiScale)
+        {   // ---- VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
+            if(t == 0)
+            {
+                AmbiScaleState &a = L.ambi[v];
+                SplitterState sp{a.coeff, a.lpZ1, a.lpZ2, a.apZ1};
+                SplitterScale(sp, sm.in + kHist, N, a.hfScale, a.lfScale);
+                a.lpZ1 = sp.lpZ1; a.lpZ2 = sp.lpZ2; a.apZ1 = sp.apZ1;
+            }
+            __syncthreads();
+        }
 
         const uint32_t counter = (ctl.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
 

@@ -683,6 +683,15 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             const float prevLoaded = plan.prefetch ? prevN : ((lane < kMaxPad) ? L.prev[size_t{v} * kMaxPad + lane] : 0.0f);
 
             LoadResampledWave(sm, w, L, v, lane, head, playing, N, N, bufferItem, looping, plan, preN, prevLoaded);
+            if(head.flags & kFlagAmbiScale)
+            {   // VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
+                const AmbiScaleState a = L.ambi[v];
+                SplitterState sp{a.coeff, a.lpZ1, a.lpZ2, a.apZ1};
+                WaveSync();
+                SplitterScan<false>(sp, w.in + kHist, N, a.hfScale, a.lfScale, lane);
+                WaveSync();
+                if(lane == 0) { L.ambi[v].lpZ1 = sp.lpZ1; L.ambi[v].lpZ2 = sp.lpZ2; L.ambi[v].apZ1 = sp.apZ1; }
+            }
 
             // the next voice's head has arrived by now: plan its window and fetch its buffer
             // descriptor, so that only the gather itself is left for the request point below

@@ -339,6 +339,25 @@ class Scene:
         self.nvoices += 1
         return v
 
+    # B-Format sources: one voice per channel over channel views of the interleaved buffer
+    # (same interface as tests/oracle_lib.Scene: `voice` = what add_ambi_voice returned)
+    def add_ambi_voice(self, buffer, nch, looping, position=0, frac=0, frequency=44100):
+        lib.oalgpu_buffer_channel_view.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        first = self.nvoices
+        for ch in range(nch):
+            view = lib.oalgpu_buffer_channel_view(self.h, buffer, ch)
+            check(min(view, 0), "oalgpu_buffer_channel_view")
+            self.add_voice(view, looping, position, frac, frequency)
+        return first
+
+    def set_channel_params(self, voice, channel, params):
+        self.set_params(voice + channel, params)
+
+    def set_channel_ambi_scale(self, voice, channel, xover_norm, hf_scale, lf_scale):
+        lib.oalgpu_voice_set_ambi_scale.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float]
+        check(lib.oalgpu_voice_set_ambi_scale(self.h, voice + channel, xover_norm, hf_scale, lf_scale),
+              "oalgpu_voice_set_ambi_scale")
+
     def set_params(self, voice, params):
         """params: any ctypes struct with the oalgpu_voice_params layout."""
         assert C.sizeof(params) == C.sizeof(VoiceParams)

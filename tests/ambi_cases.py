@@ -14,7 +14,7 @@ HF_SCALES = (1.26, 0.91, 0.91, 0.91)
 
 
 def run(L, n_updates=4, todo=(1024, 1024, 600, 1024), seed=3, sends=1, nambi=3, nmono=5, stop_at=2,
-        resampler=ol.RS_BSINC24):
+        resampler=ol.RS_BSINC24, only_channel=None):
     rng = np.random.default_rng(seed)
     sc = L.make_scene(num_dry=NLINES, num_real=0, num_sends=sends, num_slots=2 if sends else 0, wet_channels=4,
                       hrtf=False)
@@ -38,7 +38,7 @@ def run(L, n_updates=4, todo=(1024, 1024, 600, 1024), seed=3, sends=1, nambi=3, 
         ambi.append(v)
         for c in range(4):
             # voice-wide fields (step, resampler, send slots, filter-active flags) identical per channel
-            sc.set_channel_params(v, c, _chan_params(params, a, c, 0))
+            sc.set_channel_params(v, c, _chan_params(params, a, c, 0, only_channel))
             sc.set_channel_ambi_scale(v, c, XOVER, HF_SCALES[c], 1.0 if a != 1 else 0.7)
     monos = []
     for m in range(nmono):
@@ -50,7 +50,7 @@ def run(L, n_updates=4, todo=(1024, 1024, 600, 1024), seed=3, sends=1, nambi=3, 
         if k > 0:
             for a in range(0, nambi, 2):
                 for c in range(4):
-                    sc.set_channel_params(ambi[a], c, _chan_params(params, a, c, k))
+                    sc.set_channel_params(ambi[a], c, _chan_params(params, a, c, k, only_channel))
             if monos:
                 sc.set_params(monos[0], params(100, k, 0))
         if stop_at is not None and k == stop_at and len(monos) > 1:
@@ -64,11 +64,14 @@ def run(L, n_updates=4, todo=(1024, 1024, 600, 1024), seed=3, sends=1, nambi=3, 
     return np.concatenate(out)
 
 
-def _chan_params(params, a, c, k):
-    """Per-channel gains differ; everything voice-wide is taken from the voice's key."""
+def _chan_params(params, a, c, k, only_channel=None):
+    """Per-channel gains differ; everything voice-wide is taken from the voice's key.
+    only_channel: every other channel gets zero gains (its bus contribution is an exact 0)."""
     p = params(a, k, a % 2)
     r = np.random.default_rng(1000 * a + 10 * c + k)
     g = r.uniform(-0.3, 0.3, NLINES).astype(np.float32)
+    if only_channel is not None and c != only_channel:
+        g[:] = 0.0
     for i in range(NLINES):
         p.dry_gains[i] = float(g[i])
     for s in range(6):

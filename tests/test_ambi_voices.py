@@ -39,3 +39,42 @@ def test_prescale_is_live():
     finally:
         ambi_cases.HF_SCALES = saved
     assert np.abs(a - b).max() > 1e-3
+
+
+# ------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("kw", [dict(), dict(sends=0, nambi=2, nmono=0), dict(todo=(333, 1024, 64, 1000), seed=5)],
+                         ids=["default", "ambi_only", "ragged"])
+def test_gpu_matches_oracle(mode, kw):
+    import oalgpu
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    which = "ref" if ol.available("ref") else "port"
+    L = ol.load(which)
+    L.L.oal_set_simd(1)
+    api = oalgpu.Api(oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
+    a = ambi_cases.run(api, **kw).astype(np.float64)
+    b = ambi_cases.run(L, **kw).astype(np.float64)
+    # sums over several voices: the multi-voice tolerance of tests/test_gpu_parity.py
+    err = np.abs(a - b).max()
+    assert err <= 2e-5 * np.abs(b).max() + 1e-7, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channel", [0, 2])
+def test_gpu_one_channel_exact_mode_is_bit_exact(channel):
+    """One B-Format voice of which a single channel is audible, EXACT mode: the channel view,
+    the prescale (processScale in the reference's operation order) and the mix are bit-identical
+    to the reference.  (With several audible channels the partial buses of the channel voices
+    are summed in a different order than the serial loop: tolerance test above.)"""
+    import oalgpu
+    if not ol.available("ref"):
+        pytest.skip("needs the compiled reference")
+    L = ol.load("ref")
+    L.L.oal_set_simd(1)
+    api = oalgpu.Api(oalgpu.MATH_EXACT)
+    kw = dict(sends=0, nambi=1, nmono=0, n_updates=3, only_channel=channel)
+    a = ambi_cases.run(api, **kw)
+    b = ambi_cases.run(L, **kw)
+    assert np.abs(b).max() > 0.01
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
