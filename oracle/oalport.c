@@ -1068,6 +1068,14 @@ typedef struct send_params { /* SendParams core/voice.h:73-82 */
     float cur[OAL_MAX_AMBI_CHANNELS], tgt[OAL_MAX_AMBI_CHANNELS];
 } send_params;
 
+/* NfcFilter (core/filters/nfc.h): sections of order 1..4, coefficients as the reference names
+ * them; c[o] = {a0, a1.., b1..} with 2*o+1 entries used */
+typedef struct nfc_filter {
+    float base_gain[5];
+    float a[5][5], b[5][5];   /* a[o][0..o], b[o][1..o] */
+    float z[5][4];
+} nfc_filter;
+
 typedef struct voice { /* Voice core/voice.h:176-270 (mono, static sources) */
     int play_state;
     int position; unsigned position_frac;
@@ -1084,6 +1092,7 @@ typedef struct voice { /* Voice core/voice.h:176-270 (mono, static sources) */
     send_params send[OAL_MAX_SENDS];
     /* ChannelData::mAmbiSplitter / mAmbiHFScale / mAmbiLFScale + VoiceFlag::IsAmbisonic */
     int is_ambisonic; oal_splitter ambi_splitter; float ambi_hf_scale, ambi_lf_scale;
+    int has_nfc; nfc_filter nfc;   /* VoiceFlag::HasNfc, DirectParams::NFCtrlFilter */
 } voice;
 
 struct oal_scene {
@@ -1101,6 +1110,8 @@ struct oal_scene {
     float extra[LINE + HIST];
     /* DirectHrtfState */
     oal_splitter *dsplit; float *dhfscale; float *dcoeffs; uint32_t dirsize;
+    /* DeviceBase::mNFCtrlFilter, NumChannelsPerOrder */
+    nfc_filter dev_nfc; uint32_t chans_per_order[5];
 };
 
 oal_scene *oal_scene_create(const oal_device_desc *desc)
@@ -1172,6 +1183,7 @@ int oal_scene_add_voice(oal_scene *s, const oal_voice_desc *desc)
     v->cur_buffer = desc->buffer;
     v->loop_buffer = desc->looping ? desc->buffer : -1;
     v->has_hrtf = s->desc.hrtf;
+    v->nfc = s->dev_nfc;   /* chandata.mDryParams.NFCtrlFilter = device->mNFCtrlFilter, voice.cpp:1391 */
     return (int)s->nvoices++;
 }
 
@@ -1205,6 +1217,122 @@ int oal_scene_set_voice_params(oal_scene *s, int vi, const oal_voice_params *p)
         v->send_filter_active[i] = p->send_filter[i].active != 0;
         set_filter_pair(&v->send[i].lp, &v->send[i].hp, &p->send_filter[i]);
     }
+    fpu_leave(csr);
+    return 0;
+}
+
+/* ---- NfcFilter, core/filters/nfc.cpp:56-288 ---- */
+static const float NFC_B1[1] = {1.0f};
+static const float NFC_B2[2] = {3.0f, 3.0f};
+static const float NFC_B3[3] = {3.6778f, 6.4595f, 2.3222f};
+static const float NFC_B4[4] = {4.2076f, 11.4877f, 5.7924f, 9.1401f};
+
+/* the section gains g_1 (second-order part) and g_0 (remaining part) and the derived
+ * coefficients for order o and angular frequency w; out[1..o] (NfcFilterCreateN / AdjustN) */
+static float nfc_design(int o, float w, float *out)
+{
+    const float r = 0.5f * w;
+    if(o == 1)
+    {
+        const float b_00 = NFC_B1[0] * r;
+        const float g_0 = 1.0f + b_00;
+        out[1] = 2.0f * b_00 / g_0;
+        return g_0;
+    }
+    if(o == 2)
+    {
+        const float b_10 = NFC_B2[0] * r, b_11 = NFC_B2[1] * (r * r);
+        const float g_1 = 1.0f + b_10 + b_11;
+        out[1] = (2.0f * b_10 + 4.0f * b_11) / g_1;
+        out[2] = 4.0f * b_11 / g_1;
+        return g_1;
+    }
+    if(o == 3)
+    {
+        const float b_10 = NFC_B3[0] * r, b_11 = NFC_B3[1] * (r * r), b_00 = NFC_B3[2] * r;
+        const float g_1 = 1.0f + b_10 + b_11, g_0 = 1.0f + b_00;
+        out[1] = (2.0f * b_10 + 4.0f * b_11) / g_1;
+        out[2] = 4.0f * b_11 / g_1;
+        out[3] = 2.0f * b_00 / g_0;
+        return g_1 * g_0;
+    }
+    {
+        const float b_10 = NFC_B4[0] * r, b_11 = NFC_B4[1] * (r * r), b_00 = NFC_B4[2] * r, b_01 = NFC_B4[3] * (r * r);
+        const float g_1 = 1.0f + b_10 + b_11, g_0 = 1.0f + b_00 + b_01;
+        out[1] = (2.0f * b_10 + 4.0f * b_11) / g_1;
+        out[2] = 4.0f * b_11 / g_1;
+        out[3] = (2.0f * b_00 + 4.0f * b_01) / g_0;
+        out[4] = 4.0f * b_01 / g_0;
+        return g_1 * g_0;
+    }
+}
+
+static void nfc_init(nfc_filter *f, float w1) /* NfcFilter::init :205-211 */
+{
+    memset(f, 0, sizeof(*f));
+    for(int o = 1; o <= 4; ++o)
+    {
+        const float g = nfc_design(o, w1, f->a[o]);
+        f->base_gain[o] = 1.0f / g;
+        f->a[o][0] = 1.0f;
+        for(int k = 1; k <= o; ++k) f->b[o][k] = f->a[o][k];
+    }
+}
+
+static void nfc_adjust(nfc_filter *f, float w0) /* NfcFilter::adjust :213-219 */
+{
+    for(int o = 1; o <= 4; ++o)
+    {
+        const float g = nfc_design(o, w0, f->b[o]);
+        f->a[o][0] = f->base_gain[o] * g;
+    }
+}
+
+static void nfc_process(nfc_filter *f, int o, const float *src, float *dst, size_t n) /* :222-288 */
+{
+    const float *a = f->a[o], *b = f->b[o];
+    float *z = f->z[o];
+    for(size_t i = 0; i < n; ++i)
+    {
+        const float in = src[i];
+        if(o == 1)
+        {
+            const float y = in * a[0] - a[1] * z[0];
+            dst[i] = y + b[1] * z[0];
+            z[0] += y;
+            continue;
+        }
+        const float y0 = in * a[0] - a[1] * z[0] - a[2] * z[1];
+        const float out0 = y0 + b[1] * z[0] + b[2] * z[1];
+        z[1] += z[0];
+        z[0] += y0;
+        if(o == 2) { dst[i] = out0; continue; }
+        if(o == 3)
+        {
+            const float y1 = out0 - a[3] * z[2];
+            dst[i] = y1 + b[3] * z[2];
+            z[2] += y1;
+            continue;
+        }
+        const float y1 = out0 - a[3] * z[2] - a[4] * z[3];
+        dst[i] = y1 + b[3] * z[2] + b[4] * z[3];
+        z[3] += z[2];
+        z[2] += y1;
+    }
+}
+
+int oal_scene_set_nfc(oal_scene *s, float w1, const uint32_t channels_per_order[5])
+{
+    nfc_init(&s->dev_nfc, w1);
+    memcpy(s->chans_per_order, channels_per_order, sizeof(s->chans_per_order));
+    return 0;
+}
+
+int oal_scene_set_voice_nfc(oal_scene *s, int vi, float w0)
+{
+    const unsigned csr = fpu_enter();
+    nfc_adjust(&s->voices[vi].nfc, w0);
+    s->voices[vi].has_nfc = 1;
     fpu_leave(csr);
     return 0;
 }
@@ -1516,6 +1644,20 @@ static void voice_mix(oal_scene *s, voice *v, int vstate, unsigned samplesToDo)
         else
         {
             const float *tg = (vstate == OAL_VOICE_PLAYING) ? v->gains_tgt : SilentCoeffs;
+            if(v->has_nfc)
+            {   /* DoNfcMix voice.cpp:904-932 */
+                mix_lines(samples, samplesToMix, s->mix, 1, v->gains_cur, tg, counter, outPos);
+                size_t line = 1;
+                for(int order = 1; order <= 4 && s->chans_per_order[order]; ++order)
+                {
+                    const size_t cnt = s->chans_per_order[order];
+                    nfc_process(&v->nfc, order, samples, s->extra, samplesToMix);
+                    mix_lines(s->extra, samplesToMix, s->mix + line * LINE, cnt, v->gains_cur + line, tg + line,
+                        counter, outPos);
+                    line += cnt;
+                }
+            }
+            else
             mix_lines(samples, samplesToMix, s->mix, s->desc.num_dry_channels, v->gains_cur, tg, counter, outPos);
         }
         for(unsigned i = 0; i < numSends; ++i)

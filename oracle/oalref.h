@@ -245,6 +245,16 @@ int oal_scene_set_channel_params(oal_scene *s, int voice, uint32_t channel, cons
 int oal_scene_set_channel_ambi_scale(oal_scene *s, int voice, uint32_t channel, float xover_norm,
     float hf_scale, float lf_scale);
 
+/* ---- near-field control: DoNfcMix, core/voice.cpp:904-932; NfcFilter, core/filters/nfc.cpp ----
+ * Device side (alc/panning.cpp:285-299): the control filter NfcFilter::init(w1),
+ * w1 = speed_of_sound / (control_distance * sample_rate), and NumChannelsPerOrder[0..4] (a 0
+ * ends the list; [0] is the W line).  Call before adding voices: Voice::prepare copies the
+ * device's filter into every channel. */
+int oal_scene_set_nfc(oal_scene *s, float w1, const uint32_t channels_per_order[5]);
+/* Voice side (CalcAmbisonicPanning / CalcPanningAndFilters, alc/alu.cpp:919-941,1328-1341):
+ * NFCtrlFilter.adjust(w0) and VoiceFlag::HasNfc. */
+int oal_scene_set_voice_nfc(oal_scene *s, int voice, float w0);
+
 /* ---- EAX reverb: ReverbState, alc/effects/reverb.cpp:567-1883 ----
  * create = deviceUpdate (:822-852, allocLines :728-820) for a first-order target bus of
  * `num_out_lines` lines (identity AmbiMap, no up-mix); update = ReverbState::update (:1222-1395);

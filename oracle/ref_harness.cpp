@@ -660,6 +660,24 @@ int oal_scene_set_channel_ambi_scale(oal_scene *s, int voice, uint32_t channel, 
     return 0;
 }
 
+int oal_scene_set_nfc(oal_scene *s, float w1, const uint32_t channels_per_order[5])
+{
+    auto &dev = *s->dev;
+    dev.AvgSpeakerDist = 1.0f;          /* > 0: only gates the parameter side (alu.cpp:919) */
+    dev.mNFCtrlFilter.init(w1);
+    for(size_t i{0};i < 5;++i) dev.NumChannelsPerOrder[i] = channels_per_order[i];
+    return 0;
+}
+
+int oal_scene_set_voice_nfc(oal_scene *s, int voice, float w0)
+{
+    auto &v = s->voices.at(static_cast<size_t>(voice));
+    auto const fpuctl = FPUCtl{};
+    v.mChans[0].mDryParams.NFCtrlFilter.adjust(w0);
+    v.mFlags.set(VoiceFlag::HasNfc);
+    return 0;
+}
+
 int oal_scene_set_voice_state(oal_scene *s, int voice, int vstate)
 {
     s->vstate.at(static_cast<size_t>(voice)) = vstate;

@@ -174,6 +174,9 @@ class OracleLib:
                                            C.c_uint32, C.c_uint32, C.c_uint32]
         L.oal_scene_add_voice.argtypes = [C.c_void_p, C.POINTER(VoiceDesc)]
         L.oal_scene_set_voice_params.argtypes = [C.c_void_p, C.c_int, C.POINTER(VoiceParams)]
+        if hasattr(L, "oal_scene_set_nfc"):
+            L.oal_scene_set_nfc.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint32)]
+            L.oal_scene_set_voice_nfc.argtypes = [C.c_void_p, C.c_int, C.c_float]
         if hasattr(L, "oal_scene_add_voice_multi"):
             L.oal_scene_add_voice_multi.argtypes = [C.c_void_p, C.POINTER(VoiceDesc), C.c_uint32]
             L.oal_scene_set_channel_params.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(VoiceParams)]
@@ -343,6 +346,14 @@ class Scene:
 
     def set_params(self, voice, params):
         assert self.lib.L.oal_scene_set_voice_params(self.h, voice, C.byref(params)) == 0
+
+    # near-field control (DoNfcMix): device filter + lines per ambisonic order, then per voice w0
+    def set_nfc(self, w1, channels_per_order):
+        cpo = (C.c_uint32 * 5)(*(list(channels_per_order) + [0] * 5)[:5])
+        assert self.lib.L.oal_scene_set_nfc(self.h, w1, cpo) == 0
+
+    def set_voice_nfc(self, voice, w0):
+        assert self.lib.L.oal_scene_set_voice_nfc(self.h, voice, w0) == 0
 
     # B-Format sources: `voice` = what add_ambi_voice returned, `channel` = 0..nch-1
     def add_ambi_voice(self, buffer, nch, looping, position=0, frac=0, frequency=44100):

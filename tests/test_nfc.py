@@ -1,0 +1,33 @@
+"""Near-field control filters: DoNfcMix, core/voice.cpp:904-932, and NfcFilter,
+core/filters/nfc.cpp -- the restatement against the compiled reference (bit for bit), the GPU
+against the oracle."""
+import numpy as np
+import pytest
+
+import nfc_cases
+import oracle_lib as ol
+
+needs_ref = pytest.mark.skipif(not ol.available("ref"), reason="oracle/_ref not built here")
+CASES = [dict(), dict(order=1, sends=0, nvoices=3), dict(order=3, seed=4), dict(order=4, nvoices=4, seed=6),
+         dict(order=2, periphonic=False, todo=(100, 1024, 64, 1000)), dict(nfc_every=2, seed=8)]
+IDS = ["order2", "order1", "order3", "order4", "order2_2d_ragged", "mixed_nfc_and_plain"]
+
+
+@needs_ref
+@pytest.mark.parametrize("kw", CASES, ids=IDS)
+def test_port_matches_reference(kw):
+    ref, port = ol.load("ref"), ol.load("port")
+    ref.L.oal_set_simd(1); port.L.oal_set_simd(1)
+    a = nfc_cases.run(ref, **kw)
+    b = nfc_cases.run(port, **kw)
+    assert np.abs(a).max() > 0.01
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+
+
+@needs_ref
+def test_nfc_is_live():
+    """The filters are in the path: the same scene without per-voice NFC differs."""
+    ref = ol.load("ref")
+    a = nfc_cases.run(ref, sends=0)
+    b = nfc_cases.run(ref, sends=0, nfc_every=10 ** 6)
+    assert np.abs(a - b).max() > 1e-3
