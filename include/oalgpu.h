@@ -222,6 +222,16 @@ typedef struct oalgpu_voice_desc {
     uint32_t frequency;           /* mFrequency */
 } oalgpu_voice_desc;
 int oalgpu_voice_init(oalgpu_context *ctx, uint32_t voice, const oalgpu_voice_desc *desc);
+/* Near-field control (DoNfcMix, core/voice.cpp:904-932; NfcFilter, core/filters/nfc.cpp).
+ * Context side (alc/panning.cpp:285-299): the control filter NfcFilter::init(w1), w1 =
+ * speed_of_sound / (control_distance * sample_rate), and DeviceBase::NumChannelsPerOrder[0..4]
+ * (a 0 ends the list; [0] is the W line); call before the voices are initialised.  FAST-mode
+ * dry-line contexts only.  Voice side (alc/alu.cpp:919-941, 1328-1341): NFCtrlFilter.adjust(w0)
+ * and VoiceFlag::HasNfc; the W line is then mixed from the voice's samples, every order's lines
+ * from that order's NFC-filtered copy. */
+int oalgpu_context_set_nfc(oalgpu_context *ctx, float w1, const uint32_t channels_per_order[5]);
+int oalgpu_voice_set_nfc(oalgpu_context *ctx, uint32_t voice, float w0);
+
 /* VoiceFlag::IsAmbisonic for this (channel) voice: ChannelData::mAmbiSplitter.init(xover_norm),
  * mAmbiHFScale, mAmbiLFScale as Voice::prepare sets them up for a B-Format source on a
  * higher-order device (core/voice.cpp:1353-1380); every mix then runs

@@ -118,6 +118,8 @@ struct oalgpu_context {
     DevBuf<float> partLines, partLines2, partHrtf, partHrtf2, bus, streams;
     DevBuf<uint32_t> lineGains;
     DevBuf<AmbiScaleState> ambi;
+    DevBuf<NfcState> nfc;
+    NfcDesign nfcDevice{};                   // DeviceBase::mNFCtrlFilter (after init(w1))
     DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
     bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
     // HRTF store
@@ -427,6 +429,8 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->ambi.alloc(nv)); HIP_TRY(c->ambi.zero()); L.ambi = c->ambi.p;
     L.numLineGroups = L.numGroups;
     L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0; L.streamsPerVoice = 0;
+    L.nfc = nullptr; L.nfcOrders = 0;
+    for(uint32_t &n : L.chansPerOrder) n = 0;
     if(c->useWave && (!L.hrtf || L.numSends))
     {   // LinesMixKernel: at most 64 voices per partial bus; 256 partials while the buses are
         // narrow, 128 when they are wide (the partials are HBM traffic for the reduction)
@@ -608,6 +612,63 @@ int oalgpu_voice_set_ambi_scale(oalgpu_context *c, uint32_t voice, float xover_n
     st.coeff = SplitterCoeff(xover_norm);
     st.hfScale = hf_scale; st.lfScale = lf_scale;
     LaunchSetAmbiScale(c->stream, c->L, voice, st);
+    HIP_TRY(hipGetLastError());
+    return OALGPU_OK;
+}
+
+int oalgpu_context_set_nfc(oalgpu_context *c, float w1, const uint32_t channels_per_order[5])
+{
+    if(!c || !channels_per_order || !(w1 > 0.0f)) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: bad arguments");
+    if(!c->useWave || c->L.hrtf)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: near-field control needs a FAST-mode dry-line context");
+    if(c->L.nfc) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: already set");
+    uint32_t lines = channels_per_order[0], orders = 0;
+    if(channels_per_order[0] != 1) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: channels_per_order[0] must be 1 (W)");
+    for(uint32_t o = 1; o < 5 && channels_per_order[o]; ++o) { lines += channels_per_order[o]; ++orders; }
+    if(orders == 0 || lines > c->L.numDry) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: orders do not fit the dry bus");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    DeviceLayout &L = c->L;
+    const size_t nv = L.numVoices;
+    // every order adds one stream row per voice
+    DevBuf<float> streams;
+    DevBuf<uint32_t> lineGains;
+    const uint32_t spv = 2u + L.numSends + orders;
+    HIP_TRY(streams.alloc(nv * spv * kLine)); HIP_TRY(streams.zero());
+    HIP_TRY(lineGains.alloc(nv * spv * LineBlockDwords(L.lineStride))); HIP_TRY(lineGains.zero());
+    HIP_TRY(c->nfc.alloc(nv)); HIP_TRY(c->nfc.zero());
+    std::swap(c->streams.p, streams.p); std::swap(c->streams.n, streams.n);
+    std::swap(c->lineGains.p, lineGains.p); std::swap(c->lineGains.n, lineGains.n);
+    L.streams = c->streams.p; L.lineGains = c->lineGains.p; L.streamsPerVoice = spv;
+    // keep LinesMixKernel's LDS row list under 60 KB with the longer rows-per-voice
+    const uint32_t maxRows = 60000u / (4u * (1u + L.lineStride));
+    const uint32_t maxPer = std::max<uint32_t>(1u, std::min<uint32_t>(64u, maxRows / spv));
+    const uint32_t need = (uint32_t(nv) + maxPer - 1u) / maxPer;
+    if(need > L.numLineGroups)
+    {
+        L.numLineGroups = need;
+        HIP_TRY(c->partLines.alloc(size_t{L.numLineGroups} * L.mixLines * kLine));
+        L.partLines = c->partLines.p; c->partLinesBuf[0] = c->partLines.p;
+    }
+    L.nfc = c->nfc.p;
+    L.nfcOrders = orders;
+    for(int o = 0; o < 5; ++o) L.chansPerOrder[o] = (uint32_t(o) <= orders) ? channels_per_order[o] : 0u;
+    NfcInit(w1, c->nfcDevice);
+    return OALGPU_OK;
+}
+
+int oalgpu_voice_set_nfc(oalgpu_context *c, uint32_t voice, float w0)
+{
+    if(!c || voice >= c->L.numVoices || !(w0 >= 0.0f)) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_nfc: bad arguments");
+    if(!c->L.nfc) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_nfc: oalgpu_context_set_nfc first");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    NfcDesign d = c->nfcDevice;                  // chandata.NFCtrlFilter = device->mNFCtrlFilter, then adjust(w0)
+    NfcAdjust(w0, d);
+    NfcState st{};
+    std::memcpy(st.a, d.a, sizeof(st.a));
+    std::memcpy(st.b, d.b, sizeof(st.b));
+    LaunchSetNfc(c->stream, c->L, voice, st);
     HIP_TRY(hipGetLastError());
     return OALGPU_OK;
 }

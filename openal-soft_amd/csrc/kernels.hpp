@@ -28,6 +28,7 @@ enum VoiceFlagBits : uint32_t {
     kFlagDirectFilter = 1u << 2,    // mDirect.FilterActive
     kFlagHrtfDirty = 1u << 3,       // Hrtf.Target replaced since the last mix (Old != Target)
     kFlagAmbiScale = 1u << 4,       // VoiceFlag::IsAmbisonic: ambi[v] holds the channel's splitter and scales
+    kFlagNfc = 1u << 5,             // VoiceFlag::HasNfc: nfc[v] holds DirectParams::NFCtrlFilter
     kFlagSendFilterShift = 8        // bits 8..13: mSend[i].FilterActive
 };
 
@@ -55,6 +56,11 @@ static_assert(sizeof(VoiceCtl) == 128, "VoiceCtl is one 128-byte line");
 // ChannelData::mAmbiSplitter (BandSplitter: coefficient + three delay elements), mAmbiHFScale,
 // mAmbiLFScale of a B-Format channel voice
 struct alignas(16) AmbiScaleState { float coeff, lpZ1, lpZ2, apZ1, hfScale, lfScale; uint32_t pad[2]; };
+
+// DirectParams::NFCtrlFilter (NfcFilter, core/filters/nfc.h): sections of order 1..4;
+// a[o] = {a0, a1..ao}, b[o] = {-, b1..bo}, z[o] = the section's delay elements
+struct alignas(16) NfcState { float a[5][5], b[5][5], z[5][4]; uint32_t pad[10]; };
+static_assert(sizeof(NfcState) == 320, "NfcState");
 
 // a BiquadState padded to 64 bytes so each filter is one aligned segment
 struct alignas(16) BiquadSlot { BiquadState f; uint32_t pad[3]; };
@@ -89,6 +95,9 @@ struct DeviceLayout {
     BiquadSlot *sfilt;
     float *sendCur, *sendTgt;
     AmbiScaleState *ambi;                   // [voice]
+    NfcState *nfc;                          // [voice], null unless the context has NFC
+    uint32_t chansPerOrder[5];              // DeviceBase::NumChannelsPerOrder (NFC contexts)
+    uint32_t nfcOrders;                     // orders 1.. with lines (0 = no NFC)
     // partial buses written by the voice kernel: [group][mixLines][1024], [group][1152][2]
     float *partLines, *partHrtf;
     // wavefront kernel, dry-line and send mixing: stream rows [voice][streamsPerVoice][1024] and
@@ -170,6 +179,7 @@ void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo,
 
 // ---- launchers (voice_wave.hip): the FAST HRTF hot path, one wavefront per voice ----
 void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st);
+void LaunchSetNfc(hipStream_t s, const DeviceLayout &L, uint32_t voice, const NfcState &coeffs);
 bool WaveKernelApplies(bool exact, const DeviceLayout &L);
 const char *WaveKernelName(const DeviceLayout &L);
 uint32_t WaveKernelGroups(const DeviceLayout &L);

@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfSto
         ctl.step = r.step;
         ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
         ctl.rsFilterOffset = r.rsFilterOffset;
-        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale);
-        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale))
+        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc);
+        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc))
             | (L.hrtf ? (kFlagHasHrtf | kFlagHrtfDirty) : 0u);
         for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
         BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
@@ -99,6 +99,20 @@ __global__ void SetAmbiScaleKernel(DeviceLayout L, uint32_t v, AmbiScaleState st
 void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st)
 { hipLaunchKernelGGL(SetAmbiScaleKernel, dim3(1), dim3(1), 0, s, L, voice, st); }
 
+// NFCtrlFilter.adjust(w0) + VoiceFlag::HasNfc: the coefficients (designed on the host); the
+// delay elements are left as they are
+__global__ void SetNfcKernel(DeviceLayout L, uint32_t v, NfcState st)
+{
+    const uint32_t t = threadIdx.x;
+    float *dst = reinterpret_cast<float*>(&L.nfc[v]);
+    const float *src = reinterpret_cast<const float*>(&st);
+    if(t < 50) dst[t] = src[t];                          // a[5][5] | b[5][5]
+    if(t == 0) L.ctl[v].flags |= kFlagNfc;
+}
+
+void LaunchSetNfc(hipStream_t s, const DeviceLayout &L, uint32_t voice, const NfcState &coeffs)
+{ hipLaunchKernelGGL(SetNfcKernel, dim3(1), dim3(64), 0, s, L, voice, coeffs); }
+
 // Voice::prepare (core/voice.cpp:1235-1397) + InitVoice's source attach (al/source.cpp:639-670)
 // for `count` static mono voices: mixing state cleared, filters default-constructed
 // (BiquadInterpFilter{}: identity coefficients, mCounter = -1), mStep = 0, Playing, not fading.
@@ -123,6 +137,7 @@ __global__ void __launch_bounds__(64) InitVoicesKernel(DeviceLayout L, const Voi
         L.dfilt[size_t{v} * 2 + 1].f = def;
     }
     if(t < kMaxPad) L.prev[size_t{v} * kMaxPad + t] = 0.0f;
+    if(L.nfc && t < 20) reinterpret_cast<float*>(L.nfc[v].z)[t] = 0.0f;
     if(L.hrtf)
     {
         L.hist[size_t{v} * kHist + t] = 0.0f;

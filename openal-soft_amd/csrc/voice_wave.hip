@@ -541,6 +541,48 @@ __device__ __forceinline__ void WaveDoFilters(float *fst, BiquadSlot *slots, boo
     }
 }
 
+// NfcFilterN::process, core/filters/nfc.cpp:222-288, section of order o over src[0..n) -> dst, on
+// one lane in the reference's operation order (the sections are short recurrences; a block
+// scan like the biquads' is the obvious next step)
+__device__ __forceinline__ void NfcSerial(NfcState &st, uint32_t o, const float *src, float *dst, uint32_t n)
+{
+    const float a0 = st.a[o][0], a1 = st.a[o][1], a2 = st.a[o][2], a3 = st.a[o][3], a4 = st.a[o][4];
+    const float b1 = st.b[o][1], b2 = st.b[o][2], b3 = st.b[o][3], b4 = st.b[o][4];
+    float z0 = st.z[o][0], z1 = st.z[o][1], z2 = st.z[o][2], z3 = st.z[o][3];
+    if(o == 1)
+    {
+        for(uint32_t i = 0; i < n; ++i)
+        {
+            const float y = src[i] * a0 - a1 * z0;
+            dst[i] = y + b1 * z0;
+            z0 += y;
+        }
+    }
+    else
+    {
+        for(uint32_t i = 0; i < n; ++i)
+        {
+            const float y0 = src[i] * a0 - a1 * z0 - a2 * z1;
+            const float out0 = y0 + b1 * z0 + b2 * z1;
+            z1 += z0;
+            z0 += y0;
+            if(o == 2) { dst[i] = out0; continue; }
+            if(o == 3)
+            {
+                const float y1 = out0 - a3 * z2;
+                dst[i] = y1 + b3 * z2;
+                z2 += y1;
+                continue;
+            }
+            const float y1 = out0 - a3 * z2 - a4 * z3;
+            dst[i] = y1 + b3 * z2 + b4 * z3;
+            z3 += z2;
+            z2 += y1;
+        }
+    }
+    st.z[o][0] = z0; st.z[o][1] = z1; st.z[o][2] = z2; st.z[o][3] = z3;
+}
+
 // One line's share of a stream row's gain block (kernels.hpp LineBlockDwords): contributions of
 // several MixSamples calls onto the same row and line add up -- the constant gains, and for
 // the ramped frames the per-frame values (a contribution without a ramp adds its constant there)
@@ -716,16 +758,17 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 if constexpr (NL > 0)
                 {
                     if(!directFilter)
-                    {   // MixSamples onto the dry lines rides on the unfiltered row
-                        const uint32_t nd = L.numDry;
+                    {   // MixSamples onto the dry lines rides on the unfiltered row (DoNfcMix: only
+                        // the W line is mixed from the voice's own samples, voice.cpp:908-909)
+                        const uint32_t nd = (L.nfc && (head.flags & kFlagNfc)) ? 1u : L.numDry, ndAll = L.numDry;
                         float tg = 0.0f, cu = 0.0f;
                         if(lane < nd)
                         {
-                            tg = playing ? L.gainTgt[size_t{v} * nd + lane] : 0.0f;       // SilentCoeffs when Stopping
-                            cu = counter ? L.gainCur[size_t{v} * nd + lane] : tg;         // voice.cpp:1094-1112
+                            tg = playing ? L.gainTgt[size_t{v} * ndAll + lane] : 0.0f;    // SilentCoeffs when Stopping
+                            cu = counter ? L.gainCur[size_t{v} * ndAll + lane] : tg;      // voice.cpp:1094-1112
                         }
                         const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
-                        if(lane < nd) { L.gainCur[size_t{v} * nd + lane] = g.newCur; row0.add(g); }
+                        if(lane < nd) { L.gainCur[size_t{v} * ndAll + lane] = g.newCur; row0.add(g); }
                         row0Live = true;
                     }
                 }
@@ -791,7 +834,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             }
             if constexpr (NL > 0)
             {   // the direct-filtered row (voice.cpp:962-963 after an active DoFilters)
-                const uint32_t ls = L.lineStride, spv = L.streamsPerVoice, nd = L.numDry;
+                const bool nfcV = L.nfc && (head.flags & kFlagNfc);
+                const uint32_t ls = L.lineStride, spv = L.streamsPerVoice, nd = nfcV ? 1u : L.numDry;
                 uint32_t *blk1 = L.lineGains + (size_t{v} * spv + 1u) * LineBlockDwords(ls);
                 if(directFilter)
                 {
@@ -800,15 +844,44 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     float tg = 0.0f, cu = 0.0f;
                     if(lane < nd)
                     {
-                        tg = playing ? L.gainTgt[size_t{v} * nd + lane] : 0.0f;
-                        cu = counter ? L.gainCur[size_t{v} * nd + lane] : tg;
+                        tg = playing ? L.gainTgt[size_t{v} * L.numDry + lane] : 0.0f;
+                        cu = counter ? L.gainCur[size_t{v} * L.numDry + lane] : tg;
                     }
                     const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
                     RowLineGain r;
-                    if(lane < nd) { L.gainCur[size_t{v} * nd + lane] = g.newCur; r.add(g); }
+                    if(lane < nd) { L.gainCur[size_t{v} * L.numDry + lane] = g.newCur; r.add(g); }
                     StoreRowBlock(blk1, ls, lane, r, true);
                 }
                 else if(lane == 0) blk1[3u * ls] = 0u;
+                if(L.nfc)
+                {   // DoNfcMix, voice.cpp:911-931: one row per ambisonic order above 0, the voice's
+                    // (direct-filtered) samples through that order's NFC section
+                    const uint32_t rowBase = 2u + L.numSends, ndAll = L.numDry;
+                    uint32_t line = 1;
+                    for(uint32_t o = 1; o <= L.nfcOrders; ++o)
+                    {
+                        uint32_t *blkN = L.lineGains + (size_t{v} * spv + rowBase + o - 1u) * LineBlockDwords(ls);
+                        if(!nfcV) { if(lane == 0) blkN[3u * ls] = 0u; continue; }
+                        const uint32_t cnt = L.chansPerOrder[o];
+                        WaveSync();
+                        if(lane == 0) NfcSerial(L.nfc[v], o, w.in + kHist, w.rd, N);
+                        WaveSync();
+                        float *dst = L.streams + (size_t{v} * spv + rowBase + o - 1u) * kLine;
+                        for(uint32_t k = lane; k < uint32_t(kLine); k += 64) dst[k] = (k < N) ? w.rd[k] : 0.0f;
+                        const bool mine = lane >= line && lane < line + cnt;
+                        float tg = 0.0f, cu = 0.0f;
+                        if(mine)
+                        {
+                            tg = playing ? L.gainTgt[size_t{v} * ndAll + lane] : 0.0f;
+                            cu = counter ? L.gainCur[size_t{v} * ndAll + lane] : tg;
+                        }
+                        const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+                        RowLineGain r;
+                        if(mine) { L.gainCur[size_t{v} * ndAll + lane] = g.newCur; r.add(g); }
+                        StoreRowBlock(blkN, ls, lane, r, true);
+                        line += cnt;
+                    }
+                }
             }
 
             stamp(2);

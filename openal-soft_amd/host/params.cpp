@@ -150,4 +150,67 @@ float SplitterCoeff(float f0norm)
     return cw * -0.5f;
 }
 
+namespace {
+
+// the gain product of a section at angular frequency w and, in out[1..o], the derived
+// coefficients (NfcFilterCreateN / NfcFilterAdjustN, nfc.cpp:56-203; B1..B4 :49-52)
+float NfcSection(int o, float w, float *out)
+{
+    const float r = 0.5f * w;
+    if(o == 1)
+    {
+        const float b00 = 1.0f * r;
+        const float g0 = 1.0f + b00;
+        out[1] = 2.0f * b00 / g0;
+        return g0;
+    }
+    if(o == 2)
+    {
+        const float b10 = 3.0f * r, b11 = 3.0f * (r * r);
+        const float g1 = 1.0f + b10 + b11;
+        out[1] = (2.0f * b10 + 4.0f * b11) / g1;
+        out[2] = 4.0f * b11 / g1;
+        return g1;
+    }
+    if(o == 3)
+    {
+        const float b10 = 3.6778f * r, b11 = 6.4595f * (r * r), b00 = 2.3222f * r;
+        const float g1 = 1.0f + b10 + b11, g0 = 1.0f + b00;
+        out[1] = (2.0f * b10 + 4.0f * b11) / g1;
+        out[2] = 4.0f * b11 / g1;
+        out[3] = 2.0f * b00 / g0;
+        return g1 * g0;
+    }
+    const float b10 = 4.2076f * r, b11 = 11.4877f * (r * r), b00 = 5.7924f * r, b01 = 9.1401f * (r * r);
+    const float g1 = 1.0f + b10 + b11, g0 = 1.0f + b00 + b01;
+    out[1] = (2.0f * b10 + 4.0f * b11) / g1;
+    out[2] = 4.0f * b11 / g1;
+    out[3] = (2.0f * b00 + 4.0f * b01) / g0;
+    out[4] = 4.0f * b01 / g0;
+    return g1 * g0;
+}
+
+} // namespace
+
+void NfcInit(float w1, NfcDesign &d)
+{
+    std::memset(&d, 0, sizeof(d));
+    for(int o = 1; o <= 4; ++o)
+    {
+        const float g = NfcSection(o, w1, d.a[o]);
+        d.baseGain[o] = 1.0f / g;
+        d.a[o][0] = 1.0f;
+        for(int k = 1; k <= o; ++k) d.b[o][k] = d.a[o][k];
+    }
+}
+
+void NfcAdjust(float w0, NfcDesign &d)
+{
+    for(int o = 1; o <= 4; ++o)
+    {
+        const float g = NfcSection(o, w0, d.b[o]);
+        d.a[o][0] = d.baseGain[o] * g;
+    }
+}
+
 } // namespace oalgpu

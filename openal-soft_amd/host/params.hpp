@@ -19,4 +19,10 @@ void ApplyBiquadTarget(oalgpu_biquad *f, const float coeffs[5]);
 // BandSplitter::init, core/filters/splitter.cpp:14-26.
 float SplitterCoeff(float f0norm);
 
+// NfcFilter (core/filters/nfc.cpp:56-219): the sections of order 1..4 after init(w1) and
+// adjust(w0).  a[o] = {a0, a1..ao}, b[o] = {unused, b1..bo}, baseGain[o] = mBaseGain.
+struct NfcDesign { float a[5][5], b[5][5], baseGain[5]; };
+void NfcInit(float w1, NfcDesign &d);
+void NfcAdjust(float w0, NfcDesign &d);
+
 } // namespace oalgpu

@@ -339,6 +339,16 @@ class Scene:
         self.nvoices += 1
         return v
 
+    # near-field control (same interface as tests/oracle_lib.Scene)
+    def set_nfc(self, w1, channels_per_order):
+        lib.oalgpu_context_set_nfc.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint32)]
+        cpo = (C.c_uint32 * 5)(*(list(channels_per_order) + [0] * 5)[:5])
+        check(lib.oalgpu_context_set_nfc(self.h, w1, cpo), "oalgpu_context_set_nfc")
+
+    def set_voice_nfc(self, voice, w0):
+        lib.oalgpu_voice_set_nfc.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+        check(lib.oalgpu_voice_set_nfc(self.h, voice, w0), "oalgpu_voice_set_nfc")
+
     # B-Format sources: one voice per channel over channel views of the interleaved buffer
     # (same interface as tests/oracle_lib.Scene: `voice` = what add_ambi_voice returned)
     def add_ambi_voice(self, buffer, nch, looping, position=0, frac=0, frequency=44100):

@@ -31,3 +31,31 @@ def test_nfc_is_live():
     a = nfc_cases.run(ref, sends=0)
     b = nfc_cases.run(ref, sends=0, nfc_every=10 ** 6)
     assert np.abs(a - b).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", CASES, ids=IDS)
+def test_gpu_matches_oracle(kw):
+    """FAST mode (the resampler and the biquads differ from the reference in the last bits, the
+    NFC sections run in the reference's operation order on their inputs): the multi-voice
+    tolerance of tests/test_gpu_parity.py."""
+    import oalgpu
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    which = "ref" if ol.available("ref") else "port"
+    L = ol.load(which)
+    L.L.oal_set_simd(1)
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    a = nfc_cases.run(api, **kw).astype(np.float64)
+    b = nfc_cases.run(L, **kw).astype(np.float64)
+    err = np.abs(a - b).max()
+    assert err <= 2e-5 * np.abs(b).max() + 1e-7, err
+
+
+@pytest.mark.gpu
+def test_gpu_exact_mode_refuses_nfc():
+    import oalgpu
+    api = oalgpu.Api(oalgpu.MATH_EXACT)
+    sc = api.make_scene(num_dry=4, num_real=0, hrtf=False)
+    with pytest.raises(RuntimeError):
+        sc.set_nfc(0.005, [1, 3])
+    sc.close()
