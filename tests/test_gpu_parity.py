@@ -280,3 +280,77 @@ def test_scene_multi_voice_exact_mode(oracle, exact, synth_mhr, idx):
 @pytest.mark.parametrize("idx", range(len(SCENES)))
 def test_scene_multi_voice_fast_mode(oracle, fast, synth_mhr, idx):
     _cmp_scene(fast, oracle, synth_mhr, dict(SCENES[idx]), idx + 1, single=False)
+
+
+# ---- the staged parameter blocks + the pipelined update (what bench.py drives) -------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("nvoices", [64, 9])
+def test_param_blocks_through_the_pipeline(oracle, fast, synth_mhr, nvoices):
+    """oalgpu_param_block_create/apply + oalgpu_mix_update on an HRTF context: the voice kernel
+    runs as two halves and the next update's block is applied per half on its own stream.  Voices
+    on both sides of the split move every update (records in shuffled order), one more voice is
+    updated through the immediate call in between, and every update's buses and the final voice
+    states must match the oracle driven with the same parameters."""
+    oracle.hrtf_load(synth_mhr)
+    fast.hrtf_load(synth_mhr)
+    rng = np.random.default_rng(41)
+    cc = np.zeros((4, 128, 2), np.float32)
+    cc[:, :64] = rng.uniform(-0.2, 0.2, (4, 64, 2))
+    data = rng.uniform(-1, 1, 8000).astype(np.float32)
+
+    def params(v, k):
+        r = np.random.default_rng(1000 * v + k)
+        return ol.make_voice_params(60211 if v % 3 else 52000, ol.RS_BSINC24,
+                                    hrtf=(np.arcsin(r.uniform(-1, 1)), r.uniform(-np.pi, np.pi), 2.0, 0.0,
+                                          10 ** (r.uniform(-50, -20) / 20)),
+                                    direct_filter=ol.default_filter(active=v % 4 == 1, gain_hf=0.5))
+
+    def build(lib, **kw):
+        sc = lib.make_scene(num_dry=4, num_real=2, hrtf=True, **kw)
+        sc.set_direct_hrtf(cc, [1.0, 0.8, 0.8, 0.8], 400.0 / 48000.0, 64)
+        b = sc.add_buffer(data, ol.FMT_FLOAT, loop_start=0, loop_end=8000)
+        for v in range(nvoices):
+            sc.add_voice(b, looping=True, position=(v * 911) % 7000, frac=(v * 977) % 65536)
+            sc.set_params(v, params(v, 0))
+        return sc
+
+    gsc = build(fast, max_voices=nvoices)
+    osc = build(oracle)
+    moving = [v for v in range(nvoices) if v % 3 != 1]
+    order = np.random.default_rng(5).permutation(len(moving))
+    updates = 6
+    blocks = []
+    for k in range(updates):
+        vs = [moving[i] for i in order]
+        arr = (oalgpu.VoiceParams * len(vs))()
+        for i, v in enumerate(vs):
+            src = params(v, k + 1)
+            C_memmove(arr, i, src)
+        blocks.append(gsc.param_block(vs, arr))
+    got, want = [], []
+    for k in range(updates):
+        gsc.apply_block(blocks[k])
+        if k == 3:      # an immediate update of a voice the block also touched: the later call wins
+            gsc.set_params(moving[0], params(moving[0], 77))
+        gsc.mix(1024, post_process=True)
+        for v in moving:
+            osc.set_params(v, params(v, k + 1))
+        if k == 3:
+            osc.set_params(moving[0], params(moving[0], 77))
+        osc.mix(1024, post_process=True)
+        if k in (0, 2, 3, 5):       # reading back drains the pipeline: not after every update
+            got.append(np.concatenate([gsc.dry().ravel(), gsc.hrtf_accum().ravel()]))
+        want.append(np.concatenate([osc.dry().ravel(), osc.hrtf_accum().ravel()]))
+    want = [want[k] for k in (0, 2, 3, 5)]
+    for a, b in zip(got, want):
+        assert_close(a, b, "pipelined update")
+    for v in range(nvoices):
+        sa, sb = gsc.voice_state(v), osc.voice_state(v)
+        assert (sa.play_state, sa.position, sa.position_frac, sa.hrtf_old_delay[0], sa.hrtf_old_delay[1]) == \
+            (sb.play_state, sb.position, sb.position_frac, sb.hrtf_old_delay[0], sb.hrtf_old_delay[1]), v
+    gsc.close(); osc.close()
+
+
+def C_memmove(arr, i, src):
+    import ctypes as C
+    C.memmove(C.byref(arr, i * C.sizeof(src)), C.byref(src), C.sizeof(src))
