@@ -164,9 +164,20 @@ def main():
     blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(total_steps)]
 
     mixer = None
-    if world > 1:
-        from oalgpu.shard import GpuEngine, ShardedMixer
-        mixer = ShardedMixer(GpuEngine(sc, torch, local_rank, torch.cuda.current_stream()), dist, rank, world)
+    force_sharded = os.environ.get("OALGPU_FORCE_SHARDED") == "1"      # exercise the N>1 path on one GPU
+    if world > 1 or force_sharded:
+        from oalgpu.shard import GpuEngine, OverlappedGpuEngine, ShardedMixer
+        if dist is None:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        if hrtf:
+            engine = OverlappedGpuEngine(sc, torch, local_rank)
+            engine.always_reduce = force_sharded
+        else:
+            engine = GpuEngine(sc, torch, local_rank, torch.cuda.current_stream())
+        mixer = ShardedMixer(engine, dist, rank, world)
 
     def step(k):
         sc.apply_block(blocks[k])
@@ -260,6 +271,8 @@ def main():
             cb = cpu_baseline(synth, args.config, V)
             if cb:
                 out["cpu_baseline"] = cb
+        # anything native code left in C stdio buffers (the RCCL banner) goes out before the line
+        C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -295,6 +295,15 @@ int oalgpu_bus_device_ptr(oalgpu_context *ctx, void **ptr, size_t *nfloats, void
  * post_process runs MixDirectHrtf on the summed buses. */
 int oalgpu_mix_voices(oalgpu_context *ctx, uint32_t samples_to_do);
 int oalgpu_post_process(oalgpu_context *ctx, uint32_t samples_to_do);
+/* The same split on the context's own two streams (FAST HRTF contexts that were not given a
+ * caller-owned stream): mix_voices_overlapped launches the voice kernel on the main stream and
+ * the partial-bus reduction on the context's post stream, then returns; the caller enqueues its
+ * collective on the post stream (oalgpu_post_stream), and post_process_overlapped follows it
+ * there.  The next update's parameter and voice kernels run beside the collective and the
+ * post-process of this one (double-buffered partial buses). */
+int   oalgpu_mix_voices_overlapped(oalgpu_context *ctx, uint32_t samples_to_do);
+void *oalgpu_post_stream(oalgpu_context *ctx);
+int   oalgpu_post_process_overlapped(oalgpu_context *ctx, uint32_t samples_to_do, int run_post_process);
 /* Whether this context's voice kernel continues the HRTF accumulator tail carried over from
  * the previous update (HrtfAccumData, core/device.h:288).  Default on.  With the buses summed
  * across ranks exactly one rank -- the one whose post-process owns the tail -- keeps it on. */

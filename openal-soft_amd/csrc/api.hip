@@ -903,10 +903,18 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
         if(post_process) return oalgpu_post_process(c, samples_to_do);
         return OALGPU_OK;
     }
+    if(int rc = oalgpu_mix_voices_overlapped(c, samples_to_do)) return rc;
+    return oalgpu_post_process_overlapped(c, samples_to_do, post_process);
+}
+
+int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
+{
+    if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
+    if(!(c->useWave && c->L.hrtf && c->ownStream))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_mix_voices_overlapped: needs a FAST HRTF context on its own streams");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
-    if(post_process && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
     const uint32_t p = c->parity;
     DeviceLayout L = c->L;
     L.partHrtf = c->partHrtfBuf[p];
@@ -918,12 +926,27 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
     HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do));
     if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
     HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
-    // post stream: reduction (adds the carried HRTF accumulator tail) and post-process; they
-    // run beside the next update's parameter and voice kernels
+    // post stream: reduction (adds the carried HRTF accumulator tail); whatever follows on that
+    // stream -- a collective, the effects, the post-process -- runs beside the next update's
+    // parameter and voice kernels
     HIP_TRY(hipStreamWaitEvent(c->postStream, c->evVoiceDone[p], 0));
     LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->evReduceDone[p], c->postStream));
+    c->parity = p ^ 1u;
+    return OALGPU_OK;
+}
+
+void *oalgpu_post_stream(oalgpu_context *c) { return c ? static_cast<void*>(c->postStream) : nullptr; }
+
+int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, int post_process)
+{
+    if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
+    if(!(c->useWave && c->L.hrtf && c->ownStream))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_post_process_overlapped: needs a FAST HRTF context on its own streams");
+    if(post_process && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    const DeviceLayout &L = c->L;
     if(post_process) { if(int rc = RunEffects(c, c->postStream, samples_to_do)) return rc; }
     if(post_process && L.hrtf)
     {
@@ -936,7 +959,6 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->postStream)); c->timed = true; }
     HIP_TRY(hipEventRecord(c->evPostDone, c->postStream));
     c->postPending = true;
-    c->parity = p ^ 1u;
     return OALGPU_OK;
 }
 

@@ -401,6 +401,19 @@ class Scene:
     def post_process(self, samples_to_do=BUFFER_LINE):
         check(lib.oalgpu_post_process(self.h, samples_to_do), "oalgpu_post_process")
 
+    def mix_voices_overlapped(self, samples_to_do=BUFFER_LINE):
+        check(lib.oalgpu_mix_voices_overlapped(self.h, samples_to_do), "oalgpu_mix_voices_overlapped")
+
+    def post_stream(self):
+        lib.oalgpu_post_stream.restype = C.c_void_p
+        lib.oalgpu_post_stream.argtypes = [C.c_void_p]
+        return lib.oalgpu_post_stream(self.h)
+
+    def post_process_overlapped(self, samples_to_do=BUFFER_LINE, run_post_process=True):
+        lib.oalgpu_post_process_overlapped.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        check(lib.oalgpu_post_process_overlapped(self.h, samples_to_do, 1 if run_post_process else 0),
+              "oalgpu_post_process_overlapped")
+
     def set_carry_accum(self, enable):
         check(lib.oalgpu_set_carry_accum(self.h, 1 if enable else 0))
 

@@ -7,9 +7,10 @@ post-process (alc/alu.cpp:2209-2257, :289-298) on the summed buses.
 
 The orchestration is backend-agnostic: ``engine`` is anything with
     set_carry(bool) / mix_voices(n) / bus_tensor() -> torch tensor aliasing the bus block /
-    post_process(n)
-bench.py passes the HIP context (GpuEngine, nccl); tests/test_multi_rank.py passes the CPU oracle
-(gloo, world_size 2) to check the scheme itself against an unsharded scene."""
+    collective() -> context manager the reduce is issued under / post_process(n, run)
+bench.py passes the HIP context (OverlappedGpuEngine, nccl); tests/test_multi_rank.py passes the
+CPU oracle (gloo, world_size 2) to check the scheme itself against an unsharded scene."""
+import contextlib
 
 
 def shard_range(total_voices, rank, world):
@@ -27,10 +28,10 @@ class ShardedMixer:
     def update(self, samples_to_do):
         e = self.engine
         e.mix_voices(samples_to_do)
-        if self.world > 1:
-            self.dist.reduce(e.bus_tensor(), dst=0, op=self.dist.ReduceOp.SUM)
-        if self.rank == 0:
-            e.post_process(samples_to_do)
+        if self.dist is not None and (self.world > 1 or getattr(e, "always_reduce", False)):
+            with e.collective():
+                self.dist.reduce(e.bus_tensor(), dst=0, op=self.dist.ReduceOp.SUM)
+        e.post_process(samples_to_do, self.rank == 0)
 
 
 class GpuEngine:
@@ -55,5 +56,42 @@ class GpuEngine:
     def bus_tensor(self):
         return self._bus
 
-    def post_process(self, n):
-        self.sc.post_process(n)
+    def collective(self):
+        return contextlib.nullcontext()
+
+    def post_process(self, n, run):
+        if run:
+            self.sc.post_process(n)
+
+
+class OverlappedGpuEngine:
+    """The HIP context on its OWN two streams (FAST HRTF contexts): the voice kernel of update
+    k+1 runs on the main stream while the partial-bus reduction, the RCCL reduce and the
+    post-process of update k run on the context's post stream, which torch sees as an
+    ExternalStream -- the collective is issued with that stream current, so torch.distributed
+    orders it between the reduction before and the post-process after it."""
+
+    def __init__(self, scene, torch, device_index):
+        self.sc = scene
+        self.torch = torch
+        ptr, nfloats, _ = scene.bus_device_ptr()
+
+        class _Bus:
+            __cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        self._bus = torch.as_tensor(_Bus(), device=f"cuda:{device_index}")
+        self._post = torch.cuda.ExternalStream(scene.post_stream(), device=f"cuda:{device_index}")
+
+    def set_carry(self, on):
+        self.sc.set_carry_accum(on)
+
+    def mix_voices(self, n):
+        self.sc.mix_voices_overlapped(n)
+
+    def bus_tensor(self):
+        return self._bus
+
+    def collective(self):
+        return self.torch.cuda.stream(self._post)
+
+    def post_process(self, n, run):
+        self.sc.post_process_overlapped(n, run)

@@ -56,3 +56,17 @@ def test_sharded_scene_matches_unsharded(synth_mhr, world):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out}"
     assert "update 3" in outs[0]
+
+
+@pytest.mark.gpu
+def test_overlapped_engine_single_rank_nccl(synth_mhr):
+    """The GPU side of the sharded update on its real streams: OverlappedGpuEngine (voice kernel on
+    the main stream; partial-bus reduction, a torch.distributed reduce over a ONE-rank RCCL group
+    issued on the context's post stream, and the post-process behind it) against the oracle, over
+    several back-to-back updates without draining in between.  In its own process: torch has to
+    initialise its HIP runtime before liboalgpu.so loads the system one."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OAL_TEST_MHR=synth_mhr)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "overlapped_worker.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert "overlapped ok" in p.stdout
