@@ -636,8 +636,13 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     WL &w = sm.w[wave];
     const uint32_t N = samplesToDo;
 
-    const uint32_t vBegin = (group * kWWaves + wave) * vpw;
-    const uint32_t vEnd = (vBegin + vpw < L.numVoices) ? vBegin + vpw : L.numVoices;
+    // The workgroup owns kWWaves*vpw consecutive voices; a wavefront takes every SECOND one of its
+    // half of them (wave 0: v, v+2, ..; wave 1: v+1, v+3, ..).  Voices that cost more -- an active
+    // filter, a replaced HRIR -- tend to come in regular patterns (every n-th source of a scene);
+    // with consecutive voices per wavefront a period-4 pattern puts both expensive voices of a
+    // group of four on the same wavefront, and the launch lasts as long as its slowest wavefront.
+    const uint32_t vBegin = group * kWWaves * vpw + (wave & 1u) + 2u * (wave >> 1) * vpw;
+    const uint32_t vEnd = (vBegin + 2u * vpw < L.numVoices) ? vBegin + 2u * vpw : L.numVoices;   // v = vBegin + 2k < vEnd
 
     // Voices are processed in passes; pass 0 only requests the first voice's source window and
     // stages the workgroup's resampler rows.  The request for the NEXT voice's window sits at one
@@ -660,11 +665,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 #pragma unroll
     for(int q = 0; q < WL::kQ; ++q) accO[q] = f2{0.0f, 0.0f};
 
-    for(uint32_t pass = 0; pass == 0 || vBegin + pass - 1u < vEnd; ++pass)
+    for(uint32_t pass = 0; pass == 0 || vBegin + 2u * (pass - 1u) < vEnd; ++pass)
     {
         const bool first = pass == 0;
-        const uint32_t v = vBegin + pass - 1u;              // meaningless in pass 0
-        const uint32_t vn = v + 1u;                         // the voice to request (= vBegin in pass 0)
+        const uint32_t v = vBegin + 2u * (pass - 1u);       // meaningless in pass 0
+        const uint32_t vn = v + 2u;                         // the voice to request (= vBegin in pass 0)
         const bool haveNext = vn < vEnd;
 
         // ---------------- part 1: this voice up to its FIR inputs ----------------
