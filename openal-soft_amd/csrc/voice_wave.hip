@@ -628,7 +628,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     using WL = WaveLds<R, TAPS>;
     __shared__ WgLds<R, TAPS> sm;
     const uint32_t t = threadIdx.x;
-    const uint32_t lane = t & 63u;
+    const uint32_t lane0 = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t group = blockIdx.x;
     const uint32_t vpw = L.waveVoices;
@@ -654,6 +654,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     bool loopingN = false;
     float preN[kPre];
     float prevN = 0.0f;
+    // ... and its Hrtf.History, direct filter state and (replaced filters) Hrtf.Old coefficients,
+    // requested with the window; the next pass parks them in LDS before its resampler runs
+    float histN = 0.0f, fstN = 0.0f;
+    f2 oldN[TAPS / 64];
+#pragma unroll
+    for(int q = 0; q < TAPS / 64; ++q) oldN[q] = f2{0.0f, 0.0f};
 #pragma unroll
     for(int i = 0; i < kPre; ++i) preN[i] = 0.0f;
     if(vBegin < vEnd) headN = LoadHeadScalar(L.ctl + vBegin);
@@ -667,6 +673,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 
     for(uint32_t pass = 0; pass == 0 || vBegin + 2u * (pass - 1u) < vEnd; ++pass)
     {
+        // The lane index is re-derived per pass behind an opaque move: addresses built from it are
+        // then a few VALU per voice instead of loop invariants that the allocator, already at the
+        // 256-register limit of 2 waves/SIMD, would keep in scratch.
+        uint32_t lane = lane0;
+        asm volatile("" : "+v"(lane));
         const bool first = pass == 0;
         const uint32_t v = vBegin + 2u * (pass - 1u);       // meaningless in pass 0
         const uint32_t vn = v + 2u;                         // the voice to request (= vBegin in pass 0)
@@ -714,22 +725,23 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 
             // per-voice state, requested now and first used after the resampler
             if constexpr (NL == 0) tail = LoadTailScalar(L.ctl + v);
-            const float histv = NL == 0 ? L.hist[size_t{v} * kHist + lane] : 0.0f;
-            const float fstv = (lane < 32u) ? reinterpret_cast<const float*>(L.dfilt + size_t{v} * 2)[lane] : 0.0f;
-            f2 oldv[TAPS / 64];
-#pragma unroll
-            for(int q = 0; q < TAPS / 64; ++q) oldv[q] = f2{0.0f, 0.0f};
-            if(NL == 0 && dirty)
+            // requested one pass ago; none of these LDS words is touched before its consumer below
+            const float fstv = fstN;
+            if constexpr (NL == 0)
             {
-                const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{v} * irStride * 2);
+                w.in[lane] = histN;
+                if(dirty)
+                {
 #pragma unroll
-                for(int q = 0; q < TAPS / 64; ++q)
-                    if(lane + 64u * q < irStride) oldv[q] = oc[lane + 64u * q];
+                    for(int q = 0; q < TAPS / 64; ++q) w.cold[64 + lane + 64 * q] = oldN[q];
+                }
             }
+            if constexpr (!SENDS) { if(lane < 32u) w.fst[lane] = fstv; }
             const SrcPlan plan = planN;
             const float prevLoaded = plan.prefetch ? prevN : ((lane < kMaxPad) ? L.prev[size_t{v} * kMaxPad + lane] : 0.0f);
 
             LoadResampledWave(sm, w, L, v, lane, head, playing, N, N, bufferItem, looping, plan, preN, prevLoaded);
+            asm volatile("" : "+v"(lane));      // addresses used from here on are rebuilt, not carried across the resampler
             if(head.flags & kFlagAmbiScale)
             {   // VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
                 const AmbiScaleState a = L.ambi[v];
@@ -832,7 +844,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 
             // ---- DoFilters, direct path (voice.cpp:255-267): in place on w.in[kHist..]
             {
-                if(lane < 32u) w.fst[lane] = fstv;
+                if constexpr (SENDS) { if(lane < 32u) w.fst[lane] = fstv; }
                 WaveSync();
                 WaveDoFilters(w.fst, &L.dfilt[size_t{v} * 2], directFilter, w.in + kHist, N, lane);
                 WaveSync();
@@ -893,7 +905,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             if constexpr (NL == 0)
             {
             // ---- DoHrtfMix, voice.cpp:827-902
-            w.in[lane] = histv;
             WaveSync();
             if(playing) L.hist[size_t{v} * kHist + lane] = w.in[N + lane];
 
@@ -962,8 +973,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     xo = f2{w.in[kHist - odL + lane] * g, w.in[kHist - odR + lane] * g};
                 }
                 w.xo[lane] = xo;
-#pragma unroll
-                for(int q = 0; q < TAPS / 64; ++q) w.cold[64 + lane + 64 * q] = oldv[q];
             }
             WaveSync();
             }
@@ -971,6 +980,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
 
         // ---------------- the next voice's source window leaves HBM now ----------------
+        // (redefined on every path, so that nothing of this block stays live across the resampler)
+        prevN = 0.0f; histN = 0.0f; fstN = 0.0f;
+#pragma unroll
+        for(int q = 0; q < TAPS / 64; ++q) oldN[q] = f2{0.0f, 0.0f};
         if(haveNext)
         {   // its head is in headN
             if(!planned)
@@ -989,6 +1002,16 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             {
                 prevN = (lane < kMaxPad) ? L.prev[size_t{vn} * kMaxPad + lane] : 0.0f;
                 GatherStatic(preN, planN.bsrc, bufN, loopingN, uint32_t(headN.position), lane);
+            }
+            fstN = (lane < 32u) ? reinterpret_cast<const float*>(L.dfilt + size_t{vn} * 2)[lane] : 0.0f;
+            if constexpr (NL == 0)
+            {
+                histN = L.hist[size_t{vn} * kHist + lane];
+                const bool dirtyN = (headN.flags & kFlagHrtfDirty) != 0;
+                const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{vn} * irStride * 2);
+#pragma unroll
+                for(int q = 0; q < TAPS / 64; ++q)
+                    oldN[q] = (dirtyN && lane + 64u * q < irStride) ? oc[lane + 64u * q] : f2{0.0f, 0.0f};
             }
         }
 
@@ -1130,13 +1153,13 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         f2 *dump = w.x2;                     // [frame] = (L, R), frames < 64R
         WaveSync();
 #pragma unroll
-        for(int r = 0; r < R; ++r) dump[R * lane + r] = acc[r];
+        for(int r = 0; r < R; ++r) dump[R * lane0 + r] = acc[r];
         WaveSync();
 #pragma unroll
         for(int q = 0; q < WL::kQ; ++q)
         {
-            const f2 cur = dump[lane + 64 * q];
-            dump[lane + 64 * q] = f2{cur.x + accO[q].x, cur.y + accO[q].y};
+            const f2 cur = dump[lane0 + 64 * q];
+            dump[lane0 + 64 * q] = f2{cur.x + accO[q].x, cur.y + accO[q].y};
         }
         __syncthreads();
         f2 *ph = reinterpret_cast<f2*>(L.partHrtf) + size_t{group} * (kLine + kHrirLen);
