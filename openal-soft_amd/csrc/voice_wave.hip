@@ -121,23 +121,40 @@ struct WgLds {
 // requests elements l, l+64, ... of the `count` source samples starting at buffer position
 // dataPos (loop wrap; past-the-end holds the last sample).  The loads are issued here and only
 // waited for when the values are stored to LDS, one voice later.
+// The loads are GLOBAL loads (the buffer's data pointer comes out of a BufferItem in memory, so
+// the compiler would otherwise issue FLAT loads, which also count on lgkmcnt: every LDS wait of
+// the FIR that runs while the window is in flight would then wait for the window), and they
+// deliver the raw element: the int16 -> float conversion happens when the window is stored to
+// LDS (GatherDecode), so that no load has to be waited for here.
+template<int FMT>
+__device__ __forceinline__ float LoadRawGlobal(const void *data, size_t idx)
+{
+    if constexpr (FMT == OALGPU_FMT_FLOAT)
+        return reinterpret_cast<const __attribute__((address_space(1))) float*>(
+            (const __attribute__((address_space(1))) void*)data)[idx];
+    else
+        return __builtin_bit_cast(float, int32_t(reinterpret_cast<const __attribute__((address_space(1))) int16_t*>(
+            (const __attribute__((address_space(1))) void*)data)[idx]));
+}
+
+__device__ __forceinline__ float GatherDecode(float raw, bool isShort)
+{ return isShort ? float(__builtin_bit_cast(int32_t, raw)) * (1.0f / 32768.0f) : raw; }
+
 template<int FMT>
 __device__ __forceinline__ void GatherStaticT(float (&pre)[kPre], uint32_t count, const BufferItem &b, bool looping,
     uint32_t dataPos, uint32_t lane)
 {
     const uint32_t fs = b.frameStep;
     if(!looping)
-    {
+    {   // past the end: the last sample (index clamp, so that every element is one unconditional load)
         const bool any = b.sampleLen > dataPos;
-        const uint32_t avail = any ? b.sampleLen - dataPos : 0u;
-        const float last = any ? LoadSample<FMT>(b.data, size_t{b.sampleLen - 1u} * fs) : 0.0f;
+        const uint32_t lastIdx = b.sampleLen - 1u;
 #pragma unroll
         for(int i = 0; i < kPre; ++i)
         {
             const uint32_t k = lane + 64u * uint32_t(i);
-            float x = 0.0f;
-            if(k < count) x = (k < avail) ? LoadSample<FMT>(b.data, size_t{dataPos + k} * fs) : last;
-            pre[i] = x;
+            const uint32_t idx = (dataPos + k < lastIdx) ? dataPos + k : lastIdx;
+            pre[i] = (k < count && any) ? LoadRawGlobal<FMT>(b.data, size_t{idx} * fs) : 0.0f;
         }
     }
     else
@@ -149,9 +166,40 @@ __device__ __forceinline__ void GatherStaticT(float (&pre)[kPre], uint32_t count
         {
             const uint32_t k = lane + 64u * uint32_t(i);
             const uint32_t idx = (k < first) ? dataPos + k : ls + (k - first);
-            pre[i] = (k < count) ? LoadSample<FMT>(b.data, size_t{idx} * fs) : 0.0f;
+            pre[i] = (k < count) ? LoadRawGlobal<FMT>(b.data, size_t{idx} * fs) : 0.0f;
         }
     }
+}
+
+// The common shape -- a mono buffer, the window and the kPre*64 elements the gather touches all
+// inside the buffer and before the loop end: one uniform base, lane offset, immediate offsets.
+// (Elements past `count` are loaded and never used.)  ~20 instructions instead of ~20 per element;
+// the kernel is issue-bound, so this is worth ~3500 cycles per requested window.
+template<int FMT>
+__device__ __forceinline__ void GatherLinearT(float (&pre)[kPre], const BufferItem &b, uint32_t dataPos, uint32_t lane)
+{
+    if constexpr (FMT == OALGPU_FMT_FLOAT)
+    {
+        const __attribute__((address_space(1))) float *p =
+            reinterpret_cast<const __attribute__((address_space(1))) float*>((const __attribute__((address_space(1))) void*)b.data) + dataPos;
+        const __attribute__((address_space(1))) float *pl = p + lane;
+#pragma unroll
+        for(int i = 0; i < kPre; ++i) pre[i] = pl[64 * i];
+    }
+    else
+    {
+        const __attribute__((address_space(1))) int16_t *p =
+            reinterpret_cast<const __attribute__((address_space(1))) int16_t*>((const __attribute__((address_space(1))) void*)b.data) + dataPos;
+        const __attribute__((address_space(1))) int16_t *pl = p + lane;
+#pragma unroll
+        for(int i = 0; i < kPre; ++i) pre[i] = __builtin_bit_cast(float, int32_t(pl[64 * i]));
+    }
+}
+
+__device__ __forceinline__ bool GatherIsLinear(uint32_t count, const BufferItem &b, bool looping, uint32_t dataPos)
+{
+    return b.frameStep == 1u && uint64_t{dataPos} + uint32_t(kPre * 64) <= b.sampleLen
+        && (!looping || uint64_t{dataPos} + count <= b.loopEnd);
 }
 
 // The register gather covers the formats and loop shapes that matter for throughput; anything
@@ -166,7 +214,12 @@ __device__ __forceinline__ bool GatherCovers(uint32_t count, const BufferItem &b
 __device__ __forceinline__ void GatherStatic(float (&pre)[kPre], uint32_t count, const BufferItem &b, bool looping,
     uint32_t dataPos, uint32_t lane)
 {
-    if(b.fmt == OALGPU_FMT_FLOAT) GatherStaticT<OALGPU_FMT_FLOAT>(pre, count, b, looping, dataPos, lane);
+    if(GatherIsLinear(count, b, looping, dataPos))
+    {
+        if(b.fmt == OALGPU_FMT_FLOAT) GatherLinearT<OALGPU_FMT_FLOAT>(pre, b, dataPos, lane);
+        else GatherLinearT<OALGPU_FMT_SHORT>(pre, b, dataPos, lane);
+    }
+    else if(b.fmt == OALGPU_FMT_FLOAT) GatherStaticT<OALGPU_FMT_FLOAT>(pre, count, b, looping, dataPos, lane);
     else GatherStaticT<OALGPU_FMT_SHORT>(pre, count, b, looping, dataPos, lane);
 }
 
@@ -294,7 +347,7 @@ __device__ __forceinline__ void ResampleRunStagedM(const WgLds<R, TAPS> &sm, con
 template<int R, int TAPS>
 __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R, TAPS> &w, const DeviceLayout &L,
     uint32_t v, uint32_t lane, const VoiceHead &h, bool playing, uint32_t samplesToLoad, uint32_t samplesToMix,
-    int32_t bufferItem, bool looping, const SrcPlan &plan, const float (&pre)[kPre], float prevv)
+    int32_t bufferItem, bool looping, const SrcPlan &plan)
 {
     float *rdata = w.rd;
     float *srcBuffer = rdata + kMaxEdge;
@@ -303,7 +356,9 @@ __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R,
     const uint32_t rsM = h.rsM, rsL = h.rsL, increment = h.step;
     int32_t intPos = h.position;
     uint32_t fracPos = h.positionFrac;
-    if(lane < kMaxPad) rdata[lane] = prevv;
+    // plan.prefetch: mPrevSamples and the first chunk's window (plan.bsrc samples) were parked in
+    // rdata / srcBuffer by the previous pass (ParkNextVoice)
+    if(!plan.prefetch && lane < kMaxPad) rdata[lane] = L.prev[size_t{v} * kMaxPad + lane];
     const float *filter = L.tables + h.rsFilterOffset;
     const uint32_t tableKey = h.rsFilterOffset * 8u + uint32_t(kind);
     const bool staged = (kind == 2 || kind == 3) && sm.tabKey == tableKey;
@@ -361,15 +416,7 @@ __device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R,
             WaveSync();
             for(uint32_t k = best + 1 + lane; k < tofill; k += 64) srcBuffer[k] = hold;
         }
-        else if(firstPass && plan.prefetch)
-        {
-#pragma unroll
-            for(int i = 0; i < kPre; ++i)
-            {
-                const uint32_t k = lane + 64u * uint32_t(i);
-                if(k < bsrc) srcBuffer[k] = pre[i];
-            }
-        }
+        else if(firstPass && plan.prefetch) {}      // already in srcBuffer (bsrc == plan.bsrc)
         else
         {
             const uint32_t upos = intPos < 0 ? 0u : uint32_t(intPos);
@@ -649,20 +696,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     // point of the pass -- after this voice's FIR inputs are built, before its FIR runs -- so the
     // HBM latency of every window but the first is covered by ~1100 packed FMAs.
     VoiceHead headN{};
+    VoiceTail tailN{};
     SrcPlan planN{false, 0u, 0u};
     BufferItem bufN{};
     bool loopingN = false;
-    float preN[kPre];
-    float prevN = 0.0f;
-    // ... and its Hrtf.History, direct filter state and (replaced filters) Hrtf.Old coefficients,
-    // requested with the window; the next pass parks them in LDS before its resampler runs
-    float histN = 0.0f, fstN = 0.0f;
-    f2 oldN[TAPS / 64];
-#pragma unroll
-    for(int q = 0; q < TAPS / 64; ++q) oldN[q] = f2{0.0f, 0.0f};
-#pragma unroll
-    for(int i = 0; i < kPre; ++i) preN[i] = 0.0f;
-    if(vBegin < vEnd) headN = LoadHeadScalar(L.ctl + vBegin);
+    float fstC = 0.0f;                      // SENDS: the direct filter's state words, carried to the next pass
+    if(vBegin < vEnd) { headN = LoadHeadScalar(L.ctl + vBegin); if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + vBegin); }
 
     f2 acc[R];
 #pragma unroll
@@ -696,10 +735,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         {
             // head, plan, buffer and the gathered window were requested one pass ago
             head = headN;
+            tail = tailN;
             buf = bufN;
             looping = loopingN;
-            // next voice's head: in flight while this voice resamples
-            if(haveNext) headN = LoadHeadScalar(L.ctl + vn);
+            // next voice's head (and the HRTF delays/gains behind it): in flight while this voice resamples
+            if(haveNext) { headN = LoadHeadScalar(L.ctl + vn); if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + vn); }
 
             const int vstate = head.playState;
             const bool mixes = vstate == OALGPU_VOICE_PLAYING || vstate == OALGPU_VOICE_STOPPING;
@@ -723,24 +763,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             bufferItem = head.curBuffer;
             dirty = (head.flags & kFlagHrtfDirty) != 0;
 
-            // per-voice state, requested now and first used after the resampler
-            if constexpr (NL == 0) tail = LoadTailScalar(L.ctl + v);
-            // requested one pass ago; none of these LDS words is touched before its consumer below
-            const float fstv = fstN;
-            if constexpr (NL == 0)
-            {
-                w.in[lane] = histN;
-                if(dirty)
-                {
-#pragma unroll
-                    for(int q = 0; q < TAPS / 64; ++q) w.cold[64 + lane + 64 * q] = oldN[q];
-                }
-            }
-            if constexpr (!SENDS) { if(lane < 32u) w.fst[lane] = fstv; }
+            // Hrtf.History (w.in[0..63]), the direct filter state (w.fst; SENDS: fstC), a replaced
+            // filter's old coefficients (w.cold) and the source window were parked by the last pass
+            const float fstv = fstC;
             const SrcPlan plan = planN;
-            const float prevLoaded = plan.prefetch ? prevN : ((lane < kMaxPad) ? L.prev[size_t{v} * kMaxPad + lane] : 0.0f);
-
-            LoadResampledWave(sm, w, L, v, lane, head, playing, N, N, bufferItem, looping, plan, preN, prevLoaded);
+            LoadResampledWave(sm, w, L, v, lane, head, playing, N, N, bufferItem, looping, plan);
             asm volatile("" : "+v"(lane));      // addresses used from here on are rebuilt, not carried across the resampler
             if(head.flags & kFlagAmbiScale)
             {   // VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
@@ -980,10 +1007,15 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
 
         // ---------------- the next voice's source window leaves HBM now ----------------
-        // (redefined on every path, so that nothing of this block stays live across the resampler)
-        prevN = 0.0f; histN = 0.0f; fstN = 0.0f;
+        // These registers live from here to the end of the pass, where they are parked in LDS.
+        float preN[kPre];
+        float prevN = 0.0f, histN = 0.0f, fstN = 0.0f;
+        f2 oldN[TAPS / 64];
+        bool dirtyN = false;
 #pragma unroll
         for(int q = 0; q < TAPS / 64; ++q) oldN[q] = f2{0.0f, 0.0f};
+#pragma unroll
+        for(int i = 0; i < kPre; ++i) preN[i] = 0.0f;
         if(haveNext)
         {   // its head is in headN
             if(!planned)
@@ -998,16 +1030,18 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 loopingN = headN.loopBuffer >= 0 && !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd);
                 planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
             }
+            // (the window first: each gather variant starts by waiting for older loads into its
+            // registers -- the variants share them -- and must not find a fresh one in front of it)
             if(planN.prefetch)
             {
-                prevN = (lane < kMaxPad) ? L.prev[size_t{vn} * kMaxPad + lane] : 0.0f;
                 GatherStatic(preN, planN.bsrc, bufN, loopingN, uint32_t(headN.position), lane);
+                prevN = (lane < kMaxPad) ? L.prev[size_t{vn} * kMaxPad + lane] : 0.0f;
             }
             fstN = (lane < 32u) ? reinterpret_cast<const float*>(L.dfilt + size_t{vn} * 2)[lane] : 0.0f;
             if constexpr (NL == 0)
             {
                 histN = L.hist[size_t{vn} * kHist + lane];
-                const bool dirtyN = (headN.flags & kFlagHrtfDirty) != 0;
+                dirtyN = (headN.flags & kFlagHrtfDirty) != 0;
                 const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{vn} * irStride * 2);
 #pragma unroll
                 for(int q = 0; q < TAPS / 64; ++q)
@@ -1089,7 +1123,43 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     }
                 }
             }
+        }
 
+        // ---------------- the next voice's state is parked in LDS ----------------
+        // After the FIR every LDS word the next pass starts from is free (rd shares x2; in[0..63],
+        // fst and cold were last read above), and what was requested before the FIR has landed.
+        // Parked here, ahead of this voice's write-back stores, no wait of the next pass has to
+        // sit behind those stores, and the ~21 registers of the request are dead outside the FIR.
+        if(haveNext)
+        {
+            WaveSync();
+            if(planN.prefetch)
+            {
+                const bool isShort = bufN.fmt == OALGPU_FMT_SHORT;
+                if(lane < kMaxPad) w.rd[lane] = prevN;
+#pragma unroll
+                for(int i = 0; i < kPre; ++i)
+                {
+                    // all kPre*64 words (rd has room; the resampler never reads past bsrc + padding)
+                    w.rd[kMaxEdge + lane + 64u * uint32_t(i)] = GatherDecode(preN[i], isShort);
+                }
+            }
+            if constexpr (NL == 0)
+            {
+                w.in[lane] = histN;
+                if(dirtyN)
+                {
+#pragma unroll
+                    for(int q = 0; q < TAPS / 64; ++q) w.cold[64 + lane + 64 * q] = oldN[q];
+                }
+            }
+            if constexpr (SENDS) fstC = fstN;
+            else if(lane < 32u) w.fst[lane] = fstN;
+            WaveSync();
+        }
+
+        if(active)
+        {
             stamp(5);
             // voice.cpp:1094-1101 / :869-873,900: Old <- Target, Old.Gain <- reached gain
             if(NL == 0 && dirty && (counter == 0 || fademix))
