@@ -49,7 +49,8 @@ struct alignas(16) VoiceCtl {
     float hrtfOldGain;
     uint32_t hrtfTgtDelay[2];
     float hrtfTgtGain;
-    uint32_t pad[8];
+    BufferItem buf;                 // copy of buffers[curBuffer] (descriptors are immutable once registered):
+                                    // the voice kernel gets head, HRTF delays and buffer in ONE round trip
 };
 static_assert(sizeof(VoiceCtl) == 128, "VoiceCtl is one 128-byte line");
 

@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(64) InitVoicesKernel(DeviceLayout L, const Voi
         c.loopBuffer = r.looping ? r.buffer : -1;
         c.flags = L.hrtf ? kFlagHasHrtf : 0u;
         for(int i = 0; i < 6; ++i) c.sendSlot[i] = -1;
+        if(r.buffer >= 0) c.buf = L.buffers[r.buffer];
         L.ctl[v] = c;
         L.dfilt[size_t{v} * 2 + 0].f = def;
         L.dfilt[size_t{v} * 2 + 1].f = def;

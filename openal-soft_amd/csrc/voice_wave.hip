@@ -81,6 +81,16 @@ __device__ __forceinline__ VoiceTail LoadTailScalar(const VoiceCtl *p)
     return t;
 }
 
+// VoiceCtl::buf, bytes 96..127 of the voice's line
+__device__ __forceinline__ BufferItem LoadCtlBufferScalar(const VoiceCtl *p)
+{
+    static_assert(offsetof(VoiceCtl, buf) == 96 && sizeof(BufferItem) == 32, "VoiceCtl::buf layout");
+    union { BufferItem b; u4 q[2]; } u;
+    cu4 *src = (cu4*)(uintptr_t)p;
+    u.q[0] = src[6]; u.q[1] = src[7];
+    return u.b;
+}
+
 __device__ __forceinline__ BufferItem LoadBufferScalar(const BufferItem *p)
 {
     static_assert(sizeof(BufferItem) == 32, "BufferItem is two 16-byte words");
@@ -690,6 +700,21 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     // group of four on the same wavefront, and the launch lasts as long as its slowest wavefront.
     const uint32_t vBegin = group * kWWaves * vpw + (wave & 1u) + 2u * (wave >> 1) * vpw;
     const uint32_t vEnd = (vBegin + 2u * vpw < L.numVoices) ? vBegin + 2u * vpw : L.numVoices;   // v = vBegin + 2k < vEnd
+    const uint32_t vCount = vBegin < vEnd ? (vEnd - vBegin + 1u) / 2u : 0u;
+    // Two workgroups share a CU, and the launch fills the machine exactly once: workgroup g and
+    // g + gridDim/2 land on the same CU (the dispatcher deals the first half one per CU, then the
+    // second half).  Run in the same order, their wavefronts sit in the same phase at the same
+    // time -- all eight in the LDS-bound resampler, then all eight in the VALU-bound FIR.  The
+    // second half therefore takes its voices in reverse order: voices differ in cost, so the two
+    // workgroups of a CU drift out of phase within the first voice and stay complementary.
+    auto waveStamp = [&](int slot)
+    {
+        if(L.phaseTimes && lane0 == 0)
+            L.phaseTimes[size_t{L.numVoices} * 8 + size_t{group * kWWaves + wave} * 4 + slot] = __builtin_readcyclecounter();
+    };
+    waveStamp(0);
+    const bool rev = group >= (gridDim.x + 1u) / 2u;
+    auto voiceAt = [&](uint32_t j) { return vBegin + 2u * (rev ? vCount - 1u - j : j); };
 
     // Voices are processed in passes; pass 0 only requests the first voice's source window and
     // stages the workgroup's resampler rows.  The request for the NEXT voice's window sits at one
@@ -701,7 +726,16 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     BufferItem bufN{};
     bool loopingN = false;
     float fstC = 0.0f;                      // SENDS: the direct filter's state words, carried to the next pass
-    if(vBegin < vEnd) { headN = LoadHeadScalar(L.ctl + vBegin); if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + vBegin); }
+    if(vCount)
+    {
+        headN = LoadHeadScalar(L.ctl + voiceAt(0)); bufN = LoadCtlBufferScalar(L.ctl + voiceAt(0));
+        if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + voiceAt(0));
+    }
+    // the voice whose resampler rows the workgroup stages (see the prologue below): every wavefront
+    // reads its head itself, so that the choice needs no barrier
+    const uint32_t keyVoice = group * kWWaves * vpw;
+    VoiceHead headK{};
+    if(keyVoice < L.numVoices) headK = LoadHeadScalar(L.ctl + keyVoice);
 
     f2 acc[R];
 #pragma unroll
@@ -710,7 +744,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 #pragma unroll
     for(int q = 0; q < WL::kQ; ++q) accO[q] = f2{0.0f, 0.0f};
 
-    for(uint32_t pass = 0; pass == 0 || vBegin + 2u * (pass - 1u) < vEnd; ++pass)
+    for(uint32_t pass = 0; pass <= vCount; ++pass)
     {
         // The lane index is re-derived per pass behind an opaque move: addresses built from it are
         // then a few VALU per voice instead of loop invariants that the allocator, already at the
@@ -718,12 +752,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         uint32_t lane = lane0;
         asm volatile("" : "+v"(lane));
         const bool first = pass == 0;
-        const uint32_t v = vBegin + 2u * (pass - 1u);       // meaningless in pass 0
-        const uint32_t vn = v + 2u;                         // the voice to request (= vBegin in pass 0)
-        const bool haveNext = vn < vEnd;
+        const uint32_t v = first ? 0u : voiceAt(pass - 1u);  // meaningless in pass 0
+        const bool haveNext = pass < vCount;
+        const uint32_t vn = haveNext ? voiceAt(pass) : 0u;  // the voice to request (the first one in pass 0)
 
         // ---------------- part 1: this voice up to its FIR inputs ----------------
-        bool active = false, planned = false;
+        bool active = false;
         VoiceHead head{};
         BufferItem buf{};
         bool looping = false, playing = false, dirty = false, oldPass = false;
@@ -739,7 +773,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             buf = bufN;
             looping = loopingN;
             // next voice's head (and the HRTF delays/gains behind it): in flight while this voice resamples
-            if(haveNext) { headN = LoadHeadScalar(L.ctl + vn); if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + vn); }
+            if(haveNext)
+            {
+                headN = LoadHeadScalar(L.ctl + vn); bufN = LoadCtlBufferScalar(L.ctl + vn);
+                if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + vn);
+            }
 
             const int vstate = head.playState;
             const bool mixes = vstate == OALGPU_VOICE_PLAYING || vstate == OALGPU_VOICE_STOPPING;
@@ -779,14 +817,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 if(lane == 0) { L.ambi[v].lpZ1 = sp.lpZ1; L.ambi[v].lpZ2 = sp.lpZ2; L.ambi[v].apZ1 = sp.apZ1; }
             }
 
-            // the next voice's head has arrived by now: plan its window and fetch its buffer
-            // descriptor, so that only the gather itself is left for the request point below
-            if(haveNext)
-            {
-                planN = PlanSource(headN, N);
-                if(headN.curBuffer >= 0) bufN = LoadBufferScalar(L.buffers + headN.curBuffer);
-                planned = true;
-            }
             stamp(1);
             counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
 
@@ -982,11 +1012,22 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     w.x2[TAPS + i] = f2{inL[i] * g, inR[i] * g};
                 }
                 const float gbase = gainAfterBlend - mainStep * float(fademix);
-#pragma unroll 4
-                for(uint32_t i = lane + 64u; i < N; i += 64)
+                // all reads first, then all writes: in and x2 are members of one LDS object, so
+                // the compiler keeps a read behind every earlier write (one LDS round trip per
+                // frame row otherwise).  lane + 64 j <= 1023: inside w.in for any N.
+                float xl[kLine / 64 - 1], xr[kLine / 64 - 1];
+#pragma unroll
+                for(int j = 0; j < kLine / 64 - 1; ++j)
                 {
+                    const uint32_t i = lane + 64u * uint32_t(j + 1);
+                    xl[j] = inL[i]; xr[j] = inR[i];
+                }
+#pragma unroll
+                for(int j = 0; j < kLine / 64 - 1; ++j)
+                {
+                    const uint32_t i = lane + 64u * uint32_t(j + 1);
                     const float g = __builtin_fmaf(mainStep, float(i), gbase);
-                    w.x2[TAPS + i] = f2{inL[i] * g, inR[i] * g};
+                    if(i < N) w.x2[TAPS + i] = f2{xl[j] * g, xr[j] * g};
                 }
             }
             // old-filter fade-out inputs (one per lane) and coefficients, replaced filters only
@@ -1018,11 +1059,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         for(int i = 0; i < kPre; ++i) preN[i] = 0.0f;
         if(haveNext)
         {   // its head is in headN
-            if(!planned)
-            {
-                planN = PlanSource(headN, N);
-                if(headN.curBuffer >= 0) bufN = LoadBufferScalar(L.buffers + headN.curBuffer);
-            }
+            planN = PlanSource(headN, N);
             loopingN = false;
             if(headN.curBuffer >= 0)
             {
@@ -1051,7 +1088,18 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 
         if(first)
         {   // ---- workgroup prologue: pick and stage the resampler rows most voices will use
+            // Normally those of the workgroup's first voice, whose head every wavefront has read
+            // itself (no barrier, no second round trip at kernel start); if that voice does not
+            // qualify, wavefront 0 looks for one that does.
             const uint32_t gBegin = group * kWWaves * vpw;
+            const int kK = headK.rsKind;
+            const uint32_t mK = kK == 2 ? 4u : headK.rsM, lK = kK == 2 ? 1u : headK.rsL;
+            const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24 || mK == 48)))
+                && (headK.playState == OALGPU_VOICE_PLAYING || headK.playState == OALGPU_VOICE_STOPPING);
+            uint32_t key = headK.rsFilterOffset * 8u + uint32_t(kK), m = mK;
+            if(eligK) { if(t == 0) { sm.tabKey = key; sm.tabM = mK; sm.tabL = lK; } }
+            else
+            {
             if(wave == 0)
             {
                 const uint32_t cand = gBegin + lane;
@@ -1077,7 +1125,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 else if(lane == 0) { sm.tabKey = 0xffffffffu; sm.tabM = 0; sm.tabL = 0; }
             }
             __syncthreads();
-            const uint32_t key = sm.tabKey, m = sm.tabM;
+            key = sm.tabKey; m = sm.tabM;
+            }
             if(key != 0xffffffffu)
             {
                 const float *filter = L.tables + (key >> 3);
@@ -1158,6 +1207,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             WaveSync();
         }
 
+        if(first) waveStamp(1);
         if(active)
         {
             stamp(5);
@@ -1217,6 +1267,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
     }
 
+    waveStamp(2);
     if constexpr (NL > 0) return;
     // ---- one partial per workgroup: waves dump their accumulators, then a fixed-order sum
     {
@@ -1245,6 +1296,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             ph[k] = s;
         }
     }
+    waveStamp(3);
 }
 
 // ---- MixSamples of every stream row onto the mix lines -------------------------------------------

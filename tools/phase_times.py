@@ -33,3 +33,42 @@ for kn, vs in kinds.items():
 first = [v for v in allv if v % 2 == 0]; second = [v for v in allv if v % 2 == 1]
 for kn, vs in (("first voice of wave", first), ("second voice of wave", second)):
     print(kn, " ".join(f"{n}={d[vs, i].mean():.0f}" for i, n in enumerate(names)), "start-offset=%.0f" % (t[vs, 0] - t[:, 0].min()).mean())
+
+# per-wavefront view: wave w of a group of four voices mixes voices (w, w+2); span in ticks
+tt = t.reshape(-1, 2, 2, 8)                    # [group][k][parity][stamp]; voice = 4*group + 2*k + parity
+starts = np.minimum(tt[:, 0, :, 0], tt[:, 1, :, 0]); ends = np.maximum(tt[:, 0, :, 6], tt[:, 1, :, 6])     # [group][parity] (either order)
+dur = ends - starts
+print("wave busy ticks: mean=%.0f p50=%.0f p99=%.0f max=%.0f" % (dur.mean(), np.median(dur), np.percentile(dur, 99), dur.max()))
+for par, nm in ((0, "moving+static"), (1, "filtered+static")):
+    d_ = dur[:, par]
+    print("  %s waves: mean=%.0f p50=%.0f p99=%.0f max=%.0f" % (nm, d_.mean(), np.median(d_), np.percentile(d_, 99), d_.max()))
+order = [0, 7, 1, 2, 3, 4, 5, 6]
+ph = np.diff(tt[..., order], axis=-1)          # [group][k][parity][7]
+gap = np.abs(np.maximum(tt[:, 0, :, 0], tt[:, 1, :, 0]) - np.minimum(tt[:, 0, :, 6], tt[:, 1, :, 6]))   # between the two voices of a wave
+slow = dur >= np.percentile(dur, 99)
+print("phase means, all waves : first voice", " ".join("%.0f" % x for x in ph[:, 0].reshape(-1, 7).mean(axis=0)), "| gap %.0f |" % gap.mean(), "second", " ".join("%.0f" % x for x in ph[:, 1].reshape(-1, 7).mean(axis=0)))
+print("phase means, slowest 1%: first voice", " ".join("%.0f" % x for x in ph[:, 0][slow].mean(axis=0)), "| gap %.0f |" % gap[slow].mean(), "second", " ".join("%.0f" % x for x in ph[:, 1][slow].mean(axis=0)))
+
+# are slow wavefronts a workgroup / CU effect?  (workgroup = 8 voices = 4 waves)
+dw = dur.reshape(-1, 4)                         # [workgroup][wave-ish]
+wgmax = dw.max(axis=1); wgmin = dw.min(axis=1)
+print("per-workgroup: mean of max=%.0f mean of min=%.0f; corr(max,min)=%.2f" % (wgmax.mean(), wgmin.mean(), np.corrcoef(wgmax, wgmin)[0, 1]))
+idx = np.argsort(-wgmax)[:12]
+print("slowest workgroups (index, index%8, wave durations):")
+for i in idx: print("  ", i, i % 8, dw[i].tolist())
+byx = [wgmax[i::8].mean() for i in range(8)]
+print("mean wg max by index%8:", " ".join("%.0f" % x for x in byx))
+
+half = dw.shape[0] // 2
+print("workgroups of the first half: mean of max=%.0f max=%.0f; second half: mean of max=%.0f max=%.0f" % (wgmax[:half].mean(), wgmax[:half].max(), wgmax[half:].mean(), wgmax[half:].max()))
+
+# per-wavefront stamps: entry, first voice requested+parked (pass 0), voices done, partial stored
+wt = np.zeros((V, 4), np.uint64); nw = C.c_uint32(0)
+oalgpu.lib.oalgpu_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+rc = oalgpu.lib.oalgpu_debug_wave_times(sc.h, wt.ctypes.data_as(C.c_void_p), C.byref(nw)); assert rc == 0, rc
+wt = wt[:nw.value].astype(np.int64)
+d0 = wt[:, 1] - wt[:, 0]; d1 = wt[:, 2] - wt[:, 1]; d2 = wt[:, 3] - wt[:, 2]; tot = wt[:, 3] - wt[:, 0]
+for nm, x in (("pass 0 (first head/buffer/window + table staging)", d0), ("voices", d1), ("dump + partial store", d2), ("wave lifetime", tot)):
+    print("%-52s mean=%.0f p50=%.0f p99=%.0f max=%.0f" % (nm, x.mean(), np.median(x), np.percentile(x, 99), x.max()))
+h2 = nw.value // 2
+print("wave lifetime, first-half workgroups: mean=%.0f max=%.0f; second half: mean=%.0f max=%.0f" % (tot[:h2].mean(), tot[:h2].max(), tot[h2:].mean(), tot[h2:].max()))
