@@ -1,0 +1,16 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r1o
+timeout 600 python bench.py < /dev/null > gpurun_out/r1o/bench.json 2> gpurun_out/r1o/bench.err
+cat gpurun_out/r1o/bench.json | cut -c1-400
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1o/prof_c3 -o p -- python bench.py --steps 60 --warmup 5 --no-cpu-baseline < /dev/null > gpurun_out/r1o/prof_c3.log 2>&1
+head -4 gpurun_out/r1o/prof_c3/p_kernel_stats.csv | cut -c1-160
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/r1o/pmc_$c -o pmc -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline < /dev/null > gpurun_out/r1o/pmc_$c.log 2>&1
+done
+python - <<'PY'
+import csv
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    rows=[r for r in csv.DictReader(open(f"gpurun_out/r1o/pmc_{c}/pmc_counter_collection.csv")) if "VoiceWave" in r["Kernel_Name"] and r["Counter_Name"]==c]
+    vals=sorted(float(r["Counter_Value"]) for r in rows)
+    print(c, len(vals), "median", vals[len(vals)//2])
+PY

@@ -755,6 +755,47 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         const uint32_t v = first ? 0u : voiceAt(pass - 1u);  // meaningless in pass 0
         const bool haveNext = pass < vCount;
         const uint32_t vn = haveNext ? voiceAt(pass) : 0u;  // the voice to request (the first one in pass 0)
+        // The next voice's request: these registers live from the request to the end of the pass,
+        // where they are parked in LDS.
+        float preN[kPre];
+        float prevN = 0.0f, histN = 0.0f, fstN = 0.0f;
+        f2 oldN[TAPS / 64];
+        bool dirtyN = false;
+#pragma unroll
+        for(int q = 0; q < TAPS / 64; ++q) oldN[q] = f2{0.0f, 0.0f};
+#pragma unroll
+        for(int i = 0; i < kPre; ++i) preN[i] = 0.0f;
+        auto requestNext = [&]()
+        {
+            if(haveNext)
+            {   // its head is in headN
+                planN = PlanSource(headN, N);
+                loopingN = false;
+                if(headN.curBuffer >= 0)
+                {
+                    // voice.cpp:1015-1019: a position at or past the loop end plays on without looping
+                    loopingN = headN.loopBuffer >= 0 && !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd);
+                    planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
+                }
+                // (the window first: each gather variant starts by waiting for older loads into its
+                // registers -- the variants share them -- and must not find a fresh one in front of it)
+                if(planN.prefetch)
+                {
+                    GatherStatic(preN, planN.bsrc, bufN, loopingN, uint32_t(headN.position), lane);
+                    prevN = (lane < kMaxPad) ? L.prev[size_t{vn} * kMaxPad + lane] : 0.0f;
+                }
+                fstN = (lane < 32u) ? reinterpret_cast<const float*>(L.dfilt + size_t{vn} * 2)[lane] : 0.0f;
+                if constexpr (NL == 0)
+                {
+                    histN = L.hist[size_t{vn} * kHist + lane];
+                    dirtyN = (headN.flags & kFlagHrtfDirty) != 0;
+                    const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{vn} * irStride * 2);
+    #pragma unroll
+                    for(int q = 0; q < TAPS / 64; ++q)
+                        oldN[q] = (dirtyN && lane + 64u * q < irStride) ? oc[lane + 64u * q] : f2{0.0f, 0.0f};
+                }
+            }
+        };
 
         // ---------------- part 1: this voice up to its FIR inputs ----------------
         bool active = false;
@@ -807,6 +848,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             const SrcPlan plan = planN;
             LoadResampledWave(sm, w, L, v, lane, head, playing, N, N, bufferItem, looping, plan);
             asm volatile("" : "+v"(lane));      // addresses used from here on are rebuilt, not carried across the resampler
+            if constexpr (NL > 0) requestNext();
             if(head.flags & kFlagAmbiScale)
             {   // VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
                 const AmbiScaleState a = L.ambi[v];
@@ -1048,43 +1090,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
 
         // ---------------- the next voice's source window leaves HBM now ----------------
-        // These registers live from here to the end of the pass, where they are parked in LDS.
-        float preN[kPre];
-        float prevN = 0.0f, histN = 0.0f, fstN = 0.0f;
-        f2 oldN[TAPS / 64];
-        bool dirtyN = false;
-#pragma unroll
-        for(int q = 0; q < TAPS / 64; ++q) oldN[q] = f2{0.0f, 0.0f};
-#pragma unroll
-        for(int i = 0; i < kPre; ++i) preN[i] = 0.0f;
-        if(haveNext)
-        {   // its head is in headN
-            planN = PlanSource(headN, N);
-            loopingN = false;
-            if(headN.curBuffer >= 0)
-            {
-                // voice.cpp:1015-1019: a position at or past the loop end plays on without looping
-                loopingN = headN.loopBuffer >= 0 && !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd);
-                planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
-            }
-            // (the window first: each gather variant starts by waiting for older loads into its
-            // registers -- the variants share them -- and must not find a fresh one in front of it)
-            if(planN.prefetch)
-            {
-                GatherStatic(preN, planN.bsrc, bufN, loopingN, uint32_t(headN.position), lane);
-                prevN = (lane < kMaxPad) ? L.prev[size_t{vn} * kMaxPad + lane] : 0.0f;
-            }
-            fstN = (lane < 32u) ? reinterpret_cast<const float*>(L.dfilt + size_t{vn} * 2)[lane] : 0.0f;
-            if constexpr (NL == 0)
-            {
-                histN = L.hist[size_t{vn} * kHist + lane];
-                dirtyN = (headN.flags & kFlagHrtfDirty) != 0;
-                const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{vn} * irStride * 2);
-#pragma unroll
-                for(int q = 0; q < TAPS / 64; ++q)
-                    oldN[q] = (dirtyN && lane + 64u * q < irStride) ? oc[lane + 64u * q] : f2{0.0f, 0.0f};
-            }
-        }
+        // NL == 0: before the FIR, whose ~1100 packed FMAs cover the latency.  NL > 0 (no FIR in
+        // this kernel): right after the resampler, ahead of the filters and the stream-row stores.
+        if constexpr (NL > 0) { if(!active) requestNext(); }
+        else requestNext();
 
         if(first)
         {   // ---- workgroup prologue: pick and stage the resampler rows most voices will use
