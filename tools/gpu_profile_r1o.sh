@@ -1,3 +1,5 @@
+# The GPU-side command behind profiles/r1o: python bench.py (the bench line), rocprofv3 kernel stats and the two
+# HBM PMC passes of config 3.  Run from the repo root on the GPU box: gpurun -- "bash tools/gpu_profile_r1o.sh"
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r1o
 timeout 600 python bench.py < /dev/null > gpurun_out/r1o/bench.json 2> gpurun_out/r1o/bench.err
