@@ -373,7 +373,10 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(hipEventCreate(&c->evStart)); HIP_TRY(hipEventCreate(&c->evVoice)); HIP_TRY(hipEventCreate(&c->evEnd));
     HIP_TRY(hipStreamCreate(&c->postStream));
     for(hipEvent_t *e : {&c->evVoiceDone[0], &c->evVoiceDone[1], &c->evReduceDone[0], &c->evReduceDone[1], &c->evPostDone})
-        HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        // ordering between the context's two streams only: no system-scope fence (the default one
+        // costs ~3.5 us of cache write-back per record on the stream it sits in -- measured, tools/
+        // step_period.py; hosts and peers see the results through oalgpu_sync / stream order as before)
+        HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventDisableSystemFence));
 
     DeviceLayout &L = c->L;
     L.numVoices = desc->max_voices;
@@ -930,7 +933,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     // stream -- a collective, the effects, the post-process -- runs beside the next update's
     // parameter and voice kernels
     HIP_TRY(hipStreamWaitEvent(c->postStream, c->evVoiceDone[p], 0));
-    LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum);
+    LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum, true);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->evReduceDone[p], c->postStream));
     c->parity = p ^ 1u;

@@ -825,59 +825,90 @@ hipError_t LaunchVoiceMixT(hipStream_t s, const DeviceLayout &L, uint32_t sample
 // summation tree, so the result is deterministic.  Lines no voice mixes into (HRTF context:
 // the dry/real lines) are zero-filled, which is the caller-side clear of alc/alu.cpp:2417 and
 // :2196-2198.
-constexpr int kReduceWaves = 16;
-__global__ void __launch_bounds__(kReduceWaves * 64) BusReduceKernel(DeviceLayout L, uint32_t addCarry)
+// Shape: the partials are cut into kReduceSegs runs of groups whose sums are then added in run
+// order; a workgroup is FOUR wavefronts that take four runs each.  Four waves of <= 32 VGPRs and
+// 4 KB of LDS fit on a CU BESIDE the two resident workgroups of the wavefront voice kernel (which
+// leave 32 registers per lane -- 512 - 2 x 240 -- and 9 KB of LDS), so on the post stream the reduction of update k
+// runs in the shadow of the voice kernel of update k+1 instead of taking workgroup slots from it
+// (a 16-wave workgroup does: it holds back one voice workgroup of every CU it lands on, and that
+// launch, which fills the machine exactly once, ends that much later).
+// (kReduceWaves = 16, one run per wavefront, when nothing else is running: oalgpu_mix_voices.)
+constexpr int kReduceSegs = 16;
+template<int kReduceWaves>
+__global__ void __launch_bounds__(kReduceWaves * 64) __attribute__((amdgpu_num_vgpr(32))) BusReduceKernel(DeviceLayout L, uint32_t addCarry)
 {
-    __shared__ float slice[kReduceWaves][64];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ float slice[kReduceSegs][64];
+    const uint32_t wave0 = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t idx = blockIdx.x * 64u + lane;
     const uint32_t dryLines = L.numDry + L.numReal;
     const uint32_t wetLines = L.numSlots * L.wetChannels;
     const uint32_t lineFloats = (dryLines + wetLines) * kLine;
     const uint32_t total = lineFloats + (kLine + kHrirLen) * 2;
 
-    const float *src = nullptr;
-    size_t stride = 0;
-    if(idx < lineFloats)
+    // 32-bit element offsets off one uniform base per source (the partial buses are far below
+    // 2^32 floats): one address register per load keeps the wave inside its 32 VGPRs
+    const bool fromLines = blockIdx.x * 64u < lineFloats;          // lineFloats is a multiple of 1024: uniform per workgroup
+    bool have = false;
+    uint32_t off = 0, stride = 0;
+    if(fromLines)
     {
         const uint32_t line = idx / kLine, p = idx % kLine;
         int32_t from = -1;
         if(line < dryLines) { if(!L.hrtf && line < L.numDry) from = int32_t(line); }
         else from = int32_t((L.hrtf ? 0u : L.numDry) + (line - dryLines));
-        if(from >= 0) { src = L.partLines + size_t{uint32_t(from)} * kLine + p; stride = size_t{L.mixLines} * kLine; }
+        if(from >= 0) { have = true; off = uint32_t(from) * kLine + p; stride = L.mixLines * kLine; }
     }
     else if(L.hrtf && idx < total)
     {
-        src = L.partHrtf + (idx - lineFloats);
-        stride = size_t{kLine + kHrirLen} * 2;
+        have = true;
+        off = idx - lineFloats;
+        stride = uint32_t(kLine + kHrirLen) * 2u;
+    }
+    // uniform per wavefront (64 | lineFloats) and kept in SGPRs as a GLOBAL pointer, so that a
+    // load's address is one 32-bit VGPR offset
+    typedef const __attribute__((address_space(1))) float *gfloatp;
+    gfloatp base;
+    {
+        const uint64_t b = reinterpret_cast<uint64_t>(fromLines ? L.partLines : L.partHrtf);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(b)), hi = __builtin_amdgcn_readfirstlane(uint32_t(b >> 32));
+        base = reinterpret_cast<gfloatp>((uint64_t{hi} << 32) | lo);
     }
 
-    const uint32_t ngroups = (idx < lineFloats) ? L.numLineGroups : L.numGroups;
-    const uint32_t per = (ngroups + kReduceWaves - 1) / kReduceWaves;
-    const uint32_t g0 = wave * per < ngroups ? wave * per : ngroups;
-    const uint32_t g1 = (g0 + per < ngroups) ? g0 + per : ngroups;
-    float sum = 0.0f;
-    if(src)
+    const uint32_t ngroups = fromLines ? L.numLineGroups : L.numGroups;
+    const uint32_t per = (ngroups + kReduceSegs - 1) / kReduceSegs;
+#pragma unroll 1
+    for(uint32_t seg = wave0; seg < uint32_t(kReduceSegs); seg += kReduceWaves)
     {
-        uint32_t g = g0;
-        for(; g + 8 <= g1; g += 8)
+        const uint32_t g0 = seg * per < ngroups ? seg * per : ngroups;
+        const uint32_t g1 = (g0 + per < ngroups) ? g0 + per : ngroups;
+        float sum = 0.0f;
+        if(have)
         {
-            float v[8];
+            // byte offsets (the partial buses are far below 4 GB)
+            typedef const __attribute__((address_space(1))) char *gcharp;
+            const uint32_t sb = stride * 4u;
+            uint32_t g = g0, o = (off + g0 * stride) * 4u;
+#pragma unroll 1
+            for(; g + 8 <= g1; g += 8)
+            {
+                float v[8];
 #pragma unroll
-            for(int k = 0; k < 8; ++k) v[k] = src[size_t{g + uint32_t(k)} * stride];
+                for(int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + (o + uint32_t(k) * sb));
 #pragma unroll
-            for(int k = 0; k < 8; ++k) sum = sum + v[k];
+                for(int k = 0; k < 8; ++k) sum = sum + v[k];
+                o += 8u * sb;
+            }
+            for(; g < g1; ++g) { sum = sum + *reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + o); o += sb; }
         }
-        for(; g < g1; ++g) sum = sum + src[size_t{g} * stride];
+        slice[seg][lane] = sum;
     }
-    slice[wave][lane] = sum;
     __syncthreads();
-    if(wave == 0 && idx < total)
+    if(wave0 == 0 && idx < total)
     {
         float t = (addCarry && idx >= lineFloats) ? L.bus[idx] : 0.0f;
         t = t + slice[0][lane];
-#pragma unroll
-        for(int w = 1; w < kReduceWaves; ++w) t = t + slice[w][lane];
+#pragma unroll 5
+        for(int w = 1; w < kReduceSegs; ++w) t = t + slice[w][lane];
         if(idx < lineFloats || L.hrtf) L.bus[idx] = t;
     }
 }
@@ -898,11 +929,14 @@ hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint
     return LaunchVoiceMixT<false, 32>(s, L, samplesToDo, carryAccum);
 }
 
-void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry)
+void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry, bool besideVoiceKernel)
 {
     const uint32_t total = uint32_t(BusFloats(L));
     (void)samplesToDo;
-    hipLaunchKernelGGL(BusReduceKernel, dim3((total + 63u) / 64u), dim3(kReduceWaves * 64), 0, s, L, addCarry ? 1u : 0u);
+    if(besideVoiceKernel)
+        hipLaunchKernelGGL(BusReduceKernel<4>, dim3((total + 63u) / 64u), dim3(4 * 64), 0, s, L, addCarry ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(BusReduceKernel<16>, dim3((total + 63u) / 64u), dim3(16 * 64), 0, s, L, addCarry ? 1u : 0u);
 }
 
 } // namespace oalgpu

@@ -292,7 +292,8 @@ class Scene:
             self.h = None
 
     def __del__(self):
-        self.close()
+        if lib is not None:             # module globals are gone when the interpreter shuts down
+            self.close()
 
     def hrtf_info(self):
         info = HrtfInfo()
