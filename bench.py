@@ -125,8 +125,8 @@ def cpu_baseline(synth, config_id, nvoices, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU (default 4096; 8192 for config 4)")
     ap.add_argument("--math", default="fast", choices=("fast", "exact"))
@@ -160,8 +160,12 @@ def main():
     all_voices = list(range(V))
     moving = [v for v in all_voices if script.is_moving(v)]
     sc.set_params_batch(all_voices, param_array(oalgpu, script, all_voices, 0))
+    # every step applies a parameter block (new directions for the moving quarter of the voices);
+    # the blocks are resident in HBM and a ring of 96 different ones is cycled through, so that a
+    # long run needs neither gigabytes of records nor minutes of host-side preparation
     total_steps = args.warmup + 2 * args.steps
-    blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(total_steps)]
+    nblocks = min(total_steps, 96)
+    blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(nblocks)]
 
     mixer = None
     force_sharded = os.environ.get("OALGPU_FORCE_SHARDED") == "1"      # exercise the N>1 path on one GPU
@@ -180,7 +184,7 @@ def main():
         mixer = ShardedMixer(engine, dist, rank, world)
 
     def step(k):
-        sc.apply_block(blocks[k])
+        sc.apply_block(blocks[k % nblocks])
         if mixer is None:
             sc.mix(UPDATE_SAMPLES, post_process=post)
         else:
@@ -210,7 +214,7 @@ def main():
     vk = []
     tot = []
     for k in range(args.steps):
-        sc.apply_block(blocks[args.warmup + args.steps + k])
+        sc.apply_block(blocks[(args.warmup + args.steps + k) % nblocks])
         sc.mix_voices(UPDATE_SAMPLES)
         a, b = sc.last_update_ms()
         tot.append(a)
