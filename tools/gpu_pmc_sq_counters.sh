@@ -1,4 +1,4 @@
-# SQ counter passes of the voice kernel (profiles/r1o/voice_kernel_sq_counters.txt): gpurun -- "bash tools/gpu_pmc_sq_counters.sh"
+# SQ counter passes of the voice kernel (profiles/r1p/voice_kernel_sq_counters.txt): gpurun -- "bash tools/gpu_pmc_sq_counters.sh"
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_sq
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INSTS_FLAT" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES"; do
