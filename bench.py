@@ -278,6 +278,7 @@ def main():
         # anything native code left in C stdio buffers (the RCCL banner) goes out before the line
         C.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+    sc.close()
     if dist is not None:
         dist.destroy_process_group()
 

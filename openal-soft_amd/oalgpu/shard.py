@@ -88,7 +88,10 @@ class OverlappedGpuEngine:
         close_scene = scene.close
 
         def close():            # torch must not be left on a stream the context is about to destroy
-            torch.cuda.set_stream(self._default)
+            try:
+                torch.cuda.set_stream(self._default)
+            except Exception:   # interpreter shutdown: torch may already be gone
+                pass
             close_scene()
         scene.close = close
 
