@@ -1,0 +1,70 @@
+"""The two-stream update pipeline against the one-stream entry points, both on the GPU.
+
+oalgpu_mix_update (voice kernel of update k+1 beside the partial-bus reduction and the post-process
+of update k; cross-stream events without a system-scope fence; the 4-wave reduction that sits
+beside the voice kernel) must produce, bit for bit, what oalgpu_mix_voices + oalgpu_post_process
+produce with a host synchronisation after every update: same kernels, same summation order -- only
+the scheduling differs.  The pipelined scene is never synchronised between its checkpoints, so a
+missing dependency or a stale read shows up as a difference in the buses, the carried HRTF
+accumulator or the voice states.  BASELINE configs[2] geometry (4096 voices, the bench scene)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+V = 4096
+UPDATES = 48
+CHECK = (0, 1, 2, 7, 23, 47)
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_pipelined_update_equals_serial_update(synth_mhr):
+    import oalgpu
+    from oalgpu import synth
+    import bench
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    mhr = synth.synth_mhr_bytes()
+    api._mhr = mhr
+
+    def build():
+        sc, script = bench.build_scene(oalgpu, synth, api, 3, V, 0, mhr, 0)
+        allv = list(range(V))
+        moving = [v for v in allv if script.is_moving(v)]
+        sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
+        blocks = [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(UPDATES)]
+        return sc, blocks
+
+    piped, pblocks = build()
+    serial, sblocks = build()
+    assert "VoiceWaveKernel" in piped.voice_kernel_name()
+    got, want = {}, {}
+    for k in range(UPDATES):
+        piped.apply_block(pblocks[k])
+        piped.mix(1024, post_process=True)              # oalgpu_mix_update: no host sync
+        serial.apply_block(sblocks[k])
+        serial.mix_voices(1024)
+        serial.post_process(1024)
+        serial.sync()
+        if k in CHECK:                                  # the reads synchronise the pipelined scene
+            got[k] = (piped.dry().copy(), piped.hrtf_accum().copy())
+            want[k] = (serial.dry().copy(), serial.hrtf_accum().copy())
+    for k in CHECK:
+        assert np.array_equal(_bits(got[k][0]), _bits(want[k][0])), f"bus block differs after update {k}"
+        assert np.array_equal(_bits(got[k][1]), _bits(want[k][1])), f"HRTF accumulator differs after update {k}"
+        assert np.abs(want[k][0]).max() > 1e-3                       # the comparison is not of silence
+    for v in range(0, V, 97):
+        a, b = piped.voice_state(v), serial.voice_state(v)
+        assert (a.play_state, a.position, a.position_frac) == (b.play_state, b.position, b.position_frac), v
+        assert np.array_equal(_bits(a.hrtf_history), _bits(b.hrtf_history)), v
+        assert np.array_equal(_bits(a.prev_samples), _bits(b.prev_samples)), v
+    piped.close()
+    serial.close()
