@@ -91,15 +91,6 @@ __device__ __forceinline__ BufferItem LoadCtlBufferScalar(const VoiceCtl *p)
     return u.b;
 }
 
-__device__ __forceinline__ BufferItem LoadBufferScalar(const BufferItem *p)
-{
-    static_assert(sizeof(BufferItem) == 32, "BufferItem is two 16-byte words");
-    union { BufferItem b; u4 q[2]; } u;
-    cu4 *src = (cu4*)(uintptr_t)p;
-    u.q[0] = src[0]; u.q[1] = src[1];
-    return u.b;
-}
-
 template<int R, int TAPS>
 struct WaveLds {
     static constexpr int kFrames = 64 * R;
