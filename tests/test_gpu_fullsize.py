@@ -80,6 +80,20 @@ def test_full_scene_equals_sum_of_shards(env, config):
         close_to(full[k], lo[k] + hi[k], scale, f"config {config}, update {k}")
 
 
+@pytest.mark.parametrize("config", [3, 2])
+def test_three_and_four_voices_per_wavefront(env, config):
+    """Above 4096 voices a wavefront of the voice kernel takes three or four voices (and the second
+    half of the grid takes them in reverse order, switching its issue priority half-way): 6000 and
+    8192 voices against the sum of shards that run at one or two voices per wavefront."""
+    for total, cut in ((6000, 2048), (8192, 4096)):
+        full = run_gpu(env, config, total, 0, updates=3)
+        parts = [run_gpu(env, config, min(cut, total - lo), lo, updates=3) for lo in range(0, total, cut)]
+        for k in range(3):
+            scale = np.abs(full[k]).max()
+            assert scale > 0.05
+            close_to(full[k], sum(p[k] for p in parts), scale, f"config {config}, {total} voices, update {k}")
+
+
 def test_full_scene_anchored_on_the_oracle(env, synth_mhr):
     """full(4096) - rest(4032) == oracle(first 64 voices)."""
     oalgpu, synth, bench, api, mhr = env
