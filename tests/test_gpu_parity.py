@@ -282,6 +282,20 @@ def test_scene_multi_voice_fast_mode(oracle, fast, synth_mhr, idx):
     _cmp_scene(fast, oracle, synth_mhr, dict(SCENES[idx]), idx + 1, single=False)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ir_size", [24, 32, 128])
+def test_hrir_lengths_other_than_64(oracle, fast, exact, tmp_path, ir_size):
+    """Data sets whose IrSize is not 64: the 16-tap-segment form of the FIR (IrSize 24 and 32 are
+    stored as 32 taps per voice filter) and the 128-tap variant of the wavefront kernel, with moving
+    sources (old-filter pass, coefficient hand-over) -- FAST against the oracle, and one voice in
+    EXACT mode bit for bit."""
+    from oalgpu import synth
+    path = synth.write_synth_mhr(str(tmp_path / f"ir{ir_size}.mhr"), ir_size=ir_size)
+    cfg = dict(hrtf=True, fmt=ol.FMT_FLOAT, resampler=ol.RS_BSINC24, steps=[60211, 70000], n_updates=4, nvoices=14)
+    _cmp_scene(fast, oracle, path, cfg, 7, single=False)
+    _cmp_scene(exact, oracle, path, dict(cfg, nvoices=1), 7, single=True)
+
+
 # ---- the staged parameter blocks + the pipelined update (what bench.py drives) -------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("nvoices", [64, 9])
