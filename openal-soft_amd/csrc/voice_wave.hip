@@ -692,18 +692,19 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     const uint32_t vBegin = group * kWWaves * vpw + (wave & 1u) + 2u * (wave >> 1) * vpw;
     const uint32_t vEnd = (vBegin + 2u * vpw < L.numVoices) ? vBegin + 2u * vpw : L.numVoices;   // v = vBegin + 2k < vEnd
     const uint32_t vCount = vBegin < vEnd ? (vEnd - vBegin + 1u) / 2u : 0u;
-    // Two workgroups share a CU, and the launch fills the machine exactly once: workgroup g and
-    // g + gridDim/2 land on the same CU (the dispatcher deals the first half one per CU, then the
-    // second half).  Run in the same order, their wavefronts sit in the same phase at the same
-    // time -- all eight in the LDS-bound resampler, then all eight in the VALU-bound FIR.  The
-    // second half therefore takes its voices in reverse order: voices differ in cost, so the two
-    // workgroups of a CU drift out of phase within the first voice and stay complementary.
+    // profiling aid (OALGPU_PHASE_TIMES): per-wavefront stamps behind the per-voice ones
     auto waveStamp = [&](int slot)
     {
         if(L.phaseTimes && lane0 == 0)
             L.phaseTimes[size_t{L.numVoices} * 8 + size_t{group * kWWaves + wave} * 4 + slot] = __builtin_readcyclecounter();
     };
     waveStamp(0);
+    // Two workgroups share a CU, and the launch fills the machine exactly once: workgroup g and
+    // g + gridDim/2 land on the same CU (the dispatcher deals the first half one per CU, then the
+    // second half).  Run in the same order, their wavefronts sit in the same phase at the same
+    // time -- all eight in the LDS-bound resampler, then all eight in the VALU-bound FIR.  The
+    // second half therefore takes its voices in reverse order: voices differ in cost, so the two
+    // workgroups of a CU drift out of phase within the first voice and stay complementary.
     const bool rev = group >= (gridDim.x + 1u) / 2u;
     auto voiceAt = [&](uint32_t j) { return vBegin + 2u * (rev ? vCount - 1u - j : j); };
 
