@@ -1,0 +1,68 @@
+"""Register and LDS budgets the update pipeline is built on, checked from the compiler's own
+metadata (hipcc cross-compiles for gfx950 without a GPU; ~1 minute).
+
+* The wavefront voice kernels must not spill: scratch traffic was 11 MB of HBM writes per launch
+  when they did, and every variant has to stay at two workgroups per CU.
+* The post-stream reduction has to FIT BESIDE two resident workgroups of the HRTF voice kernel on
+  a CU: 512 VGPRs per SIMD lane and 160 KB of LDS per CU, allocation granules of
+  8 registers; one wavefront of each workgroup per SIMD."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "openal-soft_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-fgpu-flush-denormals-to-zero", "-O3", "-std=c++17", "-ffp-contract=off",
+         "-fno-math-errno", "--cuda-device-only", "-S"]
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
+
+
+def kernel_metadata(tmp_path, source, extra=()):
+    out = tmp_path / (source + ".s")
+    subprocess.run([HIPCC, *FLAGS, *extra, "-o", str(out), os.path.join(CSRC, source)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    meta = {}
+    # one YAML map per kernel in the amdhsa.kernels note: fields come in alphabetical order
+    for block in re.split(r"\n  - ", text[text.index("amdhsa.kernels:"):])[1:]:
+        fields = dict(re.findall(r"\.(\w+):\s+(\S+)", block))
+        if "name" in fields:
+            meta[fields["name"]] = {k: int(v) for k, v in fields.items() if v.isdigit()}
+    return meta
+
+
+def granule(n, g=8):
+    return (n + g - 1) // g * g
+
+
+@pytest.fixture(scope="module")
+def voice_wave(tmp_path_factory):
+    return kernel_metadata(tmp_path_factory.mktemp("kres"), "voice_wave.hip", ["-mllvm", "-amdgpu-load-store-vectorizer=0"])
+
+
+@pytest.fixture(scope="module")
+def voice_kernel(tmp_path_factory):
+    return kernel_metadata(tmp_path_factory.mktemp("kres2"), "voice_kernel.hip")
+
+
+def test_wavefront_voice_kernels_do_not_spill(voice_wave):
+    waves = {n: m for n, m in voice_wave.items() if "VoiceWaveKernel" in n}
+    assert len(waves) == 6, sorted(voice_wave)
+    for name, m in waves.items():
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
+        assert m["vgpr_count"] <= 256, (name, m)                       # two wavefronts per SIMD
+        assert 2 * m["group_segment_fixed_size"] <= 160 * 1024, (name, m)   # two workgroups per CU
+
+
+def test_reduction_fits_beside_the_hrtf_voice_kernel(voice_wave, voice_kernel):
+    voice = next(m for n, m in voice_wave.items() if "VoiceWaveKernelILi17ELi64ELi0ELb0E" in n)
+    reduce4 = next(m for n, m in voice_kernel.items() if "BusReduceKernelILi4E" in n)
+    assert reduce4["vgpr_spill_count"] == 0
+    # per SIMD lane: one wavefront of each of the two voice workgroups + one of the reduction's four
+    assert 2 * granule(voice["vgpr_count"]) + granule(reduce4["vgpr_count"]) <= 512, (voice, reduce4)
+    assert 2 * voice["group_segment_fixed_size"] + reduce4["group_segment_fixed_size"] <= 160 * 1024
