@@ -26,13 +26,11 @@ names = ["src in LDS", "resample", "biquad", "hist+x' build", "request next", "F
 t2 = np.stack([t[:, 0], t[:, 7], t[:, 1], t[:, 2], t[:, 3], t[:, 4], t[:, 5], t[:, 6]], axis=1)
 d = np.diff(t2, axis=1)
 kinds = {"static unfiltered": [v for v in allv if v % 4 in (2, 3)], "filtered": [v for v in allv if v % 4 == 1], "moving": moving}
-print("s_memtime ticks per phase (mean over voices), total kernel span %d ticks" % (t[:, 6].max() - t[:, 0].min()))
+# (s_memtime counters of different XCDs do not share a time base: only differences within one
+# wavefront are meaningful)
+print("s_memtime ticks per phase, mean over voices:")
 for kn, vs in kinds.items():
     print(kn, " ".join(f"{n}={d[vs, i].mean():.0f}" for i, n in enumerate(names)), "sum=%.0f" % d[vs].sum(axis=1).mean())
-# first vs second voice of a wave
-first = [v for v in allv if v % 2 == 0]; second = [v for v in allv if v % 2 == 1]
-for kn, vs in (("first voice of wave", first), ("second voice of wave", second)):
-    print(kn, " ".join(f"{n}={d[vs, i].mean():.0f}" for i, n in enumerate(names)), "start-offset=%.0f" % (t[vs, 0] - t[:, 0].min()).mean())
 
 # per-wavefront view: wave w of a group of four voices mixes voices (w, w+2); span in ticks
 tt = t.reshape(-1, 2, 2, 8)                    # [group][k][parity][stamp]; voice = 4*group + 2*k + parity
