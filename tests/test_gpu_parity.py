@@ -300,9 +300,8 @@ def test_hrir_lengths_other_than_64(oracle, fast, exact, tmp_path, ir_size):
 @pytest.mark.gpu
 @pytest.mark.parametrize("nvoices", [64, 9])
 def test_param_blocks_through_the_pipeline(oracle, fast, synth_mhr, nvoices):
-    """oalgpu_param_block_create/apply + oalgpu_mix_update on an HRTF context: the voice kernel
-    runs as two halves and the next update's block is applied per half on its own stream.  Voices
-    on both sides of the split move every update (records in shuffled order), one more voice is
+    """oalgpu_param_block_create/apply + oalgpu_mix_update on an HRTF context (the two-stream
+    update): voices all over the grid move every update (records in shuffled order), one more voice is
     updated through the immediate call in between, and every update's buses and the final voice
     states must match the oracle driven with the same parameters."""
     oracle.hrtf_load(synth_mhr)
