@@ -235,3 +235,19 @@ def test_scene_voice_mix_bit_exact(libs, mhr_paths, idx):
     fb, ib = run_scene(port, MHR, rng_seed=idx + 1, **cfg)
     assert ia == ib, "integer voice state (positions, play state, delays, counters)"
     assert_bit_equal(fa, fb, f"scene {idx}")
+
+
+@pytest.mark.parametrize("ir_size", [24, 32, 128])
+def test_other_hrir_lengths_bit_exact(libs, tmp_path, ir_size):
+    """Data sets whose IrSize is not 64 (what tests/test_gpu_parity.py::test_hrir_lengths_other_than_64
+    checks the GPU against): store, getCoeffs and a moving-source HRTF scene, restatement against the
+    compiled reference."""
+    from oalgpu import synth
+    ref, port = libs
+    path = synth.write_synth_mhr(str(tmp_path / f"ir{ir_size}.mhr"), ir_size=ir_size)
+    _check_hrtf_store(libs, path)
+    cfg = dict(hrtf=True, fmt=ol.FMT_FLOAT, resampler=ol.RS_BSINC24, steps=[60211, 70000], n_updates=4, nvoices=14)
+    fa, ia = run_scene(ref, path, rng_seed=7, **cfg)
+    fb, ib = run_scene(port, path, rng_seed=7, **cfg)
+    assert ia == ib
+    assert_bit_equal(fa, fb, f"IrSize {ir_size} scene")
