@@ -122,6 +122,7 @@ struct oalgpu_context {
     NfcDesign nfcDevice{};                   // DeviceBase::mNFCtrlFilter (after init(w1))
     DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
     bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
+    uint32_t waveGroups{0};                // partial buses of the wavefront kernel (the fallback of voice_block.hip)
     // HRTF store
     DevBuf<float> hFieldDist, hCoeffs;
     DevBuf<uint8_t> hEvCount, hDelays;
@@ -407,6 +408,10 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.waveVoices = 0;
     L.ablate = 0;
     if(const char *ab = std::getenv("OALGPU_ABLATE")) L.ablate = uint32_t(std::strtoul(ab, nullptr, 0));
+    // the HRTF FIR of the wavefront kernel: packed-VALU FMAs (default: measured 45.6 vs 47.5 us per 4096-voice
+    // update, profiles/r2/) or the matrix-pipe Toeplitz form (OALGPU_FIR=mfma)
+    L.firMfma = 0u;
+    if(const char *fm = std::getenv("OALGPU_FIR")) L.firMfma = std::strcmp(fm, "mfma") == 0;
     L.phaseTimes = nullptr;
     c->serialOnly = std::getenv("OALGPU_SERIAL") != nullptr;
     c->useWave = WaveKernelApplies(c->exact, L);
@@ -417,6 +422,24 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
         L.waveVoices = desc->voices_per_group ? std::max<uint32_t>(1u, (desc->voices_per_group + 3u) / 4u)
             : std::max<uint32_t>(1u, (desc->max_voices + 2047u) / 2048u);
         L.numGroups = std::max<uint32_t>(1u, WaveKernelGroups(L));
+    }
+    // FAST HRTF contexts without sends can also run one WORKGROUP per voice (voice_block.hip; four
+    // workgroups per CU -> ~1024 workgroups, voices_per_group is then voices per workgroup): opt-in with
+    // OALGPU_VOICE_KERNEL=block -- measured 62 us against the wavefront kernel's 46 us per 4096-voice
+    // update.  Final once the data set is loaded (IrSize <= 64).
+    L.blockVoices = 0; L.blockWaves = 0;
+    c->waveGroups = L.numGroups;
+    {
+        const char *vk = std::getenv("OALGPU_VOICE_KERNEL");
+        if(c->useWave && L.hrtf && L.numSends == 0 && vk && std::strcmp(vk, "block") == 0)
+        {
+            L.blockWaves = 4;
+            if(const char *bw = std::getenv("OALGPU_BLOCK_WAVES")) L.blockWaves = std::atoi(bw) == 3 ? 3u : 4u;
+            const uint32_t want = 256u * L.blockWaves;           // workgroups that are resident at once
+            L.blockVoices = desc->voices_per_group ? desc->voices_per_group
+                : std::max<uint32_t>(1u, (desc->max_voices + want - 1u) / want);
+            L.numGroups = std::max<uint32_t>(1u, WaveKernelGroups(L));
+        }
     }
 
     const TableBlob &blob = Blob();
@@ -511,6 +534,13 @@ int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
     DeviceLayout &L = c->L;
     L.irSize = h.irSize;
     L.irStride = (h.irSize + 15u) & ~15u;
+    if(L.blockVoices && L.irStride > 64u)
+    {   // the workgroup-per-voice kernel is the 64-tap form: longer responses stay on the wavefront kernel
+        if(int rc = oalgpu_sync(c)) return rc;
+        L.blockVoices = 0;
+        L.numGroups = c->waveGroups;
+        if(!L.streams) L.numLineGroups = L.numGroups;
+    }
     if(L.hrtf)
     {
         const size_t n = size_t{L.numVoices} * L.irStride * 2;

@@ -178,4 +178,125 @@ __device__ __forceinline__ void FirMainPk(f2 (&acc)[R], const X *xw, cf16 *co16)
     }
 }
 
+// ---- dual-ear FIR on the matrix pipe: the Toeplitz form of MixHrtf ------------------------------
+// core/mixer/hrtfbase.h:17-89 computes, per ear, y[n] = sum_{j < IrSize} h[j] * x'[n - j] over one
+// update (x' = the delayed, gain-ramped input).  Cut the output into blocks of 16 frames
+// (n = 64 a + 16 b + r; a < 16 = matrix row, b < 4 = tile, r < 16 = matrix column) and the taps into
+// j = 16 k + r - c (k < 5, c < 16): then
+//     Y_b[a][r] = sum_{k, c} x'[64 a + 16 (b - k) + c] * h[16 k + r - c]
+// is a dense (16 x 80) x (80 x 16) product per tile and ear -- 20 v_mfma_f32_16x16x4_f32 each, 64 of
+// the 80 K-rows useful (the k = 0 and k = 4 Toeplitz tiles are complementary triangles).  The
+// instruction is an exact k-ordered fp32 fma chain, so the result is fp32 like the packed-VALU form.
+// Operands: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; with the K index of MFMA (k, t)
+// chosen as c = 4 kk + t (kk = l >> 4) the four A fragments of one (b - k) are ONE ds_read_b128
+// (x'[64 a + 16 (b - k) + 4 kk .. + 3]), 8 of them per ear, each reused by up to four tiles; the
+// 20 B fragments per ear are h[16 k + (l & 15) - 4 kk - t] out of a zero-padded LDS copy of the HRIR.
+// The 64-frame ring-out (frames 1024 + 16 b' + r) is a fifth tile whose rows are b' < 4:
+//     Y_t[b'][r] = sum_{k > b', c} x'[1024 + 16 (b' - k) + c] * h[16 k + r - c]   (16 MFMAs per ear).
+// acc[e][b]: lane l, element i = frame 64 (4 (l >> 4) + i) + 16 b + (l & 15) of ear e;
+// acc[e][4]: lanes < 16, element i = frame 1024 + 16 i + l.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template<int XS /* row stride of xp in floats */, int HPLEN>
+__device__ __forceinline__ void FirMfma64(f4 (&acc)[2][5], const float *xp0, const float *xp1, const float *hp0,
+    const float *hp1, uint32_t lane)
+{
+    const uint32_t a = lane & 15u, kk = lane >> 4;
+#pragma unroll
+    for(int e = 0; e < 2; ++e)
+    {
+        const float *xp = e ? xp1 : xp0;
+        const float *hp = e ? hp1 : hp0;
+        f4 A[8];
+        const float *xa = xp + XS * a + 4u * kk;
+#pragma unroll
+        for(int d = 0; d < 8; ++d)                       // d = (b - k) + 4; rows shift by one from d = 4 on
+            A[d] = *reinterpret_cast<const f4*>(xa + XS * (d >= 4 ? 1 : 0) + 16 * (d & 3));
+        float B[5][4];
+        const float *hb = hp + 16 + a - 4u * kk;         // (l & 15) doubles as the column r here
+#pragma unroll
+        for(int k = 0; k < 5; ++k)
+#pragma unroll
+            for(int t = 0; t < 4; ++t) B[k][t] = hb[16 * k - t];
+        // the ring-out tile's inputs: row b' = l & 15 (< k), x'[1024 - 16 (k - b') + 4 kk ..]
+        f4 T[4];
+#pragma unroll
+        for(int k = 1; k < 5; ++k)
+        {
+            const bool valid = a < uint32_t(k);
+            const uint32_t i64 = valid ? 1088u - 16u * (uint32_t(k) - a) + 4u * kk : 1024u;
+            const f4 v = *reinterpret_cast<const f4*>(xp + i64 + 4u * (i64 >> 6) /* = XS-strided rows */);
+            T[k - 1] = valid ? v : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        static_assert(XS == 68, "i64 + 4*(i64 >> 6) is the stride-68 row layout");
+#pragma unroll
+        for(int k = 0; k < 5; ++k)
+#pragma unroll
+            for(int t = 0; t < 4; ++t)
+            {
+#pragma unroll
+                for(int b = 0; b < 4; ++b)
+                    acc[e][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b - k + 4][t], B[k][t], acc[e][b], 0, 0, 0);
+                if(k >= 1)
+                    acc[e][4] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[k - 1][t], B[k][t], acc[e][4], 0, 0, 0);
+            }
+    }
+}
+
+// One wavefront's share of the same product when a 4-wavefront workgroup works on ONE voice
+// (voice_block.hip): tile b (frames 64 a + 16 b + r) of both ears, and the k = b + 1 part of the
+// ring-out tile.  Per ear the 20 + 4 MFMAs run as three independent accumulator chains (even /
+// odd K steps of the main tile, ring-out), so none waits for the 40-cycle dependent latency.
+// accM[e][p]: lane l, element i = partial p of frame 64 (4 (l >> 4) + i) + 16 b + (l & 15);
+// accT[e]: lanes < 16, element i = this wave's part of frame 1024 + 16 i + l.
+template<int XS>
+__device__ __forceinline__ void FirMfmaTile(f4 (&accM)[2][2], f4 (&accT)[2], const float *xp0, const float *xp1,
+    const float *hp0, const float *hp1, uint32_t lane, uint32_t b /* wave-uniform */)
+{
+    static_assert(XS == 68, "i64 + 4*(i64 >> 6) is the stride-68 row layout");
+    const uint32_t a = lane & 15u, kk = lane >> 4;
+    const uint32_t kt = b + 1u;                           // the ring-out part this wave computes
+    const bool valid = a < kt;
+    const uint32_t i64 = valid ? 1088u - 16u * (kt - a) + 4u * kk : 1024u;
+#pragma unroll
+    for(int e = 0; e < 2; ++e)
+    {
+        const float *xp = e ? xp1 : xp0;
+        const float *hp = e ? hp1 : hp0;
+        // every fragment of this ear is requested before the first MFMA (44 registers): one LDS round
+        // trip per ear instead of one per K step
+        f4 A[5];
+        const float *xa = xp + XS * a + 4u * kk;
+#pragma unroll
+        for(int k = 0; k < 5; ++k)
+        {
+            const uint32_t d = b + 4u - uint32_t(k);      // (b - k) + 4
+            A[k] = *reinterpret_cast<const f4*>(xa + (d >= 4u ? uint32_t(XS) : 0u) + 16u * (d & 3u));
+        }
+        f4 T = *reinterpret_cast<const f4*>(xp + i64 + 4u * (i64 >> 6));
+        float B[5][4];
+        const float *hb = hp + 16 + a - 4u * kk;
+#pragma unroll
+        for(int k = 0; k < 5; ++k)
+#pragma unroll
+            for(int t = 0; t < 4; ++t) B[k][t] = hb[16 * k - t];
+        float Bt[4];                                      // = B[kt][.]: the ring-out part's taps (kt is wave-uniform)
+        const float *hbt = hb + 16u * kt;
+#pragma unroll
+        for(int t = 0; t < 4; ++t) Bt[t] = hbt[-t];
+        if(!valid) T = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        __builtin_amdgcn_sched_barrier(0);                // (the loads stay in front of the MFMAs)
+#pragma unroll
+        for(int k = 0; k < 5; ++k)
+#pragma unroll
+            for(int t = 0; t < 4; ++t)
+            {
+                accM[e][t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[k][t], B[k][t], accM[e][t & 1], 0, 0, 0);
+                if(k == 2) accT[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t], Bt[t], accT[e], 0, 0, 0);
+            }
+        // one ear's fragment registers at a time: keep the other ear's loads behind this ear's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 } // namespace oalgpu

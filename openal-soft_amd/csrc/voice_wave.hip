@@ -29,608 +29,12 @@
 // the tolerance stated in DESIGN.md; all integer state (positions, loop wrap, play state,
 // delays, fade counters) is bit-exact.  EXACT mode and every other configuration (sends, non-HRTF
 // buses) run voice_kernel.hip.
-#include "dev_wave.hpp"
+#include "wave_common.hpp"
 
 #pragma clang fp contract(off)
 
 namespace oalgpu {
 namespace {
-
-constexpr int kWWaves = 4;                    // wavefronts (= concurrent voices) per workgroup
-constexpr int kWThreads = kWWaves * 64;
-constexpr int kTabPairs = 24;                 // staged resampler rows: up to 48 taps
-
-constexpr int kPre = 17;                      // prefetched source samples per lane (17*64 = 1088)
-
-// ---- scalar-cache views of the per-voice control block and the buffer table -------------------
-// VoiceCtl (kernels.hpp) in two pieces: the head (bytes 0..47: everything needed to locate and
-// resample the source) is fetched one voice AHEAD so that voice's source window can be
-// requested from HBM while the current voice is still in its FIR; the tail (bytes 64..95: HRTF
-// delays and gains) is fetched at the start of the voice and first needed after resampling.
-struct VoiceHead {
-    int32_t playState, position;
-    uint32_t positionFrac;
-    int32_t curBuffer, loopBuffer;
-    uint32_t step;
-    int32_t rsKind;
-    uint32_t rsM, rsL;
-    float rsSf;
-    uint32_t rsFilterOffset, flags;
-};
-static_assert(sizeof(VoiceHead) == 48 && offsetof(VoiceCtl, flags) == 44, "VoiceHead mirrors the first 48 bytes of VoiceCtl");
-static_assert(offsetof(VoiceCtl, hrtfOldDelay) == 72 && offsetof(VoiceCtl, hrtfTgtGain) == 92, "VoiceCtl tail layout");
-
-__device__ __forceinline__ VoiceHead LoadHeadScalar(const VoiceCtl *p)
-{
-    union { VoiceHead h; u4 q[3]; } u;
-    cu4 *src = (cu4*)(uintptr_t)p;
-    u.q[0] = src[0]; u.q[1] = src[1]; u.q[2] = src[2];
-    return u.h;
-}
-
-struct VoiceTail { uint32_t oldDelay[2]; float oldGain; uint32_t tgtDelay[2]; float tgtGain; };
-__device__ __forceinline__ VoiceTail LoadTailScalar(const VoiceCtl *p)
-{
-    cu4 *src = (cu4*)(uintptr_t)p;
-    const u4 a = src[4], b = src[5];          // bytes 64..95
-    VoiceTail t;
-    t.oldDelay[0] = a.z; t.oldDelay[1] = a.w;
-    t.oldGain = __builtin_bit_cast(float, uint32_t(b.x));
-    t.tgtDelay[0] = b.y; t.tgtDelay[1] = b.z;
-    t.tgtGain = __builtin_bit_cast(float, uint32_t(b.w));
-    return t;
-}
-
-// VoiceCtl::buf, bytes 96..127 of the voice's line
-__device__ __forceinline__ BufferItem LoadCtlBufferScalar(const VoiceCtl *p)
-{
-    static_assert(offsetof(VoiceCtl, buf) == 96 && sizeof(BufferItem) == 32, "VoiceCtl::buf layout");
-    union { BufferItem b; u4 q[2]; } u;
-    cu4 *src = (cu4*)(uintptr_t)p;
-    u.q[0] = src[6]; u.q[1] = src[7];
-    return u.b;
-}
-
-template<int R, int TAPS>
-struct WaveLds {
-    static constexpr int kFrames = 64 * R;
-    static constexpr int kX = TAPS + kFrames;           // x2[k] = x'[k - TAPS]
-    static constexpr int kQ = TAPS / 64 + 1;            // old-filter fade: frames l + 64q, q < kQ
-    union {
-        f2 x2[kX];                                      // FIR inputs (both ears), zero padded
-        float rd[kResampleDataSize + 8];                // DeviceBase::mResampleData (dead before x2 is built)
-    };
-    float in[kHist + kLine];                            // [Hrtf.History | resampled, filtered samples]
-    f2 cold[TAPS + 128];                                // cold[k] = Hrtf.Old.Coeffs[k - 64], zero padded
-    f2 xo[64];                                          // old-filter fade-out inputs (i < 64), both ears
-    float fst[32];                                      // the voice's two BiquadSlots (2 x 16 dwords)
-    int32_t best;
-    uint32_t pad[3];
-};
-
-template<int R, int TAPS>
-struct WgLds {
-    WaveLds<R, TAPS> w[kWWaves];
-    f2 tabF[kTabPairs * 32];                            // [tap pair][phase] = fil[2p], fil[2p+1]
-    f2 tabP[kTabPairs * 32];                            //                    = phd[2p], phd[2p+1]
-    uint32_t tabKey, tabM, tabL;
-    uint32_t pad;
-};
-
-// ---- source window ----------------------------------------------------------------------------
-// The first chunk of LoadBufferStatic (core/voice.cpp:500-544) as a register gather: lane l
-// requests elements l, l+64, ... of the `count` source samples starting at buffer position
-// dataPos (loop wrap; past-the-end holds the last sample).  The loads are issued here and only
-// waited for when the values are stored to LDS, one voice later.
-// The loads are GLOBAL loads (the buffer's data pointer comes out of a BufferItem in memory, so
-// the compiler would otherwise issue FLAT loads, which also count on lgkmcnt: every LDS wait of
-// the FIR that runs while the window is in flight would then wait for the window), and they
-// deliver the raw element: the int16 -> float conversion happens when the window is stored to
-// LDS (GatherDecode), so that no load has to be waited for here.
-template<int FMT>
-__device__ __forceinline__ float LoadRawGlobal(const void *data, size_t idx)
-{
-    if constexpr (FMT == OALGPU_FMT_FLOAT)
-        return reinterpret_cast<const __attribute__((address_space(1))) float*>(
-            (const __attribute__((address_space(1))) void*)data)[idx];
-    else
-        return __builtin_bit_cast(float, int32_t(reinterpret_cast<const __attribute__((address_space(1))) int16_t*>(
-            (const __attribute__((address_space(1))) void*)data)[idx]));
-}
-
-__device__ __forceinline__ float GatherDecode(float raw, bool isShort)
-{ return isShort ? float(__builtin_bit_cast(int32_t, raw)) * (1.0f / 32768.0f) : raw; }
-
-template<int FMT>
-__device__ __forceinline__ void GatherStaticT(float (&pre)[kPre], uint32_t count, const BufferItem &b, bool looping,
-    uint32_t dataPos, uint32_t lane)
-{
-    const uint32_t fs = b.frameStep;
-    if(!looping)
-    {   // past the end: the last sample (index clamp, so that every element is one unconditional load)
-        const bool any = b.sampleLen > dataPos;
-        const uint32_t lastIdx = b.sampleLen - 1u;
-#pragma unroll
-        for(int i = 0; i < kPre; ++i)
-        {
-            const uint32_t k = lane + 64u * uint32_t(i);
-            const uint32_t idx = (dataPos + k < lastIdx) ? dataPos + k : lastIdx;
-            pre[i] = (k < count && any) ? LoadRawGlobal<FMT>(b.data, size_t{idx} * fs) : 0.0f;
-        }
-    }
-    else
-    {   // GatherWraps() said: at most one wrap inside the window, no division per element
-        const uint32_t ls = b.loopStart, le = b.loopEnd;
-        const uint32_t first = le - dataPos;
-#pragma unroll
-        for(int i = 0; i < kPre; ++i)
-        {
-            const uint32_t k = lane + 64u * uint32_t(i);
-            const uint32_t idx = (k < first) ? dataPos + k : ls + (k - first);
-            pre[i] = (k < count) ? LoadRawGlobal<FMT>(b.data, size_t{idx} * fs) : 0.0f;
-        }
-    }
-}
-
-// The common shape -- a mono buffer, the window and the kPre*64 elements the gather touches all
-// inside the buffer and before the loop end: one uniform base, lane offset, immediate offsets.
-// (Elements past `count` are loaded and never used.)  ~20 instructions instead of ~20 per element;
-// the kernel is issue-bound, so this is worth ~3500 cycles per requested window.
-template<int FMT>
-__device__ __forceinline__ void GatherLinearT(float (&pre)[kPre], const BufferItem &b, uint32_t dataPos, uint32_t lane)
-{
-    if constexpr (FMT == OALGPU_FMT_FLOAT)
-    {
-        const __attribute__((address_space(1))) float *p =
-            reinterpret_cast<const __attribute__((address_space(1))) float*>((const __attribute__((address_space(1))) void*)b.data) + dataPos;
-        const __attribute__((address_space(1))) float *pl = p + lane;
-#pragma unroll
-        for(int i = 0; i < kPre; ++i) pre[i] = pl[64 * i];
-    }
-    else
-    {
-        const __attribute__((address_space(1))) int16_t *p =
-            reinterpret_cast<const __attribute__((address_space(1))) int16_t*>((const __attribute__((address_space(1))) void*)b.data) + dataPos;
-        const __attribute__((address_space(1))) int16_t *pl = p + lane;
-#pragma unroll
-        for(int i = 0; i < kPre; ++i) pre[i] = __builtin_bit_cast(float, int32_t(pl[64 * i]));
-    }
-}
-
-__device__ __forceinline__ bool GatherIsLinear(uint32_t count, const BufferItem &b, bool looping, uint32_t dataPos)
-{
-    return b.frameStep == 1u && uint64_t{dataPos} + uint32_t(kPre * 64) <= b.sampleLen
-        && (!looping || uint64_t{dataPos} + count <= b.loopEnd);
-}
-
-// The register gather covers the formats and loop shapes that matter for throughput; anything
-// else is filled by the generic LoadBufferStatic loop (FillFromBuffer) when the voice starts.
-__device__ __forceinline__ bool GatherCovers(uint32_t count, const BufferItem &b, bool looping, uint32_t dataPos)
-{
-    if(b.fmt != OALGPU_FMT_FLOAT && b.fmt != OALGPU_FMT_SHORT) return false;
-    if(!looping) return true;
-    return dataPos < b.loopEnd && count <= (b.loopEnd - dataPos) + (b.loopEnd - b.loopStart);
-}
-
-__device__ __forceinline__ void GatherStatic(float (&pre)[kPre], uint32_t count, const BufferItem &b, bool looping,
-    uint32_t dataPos, uint32_t lane)
-{
-    if(GatherIsLinear(count, b, looping, dataPos))
-    {
-        if(b.fmt == OALGPU_FMT_FLOAT) GatherLinearT<OALGPU_FMT_FLOAT>(pre, b, dataPos, lane);
-        else GatherLinearT<OALGPU_FMT_SHORT>(pre, b, dataPos, lane);
-    }
-    else if(b.fmt == OALGPU_FMT_FLOAT) GatherStaticT<OALGPU_FMT_FLOAT>(pre, count, b, looping, dataPos, lane);
-    else GatherStaticT<OALGPU_FMT_SHORT>(pre, count, b, looping, dataPos, lane);
-}
-
-// What the first pass of LoadResampledSamples' loop will ask for (core/voice.cpp:600-640,
-// :662-753), decided from the voice head alone.  `prefetch`: the plain case -- the voice mixes,
-// has a buffer, starts at a non-negative position and its first chunk fits kPre*64 samples -- so
-// the chunk can be gathered into registers ahead of time.
-struct SrcPlan { bool prefetch; uint32_t bdst, bsrc; };
-
-__device__ __forceinline__ SrcPlan PlanSource(const VoiceHead &h, uint32_t samplesToLoad)
-{
-    SrcPlan p{false, 0u, 0u};
-    const bool mixes = h.playState == OALGPU_VOICE_PLAYING || h.playState == OALGPU_VOICE_STOPPING;
-    if(!mixes || h.step < 1u) return p;
-    CalcBufferSize(h.positionFrac, h.step, samplesToLoad, p.bdst, p.bsrc);
-    p.prefetch = h.curBuffer >= 0 && h.position >= 0 && p.bsrc <= uint32_t(kPre * 64);
-    return p;
-}
-
-// ---- resampler, staged rows -----------------------------------------------------------------
-// One wavefront's share (outputs lane, lane+64, ...) of a Resample_FastBSinc / Resample_Cubic
-// call (core/mixer/mixer_c.cpp:52-83; the SSE variants mixer_sse.cpp:199-329 compute the same
-// terms): out[k] = sum_j (fil[j] + pf*phd[j]) * src[pos + j - l], taps two at a time in packed
-// FMAs.  The taps of an output are cut into G groups of NP pairs and software-pipelined: the LDS
-// reads of the next group (or of the next output's first group) are in flight while the current
-// group is multiplied.  Every lane runs every pass of the loop (the store is predicated), so the
-// look-ahead reads need no branch; past the last output they read unused words of this wave's
-// own LDS block.  rdb = rd + MaxResamplerEdge - l.
-template<int M>
-__device__ __forceinline__ void ResampleRunStaged(const f2 *tabF, const f2 *tabP, const float *rdb, uint32_t frac0,
-    uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane)
-{
-    // Two complete outputs are in flight: while the 3*NP LDS reads of one are outstanding
-    // (rows F, P and the source pairs S) the other is multiplied, which covers the LDS latency
-    // at two waves per SIMD.  bsinc48 (24 pairs) takes its outputs in two halves.
-    constexpr int NP = M <= 24 ? M / 2 : 12;
-    constexpr int G = (M / 2) / NP;               // 1, or 2 for bsinc48
-    f2 FA[NP], PA[NP], SA[NP], FB[NP], PB[NP], SB[NP];
-    const uint32_t tstep = 64u * increment;
-    uint32_t t = frac0 + lane * increment;
-    auto load = [&](f2 (&F)[NP], f2 (&P)[NP], f2 (&S)[NP], uint32_t tt, int g)
-    {
-        const uint32_t pi = (tt >> 11) & 31u;
-        const f2 *tf = tabF + pi, *tp = tabP + pi;
-        const float *s = rdb + (tt >> kFracBits);
-#pragma unroll
-        for(int q = 0; q < NP; ++q)
-        {
-            F[q] = tf[(g * NP + q) * 32];
-            P[q] = tp[(g * NP + q) * 32];
-        }
-#pragma unroll
-        for(int q = 0; q < NP; ++q) S[q] = f2{s[2 * (g * NP + q)], s[2 * (g * NP + q) + 1]};
-    };
-    auto compute = [&](const f2 (&F)[NP], const f2 (&P)[NP], const f2 (&S)[NP], uint32_t tt, f2 &r0, f2 &r1)
-    {
-        const f2 pf = splat(float(tt & 2047u) * (1.0f / 2048.0f));
-#pragma unroll
-        for(int q = 0; q < NP; ++q)
-        {
-            const f2 c = pkfma(pf, P[q], F[q]);
-            if(q & 1) r1 = pkfma(c, S[q], r1);
-            else r0 = pkfma(c, S[q], r0);
-        }
-    };
-    auto store = [&](uint32_t k, f2 r0, f2 r1)
-    {   // lanes past the end write a scratch word instead of branching
-        float *dst = (k < bdst) ? out + k : sink;
-        *dst = (r0.x + r0.y) + (r1.x + r1.y);
-    };
-    if constexpr(G == 1)
-    {
-        load(FA, PA, SA, t, 0);
-#pragma unroll 1
-        for(uint32_t kb = 0; kb < bdst; kb += 128)
-        {
-            const uint32_t t0 = t, t1 = t + tstep;
-            t = t1 + tstep;
-            load(FB, PB, SB, t1, 0);
-            f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
-            compute(FA, PA, SA, t0, r0, r1);
-            store(kb + lane, r0, r1);
-            load(FA, PA, SA, t, 0);
-            f2 u0 = {0.0f, 0.0f}, u1 = {0.0f, 0.0f};
-            compute(FB, PB, SB, t1, u0, u1);
-            store(kb + 64u + lane, u0, u1);
-        }
-    }
-    else
-    {
-        load(FA, PA, SA, t, 0);
-#pragma unroll 1
-        for(uint32_t kb = 0; kb < bdst; kb += 64)
-        {
-            const uint32_t t0 = t;
-            t += tstep;
-            load(FB, PB, SB, t0, 1);
-            f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
-            compute(FA, PA, SA, t0, r0, r1);
-            load(FA, PA, SA, t, 0);
-            compute(FB, PB, SB, t0, r0, r1);
-            store(kb + lane, r0, r1);
-        }
-    }
-}
-
-template<int R, int TAPS>
-__device__ __forceinline__ void ResampleRunStagedM(const WgLds<R, TAPS> &sm, const float *rdb, uint32_t m,
-    uint32_t frac0, uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane)
-{
-    switch(m)
-    {
-    case 4: ResampleRunStaged<4>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
-    case 12: ResampleRunStaged<12>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
-    case 24: ResampleRunStaged<24>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
-    default: ResampleRunStaged<48>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
-    }
-}
-
-// LoadResampledSamples, core/voice.cpp:642-824, for one real channel of a static voice, by one
-// wavefront.  Produces samplesToLoad resampled samples at w.in[kHist..]; updates prev[v] when
-// Playing.  Integer logic identical to voice_kernel.hip's LoadResampled.  When plan.prefetch is
-// set the first chunk's source samples are already on their way in `pre` (GatherStatic) and
-// `prevv` holds mPrevSamples[lane].
-template<int R, int TAPS>
-__device__ __forceinline__ void LoadResampledWave(WgLds<R, TAPS> &sm, WaveLds<R, TAPS> &w, const DeviceLayout &L,
-    uint32_t v, uint32_t lane, const VoiceHead &h, bool playing, uint32_t samplesToLoad, uint32_t samplesToMix,
-    int32_t bufferItem, bool looping, const SrcPlan &plan)
-{
-    float *rdata = w.rd;
-    float *srcBuffer = rdata + kMaxEdge;
-    float *mixing = w.in + kHist;
-    const int kind = h.rsKind;
-    const uint32_t rsM = h.rsM, rsL = h.rsL, increment = h.step;
-    int32_t intPos = h.position;
-    uint32_t fracPos = h.positionFrac;
-    // plan.prefetch: mPrevSamples and the first chunk's window (plan.bsrc samples) were parked in
-    // rdata / srcBuffer by the previous pass (ParkNextVoice)
-    if(!plan.prefetch && lane < kMaxPad) rdata[lane] = L.prev[size_t{v} * kMaxPad + lane];
-    const float *filter = L.tables + h.rsFilterOffset;
-    const uint32_t tableKey = h.rsFilterOffset * 8u + uint32_t(kind);
-    const bool staged = (kind == 2 || kind == 3) && sm.tabKey == tableKey;
-    const uint32_t sM = kind == 2 ? 4u : rsM, sL = kind == 2 ? 1u : rsL;
-    WaveSync();
-
-    bool firstPass = true;
-    for(uint32_t loaded = 0; loaded < samplesToLoad;)
-    {
-        uint32_t bdst, bsrc;
-        CalcBufferSize(fracPos, increment, samplesToLoad - loaded, bdst, bsrc);
-        uint32_t srcDelay = 0;
-        bool silent = false;
-        if(intPos < 0)
-        {
-            srcDelay = uint32_t(-intPos);
-            if(srcDelay >= bsrc)
-            {   // voice.cpp:679-697: everything needed is before the buffer start
-                for(uint32_t k = lane; k < bdst; k += 64) mixing[loaded + k] = 0.0f;
-                for(uint32_t k = lane; k < bsrc; k += 64) srcBuffer[k] = 0.0f;
-                silent = true;
-            }
-            else
-                for(uint32_t k = lane; k < srcDelay; k += 64) srcBuffer[k] = 0.0f;
-        }
-        if(silent)
-        {
-            WaveSync();
-            loaded += bdst;
-            firstPass = false;
-            if(loaded < samplesToLoad)
-            {
-                fracPos += bdst * increment;
-                const uint32_t srcOffset = fracPos >> kFracBits;
-                fracPos &= kFracMask;
-                intPos = AddSat(intPos, int32_t(srcOffset));
-            }
-            continue;
-        }
-
-        if(bufferItem < 0)
-        {   // voice.cpp:704-719: hold the available sample nearest zero
-            const uint32_t avail = bsrc < uint32_t(kMaxEdge) ? bsrc : uint32_t(kMaxEdge);
-            const uint32_t tofill = bsrc > uint32_t(kMaxEdge) ? bsrc : uint32_t(kMaxEdge);
-            if(lane == 0)
-            {
-                uint32_t best = 0;
-                for(uint32_t i = 1; i < avail; ++i)
-                    if(fabsf(srcBuffer[i]) < fabsf(srcBuffer[best])) best = i;
-                w.best = int32_t(best);
-            }
-            WaveSync();
-            const uint32_t best = uint32_t(w.best);
-            const float hold = srcBuffer[best];
-            WaveSync();
-            for(uint32_t k = best + 1 + lane; k < tofill; k += 64) srcBuffer[k] = hold;
-        }
-        else if(firstPass && plan.prefetch) {}      // already in srcBuffer (bsrc == plan.bsrc)
-        else
-        {
-            const uint32_t upos = intPos < 0 ? 0u : uint32_t(intPos);
-            FillFromBuffer<64>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos, lane);
-        }
-        firstPass = false;
-        WaveSync();
-        if(L.phaseTimes && lane == 0 && loaded == 0) L.phaseTimes[size_t{v} * 8 + 7] = __builtin_readcyclecounter();
-
-        // voice.cpp:764-769
-        if((increment == kFracOne && fracPos == 0) || (L.ablate & 2u))
-        {
-            for(uint32_t k = lane; k < bdst; k += 64) mixing[loaded + k] = srcBuffer[k];
-        }
-        else if(staged)
-        {
-            ResampleRunStagedM(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded,
-                reinterpret_cast<float*>(&w.pad[0]), lane);
-        }
-        else
-        {
-            const TabLayout lay = ReferenceTabLayout(rsM);
-            for(uint32_t k = lane; k < bdst; k += 64)
-                mixing[loaded + k] = ResampleAt<false, false>(kind, rsM, rsL, h.rsSf, filter, lay, rdata, fracPos, increment, k, bdst);
-        }
-
-        // voice.cpp:772-785: history for the next update, taken at the end-of-mix position
-        if(playing)
-        {
-            const uint32_t loadEnd = loaded + bdst;
-            if(samplesToMix > loaded && samplesToMix <= loadEnd)
-            {
-                const uint32_t dstOffset = samplesToMix - loaded;
-                const uint32_t srcOffset = uint32_t((uint64_t{dstOffset} * increment + fracPos) >> kFracBits);
-                if(lane < kMaxPad) L.prev[size_t{v} * kMaxPad + lane] = rdata[srcOffset + lane];
-            }
-        }
-        loaded += bdst;
-        if(loaded < samplesToLoad)
-        {
-            fracPos += bdst * increment;
-            const uint32_t srcOffset = fracPos >> kFracBits;
-            fracPos &= kFracMask;
-            if(intPos < 0) intPos += int32_t(srcOffset);
-            else intPos = AddSat(intPos, int32_t(srcOffset));
-            // voice.cpp:807-810: slide the last 48 source samples to the front
-            WaveSync();
-            float carry = 0.0f;
-            if(lane < kMaxPad) carry = rdata[srcOffset + lane];
-            WaveSync();
-            if(lane < kMaxPad) rdata[lane] = carry;
-        }
-        WaveSync();
-    }
-}
-
-// ---- wave-parallel dual biquad (time-invariant coefficients) ---------------------------------
-// BiquadFilter::dualProcess (core/filters/biquad.cpp:254-282) is two transposed-direct-form-II
-// sections in cascade; each is linear in its state s = (z1, z2): s' = A s + B x with
-// A = [[-a1, 1], [-a2, 0]].  Lane l owns the run of samples [l*seg, (l+1)*seg) -- seg odd, so
-// the per-lane runs hit distinct LDS banks -- and keeps it in registers for both sections:
-//   (1) M = A^seg;  (2) forced response q_l of the run from a zero state;  (3) run-start states
-//   S_l = M^l S_0 + sum_{k<l} M^(l-1-k) q_k by a 6-step Kogge-Stone scan with M, M^2, .. M^32;
-//   (4) the true recurrence from S_l.  Lanes past the last sample only produce values nobody
-// reads.  The serial loop of the reference differs from this by rounding only.
-constexpr int kBqSeg = 17;                    // ceil(1024 / 64) | 1
-struct S2 { float a, b; };
-
-__device__ __forceinline__ float BqStep(S2 &s, float x, float b0, float b1, float b2, float a1, float a2)
-{
-    const float y = __builtin_fmaf(x, b0, s.a);
-    s.a = __builtin_fmaf(x, b1, __builtin_fmaf(-y, a1, s.b));
-    s.b = __builtin_fmaf(x, b2, -y * a2);
-    return y;
-}
-__device__ __forceinline__ S2 Mv2(S2 c0, S2 c1, S2 v)          // [c0 c1] * v
-{ return S2{__builtin_fmaf(c1.a, v.b, c0.a * v.a), __builtin_fmaf(c1.b, v.b, c0.b * v.a)}; }
-
-// one section over the lane's run x[0..cnt); z1/z2: state in, state after the last sample out
-__device__ __forceinline__ void BiquadWaveScan(float (&x)[kBqSeg], uint32_t cnt, uint32_t seg, const BiquadState &f,
-    float &z1, float &z2, uint32_t lane, int lastLane)
-{
-    const float b0 = f.b0, b1 = f.b1, b2 = f.b2, a1 = f.a1, a2 = f.a2;
-    S2 m0{1.0f, 0.0f}, m1{0.0f, 1.0f};                 // columns of M = A^seg
-    for(uint32_t i = 0; i < seg; ++i)
-    {
-        m0 = S2{__builtin_fmaf(-a1, m0.a, m0.b), -a2 * m0.a};
-        m1 = S2{__builtin_fmaf(-a1, m1.a, m1.b), -a2 * m1.a};
-    }
-    S2 e{0.0f, 0.0f};
-#pragma unroll
-    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < seg) BqStep(e, x[i], b0, b1, b2, a1, a2);
-    S2 s0{z1, z2};                                    // -> M^lane S_0
-    S2 p0 = m0, p1 = m1;                              // M^(2^step)
-#pragma unroll
-    for(int step = 0; step < 6; ++step)
-    {
-        const int d = 1 << step;
-        const S2 o{__shfl_up(e.a, d), __shfl_up(e.b, d)};
-        const S2 mo = Mv2(p0, p1, o);
-        if(int(lane) >= d) { e.a += mo.a; e.b += mo.b; }
-        const S2 ms = Mv2(p0, p1, s0);
-        if(lane & uint32_t(d)) s0 = ms;
-        if(step < 5) { const S2 n0 = Mv2(p0, p1, p0), n1 = Mv2(p0, p1, p1); p0 = n0; p1 = n1; }
-    }
-    const S2 prevE{__shfl_up(e.a, 1), __shfl_up(e.b, 1)};
-    S2 st = s0;
-    if(lane > 0) { st.a += prevE.a; st.b += prevE.b; }
-#pragma unroll
-    for(int i = 0; i < kBqSeg; ++i)
-        if(uint32_t(i) < cnt) x[i] = BqStep(st, x[i], b0, b1, b2, a1, a2);
-    z1 = __shfl(st.a, lastLane);
-    z2 = __shfl(st.b, lastLane);
-}
-
-__device__ __forceinline__ void BiquadDualWaveScan(BiquadState &f0, BiquadState &f1, float *buf /* in place */,
-    uint32_t n, uint32_t lane)
-{
-    const uint32_t seg = ((n + 63u) / 64u) | 1u;      // <= kBqSeg for n <= 1024
-    const uint32_t begin = lane * seg < n ? lane * seg : n;
-    const uint32_t cnt = (begin + seg < n) ? seg : n - begin;
-    const int lastLane = int((n - 1u) / seg);
-    float x[kBqSeg];
-#pragma unroll
-    for(int i = 0; i < kBqSeg; ++i) x[i] = (uint32_t(i) < cnt) ? buf[begin + i] : 0.0f;
-    BiquadWaveScan(x, cnt, seg, f0, f0.z1, f0.z2, lane, lastLane);
-    BiquadWaveScan(x, cnt, seg, f1, f1.z1, f1.z2, lane, lastLane);
-#pragma unroll
-    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < cnt) buf[begin + i] = x[i];
-}
-
-// DoFilters (voice.cpp:255-267) for one filter pair of a voice, in place over buf[0..n):
-// settled coefficients run the wave-parallel block scan, an interpolating filter the serial
-// reference loop on lane 0; an inactive pair is cleared (voice.cpp:264-265).  `fst` = this
-// wave's 32-dword LDS scratch holding the two BiquadSlots' first 16 dwords each.
-__device__ __forceinline__ void WaveDoFilters(float *fst, BiquadSlot *slots, bool filterActive, float *buf, uint32_t n,
-    uint32_t lane)
-{
-    BiquadState f0, f1;
-    {
-        const float *a = fst, *b = fst + 16;
-        f0 = BiquadState{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], __builtin_bit_cast(int32_t, a[12])};
-        f1 = BiquadState{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11], __builtin_bit_cast(int32_t, b[12])};
-    }
-    if(filterActive)
-    {
-        if(f0.counter <= 0 && f1.counter <= 0)
-        {
-            BiquadDualWaveScan(f0, f1, buf, n, lane);
-            if(lane == 0) { slots[0].f.z1 = f0.z1; slots[0].f.z2 = f0.z2; slots[1].f.z1 = f1.z1; slots[1].f.z2 = f1.z2; }
-        }
-        else
-        {
-            if(lane == 0) BiquadDualInterp(f0, f1, buf, buf, n);
-            if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
-        }
-    }
-    else
-    {   // skip the store when the pair already is clear
-        const bool clean0 = f0.z1 == 0.0f && f0.z2 == 0.0f && f0.counter == 0 && f0.b0 == f0.tb0 && f0.b1 == f0.tb1
-            && f0.b2 == f0.tb2 && f0.a1 == f0.ta1 && f0.a2 == f0.ta2;
-        const bool clean1 = f1.z1 == 0.0f && f1.z2 == 0.0f && f1.counter == 0 && f1.b0 == f1.tb0 && f1.b1 == f1.tb1
-            && f1.b2 == f1.tb2 && f1.a1 == f1.ta1 && f1.a2 == f1.ta2;
-        if(!(clean0 && clean1) && lane == 0)
-        {
-            BiquadClear(f0); BiquadClear(f1);
-            slots[0].f = f0; slots[1].f = f1;
-        }
-    }
-}
-
-// NfcFilterN::process, core/filters/nfc.cpp:222-288, section of order o over src[0..n) -> dst, on
-// one lane in the reference's operation order (the sections are short recurrences; a block
-// scan like the biquads' is the obvious next step)
-__device__ __forceinline__ void NfcSerial(NfcState &st, uint32_t o, const float *src, float *dst, uint32_t n)
-{
-    const float a0 = st.a[o][0], a1 = st.a[o][1], a2 = st.a[o][2], a3 = st.a[o][3], a4 = st.a[o][4];
-    const float b1 = st.b[o][1], b2 = st.b[o][2], b3 = st.b[o][3], b4 = st.b[o][4];
-    float z0 = st.z[o][0], z1 = st.z[o][1], z2 = st.z[o][2], z3 = st.z[o][3];
-    if(o == 1)
-    {
-        for(uint32_t i = 0; i < n; ++i)
-        {
-            const float y = src[i] * a0 - a1 * z0;
-            dst[i] = y + b1 * z0;
-            z0 += y;
-        }
-    }
-    else
-    {
-        for(uint32_t i = 0; i < n; ++i)
-        {
-            const float y0 = src[i] * a0 - a1 * z0 - a2 * z1;
-            const float out0 = y0 + b1 * z0 + b2 * z1;
-            z1 += z0;
-            z0 += y0;
-            if(o == 2) { dst[i] = out0; continue; }
-            if(o == 3)
-            {
-                const float y1 = out0 - a3 * z2;
-                dst[i] = y1 + b3 * z2;
-                z2 += y1;
-                continue;
-            }
-            const float y1 = out0 - a3 * z2 - a4 * z3;
-            dst[i] = y1 + b3 * z2 + b4 * z3;
-            z3 += z2;
-            z2 += y1;
-        }
-    }
-    st.z[o][0] = z0; st.z[o][1] = z1; st.z[o][2] = z2; st.z[o][3] = z3;
-}
-
 // One line's share of a stream row's gain block (kernels.hpp LineBlockDwords): contributions of
 // several MixSamples calls onto the same row and line add up -- the constant gains, and for
 // the ramped frames the per-frame values (a contribution without a ramp adds its constant there)
@@ -670,11 +74,15 @@ __device__ __forceinline__ void StoreRowBlock(uint32_t *blk, uint32_t ls, uint32
 // stream row too -- the unfiltered resampled samples shared by all sends (and the direct path)
 // whose filter is inactive, or its own filtered copy -- with a gain block over the wet lines.
 // Stream rows of a voice: [0] unfiltered, [1] direct-filtered (dry-line contexts), [2+i] send i filtered.
-template<int R, int TAPS, int NL, bool SENDS>
+// MF: the dual-ear FIR of HRTF voices (IrSize <= 64) on the matrix pipe (FirMfma64, dev_wave.hpp) instead
+// of packed VALU FMAs: the matrix pipe then works for one wavefront of a SIMD while the other's
+// resampler and filters own the VALU issue slots.
+template<int R, int TAPS, int NL, bool SENDS, bool MF = false>
 __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo)
 {
-    using WL = WaveLds<R, TAPS>;
-    __shared__ WgLds<R, TAPS> sm;
+    static_assert(!MF || (R == 17 && TAPS == 64 && NL == 0), "the matrix-pipe FIR is the 64-tap HRTF form");
+    using WL = WaveLds<R, TAPS, MF>;
+    __shared__ WgLds<R, TAPS, MF> sm;
     const uint32_t t = threadIdx.x;
     const uint32_t lane0 = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -729,9 +137,14 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     VoiceHead headK{};
     if(keyVoice < L.numVoices) headK = LoadHeadScalar(L.ctl + keyVoice);
 
-    f2 acc[R];
+    f2 acc[MF ? 1 : R];
 #pragma unroll
-    for(int r = 0; r < R; ++r) acc[r] = f2{0.0f, 0.0f};
+    for(int r = 0; r < (MF ? 1 : R); ++r) acc[r] = f2{0.0f, 0.0f};
+    f4 accM[2][5];                                   // MF: FirMfma64's tiles, ear x (4 main + ring-out)
+#pragma unroll
+    for(int e = 0; e < 2; ++e)
+#pragma unroll
+        for(int b = 0; b < 5; ++b) accM[e][b] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     f2 accO[WL::kQ];
 #pragma unroll
     for(int q = 0; q < WL::kQ; ++q) accO[q] = f2{0.0f, 0.0f};
@@ -762,6 +175,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         float preN[kPre];
         float prevN = 0.0f, histN = 0.0f, fstN = 0.0f;
         f2 oldN[TAPS / 64];
+        f2 hN = {0.0f, 0.0f};                        // MF: the next voice's target HRIR, tap = lane
         bool dirtyN = false;
 #pragma unroll
         for(int q = 0; q < TAPS / 64; ++q) oldN[q] = f2{0.0f, 0.0f};
@@ -790,6 +204,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 if constexpr (NL == 0)
                 {
                     histN = L.hist[size_t{vn} * kHist + lane];
+                    if constexpr (MF)
+                        hN = (lane < L.irSize) ? reinterpret_cast<const f2*>(L.hrtfTgt + size_t{vn} * irStride * 2)[lane] : f2{0.0f, 0.0f};
                     dirtyN = (headN.flags & kFlagHrtfDirty) != 0;
                     const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{vn} * irStride * 2);
     #pragma unroll
@@ -1037,9 +453,24 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             const bool merged = !dirty;
 
             // x'[i] = (In[64 - dL + i], In[64 - dR + i]) * g(i); zero pads on both sides
+            // (MF: planar per ear, frame i at xp[e][68 (i/64 + 1) + i%64]; lane + 64 j -> 68 (j + 1) + lane)
+            auto putX = [&](uint32_t j /* frame = lane + 64 j */, float xl, float xr)
+            {
+                if constexpr (MF) { w.xp[0][kXpStride * (j + 1u) + lane] = xl; w.xp[1][kXpStride * (j + 1u) + lane] = xr; }
+                else w.x2[TAPS + lane + 64u * j] = f2{xl, xr};
+            };
+            if constexpr (MF)
+            {
+                w.xp[0][lane] = 0.0f; w.xp[1][lane] = 0.0f;
+                // frames N..1023 (short updates): the lane's first frame at or after N
+                for(uint32_t i = N + ((lane + 64u - (N & 63u)) & 63u); i < uint32_t(kLine); i += 64) putX(i >> 6, 0.0f, 0.0f);
+            }
+            else
+            {
             w.x2[lane] = f2{0.0f, 0.0f};
             if(TAPS > 64) w.x2[64 + lane] = f2{0.0f, 0.0f};
             for(uint32_t k = TAPS + N + lane; k < uint32_t(WL::kX); k += 64) w.x2[k] = f2{0.0f, 0.0f};
+            }
             if(!(L.ablate & 16u))
             {
                 const float *inL = w.in + (kHist - dL), *inR = w.in + (kHist - dR);
@@ -1053,7 +484,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                         if(merged && oldOn) g += oldStep * float(fademix - i);
                     }
                     else g = gainAfterBlend + mainStep * float(i - fademix);
-                    w.x2[TAPS + i] = f2{inL[i] * g, inR[i] * g};
+                    putX(0u, inL[i] * g, inR[i] * g);
                 }
                 const float gbase = gainAfterBlend - mainStep * float(fademix);
                 // all reads first, then all writes: in and x2 are members of one LDS object, so
@@ -1071,7 +502,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 {
                     const uint32_t i = lane + 64u * uint32_t(j + 1);
                     const float g = __builtin_fmaf(mainStep, float(i), gbase);
-                    if(i < N) w.x2[TAPS + i] = f2{xl[j] * g, xr[j] * g};
+                    if(i < N) putX(uint32_t(j + 1), xl[j] * g, xr[j] * g);
                 }
             }
             // old-filter fade-out inputs (one per lane) and coefficients, replaced filters only
@@ -1151,6 +582,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             }
             // zero padding of the old-filter coefficient array (never overwritten)
             for(uint32_t k = lane; k < uint32_t(TAPS + 128); k += 64) w.cold[k] = f2{0.0f, 0.0f};
+            if constexpr (MF)
+            {   // zero padding of the HRIR copies: hp[e][0..15] and hp[e][80..95]
+                if(lane < 16u) { w.hp[0][lane] = 0.0f; w.hp[1][lane] = 0.0f; w.hp[0][80u + lane] = 0.0f; w.hp[1][80u + lane] = 0.0f; }
+            }
             __syncthreads();
         }
 
@@ -1160,6 +595,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             stamp(4);
             cf16 *co = (cf16*)(uintptr_t)(L.hrtfTgt + size_t{v} * irStride * 2);
             if(NL > 0 || (L.ablate & 1u)) {}
+            else if constexpr (MF)
+                FirMfma64<kXpStride, kHpLen>(accM, w.xp[0], w.xp[1], w.hp[0], w.hp[1], lane);
             else if(irStride == uint32_t(TAPS))
                 FirMainPk<R, TAPS>(acc, &w.x2[TAPS + R * lane], co);
             else
@@ -1207,6 +644,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             if constexpr (NL == 0)
             {
                 w.in[lane] = histN;
+                if constexpr (MF) { w.hp[0][16u + lane] = hN.x; w.hp[1][16u + lane] = hN.y; }
                 if(dirtyN)
                 {
 #pragma unroll
@@ -1284,8 +722,25 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     {
         f2 *dump = w.x2;                     // [frame] = (L, R), frames < 64R
         WaveSync();
+        if constexpr (MF)
+        {   // FirMfma64's tiles -> frames
+            const uint32_t rr = lane0 & 15u, q4 = lane0 >> 4;
+#pragma unroll
+            for(int b = 0; b < 4; ++b)
+#pragma unroll
+                for(int i = 0; i < 4; ++i)
+                    dump[64u * (4u * q4 + uint32_t(i)) + 16u * uint32_t(b) + rr] = f2{accM[0][b][i], accM[1][b][i]};
+            if(lane0 < 16u)
+            {
+#pragma unroll
+                for(int i = 0; i < 4; ++i) dump[1024u + 16u * uint32_t(i) + lane0] = f2{accM[0][4][i], accM[1][4][i]};
+            }
+        }
+        else
+        {
 #pragma unroll
         for(int r = 0; r < R; ++r) dump[R * lane0 + r] = acc[r];
+        }
         WaveSync();
 #pragma unroll
         for(int q = 0; q < WL::kQ; ++q)
@@ -1484,17 +939,23 @@ bool WaveKernelApplies(bool exact, const DeviceLayout &L)
 
 const char *WaveKernelName(const DeviceLayout &L)
 {
+    if(L.blockVoices) return "VoiceBlockKernel";
     const bool sends = L.numSends != 0;
     if(!L.hrtf) return sends ? "VoiceWaveKernel<17, 64, 1, true>" : "VoiceWaveKernel<17, 64, 1, false>";
+    if(L.irStride <= 64 && L.firMfma) return sends ? "VoiceWaveKernel<17, 64, 0, true, true>" : "VoiceWaveKernel<17, 64, 0, false, true>";
     if(L.irStride <= 64) return sends ? "VoiceWaveKernel<17, 64, 0, true>" : "VoiceWaveKernel<17, 64, 0, false>";
     return sends ? "VoiceWaveKernel<18, 128, 0, true>" : "VoiceWaveKernel<18, 128, 0, false>";
 }
 
 uint32_t WaveKernelGroups(const DeviceLayout &L)
-{ return (L.numVoices + kWWaves * L.waveVoices - 1u) / (kWWaves * L.waveVoices); }
+{
+    if(L.blockVoices) return BlockKernelGroups(L);
+    return (L.numVoices + kWWaves * L.waveVoices - 1u) / (kWWaves * L.waveVoices);
+}
 
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo)
 {
+    if(L.blockVoices) return LaunchVoiceBlock(s, L, samplesToDo);
     const uint32_t groups = WaveKernelGroups(L);
     const bool sends = L.numSends != 0;
     const dim3 grid(groups), block(kWThreads);
@@ -1502,6 +963,11 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     {
         if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, L, samplesToDo);
         else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false>), grid, block, 0, s, L, samplesToDo);
+    }
+    else if(L.irStride <= 64 && L.firMfma)
+    {
+        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true>), grid, block, 0, s, L, samplesToDo);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true>), grid, block, 0, s, L, samplesToDo);
     }
     else if(L.irStride <= 64)
     {

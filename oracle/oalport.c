@@ -1727,6 +1727,18 @@ int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process)
     return 0;
 }
 
+int oal_scene_post_process(oal_scene *s, uint32_t samples_to_do)
+{   /* DeviceBase::Process(HrtfPostProcess) alu.cpp:289-298 */
+    if(!s->desc.hrtf) return -1;
+    const unsigned csr = fpu_enter();
+    float *left = s->mix + (size_t)s->desc.num_dry_channels * LINE;
+    float *right = left + LINE;
+    mix_direct_hrtf(left, right, s->mix, s->desc.num_dry_channels, s->accum, s->dsplit, s->dhfscale,
+        s->dcoeffs, s->dirsize, samples_to_do);
+    fpu_leave(csr);
+    return 0;
+}
+
 const float *oal_scene_dry(oal_scene *s) { return s->mix; }
 const float *oal_scene_wet(oal_scene *s, int slot) { return s->wet + (size_t)slot * s->desc.wet_channels * LINE; }
 const float *oal_scene_hrtf_accum(oal_scene *s) { return s->accum; }

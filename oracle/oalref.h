@@ -204,6 +204,10 @@ int oal_scene_set_voice_state(oal_scene *s, int voice, int vstate);
 /* One update: zero Dry/Real + wet buses, Voice::mix for every Playing|Stopping voice in order,
  * then (HRTF device, post_process != 0) MixDirectHrtf.  (alc/alu.cpp:2177-2273,2412-2459) */
 int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process);
+/* DeviceBase::Process(HrtfPostProcess) alone (alc/alu.cpp:289-298): for scenes whose effect slots
+ * add into the dry lines between the voice loop and the post-process (alu.cpp:2209-2257).  The dry
+ * block oal_scene_dry() returns may be written by the caller in between (effects mix into it). */
+int oal_scene_post_process(oal_scene *s, uint32_t samples_to_do);
 /* Views valid until the next call. */
 const float *oal_scene_dry(oal_scene *s);        /* (num_dry+num_real) x 1024 */
 const float *oal_scene_wet(oal_scene *s, int slot);  /* wet_channels x 1024 */

@@ -710,6 +710,16 @@ int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process)
     return 0;
 }
 
+int oal_scene_post_process(oal_scene *s, uint32_t samples_to_do)
+{
+    if(!s->desc.hrtf) return -1;
+    auto &dev = *s->dev;
+    auto const fpuctl = FPUCtl{};
+    auto &proc = std::get<HrtfPostProcess>(dev.mPostProcess);
+    dev.Process(proc, samples_to_do);
+    return 0;
+}
+
 const float *oal_scene_dry(oal_scene *s) { return s->dev->MixBuffer[0].data(); }
 const float *oal_scene_wet(oal_scene *s, int slot)
 { return s->slots.at(static_cast<size_t>(slot)).mWetBuffer[0].data(); }

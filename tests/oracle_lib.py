@@ -184,6 +184,7 @@ class OracleLib:
                                                            C.c_float]
         L.oal_scene_set_voice_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.oal_scene_mix.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.oal_scene_post_process.argtypes = [C.c_void_p, C.c_uint32]
         for n in ("oal_scene_dry", "oal_scene_hrtf_accum"):
             getattr(L, n).argtypes = [C.c_void_p]
             getattr(L, n).restype = f32p
@@ -382,9 +383,17 @@ class Scene:
     def mix(self, samples_to_do=BUFFER_LINE, post_process=False):
         assert self.lib.L.oal_scene_mix(self.h, samples_to_do, 1 if post_process else 0) == 0
 
+    def post_process(self, samples_to_do=BUFFER_LINE):
+        """The HRTF post-process alone, after effect slots mixed into dry_view()."""
+        assert self.lib.L.oal_scene_post_process(self.h, samples_to_do) == 0
+
     def dry(self):
+        return self.dry_view().copy()
+
+    def dry_view(self):
+        """The device's dry + real lines themselves (writable: effects add into them)."""
         n = self.desc.num_dry_channels + self.desc.num_real_channels
-        return np.ctypeslib.as_array(self.lib.L.oal_scene_dry(self.h), shape=(n, BUFFER_LINE)).copy()
+        return np.ctypeslib.as_array(self.lib.L.oal_scene_dry(self.h), shape=(n, BUFFER_LINE))
 
     def wet(self, slot):
         return np.ctypeslib.as_array(self.lib.L.oal_scene_wet(self.h, slot),

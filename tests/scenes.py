@@ -7,12 +7,14 @@ import oracle_lib as ol
 
 
 def run_scene(L, MHR, hrtf, fmt, resampler, steps, n_updates, nvoices, rng_seed, sends=0, todo=1024,
-               nonloop=False, stop_at=None, move=True):
+               nonloop=False, stop_at=None, move=True, kernel_names=None):
     rng = np.random.default_rng(rng_seed)
     if hrtf:
         L.hrtf_load(MHR)
     sc = L.make_scene(num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0, num_sends=sends,
                       num_slots=2 if sends else 0, wet_channels=4, hrtf=hrtf)
+    if kernel_names is not None and hasattr(sc, "voice_kernel_name"):
+        kernel_names.append(sc.voice_kernel_name())           # which product kernel mixes this scene
     if hrtf:
         cc = np.zeros((4, 128, 2), np.float32)
         cc[:, :64] = rng.uniform(-0.2, 0.2, (4, 64, 2))

@@ -1,0 +1,183 @@
+"""DIRECT parity at BASELINE.json's full sizes: `bench.build_scene` (the scene bench.py times) and the
+SAME scene in the compiled reference (Voice::mix for every voice, the reference's own ReverbState /
+ConvolutionState on the slots, MixDirectHrtf), several updates through `oalgpu_mix_update` with the
+post-process -- the pipelined two-stream path the bench line measures -- and after every update
+
+  * every bus compared sample by sample: dry + real lines (after the effects and the post-process),
+    every slot's wet bus, the carried HRTF accumulator;
+  * every voice's integer state (play state, position, fraction, buffer, fade flag) compared exactly.
+
+No shard arithmetic: the reference mixes all 4096 / 8192 voices (~60 ms per update on one core).
+
+  config 2: 4096 voices, bsinc24 -> 5 dry lines              alc/alu.cpp:2177-2273, core/voice.cpp:934-984
+  config 3: 4096 HRTF voices, on the synthetic data set AND on the reference's own Default HRTF.mhr
+  config 4: 8192 voices, v % 5 sends into 4 EAX reverb slots  alc/effects/reverb.cpp:1813-1883
+  config 5: 4096 HRTF voices + a 65 536-tap convolution slot  alc/effects/convolution.cpp:623-716
+
+Tolerance (sums over thousands of voices in a different order than the reference's serial loop, FAST
+math): |gpu - ref| <= 2e-5 * max|ref block| + 1e-7 per compared block, the figure of every other
+multi-voice test -- widened for the HRTF accumulator and the lines fed from it to
+max(2e-5, 2.5 * sqrt(voices * IrSize / 12) * 2^-23) * max|ref| (4.4e-5 at 4096 voices x 64 taps): that is
+the random-walk rounding noise the REFERENCE itself carries there, because MixHrtf adds every tap
+product straight into the shared fp32 accumulator (tests/test_tolerance_model.py derives and measures
+it).  Integer state: exact."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REAL_MHR = os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr")
+
+UPDATES = 4
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    if not ol.available("ref"):
+        pytest.skip("needs the compiled reference (oracle/_ref)")
+    L = ol.load("ref")
+    L.L.oal_set_simd(1)
+    return L
+
+
+def build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir=None):
+    """bench.build_scene, restated on the reference: same buffers, voices, direct-HRTF decoder."""
+    hrtf = config in (3, 5)
+    nsends = {4: 4, 5: 1}.get(config, 0)
+    if hrtf:
+        L.hrtf_load(mhr_path)
+    sc = ol.Scene(L, sample_rate=48000, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0,
+                  num_sends=nsends, num_slots=nsends, wet_channels=4, hrtf=hrtf)
+    effects = []
+    if config == 4:
+        for _ in range(4):
+            rev = L.make_reverb(5)
+            rev.update(ol.ReverbProps.make(), 1.0)
+            effects.append(rev)
+    if config == 5:
+        conv = L.make_convolution(4, conv_ir)
+        conv.update(1.0)
+        effects.append(conv)
+    if hrtf:
+        rng = np.random.default_rng(1234)
+        cc = np.zeros((4, 128, 2), np.float32)
+        cc[:, :64] = rng.uniform(-0.2, 0.2, (4, 64, 2)) * np.exp(-np.arange(64) / 12.0)[None, :, None]
+        sc.set_direct_hrtf(cc, [1.0, 0.8, 0.8, 0.8], 400.0 / 48000.0, 64)
+    bufs = synth.scene_buffers(config, nvoices)
+    handles = [sc.add_buffer(b, ol.FMT_FLOAT) for b in bufs]
+    script = synth.SceneScript(config, nvoices, 0)
+    for v in range(nvoices):
+        sc.add_voice(handles[script.buffer_of(v, len(handles))], True, position=script.start_position(v))
+    return sc, script, effects
+
+
+def close_to(got, want, what, terms=(1, 1)):
+    """terms = (voices, serial fp32 adds per voice and output sample in the reference)"""
+    from test_tolerance_model import multi_voice_tolerance
+    scale = float(np.abs(want).max())
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+    bound = multi_voice_tolerance(terms[0], terms[1], scale)
+    print(f"{what}: max err {err:.3e} = {err / max(scale, 1e-30):.2e} of max|ref| {scale:.3e} (bound {bound:.3e})")
+    assert err <= bound, f"{what}: max err {err:.3e}, bound {bound:.3e} (max|ref| {scale:.3e})"
+    return scale
+
+
+def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024)):
+    import oalgpu
+    from oalgpu import synth
+    import bench
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    L = _oracle()
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    with open(mhr_path, "rb") as f:
+        mhr = f.read()
+    api._mhr = mhr
+    hrtf = config in (3, 5)
+    nslots = {4: 4, 5: 1}.get(config, 0)
+
+    gsc, gscript = bench.build_scene(oalgpu, synth, api, config, nvoices, 0, mhr, 0)
+    conv_ir = None
+    if config == 5:
+        # the reference pans a mono response to the front (ConvolutionProps orientation, convolution.cpp:511-620)
+        lcg = synth.Lcg(0x5EED0005)
+        conv_ir = np.array([lcg.uniform(-1.0, 1.0) for _ in range(65536)], np.float32)
+        conv_ir *= np.exp(-np.arange(65536) / 12000.0).astype(np.float32) * 0.05
+        gsc.effects[0].set_target_gains(L.direction_coeffs([0.0, 0.0, -1.0])[:4])
+    osc, oscript, oeffects = build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir)
+
+    allv = list(range(nvoices))
+    moving = [v for v in allv if gscript.is_moving(v)]
+    sounded = False
+    for k in range(len(todo)):
+        n = todo[k]
+        voices = allv if k == 0 else moving
+        gsc.set_params_batch(voices, bench.param_array(oalgpu, gscript, voices, k))
+        for v in voices:
+            osc.set_params(v, oscript.fill(ol.VoiceParams(), v, k))
+        # ---- the product: one pipelined update, effects and post-process included
+        gsc.mix(n, post_process=True)
+        # ---- the reference: voice loop, then the slots' effects into the dry lines, then the post-process
+        osc.mix(n, post_process=False)
+        wets = [osc.wet(s) for s in range(nslots)]
+        dry = osc.dry_view()
+        if config == 4:
+            for s in range(4):
+                oeffects[s].process_n(np.ascontiguousarray(wets[s][:4]), dry[:5], n)
+        if config == 5:
+            oeffects[0].process(wets[0][0, :n], dry[:4])
+        if hrtf:
+            osc.post_process(n)
+        want_dry = osc.dry()
+        got_dry = gsc.dry()
+        hrtf_terms = (nvoices, 64) if hrtf else (nvoices, 1)      # RealOut L/R come out of the HRTF accumulator
+        scale = close_to(got_dry[:, :n], want_dry[:, :n], f"config {config} update {k}: dry/real lines", hrtf_terms)
+        sounded = sounded or scale > 0.01
+        for s in range(nslots):
+            close_to(gsc.wet(s)[:, :n], wets[s][:, :n], f"config {config} update {k}: wet bus of slot {s}", (nvoices, 1))
+        if hrtf:
+            close_to(gsc.hrtf_accum(), osc.hrtf_accum(), f"config {config} update {k}: carried HRTF accumulator", (nvoices, 64))
+        # integer state of every voice, exact
+        for v in range(nvoices):
+            g, o = gsc.voice_state(v), osc.voice_state(v)
+            assert (g.play_state, g.position, g.position_frac, g.has_buffer, g.fading) == \
+                (o.play_state, o.position, o.position_frac, o.has_buffer, o.fading), (config, k, v)
+    assert sounded, "the scene must actually sound"
+    # float state of a sample of voices after the last update
+    for v in range(0, nvoices, 97):
+        g, o = gsc.voice_state(v), osc.voice_state(v)
+        prev_g, prev_o = np.array(g.prev_samples[:]), np.array(o.prev_samples[:])
+        assert np.abs(prev_g - prev_o).max() <= 2e-5 * max(1.0, np.abs(prev_o).max()), v
+        if hrtf:
+            hg, ho = np.array(g.hrtf_history[:]), np.array(o.hrtf_history[:])
+            assert np.abs(hg - ho).max() <= 2e-5 * max(1.0, np.abs(ho).max()) + 1e-7, v
+            assert tuple(g.hrtf_old_delay) == tuple(o.hrtf_old_delay), v
+    for e in oeffects:
+        e.close()
+    gsc.close()
+    osc.close()
+
+
+def test_config2_4096_voices_five_dry_lines(synth_mhr):
+    run_config(2, 4096, synth_mhr)
+
+
+@pytest.mark.parametrize("data_set", ["synthetic", "Default HRTF.mhr"])
+def test_config3_4096_hrtf_voices(synth_mhr, data_set):
+    if data_set == "synthetic":
+        run_config(3, 4096, synth_mhr)
+    else:
+        assert os.path.exists(REAL_MHR), "tests/golden/default_hrtf.mhr is a committed fixture"
+        run_config(3, 4096, REAL_MHR, todo=(1024, 1024, 1000, 1024))
+
+
+def test_config4_8192_voices_four_reverb_slots(synth_mhr):
+    run_config(4, 8192, synth_mhr)
+
+
+def test_config5_4096_hrtf_voices_and_a_65536_tap_convolution(synth_mhr):
+    run_config(5, 4096, synth_mhr)
