@@ -82,44 +82,104 @@ def param_array(oalgpu, script, voices, update):
     return arr
 
 
-def cpu_baseline(synth, config_id, nvoices, target_seconds=12.0):
-    """The reference CPU mixer (compiled reference if it travelled, else the C restatement) on
-    the same scene, single thread -- the reference's real operating mode."""
+def _cpu_mix_worker(config_id, voice_base, nvoices, mhr_path, updates, target_seconds):
+    """One replica of the reference CPU mixer on voices [voice_base, voice_base + nvoices) of the
+    scene; returns (updates, seconds inside Voice::mix + MixDirectHrtf, oracle kind)."""
     import oracle_lib as ol
+    from oalgpu import synth
     which = "ref" if ol.available("ref") else "port"
-    if not ol.available(which):
-        return None
     L = ol.load(which)
     L.L.oal_set_simd(1)
     hrtf = config_id == 3
-    with tempfile.TemporaryDirectory() as td:
-        if hrtf:
-            L.hrtf_load(synth.write_synth_mhr(os.path.join(td, "synth.mhr")))
-        sc = ol.Scene(L, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0, hrtf=hrtf)
-        bufs = synth.scene_buffers(config_id, nvoices)
-        handles = [sc.add_buffer(b, ol.FMT_FLOAT) for b in bufs]
-        script = synth.SceneScript(config_id, nvoices)
-        for v in range(nvoices):
-            sc.add_voice(handles[script.buffer_of(v, len(handles))], True, position=script.start_position(v))
-            sc.set_params(v, script.fill(ol.VoiceParams(), v, 0))
-        moving = [v for v in range(nvoices) if script.is_moving(v)]
-        sc.mix(UPDATE_SAMPLES, post_process=hrtf)          # warm-up (not fading yet)
+    if hrtf:
+        L.hrtf_load(mhr_path)
+    sc = ol.Scene(L, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0, hrtf=hrtf)
+    bufs = synth.scene_buffers(config_id, max(nvoices, 256))
+    handles = [sc.add_buffer(b, ol.FMT_FLOAT) for b in bufs]
+    script = synth.SceneScript(config_id, nvoices, voice_base)
+    for v in range(nvoices):
+        sc.add_voice(handles[script.buffer_of(v, len(handles))], True, position=script.start_position(v))
+        sc.set_params(v, script.fill(ol.VoiceParams(), v, 0))
+    moving = [v for v in range(nvoices) if script.is_moving(v)]
+    sc.mix(UPDATE_SAMPLES, post_process=hrtf)          # warm-up (not fading yet)
+    if updates is None:
         t0 = time.perf_counter()
         sc.mix(UPDATE_SAMPLES, post_process=hrtf)
         one = time.perf_counter() - t0
         updates = int(max(3, min(200, target_seconds / max(one, 1e-6))))
-        mix_time = 0.0
-        for k in range(updates):
-            for v in moving:                               # parameter side is not timed
-                sc.set_params(v, script.fill(ol.VoiceParams(), v, k + 2))
+    mix_time = 0.0
+    for k in range(updates):
+        for v in moving:                               # parameter side is not timed
+            sc.set_params(v, script.fill(ol.VoiceParams(), v, k + 2))
+        t0 = time.perf_counter()
+        sc.mix(UPDATE_SAMPLES, post_process=hrtf)
+        mix_time += time.perf_counter() - t0
+    sc.close()
+    return updates, mix_time, L.kind
+
+
+def _cpu_replica(args):
+    return _cpu_mix_worker(*args)
+
+
+def host_cpu_info():
+    """(physical cores, logical cpus, model name) of this host, from /proc/cpuinfo."""
+    cores, logical, model = set(), 0, ""
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "processor":
+                logical += 1
+            elif key == "model name" and not model:
+                model = val
+            elif key == "physical id":
+                phys = val
+            elif key == "core id":
+                core = val
+                cores.add((phys, core))
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (logical or 1)
+    return min(len(cores) or avail, avail), avail, model
+
+
+def cpu_baseline(config_id, nvoices, mhr_path, target_seconds=10.0):
+    """The reference CPU mixer (compiled reference if it travelled, else the C restatement) on the same
+    scene: (a) ONE thread -- the reference's real operating mode (one mixer thread per device); (b) P
+    replicas, one per physical core of this host, the voices split evenly among them."""
+    import multiprocessing as mp
+    import oracle_lib as ol
+    which = "ref" if ol.available("ref") else "port"
+    if not ol.available(which):
+        return None
+    updates, mix_time, kind = _cpu_mix_worker(config_id, 0, nvoices, mhr_path, None, target_seconds)
+    out = {"value": nvoices * updates / mix_time, "unit": "voices/s", "cores": 1,
+           "kind": "reference" if kind == "reference" else "port",
+           "sample": f"{nvoices} voices x {updates} updates of the same scene, 1 thread, "
+                     f"{mix_time:.1f} s of Voice::mix + MixDirectHrtf"}
+    cores, logical, model = host_cpu_info()
+    out["cpu_model"] = model
+    if cores > 1:
+        per = (nvoices + cores - 1) // cores
+        n_all = int(max(3, min(4000, updates * cores // 2)))      # ~half the one-core leg's time per replica
+        jobs = [(config_id, b, min(per, nvoices - b), mhr_path, n_all, 0.0)
+                for b in range(0, nvoices, per)]
+        try:
+            ctx = mp.get_context("fork")
             t0 = time.perf_counter()
-            sc.mix(UPDATE_SAMPLES, post_process=hrtf)
-            mix_time += time.perf_counter() - t0
-        sc.close()
-    return {"value": nvoices * updates / mix_time, "unit": "voices/s", "cores": 1,
-            "kind": "reference" if L.kind == "reference" else "port",
-            "sample": f"{nvoices} voices x {updates} updates of the same scene, 1 thread, "
-                      f"{mix_time:.1f} s of Voice::mix + MixDirectHrtf"}
+            with ctx.Pool(len(jobs)) as pool:
+                res = pool.map(_cpu_replica, jobs)
+            wall = time.perf_counter() - t0
+            slowest = max(r[1] for r in res)           # replicas run side by side: the update rate is the slowest one's
+            out["all_cores"] = {"value": nvoices * jobs[0][4] / slowest, "unit": "voices/s", "cores": len(jobs),
+                                "logical_cpus": logical, "cpu_model": model,
+                                "sample": f"{len(jobs)} replicas x {per} voices x {jobs[0][4]} updates side by side, "
+                                          f"slowest replica {slowest:.2f} s inside the mixer ({wall:.1f} s wall with set-up)"}
+        except Exception as e:                          # a sandbox without fork/semaphores: report the one-core leg only
+            out["all_cores"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -132,6 +192,9 @@ def main():
     ap.add_argument("--math", default="fast", choices=("fast", "exact"))
     ap.add_argument("--vpg", type=int, default=0, help="voices per workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mhr", default="default", choices=("default", "synth"),
+                    help="HRTF data set: the reference's Default HRTF.mhr (tests/golden/default_hrtf.mhr) or the synthetic one")
+    ap.add_argument("--repeats", type=int, default=5, help="extra K-step blocks timed after the contract's one (spread)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,7 +213,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
     torch.cuda.set_device(local_rank)
     api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank)
-    mhr = synth.synth_mhr_bytes()
+    real_mhr = os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr")
+    use_real = args.mhr == "default" and os.path.exists(real_mhr)
+    if use_real:
+        with open(real_mhr, "rb") as f:
+            mhr = f.read()
+    else:
+        mhr = synth.synth_mhr_bytes()
     api._mhr = mhr
     V = args.voices if args.voices else (8192 if args.config == 4 else 4096)
     hrtf = args.config in (3, 5)
@@ -216,6 +285,37 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- spread: the same K-step block a few more times (each bracketed like the contract's one)
+    extra = []
+    for r in range(max(0, args.repeats)):
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + (r + 1) * args.steps + k)
+        fence()
+        e = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([e], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e = float(tt.item())
+        extra.append(e / args.steps * 1e3)
+
+    # ---- end-to-end latency of ONE update through the boundary as a host uses it: the moving voices'
+    # oalgpu_voice_params records go in from host memory (biquad design + H2D inside
+    # oalgpu_voice_set_params), the update runs, the output lines come back (D2H + sync); nothing
+    # overlaps.  Reported beside the throughput figure, never as `value`.
+    e2e_ms = None
+    if world == 1 and moving:
+        recs = [param_array(oalgpu, script, moving, 500 + k) for k in range(8)]
+        for k in range(3):
+            sc.set_params_batch(moving, recs[k]); sc.mix(UPDATE_SAMPLES, post_process=post); sc.dry()
+        t0 = time.perf_counter()
+        n_e2e = 40
+        for k in range(n_e2e):
+            sc.set_params_batch(moving, recs[k % len(recs)])
+            sc.mix(UPDATE_SAMPLES, post_process=post)
+            sc.dry()                                       # oalgpu_read_dry: D2H of the dry + real lines, synchronises
+        e2e_ms = (time.perf_counter() - t0) / n_e2e * 1e3
+
     # ---- instrumented pass: HIP events on the context's stream around each voice-kernel launch
     sc.set_timing(True)
     vk = []
@@ -244,8 +344,10 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "voice_kernel_traffic.json")))
-            if tj.get("config") == args.config and tj.get("voices") == V:
-                traffic = tj["hbm_bytes_per_launch"]
+            ent = tj.get("configs", {}).get(str(args.config), tj)
+            if ent.get("config", args.config) == args.config and ent.get("voices") == V \
+                    and ent.get("kernel", sc.voice_kernel_name()) == sc.voice_kernel_name():
+                traffic = ent["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -260,20 +362,29 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "hbm_roofline_frac": hbm_achieved / HBM_PEAK_GBS,     # the second half of the metric string
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {V} mono f32 voices per GPU "
                                    f"(44.1k->48k, bsinc24"
-                                   + (", HRTF synthetic .mhr with Default-HRTF geometry irSize 64, "
-                                      "dual-ear FIR + MixDirectHrtf" if hrtf else ", 5-line dry mix")
+                                   + ((", HRTF Default HRTF.mhr (irSize 64), " if use_real else
+                                       ", HRTF synthetic .mhr with Default-HRTF geometry irSize 64, ")
+                                      + "dual-ear FIR + MixDirectHrtf" if hrtf else ", 5-line dry mix")
                                    + {4: ", v%5 sends into 4 reverb slots", 5: ", one send into a 65536-tap convolution slot"}.get(args.config, "")
                                    + "), 25% filtered, every 4th voice moving",
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
                        "preroll_steps": preroll, "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
+                       "e2e_ms_per_update": e2e_ms,
+                       "e2e_note": "one update alone through the C-ABI from host memory: oalgpu_voice_set_params of the "
+                                   f"{len(moving)} moving voices (host biquad design + H2D) + oalgpu_mix_update + "
+                                   "oalgpu_read_dry (D2H, sync); no overlap -- a latency, not the throughput `value` is",
+                       "repeat_ms_per_step": {"n": len(extra), "median": float(np.median(extra)) if extra else None,
+                                              "min": min(extra) if extra else None, "max": max(extra) if extra else None},
                        "parallelism": f"voice-shard x{world}" + (" + RCCL reduce of mix buses" if world > 1 else "")},
-            # 68 flop/B: the path sits above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B), so
-            # the binding roofline is the fp32 FMA rate; the HBM figures BASELINE's metric names are
-            # reported beside it
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            # 68 flop/B: the path sits above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B), so the
+            # binding roofline is the fp32 FMA rate of the vector pipes (the kernel issues v_pk_fma_f32;
+            # the MFMA variant of the FIR has the same fp32 peak and measured slower);
+            # `hbm_frac` is the "fraction of HBM roofline" BASELINE's metric string names
+            "roofline": {"bound": "fp32-valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": sc.voice_kernel_name(), "kernel_ms": vk_ms,
                          "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
@@ -281,7 +392,10 @@ def main():
                          "hbm_frac": hbm_achieved / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline and args.config in (2, 3):
-            cb = cpu_baseline(synth, args.config, V)
+            if hrtf and not use_real:
+                tmp_mhr = os.path.join(tempfile.gettempdir(), f"oalgpu_bench_{os.getpid()}.mhr")
+                synth.write_synth_mhr(tmp_mhr)
+            cb = cpu_baseline(args.config, V, real_mhr if use_real else (tmp_mhr if hrtf else ""))
             if cb:
                 out["cpu_baseline"] = cb
         # anything native code left in C stdio buffers (the RCCL banner) goes out before the line
