@@ -288,7 +288,9 @@ int oalgpu_read_dry(oalgpu_context *ctx, float *out);
 int oalgpu_read_wet(oalgpu_context *ctx, uint32_t slot, float *out);
 int oalgpu_read_hrtf_accum(oalgpu_context *ctx, float *out);
 /* Device address of the bus block [dry+real lines | wet buses | hrtf accum], its length in
- * floats, and the stream it is produced on, for zero-copy consumers (e.g. an RCCL reduce). */
+ * floats, and the stream it is produced on, for zero-copy consumers: the context's main stream for
+ * the serial entry points (oalgpu_mix_voices / oalgpu_post_process), its POST stream when the
+ * pipelined path is active (oalgpu_mix_update on a FAST HRTF context with its own streams). */
 int oalgpu_bus_device_ptr(oalgpu_context *ctx, void **ptr, size_t *nfloats, void **hip_stream);
 /* Multi-GPU split of one update: mix_voices fills this rank's partial buses (no post-process);
  * after the caller has summed the bus block across ranks (one RCCL all-reduce/reduce),
@@ -308,6 +310,23 @@ int   oalgpu_post_process_overlapped(oalgpu_context *ctx, uint32_t samples_to_do
  * the previous update (HrtfAccumData, core/device.h:288).  Default on.  With the buses summed
  * across ranks exactly one rank -- the one whose post-process owns the tail -- keeps it on. */
 int oalgpu_set_carry_accum(oalgpu_context *ctx, int enable);
+
+/* ---- multi-GPU inside the library: RCCL over xGMI -----------------------------------------------------
+ * The reference has no multi-device path (one mixer thread per device); voices are
+ * independent given their parameters, so they shard over the GPUs of a node -- one process and one
+ * context per GPU -- and the only exchange is ONE sum-reduce of the bus block
+ * [dry + real lines | wet buses | HrtfAccumData] to rank 0 per update.
+ *   rank 0:      oalgpu_comm_unique_id(id, 128)           (ncclGetUniqueId; hand the 128 bytes to the others)
+ *   every rank:  oalgpu_comm_init(ctx, id, 128, rank, world)     (ncclCommInitRank on the context's device)
+ * From then on oalgpu_mix_update / oalgpu_mix_voices issue the ncclReduce themselves, on the stream that
+ * produced the buses (the context's post stream in the pipelined path: the collective, the effects and the
+ * post-process of update k run beside the voice kernel of update k+1), and only rank 0 -- the one rank
+ * that carries the HRTF accumulator tail -- runs the effect slots and the post-process.  librccl.so is
+ * resolved at run time (an instance already in the process, e.g. torch's, is reused); a host that never
+ * calls these needs no RCCL.  `size` is the size of the id buffer (>= 128). */
+int oalgpu_comm_unique_id(void *unique_id, size_t size);
+int oalgpu_comm_init(oalgpu_context *ctx, const void *unique_id, size_t size, int rank, int world);
+int oalgpu_comm_destroy(oalgpu_context *ctx);
 
 /* Mixing state of one voice after the last update (the fields Voice::mix mutates). */
 typedef struct oalgpu_voice_state {

@@ -5,6 +5,8 @@
 #include "../../include/oalgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and enums only: the library itself is resolved with dlopen/dlsym
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -111,6 +113,7 @@ struct oalgpu_context {
     DevBuf<float> tables;
     DevBuf<BufferItem> buffers;
     std::vector<void*> bufferData;
+    std::vector<uint32_t> bufferLoopLen;   // loop_end - loop_start of every registered buffer (0: cannot loop)
     uint32_t numBuffers{0};
     DevBuf<VoiceCtl> ctl;
     DevBuf<float> prev, hrtfOld, hrtfTgt, hist, gainCur, gainTgt, sendCur, sendTgt;
@@ -123,6 +126,10 @@ struct oalgpu_context {
     DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
     bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
     uint32_t waveGroups{0};                // partial buses of the wavefront kernel (the fallback of voice_block.hip)
+    // multi-GPU (oalgpu_comm_init): this rank's RCCL communicator; the bus block is sum-reduced to rank 0
+    // right behind the partial-bus reduction, on the stream that runs it
+    void *comm{nullptr};
+    int commRank{0}, commWorld{1};
     // HRTF store
     DevBuf<float> hFieldDist, hCoeffs;
     DevBuf<uint8_t> hEvCount, hDelays;
@@ -166,9 +173,111 @@ int FlushInits(oalgpu_context *c)
     return OALGPU_OK;
 }
 
+// ---- RCCL, resolved at run time: a single-GPU host never needs the library, and a process that already
+// carries an RCCL (torch's) must use THAT instance rather than a second copy
+struct RcclApi {
+    ncclResult_t (*getUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*commInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*getErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+RcclApi &Rccl()
+{
+    static RcclApi api = []
+    {
+        RcclApi a;
+        void *h = nullptr;
+        if(dlsym(RTLD_DEFAULT, "ncclCommInitRank")) h = RTLD_DEFAULT;       // already in the process
+        else
+        {
+            for(const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        }
+        if(!h) { a.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return a; }
+        a.getUniqueId = reinterpret_cast<decltype(a.getUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        a.commInitRank = reinterpret_cast<decltype(a.commInitRank)>(dlsym(h, "ncclCommInitRank"));
+        a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(h, "ncclCommDestroy"));
+        a.reduce = reinterpret_cast<decltype(a.reduce)>(dlsym(h, "ncclReduce"));
+        a.getErrorString = reinterpret_cast<decltype(a.getErrorString)>(dlsym(h, "ncclGetErrorString"));
+        a.ok = a.getUniqueId && a.commInitRank && a.commDestroy && a.reduce;
+        if(!a.ok) a.why = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclReduce";
+        return a;
+    }();
+    return api;
+}
+
+int FailRccl(const char *what, ncclResult_t r)
+{
+    const RcclApi &a = Rccl();
+    return Fail(OALGPU_ERR_HIP, std::string(what) + ": " + (a.getErrorString ? a.getErrorString(r) : "RCCL error"));
+}
+
+// The one exchange of a sharded update: the bus block [dry + real lines | wet buses |
+// HrtfAccumData] of every rank is summed into rank 0's, in place, on the stream that just produced it.
+int CommReduceBus(oalgpu_context *c, hipStream_t s)
+{
+    if(!c->comm) return OALGPU_OK;
+    const ncclResult_t r = Rccl().reduce(c->L.bus, c->L.bus, BusFloats(c->L), ncclFloat32, ncclSum, 0,
+        static_cast<ncclComm_t>(c->comm), s);
+    if(r != ncclSuccess) return FailRccl("ncclReduce", r);
+    return OALGPU_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+/* ---- multi-GPU: voices shard over the GPUs of a node, one context per GPU and process ----------------
+ * Rank 0 calls oalgpu_comm_unique_id and hands the 128 bytes to the other ranks by whatever means the
+ * host has (a file, MPI, torch.distributed); every rank then calls oalgpu_comm_init on its context.
+ * From then on oalgpu_mix_update / oalgpu_mix_voices sum-reduce the bus block to rank 0 (ncclReduce over
+ * xGMI, issued by the library on the stream that produced the buses -- the context's post stream in the
+ * pipelined path, so it runs beside the next update's voice kernel), and only rank 0 -- the one rank
+ * that carries the HRTF accumulator tail -- runs the effect slots and the post-process. */
+int oalgpu_comm_unique_id(void *out, size_t size)
+{
+    if(!out || size < sizeof(ncclUniqueId)) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_unique_id: 128 bytes needed");
+    RcclApi &a = Rccl();
+    if(!a.ok) return Fail(OALGPU_ERR_NO_DEVICE, a.why);
+    ncclUniqueId id;
+    const ncclResult_t r = a.getUniqueId(&id);
+    if(r != ncclSuccess) return FailRccl("ncclGetUniqueId", r);
+    std::memcpy(out, &id, sizeof(id));
+    return OALGPU_OK;
+}
+
+int oalgpu_comm_init(oalgpu_context *c, const void *unique_id, size_t size, int rank, int world)
+{
+    if(!c || !unique_id || size < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init: bad arguments");
+    if(c->comm) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init: the context already has a communicator");
+    RcclApi &a = Rccl();
+    if(!a.ok) return Fail(OALGPU_ERR_NO_DEVICE, a.why);
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = a.commInitRank(&comm, world, id, rank);
+    if(r != ncclSuccess) return FailRccl("ncclCommInitRank", r);
+    c->comm = comm; c->commRank = rank; c->commWorld = world;
+    c->carryAccum = rank == 0;          // exactly one rank continues the carried HRTF accumulator
+    return OALGPU_OK;
+}
+
+int oalgpu_comm_destroy(oalgpu_context *c)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(!c->comm) return OALGPU_OK;
+    if(int rc = oalgpu_sync(c)) return rc;
+    (void)Rccl().commDestroy(static_cast<ncclComm_t>(c->comm));
+    c->comm = nullptr; c->commRank = 0; c->commWorld = 1; c->carryAccum = true;
+    return OALGPU_OK;
+}
 
 const char *oalgpu_version(void) { return "oalgpu 0.1 (gfx950)"; }
 const char *oalgpu_last_error(void) { return gLastError.c_str(); }
@@ -448,6 +557,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->buffers.alloc(std::max<uint32_t>(desc->max_buffers, 1u))); HIP_TRY(c->buffers.zero());
     L.buffers = c->buffers.p;
     c->bufferData.assign(std::max<uint32_t>(desc->max_buffers, 1u), nullptr);
+    c->bufferLoopLen.assign(std::max<uint32_t>(desc->max_buffers, 1u), 0u);
 
     const size_t nv = desc->max_voices;
     HIP_TRY(c->ctl.alloc(nv)); HIP_TRY(c->ctl.zero()); L.ctl = c->ctl.p;
@@ -508,6 +618,7 @@ void oalgpu_context_destroy(oalgpu_context *ctx)
     (void)hipSetDevice(ctx->desc.device);
     (void)hipStreamSynchronize(ctx->stream);
     if(ctx->postStream) (void)hipStreamSynchronize(ctx->postStream);
+    if(ctx->comm) (void)Rccl().commDestroy(static_cast<ncclComm_t>(ctx->comm));
     delete ctx;
 }
 
@@ -515,8 +626,17 @@ int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
 {
     if(!c || !data) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(int rc = UseDevice(c->desc.device)) return rc;
-    const std::string err = ParseMhr(data, size, c->hrtfHost);
+    HrtfData parsed;
+    const std::string err = ParseMhr(data, size, parsed);
     if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
+    // The reference resamples a data set whose rate differs from the device's (GetLoadedHrtf,
+    // core/hrtf.cpp:539-606: coefficients through a polyphase resampler, delays rescaled); that is
+    // not built here, and mixing with mistuned HRIRs silently would be wrong: refuse.
+    if(parsed.sampleRate != c->desc.sample_rate)
+        return Fail(OALGPU_ERR_INVALID, "mhr: data set at " + std::to_string(parsed.sampleRate) + " Hz, context at "
+            + std::to_string(c->desc.sample_rate) + " Hz (resample the data set to the device rate first)");
+    if(int rc = oalgpu_sync(c)) return rc;           // a second load replaces buffers the streams may still read
+    c->hrtfHost = std::move(parsed);
     const HrtfData &h = c->hrtfHost;
     HIP_TRY(c->hFieldDist.alloc(h.fieldDistance.size())); HIP_TRY(c->hFieldDist.upload(h.fieldDistance.data(), h.fieldDistance.size()));
     HIP_TRY(c->hEvCount.alloc(h.fieldEvCount.size())); HIP_TRY(c->hEvCount.upload(h.fieldEvCount.data(), h.fieldEvCount.size()));
@@ -627,6 +747,7 @@ int oalgpu_buffer_register(oalgpu_context *c, const void *data, int fmt_type, ui
     if(e != hipSuccess) { (void)hipFree(dev); return Fail(OALGPU_ERR_HIP, hipGetErrorString(e)); }
     const uint32_t h = c->numBuffers++;
     c->bufferData[h] = dev;
+    c->bufferLoopLen[h] = loop_end > loop_start ? loop_end - loop_start : 0u;
     BufferItem item{dev, fmt_type, frame_step, sample_len, loop_start, loop_end, 0};
     HIP_TRY(hipMemcpy(c->buffers.p + h, &item, sizeof(item), hipMemcpyHostToDevice));
     return int(h);
@@ -638,6 +759,8 @@ int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc
         || d->position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: bad arguments");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(d->looping && c->bufferLoopLen[size_t(d->buffer)] == 0)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: a looping voice needs a buffer registered with loop_end > loop_start");
     c->initPending.push_back(VoiceInitRecord{voice, d->buffer, d->looping ? 1 : 0, d->position, d->position_frac});
     return OALGPU_OK;
 }
@@ -725,6 +848,7 @@ int oalgpu_buffer_channel_view(oalgpu_context *c, int buffer, uint32_t channel)
     item.data = static_cast<const char*>(item.data) + size_t{channel} * bytesPer[item.fmt];
     HIP_TRY(hipMemcpy(c->buffers.p + c->numBuffers, &item, sizeof(item), hipMemcpyHostToDevice));
     c->bufferData[c->numBuffers] = nullptr;               // the storage belongs to `buffer`
+    c->bufferLoopLen[c->numBuffers] = c->bufferLoopLen[size_t(buffer)];
     return int(c->numBuffers++);
 }
 
@@ -833,7 +957,14 @@ int oalgpu_set_stream(oalgpu_context *c, void *hip_stream)
     c->postPending = false;
     if(c->ownStream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
     if(hip_stream) { c->stream = static_cast<hipStream_t>(hip_stream); c->ownStream = false; }
-    else { HIP_TRY(hipStreamCreate(&c->stream)); c->ownStream = true; }
+    else
+    {   // back to a private stream: in the highest priority class again, apart from the post stream's
+        // hardware queues (see oalgpu_context_create)
+        int prioLeast = 0, prioGreatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prioGreatest));
+        c->ownStream = true;
+    }
     return OALGPU_OK;
 }
 
@@ -907,6 +1038,7 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
     // the wavefront kernel leaves the carried HRTF accumulator tail to the reduction
     LaunchBusReduce(c->stream, c->L, samples_to_do, c->useWave && c->carryAccum);
     HIP_TRY(hipGetLastError());
+    if(int rc = CommReduceBus(c, c->stream)) return rc;
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
     return OALGPU_OK;
 }
@@ -940,11 +1072,12 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
     {   // one stream: the workgroup-per-voice-group kernel reads the carried accumulator itself,
         // and a caller-owned stream (RCCL ordering) is never forked
         if(int rc = oalgpu_mix_voices(c, samples_to_do)) return rc;
-        if(post_process) return oalgpu_post_process(c, samples_to_do);
+        if(post_process && c->commRank == 0) return oalgpu_post_process(c, samples_to_do);
         return OALGPU_OK;
     }
     if(int rc = oalgpu_mix_voices_overlapped(c, samples_to_do)) return rc;
-    return oalgpu_post_process_overlapped(c, samples_to_do, post_process);
+    // sharded contexts: the effects and the post-process run where the reduced buses are, on rank 0
+    return oalgpu_post_process_overlapped(c, samples_to_do, post_process && c->commRank == 0);
 }
 
 int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
@@ -973,6 +1106,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum, true);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->evReduceDone[p], c->postStream));
+    if(int rc = CommReduceBus(c, c->postStream)) return rc;      // beside the next update's voice kernel
     c->parity = p ^ 1u;
     return OALGPU_OK;
 }
@@ -1042,7 +1176,8 @@ int oalgpu_bus_device_ptr(oalgpu_context *c, void **ptr, size_t *nfloats, void *
     if(!c || !ptr || !nfloats) return Fail(OALGPU_ERR_INVALID, "null argument");
     *ptr = c->L.bus;
     *nfloats = BusFloats(c->L);
-    if(hip_stream) *hip_stream = c->stream;     // serial entry points (mix_voices/post_process) produce the bus here
+    if(hip_stream)      // the pipelined path produces the bus on the post stream, the serial entry points on the main one
+        *hip_stream = (c->useWave && c->L.hrtf && c->ownStream && !c->serialOnly && c->postStream) ? c->postStream : c->stream;
     return OALGPU_OK;
 }
 
@@ -1125,6 +1260,8 @@ int oalgpu_debug_wave_times(oalgpu_context *c, unsigned long long *out, uint32_t
 int oalgpu_slot_set_convolution(oalgpu_context *c, uint32_t slot, oalgpu_convolution *conv)
 {
     if(!c || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_convolution: bad slot");
+    if(conv && ConvOutLines(conv) > c->L.numDry)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_convolution: the effect mixes into more lines than the context has dry lines");
     if(int rc = oalgpu_sync(c)) return rc;
     c->slotConv[slot] = conv;
     return OALGPU_OK;
@@ -1135,6 +1272,8 @@ int oalgpu_slot_set_reverb(oalgpu_context *c, uint32_t slot, oalgpu_reverb *rev)
     if(!c || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_reverb: bad slot");
     if(rev && c->L.wetChannels < 4)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_reverb: the reverb reads a 4-line B-Format wet bus");
+    if(rev && ReverbOutLines(rev) > c->L.numDry)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_reverb: the effect mixes into more lines than the context has dry lines");
     if(int rc = oalgpu_sync(c)) return rc;
     c->slotReverb[slot] = rev;
     return OALGPU_OK;

@@ -12,6 +12,9 @@ namespace oalgpu {
 // records the message for oalgpu_last_error() on this thread and returns `code`
 int Fail(int code, const std::string &msg);
 int UseDevice(int device);
+// lines an effect instance mixes into (reverb_api.hip / conv_api.hip)
+uint32_t ReverbOutLines(const oalgpu_reverb *r);
+uint32_t ConvOutLines(const oalgpu_convolution *c);
 
 #define HIP_TRY(expr) do { \
     const hipError_t err_ = (expr); \

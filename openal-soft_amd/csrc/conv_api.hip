@@ -174,3 +174,5 @@ int oalgpu_convolution_process(oalgpu_convolution *c, const float *wet_in, float
 }
 
 } // extern "C"
+
+namespace oalgpu { uint32_t ConvOutLines(const oalgpu_convolution *c) { return c ? c->nlines : 0u; } }

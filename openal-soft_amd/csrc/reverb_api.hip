@@ -120,10 +120,17 @@ int oalgpu_reverb_set_stream(oalgpu_reverb *r, void *hip_stream)
 int oalgpu_reverb_update(oalgpu_reverb *r, const oalgpu_reverb_props *props, float slot_gain)
 {
     if(!r || !props) return Fail(OALGPU_ERR_INVALID, "null argument");
-    const bool full = r->host.update(*props, slot_gain);
+    // validate before committing: a block the kernel cannot run must not stay installed
+    auto trial = r->host;
+    const bool full = trial.update(*props, slot_gain);
+    if(r->device >= 0)
+    {
+        if(int rc = CheckOffsets(trial.params.pipe[trial.params.current_pipeline])) return rc;
+        if(full) { if(int rc = CheckOffsets(trial.params.pipe[!trial.params.current_pipeline])) return rc; }
+    }
+    r->host = trial;
     r->dirty[r->host.params.current_pipeline] = true;
     if(full) r->dirty[!r->host.params.current_pipeline] = true;
-    if(r->device >= 0) return CheckOffsets(r->host.params.pipe[r->host.params.current_pipeline]);
     return OALGPU_OK;
 }
 
@@ -139,12 +146,20 @@ int oalgpu_reverb_set_params(oalgpu_reverb *r, const oalgpu_reverb_params *param
     if(!r || !params) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(params->current_pipeline != 0 && params->current_pipeline != 1)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_set_params: current_pipeline must be 0 or 1");
+    if(r->device >= 0)
+    {   // a caller-supplied block: both pipelines are checked before anything is installed
+        if(int rc = CheckOffsets(params->pipe[0])) return rc;
+        if(int rc = CheckOffsets(params->pipe[1])) return rc;
+    }
     const bool full = r->host.install(*params);
     r->dirty[r->host.params.current_pipeline] = true;
     if(full) r->dirty[!r->host.params.current_pipeline] = true;
-    if(r->device >= 0) return CheckOffsets(r->host.params.pipe[r->host.params.current_pipeline]);
     return OALGPU_OK;
 }
+
+} // extern "C"
+namespace oalgpu { uint32_t ReverbOutLines(const oalgpu_reverb *r) { return r ? r->L.nlines : 0u; } }
+extern "C" {
 
 int oalgpu_reverb_line_lengths(oalgpu_reverb *r, uint32_t lengths[11])
 {
