@@ -255,28 +255,26 @@ def main():
     nblocks = min(total_steps, 96)
     blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(nblocks)]
 
-    mixer = None
+    # N > 1: the library's own multi-GPU path (RCCL inside liboalgpu.so: oalgpu_comm_init, then every
+    # oalgpu_mix_update issues the ncclReduce of the bus block on its post stream and only rank 0 runs
+    # the effects and the post-process) -- what a C++ host would call.  torch.distributed only carries
+    # the 128-byte id to the other ranks and the contract's barrier / max-over-ranks.
     force_sharded = os.environ.get("OALGPU_FORCE_SHARDED") == "1"      # exercise the N>1 path on one GPU
     if world > 1 or force_sharded:
-        from oalgpu.shard import GpuEngine, OverlappedGpuEngine, ShardedMixer
         if dist is None:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        if hrtf:
-            engine = OverlappedGpuEngine(sc, torch, local_rank)
-            engine.always_reduce = force_sharded
-        else:
-            engine = GpuEngine(sc, torch, local_rank, torch.cuda.current_stream())
-        mixer = ShardedMixer(engine, dist, rank, world)
+        idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(oalgpu.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        sc.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
     def step(k):
         sc.apply_block(blocks[k % nblocks])
-        if mixer is None:
-            sc.mix(UPDATE_SAMPLES, post_process=post)
-        else:
-            mixer.update(UPDATE_SAMPLES)          # partial buses, one RCCL reduce, post-process on rank 0
+        sc.mix(UPDATE_SAMPLES, post_process=post)
 
     def fence():
         if dist is not None:
@@ -345,7 +343,7 @@ def main():
         a, b = sc.last_update_ms()
         tot.append(a)
         vk.append(b)
-        if world == 1 and post:
+        if post and rank == 0:
             sc.post_process(UPDATE_SAMPLES)
     sc.sync()
     sc.set_timing(False)
@@ -398,7 +396,7 @@ def main():
                                    "oalgpu_read_dry (D2H, sync); no overlap -- a latency, not the throughput `value` is",
                        "repeat_ms_per_step": {"n": len(extra), "median": float(np.median(extra)) if extra else None,
                                               "min": min(extra) if extra else None, "max": max(extra) if extra else None},
-                       "parallelism": f"voice-shard x{world}" + (" + RCCL reduce of mix buses" if world > 1 else "")},
+                       "parallelism": f"voice-shard x{world}" + (" + ncclReduce of the bus block to rank 0, issued by the library" if world > 1 else "")},
             # 68 flop/B: the path sits above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B), so the
             # binding roofline is the fp32 FMA rate of the vector pipes (the kernel issues v_pk_fma_f32;
             # the MFMA variant of the FIR has the same fp32 peak and measured slower);

@@ -415,6 +415,15 @@ class Scene:
         check(lib.oalgpu_post_process_overlapped(self.h, samples_to_do, 1 if run_post_process else 0),
               "oalgpu_post_process_overlapped")
 
+    # multi-GPU inside the library (RCCL): see include/oalgpu.h "multi-GPU inside the library"
+    def comm_init(self, unique_id, rank, world):
+        lib.oalgpu_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+        check(lib.oalgpu_comm_init(self.h, unique_id, len(unique_id), rank, world), "oalgpu_comm_init")
+
+    def comm_destroy(self):
+        lib.oalgpu_comm_destroy.argtypes = [C.c_void_p]
+        check(lib.oalgpu_comm_destroy(self.h), "oalgpu_comm_destroy")
+
     def set_carry_accum(self, enable):
         check(lib.oalgpu_set_carry_accum(self.h, 1 if enable else 0))
 
@@ -480,6 +489,14 @@ class Scene:
         a, b = C.c_float(), C.c_float()
         check(lib.oalgpu_last_update_ms(self.h, C.byref(a), C.byref(b)), "oalgpu_last_update_ms")
         return a.value, b.value
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    lib.oalgpu_comm_unique_id.argtypes = [C.c_char_p, C.c_size_t]
+    check(lib.oalgpu_comm_unique_id(buf, 128), "oalgpu_comm_unique_id")
+    return buf.raw
 
 
 class Convolution:

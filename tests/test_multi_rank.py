@@ -27,6 +27,24 @@ def test_shard_range_partitions_voices():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_weighted_shards_balance_cost_classes():
+    from oalgpu.shard import voice_cost, weighted_shards
+    # BASELINE config 4 mix: HRTF-free voices with v % 5 sends, every fourth filtered
+    costs = [voice_cost(False, 24, v % 5, v % 4 == 1) for v in range(8192)]
+    for world in (1, 2, 3, 8):
+        shards = weighted_shards(costs, world)
+        assert sorted(v for s in shards for v in s) == list(range(8192))
+        loads = [sum(costs[v] for v in s) for s in shards]
+        assert max(loads) - min(loads) <= max(costs) + 1e-9
+    # work only rank 0 has (effects, post-process) is taken off its share
+    extra = 0.1 * sum(costs)
+    shards = weighted_shards(costs, 8, rank0_extra=extra)
+    loads = [sum(costs[v] for v in s) for s in shards]
+    assert loads[0] + extra <= max(loads[1:]) + max(costs) and loads[0] < min(loads[1:])
+    # an all-HRTF scene next to a dry one: HRTF voices weigh ~3x
+    assert 2.0 < voice_cost(True) / voice_cost(False) < 4.0
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -59,12 +77,11 @@ def test_sharded_scene_matches_unsharded(synth_mhr, world):
 
 
 @pytest.mark.gpu
-def test_overlapped_engine_single_rank_nccl(synth_mhr):
-    """The GPU side of the sharded update on its real streams: OverlappedGpuEngine (voice kernel on
-    the main stream; partial-bus reduction, a torch.distributed reduce over a ONE-rank RCCL group
-    issued on the context's post stream, and the post-process behind it) against the oracle, over
-    several back-to-back updates without draining in between.  In its own process: torch has to
-    initialise its HIP runtime before liboalgpu.so loads the system one."""
+def test_library_comm_single_rank_rccl(synth_mhr):
+    """The GPU side of the sharded update as the library runs it: oalgpu_comm_init over a ONE-rank
+    RCCL communicator, then oalgpu_mix_update (voice kernel on the main stream; partial-bus reduction,
+    ncclReduce of the bus block and the post-process on the post stream) against the oracle, over several
+    back-to-back updates without draining in between.  In its own process (librccl.so is loaded there)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OAL_TEST_MHR=synth_mhr)
     p = subprocess.run([sys.executable, os.path.join(HERE, "overlapped_worker.py")], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
