@@ -1,0 +1,526 @@
+/* oracle/ref_bridge.cpp -- TEST INFRASTRUCTURE (oracle/_ref/liboalbridge.so; never linked into the product).
+ *
+ * The REFERENCE-SIDE BINDING of liboalgpu.so, compiled against the reference's own headers and objects:
+ * what a maintainer of kcat/openal-soft would add, exercised end to end through the
+ * reference's real plumbing --
+ *
+ *   DeviceBase::renderSamples            alc/alu.cpp:2412-2519   (called as is)
+ *     -> ProcessContexts                 alc/alu.cpp:2177-2273   (as is: ProcessParamUpdates,
+ *          CalcVoiceParams for every voice with pending VoiceProps, the voice loop, the event ring)
+ *          -> voice->mix(...)            alc/alu.cpp:2201-2206   <- THE SEAM: Voice::mix is defined HERE
+ *     -> Process(AmbiDecPostProcess)     BFormatDec::process, core/bformatdec.cpp:60-95   (as is)
+ *     -> Write<float>                    alc/alu.cpp:2335-2408   (as is)
+ *
+ * Voice::mix (core/voice.cpp:988) is compiled under the name Voice::mix_cpu by ref_voice_cpu.cpp; the
+ * definition below routes every call of the voice loop
+ *   mode CPU      -> the reference's own Voice::mix (the pure CPU run: the baseline of the comparison);
+ *   mode ADAPTERS -> the reference's own Voice::mix running on top of adapters with the reference's
+ *                    function-pointer signatures -- ResamplerFunc (core/mixer/defs.h:71), MixerOutFunc
+ *                    (core/mixer.h:22-27), HrtfMixerFunc / HrtfMixerBlendFunc (core/voice.cpp:73-81) --
+ *                    that call the per-call C-ABI (oalgpu_resample / oalgpu_mix / oalgpu_mix_hrtf[_blend]);
+ *   mode BATCH    -> nothing per voice: the voices of the update are collected and, with the last one,
+ *                    described to the GPU context as INTEGRATION.md section 3 says (oalgpu_voice_params
+ *                    filled from the Voice AFTER the reference's CalcVoiceParams computed mStep, the pan
+ *                    gains and the filter targets), mixed by ONE oalgpu_mix_update, and the dry lines are
+ *                    added into DeviceBase::MixBuffer; the reference carries on with its post-process.
+ * The scene is BASELINE configs[0]: mono sources, linear resampler, a stereo device (3 first-order 2D
+ * ambisonic dry lines decoded to 2 speakers by the reference's BFormatDec with panning.cpp's StereoConfig).
+ */
+#include "config.h"
+#include "config_simd.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <numbers>
+#include <span>
+#include "alnumeric.h"
+#include "opthelpers.h"
+#define private public
+#define protected public
+#define class struct
+#include "core/filters/biquad.h"
+#undef class
+#undef private
+#undef protected
+
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "core/ambidefs.h"
+#include "core/bformatdec.h"
+#include "core/bs2b.h"
+#include "core/encoderbase.hpp"
+#include "core/front_stablizer.h"
+#include "core/mastering.h"
+#include "core/buffer_storage.h"
+#include "core/context.h"
+#include "core/cpu_caps.h"
+#include "core/device.h"
+#include "core/effectslot.h"
+#include "core/fpu_ctrl.h"
+#include "core/hrtf.h"
+#include "core/mixer.h"
+#include "core/mixer/defs.h"
+#include "core/mixer/hrtfdefs.h"
+#include "core/voice.h"
+#include "core/voice_change.h"
+#include "core/async_event.h"
+#include "ringbuffer.h"
+#include "alc/alu.h"
+
+#include "../include/oalgpu.h"
+
+extern "C" {
+void oalbridge_voice_mix_cpu(void *voice, int vstate, void *context, long long device_ns, unsigned samples_to_do);
+void oalbridge_get_hrtf_mixers(void **mixfn, void **blendfn);
+void oalbridge_set_hrtf_mixers(void *mixfn, void *blendfn);
+}
+
+namespace {
+
+enum Mode { ModeCpu = 0, ModeAdapters = 1, ModeBatch = 2 };
+
+struct Dev final : DeviceBase { Dev() : DeviceBase{DeviceType::Loopback} { } };
+struct Ctx final : ContextBase { explicit Ctx(DeviceBase *d) : ContextBase{d} { } };
+struct Item final : VoiceBufferItem { };
+struct BufferData { std::vector<float> samples; Item item; };
+
+bool gInit = false;
+void EnsureInit()
+{
+    if(gInit) return;
+    gInit = true;
+    if(auto info = GetCPUInfo()) CPUCapFlags = info->mCaps;
+    aluInit({}, 1.0f);
+    Voice::InitMixer(std::nullopt);
+}
+
+} // namespace
+
+struct oalbridge {
+    Mode mode{ModeCpu};
+    int mathMode{OALGPU_MATH_FAST};
+    std::unique_ptr<Dev> dev;
+    std::unique_ptr<Ctx> ctx;
+    std::deque<BufferData> buffers;
+    std::vector<Voice*> sources;            /* the context's voices, in creation order */
+    /* ---- the GPU side */
+    oalgpu_context *gpu{nullptr};
+    std::map<const VoiceBufferItem*, int> bufferHandle;
+    std::map<const Voice*, uint32_t> voiceIndex;
+    std::map<const Voice*, int> lastState;
+    /* ---- one update of the voice loop */
+    unsigned expected{0}, seen{0};
+    std::vector<std::pair<Voice*, Voice::State>> batch;
+    int error{0};
+    std::string errorText;
+};
+
+namespace {
+
+oalbridge *gActive = nullptr;               /* the bridge whose renderSamples is running (one mixer thread) */
+int gResamplerKind = OALGPU_RESAMPLER_LINEAR;   /* of the voice Voice::mix_cpu is working on (ADAPTERS) */
+int gMathMode = OALGPU_MATH_EXACT;
+
+/* ---- ADAPTERS: the reference's function-pointer signatures on top of the per-call C-ABI ------------------- */
+void Resample_GPU(InterpState const*, std::span<float const> src, unsigned frac, unsigned increment,
+    std::span<float> dst) noexcept
+{
+    /* `src` begins at the first source sample; the kernels read MaxResamplerEdge samples before it
+     * (core/mixer/defs.h:71-72 documents the same for the reference's own kernels) */
+    const float *base = src.data() - MaxResamplerEdge;
+    oalgpu_resample(0, gMathMode, gResamplerKind, increment, base, src.size() + MaxResamplerEdge, frac, dst.data(),
+        dst.size());
+}
+
+void Mix_GPU(std::span<float const> in, std::span<FloatBufferLine> out, std::span<float> cur,
+    std::span<float const> tgt, std::size_t counter, std::size_t outpos) noexcept
+{
+    oalgpu_mix(0, in.data(), in.size(), out[0].data(), out.size(), cur.data(), tgt.data(), counter, outpos);
+}
+
+void MixHrtf_GPU(std::span<float const> in, std::span<f32x2> accum, unsigned irSize, MixHrtfFilter const *f,
+    std::size_t n) noexcept
+{
+    const uint32_t delay[2]{f->Delay[0], f->Delay[1]};
+    oalgpu_mix_hrtf(0, gMathMode, in.data(), &accum[0][0], irSize, &f->Coeffs[0][0], delay, f->Gain, f->GainStep, n);
+}
+
+void MixHrtfBlend_GPU(std::span<float const> in, std::span<f32x2> accum, unsigned irSize, HrtfFilter const *oldp,
+    MixHrtfFilter const *newp, std::size_t n) noexcept
+{
+    const uint32_t od[2]{oldp->Delay[0], oldp->Delay[1]}, nd[2]{newp->Delay[0], newp->Delay[1]};
+    oalgpu_mix_hrtf_blend(0, gMathMode, in.data(), &accum[0][0], irSize, &oldp->Coeffs[0][0], od, oldp->Gain,
+        &newp->Coeffs[0][0], nd, newp->GainStep, n);
+}
+
+/* ---- BATCH: the descriptor builder of INTEGRATION.md section 3 ---------------------------------------------- */
+int Fail(oalbridge *b, int rc, const char *what)
+{
+    if(!b->error) { b->error = rc; b->errorText = std::string(what) + ": " + oalgpu_last_error(); }
+    return rc;
+}
+
+/* the shelf gains CalcPanningAndFilters designed the voice's direct filters with (alu.cpp:1619-1637):
+ * a high shelf's gain is its response at Nyquist, a low shelf's its response at DC */
+float ShelfGainAt(const BiquadInterpFilter &f, float z /* +1: DC, -1: Nyquist */)
+{
+    const auto &c = f.mTargetCoeffs;
+    return (c.mB0 + c.mB1*z + c.mB2) / (1.0f + c.mA1*z + c.mA2);
+}
+
+int FlushBatch(oalbridge *b, ContextBase *context, unsigned samplesToDo)
+{
+    auto &dev = *b->dev;
+    if(!b->gpu)
+    {
+        oalgpu_context_desc d{};
+        d.device = 0; d.math_mode = b->mathMode; d.sample_rate = dev.mSampleRate;
+        d.num_dry_channels = uint32_t(dev.Dry.Buffer.size());
+        d.num_real_channels = uint32_t(dev.RealOut.Buffer.size());
+        d.num_aux_sends = 0; d.num_slots = 0; d.wet_channels = 4; d.hrtf = 0;
+        d.max_voices = 1024; d.max_buffers = 256; d.voices_per_group = 0;
+        if(int rc = oalgpu_context_create(&d, &b->gpu)) return Fail(b, rc, "oalgpu_context_create");
+    }
+    std::vector<uint32_t> ids;
+    std::vector<oalgpu_voice_params> params;
+    for(auto &[voice, vstate] : b->batch)
+    {
+        auto it = b->voiceIndex.find(voice);
+        if(it == b->voiceIndex.end())
+        {   /* a voice that starts playing: register its buffer once, InitVoice (al/source.cpp:639-670) */
+            auto *item = voice->mCurrentBuffer.load(std::memory_order_relaxed);
+            if(!item) continue;
+            auto hb = b->bufferHandle.find(item);
+            if(hb == b->bufferHandle.end())
+            {
+                auto const *span = std::get_if<std::span<f32>>(&item->mSamples);
+                if(!span) return Fail(b, OALGPU_ERR_INVALID, "bridge: float buffers only");
+                const int h = oalgpu_buffer_register(b->gpu, span->data(), OALGPU_FMT_FLOAT, voice->mFrameStep,
+                    item->mSampleLen, item->mLoopStart, item->mLoopEnd);
+                if(h < 0) return Fail(b, h, "oalgpu_buffer_register");
+                hb = b->bufferHandle.emplace(item, h).first;
+            }
+            const uint32_t idx = uint32_t(b->voiceIndex.size());
+            oalgpu_voice_desc vd{hb->second, voice->mLoopBuffer.load(std::memory_order_relaxed) != nullptr,
+                voice->mPosition.load(std::memory_order_relaxed), voice->mPositionFrac.load(std::memory_order_relaxed),
+                voice->mFrequency};
+            if(int rc = oalgpu_voice_init(b->gpu, idx, &vd)) return Fail(b, rc, "oalgpu_voice_init");
+            it = b->voiceIndex.emplace(voice, idx).first;
+            b->lastState[voice] = Voice::Playing;
+        }
+        if(b->lastState[voice] != int(vstate))
+        {   /* ProcessVoiceChanges' play-state changes (alu.cpp:2057-2151) */
+            if(int rc = oalgpu_voice_set_state(b->gpu, it->second, int(vstate))) return Fail(b, rc, "oalgpu_voice_set_state");
+            b->lastState[voice] = int(vstate);
+        }
+        /* what CalcVoiceParams left in the Voice (alu.cpp:1512-1710, :2012-2031) */
+        oalgpu_voice_params p{};
+        p.step = voice->mStep;
+        p.resampler = int(voice->mProps.mResampler);
+        auto &chan = voice->mChans[0];
+        const float inv_rate = 1.0f / float(dev.mSampleRate);
+        p.direct_filter.active = voice->mDirect.FilterActive ? 1 : 0;
+        p.direct_filter.hf_norm = voice->mProps.Direct.HFReference * inv_rate;
+        p.direct_filter.lf_norm = voice->mProps.Direct.LFReference * inv_rate;
+        p.direct_filter.gain_hf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.LowPass, -1.0f) : 1.0f;
+        p.direct_filter.gain_lf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.HighPass, 1.0f) : 1.0f;
+        for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c) p.dry_gains[c] = chan.mDryParams.Gains.Target[c];
+        for(int s{0}; s < OALGPU_MAX_SENDS; ++s)
+        {
+            p.send_slot[s] = -1;
+            p.send_filter[s] = oalgpu_filter_params{0, 1.0f, 5000.0f*inv_rate, 1.0f, 250.0f*inv_rate};
+        }
+        ids.push_back(it->second);
+        params.push_back(p);
+    }
+    if(!ids.empty())
+        if(int rc = oalgpu_voice_set_params(b->gpu, ids.data(), params.data(), ids.size())) return Fail(b, rc, "oalgpu_voice_set_params");
+    /* the voice loop: one batched update, then the dry lines join the device's mixing buffer */
+    if(int rc = oalgpu_mix_update(b->gpu, samplesToDo, 0)) return Fail(b, rc, "oalgpu_mix_update");
+    std::vector<float> lines((dev.Dry.Buffer.size() + dev.RealOut.Buffer.size()) * BufferLineSize);
+    if(int rc = oalgpu_read_dry(b->gpu, lines.data())) return Fail(b, rc, "oalgpu_read_dry");
+    for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c)
+        for(size_t i{0}; i < samplesToDo; ++i)
+            dev.Dry.Buffer[c][i] += lines[c*BufferLineSize + i];
+    /* the state the reference mutates in place stays authoritative on the device; what the rest of the
+     * reference looks at (GetSourceOffset, the play state) is read back */
+    for(auto &[voice, vstate] : b->batch)
+    {
+        auto it = b->voiceIndex.find(voice);
+        if(it == b->voiceIndex.end()) continue;
+        oalgpu_voice_state st{};
+        if(int rc = oalgpu_voice_readback(b->gpu, it->second, &st)) return Fail(b, rc, "oalgpu_voice_readback");
+        voice->mPosition.store(st.position, std::memory_order_relaxed);
+        voice->mPositionFrac.store(st.position_frac, std::memory_order_relaxed);
+        if(st.fading) voice->mFlags.set(VoiceFlag::IsFading);
+        if(st.play_state != int(vstate))
+        {
+            voice->mPlayState.store(static_cast<Voice::State>(st.play_state), std::memory_order_release);
+            b->lastState[voice] = st.play_state;
+        }
+    }
+    (void)context;
+    return 0;
+}
+
+} // namespace
+
+/* ---- THE SEAM: the symbol ProcessContexts calls for every playing voice (alc/alu.cpp:2201-2206) ---------------- */
+void Voice::mix(State const vstate, ContextBase *const context, std::chrono::nanoseconds const deviceTime,
+    unsigned const samplesToDo) noexcept
+{
+    oalbridge *b = gActive;
+    if(!b || b->mode == ModeCpu || b->error)
+    {
+        oalbridge_voice_mix_cpu(this, int(vstate), context, deviceTime.count(), samplesToDo);
+        return;
+    }
+    if(b->mode == ModeAdapters)
+    {
+        /* per voice: CalcVoiceParams chose mResampler with PrepareResampler (alu.cpp:1686, :2000); the
+         * adapter of the same ResamplerFunc type takes its place for this call */
+        gResamplerKind = int(mProps.mResampler);
+        auto const saved = mResampler;
+        mResampler = Resample_GPU;
+        oalbridge_voice_mix_cpu(this, int(vstate), context, deviceTime.count(), samplesToDo);
+        mResampler = saved;
+        return;
+    }
+    /* BATCH */
+    if(b->seen == 0)
+    {
+        b->expected = 0;
+        for(Voice *v : context->getVoicesSpanAcquired())
+        {
+            auto const st = v->mPlayState.load(std::memory_order_acquire);
+            if(st != Voice::Stopped && st != Voice::Pending) ++b->expected;
+        }
+        b->batch.clear();
+    }
+    b->batch.emplace_back(this, vstate);
+    if(++b->seen == b->expected)
+    {
+        b->seen = 0;
+        if(FlushBatch(b, context, samplesToDo) != 0)
+        {   /* "on error the caller runs the CPU loop for that update"  */
+            for(auto &[voice, st] : b->batch)
+                oalbridge_voice_mix_cpu(voice, int(st), context, deviceTime.count(), samplesToDo);
+        }
+    }
+}
+
+extern "C" {
+
+/* mode: 0 CPU, 1 ADAPTERS, 2 BATCH; math_mode: oalgpu_math_mode of the GPU side */
+oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
+{
+    EnsureInit();
+    auto b = std::make_unique<oalbridge>();
+    b->mode = static_cast<Mode>(mode);
+    b->mathMode = math_mode;
+    b->dev = std::make_unique<Dev>();
+    auto &dev = *b->dev;
+    /* a stereo loopback device as alc/alc.cpp + alc/panning.cpp set it up (InitPanning with
+     * StereoConfig, panning.cpp:548-556, :719-850): 3 first-order 2D ambisonic dry lines (W, Y, X)
+     * decoded by a single-band BFormatDec to FrontLeft / FrontRight */
+    dev.mSampleRate = sample_rate;
+    dev.mUpdateSize = BufferLineSize;
+    dev.mBufferSize = BufferLineSize;
+    dev.FmtChans = DevFmtStereo;
+    dev.FmtType = DevFmtFloat;
+    dev.NumAuxSends = 0;
+    dev.mAmbiOrder = 1;
+    dev.m2DMixing = true;
+    dev.mRenderMode = RenderMode::Normal;
+    dev.AvgSpeakerDist = 0.0f;
+    dev.mXOverFreq = 400.0f;
+    constexpr size_t ambicount = 3, realcount = 2;
+    dev.MixBuffer.resize(ambicount + realcount);
+    dev.Dry.Buffer = std::span{dev.MixBuffer}.first(ambicount);
+    dev.RealOut.Buffer = std::span{dev.MixBuffer}.subspan(ambicount);
+    for(size_t i{0}; i < ambicount; ++i)
+        dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, AmbiIndex::FromACN2D[i].c_val};
+    dev.RealOut.ChannelIndex[FrontLeft] = 0_u8;
+    dev.RealOut.ChannelIndex[FrontRight] = 1_u8;
+    dev.NumChannelsPerOrder = {1u, 2u, 0u, 0u, 0u};
+    {
+        auto coeffs = std::vector<ChannelDec>(2);
+        coeffs[0] = ChannelDec{}; coeffs[1] = ChannelDec{};
+        coeffs[0][0] = 5.00000000e-1f; coeffs[0][1] =  2.88675135e-1f; coeffs[0][2] = 5.52305643e-2f;
+        coeffs[1][0] = 5.00000000e-1f; coeffs[1][1] = -2.88675135e-1f; coeffs[1][2] = 5.52305643e-2f;
+        auto dec = std::make_unique<BFormatDec>(ambicount, coeffs, std::span<const ChannelDec>{},
+            dev.mXOverFreq / float(sample_rate));
+        dev.mPostProcess.emplace<AmbiDecPostProcess>(AmbiDecPostProcess{std::move(dec)});
+    }
+
+    /* the context, registered with the device as alc/context.cpp:219-273 does */
+    b->ctx = std::make_unique<Ctx>(b->dev.get());
+    auto &ctx = *b->ctx;
+    ctx.mEnabledEvts.store({}, std::memory_order_relaxed);
+    ctx.mAsyncEvents = FifoBuffer<AsyncEvent>::Create(1024, false);
+    ctx.allocVoiceChanges();
+    {
+        VoiceChange *cur{ctx.mVoiceChangeTail};
+        while(VoiceChange *next{cur->mNext.load(std::memory_order_relaxed)}) cur = next;
+        ctx.mCurrentVoiceChange.store(cur, std::memory_order_relaxed);
+    }
+    ctx.mActiveAuxSlots.store(ContextBase::EffectSlotArray::Create(0).release(), std::memory_order_relaxed);
+    ctx.mVoices.store(ContextBase::VoiceArray::Create(0).release(), std::memory_order_relaxed);
+    ctx.mActiveVoiceCount.store(0, std::memory_order_relaxed);
+    ctx.mParams.mDistanceModel = DistanceModel::InverseClamped;
+    {
+        auto arr = DeviceBase::ContextArray::Create(1);
+        (*arr)[0] = b->ctx.get();
+        dev.mContexts.store(arr.release(), std::memory_order_release);
+    }
+    if(mode == ModeAdapters)
+    {   /* installed the way Voice::InitMixer installs the CPU variants (core/voice.cpp:139-193) */
+        gMathMode = math_mode;
+        MixSamplesOut = Mix_GPU;
+        oalbridge_set_hrtf_mixers(reinterpret_cast<void*>(MixHrtf_GPU), reinterpret_cast<void*>(MixHrtfBlend_GPU));
+    }
+    return b.release();
+}
+
+void oalbridge_destroy(oalbridge *b)
+{
+    if(!b) return;
+    if(gActive == b) gActive = nullptr;
+    if(b->mode == ModeAdapters) Voice::InitMixer(std::nullopt);      /* the reference's own kernels again */
+    if(b->gpu) oalgpu_context_destroy(b->gpu);
+    delete b;
+}
+
+int oalbridge_add_buffer(oalbridge *b, const float *data, uint32_t frames, uint32_t loop_start, uint32_t loop_end)
+{
+    auto &buf = b->buffers.emplace_back();
+    buf.samples.assign(data, data + frames);
+    buf.samples.resize(frames + 4);
+    buf.item.mSamples = std::span<f32>{reinterpret_cast<f32*>(buf.samples.data()), frames};
+    buf.item.mBlockAlign = 1;
+    buf.item.mSampleLen = frames;
+    buf.item.mLoopStart = loop_start;
+    buf.item.mLoopEnd = loop_end;
+    return int(b->buffers.size() - 1);
+}
+
+static VoicePropsItem *NewProps(oalbridge *b)
+{   /* al/source.cpp UpdateSourceProps: an item off the context's free list */
+    auto &ctx = *b->ctx;
+    auto *props = ctx.mFreeVoiceProps.load(std::memory_order_acquire);
+    if(!props) { ctx.allocVoiceProps(); props = ctx.mFreeVoiceProps.load(std::memory_order_acquire); }
+    VoicePropsItem *next;
+    do { next = props->next.load(std::memory_order_relaxed); }
+    while(!ctx.mFreeVoiceProps.compare_exchange_weak(props, next, std::memory_order_acq_rel, std::memory_order_acquire));
+    return props;
+}
+
+static void FillProps(VoiceProps &p, float gain, float x, float y, float z, int resampler, float pitch, float gain_hf)
+{   /* the defaults of a new AL source (al/source.cpp: ALsource::ALsource) with the fields the test moves */
+    p = VoiceProps{};
+    p.Pitch = pitch; p.Gain = gain; p.OuterGain = 0.0f; p.MinGain = 0.0f; p.MaxGain = 1.0f;
+    p.InnerAngle = 360.0f; p.OuterAngle = 360.0f;
+    p.RefDistance = 1.0f; p.MaxDistance = std::numeric_limits<float>::max(); p.RolloffFactor = 1.0f;
+    p.Position = {x, y, z}; p.Velocity = {0.0f, 0.0f, 0.0f}; p.Direction = {0.0f, 0.0f, 0.0f};
+    p.OrientAt = {0.0f, 0.0f, -1.0f}; p.OrientUp = {0.0f, 1.0f, 0.0f};
+    p.HeadRelative = false;
+    p.mDistanceModel = DistanceModel::InverseClamped;
+    p.mResampler = static_cast<Resampler>(resampler);
+    p.DirectChannels = DirectMode::Off;
+    p.mSpatializeMode = SpatializeMode::Auto;
+    p.mPanningEnabled = false;
+    p.DryGainHFAuto = true; p.WetGainAuto = true; p.WetGainHFAuto = true; p.OuterGainHF = 1.0f;
+    p.AirAbsorptionFactor = 0.0f; p.RoomRolloffFactor = 0.0f; p.DopplerFactor = 1.0f;
+    p.StereoPan = {std::numbers::pi_v<float>/6.0f, -std::numbers::pi_v<float>/6.0f};
+    p.Radius = 0.0f; p.EnhWidth = 0.593f; p.Panning = 0.0f;
+    p.Direct = {1.0f, gain_hf, 5000.0f, 1.0f, 250.0f};
+    for(auto &s : p.Send) s = {nullptr, 1.0f, 1.0f, 5000.0f, 1.0f, 250.0f};
+}
+
+/* a playing mono source: a voice of the context with pending VoiceProps, as al/source.cpp leaves it */
+int oalbridge_add_source(oalbridge *b, int buffer, int looping, int position, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf)
+{
+    auto &ctx = *b->ctx;
+    auto &buf = b->buffers.at(size_t(buffer));
+    const size_t n = ctx.mActiveVoiceCount.load(std::memory_order_relaxed);
+    if(n >= ctx.mVoices.load(std::memory_order_relaxed)->size()) ctx.allocVoices(64);
+    Voice *v = (*ctx.mVoices.load(std::memory_order_relaxed))[n];
+    /* InitVoice, al/source.cpp:639-670 */
+    v->mLoopBuffer.store(looping ? &buf.item : nullptr, std::memory_order_relaxed);
+    v->mFmtChannels = FmtMono;
+    v->mFrequency = 44100;
+    v->mFrameStep = 1;
+    v->mBytesPerBlock = 4;
+    v->mSamplesPerBlock = 1;
+    v->mAmbiOrder = 0;
+    v->mFlags.reset();
+    v->mFlags.set(VoiceFlag::IsStatic);
+    v->mNumCallbackBlocks = 0;
+    v->mCallbackBlockOffset = 0;
+    v->prepare(b->dev.get());
+    v->mPosition.store(position, std::memory_order_relaxed);
+    v->mPositionFrac.store(0u, std::memory_order_relaxed);
+    v->mCurrentBuffer.store(&buf.item, std::memory_order_relaxed);
+    v->mStartTime = {};
+    v->mSourceID.store(unsigned(n + 1), std::memory_order_relaxed);
+    auto *props = NewProps(b);
+    FillProps(*props, gain, x, y, z, resampler, pitch, gain_hf);
+    v->mUpdate.store(props, std::memory_order_release);
+    v->mPlayState.store(Voice::Playing, std::memory_order_release);
+    ctx.mActiveVoiceCount.store(n + 1, std::memory_order_release);
+    b->sources.push_back(v);
+    return int(n);
+}
+
+/* new source properties for the next update (a moved source): CalcVoiceParams picks them up */
+int oalbridge_update_source(oalbridge *b, int source, float gain, float x, float y, float z, int resampler, float pitch,
+    float gain_hf)
+{
+    Voice *v = b->sources.at(size_t(source));
+    auto *props = NewProps(b);
+    FillProps(*props, gain, x, y, z, resampler, pitch, gain_hf);
+    if(auto *old = v->mUpdate.exchange(props, std::memory_order_acq_rel))
+        AtomicReplaceHead(b->ctx->mFreeVoiceProps, old);
+    return 0;
+}
+
+int oalbridge_stop_source(oalbridge *b, int source)
+{   /* what ProcessVoiceChanges does for VChangeState::Stop (alu.cpp:2081-2100) */
+    Voice *v = b->sources.at(size_t(source));
+    auto st = Voice::Playing;
+    v->mPlayState.compare_exchange_strong(st, Voice::Stopping, std::memory_order_relaxed, std::memory_order_acquire);
+    return 0;
+}
+
+/* DeviceBase::renderSamples(void*, unsigned, size_t): `frames` interleaved stereo float frames */
+int oalbridge_render(oalbridge *b, float *interleaved, uint32_t frames)
+{
+    gActive = b;
+    b->seen = 0;
+    b->dev->renderSamples(interleaved, frames, 2u);
+    gActive = nullptr;
+    return b->error;
+}
+
+const char *oalbridge_error(oalbridge *b) { return b->errorText.c_str(); }
+
+/* source state for the comparison: play state, position, fraction, mStep of the voice */
+int oalbridge_source_state(oalbridge *b, int source, int32_t out[4])
+{
+    Voice *v = b->sources.at(size_t(source));
+    out[0] = int(v->mPlayState.load(std::memory_order_relaxed));
+    out[1] = v->mPosition.load(std::memory_order_relaxed);
+    out[2] = int32_t(v->mPositionFrac.load(std::memory_order_relaxed));
+    out[3] = int32_t(v->mStep);
+    return 0;
+}
+
+const char *oalbridge_kind(void) { return "reference+bridge"; }
+
+} /* extern "C" */

@@ -1,0 +1,101 @@
+"""ctypes binding of oracle/_ref/liboalbridge.so -- TEST INFRASTRUCTURE: the reference-side binding of the
+product (oracle/ref_bridge.cpp), i.e. the reference's real DeviceBase::renderSamples / ProcessContexts /
+CalcVoiceParams with Voice::mix routed to the reference itself (mode CPU), to the reference on top of
+GPU per-call adapters (mode ADAPTERS), or to ONE batched oalgpu_mix_update per update (mode BATCH)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "oracle", "_ref", "liboalbridge.so")
+MODE_CPU, MODE_ADAPTERS, MODE_BATCH = 0, 1, 2
+RS_LINEAR = 1
+f32p = C.POINTER(C.c_float)
+
+
+def available():
+    return os.path.exists(PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(PATH)
+        L.oalbridge_create.restype = C.c_void_p
+        L.oalbridge_create.argtypes = [C.c_int, C.c_uint32, C.c_int]
+        L.oalbridge_destroy.argtypes = [C.c_void_p]
+        L.oalbridge_add_buffer.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oalbridge_add_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float]
+        L.oalbridge_update_source.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float]
+        L.oalbridge_stop_source.argtypes = [C.c_void_p, C.c_int]
+        L.oalbridge_render.argtypes = [C.c_void_p, f32p, C.c_uint32]
+        L.oalbridge_error.restype = C.c_char_p
+        L.oalbridge_error.argtypes = [C.c_void_p]
+        L.oalbridge_source_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+        _lib = L
+    return _lib
+
+
+class Bridge:
+    def __init__(self, mode, math_mode=1, sample_rate=48000):
+        self.h = lib().oalbridge_create(mode, sample_rate, math_mode)
+        assert self.h
+
+    def close(self):
+        if self.h:
+            lib().oalbridge_destroy(self.h)
+            self.h = None
+
+    def add_buffer(self, data, loop_start=0, loop_end=None):
+        data = np.ascontiguousarray(data, np.float32)
+        return lib().oalbridge_add_buffer(self.h, data.ctypes.data_as(f32p), data.size, loop_start,
+                                          data.size if loop_end is None else loop_end)
+
+    def add_source(self, buffer, looping, position, gain, pos, resampler=RS_LINEAR, pitch=1.0, gain_hf=1.0):
+        return lib().oalbridge_add_source(self.h, buffer, 1 if looping else 0, position, gain, *pos, resampler, pitch, gain_hf)
+
+    def update_source(self, source, gain, pos, resampler=RS_LINEAR, pitch=1.0, gain_hf=1.0):
+        lib().oalbridge_update_source(self.h, source, gain, *pos, resampler, pitch, gain_hf)
+
+    def stop_source(self, source):
+        lib().oalbridge_stop_source(self.h, source)
+
+    def render(self, frames):
+        out = np.zeros((frames, 2), np.float32)
+        rc = lib().oalbridge_render(self.h, out.ctypes.data_as(f32p), frames)
+        assert rc == 0, lib().oalbridge_error(self.h).decode()
+        return out
+
+    def source_state(self, source):
+        st = (C.c_int32 * 4)()
+        lib().oalbridge_source_state(self.h, source, st)
+        return tuple(st)
+
+
+def build_config1(b, nsources=64, seed=0x5EED0001, resampler=RS_LINEAR, filtered=False):
+    """BASELINE configs[0]: 64 mono f32 sources at 44.1 kHz on a 48 kHz stereo device, linear resampler,
+    no effects; sources around the listener (start positions (v * 7919) % 48000)."""
+    rng = np.random.default_rng(seed)
+    bufs = [b.add_buffer(rng.uniform(-1, 1, 48000).astype(np.float32)) for _ in range(8)]
+    srcs = []
+    for v in range(nsources):
+        az = rng.uniform(-np.pi, np.pi)
+        dist = rng.uniform(1.0, 4.0)
+        pos = (float(np.sin(az) * dist), 0.0, float(-np.cos(az) * dist))
+        gain = float(10 ** (rng.uniform(-40, -12) / 20))
+        srcs.append(b.add_source(bufs[v % 8], True, (v * 7919) % 48000, gain, pos, resampler=resampler,
+                                 gain_hf=0.5 if (filtered and v % 4 == 1) else 1.0))
+    return srcs
+
+
+def move_some(b, srcs, k, seed=0x5EED0001, resampler=RS_LINEAR):
+    rng = np.random.default_rng(seed + 1000 * k)
+    for v in srcs[::4]:
+        az = rng.uniform(-np.pi, np.pi)
+        dist = rng.uniform(1.0, 4.0)
+        b.update_source(v, float(10 ** (rng.uniform(-40, -12) / 20)),
+                        (float(np.sin(az) * dist), 0.0, float(-np.cos(az) * dist)), resampler=resampler)
