@@ -130,11 +130,9 @@ int gMathMode = OALGPU_MATH_EXACT;
 void Resample_GPU(InterpState const*, std::span<float const> src, unsigned frac, unsigned increment,
     std::span<float> dst) noexcept
 {
-    /* `src` begins at the first source sample; the kernels read MaxResamplerEdge samples before it
-     * (core/mixer/defs.h:71-72 documents the same for the reference's own kernels) */
-    const float *base = src.data() - MaxResamplerEdge;
-    oalgpu_resample(0, gMathMode, gResamplerKind, increment, base, src.size() + MaxResamplerEdge, frac, dst.data(),
-        dst.size());
+    /* `src` is DeviceBase::mResampleData as voice.cpp:768 hands it over: it begins MaxResamplerEdge samples
+     * before the first source sample, which is the convention of oalgpu_resample too */
+    oalgpu_resample(0, gMathMode, gResamplerKind, increment, src.data(), src.size(), frac, dst.data(), dst.size());
 }
 
 void Mix_GPU(std::span<float const> in, std::span<FloatBufferLine> out, std::span<float> cur,
@@ -166,11 +164,12 @@ int Fail(oalbridge *b, int rc, const char *what)
 }
 
 /* the shelf gains CalcPanningAndFilters designed the voice's direct filters with (alu.cpp:1619-1637):
- * a high shelf's gain is its response at Nyquist, a low shelf's its response at DC */
+ * BiquadFilter::SetParams (biquad.cpp:48-129) builds the shelves with A = gain, so a high shelf answers
+ * gain^2 at Nyquist and a low shelf gain^2 at DC */
 float ShelfGainAt(const BiquadInterpFilter &f, float z /* +1: DC, -1: Nyquist */)
 {
     const auto &c = f.mTargetCoeffs;
-    return (c.mB0 + c.mB1*z + c.mB2) / (1.0f + c.mA1*z + c.mA2);
+    return std::sqrt(std::max((c.mB0 + c.mB1*z + c.mB2) / (1.0f + c.mA1*z + c.mA2), 0.0f));
 }
 
 int FlushBatch(oalbridge *b, ContextBase *context, unsigned samplesToDo)
