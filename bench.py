@@ -41,10 +41,14 @@ BYTES_PER_VOICE_UPDATE = {3: 3956 + 384 + 16 + 512 + 512, 2: 3956 + 384 + 16 + 2
                           4: 3956 + 384 + 16 + 3 * 4 * 5 + 2 * 3 * 4 * 4, 5: 3956 + 384 + 16 + 512 + 512 + 3 * 4 * 4}
 
 
-def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, vpg):
+def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, vpg, num_real=None):
+    """num_real: real output lines of a non-HRTF context (8 = a 7.1 device: the dry lines are then decoded
+    to speaker feeds by the reference's X71 decoder in the post-process); None = no output stage."""
     hrtf = config_id in (3, 5)
     nsends = {4: 4, 5: 1}.get(config_id, 0)
-    sc = oalgpu.Scene(api, sample_rate=48000, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0,
+    if num_real is None:
+        num_real = 2 if hrtf else 0
+    sc = oalgpu.Scene(api, sample_rate=48000, num_dry=4 if hrtf else 5, num_real=num_real,
                       num_sends=nsends, num_slots=nsends, wet_channels=4,
                       hrtf=hrtf, max_voices=nvoices, max_buffers=256, voices_per_group=vpg)
     sc.effects = []
@@ -242,8 +246,15 @@ def main():
     api._mhr = mhr
     V = args.voices if args.voices else (8192 if args.config == 4 else 4096)
     hrtf = args.config in (3, 5)
-    post = hrtf or args.config == 4          # effect slots run with the post-process
-    sc, script = build_scene(oalgpu, synth, api, args.config, V, rank * V, mhr, args.vpg)
+    post = hrtf or args.config in (2, 4)     # effect slots / the speaker decode run with the post-process
+    # config 2 is a 7.1 device: 5 ambisonic dry lines decoded to the 8 real output lines by the reference's
+    # X71 decoder (BFormatDec, dual band) in the post-process; the host takes interleaved s16 PCM away
+    sc, script = build_scene(oalgpu, synth, api, args.config, V, rank * V, mhr, args.vpg,
+                             num_real=8 if args.config == 2 else None)
+    if args.config == 2:
+        dec_hf, dec_lf = synth.x71_decoder()
+        sc.set_bformat_decoder(dec_hf, dec_lf)
+        sc.set_output(oalgpu.OUT_I16, 0.0, 22222)
 
     all_voices = list(range(V))
     moving = [v for v in all_voices if script.is_moving(v)]
@@ -323,14 +334,15 @@ def main():
     e2e_ms = None
     if world == 1 and moving:
         recs = [param_array(oalgpu, script, moving, 500 + k) for k in range(8)]
+        take = (lambda: sc.read_output(UPDATE_SAMPLES, 8)) if args.config == 2 else sc.dry
         for k in range(3):
-            sc.set_params_batch(moving, recs[k]); sc.mix(UPDATE_SAMPLES, post_process=post); sc.dry()
+            sc.set_params_batch(moving, recs[k]); sc.mix(UPDATE_SAMPLES, post_process=post); take()
         t0 = time.perf_counter()
         n_e2e = 40
         for k in range(n_e2e):
             sc.set_params_batch(moving, recs[k % len(recs)])
             sc.mix(UPDATE_SAMPLES, post_process=post)
-            sc.dry()                                       # oalgpu_read_dry: D2H of the dry + real lines, synchronises
+            take()       # oalgpu_read_dry (dry + real lines) / oalgpu_read_output (8-channel s16 PCM): D2H, synchronises
         e2e_ms = (time.perf_counter() - t0) / n_e2e * 1e3
 
     # ---- instrumented pass: HIP events on the context's stream around each voice-kernel launch
@@ -385,7 +397,8 @@ def main():
                                    f"(44.1k->48k, bsinc24"
                                    + ((", HRTF Default HRTF.mhr (irSize 64), " if use_real else
                                        ", HRTF synthetic .mhr with Default-HRTF geometry irSize 64, ")
-                                      + "dual-ear FIR + MixDirectHrtf" if hrtf else ", 5-line dry mix")
+                                      + "dual-ear FIR + MixDirectHrtf" if hrtf else
+                                      (", 5-line dry mix + X71 dual-band decode to 8 speaker lines" if args.config == 2 else ", 5-line dry mix"))
                                    + {4: ", v%5 sends into 4 reverb slots", 5: ", one send into a 65536-tap convolution slot"}.get(args.config, "")
                                    + "), 25% filtered, every 4th voice moving",
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,

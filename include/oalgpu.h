@@ -287,6 +287,28 @@ int oalgpu_set_stream(oalgpu_context *ctx, void *hip_stream);
 int oalgpu_read_dry(oalgpu_context *ctx, float *out);
 int oalgpu_read_wet(oalgpu_context *ctx, uint32_t slot, float *out);
 int oalgpu_read_hrtf_accum(oalgpu_context *ctx, float *out);
+/* ---- the stage behind the buses: speaker decode, dither, output PCM -----------------------------------
+ * BFormatDec (core/bformatdec.cpp:27-95; DeviceBase::Process(AmbiDecPostProcess), alc/alu.cpp:282-287):
+ * the post-process of a NON-HRTF context.  coeffs_hf / coeffs_lf are the constructor's `coeffs` /
+ * `coeffslf`: num_out rows (one ChannelDec per output channel, index = real output line) of
+ * OALGPU_MAX_AMBI_CHANNELS floats (column = dry line); coeffs_lf NULL = single band, otherwise every
+ * dry line goes through a BandSplitter at xover_norm (= mXOverFreq / sample rate).  With a decoder set,
+ * oalgpu_mix_update(.., post_process = 1) / oalgpu_post_process add the decoded feeds to the real output
+ * lines after the effect slots ran.  num_out = 0 removes it. */
+int oalgpu_set_bformat_decoder(oalgpu_context *ctx, uint32_t num_out, const float *coeffs_hf,
+    const float *coeffs_lf, float xover_norm);
+/* Output conversion: sample_type in DevFmtType order (core/devformat.h:56-64); dither_depth = the
+ * device's DitherDepth (2^(bits-1), 0 = off), dither_seed = DitherSeed. */
+enum oalgpu_output_type {
+    OALGPU_OUT_I8 = 0, OALGPU_OUT_U8, OALGPU_OUT_I16, OALGPU_OUT_U16, OALGPU_OUT_I32, OALGPU_OUT_U32, OALGPU_OUT_F32
+};
+int oalgpu_set_output(oalgpu_context *ctx, int sample_type, float dither_depth, uint32_t dither_seed);
+/* ApplyDither (alc/alu.cpp:2309-2332; in place on the output lines, like the reference) and
+ * Write<T> / SampleConv<T> (alu.cpp:2335-2390) of the last update's output lines (the real output lines,
+ * or the dry lines of a context without any), then ONE device-to-host copy of the interleaved PCM:
+ * samples_to_do frames of frame_step samples (channels past the output lines are silent).  Bit-exact. */
+int oalgpu_read_output(oalgpu_context *ctx, void *out, uint32_t samples_to_do, uint32_t frame_step);
+
 /* Device address of the bus block [dry+real lines | wet buses | hrtf accum], its length in
  * floats, and the stream it is produced on, for zero-copy consumers: the context's main stream for
  * the serial entry points (oalgpu_mix_voices / oalgpu_post_process), its POST stream when the

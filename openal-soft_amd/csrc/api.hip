@@ -130,6 +130,15 @@ struct oalgpu_context {
     // right behind the partial-bus reduction, on the stream that runs it
     void *comm{nullptr};
     int commRank{0}, commWorld{1};
+    // the stage behind the buses (output_kernels.hip): AmbiDecPostProcess of non-HRTF contexts, dither, PCM
+    bool decOn{false}, decDual{false};
+    uint32_t decOut{0};
+    DevBuf<float> decGainsHf, decGainsLf, decBands;
+    DevBuf<SplitterState> decSplit;
+    int outType{6};                        // DevFmtType order: 0 i8, 1 u8, 2 i16, 3 u16, 4 i32, 5 u32, 6 f32
+    float ditherDepth{0.0f};
+    uint32_t ditherSeed{22222};
+    DevBuf<unsigned char> pcm;
     // HRTF store
     DevBuf<float> hFieldDist, hCoeffs;
     DevBuf<uint8_t> hEvCount, hDelays;
@@ -1049,7 +1058,18 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = JoinPost(c)) return rc;
     if(int rc = RunEffects(c, c->stream, samples_to_do)) return rc;
-    if(!c->L.hrtf) return OALGPU_OK;
+    if(!c->L.hrtf)
+    {   // DeviceBase::Process(AmbiDecPostProcess), alc/alu.cpp:282-287: dry lines -> speaker feeds
+        if(c->decOn)
+        {
+            const DeviceLayout &D = c->L;
+            LaunchBFormatDecode(c->stream, c->exact, D.bus + size_t{D.numDry} * kLine, D.bus, c->decSplit.p, c->decBands.p,
+                c->decGainsHf.p, c->decDual ? c->decGainsLf.p : nullptr, D.numDry, c->decOut, samples_to_do);
+            HIP_TRY(hipGetLastError());
+        }
+        if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
+        return OALGPU_OK;
+    }
     const DeviceLayout &L = c->L;
     if(L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
     float *left = L.bus + size_t{L.numDry} * kLine;
@@ -1151,6 +1171,75 @@ int oalgpu_read_dry(oalgpu_context *c, float *out)
     if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(int rc = oalgpu_sync(c)) return rc;
     HIP_TRY(hipMemcpy(out, c->L.bus, BusWetOffset(c->L) * sizeof(float), hipMemcpyDeviceToHost));
+    return OALGPU_OK;
+}
+
+/* BFormatDec(inchans = num_dry_channels, coeffs, coeffslf, xover_f0norm), core/bformatdec.cpp:27-58 */
+int oalgpu_set_bformat_decoder(oalgpu_context *c, uint32_t num_out, const float *coeffs_hf, const float *coeffs_lf,
+    float xover_norm)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(c->L.hrtf) return Fail(OALGPU_ERR_INVALID, "oalgpu_set_bformat_decoder: an HRTF context post-processes with MixDirectHrtf");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    if(num_out == 0 || !coeffs_hf) { c->decOn = false; return OALGPU_OK; }
+    if(num_out > c->L.numReal || num_out > 32u)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_set_bformat_decoder: more output channels than real output lines");
+    if(coeffs_lf && !(xover_norm > 0.0f && xover_norm < 0.5f))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_set_bformat_decoder: a dual-band decoder needs 0 < xover_norm < 0.5");
+    const uint32_t nin = c->L.numDry;
+    // decoder[j].mGains[out] = coeffs[out][j] (bformatdec.cpp:33-38): stored [dry line][32]
+    std::vector<float> hf(size_t{nin} * 32, 0.0f), lf(size_t{nin} * 32, 0.0f);
+    for(uint32_t j = 0; j < nin && j < OALGPU_MAX_AMBI_CHANNELS; ++j)
+        for(uint32_t o = 0; o < num_out; ++o)
+        {
+            hf[j * 32 + o] = coeffs_hf[size_t{o} * OALGPU_MAX_AMBI_CHANNELS + j];
+            if(coeffs_lf) lf[j * 32 + o] = coeffs_lf[size_t{o} * OALGPU_MAX_AMBI_CHANNELS + j];
+        }
+    HIP_TRY(c->decGainsHf.alloc(hf.size())); HIP_TRY(c->decGainsHf.upload(hf.data(), hf.size()));
+    HIP_TRY(c->decGainsLf.alloc(lf.size())); HIP_TRY(c->decGainsLf.upload(lf.data(), lf.size()));
+    HIP_TRY(c->decBands.alloc(size_t{nin} * 2 * kLine)); HIP_TRY(c->decBands.zero());
+    std::vector<SplitterState> sp(nin);
+    for(auto &s : sp) s = SplitterState{coeffs_lf ? SplitterCoeff(xover_norm) : 0.0f, 0.0f, 0.0f, 0.0f};
+    HIP_TRY(c->decSplit.alloc(nin)); HIP_TRY(c->decSplit.upload(sp.data(), nin));
+    c->decOut = num_out; c->decDual = coeffs_lf != nullptr; c->decOn = true;
+    return OALGPU_OK;
+}
+
+/* the device's output format: DevFmtType (core/devformat.h:56-64), DitherDepth / DitherSeed (alc/alc.cpp) */
+int oalgpu_set_output(oalgpu_context *c, int sample_type, float dither_depth, uint32_t dither_seed)
+{
+    if(!c || sample_type < OALGPU_OUT_I8 || sample_type > OALGPU_OUT_F32 || dither_depth < 0.0f)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_set_output: bad arguments");
+    c->outType = sample_type; c->ditherDepth = dither_depth; c->ditherSeed = dither_seed;
+    return OALGPU_OK;
+}
+
+/* ApplyDither + Write<T> (alc/alu.cpp:2309-2408) over the output lines of the last update, then ONE D2H
+ * copy of the interleaved PCM: frames [0, samples_to_do) x frame_step samples of the configured type */
+int oalgpu_read_output(oalgpu_context *c, void *out, uint32_t samples_to_do, uint32_t frame_step)
+{
+    static const size_t bytesPer[7] = {1, 1, 2, 2, 4, 4, 4};
+    if(!c || !out || samples_to_do == 0 || samples_to_do > kLine || frame_step == 0 || frame_step > 64)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_read_output: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = JoinPost(c)) return rc;
+    const DeviceLayout &L = c->L;
+    // RealOut: the real output lines, or the dry lines themselves where the device has none (core/device.h:300)
+    float *lines = L.numReal ? L.bus + size_t{L.numDry} * kLine : L.bus;
+    const uint32_t nlines = std::min(L.numReal ? L.numReal : L.numDry, frame_step);
+    const uint32_t all = L.numReal ? L.numReal : L.numDry;
+    if(c->ditherDepth > 0.0f)
+    {
+        LaunchDither(c->stream, lines, all, samples_to_do, c->ditherDepth, c->ditherSeed);
+        c->ditherSeed = DitherAdvanceSeed(c->ditherSeed, all * samples_to_do * 2u);
+    }
+    const size_t nbytes = size_t{samples_to_do} * frame_step * bytesPer[c->outType];
+    if(c->pcm.n < nbytes) HIP_TRY(c->pcm.alloc(size_t{kLine} * 64 * 4));
+    LaunchWriteSamples(c->stream, c->outType, lines, nlines, samples_to_do, frame_step, c->pcm.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->pcm.p, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return OALGPU_OK;
 }
 

@@ -160,6 +160,15 @@ void LaunchGetCoeffs(hipStream_t s, const HrtfStoreDev &st, const float *dirs, u
 void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, float *accum,
     SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n);
 
+// ---- launchers (output_kernels.hip): BFormatDec, ApplyDither, Write<T> behind the buses ----
+// gainsHf / gainsLf: [dry line][32] (column = output line); gainsLf null = single-band decoder; bands =
+// scratch for [dry line][hp | lp][1024]
+void LaunchBFormatDecode(hipStream_t s, bool exact, float *out, const float *lines, SplitterState *states, float *bands,
+    const float *gainsHf, const float *gainsLf, uint32_t nin, uint32_t nout, uint32_t n);
+void LaunchDither(hipStream_t s, float *lines, uint32_t nlines, uint32_t n, float quantScale, uint32_t seed);
+uint32_t DitherAdvanceSeed(uint32_t seed, uint32_t draws);
+void LaunchWriteSamples(hipStream_t s, int sampleType, const float *lines, uint32_t nlines, uint32_t n, uint32_t frameStep, void *out);
+
 // ---- launcher (conv_kernels.hip): ConvolutionState::process for a mono response ----
 struct ConvLayoutHost {
     uint32_t numSegs, ringSlots, nlines, n, fifoPos, curSeg, numBlocks, numChunks, segsPerChunk;

@@ -1,0 +1,233 @@
+// The stage behind the buses: ambisonic dry lines -> speaker feeds, dither, and
+// the interleaved / converted PCM a host takes away -- so that config 2 ends in its 7.1 feeds and the
+// D2H copy of an update is the final PCM, not raw buses.
+//
+//   BFormatDec::process        core/bformatdec.cpp:60-95    (AmbiDecPostProcess, alc/alu.cpp:282-287)
+//     BandSplitter::process    core/filters/splitter.cpp:28-63   (dual-band decoders)
+//     MixSamples, Counter = 0  core/mixer/mixer_c.cpp:150-186    (constant gains, silence threshold)
+//   ApplyDither                alc/alu.cpp:2309-2332
+//   SampleConv<T>, Write<T>    alc/alu.cpp:2335-2390
+//
+// Integer results (the PCM, the dither sequence) are bit-exact in every mode; the decoder's floats are
+// bit-exact in EXACT mode (the reference's operation order: per input channel HF then LF, multiply and
+// add separately) and within the FAST tolerance otherwise.
+#include "dev_wave.hpp"
+
+#pragma clang fp contract(off)
+
+namespace oalgpu {
+namespace {
+
+constexpr float kSilence = 1.0e-5f;          // GainSilenceThreshold, core/mixer/defs.h:28
+
+// ---- BandSplitter::process: hp / lp of one dry line, state (lpZ1, lpZ2, apZ1) -----------------------------
+struct Band2 { float hp, lp; };
+__device__ __forceinline__ Band2 BandStep(Sp3 &s, float x, float apCoeff, float lpCoeff)
+{
+    const float d0 = (x - s.a) * lpCoeff;
+    const float lpY0 = s.a + d0;
+    s.a = lpY0 + d0;
+    const float d1 = (lpY0 - s.b) * lpCoeff;
+    const float lpY1 = s.b + d1;
+    s.b = lpY1 + d1;
+    const float apY = x * apCoeff + s.c;
+    s.c = x - apY * apCoeff;
+    return Band2{apY - lpY1, lpY1};
+}
+
+// one wavefront per dry line.  EXACT: the reference's serial loop on one lane; FAST: the 3-state block
+// scan of dev_wave.hpp (SplitterScan) with both bands kept.
+template<bool EXACT>
+__global__ void __launch_bounds__(64) BandSplitKernel(const float *lines, SplitterState *states, float *bands /* [line][2][1024] */,
+    uint32_t n)
+{
+    const uint32_t lane = threadIdx.x, ch = blockIdx.x;
+    const float *in = lines + size_t{ch} * kLine;
+    float *hp = bands + size_t{ch} * 2 * kLine, *lp = hp + kLine;
+    SplitterState st = states[ch];
+    const float apCoeff = st.coeff, lpCoeff = st.coeff * 0.5f + 0.5f;
+    if constexpr (EXACT)
+    {
+        if(lane == 0)
+        {
+            Sp3 s{st.lpZ1, st.lpZ2, st.apZ1};
+            for(uint32_t i = 0; i < n; ++i) { const Band2 b = BandStep(s, in[i], apCoeff, lpCoeff); hp[i] = b.hp; lp[i] = b.lp; }
+            states[ch].lpZ1 = s.a; states[ch].lpZ2 = s.b; states[ch].apZ1 = s.c;
+        }
+        return;
+    }
+    else
+    {
+        const uint32_t seg = ((n + 63u) / 64u) | 1u;
+        const uint32_t begin = lane * seg < n ? lane * seg : n;
+        const uint32_t end = (begin + seg < n) ? begin + seg : n;
+        Mat3 M{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for(uint32_t i = 0; i < seg; ++i)
+        {
+            BandStep(M.c0, 0.0f, apCoeff, lpCoeff); BandStep(M.c1, 0.0f, apCoeff, lpCoeff); BandStep(M.c2, 0.0f, apCoeff, lpCoeff);
+        }
+        Sp3 q{0, 0, 0};
+        for(uint32_t i = begin; i < end; ++i) BandStep(q, in[i], apCoeff, lpCoeff);
+        for(uint32_t i = end; i < begin + seg; ++i) BandStep(q, 0.0f, apCoeff, lpCoeff);   // runs of equal length: one transition matrix
+        Sp3 e = q;
+        Sp3 s0{st.lpZ1, st.lpZ2, st.apZ1};
+        Mat3 P = M;
+#pragma unroll
+        for(int step = 0; step < 6; ++step)
+        {
+            const int d = 1 << step;
+            Sp3 o;
+            o.a = __shfl_up(e.a, d); o.b = __shfl_up(e.b, d); o.c = __shfl_up(e.c, d);
+            const Sp3 mo = MatVec3(P, o);
+            if(int(lane) >= d) { e.a += mo.a; e.b += mo.b; e.c += mo.c; }
+            const Sp3 ms = MatVec3(P, s0);
+            if(lane & uint32_t(d)) s0 = ms;
+            if(step < 5) P = MatMul3(P, P);
+        }
+        Sp3 prevE;
+        prevE.a = __shfl_up(e.a, 1); prevE.b = __shfl_up(e.b, 1); prevE.c = __shfl_up(e.c, 1);
+        Sp3 start = s0;
+        if(lane > 0) { start.a += prevE.a; start.b += prevE.b; start.c += prevE.c; }
+        for(uint32_t i = begin; i < end; ++i) { const Band2 b = BandStep(start, in[i], apCoeff, lpCoeff); hp[i] = b.hp; lp[i] = b.lp; }
+        const int lastLane = int((n - 1u) / seg);
+        const float z0 = __shfl(start.a, lastLane), z1 = __shfl(start.b, lastLane), z2 = __shfl(start.c, lastLane);
+        if(lane == 0) { states[ch].lpZ1 = z0; states[ch].lpZ2 = z1; states[ch].apZ1 = z2; }
+    }
+}
+
+// out[c][i] += sum over the dry lines j, in the reference's order (j ascending; per j HF then LF), of
+// in_j[i] * gain[j][c]; a gain whose magnitude does not exceed GainSilenceThreshold is skipped as MixLine skips it
+template<bool EXACT, bool DUAL>
+__global__ void __launch_bounds__(256) BFormatMixKernel(float *out, const float *lines, const float *bands, const float *gainsHf /* [in][32] */,
+    const float *gainsLf, uint32_t nin, uint32_t nout, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if(i >= n) return;
+    for(uint32_t c = 0; c < nout; ++c)
+    {
+        float acc = out[size_t{c} * kLine + i];
+        for(uint32_t j = 0; j < nin; ++j)
+        {
+            const float gh = gainsHf[j * 32u + c];
+            if constexpr (DUAL)
+            {
+                const float gl = gainsLf[j * 32u + c];
+                const float hp = bands[(size_t{j} * 2) * kLine + i], lp = bands[(size_t{j} * 2 + 1) * kLine + i];
+                if(fabsf(gh) > kSilence) acc = EXACT ? acc + hp * gh : __builtin_fmaf(hp, gh, acc);
+                if(fabsf(gl) > kSilence) acc = EXACT ? acc + lp * gl : __builtin_fmaf(lp, gl, acc);
+            }
+            else
+            {
+                const float x = lines[size_t{j} * kLine + i];
+                if(fabsf(gh) > kSilence) acc = EXACT ? acc + x * gh : __builtin_fmaf(x, gh, acc);
+            }
+        }
+        out[size_t{c} * kLine + i] = acc;
+    }
+}
+
+// ---- ApplyDither: the reference draws two values of its LCG (alu.cpp:444-448) per sample, line after line;
+// draw k of the sequence is an affine map of the seed, built by square-and-multiply
+__device__ __forceinline__ uint32_t DitherJump(uint32_t seed, uint32_t k)
+{
+    uint32_t accA = 1u, accC = 0u;                   // composition so far: x -> accA x + accC
+    uint32_t a = 96314165u, c = 907633515u;          // one step
+    while(k)
+    {
+        if(k & 1u) { accC = a * accC + c; accA = a * accA; }
+        c = a * c + c; a = a * a;
+        k >>= 1;
+    }
+    return accA * seed + accC;
+}
+
+__global__ void __launch_bounds__(256) DitherKernel(float *lines, uint32_t nlines, uint32_t n, float quantScale, uint32_t seed)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, line = blockIdx.y;
+    if(i >= n || line >= nlines) return;
+    const uint32_t draw = (line * n + i) * 2u;
+    const uint32_t rng0 = DitherJump(seed, draw + 1u);
+    const uint32_t rng1 = rng0 * 96314165u + 907633515u;
+    constexpr double invRange = 1.0 / 4294967295.0;
+    float val = lines[size_t{line} * kLine + i] * quantScale;
+    val += float(double(rng0) * invRange - double(rng1) * invRange);
+    const float invScale = 1.0f / quantScale;
+    lines[size_t{line} * kLine + i] = rintf(val) * invScale;      // fast_roundf: round to nearest even
+}
+
+// ---- SampleConv<T> + Write<T>: frame i, channel c of the interleaved output
+template<typename T> __device__ __forceinline__ T ConvSample(float v);
+template<> __device__ __forceinline__ float ConvSample<float>(float v) { return v; }
+template<> __device__ __forceinline__ int32_t ConvSample<int32_t>(float v)
+{ return __float2int_rn(fminf(fmaxf(v * 2147483648.0f, -2147483648.0f), 2147483520.0f)); }
+template<> __device__ __forceinline__ int16_t ConvSample<int16_t>(float v)
+{ return int16_t(__float2int_rn(fminf(fmaxf(v * 32768.0f, -32768.0f), 32767.0f))); }
+template<> __device__ __forceinline__ int8_t ConvSample<int8_t>(float v)
+{ return int8_t(__float2int_rn(fminf(fmaxf(v * 128.0f, -128.0f), 127.0f))); }
+template<> __device__ __forceinline__ uint32_t ConvSample<uint32_t>(float v) { return uint32_t(ConvSample<int32_t>(v)) + 2147483648u; }
+template<> __device__ __forceinline__ uint16_t ConvSample<uint16_t>(float v) { return uint16_t(uint16_t(ConvSample<int16_t>(v)) + 32768u); }
+template<> __device__ __forceinline__ uint8_t ConvSample<uint8_t>(float v) { return uint8_t(uint8_t(ConvSample<int8_t>(v)) + 128u); }
+
+template<typename T>
+__global__ void __launch_bounds__(256) WriteKernel(const float *lines, uint32_t nlines, uint32_t n, uint32_t frameStep, T *out)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;          // element of the interleaved buffer
+    if(k >= n * frameStep) return;
+    const uint32_t i = k / frameStep, c = k % frameStep;
+    out[k] = ConvSample<T>(c < nlines ? lines[size_t{c} * kLine + i] : 0.0f);
+}
+
+} // namespace
+
+void LaunchBFormatDecode(hipStream_t s, bool exact, float *out, const float *lines, SplitterState *states, float *bands,
+    const float *gainsHf, const float *gainsLf, uint32_t nin, uint32_t nout, uint32_t n)
+{
+    const dim3 mgrid((n + 255u) / 256u);
+    if(gainsLf)
+    {
+        if(exact)
+        {
+            hipLaunchKernelGGL(BandSplitKernel<true>, dim3(nin), dim3(64), 0, s, lines, states, bands, n);
+            hipLaunchKernelGGL((BFormatMixKernel<true, true>), mgrid, dim3(256), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
+        }
+        else
+        {
+            hipLaunchKernelGGL(BandSplitKernel<false>, dim3(nin), dim3(64), 0, s, lines, states, bands, n);
+            hipLaunchKernelGGL((BFormatMixKernel<false, true>), mgrid, dim3(256), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
+        }
+    }
+    else if(exact) hipLaunchKernelGGL((BFormatMixKernel<true, false>), mgrid, dim3(256), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
+    else hipLaunchKernelGGL((BFormatMixKernel<false, false>), mgrid, dim3(256), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
+}
+
+uint32_t DitherAdvanceSeed(uint32_t seed, uint32_t draws)
+{   // host copy of DitherJump
+    uint32_t accA = 1u, accC = 0u, a = 96314165u, c = 907633515u, k = draws;
+    while(k)
+    {
+        if(k & 1u) { accC = a * accC + c; accA = a * accA; }
+        c = a * c + c; a = a * a;
+        k >>= 1;
+    }
+    return accA * seed + accC;
+}
+
+void LaunchDither(hipStream_t s, float *lines, uint32_t nlines, uint32_t n, float quantScale, uint32_t seed)
+{ hipLaunchKernelGGL(DitherKernel, dim3((n + 255u) / 256u, nlines), dim3(256), 0, s, lines, nlines, n, quantScale, seed); }
+
+void LaunchWriteSamples(hipStream_t s, int sampleType, const float *lines, uint32_t nlines, uint32_t n, uint32_t frameStep, void *out)
+{
+    const dim3 grid((n * frameStep + 255u) / 256u), block(256);
+    switch(sampleType)
+    {
+    case 0: hipLaunchKernelGGL(WriteKernel<int8_t>, grid, block, 0, s, lines, nlines, n, frameStep, static_cast<int8_t*>(out)); break;
+    case 1: hipLaunchKernelGGL(WriteKernel<uint8_t>, grid, block, 0, s, lines, nlines, n, frameStep, static_cast<uint8_t*>(out)); break;
+    case 2: hipLaunchKernelGGL(WriteKernel<int16_t>, grid, block, 0, s, lines, nlines, n, frameStep, static_cast<int16_t*>(out)); break;
+    case 3: hipLaunchKernelGGL(WriteKernel<uint16_t>, grid, block, 0, s, lines, nlines, n, frameStep, static_cast<uint16_t*>(out)); break;
+    case 4: hipLaunchKernelGGL(WriteKernel<int32_t>, grid, block, 0, s, lines, nlines, n, frameStep, static_cast<int32_t*>(out)); break;
+    case 5: hipLaunchKernelGGL(WriteKernel<uint32_t>, grid, block, 0, s, lines, nlines, n, frameStep, static_cast<uint32_t*>(out)); break;
+    default: hipLaunchKernelGGL(WriteKernel<float>, grid, block, 0, s, lines, nlines, n, frameStep, static_cast<float*>(out)); break;
+    }
+}
+
+} // namespace oalgpu

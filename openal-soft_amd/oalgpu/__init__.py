@@ -17,6 +17,7 @@ MAX_PAD = 48
 HRTF_HIST = 64
 HRIR_LEN = 128
 MAX_SENDS = 6
+(OUT_I8, OUT_U8, OUT_I16, OUT_U16, OUT_I32, OUT_U32, OUT_F32) = range(7)      # oalgpu_output_type
 MAX_OUT = 32
 MAX_AMBI = 25
 MATH_EXACT, MATH_FAST = 0, 1
@@ -435,6 +436,30 @@ class Scene:
         hf = np.ascontiguousarray(hfscales, np.float32)
         check(lib.oalgpu_set_direct_hrtf(self.h, _fp(cc), _fp(hf), xover_norm, irsize),
               "oalgpu_set_direct_hrtf")
+
+    # the stage behind the buses: BFormatDec, dither, output PCM (include/oalgpu.h)
+    def set_bformat_decoder(self, coeffs_hf, coeffs_lf=None, xover_norm=400.0 / 48000.0):
+        lib.oalgpu_set_bformat_decoder.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, C.c_float]
+        if coeffs_hf is None:
+            check(lib.oalgpu_set_bformat_decoder(self.h, 0, None, None, 0.0))
+            return
+        hf = np.ascontiguousarray(coeffs_hf, np.float32)
+        lf = None if coeffs_lf is None else np.ascontiguousarray(coeffs_lf, np.float32)
+        assert hf.ndim == 2 and hf.shape[1] == MAX_AMBI
+        check(lib.oalgpu_set_bformat_decoder(self.h, hf.shape[0], _fp(hf), _fp(lf) if lf is not None else None, xover_norm),
+              "oalgpu_set_bformat_decoder")
+
+    def set_output(self, sample_type, dither_depth=0.0, dither_seed=22222):
+        lib.oalgpu_set_output.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint32]
+        check(lib.oalgpu_set_output(self.h, sample_type, dither_depth, dither_seed), "oalgpu_set_output")
+        self._out_type = sample_type
+
+    def read_output(self, samples_to_do=BUFFER_LINE, frame_step=2):
+        lib.oalgpu_read_output.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        dt = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.float32][getattr(self, "_out_type", 6)]
+        out = np.zeros(samples_to_do * frame_step, dt)
+        check(lib.oalgpu_read_output(self.h, out.ctypes.data_as(C.c_void_p), samples_to_do, frame_step), "oalgpu_read_output")
+        return out
 
     def set_slot_convolution(self, slot, conv):
         lib.oalgpu_slot_set_convolution.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]

@@ -189,3 +189,36 @@ class SceneScript:
             for c in range(5):
                 p.dry_gains[c] = gain * coeffs[c]
         return p
+
+
+# ---------------------------------------------------------------------------------------------
+# Speaker decoders of the reference's built-in layouts (input data of BFormatDec, as InitPanning
+# builds them, alc/panning.cpp:719-850): rows = real output lines, 25 columns = dry lines.
+# ---------------------------------------------------------------------------------------------
+def stereo_decoder():
+    """StereoConfig, alc/panning.cpp:548-556: first-order 2D (W, Y, X) -> FrontLeft, FrontRight, single band."""
+    m = np.zeros((2, 25), np.float32)
+    m[0, :3] = [5.00000000e-1, 2.88675135e-1, 5.52305643e-2]
+    m[1, :3] = [5.00000000e-1, -2.88675135e-1, 5.52305643e-2]
+    return m, None
+
+
+def x71_decoder():
+    """X71Config, alc/panning.cpp:609-631: second-order 2D (5 dry lines) -> BackLeft, SideLeft, FrontLeft,
+    FrontRight, SideRight, BackRight, dual band (HF order gains sqrt(2), sqrt(3/2), sqrt(1/2); LF 1), on the
+    8 real output lines of a 7.1 device (FL FR FC LFE BL BR SL SR, core/devformat.cpp); returns (hf, lf)."""
+    rows = np.array([[1.66666667e-1, 9.62250449e-2, -1.66666667e-1, -1.49071198e-1, 8.60662966e-2],
+                     [1.66666667e-1, 1.92450090e-1, 0.0, 0.0, -1.72132593e-1],
+                     [1.66666667e-1, 9.62250449e-2, 1.66666667e-1, 1.49071198e-1, 8.60662966e-2],
+                     [1.66666667e-1, -9.62250449e-2, 1.66666667e-1, -1.49071198e-1, 8.60662966e-2],
+                     [1.66666667e-1, -1.92450090e-1, 0.0, 0.0, -1.72132593e-1],
+                     [1.66666667e-1, -9.62250449e-2, -1.66666667e-1, 1.49071198e-1, 8.60662966e-2]], np.float32)
+    order = [0, 1, 1, 2, 2]                                   # AmbiIndex::OrderFrom2DChannel
+    hf_gain = np.array([1.41421356, 1.22474487, 7.07106781e-1], np.float32)
+    lines = [4, 6, 0, 1, 7, 5]
+    hf = np.zeros((8, 25), np.float32)
+    lf = np.zeros((8, 25), np.float32)
+    for row, line in zip(rows, lines):
+        hf[line, :5] = row * hf_gain[order]
+        lf[line, :5] = row
+    return hf, lf

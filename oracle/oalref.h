@@ -203,6 +203,14 @@ int oal_scene_set_voice_params(oal_scene *s, int voice, const oal_voice_params *
 int oal_scene_set_voice_state(oal_scene *s, int voice, int vstate);
 /* One update: zero Dry/Real + wet buses, Voice::mix for every Playing|Stopping voice in order,
  * then (HRTF device, post_process != 0) MixDirectHrtf.  (alc/alu.cpp:2177-2273,2412-2459) */
+/* BFormatDec (core/bformatdec.cpp:27-95): coeffs_hf / coeffs_lf = nout x 25 (ChannelDec per output
+ * channel); coeffs_lf NULL = single band.  process() accumulates into out (nout x 1024). */
+typedef struct oal_bformatdec oal_bformatdec;
+oal_bformatdec *oal_bformatdec_create(uint32_t inchans, uint32_t nout, const float *coeffs_hf,
+    const float *coeffs_lf, float xover_norm);
+void oal_bformatdec_process(oal_bformatdec *d, float *out, const float *in, uint32_t n);
+void oal_bformatdec_destroy(oal_bformatdec *d);
+
 int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process);
 /* DeviceBase::Process(HrtfPostProcess) alone (alc/alu.cpp:289-298): for scenes whose effect slots
  * add into the dry lines between the voice loop and the post-process (alu.cpp:2209-2257).  The dry

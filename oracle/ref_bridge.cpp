@@ -118,6 +118,10 @@ struct oalbridge {
     std::vector<std::pair<Voice*, Voice::State>> batch;
     int error{0};
     std::string errorText;
+    /* test aid for the output stage (ApplyDither / Write<T>, alu.cpp:2309-2408, are file-local): lines added
+     * to DeviceBase::RealOut by the voice loop's first voice, so that the reference's own output stage
+     * converts a known signal */
+    std::vector<float> inject;
 };
 
 namespace {
@@ -274,6 +278,14 @@ void Voice::mix(State const vstate, ContextBase *const context, std::chrono::nan
     unsigned const samplesToDo) noexcept
 {
     oalbridge *b = gActive;
+    if(b && !b->inject.empty())
+    {
+        auto &real = b->dev->RealOut.Buffer;
+        const size_t nl = std::min(real.size(), b->inject.size() / BufferLineSize);
+        for(size_t c{0}; c < nl; ++c)
+            for(size_t i{0}; i < samplesToDo; ++i) real[c][i] += b->inject[c*BufferLineSize + i];
+        return;
+    }
     if(!b || b->mode == ModeCpu || b->error)
     {
         oalbridge_voice_mix_cpu(this, int(vstate), context, deviceTime.count(), samplesToDo);
@@ -517,6 +529,32 @@ int oalbridge_source_state(oalbridge *b, int source, int32_t out[4])
     out[1] = v->mPosition.load(std::memory_order_relaxed);
     out[2] = int32_t(v->mPositionFrac.load(std::memory_order_relaxed));
     out[3] = int32_t(v->mStep);
+    return 0;
+}
+
+/* ---- the reference's output stage on a known signal: `lines` (nlines x 1024) replace the voice loop's
+ * result on RealOut (nlines <= 2 here: the device is stereo), then Limiter (none), ApplyDither (depth > 0)
+ * and Write<T> run as DeviceBase::renderSamples runs them.  fmt: DevFmtType (0 i8, 1 u8, 2 i16, 3 u16,
+ * 4 i32, 5 u32, 6 f32); the post-process is taken out so that RealOut is exactly `lines`. */
+int oalbridge_render_lines(oalbridge *b, const float *lines, uint32_t nlines, int fmt, float dither_depth,
+    uint32_t *dither_seed, void *out, uint32_t frames, uint32_t frame_step)
+{
+    auto &dev = *b->dev;
+    if(b->sources.empty()) return -1;                    /* the hook rides on a playing voice */
+    b->inject.assign(lines, lines + size_t{nlines}*BufferLineSize);
+    auto saved = std::move(dev.mPostProcess);
+    dev.mPostProcess.emplace<std::monostate>();
+    dev.FmtType = static_cast<DevFmtType>(fmt);
+    dev.DitherDepth = dither_depth;
+    dev.DitherSeed = *dither_seed;
+    gActive = b;
+    dev.renderSamples(out, frames, frame_step);
+    gActive = nullptr;
+    *dither_seed = dev.DitherSeed;
+    dev.DitherDepth = 0.0f;
+    dev.FmtType = DevFmtFloat;
+    dev.mPostProcess = std::move(saved);
+    b->inject.clear();
     return 0;
 }
 

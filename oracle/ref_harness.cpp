@@ -835,6 +835,44 @@ void oal_conv_process(oal_conv *c, const float *wet_in, float *out_lines, uint32
 
 void oal_conv_destroy(oal_conv *c) { delete c; }
 
+/* ---- BFormatDec (core/bformatdec.cpp:27-95), the AmbiDecPostProcess of non-HRTF devices ---- */
+struct oal_bformatdec { std::unique_ptr<BFormatDec> dec; size_t inchans, nout; };
+
+oal_bformatdec *oal_bformatdec_create(uint32_t inchans, uint32_t nout, const float *coeffs_hf,
+    const float *coeffs_lf, float xover_norm)
+{
+    ApplySimd();
+    auto d = std::make_unique<oal_bformatdec>();
+    d->inchans = inchans; d->nout = nout;
+    auto hf = std::vector<ChannelDec>(nout), lf = std::vector<ChannelDec>(coeffs_lf ? nout : 0u);
+    for(size_t o{0};o < nout;++o)
+    {
+        hf[o] = ChannelDec{};
+        std::copy_n(coeffs_hf + o*MaxAmbiChannels, MaxAmbiChannels, hf[o].begin());
+        if(coeffs_lf)
+        {
+            lf[o] = ChannelDec{};
+            std::copy_n(coeffs_lf + o*MaxAmbiChannels, MaxAmbiChannels, lf[o].begin());
+        }
+    }
+    d->dec = std::make_unique<BFormatDec>(inchans, hf, lf, xover_norm);
+    return d.release();
+}
+
+/* out: nout x 1024 (accumulated into, like DeviceBase::RealOut), in: inchans x 1024 */
+void oal_bformatdec_process(oal_bformatdec *d, float *out, const float *in, uint32_t n)
+{
+    auto const fpuctl = FPUCtl{};
+    auto outl = al::vector<FloatBufferLine,16>(d->nout);
+    auto inl = al::vector<FloatBufferLine,16>(d->inchans);
+    for(size_t c{0};c < d->nout;++c) std::copy_n(out + c*BufferLineSize, BufferLineSize, outl[c].data());
+    for(size_t c{0};c < d->inchans;++c) std::copy_n(in + c*BufferLineSize, BufferLineSize, inl[c].data());
+    d->dec->process(std::span{outl}, std::span<const FloatBufferLine>{inl.data(), inl.size()}, n);
+    for(size_t c{0};c < d->nout;++c) std::copy_n(outl[c].data(), BufferLineSize, out + c*BufferLineSize);
+}
+
+void oal_bformatdec_destroy(oal_bformatdec *d) { delete d; }
+
 void oal_calc_direction_coeffs(const float dir[3], float spread, float *out25)
 {
     auto const coeffs = CalcDirectionCoeffs(std::span<const float,3>{dir, 3}, spread);

@@ -36,6 +36,8 @@ def lib():
         L.oalbridge_error.restype = C.c_char_p
         L.oalbridge_error.argtypes = [C.c_void_p]
         L.oalbridge_source_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+        L.oalbridge_render_lines.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_int, C.c_float, C.POINTER(C.c_uint32),
+                                             C.c_void_p, C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
 
@@ -69,6 +71,17 @@ class Bridge:
         rc = lib().oalbridge_render(self.h, out.ctypes.data_as(f32p), frames)
         assert rc == 0, lib().oalbridge_error(self.h).decode()
         return out
+
+    def render_lines(self, lines, fmt, dither_depth, seed, frames, frame_step):
+        """The reference's own ApplyDither + Write<T> on `lines` (<= 2 x 1024); returns (pcm, new seed)."""
+        dt = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.float32][fmt]
+        lines = np.ascontiguousarray(lines, np.float32)
+        out = np.zeros(frames * frame_step, dt)
+        sd = C.c_uint32(seed)
+        rc = lib().oalbridge_render_lines(self.h, lines.ctypes.data_as(f32p), lines.shape[0], fmt, dither_depth,
+                                          C.byref(sd), out.ctypes.data_as(C.c_void_p), frames, frame_step)
+        assert rc == 0
+        return out, sd.value
 
     def source_state(self, source):
         st = (C.c_int32 * 4)()

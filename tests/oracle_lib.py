@@ -207,6 +207,11 @@ class OracleLib:
             L.oal_reverb_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
             L.oal_reverb_line_lengths.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.oal_calc_direction_coeffs.argtypes = [f32p, C.c_float, f32p]
+        if hasattr(L, "oal_bformatdec_create"):
+            L.oal_bformatdec_create.restype = C.c_void_p
+            L.oal_bformatdec_create.argtypes = [C.c_uint32, C.c_uint32, f32p, f32p, C.c_float]
+            L.oal_bformatdec_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
+            L.oal_bformatdec_destroy.argtypes = [C.c_void_p]
         self.kind = L.oal_kind().decode()
 
     def make_scene(self, **kw):
@@ -537,6 +542,28 @@ class Convolution:
     def close(self):
         if self.h:
             self.lib.L.oal_conv_destroy(self.h)
+            self.h = None
+
+
+class BFormatDec:
+    """The reference's BFormatDec (core/bformatdec.cpp): coeffs_hf / coeffs_lf = nout x 25."""
+
+    def __init__(self, lib, inchans, coeffs_hf, coeffs_lf=None, xover_norm=400.0 / 48000.0):
+        self.lib = lib
+        hf = np.ascontiguousarray(coeffs_hf, np.float32)
+        self.nout = hf.shape[0]
+        lf = None if coeffs_lf is None else np.ascontiguousarray(coeffs_lf, np.float32)
+        self.h = lib.L.oal_bformatdec_create(inchans, self.nout, _fp(hf), _fp(lf) if lf is not None else None, xover_norm)
+        assert self.h
+
+    def process(self, out_lines, in_lines, n):
+        assert out_lines.dtype == np.float32 and out_lines.shape == (self.nout, BUFFER_LINE) and out_lines.flags.c_contiguous
+        inl = np.ascontiguousarray(in_lines, np.float32)
+        self.lib.L.oal_bformatdec_process(self.h, _fp(out_lines), _fp(inl), n)
+
+    def close(self):
+        if self.h:
+            self.lib.L.oal_bformatdec_destroy(self.h)
             self.h = None
 
 

@@ -45,13 +45,15 @@ def _oracle():
     return L
 
 
-def build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir=None):
+def build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir=None, num_real=None):
     """bench.build_scene, restated on the reference: same buffers, voices, direct-HRTF decoder."""
     hrtf = config in (3, 5)
     nsends = {4: 4, 5: 1}.get(config, 0)
     if hrtf:
         L.hrtf_load(mhr_path)
-    sc = ol.Scene(L, sample_rate=48000, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0,
+    if num_real is None:
+        num_real = 2 if hrtf else 0
+    sc = ol.Scene(L, sample_rate=48000, num_dry=4 if hrtf else 5, num_real=num_real,
                   num_sends=nsends, num_slots=nsends, wet_channels=4, hrtf=hrtf)
     effects = []
     if config == 4:
