@@ -258,6 +258,14 @@ typedef struct oalgpu_voice_params {
     oalgpu_filter_params send_filter[OALGPU_MAX_SENDS];
     float    send_gains[OALGPU_MAX_SENDS][OALGPU_MAX_AMBI_CHANNELS]; /* mWetParams[i].Gains.Target */
 } oalgpu_voice_params;
+/* Delayed start (Voice::mStartTime, core/voice.h:209; Voice::mix, core/voice.cpp:1023-1046): the voice --
+ * initialised, not mixed yet -- starts `samples` output samples after the beginning of the next update:
+ * that update mixes samples_to_do - outPos samples of it at output position outPos; updates that end
+ * earlier leave it untouched (the remaining delay shrinks by samples_to_do).  A voice told to stop before
+ * it started becomes Stopped.  samples < sample_rate (the reference does not schedule starts a second
+ * or more ahead either). */
+int oalgpu_voice_set_start_delay(oalgpu_context *ctx, uint32_t voice, uint32_t samples);
+
 /* Applies `count` parameter blocks (voices[i] <- params[i]); the HRIR blend of getCoeffs and
  * the BiquadInterpFilter::setParams state machine run on the GPU. */
 int oalgpu_voice_set_params(oalgpu_context *ctx, const uint32_t *voices,

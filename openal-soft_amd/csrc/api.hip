@@ -112,6 +112,7 @@ struct oalgpu_context {
 
     DevBuf<float> tables;
     DevBuf<BufferItem> buffers;
+    DevBuf<uint32_t> startDelay;           // [voice] samples until a delayed voice starts
     std::vector<void*> bufferData;
     std::vector<uint32_t> bufferLoopLen;   // loop_end - loop_start of every registered buffer (0: cannot loop)
     uint32_t numBuffers{0};
@@ -579,6 +580,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->sendCur.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendCur.zero()); L.sendCur = c->sendCur.p;
     HIP_TRY(c->sendTgt.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendTgt.zero()); L.sendTgt = c->sendTgt.p;
     HIP_TRY(c->ambi.alloc(nv)); HIP_TRY(c->ambi.zero()); L.ambi = c->ambi.p;
+    HIP_TRY(c->startDelay.alloc(nv)); HIP_TRY(c->startDelay.zero()); L.startDelay = c->startDelay.p;
     L.numLineGroups = L.numGroups;
     L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0; L.streamsPerVoice = 0;
     L.nfc = nullptr; L.nfcOrders = 0;
@@ -771,6 +773,21 @@ int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc
     if(d->looping && c->bufferLoopLen[size_t(d->buffer)] == 0)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: a looping voice needs a buffer registered with loop_end > loop_start");
     c->initPending.push_back(VoiceInitRecord{voice, d->buffer, d->looping ? 1 : 0, d->position, d->position_frac});
+    return OALGPU_OK;
+}
+
+/* Voice::mStartTime (core/voice.h:209): the voice starts `samples` output samples from the beginning of
+ * the next update (Voice::mix's delayed start, voice.cpp:1023-1046: outPos = round((mStartTime -
+ * deviceTime) * rate)); updates that end before that leave the voice untouched. */
+int oalgpu_voice_set_start_delay(oalgpu_context *c, uint32_t voice, uint32_t samples)
+{
+    if(!c || voice >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_start_delay: bad voice");
+    if(samples >= c->desc.sample_rate)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_start_delay: a start a second or more ahead is not scheduled yet (voice.cpp:1036-1038)");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    LaunchSetStartDelay(c->stream, c->L, voice, samples);
+    HIP_TRY(hipGetLastError());
     return OALGPU_OK;
 }
 

@@ -29,6 +29,7 @@ enum VoiceFlagBits : uint32_t {
     kFlagHrtfDirty = 1u << 3,       // Hrtf.Target replaced since the last mix (Old != Target)
     kFlagAmbiScale = 1u << 4,       // VoiceFlag::IsAmbisonic: ambi[v] holds the channel's splitter and scales
     kFlagNfc = 1u << 5,             // VoiceFlag::HasNfc: nfc[v] holds DirectParams::NFCtrlFilter
+    kFlagDelayed = 1u << 6,         // mStartTime lies ahead: startDelay[v] samples until the voice starts (voice.cpp:1023-1046)
     kFlagSendFilterShift = 8        // bits 8..13: mSend[i].FilterActive
 };
 
@@ -99,6 +100,7 @@ struct DeviceLayout {
     BiquadSlot *sfilt;
     float *sendCur, *sendTgt;
     AmbiScaleState *ambi;                   // [voice]
+    uint32_t *startDelay;                   // [voice] samples until a delayed voice starts (kFlagDelayed)
     NfcState *nfc;                          // [voice], null unless the context has NFC
     uint32_t chansPerOrder[5];              // DeviceBase::NumChannelsPerOrder (NFC contexts)
     uint32_t nfcOrders;                     // orders 1.. with lines (0 = no NFC)
@@ -195,6 +197,7 @@ void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo,
 // ---- launchers (voice_wave.hip): the FAST HRTF hot path, one wavefront per voice ----
 void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st);
 void LaunchSetNfc(hipStream_t s, const DeviceLayout &L, uint32_t voice, const NfcState &coeffs);
+void LaunchSetStartDelay(hipStream_t s, const DeviceLayout &L, uint32_t voice, uint32_t samples);
 bool WaveKernelApplies(bool exact, const DeviceLayout &L);
 const char *WaveKernelName(const DeviceLayout &L);
 uint32_t WaveKernelGroups(const DeviceLayout &L);

@@ -126,7 +126,7 @@ int oalgpu_reverb_update(oalgpu_reverb *r, const oalgpu_reverb_props *props, flo
     if(r->device >= 0)
     {
         if(int rc = CheckOffsets(trial.params.pipe[trial.params.current_pipeline])) return rc;
-        if(full) { if(int rc = CheckOffsets(trial.params.pipe[!trial.params.current_pipeline])) return rc; }
+        // (the other pipeline is either the one that was current -- validated then -- or still unused)
     }
     r->host = trial;
     r->dirty[r->host.params.current_pipeline] = true;
@@ -147,9 +147,12 @@ int oalgpu_reverb_set_params(oalgpu_reverb *r, const oalgpu_reverb_params *param
     if(params->current_pipeline != 0 && params->current_pipeline != 1)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_set_params: current_pipeline must be 0 or 1");
     if(r->device >= 0)
-    {   // a caller-supplied block: both pipelines are checked before anything is installed
-        if(int rc = CheckOffsets(params->pipe[0])) return rc;
-        if(int rc = CheckOffsets(params->pipe[1])) return rc;
+    {   // a caller-supplied block: checked before anything is installed
+        const int cur = params->current_pipeline;
+        if(int rc = CheckOffsets(params->pipe[cur])) return rc;
+        // the other pipeline runs only while a parameter change cross-fades (reverb.cpp:1840-1882)
+        if(params->pipeline_state == OALGPU_REVERB_START_FADE || params->pipeline_state == OALGPU_REVERB_FADING)
+            if(int rc = CheckOffsets(params->pipe[!cur])) return rc;
     }
     const bool full = r->host.install(*params);
     r->dirty[r->host.params.current_pipeline] = true;

@@ -186,8 +186,9 @@ __device__ __forceinline__ void RareBiquadInterp(BiquadState *f0, BiquadState *f
 { BiquadDualInterp(*f0, *f1, buf, buf, n); }
 
 // DoFilters (voice.cpp:255-267) for the direct path, in place over buf[0..n), by the whole workgroup.
+// (`aligned`: buf is 16-byte aligned -- a delayed start's line is not, and takes the serial loop)
 __device__ __forceinline__ void BlockDoFilters(BlockLds &sm, BiquadSlot *slots, bool filterActive, float *buf, uint32_t n,
-    uint32_t tid)
+    uint32_t tid, bool aligned)
 {
     if(!filterActive && tid != 0) return;               // voice.cpp:264-265 is one thread's work
     BiquadState f0, f1;
@@ -198,7 +199,7 @@ __device__ __forceinline__ void BlockDoFilters(BlockLds &sm, BiquadSlot *slots, 
     }
     if(filterActive)
     {
-        if(f0.counter <= 0 && f1.counter <= 0)
+        if(f0.counter <= 0 && f1.counter <= 0 && aligned)
         {
             BiquadDualBlockScan(f0, f1, buf, n, tid, sm.xch);
             if(tid == 0) { slots[0].f.z1 = f0.z1; slots[0].f.z2 = f0.z2; slots[1].f.z1 = f1.z1; slots[1].f.z2 = f1.z2; }
@@ -229,8 +230,8 @@ __device__ __forceinline__ void BlockDoFilters(BlockLds &sm, BiquadSlot *slots, 
 // (arguments BY VALUE: taking the address of the kernel's DeviceLayout or of a voice head would move them
 // from SGPRs to the stack for the whole kernel)
 __device__ __forceinline__ void RareLoadResampled(BlockLds *sm, DeviceLayout L, uint32_t v, uint32_t lane,
-    VoiceHead head, bool playing, uint32_t N, int32_t bufferItem, bool looping, SrcPlan plan)
-{ LoadResampledWave<true>(*sm, *sm, L, v, lane, head, playing, N, N, bufferItem, looping, plan); }
+    VoiceHead head, bool playing, uint32_t N, int32_t bufferItem, bool looping, SrcPlan plan, uint32_t mixOffset)
+{ LoadResampledWave<true>(*sm, *sm, L, v, lane, head, playing, N, N, bufferItem, looping, plan, mixOffset); }
 
 __device__ __forceinline__ void RareResampleAt(BlockLds *sm, const float *tables, VoiceHead head, uint32_t N,
     uint32_t t)
@@ -243,11 +244,11 @@ __device__ __forceinline__ void RareResampleAt(BlockLds *sm, const float *tables
             head.positionFrac, head.step, k, N);
 }
 
-__device__ __forceinline__ void RareAmbiScale(BlockLds *sm, AmbiScaleState *ambi, uint32_t N, uint32_t lane)
+__device__ __forceinline__ void RareAmbiScale(BlockLds *sm, AmbiScaleState *ambi, uint32_t N, uint32_t lane, uint32_t mixOffset)
 {
     const AmbiScaleState a = *ambi;
     SplitterState sp{a.coeff, a.lpZ1, a.lpZ2, a.apZ1};
-    SplitterScan<false>(sp, sm->in + kHist, N, a.hfScale, a.lfScale, lane);
+    SplitterScan<false>(sp, sm->in + kHist + mixOffset, N, a.hfScale, a.lfScale, lane);
     if(lane == 0) { ambi->lpZ1 = sp.lpZ1; ambi->lpZ2 = sp.lpZ2; ambi->apZ1 = sp.apZ1; }
 }
 
@@ -290,6 +291,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kBT, MINW) VoiceBlockKern
             loopingN = headN.loopBuffer >= 0 && !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd);
             planN.prefetch = planN.prefetch && GatherWindowCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
         }
+        if(headN.flags & kFlagDelayed) planN.prefetch = false;      // its window depends on where in the update it starts
         if(planN.prefetch)
         {
             GatherWindow<kPreB, kBT>(preN, bufN, loopingN, uint32_t(headN.position), t);
@@ -385,9 +387,28 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kBT, MINW) VoiceBlockKern
         const int vstate = head.playState;
         const bool mixes = vstate == OALGPU_VOICE_PLAYING || vstate == OALGPU_VOICE_STOPPING;
         const bool playing = vstate == OALGPU_VOICE_PLAYING;
-        const bool active = mixes && head.step >= 1u;
+        bool active = mixes && head.step >= 1u;
         // voice.cpp:1002-1010
         if(mixes && !active && !playing && t == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
+        uint32_t outPos = 0;
+        if(active && (head.flags & kFlagDelayed))
+        {   // delayed start, voice.cpp:1023-1046 (see voice_wave.hip): samples at offset outPos behind zeros
+            const uint32_t d = L.startDelay[v];
+            __syncthreads();
+            if(!playing)
+            {
+                if(t == 0) { L.ctl[v].playState = OALGPU_VOICE_STOPPED; L.ctl[v].flags = head.flags & ~kFlagDelayed; L.startDelay[v] = 0u; }
+                active = false;
+            }
+            else if(d >= N) { if(t == 0) L.startDelay[v] = d - N; active = false; }
+            else
+            {
+                outPos = d;
+                if(t == 0) L.startDelay[v] = 0u;
+                for(uint32_t k = t; k < outPos; k += kBT) sm.in[kHist + k] = 0.0f;
+                __syncthreads();
+            }
+        }
 
         int32_t bufferItem = head.curBuffer;
         uint32_t counter = 0, fademix = 0, todo = 0;
@@ -422,7 +443,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kBT, MINW) VoiceBlockKern
                 }
             }
             else if(wave == 0)
-                RareLoadResampled(&sm, L, v, lane, head, playing, N, bufferItem, looping, plan);
+                RareLoadResampled(&sm, L, v, lane, head, playing, N - outPos, bufferItem, looping, plan, outPos);
         }
         __syncthreads();                      // sm.in[64..] complete; sm.rd dead
         stamp(2);
@@ -434,13 +455,14 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kBT, MINW) VoiceBlockKern
         {
             if(head.flags & kFlagAmbiScale)
             {   // VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
-                if(wave == 0) RareAmbiScale(&sm, &L.ambi[v], N, lane);
+                if(wave == 0) RareAmbiScale(&sm, &L.ambi[v], N - outPos, lane, outPos);
                 __syncthreads();
             }
             counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
 
             // ---- DoFilters, direct path (voice.cpp:255-267): in place on sm.in[kHist..]
-            BlockDoFilters(sm, &L.dfilt[size_t{v} * 2], (head.flags & kFlagDirectFilter) != 0, sm.in + kHist, N, t);
+            BlockDoFilters(sm, &L.dfilt[size_t{v} * 2], (head.flags & kFlagDirectFilter) != 0, sm.in + kHist + outPos, N - outPos, t,
+                outPos == 0u);
             __syncthreads();
             stamp(3);
 
@@ -578,14 +600,14 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kBT, MINW) VoiceBlockKern
                 VoiceCtl &c = L.ctl[v];
                 if(counter == 0 || fademix) { c.hrtfOldDelay[0] = tail.tgtDelay[0]; c.hrtfOldDelay[1] = tail.tgtDelay[1]; }
                 c.hrtfOldGain = todo ? endGain : gainAfterBlend;
-                uint32_t flags = head.flags | kFlagFading;
+                uint32_t flags = (head.flags | kFlagFading) & ~kFlagDelayed;
                 if(counter == 0 || fademix) flags &= ~kFlagHrtfDirty;
                 c.flags = flags;
                 if(!playing) c.playState = OALGPU_VOICE_STOPPED;
                 else
                 {
                     int32_t bufPosInt = head.position;
-                    uint32_t bufPosFrac = head.positionFrac + head.step * N;
+                    uint32_t bufPosFrac = head.positionFrac + head.step * (N - outPos);
                     const uint32_t samplesDone = bufPosFrac >> kFracBits;
                     bufPosInt = AddSat(bufPosInt, int32_t(samplesDone));
                     bufPosFrac &= kFracMask;

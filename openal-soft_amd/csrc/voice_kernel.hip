@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfSto
         ctl.step = r.step;
         ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
         ctl.rsFilterOffset = r.rsFilterOffset;
-        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc);
-        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc))
+        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed);
+        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc | kFlagDelayed))
             | (L.hrtf ? (kFlagHasHrtf | kFlagHrtfDirty) : 0u);
         for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
         BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
@@ -95,6 +95,17 @@ __global__ void SetAmbiScaleKernel(DeviceLayout L, uint32_t v, AmbiScaleState st
     L.ambi[v] = st;
     L.ctl[v].flags |= kFlagAmbiScale;
 }
+
+// Voice::mStartTime ahead of the device clock by `samples` output samples (voice.cpp:1023-1046)
+__global__ void SetStartDelayKernel(DeviceLayout L, uint32_t v, uint32_t samples)
+{
+    L.startDelay[v] = samples;
+    if(samples) L.ctl[v].flags |= kFlagDelayed;
+    else L.ctl[v].flags &= ~kFlagDelayed;
+}
+
+void LaunchSetStartDelay(hipStream_t s, const DeviceLayout &L, uint32_t voice, uint32_t samples)
+{ hipLaunchKernelGGL(SetStartDelayKernel, dim3(1), dim3(1), 0, s, L, voice, samples); }
 
 void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st)
 { hipLaunchKernelGGL(SetAmbiScaleKernel, dim3(1), dim3(1), 0, s, L, voice, st); }
@@ -212,12 +223,12 @@ __device__ __forceinline__ void StageTable(SharedMem &sm, const float *__restric
 template<bool EXACT>
 __device__ __forceinline__ void LoadResampled(SharedMem &sm, const DeviceLayout &L, uint32_t v, const VoiceCtl &ctl,
     bool playing, int32_t intPos, uint32_t fracPos, uint32_t increment, uint32_t samplesToLoad,
-    uint32_t samplesToMix, int32_t bufferItem, bool looping, uint32_t &stagedTable)
+    uint32_t samplesToMix, int32_t bufferItem, bool looping, uint32_t &stagedTable, uint32_t mixOffset = 0)
 {
     const uint32_t t = threadIdx.x;
     float *rdata = sm.rdata;
     float *srcBuffer = rdata + kMaxEdge;
-    float *mixing = sm.in + kHist;
+    float *mixing = sm.in + kHist + mixOffset;       // mixOffset: a delayed start's output position (voice.cpp:1023-1046)
     if(t < kMaxPad) rdata[t] = L.prev[size_t{v} * kMaxPad + t];
     const float *filter = L.tables + ctl.rsFilterOffset;
     const int kind = ctl.rsKind;
@@ -507,8 +518,29 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
         {   // voice.cpp:1015-1019
             if(bufPosInt >= 0 && uint32_t(bufPosInt) >= L.buffers[bufferItem].loopEnd) loopItem = -1;
         }
-        const uint32_t samplesToMix = samplesToDo;          // no delayed start (outPos = 0)
-        const uint32_t N = samplesToMix;
+        // ---- delayed start, voice.cpp:1023-1046: the voice starts `outPos` samples into this update (or not
+        // yet).  It is on its first mix then (no fade, empty history, cleared filters), so the samplesToMix
+        // samples are produced at offset outPos of the voice's sample line behind zeros, and everything
+        // downstream mixes a full line: what lands in front of outPos is exactly zero.
+        uint32_t outPos = 0;
+        if(ctl.flags & kFlagDelayed)
+        {
+            if(t == 0) sm.best = int32_t(L.startDelay[v]);
+            __syncthreads();
+            const uint32_t d = uint32_t(sm.best);
+            __syncthreads();
+            if(!playing)
+            {   // "supposed to be stopping but hasn't actually started yet"
+                if(t == 0) { L.ctl[v].playState = OALGPU_VOICE_STOPPED; L.ctl[v].flags = ctl.flags & ~kFlagDelayed; L.startDelay[v] = 0u; }
+                continue;
+            }
+            if(d >= samplesToDo) { if(t == 0) L.startDelay[v] = d - samplesToDo; continue; }
+            outPos = d;
+            if(t == 0) L.startDelay[v] = 0u;
+        }
+        const uint32_t samplesToMix = samplesToDo - outPos;
+        const uint32_t N = samplesToDo;                     // the line downstream stages see
+        for(uint32_t k = t; k < outPos; k += kThreads) sm.in[kHist + k] = 0.0f;
         const bool hasHrtf = (ctl.flags & kFlagHasHrtf) != 0;
 
         // snapshot of this voice's gain pairs, send slots and HRIRs (read by every thread below
@@ -533,8 +565,8 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
             sm.coO[t] = L.hrtfOld[size_t{v} * irStride * 2 + t];
         }
 
-        LoadResampled<EXACT>(sm, L, v, ctl, playing, bufPosInt, bufPosFrac, increment, N, N, bufferItem, loopItem >= 0,
-            stagedTable);
+        LoadResampled<EXACT>(sm, L, v, ctl, playing, bufPosInt, bufPosFrac, increment, samplesToMix, samplesToMix, bufferItem,
+            loopItem >= 0, stagedTable, outPos);
 
         if(ctl.flags & kFlagAmbiScale)
         {   // ---- VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
@@ -542,7 +574,7 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
             {
                 AmbiScaleState &a = L.ambi[v];
                 SplitterState sp{a.coeff, a.lpZ1, a.lpZ2, a.apZ1};
-                SplitterScale(sp, sm.in + kHist, N, a.hfScale, a.lfScale);
+                SplitterScale(sp, sm.in + kHist + outPos, samplesToMix, a.hfScale, a.lfScale);
                 a.lpZ1 = sp.lpZ1; a.lpZ2 = sp.lpZ2; a.apZ1 = sp.apZ1;
             }
             __syncthreads();
@@ -570,14 +602,15 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
                 {
                     BiquadState f0 = slots[0].f, f1 = slots[1].f;
                     const bool settled = f0.counter <= 0 && f1.counter <= 0;
+                    if(active) for(uint32_t k = lane; k < outPos; k += 64) sm.filt[wave][kHist + k] = 0.0f;
                     if(active && !EXACT && settled)
                     {
-                        BiquadDualWave(f0, f1, sm.in + kHist, sm.filt[wave] + kHist, N, lane);
+                        BiquadDualWave(f0, f1, sm.in + kHist + outPos, sm.filt[wave] + kHist + outPos, samplesToMix, lane);
                         if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
                     }
                     else if(lane == 0)
                     {
-                        if(active) BiquadDualInterp(f0, f1, sm.in + kHist, sm.filt[wave] + kHist, N);
+                        if(active) BiquadDualInterp(f0, f1, sm.in + kHist + outPos, sm.filt[wave] + kHist + outPos, samplesToMix);
                         else { BiquadClear(f0); BiquadClear(f1); }
                         slots[0].f = f0; slots[1].f = f1;
                     }
@@ -739,7 +772,7 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
         if(t == 0)
         {
             VoiceCtl &c = L.ctl[v];
-            c.flags = (ctl.flags | kFlagFading) & ~((counter == 0 || N) ? kFlagHrtfDirty : 0u);
+            c.flags = (ctl.flags | kFlagFading) & ~(((counter == 0 || N) ? kFlagHrtfDirty : 0u) | kFlagDelayed);
             if(!playing) c.playState = OALGPU_VOICE_STOPPED;
             else
             {

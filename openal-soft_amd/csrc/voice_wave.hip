@@ -193,6 +193,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     loopingN = headN.loopBuffer >= 0 && !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd);
                     planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
                 }
+                if(headN.flags & kFlagDelayed) planN.prefetch = false;      // its window depends on where in the update it starts
                 // (the window first: each gather variant starts by waiting for older loads into its
                 // registers -- the variants share them -- and must not find a fresh one in front of it)
                 if(planN.prefetch)
@@ -224,6 +225,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         uint32_t counter = 0, fademix = 0, todo = 0;
         float endGain = 0.0f, gainAfterBlend = 0.0f;
         int32_t bufferItem = -1;
+        uint32_t outPos = 0;                    // delayed start (voice.cpp:1023-1046): the voice's samples begin here
         if(!first)
         {
             // head, plan, buffer and the gathered window were requested one pass ago
@@ -244,6 +246,24 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             active = mixes && head.step >= 1u;
             // voice.cpp:1002-1010
             if(mixes && !active && !playing && lane == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
+            if(active && (head.flags & kFlagDelayed))
+            {   // voice.cpp:1023-1046.  A delayed voice is on its first mix (no fade, empty history, cleared
+                // filters): its N - outPos samples are produced at offset outPos of the sample line behind
+                // zeros and everything downstream mixes a full line.
+                const uint32_t d = L.startDelay[v];
+                if(!playing)
+                {
+                    if(lane == 0) { L.ctl[v].playState = OALGPU_VOICE_STOPPED; L.ctl[v].flags = head.flags & ~kFlagDelayed; L.startDelay[v] = 0u; }
+                    active = false;
+                }
+                else if(d >= N) { if(lane == 0) L.startDelay[v] = d - N; active = false; }
+                else
+                {
+                    outPos = d;
+                    if(lane == 0) L.startDelay[v] = 0u;
+                    for(uint32_t k = lane; k < outPos; k += 64) w.in[kHist + k] = 0.0f;
+                }
+            }
             if constexpr (SENDS || NL > 0)
             {   // nothing to mix for this voice in this update
                 if(!active && lane < L.streamsPerVoice)
@@ -264,7 +284,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             // filter's old coefficients (w.cold) and the source window were parked by the last pass
             const float fstv = fstC;
             const SrcPlan plan = planN;
-            LoadResampledWave(sm, w, L, v, lane, head, playing, N, N, bufferItem, looping, plan);
+            LoadResampledWave(sm, w, L, v, lane, head, playing, N - outPos, N - outPos, bufferItem, looping, plan, outPos);
             asm volatile("" : "+v"(lane));      // addresses used from here on are rebuilt, not carried across the resampler
             if constexpr (NL > 0) requestNext();
             if(head.flags & kFlagAmbiScale)
@@ -272,7 +292,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 const AmbiScaleState a = L.ambi[v];
                 SplitterState sp{a.coeff, a.lpZ1, a.lpZ2, a.apZ1};
                 WaveSync();
-                SplitterScan<false>(sp, w.in + kHist, N, a.hfScale, a.lfScale, lane);
+                SplitterScan<false>(sp, w.in + kHist + outPos, N - outPos, a.hfScale, a.lfScale, lane);
                 WaveSync();
                 if(lane == 0) { L.ambi[v].lpZ1 = sp.lpZ1; L.ambi[v].lpZ2 = sp.lpZ2; L.ambi[v].apZ1 = sp.apZ1; }
             }
@@ -336,7 +356,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                             float *tmp = w.rd;
                             for(uint32_t k = lane; k < N; k += 64) tmp[k] = w.in[kHist + k];
                             WaveSync();
-                            WaveDoFilters(w.fst, slots, true, tmp, N, lane);
+                            WaveDoFilters(w.fst, slots, true, tmp + outPos, N - outPos, lane);
                             WaveSync();
                             float *dst = rowsV + size_t{2u + si} * kLine;
                             for(uint32_t k = lane; k < uint32_t(kLine); k += 64) dst[k] = (k < N) ? tmp[k] : 0.0f;
@@ -363,7 +383,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             {
                 if constexpr (SENDS) { if(lane < 32u) w.fst[lane] = fstv; }
                 WaveSync();
-                WaveDoFilters(w.fst, &L.dfilt[size_t{v} * 2], directFilter, w.in + kHist, N, lane);
+                WaveDoFilters(w.fst, &L.dfilt[size_t{v} * 2], directFilter, w.in + kHist + outPos, N - outPos, lane);
                 WaveSync();
             }
             if constexpr (NL > 0)
@@ -676,14 +696,14 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     if(counter == 0 || fademix) { c.hrtfOldDelay[0] = tail.tgtDelay[0]; c.hrtfOldDelay[1] = tail.tgtDelay[1]; }
                     c.hrtfOldGain = todo ? endGain : gainAfterBlend;
                 }
-                uint32_t flags = head.flags | kFlagFading;
+                uint32_t flags = (head.flags | kFlagFading) & ~kFlagDelayed;
                 if(NL > 0 || counter == 0 || fademix) flags &= ~kFlagHrtfDirty;
                 c.flags = flags;
                 if(!playing) c.playState = OALGPU_VOICE_STOPPED;
                 else
                 {
                     int32_t bufPosInt = head.position;
-                    uint32_t bufPosFrac = head.positionFrac + head.step * N;
+                    uint32_t bufPosFrac = head.positionFrac + head.step * (N - outPos);
                     const uint32_t samplesDone = bufPosFrac >> kFracBits;
                     bufPosInt = AddSat(bufPosInt, int32_t(samplesDone));
                     bufPosFrac &= kFracMask;

@@ -435,11 +435,11 @@ __device__ __forceinline__ void ResampleRunStagedM(const SM &sm, const float *rd
 template<bool LEAN = false, class SM, class WV>
 __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const DeviceLayout &L,
     uint32_t v, uint32_t lane, const VoiceHead &h, bool playing, uint32_t samplesToLoad, uint32_t samplesToMix,
-    int32_t bufferItem, bool looping, const SrcPlan &plan)
+    int32_t bufferItem, bool looping, const SrcPlan &plan, uint32_t mixOffset = 0)
 {
     float *rdata = w.rd;
     float *srcBuffer = rdata + kMaxEdge;
-    float *mixing = w.in + kHist;
+    float *mixing = w.in + kHist + mixOffset;     // mixOffset: a delayed start's output position (voice.cpp:1023-1046)
     const int kind = h.rsKind;
     const uint32_t rsM = h.rsM, rsL = h.rsL, increment = h.step;
     int32_t intPos = h.position;

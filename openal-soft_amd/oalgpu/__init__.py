@@ -428,6 +428,10 @@ class Scene:
     def set_carry_accum(self, enable):
         check(lib.oalgpu_set_carry_accum(self.h, 1 if enable else 0))
 
+    def set_start_delay(self, voice, samples):
+        lib.oalgpu_voice_set_start_delay.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        check(lib.oalgpu_voice_set_start_delay(self.h, voice, samples), "oalgpu_voice_set_start_delay")
+
     def set_state(self, voice, vstate):
         check(lib.oalgpu_voice_set_state(self.h, voice, vstate), "oalgpu_voice_set_state")
 

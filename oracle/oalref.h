@@ -211,6 +211,9 @@ oal_bformatdec *oal_bformatdec_create(uint32_t inchans, uint32_t nout, const flo
 void oal_bformatdec_process(oal_bformatdec *d, float *out, const float *in, uint32_t n);
 void oal_bformatdec_destroy(oal_bformatdec *d);
 
+/* Voice::mStartTime = now + `samples` output samples (delayed start, core/voice.cpp:1023-1046);
+ * compiled reference only */
+int oal_scene_set_voice_start_delay(oal_scene *s, int voice, uint32_t samples);
 int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process);
 /* DeviceBase::Process(HrtfPostProcess) alone (alc/alu.cpp:289-298): for scenes whose effect slots
  * add into the dry lines between the voice loop and the post-process (alu.cpp:2209-2257).  The dry

@@ -678,6 +678,16 @@ int oal_scene_set_voice_nfc(oal_scene *s, int voice, float w0)
     return 0;
 }
 
+/* Voice::mStartTime = device clock + `samples` output samples (delayed start, voice.cpp:1023-1046) */
+int oal_scene_set_voice_start_delay(oal_scene *s, int voice, uint32_t samples)
+{
+    auto &v = s->voices.at(static_cast<size_t>(voice));
+    auto const ns = std::chrono::nanoseconds{static_cast<long long>(
+        std::llround(double(samples) * 1.0e9 / double(s->dev->mSampleRate)))};
+    v.mStartTime = s->dev->getClockTime() + ns;
+    return 0;
+}
+
 int oal_scene_set_voice_state(oal_scene *s, int voice, int vstate)
 {
     s->vstate.at(static_cast<size_t>(voice)) = vstate;
@@ -706,6 +716,14 @@ int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process)
     {
         auto &proc = std::get<HrtfPostProcess>(dev.mPostProcess);
         dev.Process(proc, samples_to_do);
+    }
+    /* the device clock moves on as in DeviceBase::renderSamples (alc/alu.cpp:2426-2435) */
+    {
+        auto const samplesDone = dev.mSamplesDone.load(std::memory_order_relaxed) + samples_to_do;
+        auto const clockBaseSec = dev.mClockBaseSec.load(std::memory_order_relaxed)
+            + DeviceBase::seconds32{samplesDone/dev.mSampleRate};
+        dev.mSamplesDone.store(samplesDone%dev.mSampleRate, std::memory_order_relaxed);
+        dev.mClockBaseSec.store(clockBaseSec, std::memory_order_relaxed);
     }
     return 0;
 }

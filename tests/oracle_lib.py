@@ -379,6 +379,10 @@ class Scene:
     def set_state(self, voice, vstate):
         assert self.lib.L.oal_scene_set_voice_state(self.h, voice, vstate) == 0
 
+    def set_start_delay(self, voice, samples):
+        self.lib.L.oal_scene_set_voice_start_delay.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        assert self.lib.L.oal_scene_set_voice_start_delay(self.h, voice, samples) == 0
+
     def set_direct_hrtf(self, chan_coeffs, hfscales, xover_norm, irsize):
         cc = np.ascontiguousarray(chan_coeffs, np.float32)
         hf = np.ascontiguousarray(hfscales, np.float32)
