@@ -258,6 +258,27 @@ typedef struct oalgpu_voice_params {
     oalgpu_filter_params send_filter[OALGPU_MAX_SENDS];
     float    send_gains[OALGPU_MAX_SENDS][OALGPU_MAX_AMBI_CHANNELS]; /* mWetParams[i].Gains.Target */
 } oalgpu_voice_params;
+/* ---- streaming sources: a queue of buffers (VoiceBufferItem::mNext, core/voice.h:85) ---------------------
+ * oalgpu_buffer_queue_link(buffer, next) links `next` behind `buffer` (alSourceQueueBuffers; next < 0 ends
+ * the queue there).  oalgpu_voice_init_queue starts a voice that is NOT VoiceFlag::IsStatic on the queue's
+ * first buffer: LoadBufferQueue (core/voice.cpp:563-594) crawls the queue -- a looping voice returns to
+ * first_buffer when it ends, a non-looping one holds the last sample and stops -- and Voice::mix leaves
+ * finished buffers behind (voice.cpp:1182-1194).  oalgpu_voice_queue_state reports the current buffer
+ * (-1 once the queue ended) and how many buffers the voice has played through (the counts of
+ * AsyncBufferCompleteEvent, voice.cpp:1207-1218). */
+int oalgpu_buffer_queue_link(oalgpu_context *ctx, int buffer, int next_buffer);
+int oalgpu_voice_init_queue(oalgpu_context *ctx, uint32_t voice, int first_buffer, int looping, int32_t position,
+    uint32_t position_frac);
+int oalgpu_voice_queue_state(oalgpu_context *ctx, uint32_t voice, int32_t *current_buffer, uint32_t *buffers_done);
+
+/* IMA4 / MS ADPCM data (FmtIMA4 / FmtMSADPCM, core/buffer_storage.h:35-43; LoadSamples, core/voice.cpp:288-484):
+ * `data` = ceil(sample_len / samples_per_block) blocks of ((samples_per_block-1)/2 + 4) * channels (IMA4)
+ * or ((samples_per_block-2)/2 + 7) * channels (MS) bytes.  Decoded once, on the GPU, into interleaved
+ * 16-bit PCM: the handle then behaves like an OALGPU_FMT_SHORT buffer with frame_step = channels. */
+enum oalgpu_adpcm_type { OALGPU_ADPCM_IMA4 = 0, OALGPU_ADPCM_MS = 1 };
+int oalgpu_buffer_register_adpcm(oalgpu_context *ctx, const void *data, int adpcm_type, uint32_t channels,
+    uint32_t samples_per_block, uint32_t sample_len, uint32_t loop_start, uint32_t loop_end);
+
 /* Delayed start (Voice::mStartTime, core/voice.h:209; Voice::mix, core/voice.cpp:1023-1046): the voice --
  * initialised, not mixed yet -- starts `samples` output samples after the beginning of the next update:
  * that update mixes samples_to_do - outPos samples of it at output position outPos; updates that end

@@ -113,6 +113,7 @@ struct oalgpu_context {
     DevBuf<float> tables;
     DevBuf<BufferItem> buffers;
     DevBuf<uint32_t> startDelay;           // [voice] samples until a delayed voice starts
+    DevBuf<uint32_t> queueDone;            // [voice] buffers a streaming voice has played through
     std::vector<void*> bufferData;
     std::vector<uint32_t> bufferLoopLen;   // loop_end - loop_start of every registered buffer (0: cannot loop)
     uint32_t numBuffers{0};
@@ -581,6 +582,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->sendTgt.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendTgt.zero()); L.sendTgt = c->sendTgt.p;
     HIP_TRY(c->ambi.alloc(nv)); HIP_TRY(c->ambi.zero()); L.ambi = c->ambi.p;
     HIP_TRY(c->startDelay.alloc(nv)); HIP_TRY(c->startDelay.zero()); L.startDelay = c->startDelay.p;
+    HIP_TRY(c->queueDone.alloc(nv)); HIP_TRY(c->queueDone.zero()); L.queueDone = c->queueDone.p;
     L.numLineGroups = L.numGroups;
     L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0; L.streamsPerVoice = 0;
     L.nfc = nullptr; L.nfcOrders = 0;
@@ -772,8 +774,84 @@ int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(d->looping && c->bufferLoopLen[size_t(d->buffer)] == 0)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: a looping voice needs a buffer registered with loop_end > loop_start");
-    c->initPending.push_back(VoiceInitRecord{voice, d->buffer, d->looping ? 1 : 0, d->position, d->position_frac});
+    c->initPending.push_back(VoiceInitRecord{voice, d->buffer, d->looping ? 1 : 0, d->position, d->position_frac, 0});
     return OALGPU_OK;
+}
+
+/* ---- streaming sources: a queue of buffers (VoiceBufferItem::mNext, core/voice.h:85) --------------------
+ * oalgpu_buffer_queue_link(buffer, next) is alSourceQueueBuffers' linking (next < 0 ends the queue);
+ * oalgpu_voice_init_queue starts a voice that is NOT VoiceFlag::IsStatic on the queue's first buffer:
+ * LoadBufferQueue (voice.cpp:563-594) crawls the queue, a looping voice returns to `first_buffer` when it
+ * ends, and Voice::mix leaves finished buffers behind (voice.cpp:1182-1194). */
+int oalgpu_buffer_queue_link(oalgpu_context *c, int buffer, int next_buffer)
+{
+    if(!c || buffer < 0 || uint32_t(buffer) >= c->numBuffers || next_buffer >= int(c->numBuffers))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_queue_link: bad buffer");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    const int32_t next = next_buffer < 0 ? 0 : next_buffer + 1;
+    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(c->buffers.p + buffer) + offsetof(BufferItem, next), &next, sizeof(next),
+        hipMemcpyHostToDevice));
+    return OALGPU_OK;
+}
+
+int oalgpu_voice_init_queue(oalgpu_context *c, uint32_t voice, int first_buffer, int looping, int32_t position,
+    uint32_t position_frac)
+{
+    if(!c || voice >= c->L.numVoices || first_buffer < 0 || uint32_t(first_buffer) >= c->numBuffers || position_frac >= kFracOne)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_queue: bad arguments");
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    c->initPending.push_back(VoiceInitRecord{voice, first_buffer, looping ? 1 : 0, position, position_frac, 1});
+    return OALGPU_OK;
+}
+
+/* where a streaming voice is: its current buffer (-1: the queue ended) and the number of buffers it has
+ * played through since it was initialised (what AsyncBufferCompleteEvent counts, voice.cpp:1207-1218) */
+int oalgpu_voice_queue_state(oalgpu_context *c, uint32_t voice, int32_t *current_buffer, uint32_t *buffers_done)
+{
+    if(!c || voice >= c->L.numVoices || !current_buffer || !buffers_done)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_queue_state: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    HIP_TRY(hipMemcpy(current_buffer, &c->ctl.p[voice].curBuffer, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(buffers_done, c->queueDone.p + voice, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return OALGPU_OK;
+}
+
+/* IMA4 / MS ADPCM data (FmtIMA4 / FmtMSADPCM, core/buffer_storage.h; LoadSamples, core/voice.cpp:288-484):
+ * decoded once, on the GPU, into interleaved 16-bit PCM; the handle then behaves like an OALGPU_FMT_SHORT
+ * buffer with frame_step = channels (oalgpu_buffer_channel_view splits a stereo one). */
+int oalgpu_buffer_register_adpcm(oalgpu_context *c, const void *data, int adpcm_type, uint32_t channels,
+    uint32_t samples_per_block, uint32_t sample_len, uint32_t loop_start, uint32_t loop_end)
+{
+    if(!c || !data || (adpcm_type != OALGPU_ADPCM_IMA4 && adpcm_type != OALGPU_ADPCM_MS) || channels < 1 || channels > 2
+        || sample_len == 0 || loop_end > sample_len || loop_start >= (loop_end ? loop_end : 1u)
+        || samples_per_block < (adpcm_type == OALGPU_ADPCM_MS ? 3u : 2u) || samples_per_block > 65536u)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_register_adpcm: bad arguments");
+    if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    const uint32_t numBlocks = (sample_len + samples_per_block - 1u) / samples_per_block;
+    const size_t blockBytes = adpcm_type == OALGPU_ADPCM_MS ? size_t{(samples_per_block - 2u) / 2u + 7u} * channels
+        : size_t{(samples_per_block - 1u) / 2u + 4u} * channels;
+    const size_t nbytes = size_t{numBlocks} * blockBytes;
+    void *comp = nullptr, *pcm = nullptr;
+    HIP_TRY(hipMalloc(&comp, nbytes + 16));
+    hipError_t e = hipMemcpy(comp, data, nbytes, hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMalloc(&pcm, size_t{sample_len} * channels * sizeof(int16_t) + 16);
+    if(e != hipSuccess) { (void)hipFree(comp); return Fail(OALGPU_ERR_HIP, hipGetErrorString(e)); }
+    LaunchDecodeAdpcm(c->stream, adpcm_type == OALGPU_ADPCM_MS, static_cast<const uint8_t*>(comp), static_cast<int16_t*>(pcm),
+        numBlocks, samples_per_block, channels, sample_len);
+    e = hipGetLastError();
+    if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(comp);
+    if(e != hipSuccess) { (void)hipFree(pcm); return Fail(OALGPU_ERR_HIP, hipGetErrorString(e)); }
+    const uint32_t h = c->numBuffers++;
+    c->bufferData[h] = pcm;
+    c->bufferLoopLen[h] = loop_end > loop_start ? loop_end - loop_start : 0u;
+    BufferItem item{pcm, OALGPU_FMT_SHORT, channels, sample_len, loop_start, loop_end, 0};
+    HIP_TRY(hipMemcpy(c->buffers.p + h, &item, sizeof(item), hipMemcpyHostToDevice));
+    return int(h);
 }
 
 /* Voice::mStartTime (core/voice.h:209): the voice starts `samples` output samples from the beginning of

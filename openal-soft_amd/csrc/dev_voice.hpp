@@ -14,7 +14,7 @@ struct alignas(16) BufferItem {     // VoiceBufferItem, core/voice.h:84-98
     const void *data;
     int32_t fmt;
     uint32_t frameStep, sampleLen, loopStart, loopEnd;
-    uint32_t pad;
+    int32_t next;                   // mNext: the buffer queued behind this one (table index + 1; 0 = none)
 };
 
 // ---- SampleInfo<T>::to_float, core/fmt_traits.h:91-139 (+ the mu-law/A-law tables :12-80 in
@@ -88,6 +88,62 @@ __device__ __forceinline__ void FillFromBuffer(float *dst, uint32_t count, const
     case OALGPU_FMT_DOUBLE: FillFromStatic<OALGPU_FMT_DOUBLE, NT>(dst, count, b, looping, dataPos, tid); break;
     case OALGPU_FMT_MULAW: FillFromStatic<OALGPU_FMT_MULAW, NT>(dst, count, b, looping, dataPos, tid); break;
     default: FillFromStatic<OALGPU_FMT_ALAW, NT>(dst, count, b, looping, dataPos, tid); break;
+    }
+}
+
+__device__ __forceinline__ float LoadSampleAny(int fmt, const void *data, size_t idx)
+{
+    switch(fmt)
+    {
+    case OALGPU_FMT_UBYTE: return LoadSample<OALGPU_FMT_UBYTE>(data, idx);
+    case OALGPU_FMT_SHORT: return LoadSample<OALGPU_FMT_SHORT>(data, idx);
+    case OALGPU_FMT_INT: return LoadSample<OALGPU_FMT_INT>(data, idx);
+    case OALGPU_FMT_FLOAT: return LoadSample<OALGPU_FMT_FLOAT>(data, idx);
+    case OALGPU_FMT_DOUBLE: return LoadSample<OALGPU_FMT_DOUBLE>(data, idx);
+    case OALGPU_FMT_MULAW: return LoadSample<OALGPU_FMT_MULAW>(data, idx);
+    default: return LoadSample<OALGPU_FMT_ALAW>(data, idx);
+    }
+}
+
+// LoadBufferQueue, core/voice.cpp:563-594: `count` source samples from position dataPos of queue item
+// `item`, crawling the queue (mNext, then the loop item) and holding the last sample when it ends.
+// Every thread walks the queue itself (uniform control flow); `sync` orders the threads' LDS accesses.
+template<int NT, typename Sync>
+__device__ __forceinline__ void FillFromQueue(float *dst, uint32_t count, const BufferItem *buffers, int32_t item, int32_t loopItem,
+    uint32_t dataPos, uint32_t tid, Sync sync)
+{
+    uint32_t done = 0;
+    for(uint32_t guard = 0; item >= 0 && done < count && guard < 4096u; ++guard)
+    {
+        const BufferItem b = buffers[item];
+        const int32_t nextItem = b.next > 0 ? b.next - 1 : loopItem;
+        if(dataPos >= b.sampleLen) { dataPos -= b.sampleLen; item = nextItem; continue; }
+        const uint32_t rem = (count - done < b.sampleLen - dataPos) ? count - done : b.sampleLen - dataPos;
+        for(uint32_t k = tid; k < rem; k += NT) dst[done + k] = LoadSampleAny(b.fmt, b.data, size_t{dataPos + k} * b.frameStep);
+        done += rem;
+        dataPos = 0;
+        item = nextItem;
+    }
+    if(done < count)
+    {
+        sync();
+        const float last = done ? dst[done - 1u] : 0.0f;
+        sync();
+        for(uint32_t k = done + tid; k < count; k += NT) dst[k] = last;
+    }
+}
+
+// Voice::mix's "streaming source" position update (core/voice.cpp:1182-1194): buffers the position ran
+// past are left behind; `item` < 0 afterwards = the queue ended.
+__device__ __forceinline__ void AdvanceQueue(const BufferItem *buffers, int32_t &item, int32_t loopItem, int32_t &pos, uint32_t &buffersDone)
+{
+    for(uint32_t guard = 0; item >= 0 && guard < 65536u; ++guard)
+    {
+        const BufferItem b = buffers[item];
+        if(b.sampleLen > uint32_t(pos)) break;
+        pos -= int32_t(b.sampleLen);
+        ++buffersDone;
+        item = b.next > 0 ? b.next - 1 : loopItem;
     }
 }
 

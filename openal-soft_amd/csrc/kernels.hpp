@@ -29,6 +29,7 @@ enum VoiceFlagBits : uint32_t {
     kFlagHrtfDirty = 1u << 3,       // Hrtf.Target replaced since the last mix (Old != Target)
     kFlagAmbiScale = 1u << 4,       // VoiceFlag::IsAmbisonic: ambi[v] holds the channel's splitter and scales
     kFlagNfc = 1u << 5,             // VoiceFlag::HasNfc: nfc[v] holds DirectParams::NFCtrlFilter
+    kFlagQueue = 1u << 7,           // a streaming (buffer-queue) source, not VoiceFlag::IsStatic (voice.cpp:563-594, :1182-1194)
     kFlagDelayed = 1u << 6,         // mStartTime lies ahead: startDelay[v] samples until the voice starts (voice.cpp:1023-1046)
     kFlagSendFilterShift = 8        // bits 8..13: mSend[i].FilterActive
 };
@@ -101,6 +102,7 @@ struct DeviceLayout {
     float *sendCur, *sendTgt;
     AmbiScaleState *ambi;                   // [voice]
     uint32_t *startDelay;                   // [voice] samples until a delayed voice starts (kFlagDelayed)
+    uint32_t *queueDone;                    // [voice] buffers a streaming voice has played through (AsyncBufferCompleteEvent counts)
     NfcState *nfc;                          // [voice], null unless the context has NFC
     uint32_t chansPerOrder[5];              // DeviceBase::NumChannelsPerOrder (NFC contexts)
     uint32_t nfcOrders;                     // orders 1.. with lines (0 = no NFC)
@@ -141,7 +143,7 @@ struct ParamRecord {
     float sendGains[6][25];
 };
 
-struct VoiceInitRecord { uint32_t voice; int32_t buffer, looping, position; uint32_t positionFrac; };
+struct VoiceInitRecord { uint32_t voice; int32_t buffer, looping, position; uint32_t positionFrac; int32_t queue; };
 
 // ---- launchers (percall_kernels.hip) ----
 void LaunchResample(hipStream_t s, bool exact, const ResampleSpec &spec, const float *src, uint32_t frac,
@@ -198,6 +200,10 @@ void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo,
 void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st);
 void LaunchSetNfc(hipStream_t s, const DeviceLayout &L, uint32_t voice, const NfcState &coeffs);
 void LaunchSetStartDelay(hipStream_t s, const DeviceLayout &L, uint32_t voice, uint32_t samples);
+
+// ---- launcher (adpcm_kernels.hip): IMA4 / MS ADPCM blocks -> interleaved 16-bit PCM, one thread per block and channel ----
+void LaunchDecodeAdpcm(hipStream_t s, bool msadpcm, const uint8_t *src, int16_t *dst, uint32_t numBlocks, uint32_t samplesPerBlock,
+    uint32_t channels, uint32_t sampleLen);
 bool WaveKernelApplies(bool exact, const DeviceLayout &L);
 const char *WaveKernelName(const DeviceLayout &L);
 uint32_t WaveKernelGroups(const DeviceLayout &L);

@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfSto
         ctl.step = r.step;
         ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
         ctl.rsFilterOffset = r.rsFilterOffset;
-        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed);
-        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc | kFlagDelayed))
+        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue);
+        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue))
             | (L.hrtf ? (kFlagHasHrtf | kFlagHrtfDirty) : 0u);
         for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
         BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
@@ -141,7 +141,8 @@ __global__ void __launch_bounds__(64) InitVoicesKernel(DeviceLayout L, const Voi
         c.positionFrac = r.positionFrac;
         c.curBuffer = r.buffer;
         c.loopBuffer = r.looping ? r.buffer : -1;
-        c.flags = L.hrtf ? kFlagHasHrtf : 0u;
+        c.flags = (L.hrtf ? kFlagHasHrtf : 0u) | (r.queue ? kFlagQueue : 0u);
+        L.queueDone[v] = 0u;
         for(int i = 0; i < 6; ++i) c.sendSlot[i] = -1;
         if(r.buffer >= 0) c.buf = L.buffers[r.buffer];
         L.ctl[v] = c;
@@ -298,7 +299,11 @@ __device__ __forceinline__ void LoadResampled(SharedMem &sm, const DeviceLayout 
         else
         {
             const uint32_t upos = intPos < 0 ? 0u : uint32_t(intPos);
-            FillFromBuffer<kThreads>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos, t);
+            if(ctl.flags & kFlagQueue)
+                FillFromQueue<kThreads>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers, bufferItem, ctl.loopBuffer, upos, t,
+                    [] { __syncthreads(); });
+            else
+                FillFromBuffer<kThreads>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos, t);
         }
         __syncthreads();
 
@@ -514,8 +519,8 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
         uint32_t bufPosFrac = ctl.positionFrac;
         int32_t bufferItem = ctl.curBuffer;
         int32_t loopItem = ctl.loopBuffer;
-        if(loopItem >= 0 && bufferItem >= 0)
-        {   // voice.cpp:1015-1019
+        if(loopItem >= 0 && bufferItem >= 0 && !(ctl.flags & kFlagQueue))
+        {   // voice.cpp:1015-1019 (static voices)
             if(bufPosInt >= 0 && uint32_t(bufPosInt) >= L.buffers[bufferItem].loopEnd) loopItem = -1;
         }
         // ---- delayed start, voice.cpp:1023-1046: the voice starts `outPos` samples into this update (or not
@@ -780,7 +785,15 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
                 const uint32_t samplesDone = bufPosFrac >> kFracBits;
                 bufPosInt = AddSat(bufPosInt, int32_t(samplesDone));
                 bufPosFrac &= kFracMask;
-                if(bufferItem >= 0 && bufPosInt > 0)
+                if(bufferItem >= 0 && bufPosInt > 0 && (ctl.flags & kFlagQueue))
+                {   // a streaming source: buffers the position ran past are done (voice.cpp:1182-1194)
+                    uint32_t buffersDone = 0;
+                    const int32_t before = bufferItem;
+                    AdvanceQueue(L.buffers, bufferItem, ctl.loopBuffer, bufPosInt, buffersDone);
+                    if(buffersDone) L.queueDone[v] += buffersDone;
+                    if(bufferItem >= 0 && bufferItem != before) c.buf = L.buffers[bufferItem];
+                }
+                else if(bufferItem >= 0 && bufPosInt > 0)
                 {
                     const BufferItem &b = L.buffers[bufferItem];
                     if(loopItem >= 0)

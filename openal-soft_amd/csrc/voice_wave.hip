@@ -190,10 +190,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 if(headN.curBuffer >= 0)
                 {
                     // voice.cpp:1015-1019: a position at or past the loop end plays on without looping
-                    loopingN = headN.loopBuffer >= 0 && !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd);
+                    loopingN = headN.loopBuffer >= 0 && ((headN.flags & kFlagQueue)
+                        || !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd));
                     planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
                 }
-                if(headN.flags & kFlagDelayed) planN.prefetch = false;      // its window depends on where in the update it starts
+                if(headN.flags & (kFlagDelayed | kFlagQueue)) planN.prefetch = false;   // a delayed start's window depends on where in
+                                                                                   // the update it starts; a queue's spans several buffers
                 // (the window first: each gather variant starts by waiting for older loads into its
                 // registers -- the variants share them -- and must not find a fresh one in front of it)
                 if(planN.prefetch)
@@ -707,7 +709,15 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     const uint32_t samplesDone = bufPosFrac >> kFracBits;
                     bufPosInt = AddSat(bufPosInt, int32_t(samplesDone));
                     bufPosFrac &= kFracMask;
-                    if(bufferItem >= 0 && bufPosInt > 0)
+                    if(bufferItem >= 0 && bufPosInt > 0 && (head.flags & kFlagQueue))
+                    {   // a streaming source: buffers the position ran past are done (voice.cpp:1182-1194)
+                        uint32_t buffersDone = 0;
+                        const int32_t before = bufferItem;
+                        AdvanceQueue(L.buffers, bufferItem, head.loopBuffer, bufPosInt, buffersDone);
+                        if(buffersDone) L.queueDone[v] += buffersDone;
+                        if(bufferItem >= 0 && bufferItem != before) c.buf = L.buffers[bufferItem];
+                    }
+                    else if(bufferItem >= 0 && bufPosInt > 0)
                     {
                         if(looping)
                         {

@@ -508,7 +508,11 @@ __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const DeviceLay
         else
         {
             const uint32_t upos = intPos < 0 ? 0u : uint32_t(intPos);
-            FillFromBuffer<64>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos, lane);
+            if(h.flags & kFlagQueue)
+                FillFromQueue<64>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers, bufferItem, h.loopBuffer, upos, lane,
+                    [] { WaveSync(); });
+            else
+                FillFromBuffer<64>(srcBuffer + srcDelay, bsrc - srcDelay, L.buffers[bufferItem], looping, upos, lane);
         }
         firstPass = false;
         WaveSync();

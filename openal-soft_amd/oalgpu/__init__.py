@@ -341,6 +341,37 @@ class Scene:
         self.nvoices += 1
         return v
 
+    # IMA4 (adpcm_type 0) / MS ADPCM (1) data: decoded once on the GPU into 16-bit PCM
+    def add_buffer_adpcm(self, data, adpcm_type, channels, samples_per_block, sample_len, loop_start=0, loop_end=None):
+        data = np.ascontiguousarray(data, np.uint8)
+        lib.oalgpu_buffer_register_adpcm.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_uint32] * 5
+        return check(lib.oalgpu_buffer_register_adpcm(self.h, data.ctypes.data_as(C.c_void_p), adpcm_type, channels,
+                                                      samples_per_block, sample_len, loop_start,
+                                                      sample_len if loop_end is None else loop_end),
+                     "oalgpu_buffer_register_adpcm")
+
+    # streaming sources (same interface as tests/oracle_lib.Scene)
+    def link_buffers(self, buffer, nxt):
+        lib.oalgpu_buffer_queue_link.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        check(lib.oalgpu_buffer_queue_link(self.h, buffer, nxt), "oalgpu_buffer_queue_link")
+
+    def add_queue_voice(self, first_buffer, looping, position=0, frac=0, frequency=44100):
+        lib.oalgpu_voice_init_queue.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int32, C.c_uint32]
+        v = self.nvoices
+        check(lib.oalgpu_voice_init_queue(self.h, v, first_buffer, 1 if looping else 0, position, frac),
+              "oalgpu_voice_init_queue")
+        self.nvoices += 1
+        return v
+
+    def queue_state(self, voice):
+        lib.oalgpu_voice_queue_state.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+        cur, done = C.c_int32(0), C.c_uint32(0)
+        check(lib.oalgpu_voice_queue_state(self.h, voice, C.byref(cur), C.byref(done)), "oalgpu_voice_queue_state")
+        return cur.value, done.value
+
+    def current_buffer(self, voice):
+        return self.queue_state(voice)[0]
+
     # near-field control (same interface as tests/oracle_lib.Scene)
     def set_nfc(self, w1, channels_per_order):
         lib.oalgpu_context_set_nfc.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint32)]

@@ -214,6 +214,17 @@ void oal_bformatdec_destroy(oal_bformatdec *d);
 /* Voice::mStartTime = now + `samples` output samples (delayed start, core/voice.cpp:1023-1046);
  * compiled reference only */
 int oal_scene_set_voice_start_delay(oal_scene *s, int voice, uint32_t samples);
+/* Compiled reference only: IMA4 (adpcm_type 0) / MS ADPCM (1) buffers (LoadSamples<IMA4Data>,
+ * LoadSamples<MSADPCMData>, core/voice.cpp:288-484); buffer queues (VoiceBufferItem::mNext, LoadBufferQueue
+ * voice.cpp:563-594, buffer advance voice.cpp:1182-1194): link, a voice that is not IsStatic, and the
+ * index of its current buffer (-1 = none). */
+int oal_scene_add_buffer_adpcm(oal_scene *s, const void *data, int adpcm_type, uint32_t channels,
+    uint32_t samples_per_block, uint32_t sample_len, uint32_t loop_start, uint32_t loop_end);
+int oal_scene_link_buffers(oal_scene *s, int buffer, int next);
+int oal_scene_add_queue_voice(oal_scene *s, const oal_voice_desc *desc);
+int oal_scene_voice_current_buffer(oal_scene *s, int voice);
+/* sum of the AsyncBufferCompleteEvent counts the voice has posted (voice.cpp:1207-1218) */
+unsigned oal_scene_voice_buffers_done(oal_scene *s, int voice);
 int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process);
 /* DeviceBase::Process(HrtfPostProcess) alone (alc/alu.cpp:289-298): for scenes whose effect slots
  * add into the dry lines between the voice loop and the post-process (alu.cpp:2209-2257).  The dry

@@ -147,6 +147,7 @@ struct oal_scene {
     std::deque<BufferData> buffers;
     std::deque<Voice> voices;
     std::vector<int> vstate;
+    std::vector<unsigned> buffersDone;     /* summed AsyncBufferCompleteEvent counts per voice */
     std::deque<EffectSlotBase> slots;
     HrtfStorePtr hrtf;
 };
@@ -468,6 +469,11 @@ oal_scene *oal_scene_create(const oal_device_desc *desc)
     s->ctx = std::make_unique<Ctx>(s->dev.get());
     s->ctx->mEnabledEvts.store({}, std::memory_order_relaxed);
     s->ctx->mAsyncEvents = FifoBuffer<AsyncEvent>::Create(64, false);
+    {
+        auto evts = ContextBase::AsyncEventBitset{};
+        evts.set(AsyncEnableBits::BufferCompleted);
+        s->ctx->mEnabledEvts.store(evts, std::memory_order_relaxed);
+    }
     for(uint32_t i{0};i < desc->num_slots;++i)
     {
         auto &slot = s->slots.emplace_back();
@@ -513,9 +519,66 @@ int oal_scene_add_buffer(oal_scene *s, const void *data, int fmt_type, uint32_t 
     return static_cast<int>(s->buffers.size()-1);
 }
 
+/* IMA4 / MS ADPCM data as the buffer layer hands it to the voices (al/buffer.cpp LoadData:
+ * mBlockAlign = samples per block, mSamples = the compressed bytes) */
+int oal_scene_add_buffer_adpcm(oal_scene *s, const void *data, int adpcm_type, uint32_t channels,
+    uint32_t samples_per_block, uint32_t sample_len, uint32_t loop_start, uint32_t loop_end)
+{
+    auto const nblocks = size_t{(sample_len + samples_per_block - 1u) / samples_per_block};
+    auto const block_bytes = adpcm_type == 1 ? size_t{(samples_per_block-2u)/2u + 7u}*channels
+        : size_t{(samples_per_block-1u)/2u + 4u}*channels;
+    auto const nbytes = nblocks * block_bytes;
+    auto &b = s->buffers.emplace_back();
+    b.bytes.resize(nbytes + 16);
+    std::memcpy(b.bytes.data(), data, nbytes);
+    auto *p = b.bytes.data();
+    /* NOLINTBEGIN */
+    if(adpcm_type == 1) b.item.mSamples = std::span{reinterpret_cast<MSADPCMData*>(p), nbytes};
+    else b.item.mSamples = std::span{reinterpret_cast<IMA4Data*>(p), nbytes};
+    /* NOLINTEND */
+    b.item.mBlockAlign = samples_per_block;
+    b.item.mSampleLen = sample_len;
+    b.item.mLoopStart = loop_start;
+    b.item.mLoopEnd = loop_end;
+    b.bytes.back() = static_cast<std::byte>(channels);
+    b.bytes[b.bytes.size()-2] = static_cast<std::byte>(7 + adpcm_type);
+    return static_cast<int>(s->buffers.size()-1);
+}
+
+/* alSourceQueueBuffers' linking (al/source.cpp): `next` plays after `buffer`; next < 0 ends the queue */
+int oal_scene_link_buffers(oal_scene *s, int buffer, int next)
+{
+    auto &b = s->buffers.at(static_cast<size_t>(buffer));
+    b.item.mNext.store(next < 0 ? nullptr : &s->buffers.at(static_cast<size_t>(next)).item,
+        std::memory_order_relaxed);
+    return 0;
+}
+
+/* a streaming voice: not VoiceFlag::IsStatic, so Voice::mix loads through LoadBufferQueue
+ * (voice.cpp:563-594) and walks mCurrentBuffer along mNext (voice.cpp:1182-1194) */
+int oal_scene_add_queue_voice(oal_scene *s, const oal_voice_desc *desc)
+{
+    auto const vi = oal_scene_add_voice(s, desc);
+    if(vi < 0) return vi;
+    s->voices.at(static_cast<size_t>(vi)).mFlags.reset(VoiceFlag::IsStatic);
+    return vi;
+}
+
+unsigned oal_scene_voice_buffers_done(oal_scene *s, int voice)
+{ return static_cast<size_t>(voice) < s->buffersDone.size() ? s->buffersDone[static_cast<size_t>(voice)] : 0u; }
+
+/* index of the voice's mCurrentBuffer in the scene's buffer list, -1 = none */
+int oal_scene_voice_current_buffer(oal_scene *s, int voice)
+{
+    auto const *cur = s->voices.at(static_cast<size_t>(voice)).mCurrentBuffer.load();
+    for(size_t i{0};i < s->buffers.size();++i)
+        if(&s->buffers[i].item == cur) return static_cast<int>(i);
+    return -1;
+}
+
 int oal_scene_add_voice(oal_scene *s, const oal_voice_desc *desc)
 {
-    static constexpr std::array<unsigned,7> bps{1, 2, 4, 4, 8, 1, 1};
+    static constexpr std::array<unsigned,9> bps{1, 2, 4, 4, 8, 1, 1, 1, 1};
     auto &buf = s->buffers.at(static_cast<size_t>(desc->buffer));
     auto const frame_step = static_cast<unsigned>(buf.bytes.back());
     auto const fmt = static_cast<size_t>(buf.bytes[buf.bytes.size()-2]);
@@ -528,6 +591,12 @@ int oal_scene_add_voice(oal_scene *s, const oal_voice_desc *desc)
     v.mFrameStep = frame_step;
     v.mBytesPerBlock = frame_step * bps.at(fmt);
     v.mSamplesPerBlock = 1;
+    if(fmt >= 7)
+    {   /* InitVoice: BufferStorage::blockSizeFromFmt / mBlockAlign */
+        v.mSamplesPerBlock = buf.item.mBlockAlign;
+        v.mBytesPerBlock = (fmt == 8 ? (buf.item.mBlockAlign-2u)/2u + 7u : (buf.item.mBlockAlign-1u)/2u + 4u)
+            * frame_step;
+    }
     v.mAmbiOrder = 0;
     v.mFlags.reset();
     v.mFlags.set(VoiceFlag::IsStatic);
@@ -598,6 +667,16 @@ int oal_scene_add_voice_multi(oal_scene *s, const oal_voice_desc *desc, uint32_t
 {
     auto const vi = oal_scene_add_voice(s, desc);
     auto &v = s->voices.at(static_cast<size_t>(vi));
+    if(num_channels == 2 && v.mFrameStep == 2)
+    {   /* a plain stereo source: two ChannelData, no ambisonic handling */
+        v.mFmtChannels = FmtStereo;
+        auto const pos = v.mPosition.load(std::memory_order_relaxed);
+        auto const frac = v.mPositionFrac.load(std::memory_order_relaxed);
+        v.prepare(s->dev.get());
+        v.mPosition.store(pos, std::memory_order_relaxed);
+        v.mPositionFrac.store(frac, std::memory_order_relaxed);
+        return v.mChans.size() == 2 ? vi : -1;
+    }
     if(num_channels != 4 || v.mFrameStep != 4) return -1;
     /* a first-order B-Format source; the device has to be at least first order for prepare()
      * to keep all four channels (voice.cpp:1247-1249) */
@@ -711,6 +790,23 @@ int oal_scene_mix(oal_scene *s, uint32_t samples_to_do, int post_process)
         auto const vstate = v.mPlayState.load(std::memory_order_acquire);
         if(vstate != Voice::Stopped && vstate != Voice::Pending)
             v.mix(vstate, s->ctx.get(), curtime, samples_to_do);
+        /* what the event thread would receive (voice.cpp:1207-1218) */
+        auto *ring = s->ctx->mAsyncEvents.get();
+        auto const evts = ring->getReadVector();
+        auto count = 0_uz;
+        for(auto const &part : evts)
+        {
+            for(auto &evt : part)
+            {
+                if(auto const *done = std::get_if<AsyncBufferCompleteEvent>(&evt))
+                {
+                    if(s->buffersDone.size() < s->voices.size()) s->buffersDone.resize(s->voices.size());
+                    s->buffersDone.at(done->mId - 1u) += done->mCount;
+                }
+                ++count;
+            }
+        }
+        if(count) ring->readAdvance(count);
     }
     if(post_process && s->desc.hrtf)
     {

@@ -379,6 +379,39 @@ class Scene:
     def set_state(self, voice, vstate):
         assert self.lib.L.oal_scene_set_voice_state(self.h, voice, vstate) == 0
 
+    # compiled reference only: ADPCM buffers, buffer queues, streaming voices
+    def add_buffer_adpcm(self, data, adpcm_type, channels, samples_per_block, sample_len, loop_start=0, loop_end=None):
+        data = np.ascontiguousarray(data, np.uint8)
+        f = self.lib.L.oal_scene_add_buffer_adpcm
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_uint32] * 5
+        return f(self.h, data.ctypes.data_as(C.c_void_p), adpcm_type, channels, samples_per_block, sample_len,
+                 loop_start, sample_len if loop_end is None else loop_end)
+
+    def link_buffers(self, buffer, nxt):
+        f = self.lib.L.oal_scene_link_buffers
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        assert f(self.h, buffer, nxt) == 0
+
+    def add_queue_voice(self, first_buffer, looping, position=0, frac=0, frequency=44100):
+        d = VoiceDesc(first_buffer, 1 if looping else 0, position, frac, frequency)
+        f = self.lib.L.oal_scene_add_queue_voice
+        f.argtypes = [C.c_void_p, C.POINTER(VoiceDesc)]
+        v = f(self.h, C.byref(d))
+        assert v >= 0
+        self.nvoices += 1
+        return v
+
+    def current_buffer(self, voice):
+        f = self.lib.L.oal_scene_voice_current_buffer
+        f.argtypes = [C.c_void_p, C.c_int]
+        return f(self.h, voice)
+
+    def queue_state(self, voice):
+        f = self.lib.L.oal_scene_voice_buffers_done
+        f.argtypes = [C.c_void_p, C.c_int]
+        f.restype = C.c_uint
+        return self.current_buffer(voice), f(self.h, voice)
+
     def set_start_delay(self, voice, samples):
         self.lib.L.oal_scene_set_voice_start_delay.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
         assert self.lib.L.oal_scene_set_voice_start_delay(self.h, voice, samples) == 0
