@@ -588,22 +588,16 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.nfc = nullptr; L.nfcOrders = 0;
     for(uint32_t &n : L.chansPerOrder) n = 0;
     if(c->useWave && (!L.hrtf || L.numSends))
-    {   // LinesMixKernel: at most 64 voices per partial bus; 256 partials while the buses are
-        // narrow, 128 when they are wide (the partials are HBM traffic for the reduction)
+    {   // stream rows, mixed onto the lines by the voice kernel's tail: one partial bus per workgroup
         L.lineStride = L.mixLines <= 8 ? 8u : (L.mixLines <= 16 ? 16u : 32u);
         L.streamsPerVoice = 2u + L.numSends;
-        // its LDS row list (1 + lineStride dwords per potential row) stays under 60 KB
-        const uint32_t maxRows = 60000u / (4u * (1u + L.lineStride));
-        const uint32_t maxPer = std::max<uint32_t>(1u, std::min<uint32_t>(64u, maxRows / L.streamsPerVoice));
-        const uint32_t want = L.mixLines <= 8 ? 256u : 128u;
-        L.numLineGroups = std::max<uint32_t>(std::min<uint32_t>(want, desc->max_voices), (desc->max_voices + maxPer - 1u) / maxPer);
         HIP_TRY(c->streams.alloc(nv * L.streamsPerVoice * kLine)); HIP_TRY(c->streams.zero()); L.streams = c->streams.p;
         HIP_TRY(c->lineGains.alloc(nv * L.streamsPerVoice * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
         L.lineGains = c->lineGains.p;
     }
     HIP_TRY(c->partLines.alloc(size_t{L.numLineGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
     // the two-stream pipeline of oalgpu_mix_update alternates between two sets of partial buses
-    HIP_TRY(c->partLines2.alloc(c->useWave && L.hrtf && L.streams ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
+    HIP_TRY(c->partLines2.alloc(c->useWave && L.streams ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
     c->partLinesBuf[0] = c->partLines.p; c->partLinesBuf[1] = c->partLines2.p;
     HIP_TRY(c->partHrtf.alloc(L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0)); L.partHrtf = c->partHrtf.p;
     HIP_TRY(c->partHrtf2.alloc(c->useWave && L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
@@ -898,25 +892,11 @@ int oalgpu_context_set_nfc(oalgpu_context *c, float w1, const uint32_t channels_
     DeviceLayout &L = c->L;
     const size_t nv = L.numVoices;
     // every order adds one stream row per voice
-    DevBuf<float> streams;
-    DevBuf<uint32_t> lineGains;
     const uint32_t spv = 2u + L.numSends + orders;
-    HIP_TRY(streams.alloc(nv * spv * kLine)); HIP_TRY(streams.zero());
-    HIP_TRY(lineGains.alloc(nv * spv * LineBlockDwords(L.lineStride))); HIP_TRY(lineGains.zero());
     HIP_TRY(c->nfc.alloc(nv)); HIP_TRY(c->nfc.zero());
-    std::swap(c->streams.p, streams.p); std::swap(c->streams.n, streams.n);
-    std::swap(c->lineGains.p, lineGains.p); std::swap(c->lineGains.n, lineGains.n);
+    HIP_TRY(c->streams.alloc(nv * spv * kLine)); HIP_TRY(c->streams.zero());
+    HIP_TRY(c->lineGains.alloc(nv * spv * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
     L.streams = c->streams.p; L.lineGains = c->lineGains.p; L.streamsPerVoice = spv;
-    // keep LinesMixKernel's LDS row list under 60 KB with the longer rows-per-voice
-    const uint32_t maxRows = 60000u / (4u * (1u + L.lineStride));
-    const uint32_t maxPer = std::max<uint32_t>(1u, std::min<uint32_t>(64u, maxRows / spv));
-    const uint32_t need = (uint32_t(nv) + maxPer - 1u) / maxPer;
-    if(need > L.numLineGroups)
-    {
-        L.numLineGroups = need;
-        HIP_TRY(c->partLines.alloc(size_t{L.numLineGroups} * L.mixLines * kLine));
-        L.partLines = c->partLines.p; c->partLinesBuf[0] = c->partLines.p;
-    }
     L.nfc = c->nfc.p;
     L.nfcOrders = orders;
     for(int o = 0; o < 5; ++o) L.chansPerOrder[o] = (uint32_t(o) <= orders) ? channels_per_order[o] : 0u;
@@ -1183,7 +1163,7 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
 int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_process)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
-    if(!(c->useWave && c->L.hrtf && c->ownStream) || c->serialOnly)
+    if(!(c->useWave && c->ownStream) || c->serialOnly)
     {   // one stream: the workgroup-per-voice-group kernel reads the carried accumulator itself,
         // and a caller-owned stream (RCCL ordering) is never forked
         if(int rc = oalgpu_mix_voices(c, samples_to_do)) return rc;
@@ -1198,8 +1178,8 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
 int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
-    if(!(c->useWave && c->L.hrtf && c->ownStream))
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_mix_voices_overlapped: needs a FAST HRTF context on its own streams");
+    if(!(c->useWave && c->ownStream))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_mix_voices_overlapped: needs a FAST context (wavefront kernel) on its own streams");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
@@ -1214,11 +1194,12 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do));
     if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
     HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
-    // post stream: reduction (adds the carried HRTF accumulator tail); whatever follows on that
-    // stream -- a collective, the effects, the post-process -- runs beside the next update's
-    // parameter and voice kernels
+    // post stream: the reduction (adds the carried HRTF accumulator tail); whatever follows on that stream -- a collective, the effects, the post-process -- runs beside
+    // the next update's parameter and voice kernels
     HIP_TRY(hipStreamWaitEvent(c->postStream, c->evVoiceDone[p], 0));
-    LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum, true);
+    // (4-wavefront workgroups: they find room on a CU as soon as ONE of the next update's voice workgroups
+    // has left it; the 16-wavefront form waits for a whole CU -- measured 62 against 53 us per config-2 step)
+    LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum && L.hrtf, true);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->evReduceDone[p], c->postStream));
     if(int rc = CommReduceBus(c, c->postStream)) return rc;      // beside the next update's voice kernel
@@ -1231,9 +1212,9 @@ void *oalgpu_post_stream(oalgpu_context *c) { return c ? static_cast<void*>(c->p
 int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, int post_process)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
-    if(!(c->useWave && c->L.hrtf && c->ownStream))
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_post_process_overlapped: needs a FAST HRTF context on its own streams");
-    if(post_process && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
+    if(!(c->useWave && c->ownStream))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_post_process_overlapped: needs a FAST context (wavefront kernel) on its own streams");
+    if(post_process && c->L.hrtf && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
     if(int rc = UseDevice(c->desc.device)) return rc;
     const DeviceLayout &L = c->L;
     if(post_process) { if(int rc = RunEffects(c, c->postStream, samples_to_do)) return rc; }
@@ -1243,6 +1224,12 @@ int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, in
         float *right = left + kLine;
         LaunchPostDirectHrtfFast(c->postStream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
             c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do);
+        HIP_TRY(hipGetLastError());
+    }
+    if(post_process && !L.hrtf && c->decOn)
+    {   // DeviceBase::Process(AmbiDecPostProcess), alc/alu.cpp:282-287: dry lines -> speaker feeds
+        LaunchBFormatDecode(c->postStream, c->exact, L.bus + size_t{L.numDry} * kLine, L.bus, c->decSplit.p, c->decBands.p,
+            c->decGainsHf.p, c->decDual ? c->decGainsLf.p : nullptr, L.numDry, c->decOut, samples_to_do);
         HIP_TRY(hipGetLastError());
     }
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->postStream)); c->timed = true; }
@@ -1361,7 +1348,7 @@ int oalgpu_bus_device_ptr(oalgpu_context *c, void **ptr, size_t *nfloats, void *
     *ptr = c->L.bus;
     *nfloats = BusFloats(c->L);
     if(hip_stream)      // the pipelined path produces the bus on the post stream, the serial entry points on the main one
-        *hip_stream = (c->useWave && c->L.hrtf && c->ownStream && !c->serialOnly && c->postStream) ? c->postStream : c->stream;
+        *hip_stream = (c->useWave && c->ownStream && !c->serialOnly && c->postStream) ? c->postStream : c->stream;
     return OALGPU_OK;
 }
 

@@ -70,7 +70,7 @@ struct alignas(16) BiquadSlot { BiquadState f; uint32_t pad[3]; };
 static_assert(sizeof(BiquadSlot) == 64, "BiquadSlot");
 
 // The resolved MixLine gains (dev_mix.hpp MixLineGain) of one stream row over the mix lines, as
-// LinesMixKernel consumes them: a block of 3*S + 8 dwords per row, S = lineStride,
+// the voice kernel's tail (WgMixRows, voice_wave.hip) consumes them: a block of 3*S + 8 dwords per row, S = lineStride,
 //   [gain[S] | rampA[S] | rampB[S] | live, rampLen, 0...]
 // every frame uses gain[c] (0 when the line's constant part is not mixed); frames below rampLen
 // add rampA[c] + rampB[c]*frame, the ramp's distance from the constant (0 for lines without a
@@ -109,10 +109,10 @@ struct DeviceLayout {
     // partial buses written by the voice kernel: [group][mixLines][1024], [group][1152][2]
     float *partLines, *partHrtf;
     // wavefront kernel, dry-line and send mixing: stream rows [voice][streamsPerVoice][1024] and
-    // their gain blocks, consumed by LinesMixKernel, which writes numLineGroups partial buses
+    // their gain blocks, consumed by the kernel's own tail (WgMixRows), which writes one partial bus per workgroup
     float *streams;
     uint32_t *lineGains;
-    uint32_t numLineGroups;                 // groups of partLines (== numGroups unless LinesMixKernel runs)
+    uint32_t numLineGroups;                 // groups of partLines (== numGroups)
     uint32_t lineStride;                    // gain vector width of a stream row: mixLines rounded up to 8 / 16 / 32
     uint32_t streamsPerVoice;               // stream rows per voice: 2 + numSends (see voice_wave.hip)
     // final bus block: [(numDry+numReal) x 1024 | numSlots*wetChannels x 1024 | 1152 x 2]

@@ -58,17 +58,21 @@ __global__ void __launch_bounds__(64) BandSplitKernel(const float *lines, Splitt
     }
     else
     {
-        const uint32_t seg = ((n + 63u) / 64u) | 1u;
-        const uint32_t begin = lane * seg < n ? lane * seg : n;
-        const uint32_t end = (begin + seg < n) ? begin + seg : n;
+        // lane l owns samples [17 l, 17 l + 17) (64 runs of 17 cover 1024); its samples are requested up front
+        // (independent loads), the runs have equal length (zeros past n): one transition matrix for all
+        constexpr uint32_t seg = 17;
+        const uint32_t begin = lane * seg;
+        float x[seg];
+#pragma unroll
+        for(uint32_t i = 0; i < seg; ++i) x[i] = (begin + i < n) ? in[begin + i] : 0.0f;
         Mat3 M{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        Sp3 q{0, 0, 0};
+#pragma unroll
         for(uint32_t i = 0; i < seg; ++i)
         {
             BandStep(M.c0, 0.0f, apCoeff, lpCoeff); BandStep(M.c1, 0.0f, apCoeff, lpCoeff); BandStep(M.c2, 0.0f, apCoeff, lpCoeff);
+            BandStep(q, x[i], apCoeff, lpCoeff);
         }
-        Sp3 q{0, 0, 0};
-        for(uint32_t i = begin; i < end; ++i) BandStep(q, in[i], apCoeff, lpCoeff);
-        for(uint32_t i = end; i < begin + seg; ++i) BandStep(q, 0.0f, apCoeff, lpCoeff);   // runs of equal length: one transition matrix
         Sp3 e = q;
         Sp3 s0{st.lpZ1, st.lpZ2, st.apZ1};
         Mat3 P = M;
@@ -88,9 +92,17 @@ __global__ void __launch_bounds__(64) BandSplitKernel(const float *lines, Splitt
         prevE.a = __shfl_up(e.a, 1); prevE.b = __shfl_up(e.b, 1); prevE.c = __shfl_up(e.c, 1);
         Sp3 start = s0;
         if(lane > 0) { start.a += prevE.a; start.b += prevE.b; start.c += prevE.c; }
-        for(uint32_t i = begin; i < end; ++i) { const Band2 b = BandStep(start, in[i], apCoeff, lpCoeff); hp[i] = b.hp; lp[i] = b.lp; }
-        const int lastLane = int((n - 1u) / seg);
-        const float z0 = __shfl(start.a, lastLane), z1 = __shfl(start.b, lastLane), z2 = __shfl(start.c, lastLane);
+        // the state behind sample n-1: the run that holds it stops there
+        const uint32_t lastLane = (n - 1u) / seg, lastLen = n - lastLane * seg;
+        Sp3 fin = start;
+#pragma unroll
+        for(uint32_t i = 0; i < seg; ++i)
+        {
+            const Band2 b = BandStep(start, x[i], apCoeff, lpCoeff);
+            if(begin + i < n) { hp[begin + i] = b.hp; lp[begin + i] = b.lp; }
+            if(i + 1u == lastLen) fin = start;
+        }
+        const float z0 = __shfl(fin.a, int(lastLane)), z1 = __shfl(fin.b, int(lastLane)), z2 = __shfl(fin.c, int(lastLane));
         if(lane == 0) { states[ch].lpZ1 = z0; states[ch].lpZ2 = z1; states[ch].apZ1 = z2; }
     }
 }
@@ -98,31 +110,39 @@ __global__ void __launch_bounds__(64) BandSplitKernel(const float *lines, Splitt
 // out[c][i] += sum over the dry lines j, in the reference's order (j ascending; per j HF then LF), of
 // in_j[i] * gain[j][c]; a gain whose magnitude does not exceed GainSilenceThreshold is skipped as MixLine skips it
 template<bool EXACT, bool DUAL>
-__global__ void __launch_bounds__(256) BFormatMixKernel(float *out, const float *lines, const float *bands, const float *gainsHf /* [in][32] */,
+__global__ void __launch_bounds__(64) BFormatMixKernel(float *out, const float *lines, const float *bands, const float *gainsHf /* [in][32] */,
     const float *gainsLf, uint32_t nin, uint32_t nout, uint32_t n)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if(i >= n) return;
-    for(uint32_t c = 0; c < nout; ++c)
+    // eight output lines at a time: their sums advance together over the dry lines (every sum still in the
+    // reference's order), so that a dry line's samples are read once per eight outputs and the loads of one j
+    // do not wait for the adds of the previous one
+    for(uint32_t c0 = 0; c0 < nout; c0 += 8u)
     {
-        float acc = out[size_t{c} * kLine + i];
+        float acc[8];
+#pragma unroll
+        for(uint32_t c = 0; c < 8u; ++c) acc[c] = (c0 + c < nout) ? out[size_t{c0 + c} * kLine + i] : 0.0f;
         for(uint32_t j = 0; j < nin; ++j)
         {
-            const float gh = gainsHf[j * 32u + c];
-            if constexpr (DUAL)
+            float hp, lp = 0.0f;
+            if constexpr (DUAL) { hp = bands[(size_t{j} * 2) * kLine + i]; lp = bands[(size_t{j} * 2 + 1) * kLine + i]; }
+            else hp = lines[size_t{j} * kLine + i];
+#pragma unroll
+            for(uint32_t c = 0; c < 8u; ++c)
             {
-                const float gl = gainsLf[j * 32u + c];
-                const float hp = bands[(size_t{j} * 2) * kLine + i], lp = bands[(size_t{j} * 2 + 1) * kLine + i];
-                if(fabsf(gh) > kSilence) acc = EXACT ? acc + hp * gh : __builtin_fmaf(hp, gh, acc);
-                if(fabsf(gl) > kSilence) acc = EXACT ? acc + lp * gl : __builtin_fmaf(lp, gl, acc);
-            }
-            else
-            {
-                const float x = lines[size_t{j} * kLine + i];
-                if(fabsf(gh) > kSilence) acc = EXACT ? acc + x * gh : __builtin_fmaf(x, gh, acc);
+                const uint32_t cc = (c0 + c < nout) ? c0 + c : c0;      // gains are padded to 32 per dry line
+                const float gh = gainsHf[j * 32u + cc];
+                if(fabsf(gh) > kSilence) acc[c] = EXACT ? acc[c] + hp * gh : __builtin_fmaf(hp, gh, acc[c]);
+                if constexpr (DUAL)
+                {
+                    const float gl = gainsLf[j * 32u + cc];
+                    if(fabsf(gl) > kSilence) acc[c] = EXACT ? acc[c] + lp * gl : __builtin_fmaf(lp, gl, acc[c]);
+                }
             }
         }
-        out[size_t{c} * kLine + i] = acc;
+#pragma unroll
+        for(uint32_t c = 0; c < 8u; ++c) if(c0 + c < nout) out[size_t{c0 + c} * kLine + i] = acc[c];
     }
 }
 
@@ -182,22 +202,22 @@ __global__ void __launch_bounds__(256) WriteKernel(const float *lines, uint32_t 
 void LaunchBFormatDecode(hipStream_t s, bool exact, float *out, const float *lines, SplitterState *states, float *bands,
     const float *gainsHf, const float *gainsLf, uint32_t nin, uint32_t nout, uint32_t n)
 {
-    const dim3 mgrid((n + 255u) / 256u);
+    const dim3 mgrid((n + 63u) / 64u);
     if(gainsLf)
     {
         if(exact)
         {
             hipLaunchKernelGGL(BandSplitKernel<true>, dim3(nin), dim3(64), 0, s, lines, states, bands, n);
-            hipLaunchKernelGGL((BFormatMixKernel<true, true>), mgrid, dim3(256), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
+            hipLaunchKernelGGL((BFormatMixKernel<true, true>), mgrid, dim3(64), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
         }
         else
         {
             hipLaunchKernelGGL(BandSplitKernel<false>, dim3(nin), dim3(64), 0, s, lines, states, bands, n);
-            hipLaunchKernelGGL((BFormatMixKernel<false, true>), mgrid, dim3(256), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
+            hipLaunchKernelGGL((BFormatMixKernel<false, true>), mgrid, dim3(64), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
         }
     }
-    else if(exact) hipLaunchKernelGGL((BFormatMixKernel<true, false>), mgrid, dim3(256), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
-    else hipLaunchKernelGGL((BFormatMixKernel<false, false>), mgrid, dim3(256), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
+    else if(exact) hipLaunchKernelGGL((BFormatMixKernel<true, false>), mgrid, dim3(64), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
+    else hipLaunchKernelGGL((BFormatMixKernel<false, false>), mgrid, dim3(64), 0, s, out, lines, bands, gainsHf, gainsLf, nin, nout, n);
 }
 
 uint32_t DitherAdvanceSeed(uint32_t seed, uint32_t draws)

@@ -60,7 +60,127 @@ __device__ __forceinline__ void StoreRowBlock(uint32_t *blk, uint32_t ls, uint32
         blk[ls + lane] = __builtin_bit_cast(uint32_t, r.fadeLen ? r.cur - r.gain : 0.0f);
         blk[2u * ls + lane] = __builtin_bit_cast(uint32_t, r.fadeLen ? r.step : 0.0f);
     }
-    if(lane < 8u) blk[3u * ls + lane] = lane == 0u ? (live ? 1u : 0u) : (lane == 1u ? maxFade : 0u);
+    // flags[0]: which 8-line blocks of the gain vector carry anything (LinesMixKernel runs per block and
+    // skips rows that give nothing to its lines); flags[1]: frames covered by the longest ramp
+    const bool nz = lane < ls && (r.gain != 0.0f || (r.fadeLen && (r.cur != r.gain || r.step != 0.0f)));
+    const unsigned long long m = __ballot(nz);
+    const uint32_t mask = ((m & 0xFFull) ? 1u : 0u) | ((m & 0xFF00ull) ? 2u : 0u) | ((m & 0xFF0000ull) ? 4u : 0u)
+        | ((m & 0xFF000000ull) ? 8u : 0u);
+    if(lane < 8u) blk[3u * ls + lane] = lane == 0u ? (live ? mask : 0u) : (lane == 1u ? maxFade : 0u);
+}
+
+// ---- MixSamples of the workgroup's stream rows onto the mix lines (core/mixer/mixer_c.cpp:183-215 as
+// Voice::mix calls it, voice.cpp:934-984): out[c][f] += row_r[f] * gain_{r,c}(f) over the rows of the
+// workgroup's voices in row order, into ONE partial bus per workgroup (BusReduceKernel sums those in
+// workgroup order: deterministic).  Runs as the kernel's tail, when all four wavefronts are through their
+// voices: the rows were written moments ago by this workgroup, so they come back out of this XCD's L2, and
+// the phase overlaps with the other workgroups' resamplers instead of being a launch of its own.
+// Thread t owns frames 4t .. 4t+3 of every line.  The rows' gain blocks are staged in LDS (the voices' LDS
+// is free by now); a row feeds few lines -- the dry lines, or one slot's wet lines -- and its flags say
+// which 8-line blocks (StoreRowBlock), so only those are read and multiplied.  A gain ramp (MixLine with
+// Counter <= 64, voice.cpp:1093) only ever covers the first 64 frames: wavefront 0 adds
+// s * (rampA + rampB * f), the ramp's distance from the constant, behind the row's constant term.
+constexpr uint32_t kMixListMax = 512;             // live rows per staged chunk (>= kMixGainDwords / 32)
+constexpr uint32_t kMixGainDwords = 12288;        // staged gain blocks: 48 KB
+template<int S>
+__device__ __forceinline__ void WgMixRows(uint32_t *lds, const DeviceLayout &L, uint32_t group, uint32_t v0, uint32_t nv,
+    uint32_t t, uint32_t N)
+{
+    constexpr uint32_t kBlk = 3u * S + 8u;
+    constexpr uint32_t kRowBatch = 4;
+    const uint32_t lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t spv = L.streamsPerVoice;
+    uint32_t *list = lds, *count = lds + kMixListMax, *gl = lds + kMixListMax + 4u;
+    float acc[S][4];
+#pragma unroll
+    for(int c = 0; c < S; ++c)
+#pragma unroll
+        for(int j = 0; j < 4; ++j) acc[c][j] = 0.0f;
+    uint32_t chunkVoices = kMixGainDwords / (spv * kBlk);
+    chunkVoices = chunkVoices < 1u ? 1u : (chunkVoices > kMixListMax / spv ? kMixListMax / spv : chunkVoices);
+    for(uint32_t c0 = 0; c0 < nv; c0 += chunkVoices)
+    {
+        const uint32_t cv = (nv - c0 < chunkVoices) ? nv - c0 : chunkVoices;
+        const uint32_t nrows = cv * spv;
+        const uint32_t *src = L.lineGains + size_t{v0 + c0} * spv * kBlk;
+        __syncthreads();
+        for(uint32_t i = t; i < nrows * kBlk; i += kWThreads) gl[i] = src[i];
+        __syncthreads();
+        if(wave == 0u)
+        {   // the chunk's live rows, in row order
+            uint32_t n = 0;
+            for(uint32_t r0 = 0; r0 < nrows; r0 += 64u)
+            {
+                const uint32_t r = r0 + lane;
+                const bool live = r < nrows && gl[r * kBlk + 3u * S] != 0u;
+                const unsigned long long ml = __ballot(live);
+                if(live) list[n + uint32_t(__popcll(ml & ((1ull << lane) - 1ull)))] = r;
+                n += uint32_t(__popcll(ml));
+            }
+            if(lane == 0u) *count = n;
+        }
+        __syncthreads();
+        const uint32_t nLive = __builtin_amdgcn_readfirstlane(*count);
+        const float *rows = L.streams + size_t{v0 + c0} * spv * kLine + 4u * t;
+        for(uint32_t b = 0; b < nLive; b += kRowBatch)
+        {
+            uint32_t rr[kRowBatch];
+            float4 s[kRowBatch];
+#pragma unroll
+            for(uint32_t k = 0; k < kRowBatch; ++k)
+            {
+                rr[k] = __builtin_amdgcn_readfirstlane(list[(b + k < nLive) ? b + k : nLive - 1u]);
+                s[k] = *reinterpret_cast<const float4*>(rows + size_t{rr[k]} * kLine);
+            }
+#pragma unroll
+            for(uint32_t k = 0; k < kRowBatch; ++k)
+            {
+                if(b + k >= nLive) break;
+                const uint32_t *blk = gl + rr[k] * kBlk;
+                const uint2 fl = *reinterpret_cast<const uint2*>(blk + 3u * S);
+                const uint32_t mask = __builtin_amdgcn_readfirstlane(fl.x), len = __builtin_amdgcn_readfirstlane(fl.y);
+                const float sv[4] = {s[k].x, s[k].y, s[k].z, s[k].w};
+#pragma unroll
+                for(int z = 0; z < S / 8; ++z)
+                {
+                    if(!((mask >> z) & 1u)) continue;
+                    const float4 g0 = *reinterpret_cast<const float4*>(blk + 8 * z), g1 = *reinterpret_cast<const float4*>(blk + 8 * z + 4);
+                    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                    for(int c = 0; c < 8; ++c)
+#pragma unroll
+                        for(int j = 0; j < 4; ++j) acc[8 * z + c][j] = __builtin_fmaf(sv[j], gv[c], acc[8 * z + c][j]);
+                    if(wave == 0u && len != 0u)
+                    {
+                        const float4 a0 = *reinterpret_cast<const float4*>(blk + S + 8 * z), a1 = *reinterpret_cast<const float4*>(blk + S + 8 * z + 4);
+                        const float4 b0 = *reinterpret_cast<const float4*>(blk + 2 * S + 8 * z), b1 = *reinterpret_cast<const float4*>(blk + 2 * S + 8 * z + 4);
+                        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                        for(int j = 0; j < 4; ++j)
+                        {
+                            const uint32_t fr = 4u * t + uint32_t(j);
+                            const float sr = (fr < len) ? sv[j] : 0.0f;
+                            const float ff = float(fr);
+#pragma unroll
+                            for(int c = 0; c < 8; ++c) acc[8 * z + c][j] = __builtin_fmaf(sr, av[c] + bv[c] * ff, acc[8 * z + c][j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float *pl = L.partLines + size_t{group} * L.mixLines * kLine + 4u * t;
+#pragma unroll
+    for(int c = 0; c < S; ++c)
+    {
+        if(uint32_t(c) >= L.mixLines) continue;
+        float4 o;
+        o.x = (4u * t < N) ? acc[c][0] : 0.0f; o.y = (4u * t + 1u < N) ? acc[c][1] : 0.0f;
+        o.z = (4u * t + 2u < N) ? acc[c][2] : 0.0f; o.w = (4u * t + 3u < N) ? acc[c][3] : 0.0f;
+        *reinterpret_cast<float4*>(pl + size_t(c) * kLine) = o;
+    }
 }
 
 // NL == 0: HRTF voices (DoHrtfMix into the wave's register accumulator).
@@ -747,7 +867,20 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     }
 
     waveStamp(2);
-    if constexpr (NL > 0) return;
+    // the workgroup's stream rows onto the mix lines: one partial bus per workgroup (HRTF voices with sends:
+    // behind the accumulator dump, whose registers are free by then)
+    auto mixRows = [&]()
+    {
+        static_assert(sizeof(sm) >= (kMixListMax + 4u + kMixGainDwords) * sizeof(uint32_t), "the row mix stages its gain blocks in the voices' LDS");
+        uint32_t *lds = reinterpret_cast<uint32_t*>(&sm);
+        const uint32_t vWg = group * kWWaves * vpw;
+        const uint32_t nvWg = vWg < L.numVoices ? ((vWg + kWWaves * vpw < L.numVoices) ? kWWaves * vpw : L.numVoices - vWg) : 0u;
+        if(L.lineStride <= 8u) WgMixRows<8>(lds, L, group, vWg, nvWg, t, N);
+        else if(L.lineStride <= 16u) WgMixRows<16>(lds, L, group, vWg, nvWg, t, N);
+        else WgMixRows<32>(lds, L, group, vWg, nvWg, t, N);
+        waveStamp(3);
+    };
+    if constexpr (NL > 0) { mixRows(); return; }
     // ---- one partial per workgroup: waves dump their accumulators, then a fixed-order sum
     {
         f2 *dump = w.x2;                     // [frame] = (L, R), frames < 64R
@@ -793,169 +926,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
     }
     waveStamp(3);
-}
-
-// ---- MixSamples of every stream row onto the mix lines -------------------------------------------
-// out[c][f] += row_r[f] * gain_{r,c}(f) over the live rows of one voice group, in row order:
-// thread t owns frame 256*blockIdx.x + t of every line, blockIdx.y is the voice group.  The
-// group's live rows are compacted into an LDS list first (dead rows -- idle voices, rows a voice
-// does not use -- cost one flag read, not 4 KB); the rows are then read once, coalesced, a batch
-// in flight, and multiplied by their constant gain vectors (LDS, same address in all lanes).
-// One partial bus per group, summed by BusReduceKernel in group order: deterministic.
-// A gain ramp (MixLine with Counter <= 64, voice.cpp:1093) only ever covers the first 64 frames:
-// LinesRampKernel adds s * (ramp(f) - constant) to those frames of the partial bus afterwards.
-template<int S>                                   // gain vector width: mix lines padded to 8 / 16 / 32
-__global__ void __launch_bounds__(256) LinesMixKernel(DeviceLayout L, uint32_t samplesToDo)
-{
-    constexpr uint32_t kBlk = 3u * S + 8u;         // LineBlockDwords(S)
-    constexpr uint32_t kMixBatch = 16u;            // stream rows in flight per thread
-    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
-    // dyn: gains[maxRows][S] | rowIdx[maxRows]
-    __shared__ uint32_t waveBase[4];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t f = blockIdx.x * 256u + t;
-    const uint32_t g = blockIdx.y;
-    const uint32_t spv = L.streamsPerVoice;
-    const uint32_t per = (L.numVoices + L.numLineGroups - 1u) / L.numLineGroups;
-    const uint32_t v0 = g * per;
-    const uint32_t nv = (v0 < L.numVoices) ? ((v0 + per < L.numVoices) ? per : L.numVoices - v0) : 0u;
-    const uint32_t maxRows = per * spv;
-    float *gains = reinterpret_cast<float*>(dyn);
-    uint32_t *rowIdx = dyn + size_t{maxRows} * S;
-    const uint32_t *blk0 = L.lineGains + size_t{v0} * spv * kBlk;
-
-    // ---- compact the live rows in row order: ballot + prefix per pass of 256 potential rows
-    uint32_t nLive = 0;
-    for(uint32_t r0 = 0; r0 < nv * spv; r0 += 256)
-    {
-        const uint32_t r = r0 + t;
-        const bool live = r < nv * spv && blk0[size_t{r} * kBlk + 3u * S] != 0u;
-        const unsigned long long ml = __ballot(live);
-        if(lane == 0) waveBase[wave] = uint32_t(__popcll(ml));
-        __syncthreads();
-        uint32_t bl = nLive, tl = 0;
-        for(uint32_t w = 0; w < 4; ++w) { if(w < wave) bl += waveBase[w]; tl += waveBase[w]; }
-        if(live) rowIdx[bl + uint32_t(__popcll(ml & ((1ull << lane) - 1ull)))] = r;
-        nLive += tl;
-        __syncthreads();
-    }
-    // ---- their gain vectors
-    for(uint32_t k = t; k < nLive * S; k += 256)
-        gains[k] = __builtin_bit_cast(float, blk0[size_t{rowIdx[k / S]} * kBlk + (k % S)]);
-    __syncthreads();
-
-    float acc[S];
-#pragma unroll
-    for(int c = 0; c < S; ++c) acc[c] = 0.0f;
-    const float *rows = L.streams + size_t{v0} * spv * kLine + f;
-    for(uint32_t b = 0; b < nLive; b += kMixBatch)
-    {
-        float s[kMixBatch];
-#pragma unroll
-        for(uint32_t k = 0; k < kMixBatch; ++k)
-            s[k] = rows[size_t{rowIdx[(b + k < nLive) ? b + k : nLive - 1u]} * kLine];
-#pragma unroll
-        for(uint32_t k = 0; k < kMixBatch; ++k)
-        {
-            const bool in = b + k < nLive;
-            const float sk = in ? s[k] : 0.0f;
-            const float4 *g4 = reinterpret_cast<const float4*>(gains + size_t{in ? b + k : nLive - 1u} * S);
-#pragma unroll
-            for(int q = 0; q < S / 4; ++q)
-            {
-                const float4 x = g4[q];
-                acc[4 * q] = __builtin_fmaf(sk, x.x, acc[4 * q]);
-                acc[4 * q + 1] = __builtin_fmaf(sk, x.y, acc[4 * q + 1]);
-                acc[4 * q + 2] = __builtin_fmaf(sk, x.z, acc[4 * q + 2]);
-                acc[4 * q + 3] = __builtin_fmaf(sk, x.w, acc[4 * q + 3]);
-            }
-            // keep the gain reads of later rows from being hoisted above (register pressure)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    float *pl = L.partLines + size_t{g} * L.mixLines * kLine;
-#pragma unroll
-    for(int c = 0; c < S; ++c)
-        if(uint32_t(c) < L.mixLines) pl[size_t(c) * kLine + f] = (f < samplesToDo) ? acc[c] : 0.0f;
-}
-
-// One wavefront per voice group: lane = frame (< 64).  The group's rows with a ramp are listed
-// first (64 potential rows per ballot); then 16 of them at a time have their sample and their
-// ramp vectors (A | B, 2S <= 64 floats: one coalesced load per row) in flight together, the
-// vectors go through LDS so that every lane can read every line's pair.
-constexpr uint32_t kRampListMax = 2048;           // >= 60000 / (4 * (1 + 8)) potential rows per group
-template<int S>
-__global__ void __launch_bounds__(64) LinesRampKernel(DeviceLayout L, uint32_t samplesToDo)
-{
-    constexpr uint32_t kBlk = 3u * S + 8u;
-    constexpr uint32_t kChunk = 16;
-    __shared__ __attribute__((aligned(16))) float ab[kChunk][2 * S];
-    __shared__ uint32_t rampIdx[kRampListMax];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t g = blockIdx.x;
-    const uint32_t spv = L.streamsPerVoice;
-    const uint32_t per = (L.numVoices + L.numLineGroups - 1u) / L.numLineGroups;
-    const uint32_t v0 = g * per;
-    const uint32_t nv = (v0 < L.numVoices) ? ((v0 + per < L.numVoices) ? per : L.numVoices - v0) : 0u;
-    const uint32_t *blk0 = L.lineGains + size_t{v0} * spv * kBlk;
-    const float *rows = L.streams + size_t{v0} * spv * kLine + lane;
-    const float ff = float(lane);
-    uint32_t n = 0;
-    for(uint32_t r0 = 0; r0 < nv * spv; r0 += 64)
-    {
-        const uint32_t r = r0 + lane;
-        uint2 fl = make_uint2(0u, 0u);
-        if(r < nv * spv) fl = *reinterpret_cast<const uint2*>(blk0 + size_t{r} * kBlk + 3u * S);
-        const bool ramp = fl.x != 0u && fl.y != 0u;
-        const unsigned long long mr = __ballot(ramp);
-        if(ramp) rampIdx[n + uint32_t(__popcll(mr & ((1ull << lane) - 1ull)))] = r;
-        n += uint32_t(__popcll(mr));
-    }
-    if(n == 0u) return;
-    WaveSync();
-    float acc[S];
-#pragma unroll
-    for(int c = 0; c < S; ++c) acc[c] = 0.0f;
-    for(uint32_t b = 0; b < n; b += kChunk)
-    {
-        const uint32_t m = (n - b < kChunk) ? n - b : kChunk;
-        float sv[kChunk], abv[kChunk];
-        uint32_t len[kChunk];
-#pragma unroll
-        for(uint32_t j = 0; j < kChunk; ++j)
-        {
-            const uint32_t rr = rampIdx[b + ((j < m) ? j : m - 1u)];
-            sv[j] = rows[size_t{rr} * kLine];
-            abv[j] = (lane < 2u * S) ? __builtin_bit_cast(float, blk0[size_t{rr} * kBlk + S + lane]) : 0.0f;
-            len[j] = blk0[size_t{rr} * kBlk + 3u * S + 1u];
-        }
-        WaveSync();
-#pragma unroll
-        for(uint32_t j = 0; j < kChunk; ++j) if(lane < 2u * S) ab[j][lane] = abv[j];
-        WaveSync();
-#pragma unroll
-        for(uint32_t j = 0; j < kChunk; ++j)
-        {
-            if(j >= m) continue;
-            const float sk = (lane < len[j]) ? sv[j] : 0.0f;
-            const float4 *a4 = reinterpret_cast<const float4*>(&ab[j][0]);
-            const float4 *b4 = reinterpret_cast<const float4*>(&ab[j][S]);
-#pragma unroll
-            for(int q = 0; q < S / 4; ++q)
-            {
-                const float4 a = a4[q], bb = b4[q];
-                acc[4 * q] = __builtin_fmaf(sk, a.x + bb.x * ff, acc[4 * q]);
-                acc[4 * q + 1] = __builtin_fmaf(sk, a.y + bb.y * ff, acc[4 * q + 1]);
-                acc[4 * q + 2] = __builtin_fmaf(sk, a.z + bb.z * ff, acc[4 * q + 2]);
-                acc[4 * q + 3] = __builtin_fmaf(sk, a.w + bb.w * ff, acc[4 * q + 3]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    float *pl = L.partLines + size_t{g} * L.mixLines * kLine;
-#pragma unroll
-    for(int c = 0; c < S; ++c)
-        if(uint32_t(c) < L.mixLines && lane < samplesToDo) pl[size_t(c) * kLine + lane] += acc[c];
+    if constexpr (SENDS) mixRows();
 }
 
 } // namespace
@@ -1008,29 +979,6 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     {
         if(sends) hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, L, samplesToDo);
         else hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false>), grid, block, 0, s, L, samplesToDo);
-    }
-    if(L.streams)
-    {   // stream rows -> partial mix-line buses
-        const uint32_t per = (L.numVoices + L.numLineGroups - 1u) / L.numLineGroups;
-        const uint32_t maxRows = per * L.streamsPerVoice;
-        const dim3 mgrid(kLine / 256, L.numLineGroups);
-        const size_t lds = (size_t{maxRows} + size_t{maxRows} * L.lineStride) * sizeof(uint32_t);
-        const dim3 rgrid(L.numLineGroups);
-        if(L.lineStride <= 8)
-        {
-            hipLaunchKernelGGL(LinesMixKernel<8>, mgrid, dim3(256), lds, s, L, samplesToDo);
-            hipLaunchKernelGGL(LinesRampKernel<8>, rgrid, dim3(64), 0, s, L, samplesToDo);
-        }
-        else if(L.lineStride <= 16)
-        {
-            hipLaunchKernelGGL(LinesMixKernel<16>, mgrid, dim3(256), lds, s, L, samplesToDo);
-            hipLaunchKernelGGL(LinesRampKernel<16>, rgrid, dim3(64), 0, s, L, samplesToDo);
-        }
-        else
-        {
-            hipLaunchKernelGGL(LinesMixKernel<32>, mgrid, dim3(256), lds, s, L, samplesToDo);
-            hipLaunchKernelGGL(LinesRampKernel<32>, rgrid, dim3(64), 0, s, L, samplesToDo);
-        }
     }
     return hipGetLastError();
 }
