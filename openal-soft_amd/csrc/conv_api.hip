@@ -18,6 +18,8 @@ struct oalgpu_convolution {
     uint32_t fifoPos{0}, curSeg{0};            // mFifoPos, mCurrentSegment
     DevBuf<float> xhist, ring, filt, fir, outFifo, partial, cur, tgt, tw128, tw256;
     DevBuf<float> hostIn, hostOut;             // staging for the host-buffer entry point
+    DevBuf<uint32_t> ticket;                   // ConvFusedKernel's delivery counter
+    DevBuf<float> firOut;                      // ... and its time-domain FIR slices
 };
 
 namespace {
@@ -114,6 +116,8 @@ int oalgpu_convolution_create(int device, uint32_t num_out_lines, const float *i
     HIP_TRY(c->ring.alloc(size_t{c->ringSlots} * kFftLen)); HIP_TRY(c->ring.zero());
     HIP_TRY(c->outFifo.alloc(kFftLen)); HIP_TRY(c->outFifo.zero());
     HIP_TRY(c->partial.alloc(size_t{c->numChunks} * 8 * kFftLen)); HIP_TRY(c->partial.zero());
+    HIP_TRY(c->ticket.alloc(1)); HIP_TRY(c->ticket.zero());
+    HIP_TRY(c->firOut.alloc(OALGPU_BUFFER_LINE_SIZE)); HIP_TRY(c->firOut.zero());
     HIP_TRY(c->cur.alloc(OALGPU_MAX_OUTPUT_CHANNELS)); HIP_TRY(c->cur.zero());
     HIP_TRY(c->tgt.alloc(OALGPU_MAX_OUTPUT_CHANNELS)); HIP_TRY(c->tgt.zero());
     HIP_TRY(c->hostIn.alloc(OALGPU_BUFFER_LINE_SIZE));
@@ -151,7 +155,7 @@ int oalgpu_convolution_process_device(oalgpu_convolution *c, void *hip_stream, c
     h.numChunks = c->numChunks; h.segsPerChunk = kSegsPerChunk;
     h.wetIn = wet_in_dev; h.xhist = c->xhist.p; h.ring = c->ring.p; h.filt = c->filt.p; h.fir = c->fir.p;
     h.outFifo = c->outFifo.p; h.partial = c->partial.p; h.cur = c->cur.p; h.tgt = c->tgt.p;
-    h.outLines = out_lines_dev; h.tw128 = c->tw128.p; h.tw256 = c->tw256.p;
+    h.outLines = out_lines_dev; h.tw128 = c->tw128.p; h.tw256 = c->tw256.p; h.ticket = c->ticket.p; h.firOut = c->firOut.p;
     LaunchConvolution(static_cast<hipStream_t>(hip_stream), h);
     HIP_TRY(hipGetLastError());
     c->fifoPos = (c->fifoPos + n) % kSegLen;

@@ -7,16 +7,19 @@
 //     Y_t = sum_s  X_{t-s} * H_{s+1}          (X_t = FFT of input block t zero-padded to 256,
 //                                               H_s  = spectrum of impulse-response taps 128s..128s+127)
 // overlap-added across blocks (:644-652, :695-707).  Nothing in that recurrence depends on the
-// OUTPUT, so one update is three launches:
-//   ConvSpectraKernel  one wavefront per input block completed in this update: real FFT-256 into
-//                      the spectrum ring (mComplexData, indexed by curseg counting down, :710);
-//   ConvMacKernel      the sum over segments -- the only part with real traffic (2 x 511 KiB per
-//                      update for a 65 536-tap response): segment chunks x 128 bins, every filter
-//                      spectrum read once and reused for all (<= 8) blocks of the update through a
-//                      sliding register window of input spectra; chunk partials in a fixed order;
-//   ConvOutputKernel   one workgroup: chunk sum, inverse FFT per block, overlap-add chain, the
-//                      128-tap FIR, then MixSamples into the target lines with the
-//                      Current -> Target gain ramp over the update (NormalMix :298-304).
+// OUTPUT, so one update is ONE launch of numChunks workgroups of eight wavefronts (ConvFusedKernel):
+//   spectra   every workgroup transforms the update's <= 8 completed input blocks itself, a wavefront per
+//             block (real FFT-256 in LDS; a few microseconds of redundant work instead of a launch and an
+//             HBM round trip); workgroup 0 also files them in the spectrum ring (mComplexData, indexed by
+//             curseg counting down, :710) for later updates;
+//   MAC       the sum over the workgroup's chunk of segments -- the only part with real traffic (2 x 511 KiB
+//             per update for a 65 536-tap response): 128 bins x 4 pairs of blocks per workgroup, a pair's two
+//             input spectra sliding through registers so that every segment costs one filter and one input
+//             load; the chunk's partial sums go to HBM;
+//   output    the LAST workgroup to finish (a ticket counter behind a device-scope fence) adds the chunk
+//             partials in chunk order, runs the inverse FFT per block, the overlap-add chain and the 128-tap
+//             FIR, then MixSamples into the target lines with the Current -> Target gain ramp over the
+//             update (NormalMix :298-304).  Which workgroup that is does not change a bit of the result.
 // Spectra use pffft's packing idea in plain order: float2[128], bin 0 = (DC, Nyquist), bins
 // 1..127 complex.  The filter spectra are computed in double on the host and pre-scaled by 1/256
 // (:444-457); the forward/inverse pair here is unnormalised like pffft (inverse(forward(x)) = 256 x).
@@ -115,107 +118,170 @@ struct ConvLayout {
     const float *tgt;                     // Target gains [nlines]
     float *outLines;                      // nlines x 1024, accumulated into
     const f2 *tw128, *tw256;
+    uint32_t *ticket;                     // workgroups that have delivered their chunk (0 between launches)
+    float *firOut;                        // [1024] apply_fir of the update, computed in slices by all workgroups
 };
 
 // timeline sample i: i < 256 -> history, else this update's input
 __device__ __forceinline__ float Timeline(const ConvLayout &C, uint32_t i)
 { return i < 256u ? C.xhist[i] : C.wetIn[i - 256u]; }
 
-__global__ void __launch_bounds__(64) ConvSpectraKernel(ConvLayout C)
-{
-    __shared__ f2 z[128];
-    __shared__ f2 spec[128];
-    const uint32_t lane = threadIdx.x, t = blockIdx.x;
-    // block t of this update starts at timeline index 256 - fifoPos + 128 t and is zero-padded to 256
-    const uint32_t start = 256u - C.fifoPos + kSeg * t;
-    z[lane] = f2{Timeline(C, start + 2u * lane), Timeline(C, start + 2u * lane + 1u)};
-    z[lane + 64] = f2{0.0f, 0.0f};
-    WaveSync();
-    RealFft256Forward(z, spec, C.tw128, C.tw256, lane);
-    WaveSync();
-    // curseg counts down; the ring has 8 slots more than there are segments, so the spectra this
-    // update writes never replace one that an earlier block of the same update still reads
-    const uint32_t seg = (C.curSeg + C.ringSlots - t) % C.ringSlots;
-    C.ring[size_t{seg} * 128 + lane] = spec[lane];
-    C.ring[size_t{seg} * 128 + lane + 64] = spec[lane + 64];
-}
+constexpr uint32_t kConvThreads = 512;
 
-// Y_t = sum_{i<S} ring[(c_t + i) mod R] * filt[i],  c_t = curSeg - t (mod R); chunk = segments
-// [i0, i0 + segsPerChunk); thread = one packed bin.
-__global__ void __launch_bounds__(128) ConvMacKernel(ConvLayout C)
-{
-    const uint32_t f = threadIdx.x, chunk = blockIdx.x;
-    const uint32_t S = C.numSegs, R = C.ringSlots, K = C.numBlocks;
-    const uint32_t i0 = chunk * C.segsPerChunk;
-    const uint32_t i1 = (i0 + C.segsPerChunk < S) ? i0 + C.segsPerChunk : S;
-    f2 acc[kMaxBlocks];
-    f2 xs[kMaxBlocks];                          // xs[t] = ring[(curSeg - t + i) mod S] for the current i
-#pragma unroll
-    for(int t = 0; t < kMaxBlocks; ++t) { acc[t] = f2{0.0f, 0.0f}; xs[t] = f2{0.0f, 0.0f}; }
-    if(i0 < i1)
-    {
-        // state "before i0": xs[u] = ring[curSeg - u + i0 - 1]; the loop shifts it into place
-#pragma unroll
-        for(int u = 0; u + 1 < kMaxBlocks; ++u)
-            if(uint32_t(u) + 1u < K) xs[u] = C.ring[size_t{(C.curSeg + i0 + R - uint32_t(u) - 1u) % R} * 128 + f];
-    }
-    for(uint32_t i = i0; i < i1; ++i)
-    {
-        // xs[t] = ring[(curSeg - t + i) mod R]: one new spectrum per segment, the others slide
-#pragma unroll
-        for(int t = kMaxBlocks - 1; t >= 1; --t) xs[t] = xs[t - 1];
-        xs[0] = C.ring[size_t{(C.curSeg + i) % R} * 128 + f];
-        const f2 h = C.filt[size_t{i} * 128 + f];
-#pragma unroll
-        for(int t = 0; t < kMaxBlocks; ++t)
-        {
-            if(uint32_t(t) >= K) continue;
-            const f2 x = xs[t];
-            if(f == 0) { acc[t].x = __builtin_fmaf(x.x, h.x, acc[t].x); acc[t].y = __builtin_fmaf(x.y, h.y, acc[t].y); }
-            else
-            {
-                acc[t].x = __builtin_fmaf(x.x, h.x, __builtin_fmaf(-x.y, h.y, acc[t].x));
-                acc[t].y = __builtin_fmaf(x.x, h.y, __builtin_fmaf(x.y, h.x, acc[t].y));
-            }
-        }
-    }
-#pragma unroll
-    for(int t = 0; t < kMaxBlocks; ++t)
-        if(uint32_t(t) < K) C.partial[(size_t{chunk} * kMaxBlocks + t) * 128 + f] = acc[t];
-}
+// The chunk partials and the FIR slices travel from the workgroups that make them to the last one through
+// device-scope (agent) relaxed atomics: write-through stores and L2-coherent loads of exactly those words.
+// A release/acquire fence pair would do too, but at device scope it writes back and invalidates the WHOLE L2
+// of the XCD -- while the next update's voice kernel is filling it with stream rows on the other stream.
+__device__ __forceinline__ void StoreCoherent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float LoadCoherent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void StoreCoherent(f2 *p, f2 v)
+{ StoreCoherent(reinterpret_cast<float*>(p), v.x); StoreCoherent(reinterpret_cast<float*>(p) + 1, v.y); }
+__device__ __forceinline__ f2 LoadCoherent(const f2 *p)
+{ return f2{LoadCoherent(reinterpret_cast<const float*>(p)), LoadCoherent(reinterpret_cast<const float*>(p) + 1)}; }
 
-__global__ void __launch_bounds__(1024) ConvOutputKernel(ConvLayout C)
+__global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
 {
-    __shared__ f2 zbuf[kMaxBlocks][128];       // per block: spectrum, then z = (x[2n], x[2n+1]) * 256/256
-    __shared__ f2 spec[kMaxBlocks][128];
+    __shared__ f2 zbuf[kMaxBlocks][128];       // FFT work space; output stage: z = (x[2n], x[2n+1]) per block
+    __shared__ f2 spec[kMaxBlocks][128];       // this update's input spectra; output stage: the summed Y_t
     __shared__ float tl[256 + kLine];          // timeline
     __shared__ float chan[kLine];
+    __shared__ float firLds[kSeg];
+    __shared__ f2 tw128[64], tw256[128];       // the FFTs read a twiddle per butterfly stage: LDS, not HBM latency
+    __shared__ uint32_t isLast;
     const uint32_t t = threadIdx.x, lane = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const uint32_t K = C.numBlocks, n = C.n, p0 = C.fifoPos;
+    const uint32_t K = C.numBlocks, n = C.n, p0 = C.fifoPos, R = C.ringSlots;
 
-    for(uint32_t i = t; i < 256u + n; i += blockDim.x) tl[i] = Timeline(C, i);
-    if(wave < K)
+    for(uint32_t i = t; i < 256u + n; i += kConvThreads) tl[i] = Timeline(C, i);
+    if(t < uint32_t(kSeg)) { firLds[t] = C.fir[t]; tw256[t] = C.tw256[t]; }
+    if(t < 64u) tw128[t] = C.tw128[t];
+    __syncthreads();
+    if(K)
     {
-        for(uint32_t f = lane; f < 128u; f += 64)
+        // ---- input spectra: block `wave` of this update starts at timeline index 256 - fifoPos + 128 wave
+        // and is zero-padded to 256
+        if(wave < K)
+        {
+            const uint32_t start = 256u - p0 + kSeg * wave;
+            zbuf[wave][lane] = f2{tl[start + 2u * lane], tl[start + 2u * lane + 1u]};
+            zbuf[wave][lane + 64] = f2{0.0f, 0.0f};
+            WaveSync();
+            RealFft256Forward(zbuf[wave], spec[wave], tw128, tw256, lane);
+            WaveSync();
+            if(blockIdx.x == 0)
+            {   // curseg counts down; the ring has 8 slots more than there are segments, so the spectra this
+                // update files never replace one that a block of the same update still reads
+                const uint32_t seg = (C.curSeg + R - wave) % R;
+                C.ring[size_t{seg} * 128 + lane] = spec[wave][lane];
+                C.ring[size_t{seg} * 128 + lane + 64] = spec[wave][lane + 64];
+            }
+        }
+        __syncthreads();
+        // ---- Y_t = sum_{i<S} X(t, i) * filt[i],  X(t, i) = ring[(curSeg - t + i) mod R] -- block t - i of THIS
+        // update while i <= t (still in LDS), an older one from the ring otherwise.  Thread = one packed bin
+        // of the blocks 2q and 2q + 1: X(2q + 1, i) = X(2q, i - 1) slides through a register.
+        const uint32_t f = t & 127u, q = t >> 7;
+        const uint32_t tb = 2u * q;
+        const uint32_t i0 = blockIdx.x * C.segsPerChunk;
+        const uint32_t i1 = (i0 + C.segsPerChunk < C.numSegs) ? i0 + C.segsPerChunk : C.numSegs;
+        auto X = [&](uint32_t tt, uint32_t i) -> f2
+        {
+            if(i <= tt) return spec[tt - i][f];
+            return C.ring[size_t{(C.curSeg + i + R - tt) % R} * 128 + f];
+        };
+        f2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+        if(tb < K && i0 < i1)
+        {
+            auto mac = [&](f2 x0, f2 x1, f2 h)
+            {
+                if(f == 0)
+                {   // bin 0 = (DC, Nyquist): two real products
+                    acc0.x = __builtin_fmaf(x0.x, h.x, acc0.x); acc0.y = __builtin_fmaf(x0.y, h.y, acc0.y);
+                    acc1.x = __builtin_fmaf(x1.x, h.x, acc1.x); acc1.y = __builtin_fmaf(x1.y, h.y, acc1.y);
+                }
+                else
+                {
+                    acc0.x = __builtin_fmaf(x0.x, h.x, __builtin_fmaf(-x0.y, h.y, acc0.x));
+                    acc0.y = __builtin_fmaf(x0.x, h.y, __builtin_fmaf(x0.y, h.x, acc0.y));
+                    acc1.x = __builtin_fmaf(x1.x, h.x, __builtin_fmaf(-x1.y, h.y, acc1.x));
+                    acc1.y = __builtin_fmaf(x1.x, h.y, __builtin_fmaf(x1.y, h.x, acc1.y));
+                }
+            };
+            f2 x1 = X(tb + 1u < K ? tb + 1u : tb, i0);
+            uint32_t i = i0;
+            // the segments that still meet this update's own blocks (first chunk only)
+            for(; i < i1 && i <= tb + 1u; ++i) { const f2 x0 = X(tb, i); mac(x0, x1, C.filt[size_t{i} * 128 + f]); x1 = x0; }
+            // the rest straight from the ring: eight segments' loads in flight
+            uint32_t slot = (C.curSeg + i + R - tb) % R;
+            for(; i + 8u <= i1; i += 8u)
+            {
+                f2 xs[8], hs[8];
+#pragma unroll
+                for(uint32_t k = 0; k < 8u; ++k)
+                {
+                    xs[k] = C.ring[size_t{slot} * 128 + f];
+                    hs[k] = C.filt[size_t{i + k} * 128 + f];
+                    slot = (slot + 1u == R) ? 0u : slot + 1u;
+                }
+#pragma unroll
+                for(uint32_t k = 0; k < 8u; ++k) { mac(xs[k], x1, hs[k]); x1 = xs[k]; }
+            }
+            for(; i < i1; ++i) { const f2 x0 = X(tb, i); mac(x0, x1, C.filt[size_t{i} * 128 + f]); x1 = x0; }
+        }
+        if(tb < K) StoreCoherent(&C.partial[(size_t{blockIdx.x} * kMaxBlocks + tb) * 128 + f], acc0);
+        if(tb + 1u < K) StoreCoherent(&C.partial[(size_t{blockIdx.x} * kMaxBlocks + tb + 1u) * 128 + f], acc1);
+        // apply_fir (the first 128 taps over the newest input) of this workgroup's slice of the update
+        {
+            const uint32_t per = (n + gridDim.x - 1u) / gridDim.x;
+            for(uint32_t j = t; j < per && blockIdx.x * per + j < n; j += kConvThreads)
+            {
+                const uint32_t i = blockIdx.x * per + j;
+                float acc0 = 0.0f, acc1 = 0.0f;
+                const float *x = tl + 256 + i;
+#pragma unroll 8
+                for(int k = 0; k < kSeg; k += 2)
+                {
+                    acc0 = __builtin_fmaf(firLds[k], x[-k], acc0);
+                    acc1 = __builtin_fmaf(firLds[k + 1], x[-k - 1], acc1);
+                }
+                StoreCoherent(&C.firOut[i], acc0 + acc1);
+            }
+        }
+        // ---- the last workgroup to deliver does the rest (the barrier waits for every thread's stores)
+        __syncthreads();
+        if(t == 0) isLast = (__hip_atomic_fetch_add(C.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
+        __syncthreads();
+        if(!isLast) return;
+        if(t == 0) *C.ticket = 0u;
+        // the chunk partials in chunk order: thread = one bin of two blocks, 32 chunks' loads in flight
+        for(uint32_t w = tb; w < tb + 2u && w < K; ++w)
         {
             f2 s = {0.0f, 0.0f};
-            for(uint32_t c = 0; c < C.numChunks; ++c)
+            uint32_t c = 0;
+            for(; c + 32u <= C.numChunks; c += 32u)
             {
-                const f2 p = C.partial[(size_t{c} * kMaxBlocks + wave) * 128 + f];
+                f2 p[32];
+#pragma unroll
+                for(uint32_t k = 0; k < 32u; ++k) p[k] = LoadCoherent(&C.partial[(size_t{c + k} * kMaxBlocks + w) * 128 + f]);
+#pragma unroll
+                for(uint32_t k = 0; k < 32u; ++k) { s.x += p[k].x; s.y += p[k].y; }
+            }
+            for(; c < C.numChunks; ++c)
+            {
+                const f2 p = LoadCoherent(&C.partial[(size_t{c} * kMaxBlocks + w) * 128 + f]);
                 s.x += p.x; s.y += p.y;
             }
-            spec[wave][f] = s;
+            spec[w][f] = s;
         }
-        WaveSync();
-        RealFft256Inverse(spec[wave], zbuf[wave], C.tw128, C.tw256, lane);
+        __syncthreads();
+        if(wave < K) RealFft256Inverse(spec[wave], zbuf[wave], tw128, tw256, lane);
+        __syncthreads();
     }
-    __syncthreads();
     // ifft_b[q] = ((float*)zbuf[b])[q], q < 256.  Sample i of the update sits at fifo offset
     // q = (p0 + i) mod 128 of block b = (p0 + i) / 128 counted from the first block touched.
-    if(t < n)
+    for(uint32_t i = t; i < n; i += kConvThreads)
     {
-        const uint32_t a = p0 + t, b = a >> 7, q = a & 127u;
+        const uint32_t a = p0 + i, b = a >> 7, q = a & 127u;
         float v;
         if(b == 0) v = C.outFifo[q];                                   // pending output of earlier updates
         else
@@ -224,16 +290,21 @@ __global__ void __launch_bounds__(1024) ConvOutputKernel(ConvLayout C)
             const float prevHalf = (b >= 2) ? reinterpret_cast<const float*>(zbuf[b - 2])[128 + q] : C.outFifo[128 + q];
             v = cur[q] + prevHalf;
         }
-        // apply_fir: the first 128 taps over the newest input
-        float acc0 = 0.0f, acc1 = 0.0f;
-        const float *x = tl + 256 + t;
+        float fir;
+        if(K) fir = LoadCoherent(&C.firOut[i]);
+        else
+        {   // no block completes in this update (a single workgroup): apply_fir here
+            float acc0 = 0.0f, acc1 = 0.0f;
+            const float *x = tl + 256 + i;
 #pragma unroll 8
-        for(int k = 0; k < kSeg; k += 2)
-        {
-            acc0 = __builtin_fmaf(C.fir[k], x[-k], acc0);
-            acc1 = __builtin_fmaf(C.fir[k + 1], x[-k - 1], acc1);
+            for(int k = 0; k < kSeg; k += 2)
+            {
+                acc0 = __builtin_fmaf(firLds[k], x[-k], acc0);
+                acc1 = __builtin_fmaf(firLds[k + 1], x[-k - 1], acc1);
+            }
+            fir = acc0 + acc1;
         }
-        chan[t] = (acc0 + acc1) + v;
+        chan[i] = fir + v;
     }
     __syncthreads();
     // state for the next update
@@ -248,18 +319,38 @@ __global__ void __launch_bounds__(1024) ConvOutputKernel(ConvLayout C)
     __syncthreads();                           // every read of the old fifo is done
     if(K > 0 && t < 256u) C.outFifo[t] = nv;
     if(t < 256u) C.xhist[t] = tl[n + t];
-    // MixSamples(chan, out, Current, Target, Counter = n, OutPos = 0)
-    for(uint32_t c = 0; c < C.nlines; ++c)
+    // MixSamples(chan, out, Current, Target, Counter = n, OutPos = 0): four lines at a time, their gains and
+    // their output samples requested together
+    for(uint32_t c0 = 0; c0 < C.nlines; c0 += 4u)
     {
-        const MixLineGain g = PrepareMixLine(C.cur[c], C.tgt[c], n, n);
-        if(t < n && MixLineActive(g, t))
+        float cu[4], tg[4], o[4][2];
+#pragma unroll
+        for(uint32_t k = 0; k < 4u; ++k)
         {
-            float *o = C.outLines + size_t{c} * kLine + t;
-            *o = *o + MixLineValue(g, chan[t], t);
+            const uint32_t c = (c0 + k < C.nlines) ? c0 + k : C.nlines - 1u;
+            cu[k] = C.cur[c]; tg[k] = C.tgt[c];
+#pragma unroll
+            for(uint32_t j = 0; j < 2u; ++j)
+            {
+                const uint32_t i = t + kConvThreads * j;
+                o[k][j] = (i < n) ? C.outLines[size_t{c} * kLine + i] : 0.0f;
+            }
         }
-        __syncthreads();
-        if(t == 0) C.cur[c] = g.newCur;
+#pragma unroll
+        for(uint32_t k = 0; k < 4u; ++k)
+        {
+            if(c0 + k >= C.nlines) break;
+            const MixLineGain g = PrepareMixLine(cu[k], tg[k], n, n);
+#pragma unroll
+            for(uint32_t j = 0; j < 2u; ++j)
+            {
+                const uint32_t i = t + kConvThreads * j;
+                if(i < n && MixLineActive(g, i)) C.outLines[size_t{c0 + k} * kLine + i] = o[k][j] + MixLineValue(g, chan[i], i);
+            }
+        }
     }
+    __syncthreads();                           // every thread has read the Current gains
+    if(t < C.nlines) C.cur[t] = PrepareMixLine(C.cur[t], C.tgt[t], n, n).newCur;
 }
 
 } // namespace
@@ -275,12 +366,9 @@ void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h)
     C.fir = h.fir; C.outFifo = h.outFifo; C.partial = reinterpret_cast<f2*>(h.partial);
     C.cur = h.cur; C.tgt = h.tgt; C.outLines = h.outLines;
     C.tw128 = reinterpret_cast<const f2*>(h.tw128); C.tw256 = reinterpret_cast<const f2*>(h.tw256);
-    if(h.numBlocks)
-    {
-        hipLaunchKernelGGL(ConvSpectraKernel, dim3(h.numBlocks), dim3(64), 0, s, C);
-        hipLaunchKernelGGL(ConvMacKernel, dim3(h.numChunks), dim3(128), 0, s, C);
-    }
-    hipLaunchKernelGGL(ConvOutputKernel, dim3(1), dim3(1024), 0, s, C);
+    C.ticket = h.ticket; C.firOut = h.firOut;
+    // no block completes in this update: only the output stage (one workgroup)
+    hipLaunchKernelGGL(ConvFusedKernel, dim3(h.numBlocks ? h.numChunks : 1u), dim3(kConvThreads), 0, s, C);
 }
 
 } // namespace oalgpu

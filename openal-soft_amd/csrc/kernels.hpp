@@ -183,6 +183,8 @@ struct ConvLayoutHost {
     const float *tgt;
     float *outLines;
     const float *tw128, *tw256;
+    uint32_t *ticket;
+    float *firOut;
 };
 void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
 
