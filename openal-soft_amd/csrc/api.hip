@@ -880,8 +880,8 @@ int oalgpu_voice_set_ambi_scale(oalgpu_context *c, uint32_t voice, float xover_n
 int oalgpu_context_set_nfc(oalgpu_context *c, float w1, const uint32_t channels_per_order[5])
 {
     if(!c || !channels_per_order || !(w1 > 0.0f)) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: bad arguments");
-    if(!c->useWave || c->L.hrtf)
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: near-field control needs a FAST-mode dry-line context");
+    if(c->L.hrtf)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: near-field control is for dry-line contexts (HRTF voices mix through DoHrtfMix)");
     if(c->L.nfc) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: already set");
     uint32_t lines = channels_per_order[0], orders = 0;
     if(channels_per_order[0] != 1) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: channels_per_order[0] must be 1 (W)");
@@ -891,12 +891,14 @@ int oalgpu_context_set_nfc(oalgpu_context *c, float w1, const uint32_t channels_
     if(int rc = oalgpu_sync(c)) return rc;
     DeviceLayout &L = c->L;
     const size_t nv = L.numVoices;
-    // every order adds one stream row per voice
-    const uint32_t spv = 2u + L.numSends + orders;
     HIP_TRY(c->nfc.alloc(nv)); HIP_TRY(c->nfc.zero());
-    HIP_TRY(c->streams.alloc(nv * spv * kLine)); HIP_TRY(c->streams.zero());
-    HIP_TRY(c->lineGains.alloc(nv * spv * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
-    L.streams = c->streams.p; L.lineGains = c->lineGains.p; L.streamsPerVoice = spv;
+    if(c->useWave)
+    {   // the wavefront kernel: every order adds one stream row per voice
+        const uint32_t spv = 2u + L.numSends + orders;
+        HIP_TRY(c->streams.alloc(nv * spv * kLine)); HIP_TRY(c->streams.zero());
+        HIP_TRY(c->lineGains.alloc(nv * spv * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
+        L.streams = c->streams.p; L.lineGains = c->lineGains.p; L.streamsPerVoice = spv;
+    }
     L.nfc = c->nfc.p;
     L.nfcOrders = orders;
     for(int o = 0; o < 5; ++o) L.chansPerOrder[o] = (uint32_t(o) <= orders) ? channels_per_order[o] : 0u;

@@ -452,6 +452,47 @@ __device__ __forceinline__ float FirOne(float acc, const float *x /* x'[frame] *
     return acc;
 }
 
+// NfcFilterN::process, core/filters/nfc.cpp:222-288: the filter of order o over src[0..n) -> dst, on one lane
+// in the reference's operation order (the wavefront kernel runs the sections as block scans, wave_common.hpp)
+__device__ __forceinline__ void NfcSerial(NfcState &st, uint32_t o, const float *src, float *dst, uint32_t n)
+{
+    const float a0 = st.a[o][0], a1 = st.a[o][1], a2 = st.a[o][2], a3 = st.a[o][3], a4 = st.a[o][4];
+    const float b1 = st.b[o][1], b2 = st.b[o][2], b3 = st.b[o][3], b4 = st.b[o][4];
+    float z0 = st.z[o][0], z1 = st.z[o][1], z2 = st.z[o][2], z3 = st.z[o][3];
+    if(o == 1)
+    {
+        for(uint32_t i = 0; i < n; ++i)
+        {
+            const float y = src[i] * a0 - a1 * z0;
+            dst[i] = y + b1 * z0;
+            z0 += y;
+        }
+    }
+    else
+    {
+        for(uint32_t i = 0; i < n; ++i)
+        {
+            const float y0 = src[i] * a0 - a1 * z0 - a2 * z1;
+            const float out0 = y0 + b1 * z0 + b2 * z1;
+            z1 += z0;
+            z0 += y0;
+            if(o == 2) { dst[i] = out0; continue; }
+            if(o == 3)
+            {
+                const float y1 = out0 - a3 * z2;
+                dst[i] = y1 + b3 * z2;
+                z2 += y1;
+                continue;
+            }
+            const float y1 = out0 - a3 * z2 - a4 * z3;
+            dst[i] = y1 + b3 * z2 + b4 * z3;
+            z3 += z2;
+            z2 += y1;
+        }
+    }
+    st.z[o][0] = z0; st.z[o][1] = z1; st.z[o][2] = z2; st.z[o][3] = z3;
+}
+
 template<bool EXACT, int LINES>
 __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint32_t samplesToDo, uint32_t carryAccum)
 {
@@ -734,40 +775,58 @@ __global__ void __launch_bounds__(kThreads) VoiceMixKernel(DeviceLayout L, uint3
                 }
 
                 // ---------------- MixSamples (voice.cpp:962-963, 978-979) ----------------
-                uint32_t nlines, lineBase;
-                float *cur;
+                // `src` onto the bus lines [lineBase, lineBase + nlines) with the gains [gainOff + rel] of the
+                // target's Current/Target snapshot
                 const float *curSnap = sm.gCur[tg2], *tgtSnap = sm.gTgt[tg2];
+                auto mixOnto = [&](const float *src, uint32_t lineBase, uint32_t nlines, uint32_t gainOff, float *cur)
+                {
+                    float s4[4];
+#pragma unroll
+                    for(int k = 0; k < 4; ++k) s4[k] = (t + 256u * k < N) ? src[t + 256u * k] : 0.0f;
+#pragma unroll
+                    for(int c = 0; c < LINES; ++c)
+                    {
+                        const uint32_t rel = uint32_t(c) - lineBase;
+                        if(uint32_t(c) < lineBase || rel >= nlines) continue;
+                        const float tg = playing ? tgtSnap[gainOff + rel] : 0.0f;      // SilentCoeffs when Stopping
+                        const float cu = counter ? curSnap[gainOff + rel] : tg;        // voice.cpp:1094-1112
+                        const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+#pragma unroll
+                        for(int k = 0; k < 4; ++k)
+                        {
+                            const uint32_t p = t + 256u * k;
+                            if(p < N && MixLineActive(g, p)) lineAcc[c][k] = lineAcc[c][k] + MixLineValue(g, s4[k], p);
+                        }
+                        if(t == 0) cur[gainOff + rel] = g.newCur;
+                    }
+                };
                 if(isDirect)
                 {
-                    nlines = numDry; lineBase = 0;
-                    cur = L.gainCur + size_t{v} * numDry;
+                    float *cur = L.gainCur + size_t{v} * numDry;
+                    const bool nfcV = L.nfc && (ctl.flags & kFlagNfc);
+                    // DoNfcMix (voice.cpp:904-932): only the W line is mixed from the voice's own samples ...
+                    mixOnto(samples, 0u, nfcV ? 1u : numDry, 0u, cur);
+                    if(nfcV)
+                    {   // ... every ambisonic order above 0 from the samples through that order's NFC section
+                        // (NfcFilterN::process, one lane, in the reference's operation order)
+                        uint32_t line = 1;
+                        for(uint32_t o = 1; o <= L.nfcOrders; ++o)
+                        {
+                            const uint32_t cnt = L.chansPerOrder[o];
+                            __syncthreads();
+                            if(t == 0) NfcSerial(L.nfc[v], o, samples, sm.xl, N);
+                            __syncthreads();
+                            mixOnto(sm.xl, line, cnt, line, cur);
+                            line += cnt;
+                        }
+                    }
                 }
                 else
                 {
                     const int32_t slot = sm.sendSlot[si];
                     if(slot < 0) continue;
-                    nlines = wetCh;
-                    lineBase = (L.hrtf ? 0u : numDry) + uint32_t(slot) * wetCh;
-                    cur = L.sendCur + (size_t{v} * numSends + si) * wetCh;
-                }
-                float s4[4];
-#pragma unroll
-                for(int k = 0; k < 4; ++k) s4[k] = (t + 256u * k < N) ? samples[t + 256u * k] : 0.0f;
-#pragma unroll
-                for(int c = 0; c < LINES; ++c)
-                {
-                    const uint32_t rel = uint32_t(c) - lineBase;
-                    if(uint32_t(c) < lineBase || rel >= nlines) continue;
-                    const float tg = playing ? tgtSnap[rel] : 0.0f;      // SilentCoeffs when Stopping
-                    const float cu = counter ? curSnap[rel] : tg;        // voice.cpp:1094-1112
-                    const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
-#pragma unroll
-                    for(int k = 0; k < 4; ++k)
-                    {
-                        const uint32_t p = t + 256u * k;
-                        if(p < N && MixLineActive(g, p)) lineAcc[c][k] = lineAcc[c][k] + MixLineValue(g, s4[k], p);
-                    }
-                    if(t == 0) cur[rel] = g.newCur;
+                    mixOnto(samples, (L.hrtf ? 0u : numDry) + uint32_t(slot) * wetCh, wetCh, 0u,
+                        L.sendCur + (size_t{v} * numSends + si) * wetCh);
                 }
             }
             __syncthreads();

@@ -540,7 +540,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                         if(!nfcV) { if(lane == 0) blkN[3u * ls] = 0u; continue; }
                         const uint32_t cnt = L.chansPerOrder[o];
                         WaveSync();
-                        if(lane == 0) NfcSerial(L.nfc[v], o, w.in + kHist, w.rd, N);
+                        NfcWaveScan(L.nfc[v], o, w.in + kHist, w.rd, N, lane);
                         WaveSync();
                         float *dst = L.streams + (size_t{v} * spv + rowBase + o - 1u) * kLine;
                         for(uint32_t k = lane; k < uint32_t(kLine); k += 64) dst[k] = (k < N) ? w.rd[k] : 0.0f;

@@ -683,46 +683,113 @@ __device__ __forceinline__ void WaveDoFilters(float *fst, BiquadSlot *slots, boo
     }
 }
 
-// NfcFilterN::process, core/filters/nfc.cpp:222-288, section of order o over src[0..n) -> dst, on
-// one lane in the reference's operation order (the sections are short recurrences; a block
-// scan like the biquads' is the obvious next step)
-__device__ __forceinline__ void NfcSerial(NfcState &st, uint32_t o, const float *src, float *dst, uint32_t n)
+// NfcFilterN::process, core/filters/nfc.cpp:222-288: the filter of order o is a cascade of sections, each a
+// short linear recurrence in its integrator states --
+//   first order   y = x g - a1 z0;            out = y + b1 z0;            z0 += y
+//   second order  y = x g - a1 z0 - a2 z1;    out = y + b1 z0 + b2 z1;    z1 += z0; z0 += y
+// (order 1: one first-order section; 2: one second-order; 3: second then first; 4: two second-order) -- so a
+// wavefront runs each section as the same block scan as the biquads: lane l owns the run [17 l, 17 l + 17),
+// M = A^17, the run's forced response, run-start states by a 6-step Kogge-Stone scan with M, M^2 .. M^32, then
+// the recurrence itself from the true start state.  The reference's serial loop differs by rounding only.
+__device__ __forceinline__ float Nfc1Step(float &z, float x, float g, float a1, float b1)
+{
+    const float y = __builtin_fmaf(x, g, -a1 * z);
+    const float out = __builtin_fmaf(b1, z, y);
+    z += y;
+    return out;
+}
+__device__ __forceinline__ float Nfc2Step(S2 &s, float x, float g, float a1, float a2, float b1, float b2)
+{
+    const float y = __builtin_fmaf(x, g, __builtin_fmaf(-a1, s.a, -a2 * s.b));
+    const float out = __builtin_fmaf(b1, s.a, __builtin_fmaf(b2, s.b, y));
+    s.b += s.a;
+    s.a += y;
+    return out;
+}
+__device__ __forceinline__ void Nfc1WaveScan(float (&x)[kBqSeg], uint32_t cnt, uint32_t seg, float g, float a1, float b1, float &z,
+    uint32_t lane, int lastLane)
+{
+    float m = 1.0f;                                   // (1 - a1)^seg
+    for(uint32_t i = 0; i < seg; ++i) m = __builtin_fmaf(-a1, m, m);
+    float e = 0.0f;
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < seg) Nfc1Step(e, x[i], g, a1, b1);
+    float s0 = z, p = m;
+#pragma unroll
+    for(int step = 0; step < 6; ++step)
+    {
+        const int d = 1 << step;
+        const float o = __shfl_up(e, d);
+        if(int(lane) >= d) e = __builtin_fmaf(p, o, e);
+        if(lane & uint32_t(d)) s0 = p * s0;
+        p = p * p;
+    }
+    const float prevE = __shfl_up(e, 1);
+    float st = s0;
+    if(lane > 0) st += prevE;
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i)
+        if(uint32_t(i) < cnt) x[i] = Nfc1Step(st, x[i], g, a1, b1);
+    z = __shfl(st, lastLane);
+}
+__device__ __forceinline__ void Nfc2WaveScan(float (&x)[kBqSeg], uint32_t cnt, uint32_t seg, float g, float a1, float a2, float b1,
+    float b2, float &z0, float &z1, uint32_t lane, int lastLane)
+{
+    S2 m0{1.0f, 0.0f}, m1{0.0f, 1.0f};                 // columns of M = A^seg, A = [[1 - a1, -a2], [1, 1]]
+    for(uint32_t i = 0; i < seg; ++i)
+    {
+        Nfc2Step(m0, 0.0f, g, a1, a2, b1, b2);
+        Nfc2Step(m1, 0.0f, g, a1, a2, b1, b2);
+    }
+    S2 e{0.0f, 0.0f};
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < seg) Nfc2Step(e, x[i], g, a1, a2, b1, b2);
+    S2 s0{z0, z1};
+    S2 p0 = m0, p1 = m1;
+#pragma unroll
+    for(int step = 0; step < 6; ++step)
+    {
+        const int d = 1 << step;
+        const S2 o{__shfl_up(e.a, d), __shfl_up(e.b, d)};
+        const S2 mo = Mv2(p0, p1, o);
+        if(int(lane) >= d) { e.a += mo.a; e.b += mo.b; }
+        const S2 ms = Mv2(p0, p1, s0);
+        if(lane & uint32_t(d)) s0 = ms;
+        if(step < 5) { const S2 n0 = Mv2(p0, p1, p0), n1 = Mv2(p0, p1, p1); p0 = n0; p1 = n1; }
+    }
+    const S2 prevE{__shfl_up(e.a, 1), __shfl_up(e.b, 1)};
+    S2 st = s0;
+    if(lane > 0) { st.a += prevE.a; st.b += prevE.b; }
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i)
+        if(uint32_t(i) < cnt) x[i] = Nfc2Step(st, x[i], g, a1, a2, b1, b2);
+    z0 = __shfl(st.a, lastLane);
+    z1 = __shfl(st.b, lastLane);
+}
+
+// order o over src[0..n) -> dst (both LDS), by one wavefront; the filter's states move on
+__device__ __forceinline__ void NfcWaveScan(NfcState &st, uint32_t o, const float *src, float *dst, uint32_t n, uint32_t lane)
 {
     const float a0 = st.a[o][0], a1 = st.a[o][1], a2 = st.a[o][2], a3 = st.a[o][3], a4 = st.a[o][4];
     const float b1 = st.b[o][1], b2 = st.b[o][2], b3 = st.b[o][3], b4 = st.b[o][4];
     float z0 = st.z[o][0], z1 = st.z[o][1], z2 = st.z[o][2], z3 = st.z[o][3];
-    if(o == 1)
-    {
-        for(uint32_t i = 0; i < n; ++i)
-        {
-            const float y = src[i] * a0 - a1 * z0;
-            dst[i] = y + b1 * z0;
-            z0 += y;
-        }
-    }
+    const uint32_t seg = ((n + 63u) / 64u) | 1u;      // <= kBqSeg for n <= 1024
+    const uint32_t begin = lane * seg < n ? lane * seg : n;
+    const uint32_t cnt = (begin + seg < n) ? seg : n - begin;
+    const int lastLane = int((n - 1u) / seg);
+    float x[kBqSeg];
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) x[i] = (uint32_t(i) < cnt) ? src[begin + i] : 0.0f;
+    if(o == 1) Nfc1WaveScan(x, cnt, seg, a0, a1, b1, z0, lane, lastLane);
     else
     {
-        for(uint32_t i = 0; i < n; ++i)
-        {
-            const float y0 = src[i] * a0 - a1 * z0 - a2 * z1;
-            const float out0 = y0 + b1 * z0 + b2 * z1;
-            z1 += z0;
-            z0 += y0;
-            if(o == 2) { dst[i] = out0; continue; }
-            if(o == 3)
-            {
-                const float y1 = out0 - a3 * z2;
-                dst[i] = y1 + b3 * z2;
-                z2 += y1;
-                continue;
-            }
-            const float y1 = out0 - a3 * z2 - a4 * z3;
-            dst[i] = y1 + b3 * z2 + b4 * z3;
-            z3 += z2;
-            z2 += y1;
-        }
+        Nfc2WaveScan(x, cnt, seg, a0, a1, a2, b1, b2, z0, z1, lane, lastLane);
+        if(o == 3) Nfc1WaveScan(x, cnt, seg, 1.0f, a3, b3, z2, lane, lastLane);
+        else if(o >= 4) Nfc2WaveScan(x, cnt, seg, 1.0f, a3, a4, b3, b4, z2, z3, lane, lastLane);
     }
-    st.z[o][0] = z0; st.z[o][1] = z1; st.z[o][2] = z2; st.z[o][3] = z3;
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < cnt) dst[begin + i] = x[i];
+    if(lane == 0) { st.z[o][0] = z0; st.z[o][1] = z1; st.z[o][2] = z2; st.z[o][3] = z3; }
 }
 
 

@@ -52,10 +52,33 @@ def test_gpu_matches_oracle(kw):
 
 
 @pytest.mark.gpu
-def test_gpu_exact_mode_refuses_nfc():
+@pytest.mark.parametrize("kw", CASES, ids=IDS)
+def test_gpu_exact_mode_matches_oracle(kw):
+    """EXACT contexts (the workgroup-per-voice-group kernel): the NFC sections run on one lane in the reference's
+    operation order.  Several voices: their sums onto a line are added in a different order than the reference's
+    voice loop does, hence the multi-voice tolerance; ONE voice: bit for bit."""
     import oalgpu
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    which = "ref" if ol.available("ref") else "port"
+    L = ol.load(which)
+    L.L.oal_set_simd(1)
     api = oalgpu.Api(oalgpu.MATH_EXACT)
-    sc = api.make_scene(num_dry=4, num_real=0, hrtf=False)
+    a = nfc_cases.run(api, **kw)
+    b = nfc_cases.run(L, **kw)
+    err = np.abs(a.astype(np.float64) - b.astype(np.float64)).max()
+    assert err <= 2e-5 * np.abs(b).max() + 1e-7, err
+    one = dict(kw, nvoices=1)
+    a1, b1 = nfc_cases.run(api, **one), nfc_cases.run(L, **one)
+    assert np.abs(b1).max() > 1e-3
+    assert np.array_equal(a1.view(np.uint32), b1.view(np.uint32)), float(np.abs(a1 - b1).max())
+
+
+@pytest.mark.gpu
+def test_gpu_hrtf_context_refuses_nfc(synth_mhr):
+    import oalgpu
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    api.hrtf_load(synth_mhr)
+    sc = api.make_scene(num_dry=4, num_real=2, hrtf=True)
     with pytest.raises(RuntimeError):
         sc.set_nfc(0.005, [1, 3])
     sc.close()
