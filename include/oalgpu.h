@@ -407,19 +407,38 @@ const char *oalgpu_voice_kernel_name(oalgpu_context *ctx);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution reverb: ConvolutionState (alc/effects/convolution.cpp:253-716) behind
- * EffectState::deviceUpdate / update / process (core/effects/base.h:197-209), for a mono float
- * impulse response at the device rate.  The first 128 taps run as a time-domain FIR, the rest
- * as 128-tap segments in the frequency domain (LDS FFT in place of common/pffft.cpp).
+ * EffectState::deviceUpdate / update / process (core/effects/base.h:197-209), for float impulse
+ * responses of 1 .. 8 channels (mono, stereo .. 7.1, first-order B-Format: one ChannelData each,
+ * all fed from the slot's input channel) at any sample rate.  The first 128 taps run as a time-domain
+ * FIR, the rest as 128-tap segments in the frequency domain (LDS FFT in place of common/pffft.cpp).
  * ---------------------------------------------------------------------------------------- */
 typedef struct oalgpu_convolution oalgpu_convolution;
 /* deviceUpdate(device, buffer), convolution.cpp:318-471: num_out_lines = lines of the target
  * bus (EffectTarget::Main, <= 32). */
 int  oalgpu_convolution_create(int device, uint32_t num_out_lines, const float *ir, uint32_t ir_len,
     oalgpu_convolution **out);
+/* The general form: `ir` holds ir_frames interleaved frames of `channels` samples at ir_rate; when
+ * ir_rate differs from device_rate every channel is resampled once with the reference's polyphase
+ * Kaiser-sinc resampler (PPhaseResampler, common/polyphase_resampler.cpp; convolution.cpp:351-362,
+ * :412-422).  ir_rate = device_rate = 0: already at the device's rate. */
+int  oalgpu_convolution_create_ex(int device, uint32_t num_out_lines, const float *ir, uint32_t ir_frames,
+    uint32_t channels, uint32_t ir_rate, uint32_t device_rate, oalgpu_convolution **out);
 void oalgpu_convolution_destroy(oalgpu_convolution *conv);
+/* PPhaseResampler::init(src_rate, dst_rate) + process(in, out) on host memory (pure host code) */
+int  oalgpu_polyphase_resample(uint32_t src_rate, uint32_t dst_rate, const double *in, size_t n_in, double *out,
+    size_t n_out);
 /* The result of update(), convolution.cpp:474-621: mChans[0].Target (ComputePanGains of the
  * response's direction times the slot gain, computed by the caller). */
 int  oalgpu_convolution_set_target_gains(oalgpu_convolution *conv, const float *gains);
+/* ... for every channel of the response: gains[channel][num_out_lines] = mChans[c].Target (a stereo
+ * response's two panned positions, a B-Format one's rotated and scaled rows, convolution.cpp:485-621) */
+int  oalgpu_convolution_set_channel_gains(oalgpu_convolution *conv, const float *gains);
+/* mMix = UpsampleMix (convolution.cpp:306-316, chosen by update() :489-513 when the device's ambisonic
+ * order is above the response's): every channel goes through its BandSplitter::processScale(hf_scales[c],
+ * lf_scales[c]) in front of the mix.  xover_norm = device->mXOverFreq / sample rate (:364).  NULL scales:
+ * back to NormalMix. */
+int  oalgpu_convolution_set_upsample(oalgpu_convolution *conv, const float *hf_scales, const float *lf_scales,
+    float xover_norm);
 /* process(samplesToDo, samplesIn, samplesOut), convolution.cpp:623-716, host buffers: wet_in =
  * channel 0 of the slot's wet bus (n samples), out_lines = num_out_lines x 1024, added to. */
 int  oalgpu_convolution_process(oalgpu_convolution *conv, const float *wet_in, float *out_lines, uint32_t n);

@@ -1,5 +1,6 @@
-// Convolution reverb: ConvolutionState::process, alc/effects/convolution.cpp:623-716, for a mono
-// impulse response (mChans.size() == 1), replacing the pffft calls (common/pffft.cpp:1476-1552
+// Convolution reverb: ConvolutionState::process, alc/effects/convolution.cpp:623-716, for impulse responses
+// of 1 .. 8 channels (mono, stereo .. 7.1, first-order B-Format: one ChannelData each, all fed from the slot's
+// one input channel), replacing the pffft calls (common/pffft.cpp:1476-1552
 // transform, :2115-2166 zconvolve_accumulate) with a wavefront FFT in LDS.
 //
 // The reference walks the update in 128-sample blocks: a 128-tap time-domain FIR over the newest
@@ -107,19 +108,25 @@ struct ConvLayout {
     uint32_t numSegs, ringSlots, nlines, n; // frequency-domain segments, ring slots (numSegs + 8), target lines, samples
     uint32_t fifoPos, curSeg, numBlocks;  // mFifoPos / mCurrentSegment at entry; blocks completed by this update
     uint32_t numChunks, segsPerChunk;
+    uint32_t channels;                    // mChans.size(); blockIdx.y
+    uint32_t upsample;                    // mMix == UpsampleMix: band-split + HF/LF scale per channel before the mix
     const float *wetIn;                   // channel 0 of the slot's wet bus (n samples)
     float *xhist;                         // the 256 input samples before this update
     f2 *ring;                             // [numSegs][128] input spectra (mComplexData head)
-    const f2 *filt;                       // [numSegs][128] filter spectra (mComplexData tail), pre-scaled
-    const float *fir;                     // taps 0..127 of the response
-    float *outFifo;                       // mOutput[0]: [0,128) pending, [128,256) saved second half
-    f2 *partial;                          // [numChunks][kMaxBlocks][128] chunk sums
-    float *cur;                           // Current gains [nlines]
-    const float *tgt;                     // Target gains [nlines]
+    const f2 *filt;                       // [channel][numSegs][128] filter spectra (mComplexData tail), pre-scaled
+    const float *fir;                     // [channel][128] taps 0..127 of the response
+    float *outFifo;                       // [channel][256] mOutput[c]: [0,128) pending, [128,256) saved second half
+    f2 *partial;                          // [channel][numChunks][kMaxBlocks][128] chunk sums
+    float *cur;                           // [channel][nlines] Current gains
+    const float *tgt;                     // [channel][nlines] Target gains
     float *outLines;                      // nlines x 1024, accumulated into
     const f2 *tw128, *tw256;
-    uint32_t *ticket;                     // workgroups that have delivered their chunk (0 between launches)
-    float *firOut;                        // [1024] apply_fir of the update, computed in slices by all workgroups
+    uint32_t *ticket;                     // [channel] workgroups that have delivered their chunk, [8]: channels whose
+                                          // output is ready (all 0 between launches)
+    float *firOut;                        // [channel][1024] apply_fir of the update, computed in slices by all workgroups
+    float *chanOut;                       // [channel][1024] mChans[c].mBuffer of the update (channels > 1)
+    SplitterState *split;                 // [channel] mChans[c].mFilter
+    const float *hfScale, *lfScale;       // [channel] mHfScale / mLfScale
 };
 
 // timeline sample i: i < 256 -> history, else this update's input
@@ -151,9 +158,15 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
     const uint32_t t = threadIdx.x, lane = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t K = C.numBlocks, n = C.n, p0 = C.fifoPos, R = C.ringSlots;
+    const uint32_t ch = blockIdx.y;            // the impulse response's channel this workgroup convolves with
+    const f2 *filt = C.filt + size_t{ch} * C.numSegs * 128;
+    const float *fir = C.fir + size_t{ch} * kSeg;
+    float *outFifo = C.outFifo + size_t{ch} * 256;
+    f2 *partial = C.partial + size_t{ch} * C.numChunks * kMaxBlocks * 128;
+    float *firOut = C.firOut + size_t{ch} * kLine;
 
     for(uint32_t i = t; i < 256u + n; i += kConvThreads) tl[i] = Timeline(C, i);
-    if(t < uint32_t(kSeg)) { firLds[t] = C.fir[t]; tw256[t] = C.tw256[t]; }
+    if(t < uint32_t(kSeg)) { firLds[t] = fir[t]; tw256[t] = C.tw256[t]; }
     if(t < 64u) tw128[t] = C.tw128[t];
     __syncthreads();
     if(K)
@@ -168,7 +181,7 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
             WaveSync();
             RealFft256Forward(zbuf[wave], spec[wave], tw128, tw256, lane);
             WaveSync();
-            if(blockIdx.x == 0)
+            if(blockIdx.x == 0 && ch == 0)
             {   // curseg counts down; the ring has 8 slots more than there are segments, so the spectra this
                 // update files never replace one that a block of the same update still reads
                 const uint32_t seg = (C.curSeg + R - wave) % R;
@@ -210,7 +223,7 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
             f2 x1 = X(tb + 1u < K ? tb + 1u : tb, i0);
             uint32_t i = i0;
             // the segments that still meet this update's own blocks (first chunk only)
-            for(; i < i1 && i <= tb + 1u; ++i) { const f2 x0 = X(tb, i); mac(x0, x1, C.filt[size_t{i} * 128 + f]); x1 = x0; }
+            for(; i < i1 && i <= tb + 1u; ++i) { const f2 x0 = X(tb, i); mac(x0, x1, filt[size_t{i} * 128 + f]); x1 = x0; }
             // the rest straight from the ring: eight segments' loads in flight
             uint32_t slot = (C.curSeg + i + R - tb) % R;
             for(; i + 8u <= i1; i += 8u)
@@ -220,16 +233,16 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
                 for(uint32_t k = 0; k < 8u; ++k)
                 {
                     xs[k] = C.ring[size_t{slot} * 128 + f];
-                    hs[k] = C.filt[size_t{i + k} * 128 + f];
+                    hs[k] = filt[size_t{i + k} * 128 + f];
                     slot = (slot + 1u == R) ? 0u : slot + 1u;
                 }
 #pragma unroll
                 for(uint32_t k = 0; k < 8u; ++k) { mac(xs[k], x1, hs[k]); x1 = xs[k]; }
             }
-            for(; i < i1; ++i) { const f2 x0 = X(tb, i); mac(x0, x1, C.filt[size_t{i} * 128 + f]); x1 = x0; }
+            for(; i < i1; ++i) { const f2 x0 = X(tb, i); mac(x0, x1, filt[size_t{i} * 128 + f]); x1 = x0; }
         }
-        if(tb < K) StoreCoherent(&C.partial[(size_t{blockIdx.x} * kMaxBlocks + tb) * 128 + f], acc0);
-        if(tb + 1u < K) StoreCoherent(&C.partial[(size_t{blockIdx.x} * kMaxBlocks + tb + 1u) * 128 + f], acc1);
+        if(tb < K) StoreCoherent(&partial[(size_t{blockIdx.x} * kMaxBlocks + tb) * 128 + f], acc0);
+        if(tb + 1u < K) StoreCoherent(&partial[(size_t{blockIdx.x} * kMaxBlocks + tb + 1u) * 128 + f], acc1);
         // apply_fir (the first 128 taps over the newest input) of this workgroup's slice of the update
         {
             const uint32_t per = (n + gridDim.x - 1u) / gridDim.x;
@@ -244,15 +257,15 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
                     acc0 = __builtin_fmaf(firLds[k], x[-k], acc0);
                     acc1 = __builtin_fmaf(firLds[k + 1], x[-k - 1], acc1);
                 }
-                StoreCoherent(&C.firOut[i], acc0 + acc1);
+                StoreCoherent(&firOut[i], acc0 + acc1);
             }
         }
         // ---- the last workgroup to deliver does the rest (the barrier waits for every thread's stores)
         __syncthreads();
-        if(t == 0) isLast = (__hip_atomic_fetch_add(C.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
+        if(t == 0) isLast = (__hip_atomic_fetch_add(C.ticket + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
         __syncthreads();
         if(!isLast) return;
-        if(t == 0) *C.ticket = 0u;
+        if(t == 0) C.ticket[ch] = 0u;
         // the chunk partials in chunk order: thread = one bin of two blocks, 32 chunks' loads in flight
         for(uint32_t w = tb; w < tb + 2u && w < K; ++w)
         {
@@ -262,13 +275,13 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
             {
                 f2 p[32];
 #pragma unroll
-                for(uint32_t k = 0; k < 32u; ++k) p[k] = LoadCoherent(&C.partial[(size_t{c + k} * kMaxBlocks + w) * 128 + f]);
+                for(uint32_t k = 0; k < 32u; ++k) p[k] = LoadCoherent(&partial[(size_t{c + k} * kMaxBlocks + w) * 128 + f]);
 #pragma unroll
                 for(uint32_t k = 0; k < 32u; ++k) { s.x += p[k].x; s.y += p[k].y; }
             }
             for(; c < C.numChunks; ++c)
             {
-                const f2 p = LoadCoherent(&C.partial[(size_t{c} * kMaxBlocks + w) * 128 + f]);
+                const f2 p = LoadCoherent(&partial[(size_t{c} * kMaxBlocks + w) * 128 + f]);
                 s.x += p.x; s.y += p.y;
             }
             spec[w][f] = s;
@@ -283,15 +296,15 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
     {
         const uint32_t a = p0 + i, b = a >> 7, q = a & 127u;
         float v;
-        if(b == 0) v = C.outFifo[q];                                   // pending output of earlier updates
+        if(b == 0) v = outFifo[q];                                     // pending output of earlier updates
         else
         {
             const float *cur = reinterpret_cast<const float*>(zbuf[b - 1]);
-            const float prevHalf = (b >= 2) ? reinterpret_cast<const float*>(zbuf[b - 2])[128 + q] : C.outFifo[128 + q];
+            const float prevHalf = (b >= 2) ? reinterpret_cast<const float*>(zbuf[b - 2])[128 + q] : outFifo[128 + q];
             v = cur[q] + prevHalf;
         }
         float fir;
-        if(K) fir = LoadCoherent(&C.firOut[i]);
+        if(K) fir = LoadCoherent(&firOut[i]);
         else
         {   // no block completes in this update (a single workgroup): apply_fir here
             float acc0 = 0.0f, acc1 = 0.0f;
@@ -313,22 +326,41 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
     {
         const float *last = reinterpret_cast<const float*>(zbuf[K - 1]);
         if(t < 128u)
-            nv = last[t] + ((K >= 2) ? reinterpret_cast<const float*>(zbuf[K - 2])[128 + t] : C.outFifo[128 + t]);
+            nv = last[t] + ((K >= 2) ? reinterpret_cast<const float*>(zbuf[K - 2])[128 + t] : outFifo[128 + t]);
         else nv = last[t];
     }
     __syncthreads();                           // every read of the old fifo is done
-    if(K > 0 && t < 256u) C.outFifo[t] = nv;
+    if(K > 0 && t < 256u) outFifo[t] = nv;
+    if(C.upsample)
+    {   // UpsampleMix (:306-316): mChans[c].mFilter.processScale(src, mHfScale, mLfScale) in front of the mix
+        if(wave == 0)
+        {
+            SplitterState sp = C.split[ch];
+            SplitterScan<false>(sp, chan, n, C.hfScale[ch], C.lfScale[ch], lane);
+            if(lane == 0) C.split[ch] = sp;
+        }
+        __syncthreads();
+    }
+    const uint32_t nch = C.channels;
+    if(nch > 1u)
+    {   // the channels are mixed in channel order by ONE workgroup: the last one whose channel is ready
+        for(uint32_t i = t; i < n; i += kConvThreads) StoreCoherent(&C.chanOut[size_t{ch} * kLine + i], chan[i]);
+        __syncthreads();
+        if(t == 0) isLast = (__hip_atomic_fetch_add(C.ticket + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nch - 1u) ? 1u : 0u;
+        __syncthreads();
+        if(!isLast) return;
+        if(t == 0) C.ticket[8] = 0u;
+    }
     if(t < 256u) C.xhist[t] = tl[n + t];
-    // MixSamples(chan, out, Current, Target, Counter = n, OutPos = 0): four lines at a time, their gains and
-    // their output samples requested together
+    // MixSamples(chan_c, out, Current_c, Target_c, Counter = n, OutPos = 0) for c = 0, 1, ..: a line's sum takes the
+    // channels in that order; four lines at a time, their gains and their output samples requested together
     for(uint32_t c0 = 0; c0 < C.nlines; c0 += 4u)
     {
-        float cu[4], tg[4], o[4][2];
+        float o[4][2];
 #pragma unroll
         for(uint32_t k = 0; k < 4u; ++k)
         {
             const uint32_t c = (c0 + k < C.nlines) ? c0 + k : C.nlines - 1u;
-            cu[k] = C.cur[c]; tg[k] = C.tgt[c];
 #pragma unroll
             for(uint32_t j = 0; j < 2u; ++j)
             {
@@ -336,21 +368,48 @@ __global__ void __launch_bounds__(kConvThreads) ConvFusedKernel(ConvLayout C)
                 o[k][j] = (i < n) ? C.outLines[size_t{c} * kLine + i] : 0.0f;
             }
         }
-#pragma unroll
-        for(uint32_t k = 0; k < 4u; ++k)
+        for(uint32_t cc = 0; cc < nch; ++cc)
         {
-            if(c0 + k >= C.nlines) break;
-            const MixLineGain g = PrepareMixLine(cu[k], tg[k], n, n);
+            float cu[4], tg[4], x[2];
+#pragma unroll
+            for(uint32_t k = 0; k < 4u; ++k)
+            {
+                const uint32_t c = (c0 + k < C.nlines) ? c0 + k : C.nlines - 1u;
+                cu[k] = C.cur[size_t{cc} * C.nlines + c]; tg[k] = C.tgt[size_t{cc} * C.nlines + c];
+            }
 #pragma unroll
             for(uint32_t j = 0; j < 2u; ++j)
             {
                 const uint32_t i = t + kConvThreads * j;
-                if(i < n && MixLineActive(g, i)) C.outLines[size_t{c0 + k} * kLine + i] = o[k][j] + MixLineValue(g, chan[i], i);
+                x[j] = (i >= n) ? 0.0f : (nch > 1u ? LoadCoherent(&C.chanOut[size_t{cc} * kLine + i]) : chan[i]);
+            }
+#pragma unroll
+            for(uint32_t k = 0; k < 4u; ++k)
+            {
+                if(c0 + k >= C.nlines) break;
+                const MixLineGain g = PrepareMixLine(cu[k], tg[k], n, n);
+#pragma unroll
+                for(uint32_t j = 0; j < 2u; ++j)
+                {
+                    const uint32_t i = t + kConvThreads * j;
+                    if(i < n && MixLineActive(g, i)) o[k][j] = o[k][j] + MixLineValue(g, x[j], i);
+                }
+            }
+        }
+#pragma unroll
+        for(uint32_t k = 0; k < 4u; ++k)
+        {
+            if(c0 + k >= C.nlines) break;
+#pragma unroll
+            for(uint32_t j = 0; j < 2u; ++j)
+            {
+                const uint32_t i = t + kConvThreads * j;
+                if(i < n) C.outLines[size_t{c0 + k} * kLine + i] = o[k][j];
             }
         }
     }
     __syncthreads();                           // every thread has read the Current gains
-    if(t < C.nlines) C.cur[t] = PrepareMixLine(C.cur[t], C.tgt[t], n, n).newCur;
+    for(uint32_t k = t; k < nch * C.nlines; k += kConvThreads) C.cur[k] = PrepareMixLine(C.cur[k], C.tgt[k], n, n).newCur;
 }
 
 } // namespace
@@ -367,8 +426,10 @@ void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h)
     C.cur = h.cur; C.tgt = h.tgt; C.outLines = h.outLines;
     C.tw128 = reinterpret_cast<const f2*>(h.tw128); C.tw256 = reinterpret_cast<const f2*>(h.tw256);
     C.ticket = h.ticket; C.firOut = h.firOut;
-    // no block completes in this update: only the output stage (one workgroup)
-    hipLaunchKernelGGL(ConvFusedKernel, dim3(h.numBlocks ? h.numChunks : 1u), dim3(kConvThreads), 0, s, C);
+    C.channels = h.channels; C.upsample = h.upsample; C.chanOut = h.chanOut;
+    C.split = h.split; C.hfScale = h.hfScale; C.lfScale = h.lfScale;
+    // no block completes in this update: only the output stage (one workgroup per channel)
+    hipLaunchKernelGGL(ConvFusedKernel, dim3(h.numBlocks ? h.numChunks : 1u, h.channels), dim3(kConvThreads), 0, s, C);
 }
 
 } // namespace oalgpu

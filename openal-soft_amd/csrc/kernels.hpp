@@ -185,6 +185,10 @@ struct ConvLayoutHost {
     const float *tw128, *tw256;
     uint32_t *ticket;
     float *firOut;
+    uint32_t channels, upsample;
+    float *chanOut;
+    SplitterState *split;
+    const float *hfScale, *lfScale;
 };
 void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
 

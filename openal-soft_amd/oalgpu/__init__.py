@@ -560,10 +560,14 @@ def comm_unique_id():
 
 
 class Convolution:
-    """oalgpu_convolution: ConvolutionState (alc/effects/convolution.cpp) for a mono response."""
+    """oalgpu_convolution: ConvolutionState (alc/effects/convolution.cpp); ir = [frames] (mono) or
+    [frames, channels] at ir_rate (None: the device's rate)."""
 
-    def __init__(self, num_out_lines, ir, device=0):
-        lib.oalgpu_convolution_create.argtypes = [C.c_int, C.c_uint32, f32p, C.c_uint32, C.POINTER(C.c_void_p)]
+    def __init__(self, num_out_lines, ir, device=0, ir_rate=None, device_rate=48000):
+        lib.oalgpu_convolution_create_ex.argtypes = [C.c_int, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                     C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.oalgpu_convolution_set_channel_gains.argtypes = [C.c_void_p, f32p]
+        lib.oalgpu_convolution_set_upsample.argtypes = [C.c_void_p, f32p, f32p, C.c_float]
         lib.oalgpu_convolution_destroy.argtypes = [C.c_void_p]
         lib.oalgpu_convolution_destroy.restype = None
         lib.oalgpu_convolution_set_target_gains.argtypes = [C.c_void_p, f32p]
@@ -571,10 +575,24 @@ class Convolution:
         lib.oalgpu_slot_set_convolution.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         self.nlines = num_out_lines
         ir = np.ascontiguousarray(ir, np.float32)
+        self.channels = 1 if ir.ndim == 1 else ir.shape[1]
         h = C.c_void_p()
-        check(lib.oalgpu_convolution_create(device, num_out_lines, _fp(ir), ir.size, C.byref(h)),
-              "oalgpu_convolution_create")
+        check(lib.oalgpu_convolution_create_ex(device, num_out_lines, _fp(ir), ir.shape[0], self.channels,
+                                               0 if ir_rate is None else ir_rate, 0 if ir_rate is None else device_rate,
+                                               C.byref(h)), "oalgpu_convolution_create_ex")
         self.h = h
+
+    def set_channel_gains(self, gains):
+        g = np.ascontiguousarray(gains, np.float32).reshape(self.channels, -1)[:, :self.nlines]
+        check(lib.oalgpu_convolution_set_channel_gains(self.h, _fp(np.ascontiguousarray(g))), "oalgpu_convolution_set_channel_gains")
+
+    def set_upsample(self, hf_scales, lf_scales, xover_norm):
+        if hf_scales is None:
+            check(lib.oalgpu_convolution_set_upsample(self.h, None, None, 0.0))
+            return
+        hf = np.ascontiguousarray(hf_scales, np.float32)
+        lf = np.ascontiguousarray(lf_scales, np.float32)
+        check(lib.oalgpu_convolution_set_upsample(self.h, _fp(hf), _fp(lf), xover_norm), "oalgpu_convolution_set_upsample")
 
     def set_target_gains(self, gains):
         g = np.zeros(MAX_OUT, np.float32)

@@ -249,6 +249,18 @@ int oal_scene_set_direct_hrtf(oal_scene *s, const float *chan_coeffs, const floa
 typedef struct oal_conv oal_conv;
 oal_conv *oal_conv_create(uint32_t sample_rate, uint32_t num_out_lines, const float *ir,
     uint32_t ir_len, uint32_t ir_rate);
+/* Compiled reference only.  The general form: `ir` = ir_len interleaved frames of `channels` samples (1 mono,
+ * 2 stereo, 4 first-order B-Format, ACN / N3D) at ir_rate; the device has ambisonic order device_order and
+ * num_out_lines dry lines (identity AmbiMap).  update() pans stereo channels to -30 / +30 degrees and rotates /
+ * scales B-Format rows (convolution.cpp:485-621); with device_order > 1 a B-Format response goes through
+ * UpsampleMix (:306-316).  oal_conv_channel_info returns what update() left per channel: targets = channels
+ * x 25 (MaxAmbiChannels), hf / lf scales, whether UpsampleMix was chosen, the splitters' crossover. */
+oal_conv *oal_conv_create_ex(uint32_t sample_rate, uint32_t num_out_lines, uint32_t device_order, const float *ir,
+    uint32_t ir_len, uint32_t channels, uint32_t ir_rate);
+void oal_conv_set_orientation(oal_conv *c, const float at[3], const float up[3]);
+uint32_t oal_conv_channel_info(oal_conv *c, float *targets, float *hf, float *lf, int *upsample, float *xover_norm);
+/* PPhaseResampler::init + process (common/polyphase_resampler.cpp), compiled reference only */
+void oal_pphase_resample(uint32_t src_rate, uint32_t dst_rate, const double *in, size_t n_in, double *out, size_t n_out);
 void oal_conv_update(oal_conv *c, float slot_gain);
 void oal_conv_process(oal_conv *c, const float *wet_in, float *out_lines, uint32_t n);
 void oal_conv_destroy(oal_conv *c);

@@ -63,6 +63,7 @@
 #include "core/voice.h"
 #include "core/async_event.h"
 #include "ringbuffer.h"
+#include "polyphase_resampler.h"
 
 #include "oalref.h"
 
@@ -91,6 +92,11 @@ void ApplySimd()
     aluInit({}, 1.0f);
     Voice::InitMixer(std::nullopt);
 }
+
+} // namespace
+/* for ref_conv.cpp: the mixer function pointers follow oal_set_simd there too */
+void oalref_apply_simd() { ApplySimd(); }
+namespace {
 
 std::unique_ptr<HrtfStore> gHrtfOwner;
 HrtfStore *gHrtf = nullptr;
@@ -884,70 +890,17 @@ int oal_scene_set_direct_hrtf(oal_scene *s, const float *chan_coeffs, const floa
     return 0;
 }
 
-/* ---- convolution reverb ---- */
-} // extern "C" (reopened below)
+/* (the convolution reverb lives in ref_conv.cpp, which compiles alc/effects/convolution.cpp itself to
+ * reach its file-local ConvolutionState) */
 
-struct oal_conv {
-    std::unique_ptr<Dev> dev;
-    std::unique_ptr<Ctx> ctx;
-    EffectSlotBase slot;
-    al::intrusive_ptr<EffectState> state;
-    std::vector<float> ir;
-    BufferStorage storage;
-    EffectProps props;
-    std::array<FloatBufferLine, 1> wet{};
-};
-
-extern "C" {
-
-oal_conv *oal_conv_create(uint32_t sample_rate, uint32_t num_out_lines, const float *ir,
-    uint32_t ir_len, uint32_t ir_rate)
+/* PPhaseResampler (common/polyphase_resampler.cpp): init(src_rate, dst_rate) + process(in, out) */
+void oal_pphase_resample(uint32_t src_rate, uint32_t dst_rate, const double *in, size_t n_in, double *out,
+    size_t n_out)
 {
-    ApplySimd();
-    auto c = std::make_unique<oal_conv>();
-    c->dev = std::make_unique<Dev>();
-    auto &dev = *c->dev;
-    dev.mSampleRate = sample_rate;
-    dev.mUpdateSize = BufferLineSize;
-    dev.mBufferSize = BufferLineSize;
-    dev.FmtType = DevFmtFloat;
-    dev.mAmbiOrder = 1;
-    dev.MixBuffer.resize(num_out_lines);
-    dev.Dry.Buffer = std::span{dev.MixBuffer};
-    dev.RealOut.Buffer = dev.Dry.Buffer;
-    for(uint32_t i{0};i < num_out_lines;++i) dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, i};
-    c->ctx = std::make_unique<Ctx>(c->dev.get());
-    c->ir.assign(ir, ir + ir_len);
-    c->storage.mData = std::span<f32>{reinterpret_cast<f32*>(c->ir.data()), c->ir.size()};
-    c->storage.mSampleRate = ir_rate;
-    c->storage.mChannels = FmtMono;
-    c->storage.mType = FmtFloat;
-    c->storage.mSampleLen = ir_len;
-    c->state = ConvolutionStateFactory_getFactory()->create();
-    c->state->deviceUpdate(c->dev.get(), &c->storage);
-    c->props = ConvolutionProps{{0.0f, 0.0f, -1.0f}, {0.0f, 1.0f, 0.0f}};
-    return c.release();
+    auto rs = PPhaseResampler{};
+    rs.init(src_rate, dst_rate);
+    rs.process(std::span{in, n_in}, std::span{out, n_out});
 }
-
-void oal_conv_update(oal_conv *c, float slot_gain)
-{
-    c->slot.Gain = slot_gain;
-    c->state->update(c->ctx.get(), &c->slot, &c->props, EffectTarget{&c->dev->Dry, &c->dev->RealOut});
-}
-
-void oal_conv_process(oal_conv *c, const float *wet_in, float *out_lines, uint32_t n)
-{
-    auto const fpuctl = FPUCtl{};
-    auto &dev = *c->dev;
-    std::copy_n(wet_in, n, c->wet[0].begin());
-    for(size_t l{0};l < dev.MixBuffer.size();++l)
-        std::copy_n(out_lines + l*BufferLineSize, BufferLineSize, dev.MixBuffer[l].begin());
-    c->state->process(n, c->wet, c->state->mOutTarget);
-    for(size_t l{0};l < dev.MixBuffer.size();++l)
-        std::copy_n(dev.MixBuffer[l].begin(), BufferLineSize, out_lines + l*BufferLineSize);
-}
-
-void oal_conv_destroy(oal_conv *c) { delete c; }
 
 /* ---- BFormatDec (core/bformatdec.cpp:27-95), the AmbiDecPostProcess of non-HRTF devices ---- */
 struct oal_bformatdec { std::unique_ptr<BFormatDec> dec; size_t inchans, nout; };

@@ -218,8 +218,18 @@ class OracleLib:
         return Scene(self, **kw)
 
     # ---- convolution reverb (ConvolutionState, alc/effects/convolution.cpp) ----
-    def make_convolution(self, num_out_lines, ir, sample_rate=48000, ir_rate=None):
-        return Convolution(self, num_out_lines, ir, sample_rate, ir_rate or sample_rate)
+    def pphase_resample(self, src_rate, dst_rate, x, n_out):
+        """PPhaseResampler::init + process (compiled reference only)"""
+        f = self.L.oal_pphase_resample
+        f.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        f.restype = None
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.zeros(n_out, np.float64)
+        f(src_rate, dst_rate, x.ctypes.data_as(C.c_void_p), x.size, out.ctypes.data_as(C.c_void_p), n_out)
+        return out
+
+    def make_convolution(self, num_out_lines, ir, sample_rate=48000, ir_rate=None, device_order=1):
+        return Convolution(self, num_out_lines, ir, sample_rate, ir_rate or sample_rate, device_order)
 
     def make_reverb(self, num_out_lines, sample_rate=48000):
         return Reverb(self, num_out_lines, sample_rate)
@@ -561,12 +571,34 @@ class Reverb:
 class Convolution:
     """EffectState-shaped handle: update(slot_gain) then process(wet_in, out_lines)."""
 
-    def __init__(self, lib, num_out_lines, ir, sample_rate, ir_rate):
+    def __init__(self, lib, num_out_lines, ir, sample_rate, ir_rate, device_order=1):
         self.lib = lib
         self.nlines = num_out_lines
         ir = np.ascontiguousarray(ir, np.float32)
-        self.h = lib.L.oal_conv_create(sample_rate, num_out_lines, _fp(ir), ir.size, ir_rate)
+        self.channels = 1 if ir.ndim == 1 else ir.shape[1]
+        if self.channels == 1 and device_order == 1:
+            self.h = lib.L.oal_conv_create(sample_rate, num_out_lines, _fp(ir), ir.size, ir_rate)
+        else:       # compiled reference only: [frames, channels] responses, higher-order devices
+            f = lib.L.oal_conv_create_ex
+            f.restype = C.c_void_p
+            f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_uint32]
+            self.h = f(sample_rate, num_out_lines, device_order, _fp(ir), ir.shape[0], self.channels, ir_rate)
         assert self.h, "oal_conv_create failed"
+
+    def set_orientation(self, at, up):
+        f = self.lib.L.oal_conv_set_orientation
+        f.argtypes = [C.c_void_p, f32p, f32p]
+        f(self.h, _fp(np.asarray(at, np.float32)), _fp(np.asarray(up, np.float32)))
+
+    def channel_info(self):
+        """what update() computed: (targets [channels, 25 = MaxAmbiChannels], hf, lf, upsample, xover_norm)"""
+        f = self.lib.L.oal_conv_channel_info
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_void_p, f32p, f32p, f32p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        tg, hf, lf = np.zeros((8, 25), np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32)
+        up, xo = C.c_int(0), C.c_float(0.0)
+        n = f(self.h, _fp(tg), _fp(hf), _fp(lf), C.byref(up), C.byref(xo))
+        return tg[:n].copy(), hf[:n].copy(), lf[:n].copy(), bool(up.value), xo.value
 
     def update(self, slot_gain):
         self.lib.L.oal_conv_update(self.h, slot_gain)
