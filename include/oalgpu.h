@@ -508,6 +508,15 @@ typedef struct oalgpu_reverb oalgpu_reverb;
  * half can be exercised without a GPU. */
 int  oalgpu_reverb_create(int device, uint32_t sample_rate, uint32_t num_out_lines, oalgpu_reverb **out);
 void oalgpu_reverb_destroy(oalgpu_reverb *rev);
+/* deviceUpdate on a device above first order (reverb.cpp:835-851): mUpmixOutput -- process() then ends in
+ * MixOutAmbiUp (:658-699: A-to-B-Format rows, BandSplitter::processHfScale per row, gains that pan and
+ * upsample) and update3DPanning combines its transforms with the first-order upsample matrix (:1166-1184).
+ * The ambisonic layer's constants come from the caller: order_scales[0..1] = AmbiScale::GetHFOrderScales(1,
+ * device order, 2D mixing), first_order_up = AmbiScale::FirstOrderUp (4 x 25, core/ambidefs.cpp),
+ * xover_norm = device->mXOverFreq / frequency.  NULL order_scales: MixOutPlain again.  Takes effect with
+ * the next oalgpu_reverb_update. */
+int  oalgpu_reverb_set_upmix(oalgpu_reverb *rev, const float order_scales[2], const float *first_order_up,
+    float xover_norm);
 /* The stream update() and process() enqueue on (NULL = the default stream).  A reverb attached
  * to a context slot uses the context's effect stream. */
 int  oalgpu_reverb_set_stream(oalgpu_reverb *rev, void *hip_stream);

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <memory>
 
+#include "../host/params.hpp"
 #include "../host/reverb_params.hpp"
 #include "../host/tables.hpp"
 
@@ -96,6 +97,28 @@ int oalgpu_reverb_create(int device, uint32_t sample_rate, uint32_t num_out_line
         L.stamps = r->stamps.p;
     }
     *out = r.release();
+    return OALGPU_OK;
+}
+
+/* deviceUpdate on a device above first order (reverb.cpp:835-851): mUpmixOutput, mOrderScales, the pipelines'
+ * band splitters.  The constants of the ambisonic layer come from the caller: order_scales[0..1] =
+ * AmbiScale::GetHFOrderScales(1, device order, 2D mixing), first_order_up = AmbiScale::FirstOrderUp (4 x 25,
+ * core/ambidefs.cpp), xover_norm = device->mXOverFreq / frequency.  NULL order_scales: back to MixOutPlain.
+ * Takes effect with the next oalgpu_reverb_update (which designs the panning gains). */
+int oalgpu_reverb_set_upmix(oalgpu_reverb *r, const float order_scales[2], const float *first_order_up, float xover_norm)
+{
+    if(!r) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(!order_scales || !first_order_up)
+    {
+        r->host.upmix = false; r->L.upmix = 0u;
+        return OALGPU_OK;
+    }
+    if(!(xover_norm > 0.0f && xover_norm < 0.5f)) return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_set_upmix: 0 < xover_norm < 0.5");
+    r->host.upmix = true;
+    std::memcpy(r->host.firstOrderUp, first_order_up, sizeof(r->host.firstOrderUp));
+    r->L.upmix = 1u;
+    r->L.orderScale[0] = order_scales[0]; r->L.orderScale[1] = order_scales[1];
+    r->L.splitCoeff = SplitterCoeff(xover_norm);
     return OALGPU_OK;
 }
 

@@ -19,6 +19,7 @@ struct RvPipeState {
     float earlyCur[4][OALGPU_MAX_AMBI_CHANNELS];
     float lateCur[4][OALGPU_MAX_AMBI_CHANNELS];
     float z[4][8];                 // per line: mFilter Lp z1,z2 / Hp z1,z2, T60 HF z1,z2 / LF z1,z2
+    float split[2][4][4];          // mAmbiSplitter[early | late][row]: lpZ1, lpZ2, apZ1 (MixOutAmbiUp)
 };
 
 struct RvLines {                   // per pipeline; strides = samples per line (powers of two)
@@ -41,6 +42,9 @@ struct RvLayout {
     uint32_t modIndex[2];          // mLate.Mod.Index at the start of this block
     int current;                   // mCurrentPipeline
     int oldMode;                   // ReverbHost::Step::oldMode
+    uint32_t upmix;                // mUpmixOutput: MixOutAmbiUp instead of MixOutPlain
+    float orderScale[2];           // mOrderScales[0], [1]
+    float splitCoeff;              // BandSplitter{device->mXOverFreq / frequency}.mCoeff
     unsigned long long *stamps;    // profiling aid (env OALGPU_PHASE_TIMES): [4 roles][8 sub-blocks][8]
 };
 

@@ -481,6 +481,69 @@ __device__ __forceinline__ void ReverbProcessBody(const RvLayout &L, RvLds &sm, 
     }
     __syncthreads();
     if(L.stamps && t == 0) L.stamps[7 * 8 + 2] = __builtin_readcyclecounter();
+    // MixOutAmbiUp, :658-699 (devices above first order): the A-Format lines become B-Format rows here
+    // (DoMixRow :619-634, with EarlyA2B / LateA2B), every row goes through its band splitter's
+    // processHfScale (the in-place form, core/filters/splitter.cpp:98-131: one lane per row, the reference's operation order) and
+    // the panning gains then pan AND upsample the rows.  The rows live in the pipelines' LDS, free by now.
+    float *rowsLds[2] = {reinterpret_cast<float*>(&sm.pipe[0]), reinterpret_cast<float*>(&sm.pipe[1])};
+    static_assert(sizeof(PipeLds) >= 8u * kLine * sizeof(float), "MixOutAmbiUp keeps its eight rows in a pipeline's LDS");
+    if(L.upmix)
+    {
+        constexpr float kInvSqrt2 = 0.70710678118654752440f;
+        constexpr float A2B[2][4][4] = {
+            {{0.5f, 0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f, -0.5f}, {0.5f, -0.5f, -0.5f, 0.5f}, {0.5f, 0.5f, -0.5f, -0.5f}},
+            {{0.5f, 0.5f, 0.5f, 0.5f}, {kInvSqrt2, -kInvSqrt2, 0.0f, 0.0f}, {0.0f, 0.0f, -kInvSqrt2, kInvSqrt2},
+             {0.5f, 0.5f, -0.5f, -0.5f}}};
+        const uint32_t npipes = oldRuns ? 2u : 1u;
+        for(uint32_t q = 0; q < npipes; ++q)
+        {
+            const int p = q ? old : cur;
+            const float *src[2] = {L.earlyOut + size_t(p) * 4u * kLine, L.lateOut + size_t(p) * 4u * kLine};
+            for(uint32_t i = t; i < n; i += 256)
+#pragma unroll
+                for(int e = 0; e < 2; ++e)
+                {
+                    float in[4];
+#pragma unroll
+                    for(int k = 0; k < 4; ++k) in[k] = src[e][k * kLine + i];
+#pragma unroll
+                    for(int r = 0; r < 4; ++r)
+                    {
+                        float tmp = 0.0f;
+#pragma unroll
+                        for(int k = 0; k < 4; ++k)
+                            if(fabsf(A2B[e][r][k]) > 0.00001f) tmp = tmp + in[k] * A2B[e][r][k];
+                        rowsLds[q][(e * 4 + r) * kLine + i] = tmp;
+                    }
+                }
+        }
+        __syncthreads();
+        if(t < 8u * npipes)
+        {
+            const uint32_t q = t >> 3, e = (t >> 2) & 1u, r = t & 3u;
+            const int p = q ? old : cur;
+            float *row = rowsLds[q] + (e * 4u + r) * kLine;
+            float *st = L.state[p].split[e][r];
+            const float hfscale = L.orderScale[r ? 1 : 0];
+            const float apCoeff = L.splitCoeff, lpCoeff = L.splitCoeff * 0.5f + 0.5f;
+            float lpZ1 = st[0], lpZ2 = st[1], apZ1 = st[2];
+            for(uint32_t i = 0; i < n; ++i)
+            {
+                const float in = row[i];
+                const float d0 = (in - lpZ1) * lpCoeff;
+                const float lpY0 = lpZ1 + d0;
+                lpZ1 = lpY0 + d0;
+                const float d1 = (lpY0 - lpZ2) * lpCoeff;
+                const float lpY1 = lpZ2 + d1;
+                lpZ2 = lpY1 + d1;
+                const float apY = in * apCoeff + apZ1;
+                apZ1 = in - apY * apCoeff;
+                row[i] = (apY - lpY1) * hfscale + lpY1;
+            }
+            st[0] = lpZ1; st[1] = lpZ2; st[2] = apZ1;
+        }
+        __syncthreads();
+    }
     if(ticket)
     {
         if(t == 0)
@@ -521,6 +584,12 @@ __device__ __forceinline__ void ReverbProcessBody(const RvLayout &L, RvLds &sm, 
                 for(uint32_t k = 0; k < 4; ++k)
                 {
                     const uint32_t i = t + 256u * k;
+                    if(L.upmix)
+                    {
+                        in[q][j][k] = rowsLds[q][j * kLine + (i < n ? i : 0u)];
+                        in[q][4 + j][k] = rowsLds[q][(4u + j) * kLine + (i < n ? i : 0u)];
+                        continue;
+                    }
                     in[q][j][k] = eo[j * kLine + (i < n ? i : 0u)];
                     in[q][4 + j][k] = lo[j * kLine + (i < n ? i : 0u)];
                 }

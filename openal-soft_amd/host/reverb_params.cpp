@@ -98,15 +98,24 @@ void TransformFromVector(const float vec[3], float m[4][4])
     std::memcpy(m, r, sizeof(r));
 }
 
-// update3DPanning without up-mixing (:1186-1203) + ComputePanGains over an identity map
+// update3DPanning (:1151-1220) + ComputePanGains over an identity map.  Without up-mixing the A-to-B-Format
+// conversion is combined with the panning transform (:1186-1203); with it (firstOrderUp != nullptr) the
+// transform is combined with the first-order upsample matrix (:1166-1184) -- MixOutAmbiUp does the A-to-B
+// conversion itself.
 void PanGains(const float a2b[4][4], const float matrix[4][4], float gain, uint32_t numLines,
-    float target[4][OALGPU_MAX_AMBI_CHANNELS])
+    const float (*firstOrderUp)[OALGPU_MAX_AMBI_CHANNELS], float target[4][OALGPU_MAX_AMBI_CHANNELS])
 {
     for(int i = 0; i < 4; ++i)
     {
         float coeffs[OALGPU_MAX_AMBI_CHANNELS] = {};
         for(int j = 0; j < 4; ++j)
         {
+            if(firstOrderUp)
+            {
+                const float a = matrix[i][j];
+                for(int k = 0; k < OALGPU_MAX_AMBI_CHANNELS; ++k) coeffs[k] = a * firstOrderUp[j][k] + coeffs[k];
+                continue;
+            }
             const float a = a2b[j][i];
             for(int k = 0; k < 4; ++k) coeffs[k] = a * matrix[j][k] + coeffs[k];
         }
@@ -219,8 +228,9 @@ bool ReverbHost::update(const oalgpu_reverb_props &props, float slotGain)
         float earlymat[4][4], latemat[4][4];
         TransformFromVector(props.reflections_pan, earlymat);
         TransformFromVector(props.late_reverb_pan, latemat);
-        PanGains(kEarlyA2B, earlymat, props.reflections_gain * gain, numLines, P.early_gains_target);
-        PanGains(kLateA2B, latemat, props.late_reverb_gain * gain, numLines, P.late_gains_target);
+        const float (*up)[OALGPU_MAX_AMBI_CHANNELS] = upmix ? firstOrderUp : nullptr;
+        PanGains(kEarlyA2B, earlymat, props.reflections_gain * gain, numLines, up, P.early_gains_target);
+        PanGains(kLateA2B, latemat, props.late_reverb_gain * gain, numLines, up, P.late_gains_target);
     }
 
     // master filters, :1298-1309

@@ -14,6 +14,10 @@ size_t ReverbLineLengths(float frequency, uint32_t lengths[11]);
 
 struct ReverbHost {
     uint32_t sampleRate{48000}, numLines{4};
+    // mUpmixOutput (:835-843): the panning gains pan AND upsample first-order B-Format, through
+    // AmbiScale::FirstOrderUp (4 x MaxAmbiChannels, handed in by the caller)
+    bool upmix{false};
+    float firstOrderUp[4][OALGPU_MAX_AMBI_CHANNELS]{};
     // ReverbState::mParams, :573-587
     struct Last {
         float density{1.0f}, diffusion{1.0f}, decayTime{1.49f}, hfDecayTime{0.83f * 1.49f},

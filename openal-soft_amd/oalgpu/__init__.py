@@ -690,6 +690,16 @@ class Reverb:
         check(lib.oalgpu_reverb_create(device, sample_rate, num_out_lines, C.byref(h)), "oalgpu_reverb_create")
         self.h = h
 
+    def set_upmix(self, order_scales, first_order_up, xover_norm):
+        """a device above first order: MixOutAmbiUp (see oalgpu_reverb_set_upmix); None = MixOutPlain"""
+        lib.oalgpu_reverb_set_upmix.argtypes = [C.c_void_p, f32p, f32p, C.c_float]
+        if order_scales is None:
+            check(lib.oalgpu_reverb_set_upmix(self.h, None, None, 0.0))
+            return
+        sc = np.ascontiguousarray(order_scales, np.float32)
+        up = np.ascontiguousarray(first_order_up, np.float32).reshape(4, 25)
+        check(lib.oalgpu_reverb_set_upmix(self.h, _fp(sc), _fp(up), xover_norm), "oalgpu_reverb_set_upmix")
+
     def update(self, props, slot_gain=1.0):
         check(lib.oalgpu_reverb_update(self.h, C.byref(props), slot_gain), "oalgpu_reverb_update")
 

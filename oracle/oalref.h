@@ -337,6 +337,12 @@ typedef struct oal_reverb_props {             /* ReverbProps, core/effects/base.
 } oal_reverb_props;
 typedef struct oal_reverb oal_reverb;
 oal_reverb *oal_reverb_create(uint32_t sample_rate, uint32_t num_out_lines);
+/* compiled reference only: a device of ambisonic order device_order (> 1: ReverbState::mUpmixOutput,
+ * MixOutAmbiUp :658-699), and what such a device hands the effect: GetHFOrderScales(1, order, 2D)[0..1],
+ * AmbiScale::FirstOrderUp (4 x 25), mXOverFreq / sample_rate */
+oal_reverb *oal_reverb_create_ex(uint32_t sample_rate, uint32_t num_out_lines, uint32_t device_order);
+void oal_ambi_upmix_info(uint32_t device_order, int horizontal, uint32_t sample_rate, float *order_scales2,
+    float *first_order_up, float *xover_norm);
 void oal_reverb_destroy(oal_reverb *r);
 /* compiled reference only (the restatement returns -1): ReverbState::update, then the block */
 int oal_reverb_update(oal_reverb *r, const oal_reverb_props *props, float slot_gain);

@@ -42,7 +42,24 @@ struct oal_reverb {
 
 extern "C" {
 
+/* AmbiScale::GetHFOrderScales(1, device_order, horizontal)[0..1], AmbiScale::FirstOrderUp (4 x 25) and the
+ * default crossover (DeviceBase::mXOverFreq) relative to sample_rate: what a device of that order hands the
+ * effect in deviceUpdate (reverb.cpp:835-851) */
+void oal_ambi_upmix_info(uint32_t device_order, int horizontal, uint32_t sample_rate, float *order_scales2,
+    float *first_order_up, float *xover_norm)
+{
+    auto const scales = AmbiScale::GetHFOrderScales(1, device_order, horizontal != 0);
+    order_scales2[0] = scales[0]; order_scales2[1] = scales[1];
+    for(size_t i{0};i < 4;++i)
+        std::copy_n(AmbiScale::FirstOrderUp[i].begin(), MaxAmbiChannels, first_order_up + i*MaxAmbiChannels);
+    *xover_norm = RDev{}.mXOverFreq / static_cast<float>(sample_rate);
+}
+
 oal_reverb *oal_reverb_create(uint32_t sample_rate, uint32_t num_out_lines)
+{ return oal_reverb_create_ex(sample_rate, num_out_lines, 1); }
+
+/* device_order > 1: the reference's ReverbState up-mixes (mUpmixOutput); num_out_lines = (order+1)^2 */
+oal_reverb *oal_reverb_create_ex(uint32_t sample_rate, uint32_t num_out_lines, uint32_t device_order)
 {
     auto r = std::make_unique<oal_reverb>();
     r->dev = std::make_unique<RDev>();
@@ -51,7 +68,7 @@ oal_reverb *oal_reverb_create(uint32_t sample_rate, uint32_t num_out_lines)
     dev.mUpdateSize = BufferLineSize;
     dev.mBufferSize = BufferLineSize;
     dev.FmtType = DevFmtFloat;
-    dev.mAmbiOrder = 1;
+    dev.mAmbiOrder = device_order;
     dev.MixBuffer.resize(num_out_lines);
     dev.Dry.Buffer = std::span{dev.MixBuffer};
     dev.RealOut.Buffer = dev.Dry.Buffer;

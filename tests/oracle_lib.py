@@ -231,8 +231,17 @@ class OracleLib:
     def make_convolution(self, num_out_lines, ir, sample_rate=48000, ir_rate=None, device_order=1):
         return Convolution(self, num_out_lines, ir, sample_rate, ir_rate or sample_rate, device_order)
 
-    def make_reverb(self, num_out_lines, sample_rate=48000):
-        return Reverb(self, num_out_lines, sample_rate)
+    def make_reverb(self, num_out_lines, sample_rate=48000, device_order=1):
+        return Reverb(self, num_out_lines, sample_rate, device_order)
+
+    def ambi_upmix_info(self, device_order, horizontal=False, sample_rate=48000):
+        """(order_scales[2], first_order_up[4, 25], xover_norm) of a device of that order (compiled reference only)"""
+        f = self.L.oal_ambi_upmix_info
+        f.argtypes = [C.c_uint32, C.c_int, C.c_uint32, f32p, f32p, C.POINTER(C.c_float)]
+        f.restype = None
+        sc, up, xo = np.zeros(2, np.float32), np.zeros((4, 25), np.float32), C.c_float(0.0)
+        f(device_order, 1 if horizontal else 0, sample_rate, _fp(sc), _fp(up), C.byref(xo))
+        return sc, up, xo.value
 
     def direction_coeffs(self, direction, spread=0.0):
         d = np.ascontiguousarray(direction, np.float32)
@@ -528,10 +537,16 @@ class Reverb:
     """ReverbState-shaped handle.  The compiled reference implements update()/get_params(); the
     restatement implements set_params() (fed with the reference's block, or the product host's)."""
 
-    def __init__(self, lib, num_out_lines, sample_rate):
+    def __init__(self, lib, num_out_lines, sample_rate, device_order=1):
         self.lib = lib
         self.nlines = num_out_lines
-        self.h = lib.L.oal_reverb_create(sample_rate, num_out_lines)
+        if device_order == 1:
+            self.h = lib.L.oal_reverb_create(sample_rate, num_out_lines)
+        else:       # compiled reference only
+            f = lib.L.oal_reverb_create_ex
+            f.restype = C.c_void_p
+            f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+            self.h = f(sample_rate, num_out_lines, device_order)
         assert self.h, "oal_reverb_create failed"
 
     def update(self, props, slot_gain=1.0):

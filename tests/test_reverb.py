@@ -413,3 +413,66 @@ def test_gpu_four_reverb_slots_in_scene(synth_mhr):
     for x in grev + orev:
         x.close()
     gsc.close(); osc.close()
+
+
+# ---- devices above first order: mUpmixOutput / MixOutAmbiUp (reverb.cpp:658-699, :835-851, :1166-1184) ----------
+UPMIX_CASES = [("default", 2, False), ("panned", 3, False), ("pipeline_fade", 2, False), ("ragged", 3, False),
+               ("modulated", 4, False)]
+
+
+@pytest.mark.skipif(not ol.available("ref"), reason="needs the compiled reference")
+@pytest.mark.parametrize("name,order,horizontal", UPMIX_CASES, ids=[f"{c[0]}_order{c[1]}" for c in UPMIX_CASES])
+def test_host_upmix_update_matches_reference(name, order, horizontal):
+    """The product's host half on a parameter-only instance: the panning gains of an up-mixing device
+    (update3DPanning combined with AmbiScale::FirstOrderUp), bit for bit."""
+    import oalgpu
+    ref = ol.load("ref")
+    nlines = (order + 1) ** 2
+    schedule = dict(CASES)[name]
+    orc = ref.make_reverb(nlines, device_order=order)
+    host = oalgpu.Reverb(nlines, device=-1)
+    sc, up, xo = ref.ambi_upmix_info(order, horizontal)
+    host.set_upmix(sc, up, xo)
+    assert np.abs(up).max() > 0.1 and sc[0] > 0.0
+    for st in schedule:
+        if st["props"] is None:
+            continue
+        orc.update(ol.ReverbProps.make(**st["props"]), st["slot_gain"])
+        host.update(oalgpu.ReverbProps.make(**st["props"]), st["slot_gain"])
+        a, b = host.get_params(), orc.get_params()
+        for p in range(2):
+            ga = np.array(a.pipe[p].early_gains_target), np.array(a.pipe[p].late_gains_target)
+            gb = np.array(b.pipe[p].early_gains_target), np.array(b.pipe[p].late_gains_target)
+            assert np.array_equal(bits(ga[0]), bits(gb[0])) and np.array_equal(bits(ga[1]), bits(gb[1])), (name, p)
+        if name == "panned":       # an unpanned reverb is omnidirectional: nothing above first order
+            assert np.abs(np.array(b.pipe[b.current_pipeline].late_gains_target)[:, 4:nlines]).max() > 1e-4
+    orc.close(); host.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,order,horizontal", UPMIX_CASES, ids=[f"{c[0]}_order{c[1]}" for c in UPMIX_CASES])
+def test_gpu_upmix_matches_reference(name, order, horizontal):
+    """process() on an up-mixing device against the compiled reference's MixOutAmbiUp: bit for bit, every update
+    (the reverb keeps the reference's operation order throughout; the band splitters run one lane per row)."""
+    oalgpu = _gpu()
+    if not ol.available("ref"):
+        pytest.skip("needs the compiled reference")
+    ref = ol.load("ref")
+    nlines = (order + 1) ** 2
+    schedule = dict(CASES)[name]
+    orc = ref.make_reverb(nlines, device_order=order)
+    g = oalgpu.Reverb(nlines)
+    sc, up, xo = ref.ambi_upmix_info(order, horizontal)
+    g.set_upmix(sc, up, xo)
+    x = wet_input(SEED[name] + 5, len(schedule))
+    for u, st in enumerate(schedule):
+        if st["props"] is not None:
+            orc.update(ol.ReverbProps.make(**st["props"]), st["slot_gain"])
+            g.update(oalgpu.ReverbProps.make(**st["props"]), st["slot_gain"])
+        a, b = out_init(nlines), out_init(nlines)
+        g.process_n(x[u], a, st["n"])
+        orc.process_n(x[u], b, st["n"])
+        assert np.array_equal(bits(a), bits(b)), (name, u, float(np.abs(a - b).max()))
+    if name == "panned":
+        assert np.abs(b[4:, 7:]).max() > 0.0, "higher-order lines are fed"
+    g.close(); orc.close()
