@@ -70,3 +70,13 @@ for nm, x in (("pass 0 (first head/buffer/window + table staging)", d0), ("voice
     print("%-52s mean=%.0f p50=%.0f p99=%.0f max=%.0f" % (nm, x.mean(), np.median(x), np.percentile(x, 99), x.max()))
 h2 = nw.value // 2
 print("wave lifetime, first-half workgroups: mean=%.0f max=%.0f; second half: mean=%.0f max=%.0f" % (tot[:h2].mean(), tot[:h2].max(), tot[h2:].mean(), tot[h2:].max()))
+
+# cold start: the same kind of voice (static, unfiltered) when it is the FIRST voice its wavefront mixes
+# (second-half workgroups run their voices in reverse order) against when it is the second
+ngroups = V // 8
+grp = np.arange(V) // 8
+is_static = np.isin(np.arange(V) % 4, (2, 3))
+first_static = is_static & (grp >= (ngroups + 1) // 2)
+second_static = is_static & (grp < (ngroups + 1) // 2)
+print("static voice as the wave's FIRST voice :", " ".join(f"{n}={d[first_static, i].mean():.0f}" for i, n in enumerate(names)), "sum=%.0f" % d[first_static].sum(axis=1).mean())
+print("static voice as the wave's SECOND voice:", " ".join(f"{n}={d[second_static, i].mean():.0f}" for i, n in enumerate(names)), "sum=%.0f" % d[second_static].sum(axis=1).mean())

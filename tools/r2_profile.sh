@@ -35,3 +35,7 @@ for c, per in out.items():
         if any(x in k for x in ("VoiceWave", "VoiceBlock", "LinesMix", "Conv", "Reverb")):
             print(c, k[:70], {n: round(x["median_kb"]) for n, x in d.items()})
 PY
+# the convolution kernel alone, the voice kernel's phases and its instruction-cache counters
+python tools/conv_period.py > $O/conv_period.txt 2>&1; python tools/conv_period.py 8192 >> $O/conv_period.txt 2>&1; cat $O/conv_period.txt
+timeout 300 python tools/phase_times.py > $O/voice_kernel_phase_times.txt 2>&1; tail -3 $O/voice_kernel_phase_times.txt
+bash tools/r2_icache.sh > $O/voice_kernel_icache_counters.txt 2>&1; cat $O/voice_kernel_icache_counters.txt
