@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--mhr", default="default", choices=("default", "synth"),
                     help="HRTF data set: the reference's Default HRTF.mhr (tests/golden/default_hrtf.mhr) or the synthetic one")
     ap.add_argument("--repeats", type=int, default=5, help="extra K-step blocks timed after the contract's one (spread)")
+    ap.add_argument("--graph", type=int, default=0, metavar="G",
+                    help="issue the steps as hipGraphs of G (even) updates each (oalgpu_update_graph_*): one host launch per G "
+                         "steps; configs 2 and 3 on one GPU; G must divide --steps and --warmup")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -264,6 +267,11 @@ def main():
     # long run needs neither gigabytes of records nor minutes of host-side preparation
     total_steps = args.warmup + 2 * args.steps
     nblocks = min(total_steps, 96)
+    G = args.graph
+    if G:
+        if world > 1 or args.config not in (2, 3) or G % 2 or args.steps % G or args.warmup % G:
+            raise SystemExit("--graph G: one GPU, config 2 or 3, G even and a divisor of --steps and --warmup")
+        nblocks = G * max(1, 96 // G)
     blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(nblocks)]
 
     # N > 1: the library's own multi-GPU path (RCCL inside liboalgpu.so: oalgpu_comm_init, then every
@@ -283,7 +291,13 @@ def main():
         dist.broadcast(idt, src=0)
         sc.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
+    graphs = [sc.update_graph(blocks[j:j + G], UPDATE_SAMPLES, post) for j in range(0, nblocks, G)] if G else []
+
     def step(k):
+        if G:                        # the same steps, G at a time: graph j covers blocks [jG, jG + G)
+            if k % G == 0:
+                graphs[(k // G) % len(graphs)].launch()
+            return
         sc.apply_block(blocks[k % nblocks])
         sc.mix(UPDATE_SAMPLES, post_process=post)
 
@@ -297,6 +311,8 @@ def main():
     # pipeline full, GPU clocks up) before the W warm-up and the K timed steps the contract names;
     # without it a short run (K = 50 is 3 ms) measures the clock ramp: 58.9 vs 54.9 us per step.
     preroll = max(0, 400 - args.warmup)
+    if G:
+        preroll -= preroll % G
     for k in range(preroll):
         step(k)
     fence()
@@ -402,7 +418,7 @@ def main():
                                    + {4: ", v%5 sends into 4 reverb slots", 5: ", one send into a 65536-tap convolution slot"}.get(args.config, "")
                                    + "), 25% filtered, every 4th voice moving",
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
-                       "preroll_steps": preroll, "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
+                       "preroll_steps": preroll, "update_graph": G, "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
                        "e2e_ms_per_update": e2e_ms,
                        "e2e_note": "one update alone through the C-ABI from host memory: oalgpu_voice_set_params of the "
                                    f"{len(moving)} moving voices (host biquad design + H2D) + oalgpu_mix_update + "

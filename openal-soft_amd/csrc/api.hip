@@ -1211,6 +1211,118 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
 
 void *oalgpu_post_stream(oalgpu_context *c) { return c ? static_cast<void*>(c->postStream) : nullptr; }
 
+/* ---- a run of updates as ONE hipGraph --------------------------------------------------------------------
+ * `count` consecutive updates -- update i applies param_blocks[i] (NULL entries: none), then does what
+ * oalgpu_mix_update(samples_to_do, post_process) does -- captured from the context's two streams into one
+ * graph: the voice kernel of update i+1 still runs beside the reduction and the post-process of update i
+ * (fork / join through events of the graph's own), but the host pays ONE launch for the whole run instead
+ * of ~8 runtime calls per update.  Kernel arguments are frozen at capture: everything the kernels read that
+ * changes between updates lives in device memory (voice state, parameter blocks), except the effects'
+ * (delay-line offsets, ring positions, pipeline states advance on the host) -- contexts with an effect
+ * attached to a slot, sharded contexts and caller-owned streams are refused. */
+struct oalgpu_update_graph {
+    oalgpu_context *ctx{nullptr};
+    hipGraph_t graph{nullptr};
+    hipGraphExec_t exec{nullptr};
+    hipEvent_t evVoice[2]{nullptr, nullptr}, evReduce[2]{nullptr, nullptr}, evJoin{nullptr};
+    uint32_t count{0};
+};
+
+void oalgpu_update_graph_destroy(oalgpu_update_graph *g)
+{
+    if(!g) return;
+    if(g->ctx) { (void)hipSetDevice(g->ctx->desc.device); (void)oalgpu_sync(g->ctx); }
+    if(g->exec) (void)hipGraphExecDestroy(g->exec);
+    if(g->graph) (void)hipGraphDestroy(g->graph);
+    for(hipEvent_t e : {g->evVoice[0], g->evVoice[1], g->evReduce[0], g->evReduce[1], g->evJoin}) if(e) (void)hipEventDestroy(e);
+    delete g;
+}
+
+int oalgpu_update_graph_create(oalgpu_context *c, oalgpu_param_block *const *param_blocks, uint32_t count,
+    uint32_t samples_to_do, int post_process, oalgpu_update_graph **out)
+{
+    if(!c || !out || count == 0 || (count & 1u) || count > 4096 || samples_to_do == 0 || samples_to_do > kLine)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: count must be even and 1 <= samples_to_do <= 1024");
+    *out = nullptr;
+    if(!(c->useWave && c->ownStream) || c->serialOnly || c->comm || c->timing)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: needs an unsharded FAST context (wavefront kernel) on its own streams, timing off");
+    for(uint32_t s = 0; s < c->L.numSlots; ++s)
+        if(c->slotConv[s] || c->slotReverb[s])
+            return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: an effect's launch arguments advance on the host every update; detach the slots' effects");
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(post_process && c->L.hrtf && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    std::unique_ptr<oalgpu_update_graph, void(*)(oalgpu_update_graph*)> g(new oalgpu_update_graph, oalgpu_update_graph_destroy);
+    g->ctx = c; g->count = count;
+    for(hipEvent_t *e : {&g->evVoice[0], &g->evVoice[1], &g->evReduce[0], &g->evReduce[1], &g->evJoin})
+        HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventDisableSystemFence));
+
+    const DeviceLayout &L0 = c->L;
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t err = hipSuccess;
+    auto ok = [&](hipError_t e) { if(err == hipSuccess && e != hipSuccess) err = e; return err == hipSuccess; };
+    for(uint32_t i = 0; i < count && err == hipSuccess; ++i)
+    {
+        const uint32_t p = (c->parity + i) & 1u;
+        DeviceLayout L = L0;
+        L.partHrtf = c->partHrtfBuf[p];
+        if(L.streams) L.partLines = c->partLinesBuf[p];
+        if(param_blocks && param_blocks[i])
+        {
+            LaunchApplyParams(c->stream, L0, c->hrtfDev, param_blocks[i]->recs.p, param_blocks[i]->count);
+            ok(hipGetLastError());
+        }
+        // this update's partial buses were last read by the reduction of two updates ago (the first two
+        // updates of the graph start from a drained context)
+        if(i >= 2) ok(hipStreamWaitEvent(c->stream, g->evReduce[p], 0));
+        ok(LaunchVoiceWave(c->stream, L, samples_to_do));
+        ok(hipEventRecord(g->evVoice[p], c->stream));
+        ok(hipStreamWaitEvent(c->postStream, g->evVoice[p], 0));        // the post stream joins the capture here
+        LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum && L.hrtf, true);
+        ok(hipGetLastError());
+        ok(hipEventRecord(g->evReduce[p], c->postStream));
+        if(post_process && L.hrtf)
+        {
+            float *left = L.bus + size_t{L.numDry} * kLine;
+            LaunchPostDirectHrtfFast(c->postStream, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
+                c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do);
+            ok(hipGetLastError());
+        }
+        if(post_process && !L.hrtf && c->decOn)
+        {
+            LaunchBFormatDecode(c->postStream, c->exact, L.bus + size_t{L.numDry} * kLine, L.bus, c->decSplit.p, c->decBands.p,
+                c->decGainsHf.p, c->decDual ? c->decGainsLf.p : nullptr, L.numDry, c->decOut, samples_to_do);
+            ok(hipGetLastError());
+        }
+    }
+    // the post stream's branch rejoins the stream the capture began on
+    ok(hipEventRecord(g->evJoin, c->postStream));
+    ok(hipStreamWaitEvent(c->stream, g->evJoin, 0));
+    hipGraph_t graph = nullptr;
+    const hipError_t endErr = hipStreamEndCapture(c->stream, &graph);
+    g->graph = graph;
+    if(err != hipSuccess) return Fail(OALGPU_ERR_HIP, std::string("oalgpu_update_graph_create (capture): ") + hipGetErrorString(err));
+    HIP_TRY(endErr);
+    HIP_TRY(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+    *out = g.release();
+    return OALGPU_OK;
+}
+
+int oalgpu_update_graph_launch(oalgpu_update_graph *g)
+{
+    if(!g || !g->ctx || !g->exec) return Fail(OALGPU_ERR_INVALID, "null argument");
+    oalgpu_context *c = g->ctx;
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    // whatever a pipelined oalgpu_mix_update left on the post stream comes first: the graph's first two
+    // updates take both partial-bus buffers as free
+    if(int rc = JoinPost(c)) return rc;
+    HIP_TRY(hipGraphLaunch(g->exec, c->stream));
+    return OALGPU_OK;   // the graph ends joined on the main stream: nothing is left pending on the post stream
+}
+
 int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, int post_process)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");

@@ -425,6 +425,10 @@ class Scene:
     def apply_block(self, block):
         check(lib.oalgpu_param_block_apply(self.h, block), "oalgpu_param_block_apply")
 
+    def update_graph(self, blocks, samples_to_do=BUFFER_LINE, post_process=True):
+        """`len(blocks)` (even) updates as one hipGraph: update i applies blocks[i] (None: no change) and mixes"""
+        return UpdateGraph(self, blocks, samples_to_do, post_process)
+
     def set_stream(self, stream_ptr):
         check(lib.oalgpu_set_stream(self.h, stream_ptr), "oalgpu_set_stream")
 
@@ -549,6 +553,36 @@ class Scene:
         a, b = C.c_float(), C.c_float()
         check(lib.oalgpu_last_update_ms(self.h, C.byref(a), C.byref(b)), "oalgpu_last_update_ms")
         return a.value, b.value
+
+
+class UpdateGraph:
+    """oalgpu_update_graph: a run of updates captured into one hipGraph (keeps its parameter blocks alive)."""
+
+    def __init__(self, scene, blocks, samples_to_do, post_process):
+        lib.oalgpu_update_graph_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int,
+                                                   C.POINTER(C.c_void_p)]
+        lib.oalgpu_update_graph_launch.argtypes = [C.c_void_p]
+        lib.oalgpu_update_graph_destroy.argtypes = [C.c_void_p]
+        lib.oalgpu_update_graph_destroy.restype = None
+        self.scene, self.blocks, self.count = scene, list(blocks), len(blocks)
+        arr = (C.c_void_p * self.count)(*[(b.value if isinstance(b, C.c_void_p) else b) for b in self.blocks])
+        h = C.c_void_p()
+        self.h = None
+        check(lib.oalgpu_update_graph_create(scene.h, arr, self.count, samples_to_do, 1 if post_process else 0, C.byref(h)),
+              "oalgpu_update_graph_create")
+        self.h = h
+
+    def launch(self):
+        check(lib.oalgpu_update_graph_launch(self.h), "oalgpu_update_graph_launch")
+
+    def close(self):
+        if self.h:
+            lib.oalgpu_update_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        if lib is not None:
+            self.close()
 
 
 def comm_unique_id():
