@@ -258,6 +258,25 @@ typedef struct oalgpu_voice_params {
     oalgpu_filter_params send_filter[OALGPU_MAX_SENDS];
     float    send_gains[OALGPU_MAX_SENDS][OALGPU_MAX_AMBI_CHANNELS]; /* mWetParams[i].Gains.Target */
 } oalgpu_voice_params;
+/* ---- panning on the GPU: CalcDirectionCoeffs + ComputePanGains -----------------------------
+ * What CalcPanningAndFilters does for a point source (alc/alu.cpp; core/mixer.h:68-73, core/ambidefs.h:219-271,
+ * core/mixer.cpp:16-102): coeffs = CalcDirectionCoeffs(dir, spread), then ComputePanGains(&Device->Dry, coeffs,
+ * dry_gain, mDryParams.Gains.Target) and, per send with a slot, ComputePanGains(&Slot->Wet, coeffs, send_gain[i],
+ * mWetParams[i].Gains.Target) -- gains[line] = AmbiMap[line].Scale * coeffs[AmbiMap[line].Index] * gain.  The
+ * device's and the slots' AmbiMaps (core/device.h MixParams) are handed over once; until then they are the
+ * identity (line i = ACN i, scale 1).  oalgpu_voice_set_pan REPLACES the dry_gains / send_gains of the voices'
+ * last oalgpu_voice_params (an HRTF context has no dry gains: only the sends'); `dir` is the normalized
+ * OpenAL-space direction.  Without spread the gains are bit-identical to the reference's. */
+typedef struct oalgpu_voice_pan {
+    float dir[3];
+    float spread;                                    /* 0 .. tau */
+    float dry_gain;                                  /* DryGain.Base * downmix gain */
+    float send_gain[OALGPU_MAX_SENDS];               /* WetGain[i].Base * downmix gain */
+} oalgpu_voice_pan;
+int oalgpu_context_set_ambi_map(oalgpu_context *ctx, const uint8_t *index, const float *scale);        /* num_dry entries */
+int oalgpu_slot_set_ambi_map(oalgpu_context *ctx, uint32_t slot, const uint8_t *index, const float *scale); /* wet_channels */
+int oalgpu_voice_set_pan(oalgpu_context *ctx, const uint32_t *voices, const oalgpu_voice_pan *pans, size_t count);
+
 /* ---- streaming sources: a queue of buffers (VoiceBufferItem::mNext, core/voice.h:85) ---------------------
  * oalgpu_buffer_queue_link(buffer, next) links `next` behind `buffer` (alSourceQueueBuffers; next < 0 ends
  * the queue there).  oalgpu_voice_init_queue starts a voice that is NOT VoiceFlag::IsStatic on the queue's

@@ -126,6 +126,8 @@ struct oalgpu_context {
     DevBuf<NfcState> nfc;
     NfcDesign nfcDevice{};                   // DeviceBase::mNFCtrlFilter (after init(w1))
     DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
+    DevBuf<AmbiMapEntry> dryMap, wetMaps;   // MixParams::AmbiMap of the dry bus / of every slot's wet bus
+    DevBuf<PanRecord> panRecs;
     bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
     uint32_t waveGroups{0};                // partial buses of the wavefront kernel (the fallback of voice_block.hip)
     // multi-GPU (oalgpu_comm_init): this rank's RCCL communicator; the bus block is sum-reduced to rank 0
@@ -582,6 +584,14 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->sendTgt.alloc(nv * L.numSends * L.wetChannels)); HIP_TRY(c->sendTgt.zero()); L.sendTgt = c->sendTgt.p;
     HIP_TRY(c->ambi.alloc(nv)); HIP_TRY(c->ambi.zero()); L.ambi = c->ambi.p;
     HIP_TRY(c->startDelay.alloc(nv)); HIP_TRY(c->startDelay.zero()); L.startDelay = c->startDelay.p;
+    {   // identity ambisonic maps until the host hands over the device's (ACN i, scale 1)
+        std::vector<AmbiMapEntry> ident(std::max<size_t>(L.numDry, size_t{L.numSlots} * L.wetChannels) + 1);
+        for(size_t i = 0; i < ident.size(); ++i) ident[i] = AmbiMapEntry{uint32_t(i < OALGPU_MAX_AMBI_CHANNELS ? i : 0), 1.0f};
+        HIP_TRY(c->dryMap.alloc(L.numDry)); HIP_TRY(c->dryMap.upload(ident.data(), L.numDry));
+        HIP_TRY(c->wetMaps.alloc(size_t{L.numSlots} * L.wetChannels));
+        for(uint32_t s = 0; s < L.numSlots; ++s)
+            HIP_TRY(hipMemcpy(c->wetMaps.p + size_t{s} * L.wetChannels, ident.data(), L.wetChannels * sizeof(AmbiMapEntry), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c->queueDone.alloc(nv)); HIP_TRY(c->queueDone.zero()); L.queueDone = c->queueDone.p;
     L.numLineGroups = L.numGroups;
     L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0; L.streamsPerVoice = 0;
@@ -1051,6 +1061,60 @@ int oalgpu_set_stream(oalgpu_context *c, void *hip_stream)
         HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prioGreatest));
         c->ownStream = true;
     }
+    return OALGPU_OK;
+}
+
+/* ---- panning on the GPU: CalcDirectionCoeffs + ComputePanGains (core/mixer.h:68-73, core/mixer.cpp:16-102) ---- */
+static int UploadAmbiMap(DevBuf<AmbiMapEntry> &dst, size_t at, const uint8_t *index, const float *scale, uint32_t n)
+{
+    std::vector<AmbiMapEntry> m(n);
+    for(uint32_t i = 0; i < n; ++i)
+    {
+        if(index[i] >= OALGPU_MAX_AMBI_CHANNELS) return Fail(OALGPU_ERR_INVALID, "ambisonic channel index out of range");
+        m[i] = AmbiMapEntry{index[i], scale[i]};
+    }
+    HIP_TRY(hipMemcpy(dst.p + at, m.data(), n * sizeof(AmbiMapEntry), hipMemcpyHostToDevice));
+    return OALGPU_OK;
+}
+
+int oalgpu_context_set_ambi_map(oalgpu_context *c, const uint8_t *index, const float *scale)
+{
+    if(!c || !index || !scale) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    return UploadAmbiMap(c->dryMap, 0, index, scale, c->L.numDry);
+}
+
+int oalgpu_slot_set_ambi_map(oalgpu_context *c, uint32_t slot, const uint8_t *index, const float *scale)
+{
+    if(!c || !index || !scale || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_ambi_map: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    return UploadAmbiMap(c->wetMaps, size_t{slot} * c->L.wetChannels, index, scale, c->L.wetChannels);
+}
+
+int oalgpu_voice_set_pan(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_pan *pans, size_t count)
+{
+    if(!c || !voices || !pans || count == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_pan: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    std::vector<PanRecord> recs(count);
+    for(size_t i = 0; i < count; ++i)
+    {
+        if(voices[i] >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_pan: bad voice index");
+        PanRecord &r = recs[i];
+        r.voice = voices[i];
+        std::memcpy(r.dir, pans[i].dir, sizeof(r.dir));
+        r.spread = pans[i].spread; r.dryGain = pans[i].dry_gain;
+        std::memcpy(r.sendGain, pans[i].send_gain, sizeof(r.sendGain));
+    }
+    // (the records of the previous call may still be read by its kernel)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if(c->panRecs.n < count) HIP_TRY(c->panRecs.alloc(count));
+    HIP_TRY(hipMemcpyAsync(c->panRecs.p, recs.data(), count * sizeof(PanRecord), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    LaunchPanGains(c->stream, c->L, c->panRecs.p, uint32_t(count), c->dryMap.p, c->wetMaps.p);
+    HIP_TRY(hipGetLastError());
     return OALGPU_OK;
 }
 

@@ -205,6 +205,12 @@ void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo,
 // ---- launchers (voice_wave.hip): the FAST HRTF hot path, one wavefront per voice ----
 void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st);
 void LaunchSetNfc(hipStream_t s, const DeviceLayout &L, uint32_t voice, const NfcState &coeffs);
+
+// ---- launcher (pan_kernels.hip): CalcDirectionCoeffs + ComputePanGains for `count` voices ----
+struct AmbiMapEntry { uint32_t index; float scale; };          // BFChannelConfig, core/device.h
+struct PanRecord { uint32_t voice; float dir[3]; float spread; float dryGain; float sendGain[6]; };
+void LaunchPanGains(hipStream_t s, const DeviceLayout &L, const PanRecord *recs, uint32_t count, const AmbiMapEntry *dryMap,
+    const AmbiMapEntry *wetMaps);
 void LaunchSetStartDelay(hipStream_t s, const DeviceLayout &L, uint32_t voice, uint32_t samples);
 
 // ---- launcher (adpcm_kernels.hip): IMA4 / MS ADPCM blocks -> interleaved 16-bit PCM, one thread per block and channel ----

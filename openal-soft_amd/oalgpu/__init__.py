@@ -372,6 +372,24 @@ class Scene:
     def current_buffer(self, voice):
         return self.queue_state(voice)[0]
 
+    # panning on the GPU: CalcDirectionCoeffs + ComputePanGains (replaces the gains of the last set_params)
+    def set_ambi_map(self, index, scale):
+        lib.oalgpu_context_set_ambi_map.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), f32p]
+        idx = np.ascontiguousarray(index, np.uint8); sc = np.ascontiguousarray(scale, np.float32)
+        check(lib.oalgpu_context_set_ambi_map(self.h, idx.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(sc)), "oalgpu_context_set_ambi_map")
+
+    def set_slot_ambi_map(self, slot, index, scale):
+        lib.oalgpu_slot_set_ambi_map.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8), f32p]
+        idx = np.ascontiguousarray(index, np.uint8); sc = np.ascontiguousarray(scale, np.float32)
+        check(lib.oalgpu_slot_set_ambi_map(self.h, slot, idx.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(sc)), "oalgpu_slot_set_ambi_map")
+
+    def set_pan(self, voices, pans):
+        """pans: rows of [dir x, y, z, spread, dry_gain, send_gain 0..5] (11 floats)"""
+        lib.oalgpu_voice_set_pan.argtypes = [C.c_void_p, u32p, f32p, C.c_size_t]
+        v = np.ascontiguousarray(voices, np.uint32)
+        p = np.ascontiguousarray(pans, np.float32).reshape(len(v), 11)
+        check(lib.oalgpu_voice_set_pan(self.h, v.ctypes.data_as(u32p), _fp(p), len(v)), "oalgpu_voice_set_pan")
+
     # near-field control (same interface as tests/oracle_lib.Scene)
     def set_nfc(self, w1, channels_per_order):
         lib.oalgpu_context_set_nfc.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_uint32)]
