@@ -421,6 +421,22 @@ int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_stat
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);
 /* Enables/disables the event timing above (off by default: it adds two event records). */
 int oalgpu_set_timing(oalgpu_context *ctx, int enable);
+/* ---- SampleConverter (core/converter.h:15-59, core/converter.cpp:175-330) ------------------------
+ * The format and rate converter of the capture side and of some backends -- the second consumer of the
+ * resamplers: interleaved frames of `channels` samples of src_type (oalgpu_output_type = DevFmtType order) at
+ * src_rate in, dst_type at dst_rate out, with the state SampleConverter carries between calls (prep samples,
+ * fractional offset).  oalgpu_converter_convert is SampleConverter::convert: it writes up to dst_frames frames to
+ * `dst`, advances *src past the frames it consumed, leaves in *src_frames what it did not take, and returns the
+ * frames written (or a negative oalgpu_error); oalgpu_converter_available_out is availableOut().  Host buffers;
+ * results are bit-identical to the reference's (the resamplers in the reference's operation order). */
+typedef struct oalgpu_converter oalgpu_converter;
+int  oalgpu_converter_create(int device, int src_type, int dst_type, uint32_t channels, uint32_t src_rate,
+    uint32_t dst_rate, int resampler, oalgpu_converter **out);
+void oalgpu_converter_destroy(oalgpu_converter *conv);
+uint32_t oalgpu_converter_available_out(const oalgpu_converter *conv, uint32_t src_frames);
+int  oalgpu_converter_convert(oalgpu_converter *conv, const void **src, uint32_t *src_frames, void *dst,
+    uint32_t dst_frames);
+
 /* ---- a run of updates as ONE hipGraph --------------------------------------------------------------------
  * `count` (even) consecutive updates -- update i applies param_blocks[i] (the array or an entry may be NULL:
  * no parameter change), then does what oalgpu_mix_update(samples_to_do, post_process) does -- captured from

@@ -369,6 +369,133 @@ int oalgpu_resample(int device, int mode, int resampler, uint32_t increment, con
     return OALGPU_OK;
 }
 
+/* ---- SampleConverter (core/converter.h:15-59, core/converter.cpp:175-330): the second consumer of the resamplers ----
+ * The integer bookkeeping of convert() / availableOut() runs here on the host, exactly as the reference's; the
+ * float work of a call -- LoadSample<T>, the resampler, StoreSample<T> for every channel and chunk -- is one launch
+ * (SampleConvertKernel, output_kernels.hip). */
+struct oalgpu_converter {
+    int device{0};
+    int srcType{0}, dstType{0};
+    uint32_t channels{1}, increment{kFracOne};
+    uint32_t srcPrepCount{kMaxPad}, fracOffset{0};          // mSrcPrepCount, mFracOffset
+    oalgpu_interp_state st{};
+    DevBuf<float> tables, prev, prev2;
+    DevBuf<unsigned char> src, dst;
+    DevBuf<ConvertChunk> chunks;
+    bool flip{false};                                       // which of prev / prev2 holds the current PrevSamples
+};
+
+static size_t DevFmtBytes(int type) { static const size_t b[7] = {1, 1, 2, 2, 4, 4, 4}; return b[type]; }
+
+int oalgpu_converter_create(int device, int src_type, int dst_type, uint32_t channels, uint32_t src_rate, uint32_t dst_rate,
+    int resampler, oalgpu_converter **out)
+{
+    if(!out || src_type < OALGPU_OUT_I8 || src_type > OALGPU_OUT_F32 || dst_type < OALGPU_OUT_I8 || dst_type > OALGPU_OUT_F32
+        || channels < 1 || channels > 64 || src_rate < 1 || dst_rate < 1 || resampler < 0 || resampler > OALGPU_RESAMPLER_BSINC48)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_converter_create: bad arguments");
+    *out = nullptr;
+    if(int rc = UseDevice(device)) return rc;
+    auto c = std::make_unique<oalgpu_converter>();
+    c->device = device; c->srcType = src_type; c->dstType = dst_type; c->channels = channels;
+    // converter.cpp:199-201: step = clamp(round(srcRate * MixerFracOne / dstRate), 1, MaxPitch * MixerFracOne)
+    const double step = std::min(std::max(std::round(double(src_rate) * double(kFracOne) / double(dst_rate)), 1.0), 10.0 * double(kFracOne));
+    c->increment = uint32_t(step);
+    if(c->increment != kFracOne)
+        if(int rc = oalgpu_prepare_resampler(resampler, c->increment, &c->st)) return rc;
+    const TableBlob &blob = Blob();
+    HIP_TRY(c->tables.alloc(blob.data.size())); HIP_TRY(c->tables.upload(blob.data.data(), blob.data.size()));
+    HIP_TRY(c->prev.alloc(size_t{channels} * kMaxPad)); HIP_TRY(c->prev.zero());
+    HIP_TRY(c->prev2.alloc(size_t{channels} * kMaxPad)); HIP_TRY(c->prev2.zero());
+    *out = c.release();
+    return OALGPU_OK;
+}
+
+void oalgpu_converter_destroy(oalgpu_converter *c)
+{
+    if(!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    delete c;
+}
+
+/* SampleConverter::availableOut, converter.cpp:216-234 */
+uint32_t oalgpu_converter_available_out(const oalgpu_converter *c, uint32_t src_frames)
+{
+    if(!c || src_frames < 1) return 0;
+    const uint32_t prep = c->srcPrepCount;
+    if(prep < kMaxPad && kMaxPad - prep >= src_frames) return 0;
+    uint64_t size = uint64_t{prep} + src_frames - kMaxPad;
+    size <<= kFracBits;
+    size -= c->fracOffset;
+    const uint64_t n = (size + c->increment - 1) / c->increment;
+    return uint32_t(std::min<uint64_t>(std::max<uint64_t>(n, 1), 2147483647ull));
+}
+
+int oalgpu_converter_convert(oalgpu_converter *c, const void **src, uint32_t *src_frames, void *dst, uint32_t dst_frames)
+{
+    if(!c || !src || !src_frames || (!*src && *src_frames) || (!dst && dst_frames))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_converter_convert: bad arguments");
+    if(int rc = UseDevice(c->device)) return rc;
+    const uint32_t inc = c->increment, total = *src_frames;
+    // ---- the chunk loop of convert(), integers only (converter.cpp:248-327)
+    std::vector<ConvertChunk> chunks;
+    uint32_t pos = 0, left = total, consumed = 0, prep = c->srcPrepCount, frac = c->fracOffset, base = 0;
+    const uint32_t prep0 = prep;
+    while(pos < dst_frames && left > 0)
+    {
+        const uint32_t readable = std::min(left, uint32_t(kLine) - prep);
+        if(prep < kMaxPad && kMaxPad - prep >= readable)
+        {   // not enough input for one output: keep what came (the reference reports it all as taken)
+            prep += readable;
+            left = 0;
+            break;
+        }
+        uint64_t size = uint64_t{prep} + readable - kMaxPad;
+        size <<= kFracBits;
+        size -= frac;
+        uint32_t dstSize = uint32_t(std::min<uint64_t>(std::max<uint64_t>((size + inc - 1) / inc, 1), uint64_t(kLine)));
+        dstSize = std::min(dstSize, dst_frames - pos);
+        const uint32_t posEnd = dstSize * inc + frac;
+        const uint32_t srcEnd = posEnd >> kFracBits;
+        const uint32_t nextPrep = std::min(prep + readable - srcEnd, uint32_t(kMaxPad));
+        chunks.push_back(ConvertChunk{base, frac, pos, dstSize});
+        const uint32_t srcRead = std::min(left, srcEnd + nextPrep - prep);
+        base += srcEnd;
+        prep = nextPrep;
+        frac = posEnd & kFracMask;
+        consumed += srcRead; left -= srcRead;
+        pos += dstSize;
+    }
+    if(prep != c->srcPrepCount || !chunks.empty())
+    {
+        const size_t srcBytes = size_t{total} * c->channels * DevFmtBytes(c->srcType);
+        const size_t dstBytes = size_t{pos} * c->channels * DevFmtBytes(c->dstType);
+        if(c->src.n < srcBytes) HIP_TRY(c->src.alloc(srcBytes));
+        if(c->dst.n < dstBytes) HIP_TRY(c->dst.alloc(std::max<size_t>(dstBytes, 16)));
+        if(c->chunks.n < chunks.size()) HIP_TRY(c->chunks.alloc(std::max<size_t>(chunks.size(), 1)));
+        HIP_TRY(hipMemcpy(c->src.p, *src, srcBytes, hipMemcpyHostToDevice));
+        if(!chunks.empty()) HIP_TRY(c->chunks.upload(chunks.data(), chunks.size()));
+        ConvertJob J{};
+        const TableBlob &blob = Blob();
+        J.spec = ResampleSpec{c->st.kind, c->st.m, c->st.l, c->st.sf, inc != kFracOne ? c->tables.p + blob.filterBase(c->st) : c->tables.p};
+        J.increment = inc;
+        J.prev = c->flip ? c->prev2.p : c->prev.p; J.newPrev = c->flip ? c->prev.p : c->prev2.p;
+        J.src = c->src.p; J.dst = c->dst.p;
+        J.prep0 = prep0; J.srcFrames = total; J.channels = c->channels; J.numChunks = uint32_t(chunks.size());
+        J.endBase = base; J.nextPrep = prep;
+        J.srcType = c->srcType; J.dstType = c->dstType;
+        LaunchSampleConvert(nullptr, J, c->chunks.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        if(dstBytes) HIP_TRY(hipMemcpy(dst, c->dst.p, dstBytes, hipMemcpyDeviceToHost));
+        c->flip = !c->flip;
+    }
+    c->srcPrepCount = prep; c->fracOffset = frac;
+    *src = static_cast<const unsigned char*>(*src) + size_t{consumed} * c->channels * DevFmtBytes(c->srcType);
+    *src_frames = left;
+    return int(pos);
+}
+
 int oalgpu_mix(int device, const float *in, size_t n, float *out, size_t nlines, float *current_gains,
     const float *target_gains, size_t counter, size_t outpos)
 {

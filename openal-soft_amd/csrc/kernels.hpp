@@ -172,6 +172,16 @@ void LaunchBFormatDecode(hipStream_t s, bool exact, float *out, const float *lin
 void LaunchDither(hipStream_t s, float *lines, uint32_t nlines, uint32_t n, float quantScale, uint32_t seed);
 uint32_t DitherAdvanceSeed(uint32_t seed, uint32_t draws);
 void LaunchWriteSamples(hipStream_t s, int sampleType, const float *lines, uint32_t nlines, uint32_t n, uint32_t frameStep, void *out);
+// SampleConverter::convert (core/converter.cpp:236-330): one launch per call, see output_kernels.hip
+struct ConvertChunk { uint32_t srcBase, frac0, dstBase, dstSize; };      // timeline index of SrcData[0], DataPosFrac, first output, DstSize
+struct ConvertJob {
+    ResampleSpec spec; uint32_t increment;
+    const float *prev; float *newPrev;          // [channel][48] PrevSamples before / after the call
+    const void *src; void *dst;                 // interleaved frames, device memory
+    uint32_t prep0, srcFrames, channels, numChunks, endBase, nextPrep;
+    int srcType, dstType;
+};
+void LaunchSampleConvert(hipStream_t s, const ConvertJob &J, const ConvertChunk *chunks);
 
 // ---- launcher (conv_kernels.hip): ConvolutionState::process for a mono response ----
 struct ConvLayoutHost {

@@ -12,6 +12,7 @@
 // bit-exact in EXACT mode (the reference's operation order: per input channel HF then LF, multiply and
 // add separately) and within the FAST tolerance otherwise.
 #include "dev_wave.hpp"
+#include "dev_resample.hpp"
 
 #pragma clang fp contract(off)
 
@@ -197,7 +198,90 @@ __global__ void __launch_bounds__(256) WriteKernel(const float *lines, uint32_t 
     out[k] = ConvSample<T>(c < nlines ? lines[size_t{c} * kLine + i] : 0.0f);
 }
 
+// ---- SampleConverter::convert, core/converter.cpp:236-330 ------------------------------------------------------
+// The reference walks the input in chunks of <= 1024 frames: per channel [PrevSamples | new input] -> float
+// (LoadSample<T>, :31-49), mResample into <= 1024 outputs, StoreSample<T> (:100-118).  Every chunk's source line
+// is a window of ONE timeline -- the converter's prep samples followed by the call's input frames -- so the
+// host only does the integer bookkeeping (the chunk table) and one launch computes every output of the call:
+// block.y = chunk, block.z = channel, thread = output i of the chunk (the cubic resampler's summation order
+// depends on i and on the chunk's size, hence the table).  Another block row files the next call's prep samples.
+template<typename T> __device__ __forceinline__ float LoadDevSample(const void *src, size_t k);
+template<> __device__ __forceinline__ float LoadDevSample<int8_t>(const void *s, size_t k) { return float(static_cast<const int8_t*>(s)[k]) * (1.0f / 128.0f); }
+template<> __device__ __forceinline__ float LoadDevSample<uint8_t>(const void *s, size_t k) { return float(int8_t(static_cast<const uint8_t*>(s)[k] - 128u)) * (1.0f / 128.0f); }
+template<> __device__ __forceinline__ float LoadDevSample<int16_t>(const void *s, size_t k) { return float(static_cast<const int16_t*>(s)[k]) * (1.0f / 32768.0f); }
+template<> __device__ __forceinline__ float LoadDevSample<uint16_t>(const void *s, size_t k) { return float(int16_t(static_cast<const uint16_t*>(s)[k] - 32768u)) * (1.0f / 32768.0f); }
+template<> __device__ __forceinline__ float LoadDevSample<int32_t>(const void *s, size_t k) { return float(static_cast<const int32_t*>(s)[k]) * (1.0f / 2147483648.0f); }
+template<> __device__ __forceinline__ float LoadDevSample<uint32_t>(const void *s, size_t k) { return float(int32_t(static_cast<const uint32_t*>(s)[k] - 2147483648u)) * (1.0f / 2147483648.0f); }
+template<> __device__ __forceinline__ float LoadDevSample<float>(const void *s, size_t k) { return static_cast<const float*>(s)[k]; }
+
+__device__ __forceinline__ float LoadDevSampleAny(int type, const void *src, size_t k)
+{
+    switch(type)
+    {
+    case OALGPU_OUT_I8: return LoadDevSample<int8_t>(src, k);
+    case OALGPU_OUT_U8: return LoadDevSample<uint8_t>(src, k);
+    case OALGPU_OUT_I16: return LoadDevSample<int16_t>(src, k);
+    case OALGPU_OUT_U16: return LoadDevSample<uint16_t>(src, k);
+    case OALGPU_OUT_I32: return LoadDevSample<int32_t>(src, k);
+    case OALGPU_OUT_U32: return LoadDevSample<uint32_t>(src, k);
+    default: return LoadDevSample<float>(src, k);
+    }
+}
+__device__ __forceinline__ void StoreDevSampleAny(int type, void *dst, size_t k, float v)
+{
+    switch(type)
+    {
+    case OALGPU_OUT_I8: static_cast<int8_t*>(dst)[k] = ConvSample<int8_t>(v); break;
+    case OALGPU_OUT_U8: static_cast<uint8_t*>(dst)[k] = ConvSample<uint8_t>(v); break;
+    case OALGPU_OUT_I16: static_cast<int16_t*>(dst)[k] = ConvSample<int16_t>(v); break;
+    case OALGPU_OUT_U16: static_cast<uint16_t*>(dst)[k] = ConvSample<uint16_t>(v); break;
+    case OALGPU_OUT_I32: static_cast<int32_t*>(dst)[k] = ConvSample<int32_t>(v); break;
+    case OALGPU_OUT_U32: static_cast<uint32_t*>(dst)[k] = ConvSample<uint32_t>(v); break;
+    default: static_cast<float*>(dst)[k] = v; break;
+    }
+}
+
+// element g of channel c's timeline: the prep samples the call started with, then the call's input
+struct ConvTimeline {
+    const float *prev; const void *src; uint32_t prep0, channels, chan, srcFrames; int type; uint32_t base;
+    __device__ __forceinline__ float operator[](uint32_t idx) const
+    {
+        const uint32_t g = base + idx;
+        if(g < prep0) return prev[g];
+        const uint32_t f = g - prep0;
+        return f < srcFrames ? LoadDevSampleAny(type, src, size_t{f} * channels + chan) : 0.0f;
+    }
+};
+
+__global__ void __launch_bounds__(256) SampleConvertKernel(ConvertJob J, const ConvertChunk *chunks)
+{
+    const uint32_t c = blockIdx.z, t = threadIdx.x;
+    if(blockIdx.y == J.numChunks)
+    {   // the prep samples the next call starts from: timeline[endBase .. endBase + nextPrep), zero-filled
+        if(blockIdx.x == 0 && t < kMaxPad)
+        {
+            const ConvTimeline tl{J.prev + size_t{c} * kMaxPad, J.src, J.prep0, J.channels, c, J.srcFrames, J.srcType, J.endBase};
+            J.newPrev[size_t{c} * kMaxPad + t] = t < J.nextPrep ? tl[t] : 0.0f;
+        }
+        return;
+    }
+    const ConvertChunk k = chunks[blockIdx.y];
+    const uint32_t i = blockIdx.x * 256u + t;
+    if(i >= k.dstSize) return;
+    const ConvTimeline tl{J.prev + size_t{c} * kMaxPad, J.src, J.prep0, J.channels, c, J.srcFrames, J.srcType, k.srcBase};
+    float v;
+    if(J.increment == kFracOne) v = tl[kMaxEdge + i];                  // the copy "resampler" of :208-213
+    else v = ResampleAt<true>(J.spec.kind, J.spec.m, J.spec.l, J.spec.sf, J.spec.filter, ReferenceTabLayout(J.spec.m), tl, k.frac0,
+        J.increment, i, k.dstSize);
+    StoreDevSampleAny(J.dstType, J.dst, (size_t{k.dstBase} + i) * J.channels + c, v);
+}
+
 } // namespace
+
+void LaunchSampleConvert(hipStream_t s, const ConvertJob &J, const ConvertChunk *chunks)
+{
+    hipLaunchKernelGGL(SampleConvertKernel, dim3(kLine / 256, J.numChunks + 1u, J.channels), dim3(256), 0, s, J, chunks);
+}
 
 void LaunchBFormatDecode(hipStream_t s, bool exact, float *out, const float *lines, SplitterState *states, float *bands,
     const float *gainsHf, const float *gainsLf, uint32_t nin, uint32_t nout, uint32_t n)

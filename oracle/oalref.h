@@ -259,6 +259,16 @@ oal_conv *oal_conv_create_ex(uint32_t sample_rate, uint32_t num_out_lines, uint3
     uint32_t ir_len, uint32_t channels, uint32_t ir_rate);
 void oal_conv_set_orientation(oal_conv *c, const float at[3], const float up[3]);
 uint32_t oal_conv_channel_info(oal_conv *c, float *targets, float *hf, float *lf, int *upsample, float *xover_norm);
+/* SampleConverter (core/converter.cpp:175-330), compiled reference only: types in DevFmtType order (0 = int8 ..
+ * 6 = float), `resampler` as for oal_prepare_resampler; convert() returns the frames written and reports how
+ * many source bytes it consumed and (in *src_frames) how many frames it left */
+typedef struct oal_converter oal_converter;
+oal_converter *oal_converter_create(int src_type, int dst_type, uint32_t channels, uint32_t src_rate, uint32_t dst_rate,
+    int resampler);
+uint32_t oal_converter_available_out(oal_converter *c, uint32_t src_frames);
+uint32_t oal_converter_convert(oal_converter *c, const void *src, uint32_t *src_frames, void *dst, uint32_t dst_frames,
+    uint64_t *consumed_bytes);
+void oal_converter_destroy(oal_converter *c);
 /* PPhaseResampler::init + process (common/polyphase_resampler.cpp), compiled reference only */
 void oal_pphase_resample(uint32_t src_rate, uint32_t dst_rate, const double *in, size_t n_in, double *out, size_t n_out);
 void oal_conv_update(oal_conv *c, float slot_gain);

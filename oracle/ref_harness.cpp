@@ -64,6 +64,7 @@
 #include "core/async_event.h"
 #include "ringbuffer.h"
 #include "polyphase_resampler.h"
+#include "core/converter.h"
 
 #include "oalref.h"
 
@@ -892,6 +893,29 @@ int oal_scene_set_direct_hrtf(oal_scene *s, const float *chan_coeffs, const floa
 
 /* (the convolution reverb lives in ref_conv.cpp, which compiles alc/effects/convolution.cpp itself to
  * reach its file-local ConvolutionState) */
+
+/* SampleConverter (core/converter.cpp:175-330): Create / availableOut / convert as they are */
+struct oal_converter { SampleConverterPtr conv; };
+oal_converter *oal_converter_create(int src_type, int dst_type, uint32_t channels, uint32_t src_rate, uint32_t dst_rate,
+    int resampler)
+{
+    ApplySimd();
+    auto c = std::make_unique<oal_converter>();
+    c->conv = SampleConverter::Create(static_cast<DevFmtType>(src_type), static_cast<DevFmtType>(dst_type), channels,
+        src_rate, dst_rate, static_cast<Resampler>(resampler));
+    return c->conv ? c.release() : nullptr;
+}
+uint32_t oal_converter_available_out(oal_converter *c, uint32_t src_frames) { return c->conv->availableOut(src_frames); }
+/* returns the frames written; *consumed_bytes = how far convert() advanced the source pointer */
+uint32_t oal_converter_convert(oal_converter *c, const void *src, uint32_t *src_frames, void *dst, uint32_t dst_frames,
+    uint64_t *consumed_bytes)
+{
+    const void *p = src;
+    auto const n = c->conv->convert(&p, src_frames, dst, dst_frames);
+    *consumed_bytes = static_cast<uint64_t>(static_cast<const char*>(p) - static_cast<const char*>(src));
+    return n;
+}
+void oal_converter_destroy(oal_converter *c) { delete c; }
 
 /* PPhaseResampler (common/polyphase_resampler.cpp): init(src_rate, dst_rate) + process(in, out) */
 void oal_pphase_resample(uint32_t src_rate, uint32_t dst_rate, const double *in, size_t n_in, double *out,
