@@ -421,6 +421,34 @@ int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_stat
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);
 /* Enables/disables the event timing above (off by default: it adds two event records). */
 int oalgpu_set_timing(oalgpu_context *ctx, int enable);
+/* ---- the small EffectStates: equalizer, ring modulator, echo, dedicated ------------------------
+ * EffectState::deviceUpdate / update / process (core/effects/base.h:197-209) of alc/effects/{equalizer,modulator,
+ * echo,dedicated}.cpp.  create = deviceUpdate; update takes the effect's EFX properties (core/effects/base.h:
+ * 116-169) and what update() derives from the ambisonic layer, resolved by the caller:
+ *   equalizer, modulator  target_channels[num_in] / gains[num_in] = mChans[i].mTargetChannel / mTargetGain
+ *                         (MixParams::setAmbiMixParams(slot->Wet, slot->Gain, ...); OALGPU_INVALID_CHANNEL: unused)
+ *   echo                  gains[2][num_out_lines] = mGains[tap].Target (ComputePanGains of the two taps)
+ *   dedicated             props = NULL, gains[num_out_lines] = mTargetGains (Gain on the dialog / LFE line)
+ * process: wet_in = the slot's wet bus (num_in x 1024; echo and dedicated use channel 0), out_lines = num_out_lines
+ * x 1024, added to.  Like the reverb these keep the reference's operation order in both math modes: the output
+ * is bit-identical to the reference's, except the modulator's sinusoid carrier (the GPU's sinf against libm). */
+enum oalgpu_effect_kind { OALGPU_EFFECT_EQUALIZER = 0, OALGPU_EFFECT_MODULATOR, OALGPU_EFFECT_ECHO, OALGPU_EFFECT_DEDICATED };
+enum oalgpu_modulator_waveform { OALGPU_MODULATOR_SINUSOID = 0, OALGPU_MODULATOR_SAWTOOTH, OALGPU_MODULATOR_SQUARE };
+#define OALGPU_INVALID_CHANNEL 0xffffffffu
+typedef struct oalgpu_equalizer_props {              /* EqualizerProps */
+    float low_cutoff, low_gain, mid1_center, mid1_gain, mid1_width, mid2_center, mid2_gain, mid2_width, high_cutoff, high_gain;
+} oalgpu_equalizer_props;
+typedef struct oalgpu_modulator_props { float frequency, high_pass_cutoff; int32_t waveform; } oalgpu_modulator_props;
+typedef struct oalgpu_echo_props { float delay, lr_delay, damping, feedback, spread; } oalgpu_echo_props;
+typedef struct oalgpu_effect oalgpu_effect;
+int  oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_rate, uint32_t num_in_channels,
+    uint32_t num_out_lines, oalgpu_effect **out);
+void oalgpu_effect_destroy(oalgpu_effect *effect);
+int  oalgpu_effect_update(oalgpu_effect *effect, const void *props, const uint32_t *target_channels, const float *gains);
+int  oalgpu_effect_process(oalgpu_effect *effect, const float *wet_in, float *out_lines, uint32_t n);
+/* Attach to effect slot `slot` of a context (like oalgpu_slot_set_convolution); NULL detaches. */
+int  oalgpu_slot_set_effect(oalgpu_context *ctx, uint32_t slot, oalgpu_effect *effect);
+
 /* ---- SampleConverter (core/converter.h:15-59, core/converter.cpp:175-330) ------------------------
  * The format and rate converter of the capture side and of some backends -- the second consumer of the
  * resamplers: interleaved frames of `channels` samples of src_type (oalgpu_output_type = DevFmtType order) at

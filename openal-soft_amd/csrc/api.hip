@@ -108,6 +108,7 @@ struct oalgpu_context {
     bool useWave{false};                   // FAST contexts without sends (HRTF, or <= 8 dry lines): voice_wave.hip
     std::vector<oalgpu_convolution*> slotConv;   // per effect slot: attached convolution reverb (not owned)
     std::vector<oalgpu_reverb*> slotReverb;      // per effect slot: attached EAX reverb (not owned)
+    std::vector<oalgpu_effect*> slotEffect;      // per effect slot: equalizer / modulator / echo / dedicated (not owned)
     DevBuf<uint32_t> reverbTicket;               // mix-out order word of a reverb batch launch
 
     DevBuf<float> tables;
@@ -644,6 +645,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.mixLines = mixLines;
     c->slotConv.assign(desc->num_slots, nullptr);
     c->slotReverb.assign(desc->num_slots, nullptr);
+    c->slotEffect.assign(desc->num_slots, nullptr);
     HIP_TRY(c->reverbTicket.alloc(1)); HIP_TRY(c->reverbTicket.zero());
     uint32_t vpg = desc->voices_per_group;
     if(vpg == 0)
@@ -1269,6 +1271,10 @@ static int RunEffects(oalgpu_context *c, hipStream_t s, uint32_t samples_to_do)
         {
             if(int rc = oalgpu_convolution_process_device(conv, s, wet, L.bus, samples_to_do)) return rc;
         }
+        if(oalgpu_effect *fx = c->slotEffect[slot])
+        {
+            if(int rc = oalgpu_effect_process_device(fx, s, wet, L.bus, samples_to_do)) return rc;
+        }
     }
     // the EAX reverbs of all slots: one launch, instances side by side, mix-out in slot order
     oalgpu_reverb *revs[kRvBatchMax];
@@ -1438,7 +1444,7 @@ int oalgpu_update_graph_create(oalgpu_context *c, oalgpu_param_block *const *par
     if(!(c->useWave && c->ownStream) || c->serialOnly || c->comm || c->timing)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: needs an unsharded FAST context (wavefront kernel) on its own streams, timing off");
     for(uint32_t s = 0; s < c->L.numSlots; ++s)
-        if(c->slotConv[s] || c->slotReverb[s])
+        if(c->slotConv[s] || c->slotReverb[s] || c->slotEffect[s])
             return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: an effect's launch arguments advance on the host every update; detach the slots' effects");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(post_process && c->L.hrtf && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
@@ -1740,6 +1746,17 @@ int oalgpu_slot_set_convolution(oalgpu_context *c, uint32_t slot, oalgpu_convolu
         return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_convolution: the effect mixes into more lines than the context has dry lines");
     if(int rc = oalgpu_sync(c)) return rc;
     c->slotConv[slot] = conv;
+    return OALGPU_OK;
+}
+
+int oalgpu_slot_set_effect(oalgpu_context *c, uint32_t slot, oalgpu_effect *fx)
+{
+    if(!c || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_effect: bad slot");
+    // (a dedicated effect may address the real output lines, which follow the dry lines in the bus block)
+    if(fx && (EffectOutLines(fx) > c->L.numDry + c->L.numReal || EffectInChannels(fx) > c->L.wetChannels))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_effect: the effect's lines do not fit the context's buses");
+    if(int rc = oalgpu_sync(c)) return rc;
+    c->slotEffect[slot] = fx;
     return OALGPU_OK;
 }
 

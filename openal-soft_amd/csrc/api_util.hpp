@@ -15,6 +15,12 @@ int UseDevice(int device);
 // lines an effect instance mixes into (reverb_api.hip / conv_api.hip)
 uint32_t ReverbOutLines(const oalgpu_reverb *r);
 uint32_t ConvOutLines(const oalgpu_convolution *c);
+uint32_t EffectOutLines(const oalgpu_effect *e);
+uint32_t EffectInChannels(const oalgpu_effect *e);
+} // namespace oalgpu
+// the effect's block on device memory, asynchronous on `hip_stream` (effects_api.hip)
+int oalgpu_effect_process_device(oalgpu_effect *e, void *hip_stream, const float *wet_in_dev, float *out_lines_dev, uint32_t n);
+namespace oalgpu {
 
 #define HIP_TRY(expr) do { \
     const hipError_t err_ = (expr); \

@@ -1,0 +1,169 @@
+// The small EffectStates behind the effect-slot boundary, one workgroup per instance:
+//
+//   EqualizerState::process   alc/effects/equalizer.cpp:167-187   per wet channel: two DualBiquads, MixSamples 1 -> 1
+//   ModulatorState::process   alc/effects/modulator.cpp:165-209   per wet channel: high-pass, x carrier, MixSamples 1 -> 1
+//   EchoState::process        alc/effects/echo.cpp:119-163        two-tap feedback delay with a damping shelf, MixSamples 1 -> N
+//   DedicatedState::process   alc/effects/dedicated.cpp:102-108   MixSamples 1 -> N
+//
+// (update() -- coefficient design, delays, the carrier's period -- is host work, effects_api.hip; what it derives
+// from the ambisonic layer, the target channel / gain per wet channel and the panned gains, comes from the caller.)
+// Like the EAX reverb, these keep the reference's operation order in every mode: the recurrences run one lane per
+// channel (four channels side by side), everything around them over the workgroup -- the output is bit-identical
+// to the reference's, except the sinusoid carrier (the GPU's sinf against libm).  A block-scan form of the
+// biquads was built first and dropped: the equalizer's high-Q peaking sections and the modulator's 200 Hz
+// high-pass amplify float32 rounding so much (the reference's own serial loop is 7e-6 of the block maximum away
+// from a double-precision run) that a reordered evaluation lands at 1e-4 .. 1e-3, which is no parity statement.
+#include "wave_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace oalgpu {
+namespace {
+
+// BiquadFilter::process, core/filters/biquad.cpp:176-201
+template<typename SrcPtr, typename DstPtr>
+__device__ __forceinline__ void BiquadRaw(BiquadState &f, SrcPtr src, DstPtr dst, uint32_t n)
+{
+    float z1 = f.z1, z2 = f.z2;
+    const float b0 = f.b0, b1 = f.b1, b2 = f.b2, a1 = f.a1, a2 = f.a2;
+    for(uint32_t i = 0; i < n; ++i)
+    {
+        const float x = src[i];
+        const float y = x * b0 + z1;
+        z1 = x * b1 - y * a1 + z2;
+        z2 = x * b2 - y * a2;
+        dst[i] = y;
+    }
+    f.z1 = z1; f.z2 = z2;
+}
+
+__device__ __forceinline__ float Carrier(int wave, uint32_t index, float scale)
+{   // SinFunc / SawFunc / SquareFunc / OneFunc, modulator.cpp:49-69
+    switch(wave)
+    {
+    case 1: return sinf(float(index) * scale);
+    case 2: return float(index) * scale - 1.0f;
+    case 3: return float(float(index) * scale < 0.5f) * 2.0f - 1.0f;
+    default: return 1.0f;
+    }
+}
+
+// MixSamples(src, out[c], Current, Target, counter) for c < nlines, thread = frames t, t + 256, ..
+__device__ __forceinline__ void MixOntoLines(const float *src, float *out, uint32_t nlines, float *cur, const float *tgt,
+    uint32_t counter, uint32_t n, uint32_t t)
+{
+    for(uint32_t c = 0; c < nlines; ++c)
+    {
+        const MixLineGain g = PrepareMixLine(cur[c], tgt[c], counter, n);
+        for(uint32_t p = t; p < n; p += 256u)
+            if(MixLineActive(g, p)) { float *o = out + size_t{c} * kLine + p; *o = *o + MixLineValue(g, src[p], p); }
+    }
+    __syncthreads();
+    for(uint32_t c = t; c < nlines; c += 256u) cur[c] = PrepareMixLine(cur[c], tgt[c], counter, n).newCur;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) EffectKernel(FxLaunch F)
+{
+    __shared__ float buf[4][kLine];
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t n = F.n;
+    FxState &S = *F.st;
+
+    if(F.kind == OALGPU_EFFECT_EQUALIZER || F.kind == OALGPU_EFFECT_MODULATOR)
+    {
+        const bool mod = F.kind == OALGPU_EFFECT_MODULATOR;
+        for(uint32_t c0 = 0; c0 < F.numIn; c0 += 4u)
+        {
+            const uint32_t c = c0 + wave;
+            const bool mine = c < F.numIn && F.target[c] < F.nlines;
+            if(mine)
+            {
+                const float *in = F.wetIn + size_t{c} * kLine;
+                for(uint32_t i = lane; i < n; i += 64u) buf[wave][i] = in[i];
+                WaveSync();
+                BiquadState f0 = S.bq[c][0], f1 = S.bq[c][1], f2 = S.bq[c][2], f3 = S.bq[c][3];
+                if(lane == 0)
+                {   // the recurrences: one lane per channel, the reference's operation order
+                    if(mod) BiquadRaw(f0, buf[wave], buf[wave], n);
+                    else { BiquadDualRaw(f0, f1, buf[wave], buf[wave], n); BiquadDualRaw(f2, f3, buf[wave], buf[wave], n); }
+                }
+                if(lane == 0)
+                {
+                    S.bq[c][0].z1 = f0.z1; S.bq[c][0].z2 = f0.z2;
+                    if(!mod)
+                    {
+                        S.bq[c][1].z1 = f1.z1; S.bq[c][1].z2 = f1.z2; S.bq[c][2].z1 = f2.z1; S.bq[c][2].z2 = f2.z2;
+                        S.bq[c][3].z1 = f3.z1; S.bq[c][3].z2 = f3.z2;
+                    }
+                }
+                WaveSync();
+                if(mod)
+                    for(uint32_t i = lane; i < n; i += 64u)
+                        buf[wave][i] = buf[wave][i] * Carrier(F.modWave, (F.modIndex + i) % F.modRange, F.modScale);
+            }
+            __syncthreads();
+            // MixSamples in channel order (two channels may share a target line)
+            for(uint32_t w = 0; w < 4u; ++w)
+            {
+                const uint32_t cc = c0 + w;
+                if(cc >= F.numIn || F.target[cc] >= F.nlines) continue;
+                const uint32_t counter = mod ? (n < 64u ? n : 64u) : n;
+                const MixLineGain g = PrepareMixLine(S.cur[cc], F.tgtGain[cc], counter, n);
+                float *out = F.outLines + size_t{F.target[cc]} * kLine;
+                for(uint32_t p = t; p < n; p += 256u)
+                    if(MixLineActive(g, p)) out[p] = out[p] + MixLineValue(g, buf[w][p], p);
+                __syncthreads();
+                if(t == 0) S.cur[cc] = g.newCur;
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    if(F.kind == OALGPU_EFFECT_DEDICATED)
+    {
+        for(uint32_t i = t; i < n; i += 256u) buf[0][i] = F.wetIn[i];
+        __syncthreads();
+        MixOntoLines(buf[0], F.outLines, F.nlines, S.cur, F.tgtGains, n, n, t);
+        return;
+    }
+    // ---- echo: buf[0] = first tap, buf[1] = second tap, buf[2] = what goes into the delay line, buf[3] = input
+    const uint32_t mask = F.delayMask, d1 = F.tap[0], d2 = F.tap[1], off = F.offset;
+    for(uint32_t i = t; i < n; i += 256u)
+    {
+        buf[3][i] = F.wetIn[i];
+        // the taps as far as they lie before this block; the rest is written by the block itself
+        buf[0][i] = F.delay[(off + i - d1) & mask];
+        buf[1][i] = F.delay[(off + i - d2) & mask];
+    }
+    __syncthreads();
+    if(t == 0)
+    {   // delaybuf[offset] = in; out1 = delaybuf[tap1]; out2 = delaybuf[tap2]; delaybuf[offset] += filter(out2) * feed
+        BiquadState f = S.bq[0][0];
+        float z1 = f.z1, z2 = f.z2;
+        for(uint32_t i = 0; i < n; ++i)
+        {
+            // a tap shorter than the block reads what an earlier iteration stored; a tap of exactly 0 distance
+            // cannot occur (mDelayTap[0] >= 1)
+            if(i >= d1) buf[0][i] = buf[2][i - d1];
+            if(i >= d2) buf[1][i] = buf[2][i - d2];
+            const float x = buf[1][i];
+            const float y = x * f.b0 + z1;                       // BiquadFilter::processOne
+            z1 = x * f.b1 - y * f.a1 + z2;
+            z2 = x * f.b2 - y * f.a2;
+            buf[2][i] = buf[3][i] + y * F.feedGain;
+        }
+        S.bq[0][0].z1 = z1; S.bq[0][0].z2 = z2;
+    }
+    __syncthreads();
+    for(uint32_t i = t; i < n; i += 256u) F.delay[(off + i) & mask] = buf[2][i];
+    MixOntoLines(buf[0], F.outLines, F.nlines, S.cur, F.tgtGains, n, n, t);
+    MixOntoLines(buf[1], F.outLines, F.nlines, S.cur + 32, F.tgtGains + F.nlines, n, n, t);
+}
+
+} // namespace
+
+void LaunchEffect(hipStream_t s, const FxLaunch &F) { hipLaunchKernelGGL(EffectKernel, dim3(1), dim3(256), 0, s, F); }
+
+} // namespace oalgpu

@@ -172,6 +172,24 @@ void LaunchBFormatDecode(hipStream_t s, bool exact, float *out, const float *lin
 void LaunchDither(hipStream_t s, float *lines, uint32_t nlines, uint32_t n, float quantScale, uint32_t seed);
 uint32_t DitherAdvanceSeed(uint32_t seed, uint32_t draws);
 void LaunchWriteSamples(hipStream_t s, int sampleType, const float *lines, uint32_t nlines, uint32_t n, uint32_t frameStep, void *out);
+// ---- launcher (effects_kernels.hip): equalizer / modulator / echo / dedicated, one workgroup per instance ----
+constexpr uint32_t kFxMaxIn = 16;
+struct FxState {                       // device-resident per instance
+    BiquadState bq[kFxMaxIn][4];       // EQ: four per wet channel; MOD: [c][0] high-pass; ECHO: [0][0] damping shelf
+    float cur[64];                     // Current gains -- EQ / MOD: [wet channel]; DEDICATED: [line]; ECHO: [tap][32]
+};
+struct FxLaunch {
+    int kind, exact;
+    uint32_t numIn, nlines, n;
+    FxState *st;
+    const float *wetIn; float *outLines;
+    uint32_t target[kFxMaxIn]; float tgtGain[kFxMaxIn];   // EQ / MOD: mChans[c].mTargetChannel / mTargetGain
+    const float *tgtGains;                                // DEDICATED: [nlines]; ECHO: [2][nlines] (device memory)
+    uint32_t modIndex, modRange; float modScale; int modWave;        // 0 one, 1 sin, 2 saw, 3 square
+    float *delay; uint32_t delayMask, offset, tap[2]; float feedGain;
+};
+void LaunchEffect(hipStream_t s, const FxLaunch &F);
+
 // SampleConverter::convert (core/converter.cpp:236-330): one launch per call, see output_kernels.hip
 struct ConvertChunk { uint32_t srcBase, frac0, dstBase, dstSize; };      // timeline index of SrcData[0], DataPosFrac, first output, DstSize
 struct ConvertJob {

@@ -74,7 +74,17 @@ void PrepareResampler(int resampler, uint32_t increment, oalgpu_interp_state *ou
 void DesignBiquadFromSlope(int type, float f0norm, float gain, float slope, float c[5])
 {
     gain = std::max(gain, 0.001f);                       // setParamsFromSlope: -60 dB floor
-    const float rcpQ = std::sqrt((gain + 1.0f / gain) * (1.0f / slope - 1.0f) + 2.0f);
+    DesignBiquad(type, f0norm, gain, std::sqrt((gain + 1.0f / gain) * (1.0f / slope - 1.0f) + 2.0f), c);
+}
+
+void DesignBiquadFromBandwidth(int type, float f0norm, float gain, float bandwidth, float c[5])
+{   // rcpQFromBandwidth, biquad.h:71-75
+    const float w0 = 3.14159265358979323846f * 2.0f * f0norm;
+    DesignBiquad(type, f0norm, gain, 2.0f * std::sinh(std::log(2.0f) / 2.0f * bandwidth * w0 / std::sin(w0)), c);
+}
+
+void DesignBiquad(int type, float f0norm, float gain, float rcpQ, float c[5])
+{
     gain = std::max(gain, 0.00001f);                     // SetParams: -100 dB floor
     const float w0 = 3.14159265358979323846f * 2.0f * std::min(f0norm, 0.49f);
     const float sw = std::sin(w0), cw = std::cos(w0);

@@ -11,6 +11,9 @@ void PrepareResampler(int resampler, uint32_t increment, oalgpu_interp_state *ou
 // BiquadFilter::SetParams coefficient design, core/filters/biquad.cpp:48-129, for
 // setParamsFromSlope (biquad.h:172-177).  Writes b0,b1,b2,a1,a2 (a0-normalised) to coeffs[5].
 void DesignBiquadFromSlope(int type, float f0norm, float gain, float slope, float coeffs[5]);
+// setParamsFromBandwidth (biquad.h:111-113) and SetParams itself (rcpQ given)
+void DesignBiquadFromBandwidth(int type, float f0norm, float gain, float bandwidth, float coeffs[5]);
+void DesignBiquad(int type, float f0norm, float gain, float rcpQ, float coeffs[5]);
 
 // check_set (biquad.cpp:38-43) over the 5 coefficients + BiquadInterpFilter::setParams state
 // machine (:131-149), applied to a host-side filter image.

@@ -522,6 +522,10 @@ class Scene:
         lib.oalgpu_slot_set_convolution.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         check(lib.oalgpu_slot_set_convolution(self.h, slot, conv.h if conv is not None else None))
 
+    def set_slot_effect(self, slot, fx):
+        lib.oalgpu_slot_set_effect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        check(lib.oalgpu_slot_set_effect(self.h, slot, fx.h if fx is not None else None), "oalgpu_slot_set_effect")
+
     def set_slot_reverb(self, slot, rev):
         lib.oalgpu_slot_set_reverb.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         check(lib.oalgpu_slot_set_reverb(self.h, slot, rev.h if rev is not None else None))
@@ -660,6 +664,54 @@ class Convolution:
     def close(self):
         if self.h:
             lib.oalgpu_convolution_destroy(self.h)
+            self.h = None
+
+
+EFFECT_EQUALIZER, EFFECT_MODULATOR, EFFECT_ECHO, EFFECT_DEDICATED = range(4)
+INVALID_CHANNEL = 0xffffffff
+
+
+class Effect:
+    """oalgpu_effect: EqualizerState / ModulatorState / EchoState / DedicatedState (alc/effects/*.cpp)."""
+
+    def __init__(self, kind, num_out_lines, num_in=4, sample_rate=48000, mode=MATH_FAST, device=0):
+        lib.oalgpu_effect_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.oalgpu_effect_destroy.argtypes = [C.c_void_p]
+        lib.oalgpu_effect_destroy.restype = None
+        lib.oalgpu_effect_update.argtypes = [C.c_void_p, C.c_void_p, u32p, f32p]
+        lib.oalgpu_effect_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
+        lib.oalgpu_slot_set_effect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        self.kind, self.nlines, self.num_in = kind, num_out_lines, num_in
+        h = C.c_void_p()
+        check(lib.oalgpu_effect_create(device, mode, kind, sample_rate, num_in, num_out_lines, C.byref(h)), "oalgpu_effect_create")
+        self.h = h
+
+    def update(self, props, targets, gains):
+        """props: the property struct's fields in order (the modulator's waveform as its third); None for dedicated"""
+        g = np.ascontiguousarray(gains, np.float32)
+        tp = None
+        if targets is not None:
+            t = np.ascontiguousarray(targets, np.uint32)
+            tp = t.ctypes.data_as(u32p)
+        pp = None
+        if props is not None:
+            if self.kind == EFFECT_MODULATOR:
+                raw = np.zeros(3, np.float32)
+                raw[:2] = props[:2]
+                raw.view(np.int32)[2] = int(props[2])
+            else:
+                raw = np.ascontiguousarray(props, np.float32)
+            pp = raw.ctypes.data_as(C.c_void_p)
+        check(lib.oalgpu_effect_update(self.h, pp, tp, _fp(g)), "oalgpu_effect_update")
+
+    def process(self, wet_in, out_lines, n=BUFFER_LINE):
+        wet_in = np.ascontiguousarray(wet_in, np.float32)
+        assert wet_in.shape == (self.num_in, BUFFER_LINE) and out_lines.shape == (self.nlines, BUFFER_LINE)
+        check(lib.oalgpu_effect_process(self.h, _fp(wet_in), _fp(out_lines), n), "oalgpu_effect_process")
+
+    def close(self):
+        if self.h:
+            lib.oalgpu_effect_destroy(self.h)
             self.h = None
 
 

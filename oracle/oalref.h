@@ -259,6 +259,16 @@ oal_conv *oal_conv_create_ex(uint32_t sample_rate, uint32_t num_out_lines, uint3
     uint32_t ir_len, uint32_t channels, uint32_t ir_rate);
 void oal_conv_set_orientation(oal_conv *c, const float at[3], const float up[3]);
 uint32_t oal_conv_channel_info(oal_conv *c, float *targets, float *hf, float *lf, int *upsample, float *xover_norm);
+/* The small EffectStates (alc/effects/{equalizer,modulator,echo,dedicated}.cpp), compiled reference only.
+ * kind: 0 equalizer, 1 modulator, 2 echo, 3 dedicated.  The device has num_out_lines dry lines with the identity
+ * AmbiMap and num_real real output lines (FrontCenter at index front_center, < 0: none); the slot's wet bus has 4
+ * lines, identity AmbiMap.  props = the floats of the effect's property struct in declaration order. */
+typedef struct oal_effect oal_effect;
+oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center);
+void oal_effect_update(oal_effect *e, const float *props, float slot_gain);
+void oal_effect_process(oal_effect *e, const float *wet_in, float *lines, uint32_t n);
+int oal_effect_targets_real(oal_effect *e);
+void oal_effect_destroy(oal_effect *e);
 /* SampleConverter (core/converter.cpp:175-330), compiled reference only: types in DevFmtType order (0 = int8 ..
  * 6 = float), `resampler` as for oal_prepare_resampler; convert() returns the frames written and reports how
  * many source bytes it consumed and (in *src_frames) how many frames it left */

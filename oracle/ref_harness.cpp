@@ -894,6 +894,87 @@ int oal_scene_set_direct_hrtf(oal_scene *s, const float *chan_coeffs, const floa
 /* (the convolution reverb lives in ref_conv.cpp, which compiles alc/effects/convolution.cpp itself to
  * reach its file-local ConvolutionState) */
 
+/* ---- the small EffectStates: alc/effects/{equalizer,modulator,echo,dedicated}.cpp behind their factories ---- */
+struct oal_effect {
+    std::unique_ptr<Dev> dev;
+    std::unique_ptr<Ctx> ctx;
+    EffectSlotBase slot;
+    al::intrusive_ptr<EffectState> state;
+    EffectProps props;
+    std::array<FloatBufferLine, 4> wet{};
+    int kind{};
+};
+
+/* kind: 0 equalizer, 1 modulator, 2 echo, 3 dedicated; a device with num_out_lines dry lines (identity AmbiMap)
+ * and, for the dedicated effect, num_real real output lines whose FrontCenter sits at front_center (< 0: none) */
+oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center)
+{
+    ApplySimd();
+    auto e = std::make_unique<oal_effect>();
+    e->kind = kind;
+    e->dev = std::make_unique<Dev>();
+    auto &dev = *e->dev;
+    dev.mSampleRate = sample_rate;
+    dev.mUpdateSize = BufferLineSize;
+    dev.mBufferSize = BufferLineSize;
+    dev.FmtType = DevFmtFloat;
+    dev.mAmbiOrder = 1;
+    dev.MixBuffer.resize(num_out_lines + num_real);
+    dev.Dry.Buffer = std::span{dev.MixBuffer}.first(num_out_lines);
+    dev.RealOut.Buffer = num_real ? std::span{dev.MixBuffer}.subspan(num_out_lines) : dev.Dry.Buffer;
+    dev.RealOut.ChannelIndex.fill(InvalidChannelIndex);
+    if(front_center >= 0) dev.RealOut.ChannelIndex[FrontCenter] = u8{static_cast<u8::value_t>(front_center)};
+    for(uint32_t i{0};i < num_out_lines;++i) dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, i};
+    e->ctx = std::make_unique<Ctx>(e->dev.get());
+    e->slot.mWetBuffer.resize(4);
+    e->slot.Wet.Buffer = e->slot.mWetBuffer;
+    for(uint32_t i{0};i < 4;++i) e->slot.Wet.AmbiMap[i] = BFChannelConfig{1.0f, i};
+    switch(kind)
+    {
+    case 0: e->state = EqualizerStateFactory_getFactory()->create(); break;
+    case 1: e->state = ModulatorStateFactory_getFactory()->create(); break;
+    case 2: e->state = EchoStateFactory_getFactory()->create(); break;
+    case 3: e->state = DedicatedStateFactory_getFactory()->create(); break;
+    default: return nullptr;
+    }
+    e->state->deviceUpdate(e->dev.get(), nullptr);
+    return e.release();
+}
+
+/* props: the floats of the effect's property struct in declaration order (core/effects/base.h:116-169; the
+ * modulator's waveform and the dedicated effect's target as a float-coded integer) */
+void oal_effect_update(oal_effect *e, const float *p, float slot_gain)
+{
+    switch(e->kind)
+    {
+    case 0: e->props = EqualizerProps{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9]}; break;
+    case 1: e->props = ModulatorProps{p[0], p[1], static_cast<ModulatorWaveform>(static_cast<int>(p[2]))}; break;
+    case 2: e->props = EchoProps{p[0], p[1], p[2], p[3], p[4]}; break;
+    default: e->props = DedicatedProps{static_cast<int>(p[0]) ? DedicatedProps::Lfe : DedicatedProps::Dialog, p[1]}; break;
+    }
+    e->slot.Gain = slot_gain;
+    e->state->update(e->ctx.get(), &e->slot, &e->props, EffectTarget{&e->dev->Dry, &e->dev->RealOut});
+}
+
+/* wet_in: 4 x 1024; lines: (num_out_lines + num_real) x 1024, added to */
+void oal_effect_process(oal_effect *e, const float *wet_in, float *lines, uint32_t n)
+{
+    auto const fpuctl = FPUCtl{};
+    auto &dev = *e->dev;
+    for(size_t c{0};c < 4;++c) std::copy_n(wet_in + c*BufferLineSize, BufferLineSize, e->wet[c].begin());
+    for(size_t l{0};l < dev.MixBuffer.size();++l)
+        std::copy_n(lines + l*BufferLineSize, BufferLineSize, dev.MixBuffer[l].begin());
+    e->state->process(n, e->wet, e->state->mOutTarget);
+    for(size_t l{0};l < dev.MixBuffer.size();++l)
+        std::copy_n(dev.MixBuffer[l].begin(), BufferLineSize, lines + l*BufferLineSize);
+}
+
+/* 1 when the state's output target is the real output lines (a dedicated effect with a FrontCenter / LFE line) */
+int oal_effect_targets_real(oal_effect *e)
+{ return e->state->mOutTarget.data() == e->dev->RealOut.Buffer.data() && e->dev->RealOut.Buffer.data() != e->dev->Dry.Buffer.data(); }
+
+void oal_effect_destroy(oal_effect *e) { delete e; }
+
 /* SampleConverter (core/converter.cpp:175-330): Create / availableOut / convert as they are */
 struct oal_converter { SampleConverterPtr conv; };
 oal_converter *oal_converter_create(int src_type, int dst_type, uint32_t channels, uint32_t src_rate, uint32_t dst_rate,
