@@ -429,10 +429,14 @@ int oalgpu_set_timing(oalgpu_context *ctx, int enable);
  *                         (MixParams::setAmbiMixParams(slot->Wet, slot->Gain, ...); OALGPU_INVALID_CHANNEL: unused)
  *   echo                  gains[2][num_out_lines] = mGains[tap].Target (ComputePanGains of the two taps)
  *   dedicated             props = NULL, gains[num_out_lines] = mTargetGains (Gain on the dialog / LFE line)
+ *   compressor            props = oalgpu_compressor_props; target_channels / gains as for the equalizer
+ *                         (alc/effects/compressor.cpp: envelope follower on wet channel 0, no gain ramp)
  * process: wet_in = the slot's wet bus (num_in x 1024; echo and dedicated use channel 0), out_lines = num_out_lines
  * x 1024, added to.  Like the reverb these keep the reference's operation order in both math modes: the output
  * is bit-identical to the reference's, except the modulator's sinusoid carrier (the GPU's sinf against libm). */
-enum oalgpu_effect_kind { OALGPU_EFFECT_EQUALIZER = 0, OALGPU_EFFECT_MODULATOR, OALGPU_EFFECT_ECHO, OALGPU_EFFECT_DEDICATED };
+enum oalgpu_effect_kind {
+    OALGPU_EFFECT_EQUALIZER = 0, OALGPU_EFFECT_MODULATOR, OALGPU_EFFECT_ECHO, OALGPU_EFFECT_DEDICATED, OALGPU_EFFECT_COMPRESSOR
+};
 enum oalgpu_modulator_waveform { OALGPU_MODULATOR_SINUSOID = 0, OALGPU_MODULATOR_SAWTOOTH, OALGPU_MODULATOR_SQUARE };
 #define OALGPU_INVALID_CHANNEL 0xffffffffu
 typedef struct oalgpu_equalizer_props {              /* EqualizerProps */
@@ -440,6 +444,7 @@ typedef struct oalgpu_equalizer_props {              /* EqualizerProps */
 } oalgpu_equalizer_props;
 typedef struct oalgpu_modulator_props { float frequency, high_pass_cutoff; int32_t waveform; } oalgpu_modulator_props;
 typedef struct oalgpu_echo_props { float delay, lr_delay, damping, feedback, spread; } oalgpu_echo_props;
+typedef struct oalgpu_compressor_props { int32_t on_off; } oalgpu_compressor_props;
 typedef struct oalgpu_effect oalgpu_effect;
 int  oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_rate, uint32_t num_in_channels,
     uint32_t num_out_lines, oalgpu_effect **out);

@@ -46,7 +46,7 @@ extern "C" {
 int oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_rate, uint32_t num_in_channels,
     uint32_t num_out_lines, oalgpu_effect **out)
 {
-    if(!out || kind < OALGPU_EFFECT_EQUALIZER || kind > OALGPU_EFFECT_DEDICATED || sample_rate < 8000 || num_in_channels < 1
+    if(!out || kind < OALGPU_EFFECT_EQUALIZER || kind > OALGPU_EFFECT_COMPRESSOR || sample_rate < 8000 || num_in_channels < 1
         || num_in_channels > kFxMaxIn || num_out_lines < 1 || num_out_lines > OALGPU_MAX_OUTPUT_CHANNELS)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_effect_create: bad arguments");
     *out = nullptr;
@@ -69,6 +69,13 @@ int oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_ra
         const uint32_t len = NextPow2(uint32_t(0.207f * f + 0.5f) + uint32_t(0.404f * f + 0.5f));
         HIP_TRY(e->delay.alloc(len)); HIP_TRY(e->delay.zero());
         F.delay = e->delay.p; F.delayMask = len - 1u;
+    }
+    if(kind == OALGPU_EFFECT_COMPRESSOR)
+    {   // CompressorState::deviceUpdate, compressor.cpp:87-101: 100 ms from 0.5 to 2, 200 ms back; mEnvFollower = 1
+        F.attackMult = std::pow(2.0f / 0.5f, 1.0f / (float(sample_rate) * 0.1f));
+        F.releaseMult = std::pow(0.5f / 2.0f, 1.0f / (float(sample_rate) * 0.2f));
+        const float one = 1.0f;
+        HIP_TRY(hipMemcpy(reinterpret_cast<char*>(e->st.p) + offsetof(FxState, env), &one, sizeof(one), hipMemcpyHostToDevice));
     }
     // a BiquadFilter starts as the identity (mB0 = 1)
     for(uint32_t c = 0; c < kFxMaxIn; ++c)
@@ -136,6 +143,10 @@ int oalgpu_effect_update(oalgpu_effect *e, const void *props, const uint32_t *ta
                 if(int rc = UploadBiquad(e, ch, 0, c)) return rc;
         }
         break;
+    case OALGPU_EFFECT_COMPRESSOR:
+        if(!props || !target_channels) return Fail(OALGPU_ERR_INVALID, "oalgpu_effect_update: compressor needs props and targets");
+        F.compOn = static_cast<const oalgpu_compressor_props*>(props)->on_off ? 1 : 0;
+        break;
     case OALGPU_EFFECT_ECHO:
         {   // EchoState::update, echo.cpp:93-117 (the two taps' panned gains come from the caller)
             if(!props) return Fail(OALGPU_ERR_INVALID, "oalgpu_effect_update: echo needs props");
@@ -155,7 +166,7 @@ int oalgpu_effect_update(oalgpu_effect *e, const void *props, const uint32_t *ta
         HIP_TRY(e->tgtGains.upload(gains, e->nlines));
         break;
     }
-    if(e->kind == OALGPU_EFFECT_EQUALIZER || e->kind == OALGPU_EFFECT_MODULATOR)
+    if(e->kind == OALGPU_EFFECT_EQUALIZER || e->kind == OALGPU_EFFECT_MODULATOR || e->kind == OALGPU_EFFECT_COMPRESSOR)
         for(uint32_t ch = 0; ch < e->numIn; ++ch) { F.target[ch] = target_channels[ch]; F.tgtGain[ch] = gains[ch]; }
     e->updated = true;
     return OALGPU_OK;

@@ -121,6 +121,34 @@ __global__ void __launch_bounds__(256) EffectKernel(FxLaunch F)
         }
         return;
     }
+    if(F.kind == OALGPU_EFFECT_COMPRESSOR)
+    {   // CompressorState::process, compressor.cpp:115-181: gains[i] = 1 / envelope(i) from wet channel 0, then
+        // out[target c][i] += in[c][i] * gains[i] * gain (no ramp; silent gains skipped)
+        for(uint32_t i = t; i < n; i += 256u) buf[1][i] = F.wetIn[i];
+        __syncthreads();
+        if(t == 0)
+        {
+            float env = S.env;
+            for(uint32_t i = 0; i < n; ++i)
+            {
+                const float amplitude = F.compOn ? fminf(fmaxf(fabsf(buf[1][i]), 0.5f), 2.0f) : 1.0f;
+                if(amplitude > env) env = fminf(env * F.attackMult, amplitude);
+                else if(amplitude < env) env = fmaxf(env * F.releaseMult, amplitude);
+                buf[0][i] = 1.0f / env;
+            }
+            S.env = env;
+        }
+        __syncthreads();
+        for(uint32_t c = 0; c < F.numIn; ++c)
+        {
+            if(F.target[c] >= F.nlines || !(fabsf(F.tgtGain[c]) > 0.00001f)) continue;
+            const float *in = F.wetIn + size_t{c} * kLine;
+            float *out = F.outLines + size_t{F.target[c]} * kLine;
+            for(uint32_t i = t; i < n; i += 256u) out[i] = out[i] + in[i] * buf[0][i] * F.tgtGain[c];
+            __syncthreads();
+        }
+        return;
+    }
     if(F.kind == OALGPU_EFFECT_DEDICATED)
     {
         for(uint32_t i = t; i < n; i += 256u) buf[0][i] = F.wetIn[i];

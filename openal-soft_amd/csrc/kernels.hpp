@@ -177,6 +177,7 @@ constexpr uint32_t kFxMaxIn = 16;
 struct FxState {                       // device-resident per instance
     BiquadState bq[kFxMaxIn][4];       // EQ: four per wet channel; MOD: [c][0] high-pass; ECHO: [0][0] damping shelf
     float cur[64];                     // Current gains -- EQ / MOD: [wet channel]; DEDICATED: [line]; ECHO: [tap][32]
+    float env;                         // CompressorState::mEnvFollower
 };
 struct FxLaunch {
     int kind, exact;
@@ -187,6 +188,7 @@ struct FxLaunch {
     const float *tgtGains;                                // DEDICATED: [nlines]; ECHO: [2][nlines] (device memory)
     uint32_t modIndex, modRange; float modScale; int modWave;        // 0 one, 1 sin, 2 saw, 3 square
     float *delay; uint32_t delayMask, offset, tap[2]; float feedGain;
+    int compOn; float attackMult, releaseMult;                       // compressor
 };
 void LaunchEffect(hipStream_t s, const FxLaunch &F);
 

@@ -667,7 +667,7 @@ class Convolution:
             self.h = None
 
 
-EFFECT_EQUALIZER, EFFECT_MODULATOR, EFFECT_ECHO, EFFECT_DEDICATED = range(4)
+EFFECT_EQUALIZER, EFFECT_MODULATOR, EFFECT_ECHO, EFFECT_DEDICATED, EFFECT_COMPRESSOR = range(5)
 INVALID_CHANNEL = 0xffffffff
 
 
@@ -699,6 +699,8 @@ class Effect:
                 raw = np.zeros(3, np.float32)
                 raw[:2] = props[:2]
                 raw.view(np.int32)[2] = int(props[2])
+            elif self.kind == EFFECT_COMPRESSOR:
+                raw = np.array([int(props[0])], np.int32)
             else:
                 raw = np.ascontiguousarray(props, np.float32)
             pp = raw.ctypes.data_as(C.c_void_p)

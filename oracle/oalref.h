@@ -260,7 +260,7 @@ oal_conv *oal_conv_create_ex(uint32_t sample_rate, uint32_t num_out_lines, uint3
 void oal_conv_set_orientation(oal_conv *c, const float at[3], const float up[3]);
 uint32_t oal_conv_channel_info(oal_conv *c, float *targets, float *hf, float *lf, int *upsample, float *xover_norm);
 /* The small EffectStates (alc/effects/{equalizer,modulator,echo,dedicated}.cpp), compiled reference only.
- * kind: 0 equalizer, 1 modulator, 2 echo, 3 dedicated.  The device has num_out_lines dry lines with the identity
+ * kind: 0 equalizer, 1 modulator, 2 echo, 3 dedicated, 4 compressor.  The device has num_out_lines dry lines with the identity
  * AmbiMap and num_real real output lines (FrontCenter at index front_center, < 0: none); the slot's wet bus has 4
  * lines, identity AmbiMap.  props = the floats of the effect's property struct in declaration order. */
 typedef struct oal_effect oal_effect;

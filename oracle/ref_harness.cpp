@@ -905,7 +905,7 @@ struct oal_effect {
     int kind{};
 };
 
-/* kind: 0 equalizer, 1 modulator, 2 echo, 3 dedicated; a device with num_out_lines dry lines (identity AmbiMap)
+/* kind: 0 equalizer, 1 modulator, 2 echo, 3 dedicated, 4 compressor; a device with num_out_lines dry lines (identity AmbiMap)
  * and, for the dedicated effect, num_real real output lines whose FrontCenter sits at front_center (< 0: none) */
 oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center)
 {
@@ -935,6 +935,7 @@ oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_l
     case 1: e->state = ModulatorStateFactory_getFactory()->create(); break;
     case 2: e->state = EchoStateFactory_getFactory()->create(); break;
     case 3: e->state = DedicatedStateFactory_getFactory()->create(); break;
+    case 4: e->state = CompressorStateFactory_getFactory()->create(); break;
     default: return nullptr;
     }
     e->state->deviceUpdate(e->dev.get(), nullptr);
@@ -950,7 +951,8 @@ void oal_effect_update(oal_effect *e, const float *p, float slot_gain)
     case 0: e->props = EqualizerProps{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9]}; break;
     case 1: e->props = ModulatorProps{p[0], p[1], static_cast<ModulatorWaveform>(static_cast<int>(p[2]))}; break;
     case 2: e->props = EchoProps{p[0], p[1], p[2], p[3], p[4]}; break;
-    default: e->props = DedicatedProps{static_cast<int>(p[0]) ? DedicatedProps::Lfe : DedicatedProps::Dialog, p[1]}; break;
+    case 3: e->props = DedicatedProps{static_cast<int>(p[0]) ? DedicatedProps::Lfe : DedicatedProps::Dialog, p[1]}; break;
+    default: e->props = CompressorProps{p[0] != 0.0f}; break;
     }
     e->slot.Gain = slot_gain;
     e->state->update(e->ctx.get(), &e->slot, &e->props, EffectTarget{&e->dev->Dry, &e->dev->RealOut});

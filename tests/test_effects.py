@@ -56,12 +56,13 @@ MOD = [([440.0, 800.0, 0], 1.0, 1024), (None, 1.0, 1024), ([1000.0, 200.0, 1], 0
 ECHO = [([0.1, 0.1, 0.5, 0.5, -1.0], 1.0, 1024), (None, 1.0, 1024), (None, 1.0, 1024), (None, 1.0, 1024), (None, 1.0, 1024),
         (None, 1.0, 1024), ([0.004, 0.002, 0.2, 0.8, 0.5], 0.9, 1024), (None, 0.9, 777), (None, 0.9, 1024),
         ([0.0001, 0.0, 0.9, 0.9, 0.0], 1.0, 1024), (None, 1.0, 64)]
+COMP = [([1], 1.0, 1024), (None, 1.0, 1024), (None, 1.0, 1024), ([0], 0.6, 1024), (None, 0.6, 300), ([1], 1.0, 1024), (None, 1.0, 1024)]
 DED = [([0, 0.8], 1.0, 1024), (None, 1.0, 1024), ([0, 0.3], 0.5, 500), (None, 0.5, 1024)]
 
 
 def targets_for(L, kind, props, slot_gain, nlines):
     """what the reference's update() resolves on a device with identity AmbiMaps"""
-    if kind in (0, 1):
+    if kind in (0, 1, 4):
         return np.arange(4, dtype=np.uint32), np.full(4, slot_gain, np.float32)
     if kind == 2:
         x = np.float32(props[4])
@@ -76,7 +77,8 @@ def targets_for(L, kind, props, slot_gain, nlines):
 
 
 @pytest.mark.parametrize("mode", ["exact", "fast"])
-@pytest.mark.parametrize("kind,schedule", [(0, EQ), (1, MOD), (2, ECHO), (3, DED)], ids=["equalizer", "modulator", "echo", "dedicated"])
+@pytest.mark.parametrize("kind,schedule", [(0, EQ), (1, MOD), (2, ECHO), (3, DED), (4, COMP)],
+                         ids=["equalizer", "modulator", "echo", "dedicated", "compressor"])
 def test_effect_matches_reference(kind, schedule, mode):
     import oalgpu
     assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
@@ -85,6 +87,8 @@ def test_effect_matches_reference(kind, schedule, mode):
     assert ref
     fx = oalgpu.Effect(kind, NLINES, 4, 48000, oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
     x = wet_blocks(40 + kind, len(schedule))
+    if kind == 4:
+        x *= 6.0                   # the compressor's envelope moves between amplitudes 0.5 and 2
     cur_props = None
     sounded = False
     for u, (props, gain, n) in enumerate(schedule):
