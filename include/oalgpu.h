@@ -435,7 +435,8 @@ int oalgpu_set_timing(oalgpu_context *ctx, int enable);
  * x 1024, added to.  Like the reverb these keep the reference's operation order in both math modes: the output
  * is bit-identical to the reference's, except the modulator's sinusoid carrier (the GPU's sinf against libm). */
 enum oalgpu_effect_kind {
-    OALGPU_EFFECT_EQUALIZER = 0, OALGPU_EFFECT_MODULATOR, OALGPU_EFFECT_ECHO, OALGPU_EFFECT_DEDICATED, OALGPU_EFFECT_COMPRESSOR
+    OALGPU_EFFECT_EQUALIZER = 0, OALGPU_EFFECT_MODULATOR, OALGPU_EFFECT_ECHO, OALGPU_EFFECT_DEDICATED, OALGPU_EFFECT_COMPRESSOR,
+    OALGPU_EFFECT_CHORUS, OALGPU_EFFECT_DISTORTION, OALGPU_EFFECT_AUTOWAH, OALGPU_EFFECT_VMORPHER, OALGPU_EFFECT_FSHIFTER
 };
 enum oalgpu_modulator_waveform { OALGPU_MODULATOR_SINUSOID = 0, OALGPU_MODULATOR_SAWTOOTH, OALGPU_MODULATOR_SQUARE };
 #define OALGPU_INVALID_CHANNEL 0xffffffffu
@@ -445,12 +446,41 @@ typedef struct oalgpu_equalizer_props {              /* EqualizerProps */
 typedef struct oalgpu_modulator_props { float frequency, high_pass_cutoff; int32_t waveform; } oalgpu_modulator_props;
 typedef struct oalgpu_echo_props { float delay, lr_delay, damping, feedback, spread; } oalgpu_echo_props;
 typedef struct oalgpu_compressor_props { int32_t on_off; } oalgpu_compressor_props;
+/* The rest of alc/effects/ (core/effects/base.h:93-169), same boundary:
+ *   chorus / flanger    ChorusState (chorus.cpp): B- to A-Format, four LFO-modulated feedback delay lines, back to B-Format
+ *   distortion          DistortionState (distortion.cpp): 4x oversampled low-pass, wave shaper, band-pass
+ *   autowah             AutowahState (autowah.cpp): envelope follower on wet channel 0 drives a peaking filter per sample
+ *   vocal morpher       VmorpherState (vmorpher.cpp): two 4-band formant filters blended by an LFO (phonemes A E I O U have
+ *                       formants, the others are FormantFilter{} as in the reference)
+ *   frequency shifter   FshifterState (fshifter.cpp): 1024-point STFT in double precision, analytic signal, phase rotation
+ * update: target_channels[c] / gains[c] = mChans[c].mTargetChannel / mTargetGain as for the equalizer (the distortion's
+ * gain includes props.gain, distortion.cpp:172).  The chorus, the distortion and the frequency shifter work on a
+ * first-order A-Format (four lines); on a device above first order their deviceUpdate installs an up-sampler
+ * (chorus.cpp:143-162) -- oalgpu_effect_set_upsampler(order_scales = AmbiScale::GetHFOrderScales(1, device order, 2D),
+ * xover_norm = mXOverFreq / rate), after which update's gains are [4][num_out_lines] = ComputePanGains(target.Main,
+ * AmbiScale::FirstOrderUp[c], gain) (:239-250) and process ends in BandSplitter::processHfScale + MixSamples onto every
+ * line (:393-411).  NULL order_scales: first order again.  Call it before the first update.
+ * Bit-identical to the reference except where libm's sinf / cosf meet the GPU's (chorus sinusoid LFO, autowah filter
+ * coefficients, the morpher's sinusoid LFO: evaluated through double precision, equal almost always).  The pitch
+ * shifter is not built: a phase vocoder picks bins by comparing magnitudes, so the last bit of pffft's butterflies
+ * decides audible detail and no tolerance states parity. */
+enum oalgpu_chorus_waveform { OALGPU_CHORUS_SINUSOID = 0, OALGPU_CHORUS_TRIANGLE };
+enum oalgpu_vmorpher_waveform { OALGPU_VMORPHER_SINUSOID = 0, OALGPU_VMORPHER_TRIANGLE, OALGPU_VMORPHER_SAWTOOTH };
+enum oalgpu_fshifter_direction { OALGPU_FSHIFTER_DOWN = 0, OALGPU_FSHIFTER_UP, OALGPU_FSHIFTER_OFF };
+typedef struct oalgpu_chorus_props { int32_t waveform, phase; float rate, depth, feedback, delay; } oalgpu_chorus_props;
+typedef struct oalgpu_distortion_props { float edge, gain, lowpass_cutoff, eq_center, eq_bandwidth; } oalgpu_distortion_props;
+typedef struct oalgpu_autowah_props { float attack_time, release_time, resonance, peak_gain; } oalgpu_autowah_props;
+typedef struct oalgpu_vmorpher_props {              /* VmorpherProps; phonemes in VMorpherPhenome order (A E I O U = 0..4) */
+    float rate; int32_t phoneme_a, phoneme_b, phoneme_a_coarse_tuning, phoneme_b_coarse_tuning, waveform;
+} oalgpu_vmorpher_props;
+typedef struct oalgpu_fshifter_props { float frequency; int32_t left_direction, right_direction; } oalgpu_fshifter_props;
 typedef struct oalgpu_effect oalgpu_effect;
 int  oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_rate, uint32_t num_in_channels,
     uint32_t num_out_lines, oalgpu_effect **out);
 void oalgpu_effect_destroy(oalgpu_effect *effect);
 int  oalgpu_effect_update(oalgpu_effect *effect, const void *props, const uint32_t *target_channels, const float *gains);
 int  oalgpu_effect_process(oalgpu_effect *effect, const float *wet_in, float *out_lines, uint32_t n);
+int  oalgpu_effect_set_upsampler(oalgpu_effect *effect, const float order_scales[2], float xover_norm);
 /* Attach to effect slot `slot` of a context (like oalgpu_slot_set_convolution); NULL detaches. */
 int  oalgpu_slot_set_effect(oalgpu_context *ctx, uint32_t slot, oalgpu_effect *effect);
 

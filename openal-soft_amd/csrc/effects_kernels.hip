@@ -13,29 +13,12 @@
 // biquads was built first and dropped: the equalizer's high-Q peaking sections and the modulator's 200 Hz
 // high-pass amplify float32 rounding so much (the reference's own serial loop is 7e-6 of the block maximum away
 // from a double-precision run) that a reordered evaluation lands at 1e-4 .. 1e-3, which is no parity statement.
-#include "wave_common.hpp"
+#include "effects_dev.hpp"
 
 #pragma clang fp contract(off)
 
 namespace oalgpu {
 namespace {
-
-// BiquadFilter::process, core/filters/biquad.cpp:176-201
-template<typename SrcPtr, typename DstPtr>
-__device__ __forceinline__ void BiquadRaw(BiquadState &f, SrcPtr src, DstPtr dst, uint32_t n)
-{
-    float z1 = f.z1, z2 = f.z2;
-    const float b0 = f.b0, b1 = f.b1, b2 = f.b2, a1 = f.a1, a2 = f.a2;
-    for(uint32_t i = 0; i < n; ++i)
-    {
-        const float x = src[i];
-        const float y = x * b0 + z1;
-        z1 = x * b1 - y * a1 + z2;
-        z2 = x * b2 - y * a2;
-        dst[i] = y;
-    }
-    f.z1 = z1; f.z2 = z2;
-}
 
 __device__ __forceinline__ float Carrier(int wave, uint32_t index, float scale)
 {   // SinFunc / SawFunc / SquareFunc / OneFunc, modulator.cpp:49-69
@@ -46,21 +29,6 @@ __device__ __forceinline__ float Carrier(int wave, uint32_t index, float scale)
     case 3: return float(float(index) * scale < 0.5f) * 2.0f - 1.0f;
     default: return 1.0f;
     }
-}
-
-// MixSamples(src, out[c], Current, Target, counter) for c < nlines, thread = frames t, t + 256, ..
-__device__ __forceinline__ void MixOntoLines(const float *src, float *out, uint32_t nlines, float *cur, const float *tgt,
-    uint32_t counter, uint32_t n, uint32_t t)
-{
-    for(uint32_t c = 0; c < nlines; ++c)
-    {
-        const MixLineGain g = PrepareMixLine(cur[c], tgt[c], counter, n);
-        for(uint32_t p = t; p < n; p += 256u)
-            if(MixLineActive(g, p)) { float *o = out + size_t{c} * kLine + p; *o = *o + MixLineValue(g, src[p], p); }
-    }
-    __syncthreads();
-    for(uint32_t c = t; c < nlines; c += 256u) cur[c] = PrepareMixLine(cur[c], tgt[c], counter, n).newCur;
-    __syncthreads();
 }
 
 __global__ void __launch_bounds__(256) EffectKernel(FxLaunch F)

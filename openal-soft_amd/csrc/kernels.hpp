@@ -192,6 +192,39 @@ struct FxLaunch {
 };
 void LaunchEffect(hipStream_t s, const FxLaunch &F);
 
+// ---- launcher (effects2_kernels.hip): chorus / flanger, distortion, autowah, vocal morpher, frequency shifter ----
+struct Fx2State {                      // device-resident per instance
+    float cur[kFxMaxIn];               // mChans[c].mCurrentGain
+    float upCur[4][32];                // UpsampleParams::mCurrentGains of the A-Format effects
+    float split[4][3];                 // UpsampleParams::mSplitter: lp_z1, lp_z2, ap_z1
+    BiquadState lp[4], bp[4];          // distortion: mChans[c].mLowpass / mBandpass
+    float envDelay, awZ[kFxMaxIn][2];  // autowah: mEnvDelay, mChans[c].mFilter
+    float vmS[kFxMaxIn][8][2];         // vocal morpher: [channel][vowel A 0..3 | vowel B 4..7] {mS1, mS2}
+};
+struct FsPair { double x, y; };        // std::complex<double>
+struct Fx2Launch {
+    int kind;
+    uint32_t numIn, nlines, n;
+    Fx2State *st;
+    const float *wetIn; float *outLines;
+    uint32_t target[kFxMaxIn]; float tgtGain[kFxMaxIn];
+    int upsample; float hfScale[2], splitCoeff; const float *upTgt;       // mUpsampler: [4][32] target gains (device memory)
+    // chorus (alc/effects/chorus.cpp)
+    int chWave; uint32_t lfoStart[2], lfoRange; float lfoScale, chDepth; int32_t chDelay; float chFeedback;
+    uint32_t chAvgDelay, chHist;
+    float *delay; uint32_t delayMask, offset; const float *cubic;
+    // distortion
+    float edgeCoeff;
+    // autowah
+    float attackRate, releaseRate, resonanceGain, peakGain, freqMinNorm, bandwidthNorm;
+    // vocal morpher: the eight formants (the same for every channel)
+    int vmWave; uint32_t vmIndex, vmStep; float vmG[8], vmGain[8];
+    // frequency shifter
+    double *fsIn; FsPair *fsOutFifo, *fsAccum, *fsOutdata; const FsPair *fsTw, *fsPhase; const float *fsWindow;
+    uint32_t fsCount, fsPos, fsPhaseStep[4], fsPhaseIdx[4]; double fsSign[4];
+};
+void LaunchEffect2(hipStream_t s, const Fx2Launch &F, uint32_t ldsBytes);
+
 // SampleConverter::convert (core/converter.cpp:236-330): one launch per call, see output_kernels.hip
 struct ConvertChunk { uint32_t srcBase, frac0, dstBase, dstSize; };      // timeline index of SrcData[0], DataPosFrac, first output, DstSize
 struct ConvertJob {

@@ -667,12 +667,16 @@ class Convolution:
             self.h = None
 
 
-EFFECT_EQUALIZER, EFFECT_MODULATOR, EFFECT_ECHO, EFFECT_DEDICATED, EFFECT_COMPRESSOR = range(5)
+(EFFECT_EQUALIZER, EFFECT_MODULATOR, EFFECT_ECHO, EFFECT_DEDICATED, EFFECT_COMPRESSOR, EFFECT_CHORUS, EFFECT_DISTORTION,
+ EFFECT_AUTOWAH, EFFECT_VMORPHER, EFFECT_FSHIFTER) = range(10)
+# which fields of the property struct are integers (the rest are floats), in declaration order
+_EFFECT_INT_FIELDS = {EFFECT_MODULATOR: (2,), EFFECT_COMPRESSOR: (0,), EFFECT_CHORUS: (0, 1), EFFECT_VMORPHER: (1, 2, 3, 4, 5),
+                      EFFECT_FSHIFTER: (1, 2)}
 INVALID_CHANNEL = 0xffffffff
 
 
 class Effect:
-    """oalgpu_effect: EqualizerState / ModulatorState / EchoState / DedicatedState (alc/effects/*.cpp)."""
+    """oalgpu_effect: the EffectStates of alc/effects/*.cpp other than the reverb and the convolution."""
 
     def __init__(self, kind, num_out_lines, num_in=4, sample_rate=48000, mode=MATH_FAST, device=0):
         lib.oalgpu_effect_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -681,6 +685,7 @@ class Effect:
         lib.oalgpu_effect_update.argtypes = [C.c_void_p, C.c_void_p, u32p, f32p]
         lib.oalgpu_effect_process.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
         lib.oalgpu_slot_set_effect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.oalgpu_effect_set_upsampler.argtypes = [C.c_void_p, f32p, C.c_float]
         self.kind, self.nlines, self.num_in = kind, num_out_lines, num_in
         h = C.c_void_p()
         check(lib.oalgpu_effect_create(device, mode, kind, sample_rate, num_in, num_out_lines, C.byref(h)), "oalgpu_effect_create")
@@ -695,16 +700,16 @@ class Effect:
             tp = t.ctypes.data_as(u32p)
         pp = None
         if props is not None:
-            if self.kind == EFFECT_MODULATOR:
-                raw = np.zeros(3, np.float32)
-                raw[:2] = props[:2]
-                raw.view(np.int32)[2] = int(props[2])
-            elif self.kind == EFFECT_COMPRESSOR:
-                raw = np.array([int(props[0])], np.int32)
-            else:
-                raw = np.ascontiguousarray(props, np.float32)
+            raw = np.ascontiguousarray(props, np.float32).copy()
+            for k in _EFFECT_INT_FIELDS.get(self.kind, ()):
+                raw.view(np.int32)[k] = int(props[k])
             pp = raw.ctypes.data_as(C.c_void_p)
         check(lib.oalgpu_effect_update(self.h, pp, tp, _fp(g)), "oalgpu_effect_update")
+
+    def set_upsampler(self, order_scales, xover_norm):
+        """the A-Format effects on a device above first order; None: first order again"""
+        sc = None if order_scales is None else np.ascontiguousarray(order_scales, np.float32)
+        check(lib.oalgpu_effect_set_upsampler(self.h, None if sc is None else _fp(sc), xover_norm), "oalgpu_effect_set_upsampler")
 
     def process(self, wet_in, out_lines, n=BUFFER_LINE):
         wet_in = np.ascontiguousarray(wet_in, np.float32)

@@ -265,6 +265,8 @@ uint32_t oal_conv_channel_info(oal_conv *c, float *targets, float *hf, float *lf
  * lines, identity AmbiMap.  props = the floats of the effect's property struct in declaration order. */
 typedef struct oal_effect oal_effect;
 oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center);
+oal_effect *oal_effect_create_ex(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center,
+    uint32_t ambi_order, int horizontal, float xover_freq, uint32_t wet_channels);
 void oal_effect_update(oal_effect *e, const float *props, float slot_gain);
 void oal_effect_process(oal_effect *e, const float *wet_in, float *lines, uint32_t n);
 int oal_effect_targets_real(oal_effect *e);

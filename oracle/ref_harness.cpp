@@ -901,24 +901,33 @@ struct oal_effect {
     EffectSlotBase slot;
     al::intrusive_ptr<EffectState> state;
     EffectProps props;
-    std::array<FloatBufferLine, 4> wet{};
+    std::array<FloatBufferLine, 9> wet{};
+    size_t numWet{4};
     int kind{};
 };
 
-/* kind: 0 equalizer, 1 modulator, 2 echo, 3 dedicated, 4 compressor; a device with num_out_lines dry lines (identity AmbiMap)
- * and, for the dedicated effect, num_real real output lines whose FrontCenter sits at front_center (< 0: none) */
-oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center)
+/* kind: 0 equalizer, 1 modulator, 2 echo, 3 dedicated, 4 compressor, 5 chorus / flanger, 6 distortion, 7 autowah,
+ * 8 vocal morpher, 9 frequency shifter, 10 pitch shifter; a device with num_out_lines dry lines (identity AmbiMap:
+ * line i = ACN i, scale 1) and, for the dedicated effect, num_real real output lines whose FrontCenter sits at
+ * front_center (< 0: none).  ambi_order / horizontal / xover_freq: the device's mAmbiOrder, m2DMixing and mXOverFreq
+ * (what the A-Format effects' deviceUpdate builds its up-sampler from); wet_channels: the slot's wet lines */
+oal_effect *oal_effect_create_ex(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center,
+    uint32_t ambi_order, int horizontal, float xover_freq, uint32_t wet_channels)
 {
     ApplySimd();
+    if(wet_channels < 1 || wet_channels > 9) return nullptr;
     auto e = std::make_unique<oal_effect>();
     e->kind = kind;
+    e->numWet = wet_channels;
     e->dev = std::make_unique<Dev>();
     auto &dev = *e->dev;
     dev.mSampleRate = sample_rate;
     dev.mUpdateSize = BufferLineSize;
     dev.mBufferSize = BufferLineSize;
     dev.FmtType = DevFmtFloat;
-    dev.mAmbiOrder = 1;
+    dev.mAmbiOrder = ambi_order;
+    dev.m2DMixing = horizontal != 0;
+    dev.mXOverFreq = xover_freq;
     dev.MixBuffer.resize(num_out_lines + num_real);
     dev.Dry.Buffer = std::span{dev.MixBuffer}.first(num_out_lines);
     dev.RealOut.Buffer = num_real ? std::span{dev.MixBuffer}.subspan(num_out_lines) : dev.Dry.Buffer;
@@ -926,9 +935,9 @@ oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_l
     if(front_center >= 0) dev.RealOut.ChannelIndex[FrontCenter] = u8{static_cast<u8::value_t>(front_center)};
     for(uint32_t i{0};i < num_out_lines;++i) dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, i};
     e->ctx = std::make_unique<Ctx>(e->dev.get());
-    e->slot.mWetBuffer.resize(4);
+    e->slot.mWetBuffer.resize(wet_channels);
     e->slot.Wet.Buffer = e->slot.mWetBuffer;
-    for(uint32_t i{0};i < 4;++i) e->slot.Wet.AmbiMap[i] = BFChannelConfig{1.0f, i};
+    for(uint32_t i{0};i < wet_channels;++i) e->slot.Wet.AmbiMap[i] = BFChannelConfig{1.0f, i};
     switch(kind)
     {
     case 0: e->state = EqualizerStateFactory_getFactory()->create(); break;
@@ -936,11 +945,20 @@ oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_l
     case 2: e->state = EchoStateFactory_getFactory()->create(); break;
     case 3: e->state = DedicatedStateFactory_getFactory()->create(); break;
     case 4: e->state = CompressorStateFactory_getFactory()->create(); break;
+    case 5: e->state = ChorusStateFactory_getFactory()->create(); break;
+    case 6: e->state = DistortionStateFactory_getFactory()->create(); break;
+    case 7: e->state = AutowahStateFactory_getFactory()->create(); break;
+    case 8: e->state = VmorpherStateFactory_getFactory()->create(); break;
+    case 9: e->state = FshifterStateFactory_getFactory()->create(); break;
+    case 10: e->state = PshifterStateFactory_getFactory()->create(); break;
     default: return nullptr;
     }
     e->state->deviceUpdate(e->dev.get(), nullptr);
     return e.release();
 }
+
+oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center)
+{ return oal_effect_create_ex(kind, sample_rate, num_out_lines, num_real, front_center, 1u, 0, 400.0f, 4u); }
 
 /* props: the floats of the effect's property struct in declaration order (core/effects/base.h:116-169; the
  * modulator's waveform and the dedicated effect's target as a float-coded integer) */
@@ -952,21 +970,30 @@ void oal_effect_update(oal_effect *e, const float *p, float slot_gain)
     case 1: e->props = ModulatorProps{p[0], p[1], static_cast<ModulatorWaveform>(static_cast<int>(p[2]))}; break;
     case 2: e->props = EchoProps{p[0], p[1], p[2], p[3], p[4]}; break;
     case 3: e->props = DedicatedProps{static_cast<int>(p[0]) ? DedicatedProps::Lfe : DedicatedProps::Dialog, p[1]}; break;
-    default: e->props = CompressorProps{p[0] != 0.0f}; break;
+    case 4: e->props = CompressorProps{p[0] != 0.0f}; break;
+    case 5: e->props = ChorusProps{static_cast<ChorusWaveform>(static_cast<int>(p[0])), static_cast<int>(p[1]), p[2], p[3], p[4], p[5]}; break;
+    case 6: e->props = DistortionProps{p[0], p[1], p[2], p[3], p[4]}; break;
+    case 7: e->props = AutowahProps{p[0], p[1], p[2], p[3]}; break;
+    case 8: e->props = VmorpherProps{p[0], static_cast<VMorpherPhenome>(static_cast<int>(p[1])),
+        static_cast<VMorpherPhenome>(static_cast<int>(p[2])), static_cast<int>(p[3]), static_cast<int>(p[4]),
+        static_cast<VMorpherWaveform>(static_cast<int>(p[5]))}; break;
+    case 9: e->props = FshifterProps{p[0], static_cast<FShifterDirection>(static_cast<int>(p[1])),
+        static_cast<FShifterDirection>(static_cast<int>(p[2]))}; break;
+    default: e->props = PshifterProps{static_cast<int>(p[0]), static_cast<int>(p[1])}; break;
     }
     e->slot.Gain = slot_gain;
     e->state->update(e->ctx.get(), &e->slot, &e->props, EffectTarget{&e->dev->Dry, &e->dev->RealOut});
 }
 
-/* wet_in: 4 x 1024; lines: (num_out_lines + num_real) x 1024, added to */
+/* wet_in: wet_channels x 1024; lines: (num_out_lines + num_real) x 1024, added to */
 void oal_effect_process(oal_effect *e, const float *wet_in, float *lines, uint32_t n)
 {
     auto const fpuctl = FPUCtl{};
     auto &dev = *e->dev;
-    for(size_t c{0};c < 4;++c) std::copy_n(wet_in + c*BufferLineSize, BufferLineSize, e->wet[c].begin());
+    for(size_t c{0};c < e->numWet;++c) std::copy_n(wet_in + c*BufferLineSize, BufferLineSize, e->wet[c].begin());
     for(size_t l{0};l < dev.MixBuffer.size();++l)
         std::copy_n(lines + l*BufferLineSize, BufferLineSize, dev.MixBuffer[l].begin());
-    e->state->process(n, e->wet, e->state->mOutTarget);
+    e->state->process(n, std::span{e->wet}.first(e->numWet), e->state->mOutTarget);
     for(size_t l{0};l < dev.MixBuffer.size();++l)
         std::copy_n(dev.MixBuffer[l].begin(), BufferLineSize, lines + l*BufferLineSize);
 }
