@@ -436,7 +436,8 @@ int oalgpu_set_timing(oalgpu_context *ctx, int enable);
  * is bit-identical to the reference's, except the modulator's sinusoid carrier (the GPU's sinf against libm). */
 enum oalgpu_effect_kind {
     OALGPU_EFFECT_EQUALIZER = 0, OALGPU_EFFECT_MODULATOR, OALGPU_EFFECT_ECHO, OALGPU_EFFECT_DEDICATED, OALGPU_EFFECT_COMPRESSOR,
-    OALGPU_EFFECT_CHORUS, OALGPU_EFFECT_DISTORTION, OALGPU_EFFECT_AUTOWAH, OALGPU_EFFECT_VMORPHER, OALGPU_EFFECT_FSHIFTER
+    OALGPU_EFFECT_CHORUS, OALGPU_EFFECT_DISTORTION, OALGPU_EFFECT_AUTOWAH, OALGPU_EFFECT_VMORPHER, OALGPU_EFFECT_FSHIFTER,
+    OALGPU_EFFECT_PSHIFTER
 };
 enum oalgpu_modulator_waveform { OALGPU_MODULATOR_SINUSOID = 0, OALGPU_MODULATOR_SAWTOOTH, OALGPU_MODULATOR_SQUARE };
 #define OALGPU_INVALID_CHANNEL 0xffffffffu
@@ -461,9 +462,12 @@ typedef struct oalgpu_compressor_props { int32_t on_off; } oalgpu_compressor_pro
  * AmbiScale::FirstOrderUp[c], gain) (:239-250) and process ends in BandSplitter::processHfScale + MixSamples onto every
  * line (:393-411).  NULL order_scales: first order again.  Call it before the first update.
  * Bit-identical to the reference except where libm's sinf / cosf meet the GPU's (chorus sinusoid LFO, autowah filter
- * coefficients, the morpher's sinusoid LFO: evaluated through double precision, equal almost always).  The pitch
- * shifter is not built: a phase vocoder picks bins by comparing magnitudes, so the last bit of pffft's butterflies
- * decides audible detail and no tolerance states parity. */
+ * coefficients, the morpher's sinusoid LFO: evaluated through double precision, 1e-6 of the block maximum or less).
+ *   pitch shifter       PshifterState (pshifter.cpp): 1024-point STFT phase vocoder, hop 128, up to 9 wet channels (second
+ *                       order); its up-sampler (a device above SECOND order) takes order_scales = GetHFOrderScales(2, ..)
+ *                       and gains [9][num_out_lines] from AmbiScale::SecondOrderUp.  The transforms are not pffft's
+ *                       butterfly order and atan2f / hypotf / sinf / cosf are the GPU's, so parity is a tolerance: 1e-4 of
+ *                       the block maximum over runs of 20 blocks (tests/test_effects2.py; measured a few 1e-5). */
 enum oalgpu_chorus_waveform { OALGPU_CHORUS_SINUSOID = 0, OALGPU_CHORUS_TRIANGLE };
 enum oalgpu_vmorpher_waveform { OALGPU_VMORPHER_SINUSOID = 0, OALGPU_VMORPHER_TRIANGLE, OALGPU_VMORPHER_SAWTOOTH };
 enum oalgpu_fshifter_direction { OALGPU_FSHIFTER_DOWN = 0, OALGPU_FSHIFTER_UP, OALGPU_FSHIFTER_OFF };
@@ -474,6 +478,7 @@ typedef struct oalgpu_vmorpher_props {              /* VmorpherProps; phonemes i
     float rate; int32_t phoneme_a, phoneme_b, phoneme_a_coarse_tuning, phoneme_b_coarse_tuning, waveform;
 } oalgpu_vmorpher_props;
 typedef struct oalgpu_fshifter_props { float frequency; int32_t left_direction, right_direction; } oalgpu_fshifter_props;
+typedef struct oalgpu_pshifter_props { int32_t coarse_tune, fine_tune; } oalgpu_pshifter_props;
 typedef struct oalgpu_effect oalgpu_effect;
 int  oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_rate, uint32_t num_in_channels,
     uint32_t num_out_lines, oalgpu_effect **out);

@@ -7,6 +7,7 @@
 //   AutowahState::process     alc/effects/autowah.cpp:124-196     envelope follower on channel 0, a peaking filter that changes every sample
 //   VmorpherState::process    alc/effects/vmorpher.cpp:279-335    two 4-band formant filters (state variable) blended by an LFO
 //   FshifterState::process    alc/effects/fshifter.cpp:216-365    STFT (1024 / hop 256, double precision) -> analytic signal -> phase rotation
+//   PshifterState::process    alc/effects/pshifter.cpp:213-460    STFT (1024 / hop 128) phase vocoder, up to second order (9 channels)
 //
 // As for the other effects the reference's operation order is kept in every mode.  Recurrences run through WaveSerial
 // (effects_dev.hpp): their inputs are fetched 64 samples at a time, the dependent chain itself sees no memory.  Where
@@ -58,16 +59,18 @@ __device__ __forceinline__ float AFormat(const Fx2Launch &F, bool distortion, ui
 // The A-Format effects' tail: rows[c] = mBBuffer[c] -> the output lines, through the up-sampler of a device above
 // first order (BandSplitter::processHfScale, the two-span form core/filters/splitter.cpp:65-97, then MixSamples
 // onto every line) or onto the channel's own target line (chorus.cpp:393-427 and alike)
-__device__ void FxOutput(const Fx2Launch &F, Fx2State &S, float (*rows)[kLine], uint32_t t)
+__device__ void FxOutput(const Fx2Launch &F, Fx2State &S, float (*rows)[kLine], uint32_t nchan, uint32_t t)
 {
     const uint32_t lane = t & 63u, wave = __builtin_amdgcn_readfirstlane(t >> 6), n = F.n;
     if(F.upsample)
     {
-        if(F.target[wave] != kInvalid)
+        for(uint32_t c0 = 0; c0 < nchan; c0 += 4u)
         {
-            const float apc = F.splitCoeff, lpc = F.splitCoeff * 0.5f + 0.5f, hf = F.hfScale[wave ? 1 : 0];
-            float z1 = S.split[wave][0], z2 = S.split[wave][1], az = S.split[wave][2];
-            float *row = rows[wave];
+            const uint32_t c = c0 + wave;
+            if(c >= nchan || F.target[c] == kInvalid) continue;
+            const float apc = F.splitCoeff, lpc = F.splitCoeff * 0.5f + 0.5f, hf = F.hfScale[c ? 1 : 0];
+            float z1 = S.split[c][0], z2 = S.split[c][1], az = S.split[c][2];
+            float *row = rows[c];
             WaveSerial<1>(n, lane, row, [&](uint32_t i, float *v) { v[0] = row[i]; },
                 [&](const float *x) {
                     const float in = x[0];
@@ -81,14 +84,14 @@ __device__ void FxOutput(const Fx2Launch &F, Fx2State &S, float (*rows)[kLine], 
                     az = in - ay * apc;
                     return (ay - y1) * hf + y1;
                 });
-            if(lane == 0) { S.split[wave][0] = z1; S.split[wave][1] = z2; S.split[wave][2] = az; }
+            if(lane == 0) { S.split[c][0] = z1; S.split[c][1] = z2; S.split[c][2] = az; }
         }
         __syncthreads();
-        for(uint32_t c = 0; c < 4u; ++c)
+        for(uint32_t c = 0; c < nchan; ++c)
             if(F.target[c] != kInvalid) MixOntoLines(rows[c], F.outLines, F.nlines, S.upCur[c], F.upTgt + c * 32u, n, n, t);
         return;
     }
-    for(uint32_t c = 0; c < 4u; ++c)
+    for(uint32_t c = 0; c < nchan; ++c)
     {
         if(F.target[c] >= F.nlines) continue;
         const MixLineGain g = PrepareMixLine(S.cur[c], F.tgtGain[c], n, n);
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(256) ChorusKernel(Fx2Launch F)
         }
     }
     __syncthreads();
-    FxOutput(F, S, Bb, t);
+    FxOutput(F, S, Bb, 4u, t);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256) DistortionKernel(Fx2Launch F)
     }
     if(lane == 0) { S.lp[c].z1 = lp.z1; S.lp[c].z2 = lp.z2; S.bp[c].z1 = bp.z1; S.bp[c].z2 = bp.z2; }
     __syncthreads();
-    FxOutput(F, S, Bb, t);
+    FxOutput(F, S, Bb, 4u, t);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -470,7 +473,173 @@ __global__ void __launch_bounds__(256) FshifterMixKernel(Fx2Launch F)
         for(uint32_t i = 0; i < 4u; ++i) Bb[i][p] = b[i];
     }
     __syncthreads();
-    FxOutput(F, S, Bb, t);
+    FxOutput(F, S, Bb, 4u, t);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// pitch shifter (alc/effects/pshifter.cpp:213-460): a phase vocoder -- 1024-point STFT, hop 128; the W channel's
+// bins are analysed for their true frequency, moved to round(k * pitch) and re-synthesised with accumulated phases,
+// the other channels keep their phase offset from W.  PshifterLineKernel: workgroup c = channel c.  A hop of
+// channel c > 0 needs what W's analysis of the SAME hop left in mLastPhase / mSumPhase, so every workgroup redoes
+// W's analysis for itself (one more transform per hop) instead of waiting for workgroup 0; the state a launch
+// reads (input history, phases) and the state it leaves are separate buffers, so no workgroup reads what another
+// one writes.  The transforms are plain radix-2 complex FFTs in LDS, not pffft's butterfly order, and atan2f /
+// hypotf / sinf / cosf are the GPU's: parity is a tolerance here (tests/test_effects2.py), not bit equality.
+// ---------------------------------------------------------------------------------------------------------------
+struct Cf { float x, y; };
+
+// data in bit-reversed order -> natural order; tw[m] = e^(-2 pi i m / 1024); inverse: the conjugate, unnormalised
+__device__ void FftF1024(Cf *buf, const Cf *tw, bool inverse, uint32_t t)
+{
+    for(uint32_t i = 0; i < 10u; ++i)
+    {
+        const uint32_t step2 = 1u << i;
+        for(uint32_t p = t; p < 512u; p += 256u)
+        {
+            const uint32_t j = p & (step2 - 1u), k = ((p >> i) << (i + 1u)) | j;
+            const Cf a = buf[k], b = buf[k + step2];
+            Cf u = tw[j << (9u - i)];
+            if(inverse) u.y = -u.y;
+            const Cf tmp{b.x * u.x - b.y * u.y, b.x * u.y + b.y * u.x};
+            buf[k + step2] = Cf{a.x - tmp.x, a.y - tmp.y};
+            buf[k] = Cf{a.x + tmp.x, a.y + tmp.y};
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float WrapPhase(float tmp)
+{   // qpd = float2int(tmp); tmp -= qpd + qpd%2, pshifter.cpp:296-297
+    const int32_t qpd = int32_t(tmp);
+    return tmp - float(qpd + (qpd % 2));
+}
+
+__global__ void __launch_bounds__(256) PshifterLineKernel(Fx2Launch F)
+{
+    __shared__ Cf buf[1024];
+    __shared__ float mag[513], ph[513], sm[513], sf[513], last[513], sum[513];
+    const uint32_t t = threadIdx.x, n = F.n, c = blockIdx.x;
+    const float kExpected = kPiF * 2.0f / 8.0f, kInvPi = 0.318309886183790671538f;
+    const float *ring0 = F.psRingIn, *ringC = F.psRingIn + size_t{c} * 1024u;
+    const float *in0 = F.wetIn, *inC = F.wetIn + size_t{c} * kLine;
+    float *accum = F.psAccum + size_t{c} * 1024u, *outFifo = F.psOutFifo + size_t{c} * 128u, *rows = F.psRows + size_t{c} * kLine;
+    // the timeline of channel ch: the 1024 samples before this launch, then this block
+    auto timeline = [&](const float *ring, const float *in, uint32_t x) { return x < 1024u ? ring[x] : in[x - 1024u]; };
+    for(uint32_t k = t; k < 513u; k += 256u) { last[k] = F.psPhaseIn[k]; sum[k] = F.psPhaseIn[513u + k]; }
+    uint32_t count = F.psCount, pos = F.psPos;
+    const uint32_t pitchI = F.psPitchI;
+    const uint32_t binCount = min(513u, ((513u << 16) - 32768u - 1u) / pitchI + 1u);
+    __syncthreads();
+    for(uint32_t base = 0; base < n;)
+    {
+        const uint32_t todo = (128u - count) < (n - base) ? (128u - count) : (n - base);
+        for(uint32_t j = t; j < todo; j += 256u) rows[base + j] = outFifo[count + j];
+        count += todo; base += todo;
+        if(count < 128u) break;
+        count = 0; pos = (pos + 128u) & 1023u;
+        const uint32_t start = base;                    // the window: timeline[base .. base + 1024)
+        __syncthreads();
+        for(uint32_t pass = 0; pass < 2u; ++pass)
+        {   // pass 0: W's analysis (every workgroup); pass 1: this channel (workgroup 0: W's own synthesis)
+            const bool own = pass == 1u;
+            if(own && c == 0u) { /* W: the spectrum analysed in pass 0 is still what is needed; go on to synthesis */ }
+            else
+            {
+                const float *ring = own ? ringC : ring0, *in = own ? inC : in0;
+                for(uint32_t k = t; k < 1024u; k += 256u)
+                    buf[Rev10(k)] = Cf{timeline(ring, in, start + k) * F.psWindow[k], 0.0f};
+                __syncthreads();
+                FftF1024(buf, reinterpret_cast<const Cf*>(F.psTw), false, t);
+                for(uint32_t k = t; k < 513u; k += 256u)
+                {
+                    const Cf v = (k == 0u || k == 512u) ? Cf{buf[k].x, 0.0f} : buf[k];
+                    mag[k] = hypotf(v.x, v.y);
+                    ph[k] = atan2f(v.y, v.x);
+                }
+                __syncthreads();
+            }
+            if(!own)
+            {   // W: true frequency per bin, moved bins, accumulated synthesis phases (pshifter.cpp:268-356)
+                for(uint32_t k = t; k < 513u; k += 256u)
+                {
+                    float tmp = (ph[k] - last[k]) - float(k & 7u) * kExpected;
+                    last[k] = ph[k];
+                    tmp = WrapPhase(tmp * kInvPi) * 4.0f;
+                    ph[k] = (float(k) + tmp) * F.psPitch;           // freqbin * mPitchShift
+                }
+                __syncthreads();
+            }
+            else if(c != 0u)
+            {
+                for(uint32_t k = t; k < 513u; k += 256u) ph[k] = ph[k] - last[k];     // phase offset from W
+                __syncthreads();
+            }
+            if(!(own && c == 0u))
+            {   // mSynthesisBuffer[j]: the source bins k with round(k * pitch) == j, in ascending order
+                const uint32_t kcount = own ? binCount : 513u;
+                for(uint32_t j = t; j < 513u; j += 256u)
+                {
+                    const uint64_t lo = (uint64_t{j} << 16) < 32768u ? 0u : ((uint64_t{j} << 16) - 32768u + pitchI - 1u) / pitchI;
+                    const uint64_t hiEx = (((uint64_t{j} + 1u) << 16) - 32768u + pitchI - 1u) / pitchI;     // first k beyond j
+                    float m = 0.0f, f = 0.0f;
+                    for(uint64_t k = lo; k < hiEx && k < kcount; ++k)
+                    {
+                        if(m < mag[k]) f = ph[k];
+                        m = m + mag[k];
+                    }
+                    sm[j] = m; sf[j] = f;
+                }
+                __syncthreads();
+            }
+            if(!own)
+            {
+                for(uint32_t k = t; k < 513u; k += 256u)
+                {
+                    float tmp = (sf[k] - float(k & ~7u)) * kExpected;
+                    tmp = WrapPhase((tmp + sum[k]) * kInvPi);
+                    sum[k] = tmp * kPiF;
+                }
+                __syncthreads();
+                if(c != 0u) continue;                  // the other channels only needed W's phases
+            }
+            // polar(magnitude, phase) -> the Hermitian spectrum -> inverse transform
+            for(uint32_t k = t; k < 513u; k += 256u)
+            {
+                const float phase = (c == 0u) ? sum[k] : WrapPhase((sum[k] + sf[k]) * kInvPi) * kPiF;
+                Cf v{sm[k] * CosViaDouble(phase), sm[k] * SinViaDouble(phase)};
+                if(k == 0u || k == 512u) v.y = 0.0f;
+                buf[Rev10(k)] = v;
+                if(k != 0u && k != 512u) buf[Rev10(1024u - k)] = Cf{v.x, -v.y};
+            }
+            __syncthreads();
+            FftF1024(buf, reinterpret_cast<const Cf*>(F.psTw), true, t);
+            for(uint32_t k = t; k < 1024u; k += 256u)
+            {
+                const float y = F.psWindow[k] * buf[k].x * (3.0f / 8.0f / 1024.0f);
+                accum[(pos + k) & 1023u] = accum[(pos + k) & 1023u] + y;
+            }
+            __syncthreads();
+            if(t < 128u) { outFifo[t] = accum[pos + t]; accum[pos + t] = 0.0f; }
+            __syncthreads();
+            if(c == 0u) break;                          // W is done after its single pass pair
+        }
+    }
+    // what the next launch starts from
+    for(uint32_t i = t; i < 1024u; i += 256u) F.psRingOut[size_t{c} * 1024u + i] = timeline(ringC, inC, n + i);
+    if(c == 0u)
+        for(uint32_t k = t; k < 513u; k += 256u) { F.psPhaseOut[k] = last[k]; F.psPhaseOut[513u + k] = sum[k]; }
+}
+
+__global__ void __launch_bounds__(256) PshifterMixKernel(Fx2Launch F)
+{
+    __shared__ float Bb[9][kLine];
+    const uint32_t t = threadIdx.x, n = F.n;
+    const uint32_t nchan = F.numIn < 9u ? F.numIn : 9u;
+    for(uint32_t c = 0; c < nchan; ++c)
+        for(uint32_t p = t; p < n; p += 256u) Bb[c][p] = F.psRows[size_t{c} * kLine + p];
+    __syncthreads();
+    FxOutput(F, *F.st, Bb, nchan, t);
 }
 
 } // namespace
@@ -486,6 +655,10 @@ void LaunchEffect2(hipStream_t s, const Fx2Launch &F, uint32_t ldsBytes)
     case OALGPU_EFFECT_FSHIFTER:
         hipLaunchKernelGGL(FshifterLineKernel, dim3(4), dim3(256), 0, s, F);
         hipLaunchKernelGGL(FshifterMixKernel, dim3(1), dim3(256), 0, s, F);
+        break;
+    case OALGPU_EFFECT_PSHIFTER:
+        hipLaunchKernelGGL(PshifterLineKernel, dim3(F.numIn < 9u ? F.numIn : 9u), dim3(256), 0, s, F);
+        hipLaunchKernelGGL(PshifterMixKernel, dim3(1), dim3(256), 0, s, F);
         break;
     default: break;
     }

@@ -30,12 +30,15 @@ struct oalgpu_effect {
     DevBuf<float> cubic, upTgt, window;
     DevBuf<double> fsIn;
     DevBuf<FsPair> fsOutFifo, fsAccum, fsOutdata, fsTw, fsPhase;
+    DevBuf<float> psRing, psPhase, psAccum, psOutFifo, psRows, psTw;     // psRing / psPhase: two copies, read [parity], written [parity ^ 1]
     Fx2Launch G{};
     // ChorusState::mOffset / mLfoOffset / mLfoRange / mLfoDisp (chorus.cpp:83-88)
     uint32_t chOffset{0}, lfoOffset{0}, lfoRange{1}, lfoDisp{0};
     // VmorpherState::mIndex (vmorpher.cpp:152); FshifterState::mCount / mPos / mChans[c].mPhase (fshifter.cpp:100-113)
     uint32_t vmIndex{0};
     uint32_t fsCount{0}, fsPos{768}, fsPhase4[4]{};
+    // PshifterState::mCount / mPos (pshifter.cpp:86-87)
+    uint32_t psCount{0}, psPos{1024 - 128}, psParity{0};
 };
 
 namespace {
@@ -51,7 +54,7 @@ int UploadBiquad(oalgpu_effect *e, uint32_t chan, uint32_t which, const float c[
 
 uint32_t NextPow2(uint32_t v) { uint32_t p = 1; while(p < v) p <<= 1; return p; }
 
-bool IsFx2(int kind) { return kind >= OALGPU_EFFECT_CHORUS && kind <= OALGPU_EFFECT_FSHIFTER; }
+bool IsFx2(int kind) { return kind >= OALGPU_EFFECT_CHORUS && kind <= OALGPU_EFFECT_PSHIFTER; }
 
 // float2int / float2uint (common/alnumeric.h): truncation
 int32_t TruncI(float f) { return static_cast<int32_t>(f); }
@@ -64,6 +67,19 @@ int UploadAt(void *base, size_t offset, const T *src, size_t count)
 {
     HIP_TRY(hipMemcpy(static_cast<char*>(base) + offset, src, count * sizeof(T), hipMemcpyHostToDevice));
     return OALGPU_OK;
+}
+
+// gHannWindow<1024>, common/hann_window.hpp: sin^2 through double, mirrored
+std::vector<float> HannWindow1024()
+{
+    std::vector<float> win(1024);
+    const double scale = 3.14159265358979323846 / double(1024 + 1);
+    for(uint32_t i = 0; i < 512; ++i)
+    {
+        const double v = std::sin((i + 1.0) * scale);
+        win[i] = win[1023 - i] = static_cast<float>(v * v);
+    }
+    return win;
 }
 
 #pragma clang fp contract(off)
@@ -200,6 +216,15 @@ int UpdateFx2(oalgpu_effect *e, const void *props, const uint32_t *target_channe
             if(int rc = UploadAt(e->st2.p, offsetof(Fx2State, vmS), zeros.data(), zeros.size())) return rc;
         }
         break;
+    case OALGPU_EFFECT_PSHIFTER:
+        {   // PshifterState::update, pshifter.cpp:168-199
+            const auto &p = *static_cast<const oalgpu_pshifter_props*>(props);
+            const int32_t tune = p.coarse_tune * 100 + p.fine_tune;
+            const float pitch = std::pow(2.0f, float(tune) / 1200.0f);
+            G.psPitchI = RoundU(std::min(std::max(pitch, 0.5f), 2.0f) * 65536.0f);
+            G.psPitch = float(G.psPitchI) * (1.0f / 65536.0f);
+        }
+        break;
     default:
         {   // FshifterState::update, fshifter.cpp:162-214
             const auto &p = *static_cast<const oalgpu_fshifter_props*>(props);
@@ -218,12 +243,15 @@ int UpdateFx2(oalgpu_effect *e, const void *props, const uint32_t *target_channe
         break;
     }
     for(uint32_t ch = 0; ch < kFxMaxIn; ++ch) { G.target[ch] = OALGPU_INVALID_CHANNEL; G.tgtGain[ch] = 0.0f; }
-    const uint32_t chans = aformat ? std::min(e->numIn, 4u) : e->numIn;
+    const bool pshift = e->kind == OALGPU_EFFECT_PSHIFTER;
+    const uint32_t chans = aformat ? std::min(e->numIn, 4u) : pshift ? std::min(e->numIn, 9u) : e->numIn;
     for(uint32_t ch = 0; ch < chans; ++ch) G.target[ch] = target_channels[ch];
-    if(aformat && G.upsample)
-    {   // UpsampleParams::mTargetGains = ComputePanGains(target.Main, AmbiScale::FirstOrderUp[ch], gain): gains[4][num_out_lines]
-        std::vector<float> up(4 * 32, 0.0f);
-        for(uint32_t ch = 0; ch < 4; ++ch)
+    if((aformat || pshift) && G.upsample)
+    {   // UpsampleParams::mTargetGains = ComputePanGains(target.Main, AmbiScale::FirstOrderUp[ch] (pitch shifter: SecondOrderUp[ch]),
+        // gain): gains[4 or 9][num_out_lines]
+        const uint32_t rows = pshift ? 9u : 4u;
+        std::vector<float> up(9 * 32, 0.0f);
+        for(uint32_t ch = 0; ch < rows; ++ch)
             for(uint32_t l = 0; l < e->nlines; ++l) up[ch * 32 + l] = gains[size_t{ch} * e->nlines + l];
         HIP_TRY(e->upTgt.upload(up.data(), up.size()));
     }
@@ -240,7 +268,7 @@ extern "C" {
 int oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_rate, uint32_t num_in_channels,
     uint32_t num_out_lines, oalgpu_effect **out)
 {
-    if(!out || kind < OALGPU_EFFECT_EQUALIZER || kind > OALGPU_EFFECT_FSHIFTER || sample_rate < 8000 || num_in_channels < 1
+    if(!out || kind < OALGPU_EFFECT_EQUALIZER || kind > OALGPU_EFFECT_PSHIFTER || sample_rate < 8000 || num_in_channels < 1
         || num_in_channels > kFxMaxIn || num_out_lines < 1 || num_out_lines > OALGPU_MAX_OUTPUT_CHANNELS)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_effect_create: bad arguments");
     *out = nullptr;
@@ -275,7 +303,7 @@ int oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_ra
     {
         const float f = float(sample_rate);
         HIP_TRY(e->st2.alloc(1)); HIP_TRY(e->st2.zero());
-        HIP_TRY(e->upTgt.alloc(4 * 32)); HIP_TRY(e->upTgt.zero());
+        HIP_TRY(e->upTgt.alloc(9 * 32)); HIP_TRY(e->upTgt.zero());
         Fx2Launch &G = e->G;
         G.kind = kind; G.numIn = num_in_channels; G.nlines = num_out_lines; G.st = e->st2.p; G.upTgt = e->upTgt.p;
         for(uint32_t c = 0; c < kFxMaxIn; ++c) { G.target[c] = OALGPU_INVALID_CHANNEL; G.tgtGain[c] = 0.0f; }
@@ -320,18 +348,33 @@ int oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_ra
             }
             HIP_TRY(e->fsPhase.alloc(ph.size()));
             HIP_TRY(e->fsPhase.upload(ph.data(), ph.size()));
-            std::vector<float> win(1024);
-            const double scale = 3.14159265358979323846 / double(1024 + 1);
-            for(uint32_t i = 0; i < 512; ++i)
-            {
-                const double v = std::sin((i + 1.0) * scale);
-                win[i] = win[1023 - i] = static_cast<float>(v * v);
-            }
+            const std::vector<float> win = HannWindow1024();
             HIP_TRY(e->window.alloc(win.size()));
             HIP_TRY(e->window.upload(win.data(), win.size()));
             G.fsIn = e->fsIn.p; G.fsOutFifo = e->fsOutFifo.p; G.fsAccum = e->fsAccum.p; G.fsOutdata = e->fsOutdata.p;
             G.fsTw = e->fsTw.p; G.fsPhase = e->fsPhase.p; G.fsWindow = e->window.p;
             for(int c = 0; c < 4; ++c) G.fsSign[c] = 1.0;
+        }
+        if(kind == OALGPU_EFFECT_PSHIFTER)
+        {   // PshifterState::deviceUpdate, pshifter.cpp:128-166: up to second order; pitch 1
+            if(num_in_channels > 9) return Fail(OALGPU_ERR_INVALID, "oalgpu_effect_create: the pitch shifter works on up to 9 channels (second order)");
+            HIP_TRY(e->psRing.alloc(2 * 9 * 1024)); HIP_TRY(e->psRing.zero());
+            HIP_TRY(e->psPhase.alloc(2 * 2 * 513)); HIP_TRY(e->psPhase.zero());
+            HIP_TRY(e->psAccum.alloc(9 * 1024)); HIP_TRY(e->psAccum.zero());
+            HIP_TRY(e->psOutFifo.alloc(9 * 128)); HIP_TRY(e->psOutFifo.zero());
+            HIP_TRY(e->psRows.alloc(9 * OALGPU_BUFFER_LINE_SIZE)); HIP_TRY(e->psRows.zero());
+            std::vector<float> tw(2 * 512);
+            for(uint32_t m = 0; m < 512; ++m)
+            {
+                const double a = -2.0 * 3.14159265358979323846 * double(m) / 1024.0;
+                tw[2 * m] = static_cast<float>(std::cos(a)); tw[2 * m + 1] = static_cast<float>(std::sin(a));
+            }
+            HIP_TRY(e->psTw.alloc(tw.size())); HIP_TRY(e->psTw.upload(tw.data(), tw.size()));
+            const std::vector<float> win = HannWindow1024();
+            HIP_TRY(e->window.alloc(win.size())); HIP_TRY(e->window.upload(win.data(), win.size()));
+            G.psAccum = e->psAccum.p; G.psOutFifo = e->psOutFifo.p; G.psRows = e->psRows.p;
+            G.psTw = e->psTw.p; G.psWindow = e->window.p;
+            G.psPitchI = 65536u; G.psPitch = 1.0f;
         }
         *out = e.release();
         return OALGPU_OK;
@@ -436,8 +479,9 @@ int oalgpu_effect_update(oalgpu_effect *e, const void *props, const uint32_t *ta
 int oalgpu_effect_set_upsampler(oalgpu_effect *e, const float order_scales[2], float xover_norm)
 {
     if(!e) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(!(e->kind == OALGPU_EFFECT_CHORUS || e->kind == OALGPU_EFFECT_DISTORTION || e->kind == OALGPU_EFFECT_FSHIFTER))
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_effect_set_upsampler: only the A-Format effects (chorus, distortion, frequency shifter) up-sample");
+    if(!(e->kind == OALGPU_EFFECT_CHORUS || e->kind == OALGPU_EFFECT_DISTORTION || e->kind == OALGPU_EFFECT_FSHIFTER
+        || e->kind == OALGPU_EFFECT_PSHIFTER))
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_effect_set_upsampler: only the chorus, the distortion and the frequency / pitch shifters up-sample");
     if(e->nlines > 32) return Fail(OALGPU_ERR_INVALID, "oalgpu_effect_set_upsampler: at most 32 output lines");
     if(int rc = UseDevice(e->device)) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -449,7 +493,7 @@ int oalgpu_effect_set_upsampler(oalgpu_effect *e, const float order_scales[2], f
         G.splitCoeff = SplitterCoeff(xover_norm);
     }
     // a fresh BandSplitter and zeroed gains, as deviceUpdate leaves them
-    std::vector<float> zeros(4 * 32 + 4 * 3, 0.0f);
+    std::vector<float> zeros(9 * 32 + 9 * 3, 0.0f);
     if(int rc = UploadAt(e->st2.p, offsetof(Fx2State, upCur), zeros.data(), zeros.size())) return rc;
     e->updated = false;
     return OALGPU_OK;
@@ -477,6 +521,13 @@ int ProcessFx2(oalgpu_effect *e, hipStream_t stream, const float *wet_in_dev, fl
         G.fsCount = e->fsCount; G.fsPos = e->fsPos;
         for(int c = 0; c < 4; ++c) G.fsPhaseIdx[c] = e->fsPhase4[c];
     }
+    if(e->kind == OALGPU_EFFECT_PSHIFTER)
+    {
+        const uint32_t p = e->psParity;
+        G.psRingIn = e->psRing.p + size_t{p} * 9 * 1024; G.psRingOut = e->psRing.p + size_t{p ^ 1u} * 9 * 1024;
+        G.psPhaseIn = e->psPhase.p + size_t{p} * 2 * 513; G.psPhaseOut = e->psPhase.p + size_t{p ^ 1u} * 2 * 513;
+        G.psCount = e->psCount; G.psPos = e->psPos;
+    }
     LaunchEffect2(stream, G, lds);
     HIP_TRY(hipGetLastError());
     // the scalars process() moves on (chorus.cpp:283,391; vmorpher.cpp:293-294; fshifter.cpp:228-259,330-336)
@@ -484,6 +535,17 @@ int ProcessFx2(oalgpu_effect *e, hipStream_t stream, const float *wet_in_dev, fl
     {
         e->chOffset += n;
         e->lfoOffset = (e->lfoOffset + n) % e->lfoRange;
+    }
+    if(e->kind == OALGPU_EFFECT_PSHIFTER)
+    {
+        e->psParity ^= 1u;
+        for(uint32_t base = 0; base < n;)
+        {
+            const uint32_t todo = std::min(128u - e->psCount, n - base);
+            e->psCount += todo; base += todo;
+            if(e->psCount < 128u) break;
+            e->psCount = 0; e->psPos = (e->psPos + 128u) & 1023u;
+        }
     }
     if(e->kind == OALGPU_EFFECT_VMORPHER)
         for(uint32_t base = 0; base < n; base += 256u)

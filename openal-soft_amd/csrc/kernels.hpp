@@ -195,8 +195,8 @@ void LaunchEffect(hipStream_t s, const FxLaunch &F);
 // ---- launcher (effects2_kernels.hip): chorus / flanger, distortion, autowah, vocal morpher, frequency shifter ----
 struct Fx2State {                      // device-resident per instance
     float cur[kFxMaxIn];               // mChans[c].mCurrentGain
-    float upCur[4][32];                // UpsampleParams::mCurrentGains of the A-Format effects
-    float split[4][3];                 // UpsampleParams::mSplitter: lp_z1, lp_z2, ap_z1
+    float upCur[9][32];                // UpsampleParams::mCurrentGains (A-Format effects: 4 rows; pitch shifter: 9)
+    float split[9][3];                 // UpsampleParams::mSplitter: lp_z1, lp_z2, ap_z1
     BiquadState lp[4], bp[4];          // distortion: mChans[c].mLowpass / mBandpass
     float envDelay, awZ[kFxMaxIn][2];  // autowah: mEnvDelay, mChans[c].mFilter
     float vmS[kFxMaxIn][8][2];         // vocal morpher: [channel][vowel A 0..3 | vowel B 4..7] {mS1, mS2}
@@ -208,7 +208,7 @@ struct Fx2Launch {
     Fx2State *st;
     const float *wetIn; float *outLines;
     uint32_t target[kFxMaxIn]; float tgtGain[kFxMaxIn];
-    int upsample; float hfScale[2], splitCoeff; const float *upTgt;       // mUpsampler: [4][32] target gains (device memory)
+    int upsample; float hfScale[2], splitCoeff; const float *upTgt;       // mUpsampler: [4 or 9][32] target gains (device memory)
     // chorus (alc/effects/chorus.cpp)
     int chWave; uint32_t lfoStart[2], lfoRange; float lfoScale, chDepth; int32_t chDelay; float chFeedback;
     uint32_t chAvgDelay, chHist;
@@ -222,6 +222,12 @@ struct Fx2Launch {
     // frequency shifter
     double *fsIn; FsPair *fsOutFifo, *fsAccum, *fsOutdata; const FsPair *fsTw, *fsPhase; const float *fsWindow;
     uint32_t fsCount, fsPos, fsPhaseStep[4], fsPhaseIdx[4]; double fsSign[4];
+    // pitch shifter: [parity] = what this launch reads, [parity ^ 1] = what it leaves
+    const float *psRingIn; float *psRingOut;            // [9][1024] the last 1024 input samples per channel
+    const float *psPhaseIn; float *psPhaseOut;          // mLastPhase[513] | mSumPhase[513]
+    float *psAccum, *psOutFifo, *psRows;                // mOutputAccum [9][1024]; the hop's output [9][128]; mBBuffer [9][1024]
+    const float *psTw, *psWindow;                       // e^(-2 pi i m / 1024), m < 512 (re, im); the Hann window
+    uint32_t psCount, psPos, psPitchI; float psPitch;
 };
 void LaunchEffect2(hipStream_t s, const Fx2Launch &F, uint32_t ldsBytes);
 

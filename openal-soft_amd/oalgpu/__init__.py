@@ -668,10 +668,10 @@ class Convolution:
 
 
 (EFFECT_EQUALIZER, EFFECT_MODULATOR, EFFECT_ECHO, EFFECT_DEDICATED, EFFECT_COMPRESSOR, EFFECT_CHORUS, EFFECT_DISTORTION,
- EFFECT_AUTOWAH, EFFECT_VMORPHER, EFFECT_FSHIFTER) = range(10)
+ EFFECT_AUTOWAH, EFFECT_VMORPHER, EFFECT_FSHIFTER, EFFECT_PSHIFTER) = range(11)
 # which fields of the property struct are integers (the rest are floats), in declaration order
 _EFFECT_INT_FIELDS = {EFFECT_MODULATOR: (2,), EFFECT_COMPRESSOR: (0,), EFFECT_CHORUS: (0, 1), EFFECT_VMORPHER: (1, 2, 3, 4, 5),
-                      EFFECT_FSHIFTER: (1, 2)}
+                      EFFECT_FSHIFTER: (1, 2), EFFECT_PSHIFTER: (0, 1)}
 INVALID_CHANNEL = 0xffffffff
 
 

@@ -267,6 +267,7 @@ typedef struct oal_effect oal_effect;
 oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center);
 oal_effect *oal_effect_create_ex(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center,
     uint32_t ambi_order, int horizontal, float xover_freq, uint32_t wet_channels);
+void oal_ambi_upmix_info2(uint32_t device_order, int horizontal, float *order_scales2, float *second_order_up);
 void oal_effect_update(oal_effect *e, const float *props, float slot_gain);
 void oal_effect_process(oal_effect *e, const float *wet_in, float *lines, uint32_t n);
 int oal_effect_targets_real(oal_effect *e);

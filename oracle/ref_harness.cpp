@@ -960,6 +960,16 @@ oal_effect *oal_effect_create_ex(int kind, uint32_t sample_rate, uint32_t num_ou
 oal_effect *oal_effect_create(int kind, uint32_t sample_rate, uint32_t num_out_lines, uint32_t num_real, int front_center)
 { return oal_effect_create_ex(kind, sample_rate, num_out_lines, num_real, front_center, 1u, 0, 400.0f, 4u); }
 
+/* AmbiScale::SecondOrderUp (9 x MaxAmbiChannels) and GetHFOrderScales(2, device_order, horizontal)[0..1]: what the pitch
+ * shifter's up-sampler is built from (pshifter.cpp:148-165, :188-198) */
+void oal_ambi_upmix_info2(uint32_t device_order, int horizontal, float *order_scales2, float *second_order_up)
+{
+    auto const scales = AmbiScale::GetHFOrderScales(2, device_order, horizontal != 0);
+    order_scales2[0] = scales[0]; order_scales2[1] = scales[1];
+    for(size_t i{0};i < 9;++i)
+        std::copy_n(AmbiScale::SecondOrderUp[i].begin(), MaxAmbiChannels, second_order_up + i*MaxAmbiChannels);
+}
+
 /* props: the floats of the effect's property struct in declaration order (core/effects/base.h:116-169; the
  * modulator's waveform and the dedicated effect's target as a float-coded integer) */
 void oal_effect_update(oal_effect *e, const float *p, float slot_gain)

@@ -17,7 +17,7 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 f32p = C.POINTER(C.c_float)
 
-CHORUS, DISTORTION, AUTOWAH, VMORPHER, FSHIFTER = 5, 6, 7, 8, 9
+CHORUS, DISTORTION, AUTOWAH, VMORPHER, FSHIFTER, PSHIFTER = 5, 6, 7, 8, 9, 10
 
 
 def _ref():
@@ -74,9 +74,12 @@ SCHEDULES = {
     "fshifter": (FSHIFTER, [([100.0, 0, 1], 1.0, 1024), (None, 1.0, 1024), (None, 1.0, 300), (None, 1.0, 1024), (None, 1.0, 1),
                             (None, 1.0, 700), ([2500.0, 2, 0], 0.8, 1024), (None, 0.8, 1024), ([0.0, 1, 1], 1.0, 1024),
                             (None, 1.0, 1024), ([30000.0, 1, 2], 1.0, 1024), (None, 1.0, 255), (None, 1.0, 1024)]),
+    "pshifter": (PSHIFTER, [([12, 0], 1.0, 1024)] + [(None, 1.0, 1024)] * 5 + [(None, 1.0, 300), ([-12, 0], 0.8, 1024)]
+                 + [(None, 0.8, 1024)] * 4 + [([3, -20], 1.0, 1024)] + [(None, 1.0, 1024)] * 3 + [(None, 1.0, 1), ([0, 0], 1.0, 1024),
+                                                                                                  (None, 1.0, 1024)]),
 }
-# which fields are integers on the product side (the harness takes float-coded integers)
-SINUSOID = {"chorus_sinusoid", "vmorpher_sinusoid", "autowah"}
+# compared within a bound instead of bit for bit
+SINUSOID = {"chorus_sinusoid", "vmorpher_sinusoid", "autowah", "pshifter"}
 
 
 def out_gain(kind, props, slot_gain):
@@ -94,21 +97,29 @@ def run(name, nlines, order, wet_chans, mode):
     assert ref
     fx = oalgpu.Effect(kind, nlines, wet_chans, 48000, oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
     up = None
-    if order > 1:
+    if kind == PSHIFTER and order > 2:
+        sc, up = np.zeros(2, np.float32), np.zeros((9, 25), np.float32)
+        R.oal_ambi_upmix_info2.argtypes = [C.c_uint32, C.c_int, f32p, f32p]
+        R.oal_ambi_upmix_info2.restype = None
+        R.oal_ambi_upmix_info2(order, 0, fp(sc), fp(up))
+        fx.set_upsampler(sc, 400.0 / 48000.0)
+    elif kind != PSHIFTER and order > 1:
         sc, up, xo = L.ambi_upmix_info(order, False)
         fx.set_upsampler(sc, xo)
     x = wet_blocks(60 + kind, len(schedule), wet_chans)
     if kind == AUTOWAH:
         x *= 0.5
-    worst, sounded, differing, total = 0.0, False, 0, 0
+    worst_abs, run_scale, sounded, differing, total = 0.0, 0.0, False, 0, 0
     for u, (props, gain, n) in enumerate(schedule):
         if props is not None:
             R.oal_effect_update(ref, fp(np.asarray(props, np.float32)), gain)
             g = out_gain(kind, props, gain)
             targets = np.full(max(wet_chans, 4), 0xffffffff, np.uint32)
             targets[:wet_chans] = np.arange(wet_chans)
-            if up is not None:       # ComputePanGains(Dry, FirstOrderUp[c], gain) on an identity AmbiMap
+            if up is not None:       # ComputePanGains(Dry, FirstOrderUp[c] / SecondOrderUp[c], gain) on an identity AmbiMap
                 gains = ((np.float32(1.0) * up[:, :nlines]) * g).astype(np.float32)
+                targets = np.full(len(up), 0xffffffff, np.uint32)
+                targets[:wet_chans] = np.arange(wet_chans)
             else:
                 gains = np.full(max(wet_chans, 4), g, np.float32)
             fx.update(props, targets, gains)
@@ -122,12 +133,13 @@ def run(name, nlines, order, wet_chans, mode):
         if name not in SINUSOID:
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, u, float(np.abs(got - want).max()))
         else:
-            worst = max(worst, float(np.abs(got.astype(np.float64) - want).max()) / max(scale, 1e-9))
+            worst_abs = max(worst_abs, float(np.abs(got.astype(np.float64) - want).max()))
+            run_scale = max(run_scale, scale)
             differing += int((got.view(np.uint32) != want.view(np.uint32)).sum()); total += got.size
     assert sounded
     R.oal_effect_destroy(ref)
     fx.close()
-    return worst, differing / max(total, 1)
+    return worst_abs / max(run_scale, 1e-9), differing / max(total, 1)      # against the run's maximum
 
 
 @pytest.mark.parametrize("mode", ["exact", "fast"])
@@ -181,3 +193,15 @@ def test_autowah_and_morpher_follow_the_wet_channel_count():
     run("vmorpher_triangle", 4, 1, 3, "fast")
     worst, _ = run("autowah", 4, 1, 2, "fast")
     assert worst <= 1e-5
+
+
+@pytest.mark.parametrize("wet_chans,order", [(4, 1), (1, 1), (9, 2), (9, 3)], ids=["first_order", "mono", "second_order", "upsampled_to_third"])
+def test_pitch_shifter(wet_chans, order):
+    """The phase vocoder against the reference's (pffft transforms, libm atan2f / hypotf / sinf / cosf): octave up, octave
+    down (several source bins per target bin: the dominant-magnitude choice), a detuned interval, unison -- 20 blocks,
+    160 hops with the synthesis phases accumulating throughout.  Bound: 1e-4 of the run's maximum."""
+    nlines = (order + 1) ** 2 if order > 1 else 4
+    nlines = max(nlines, 9) if wet_chans == 9 else nlines
+    worst, _ = run("pshifter", nlines, order, wet_chans, "fast")
+    print("pitch shifter worst relative error", worst)
+    assert worst <= 1e-4, worst
