@@ -421,7 +421,7 @@ int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_stat
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);
 /* Enables/disables the event timing above (off by default: it adds two event records). */
 int oalgpu_set_timing(oalgpu_context *ctx, int enable);
-/* ---- the small EffectStates: equalizer, ring modulator, echo, dedicated ------------------------
+/* ---- the EffectStates of alc/effects/ besides the reverbs -----------------------------------------
  * EffectState::deviceUpdate / update / process (core/effects/base.h:197-209) of alc/effects/{equalizer,modulator,
  * echo,dedicated}.cpp.  create = deviceUpdate; update takes the effect's EFX properties (core/effects/base.h:
  * 116-169) and what update() derives from the ambisonic layer, resolved by the caller:

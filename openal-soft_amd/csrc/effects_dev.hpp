@@ -43,7 +43,7 @@ __device__ __forceinline__ void MixOntoLines(const float *src, float *out, uint3
 // every lane fetches the NV inputs of one sample (load(i, v): anything that does not depend on the recurrence -- LDS
 // or global reads, per-sample coefficient math -- happens here, 64 samples at once), the samples then go through
 // step() one after the other, their inputs broadcast with v_readlane; step() runs uniformly on all lanes, so no
-// memory latency sits on the recurrence's dependent chain.  dst may alias what load() reads.
+// memory latency sits on the recurrence's dependent chain.  dst (LDS) may alias what load() reads.
 template<int NV, typename Load, typename Step>
 __device__ __forceinline__ void WaveSerial(uint32_t n, uint32_t lane, float *dst, Load &&load, Step &&step)
 {
@@ -52,8 +52,8 @@ __device__ __forceinline__ void WaveSerial(uint32_t n, uint32_t lane, float *dst
         const uint32_t i = base + lane;
         float v[NV];
         load(i < n ? i : n - 1u, v);
-        float yv = 0.0f;
         const uint32_t cnt = __builtin_amdgcn_readfirstlane((n - base) < 64u ? (n - base) : 64u);
+        // every lane holds the same y: all of them store it to the one address (one LDS instruction, no VALU select)
         if(cnt == 64u)
         {
 #pragma unroll
@@ -62,8 +62,7 @@ __device__ __forceinline__ void WaveSerial(uint32_t n, uint32_t lane, float *dst
                 float x[NV];
 #pragma unroll
                 for(int q = 0; q < NV; ++q) x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[q]), k));
-                const float y = step(x);
-                yv = (lane == uint32_t(k)) ? y : yv;
+                dst[base + uint32_t(k)] = step(x);
             }
         }
         else
@@ -74,11 +73,9 @@ __device__ __forceinline__ void WaveSerial(uint32_t n, uint32_t lane, float *dst
 #pragma unroll
                 for(int q = 0; q < NV; ++q)
                     x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[q]), int(__builtin_amdgcn_readfirstlane(k))));
-                const float y = step(x);
-                yv = (lane == k) ? y : yv;
+                dst[base + k] = step(x);
             }
         }
-        if(i < n) dst[i] = yv;
     }
 }
 

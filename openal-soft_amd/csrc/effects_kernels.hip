@@ -7,8 +7,8 @@
 //
 // (update() -- coefficient design, delays, the carrier's period -- is host work, effects_api.hip; what it derives
 // from the ambisonic layer, the target channel / gain per wet channel and the panned gains, comes from the caller.)
-// Like the EAX reverb, these keep the reference's operation order in every mode: the recurrences run one lane per
-// channel (four channels side by side), everything around them over the workgroup -- the output is bit-identical
+// Like the EAX reverb, these keep the reference's operation order in every mode: the recurrences run one wavefront per
+// channel (four channels side by side, WaveSerial of effects_dev.hpp), everything around them over the workgroup -- the output is bit-identical
 // to the reference's, except the sinusoid carrier (the GPU's sinf against libm).  A block-scan form of the
 // biquads was built first and dropped: the equalizer's high-Q peaking sections and the modulator's 200 Hz
 // high-pass amplify float32 rounding so much (the reference's own serial loop is 7e-6 of the block maximum away
@@ -52,11 +52,20 @@ __global__ void __launch_bounds__(256) EffectKernel(FxLaunch F)
                 for(uint32_t i = lane; i < n; i += 64u) buf[wave][i] = in[i];
                 WaveSync();
                 BiquadState f0 = S.bq[c][0], f1 = S.bq[c][1], f2 = S.bq[c][2], f3 = S.bq[c][3];
-                if(lane == 0)
-                {   // the recurrences: one lane per channel, the reference's operation order
-                    if(mod) BiquadRaw(f0, buf[wave], buf[wave], n);
-                    else { BiquadDualRaw(f0, f1, buf[wave], buf[wave], n); BiquadDualRaw(f2, f3, buf[wave], buf[wave], n); }
-                }
+                // the recurrences: in the reference's operation order, one sample after the other (WaveSerial keeps the
+                // LDS reads off the dependent chain); the equalizer's two DualBiquad passes run sample-interleaved,
+                // which gives every filter the same input sequence
+                auto one = [](BiquadState &f, float x) {
+                    const float y = x * f.b0 + f.z1;
+                    f.z1 = x * f.b1 - y * f.a1 + f.z2;
+                    f.z2 = x * f.b2 - y * f.a2;
+                    return y;
+                };
+                float *row = buf[wave];
+                if(mod) WaveSerial<1>(n, lane, row, [&](uint32_t i, float *v) { v[0] = row[i]; }, [&](const float *x) { return one(f0, x[0]); });
+                else
+                    WaveSerial<1>(n, lane, row, [&](uint32_t i, float *v) { v[0] = row[i]; },
+                        [&](const float *x) { return one(f3, one(f2, one(f1, one(f0, x[0])))); });
                 if(lane == 0)
                 {
                     S.bq[c][0].z1 = f0.z1; S.bq[c][0].z2 = f0.z2;
@@ -94,17 +103,19 @@ __global__ void __launch_bounds__(256) EffectKernel(FxLaunch F)
         // out[target c][i] += in[c][i] * gains[i] * gain (no ramp; silent gains skipped)
         for(uint32_t i = t; i < n; i += 256u) buf[1][i] = F.wetIn[i];
         __syncthreads();
-        if(t == 0)
+        if(wave == 0)
         {
             float env = S.env;
-            for(uint32_t i = 0; i < n; ++i)
-            {
-                const float amplitude = F.compOn ? fminf(fmaxf(fabsf(buf[1][i]), 0.5f), 2.0f) : 1.0f;
-                if(amplitude > env) env = fminf(env * F.attackMult, amplitude);
-                else if(amplitude < env) env = fmaxf(env * F.releaseMult, amplitude);
-                buf[0][i] = 1.0f / env;
-            }
-            S.env = env;
+            const float *src = buf[1];
+            WaveSerial<1>(n, lane, buf[0],
+                [&](uint32_t i, float *v) { v[0] = F.compOn ? fminf(fmaxf(fabsf(src[i]), 0.5f), 2.0f) : 1.0f; },
+                [&](const float *x) {
+                    const float amplitude = x[0];
+                    if(amplitude > env) env = fminf(env * F.attackMult, amplitude);
+                    else if(amplitude < env) env = fmaxf(env * F.releaseMult, amplitude);
+                    return 1.0f / env;
+                });
+            if(lane == 0) S.env = env;
         }
         __syncthreads();
         for(uint32_t c = 0; c < F.numIn; ++c)
