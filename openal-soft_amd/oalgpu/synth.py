@@ -56,31 +56,41 @@ def lcg_block_f32(seed, n):
     return (x.astype(np.float64) / 2147483648.0 - 1.0).astype(np.float32)
 
 
-def synth_mhr_bytes(seed=0x5EED1234, ir_size=64, az_counts=None, rate=48000, dist_mm=1200):
-    az_counts = list(DEFAULT_AZ_COUNTS if az_counts is None else az_counts)
-    ev_count = len(az_counts)
-    n_ir = sum(az_counts)
+def synth_mhr_bytes(seed=0x5EED1234, ir_size=64, az_counts=None, rate=48000, dist_mm=1200, fields=None, stereo=False):
+    """MinPHR03 data set.  fields: [(distance in mm, azimuth counts per elevation), ...] in the file's order
+    (every distance smaller than the one before, core/hrtf_loader.cpp:627-632); default: one field.
+    stereo: channel type 1 (left AND right responses stored, no mirroring)."""
+    if fields is None:
+        fields = [(dist_mm, list(DEFAULT_AZ_COUNTS if az_counts is None else az_counts))]
+    fields = [(int(d), list(a)) for d, a in fields]
     rng = np.random.default_rng(seed)
-    hdr = b"MinPHR03" + struct.pack("<IBBB", rate, 0, ir_size, 1)
-    hdr += struct.pack("<HB", dist_mm, ev_count) + bytes(az_counts)
+    hdr = b"MinPHR03" + struct.pack("<IBBB", rate, 1 if stereo else 0, ir_size, len(fields))
+    for d, azs in fields:
+        hdr += struct.pack("<HB", d, len(azs)) + bytes(azs)
+    n_ir = sum(sum(a) for _, a in fields)
+    ears = 2 if stereo else 1
     t = np.arange(ir_size)
-    coeffs = np.zeros((n_ir, ir_size), np.float64)
-    delays = np.zeros(n_ir, np.uint8)
+    coeffs = np.zeros((n_ir, ir_size, ears), np.float64)
+    delays = np.zeros((n_ir, ears), np.uint8)
     k = 0
-    for e, azc in enumerate(az_counts):
-        ev = -np.pi / 2 + np.pi * e / (ev_count - 1)
-        for a in range(azc):
-            az = 2 * np.pi * a / azc
-            lateral = np.sin(az) * np.cos(ev)          # +1 = source on the right
-            onset = 4.0 + 3.0 * (1.0 + lateral)        # left ear hears right-side sources later
-            env = np.exp(-np.maximum(t - onset, 0) / 6.0) * (t >= np.floor(onset))
-            ir = rng.standard_normal(ir_size) * env * (0.25 + 0.2 * (1.0 - lateral))
-            coeffs[k] = np.clip(ir, -0.95, 0.95)
-            delays[k] = int(round((20.0 + 18.0 * (1.0 + lateral)) * 4.0))   # quarter samples, <= 252
-            k += 1
+    for fi, (d, az_counts) in enumerate(fields):
+        ev_count = len(az_counts)
+        near = 1.0 + 0.25 * fi                        # nearer fields: a little louder
+        for e, azc in enumerate(az_counts):
+            ev = -np.pi / 2 + np.pi * e / (ev_count - 1)
+            for a in range(azc):
+                az = 2 * np.pi * a / azc
+                for ear in range(ears):
+                    lateral = np.sin(az) * np.cos(ev) * (1.0 if ear == 0 else -1.0)    # +1 = source on the far side of this ear
+                    onset = 4.0 + 3.0 * (1.0 + lateral)        # the far ear hears the source later
+                    env = np.exp(-np.maximum(t - onset, 0) / 6.0) * (t >= np.floor(onset))
+                    ir = rng.standard_normal(ir_size) * env * (0.25 + 0.2 * (1.0 - lateral)) * near
+                    coeffs[k, :, ear] = np.clip(ir, -0.95, 0.95)
+                    delays[k, ear] = int(round((20.0 + 18.0 * (1.0 + lateral)) * 4.0))   # quarter samples, <= 252
+                k += 1
     q = np.round(coeffs * 8388608.0).astype(np.int64)
     q = np.clip(q, -8388608, 8388607) & 0xFFFFFF
-    b = np.empty((n_ir, ir_size, 3), np.uint8)
+    b = np.empty((n_ir, ir_size, ears, 3), np.uint8)
     b[..., 0] = q & 0xFF
     b[..., 1] = (q >> 8) & 0xFF
     b[..., 2] = (q >> 16) & 0xFF

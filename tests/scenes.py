@@ -7,7 +7,7 @@ import oracle_lib as ol
 
 
 def run_scene(L, MHR, hrtf, fmt, resampler, steps, n_updates, nvoices, rng_seed, sends=0, todo=1024,
-               nonloop=False, stop_at=None, move=True, kernel_names=None):
+               nonloop=False, stop_at=None, move=True, kernel_names=None, distances=None):
     rng = np.random.default_rng(rng_seed)
     if hrtf:
         L.hrtf_load(MHR)
@@ -43,7 +43,8 @@ def run_scene(L, MHR, hrtf, fmt, resampler, steps, n_updates, nvoices, rng_seed,
         if hrtf:
             return ol.make_voice_params(steps[v % len(steps)], resampler,
                                         hrtf=(np.arcsin(r.uniform(-1, 1)), r.uniform(-np.pi, np.pi),
-                                              2.0, 0.0, 10 ** (r.uniform(-60, -20) / 20)),
+                                              distances[(v + k) % len(distances)] if distances else 2.0, 0.0,
+                                              10 ** (r.uniform(-60, -20) / 20)),
                                         direct_filter=filt, sends=snd)
         return ol.make_voice_params(steps[v % len(steps)], resampler, dry_gains=r.uniform(0, 0.1, 5),
                                     direct_filter=filt, sends=snd)

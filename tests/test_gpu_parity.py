@@ -217,6 +217,42 @@ def test_get_coeffs_on_gpu_bit_exact(oracle, exact, synth_mhr):
     sc.close()
 
 
+@pytest.mark.parametrize("stereo", [False, True], ids=["left_only", "left_right"])
+def test_get_coeffs_multi_field_sets(oracle, exact, fast, tmp_path, stereo):
+    """three field depths with different layouts, and a set that stores both ears: the parsed store, and getCoeffs on
+    the GPU (the parameter kernel's LDS copy of the index tables) for directions at distances around every field
+    boundary, bit for bit"""
+    from oalgpu import synth
+    fields = [(1400, [1, 12, 24, 36, 24, 12, 1]), (900, [1, 8, 16, 24, 30, 24, 16, 8, 1]), (300, [1, 6, 12, 6, 1])]
+    path = synth.write_synth_mhr(str(tmp_path / "fields.mhr"), fields=fields, stereo=stereo, ir_size=32)
+    oracle.hrtf_load(path)
+    exact.hrtf_load(path)
+    sc = exact.make_scene(num_dry=4, num_real=2, hrtf=True)
+    raw_a, raw_b = sc.hrtf_raw(), oracle.hrtf_raw()
+    for k in ("field_evcount", "elev_azcount", "elev_iroffset", "delays"):
+        assert np.array_equal(raw_a[k], raw_b[k]), k
+    assert_bit_equal(raw_a["coeffs"], raw_b["coeffs"], "parsed HRIR store")
+    rng = np.random.default_rng(19)
+    dirs = [(0.2, 1.0, d, 0.0) for d in (0.05, 0.3, 0.3000001, 0.31, 0.9, 0.91, 1.4, 1.41, 3.0)]
+    dirs += [(np.arcsin(rng.uniform(-1, 1)), rng.uniform(-np.pi, np.pi), rng.uniform(0.05, 2.0), rng.uniform(0, 2 * np.pi))
+             for _ in range(200)]
+    dirs = np.array(dirs, np.float32)
+    co, de = sc.hrtf_get_coeffs(dirs)
+    fields_seen = set()
+    for i, d in enumerate(dirs):
+        c_ref, d_ref = oracle.hrtf_get_coeffs(float(d[0]), float(d[1]), float(d[2]), float(d[3]))
+        assert tuple(de[i]) == d_ref, (i, d)
+        assert_bit_equal(co[i], c_ref, f"getCoeffs {i}")
+        fields_seen.add(0 if d[2] >= 1.4 else 1 if d[2] >= 0.9 else 2)
+    assert fields_seen == {0, 1, 2}
+    sc.close()
+    # the voice path: moving sources whose parameter records carry those distances (ApplyParamsKernel)
+    cfg = dict(hrtf=True, fmt=ol.FMT_FLOAT, resampler=ol.RS_BSINC24, steps=[60211], n_updates=3, nvoices=10,
+               distances=[0.1, 0.3, 0.5, 0.9, 1.0, 1.4, 2.0])
+    _cmp_scene(exact, oracle, path, cfg, 11, single=False)
+    _cmp_scene(fast, oracle, path, cfg, 12, single=False)
+
+
 # ------------------------------------------------------------------ golden vectors (EXACT)
 def test_per_call_kernels_match_reference_golden(exact, synth_mhr):
     """Same cases as tests/golden_cases.py, per-call kernels only, against the committed

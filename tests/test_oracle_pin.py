@@ -251,3 +251,30 @@ def test_other_hrir_lengths_bit_exact(libs, tmp_path, ir_size):
     fb, ib = run_scene(port, path, rng_seed=7, **cfg)
     assert ia == ib
     assert_bit_equal(fa, fb, f"IrSize {ir_size} scene")
+
+
+MULTI_FIELD = [(1400, [1, 12, 24, 36, 24, 12, 1]), (900, [1, 8, 16, 24, 30, 24, 16, 8, 1]), (300, [1, 6, 12, 6, 1])]
+
+
+@pytest.mark.parametrize("stereo", [False, True], ids=["left_only", "left_right"])
+def test_multi_field_data_sets_bit_exact(libs, tmp_path, stereo):
+    """A data set with three field depths of different elevation / azimuth layouts (HrtfStore::getCoeffs picks the field
+    by distance, core/hrtf.cpp:198-207) and one that stores both ears (no mirroring): store, getCoeffs and a scene
+    whose sources sit at distances on both sides of every field boundary."""
+    from oalgpu import synth
+    ref, port = libs
+    path = synth.write_synth_mhr(str(tmp_path / "fields.mhr"), fields=MULTI_FIELD, stereo=stereo, ir_size=32)
+    info = ref.hrtf_load(path)
+    assert info.num_fields == 3 and info.num_elevs == 7 + 9 + 5
+    _check_hrtf_store(libs, path)
+    for dist in (0.1, 0.3, 0.31, 0.9, 0.95, 1.4, 2.0):
+        ca, da = ref.hrtf_get_coeffs(0.2, 1.0, dist, 0.0)
+        cb, db = port.hrtf_get_coeffs(0.2, 1.0, dist, 0.0)
+        assert da == db
+        assert_bit_equal(ca, cb, f"getCoeffs at {dist} m")
+    cfg = dict(hrtf=True, fmt=ol.FMT_FLOAT, resampler=ol.RS_BSINC24, steps=[60211], n_updates=3, nvoices=10,
+               distances=[0.1, 0.3, 0.5, 0.9, 1.0, 1.4, 2.0])
+    fa, ia = run_scene(ref, path, rng_seed=11, **cfg)
+    fb, ib = run_scene(port, path, rng_seed=11, **cfg)
+    assert ia == ib
+    assert_bit_equal(fa, fb, "multi-field scene")
