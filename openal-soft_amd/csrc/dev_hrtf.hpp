@@ -61,14 +61,7 @@ struct HrtfStoreDev {
 
 struct HrirBlend { uint32_t idx[4]; float w[4]; float passthru; uint32_t delay[2]; };
 
-// the store's small index tables, wherever the caller keeps them (global memory, or a copy in LDS)
-struct HrtfTables {
-    const float *fieldDistance;
-    const uint8_t *fieldEvCount;
-    const uint16_t *elevAzCount, *elevIrOffset;
-};
-
-__device__ __forceinline__ HrirBlend HrtfBlendFor(const HrtfStoreDev &st, const HrtfTables &tb, float elevation, float azimuth,
+__device__ __forceinline__ HrirBlend HrtfBlendFor(const HrtfStoreDev &st, float elevation, float azimuth,
     float distance, float spread)
 {
     constexpr float invPi = 0.318309886183790671538f;
@@ -78,10 +71,10 @@ __device__ __forceinline__ HrirBlend HrtfBlendFor(const HrtfStoreDev &st, const 
     uint32_t ebase = 0, field = 0;
     for(; field + 1 < st.numFields; ++field)
     {
-        if(distance >= tb.fieldDistance[field]) break;
-        ebase += tb.fieldEvCount[field];
+        if(distance >= st.fieldDistance[field]) break;
+        ebase += st.fieldEvCount[field];
     }
-    const uint32_t evcount = tb.fieldEvCount[field];
+    const uint32_t evcount = st.fieldEvCount[field];
 
     // CalcEvIndex, hrtf.cpp:167-173
     const float evf = (invPi * elevation + 0.5f) * float(evcount - 1);
@@ -90,8 +83,8 @@ __device__ __forceinline__ HrirBlend HrtfBlendFor(const HrtfStoreDev &st, const 
     const float evBlend = evf - float(evraw);
     const uint32_t ev1 = (ev0 + 1u < evcount - 1u) ? ev0 + 1u : evcount - 1u;
 
-    const uint32_t ir0 = tb.elevIrOffset[ebase + ev0], ir1 = tb.elevIrOffset[ebase + ev1];
-    const uint32_t azc0 = tb.elevAzCount[ebase + ev0], azc1 = tb.elevAzCount[ebase + ev1];
+    const uint32_t ir0 = st.elevIrOffset[ebase + ev0], ir1 = st.elevIrOffset[ebase + ev1];
+    const uint32_t azc0 = st.elevAzCount[ebase + ev0], azc1 = st.elevAzCount[ebase + ev1];
     // CalcAzIndex, hrtf.cpp:178-184
     const float az0f = (invPi * 0.5f * azimuth + 1.0f) * float(azc0);
     const uint32_t az0raw = float2uint(az0f);
@@ -120,9 +113,6 @@ __device__ __forceinline__ HrirBlend HrtfBlendFor(const HrtfStoreDev &st, const 
     b.passthru = float(1.0 / 1.41421356237309504880) * (1.0f - dirfact);   // PassthruCoeff, hrtf.cpp:81
     return b;
 }
-
-__device__ __forceinline__ HrirBlend HrtfBlendFor(const HrtfStoreDev &st, float elevation, float azimuth, float distance, float spread)
-{ return HrtfBlendFor(st, HrtfTables{st.fieldDistance, st.fieldEvCount, st.elevAzCount, st.elevIrOffset}, elevation, azimuth, distance, spread); }
 
 // element e (0..255) of the blended HrirArray, hrtf.cpp:247-259: starts from the pass-through
 // tap (elements 0,1) or 0, then adds the four weighted HRIRs in order (mul, then add).

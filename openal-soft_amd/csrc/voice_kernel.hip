@@ -50,24 +50,9 @@ struct alignas(16) SharedMem {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfStoreDev st, const ParamRecord *__restrict__ recs)
 {
-    // The store's index tables go to LDS while the record is on its way (they do not depend on it), so that the
-    // blend's chain of dependent loads is record -> HRIRs instead of record -> field -> elevation -> HRIRs; the
-    // wavefronts split the work: 0 the voice's scalars and direct filters, 1 the send filters, 2-3 the HRIR blend.
-    constexpr uint32_t kMaxElevLds = 512;
-    __shared__ uint16_t azLds[kMaxElevLds], irLds[kMaxElevLds];
-    __shared__ float distLds[8];
-    __shared__ uint8_t evLds[8];
-    const uint32_t t = threadIdx.x;
-    const bool tablesInLds = L.hrtf && st.numElevs <= kMaxElevLds && st.numFields <= 8u;
     const ParamRecord &r = recs[blockIdx.x];
     const uint32_t v = r.voice;
-    const float dir[4] = {r.hrtfDir[0], r.hrtfDir[1], r.hrtfDir[2], r.hrtfDir[3]};
-    if(tablesInLds)
-    {
-        for(uint32_t i = t; i < st.numElevs; i += 256u) { azLds[i] = st.elevAzCount[i]; irLds[i] = st.elevIrOffset[i]; }
-        if(t < st.numFields) { distLds[t] = st.fieldDistance[t]; evLds[t] = st.fieldEvCount[t]; }
-        __syncthreads();                  // before the roles split: nobody waits for wavefront 0's chores
-    }
+    const uint32_t t = threadIdx.x;
     VoiceCtl &ctl = L.ctl[v];
     if(t == 0)
     {
@@ -89,18 +74,13 @@ __global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfSto
     }
     if(L.hrtf)
     {
-        if(t >= 128u)
+        const HrirBlend b = HrtfBlendFor(st, r.hrtfDir[0], r.hrtfDir[1], r.hrtfDir[2], r.hrtfDir[3]);
+        if(t < L.irStride * 2)
+            L.hrtfTgt[size_t{v} * L.irStride * 2 + t] = HrtfBlendElement(st, b, t);
+        if(t == 0)
         {
-            const HrtfTables tb = tablesInLds ? HrtfTables{distLds, evLds, azLds, irLds}
-                : HrtfTables{st.fieldDistance, st.fieldEvCount, st.elevAzCount, st.elevIrOffset};
-            const HrirBlend b = HrtfBlendFor(st, tb, dir[0], dir[1], dir[2], dir[3]);
-            for(uint32_t e = t - 128u; e < L.irStride * 2; e += 128u)
-                L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = HrtfBlendElement(st, b, e);
-            if(t == 128u)
-            {
-                ctl.hrtfTgtDelay[0] = b.delay[0]; ctl.hrtfTgtDelay[1] = b.delay[1];
-                ctl.hrtfTgtGain = r.hrtfGain;
-            }
+            ctl.hrtfTgtDelay[0] = b.delay[0]; ctl.hrtfTgtDelay[1] = b.delay[1];
+            ctl.hrtfTgtGain = r.hrtfGain;
         }
     }
     else if(t < L.numDry)
