@@ -205,3 +205,55 @@ def test_pitch_shifter(wet_chans, order):
     worst, _ = run("pshifter", nlines, order, wet_chans, "fast")
     print("pitch shifter worst relative error", worst)
     assert worst <= 1e-4, worst
+
+
+def test_chorus_and_pitch_shifter_on_context_slots(synth_mhr):
+    """two slots of a scene, a chorus on one and a pitch shifter on the other: oalgpu_mix_update runs them between the
+    reduction and the post-process from the slots' wet buses into the dry lines (the path every oalgpu_effect kind
+    shares); the reference side: the oracle scene's wet buses through the compiled ChorusState / PshifterState"""
+    import oalgpu
+    L, R = _ref()
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    api.hrtf_load(synth_mhr)
+    L.hrtf_load(synth_mhr)
+
+    def build(lib):
+        sc = lib.make_scene(num_dry=4, num_real=2, num_sends=2, num_slots=2, wet_channels=4, hrtf=True,
+                            **({"max_voices": 8} if lib is api else {}))
+        cc = np.zeros((4, 128, 2), np.float32); cc[:, :64] = np.random.default_rng(5).uniform(-0.2, 0.2, (4, 64, 2))
+        sc.set_direct_hrtf(cc, [1.0, 0.8, 0.8, 0.8], 400.0 / 48000.0, 64)
+        buf = sc.add_buffer(np.random.default_rng(6).uniform(-1, 1, 6000).astype(np.float32), ol.FMT_FLOAT)
+        for v in range(6):
+            sc.add_voice(buf, True, position=v * 700)
+            r = np.random.default_rng(50 + v)
+            sc.set_params(v, ol.make_voice_params(60211, ol.RS_BSINC24, hrtf=(0.2 * v, 0.9 * v, 2.0, 0.0, 0.1),
+                                                  sends=[(0, r.uniform(0.1, 0.4, 4), None), (1, r.uniform(0.1, 0.4, 4), None)]))
+        return sc
+
+    chorus_props, shifter_props = [1, 90, 1.1, 0.1, 0.25, 0.016], [7, 0]
+    gsc = build(api)
+    fx = [oalgpu.Effect(CHORUS, 4, 4, 48000, oalgpu.MATH_FAST), oalgpu.Effect(PSHIFTER, 4, 4, 48000, oalgpu.MATH_FAST)]
+    for e, props, slot in zip(fx, (chorus_props, shifter_props), (0, 1)):
+        e.update(props, np.arange(4, dtype=np.uint32), np.full(4, 1.0, np.float32))
+        gsc.set_slot_effect(slot, e)
+    osc = build(L)
+    refs = [R.oal_effect_create_ex(CHORUS, 48000, 4, 0, -1, 1, 0, 400.0, 4), R.oal_effect_create_ex(PSHIFTER, 48000, 4, 0, -1, 1, 0, 400.0, 4)]
+    for r, props in zip(refs, (chorus_props, shifter_props)):
+        R.oal_effect_update(r, fp(np.asarray(props, np.float32)), 1.0)
+    for k in range(10):                     # the shifter's FIFO needs 1024 - 128 samples before anything comes out
+        gsc.mix(1024, post_process=True)
+        osc.mix(1024, post_process=False)
+        dry = osc.dry_view()
+        lines = np.ascontiguousarray(dry[:4])
+        for slot, r in enumerate(refs):     # slots in order, each adding to the dry lines (alu.cpp:2209-2257)
+            R.oal_effect_process(r, fp(np.ascontiguousarray(osc.wet(slot)[:4])), fp(lines), 1024)
+        dry[:4] = lines
+        osc.post_process(1024)
+        a, b = gsc.dry(), osc.dry()
+        assert np.abs(b).max() > 1e-3
+        assert np.abs(a.astype(np.float64) - b).max() <= 1e-4 * np.abs(b).max() + 1e-7, k
+    gsc.close(); osc.close()
+    for e in fx:
+        e.close()
+    for r in refs:
+        R.oal_effect_destroy(r)
