@@ -88,23 +88,23 @@ def out_gain(kind, props, slot_gain):
     return np.float32(slot_gain)
 
 
-def run(name, nlines, order, wet_chans, mode):
+def run(name, nlines, order, wet_chans, mode, rate=48000):
     import oalgpu
     assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
     L, R = _ref()
     kind, schedule = SCHEDULES[name]
-    ref = R.oal_effect_create_ex(kind, 48000, nlines, 0, -1, order, 0, 400.0, wet_chans)
+    ref = R.oal_effect_create_ex(kind, rate, nlines, 0, -1, order, 0, 400.0, wet_chans)
     assert ref
-    fx = oalgpu.Effect(kind, nlines, wet_chans, 48000, oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
+    fx = oalgpu.Effect(kind, nlines, wet_chans, rate, oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
     up = None
     if kind == PSHIFTER and order > 2:
         sc, up = np.zeros(2, np.float32), np.zeros((9, 25), np.float32)
         R.oal_ambi_upmix_info2.argtypes = [C.c_uint32, C.c_int, f32p, f32p]
         R.oal_ambi_upmix_info2.restype = None
         R.oal_ambi_upmix_info2(order, 0, fp(sc), fp(up))
-        fx.set_upsampler(sc, 400.0 / 48000.0)
+        fx.set_upsampler(sc, 400.0 / rate)
     elif kind != PSHIFTER and order > 1:
-        sc, up, xo = L.ambi_upmix_info(order, False)
+        sc, up, xo = L.ambi_upmix_info(order, False, rate)
         fx.set_upsampler(sc, xo)
     x = wet_blocks(60 + kind, len(schedule), wet_chans)
     if kind == AUTOWAH:
@@ -157,9 +157,10 @@ def test_chorus_sinusoid_lfo():
 
 
 def test_autowah():
-    """cosf / sinf of every sample's filter frequency: a last-bit difference enters a recursive filter and decays"""
+    """cosf / sinf of every sample's filter frequency: a last-bit difference enters a recursive filter (Q = 5 and the
+    resonance gain on top) and decays; 5e-5 of the run's maximum bounds it (measured 1e-6 .. 1.4e-5 over the rates)"""
     worst, frac = run("autowah", 4, 1, 4, "fast")
-    assert worst <= 1e-5, (worst, frac)
+    assert worst <= 5e-5, (worst, frac)
 
 
 def test_vmorpher_sinusoid_lfo():
@@ -192,7 +193,7 @@ def test_mono_wet_bus():
 def test_autowah_and_morpher_follow_the_wet_channel_count():
     run("vmorpher_triangle", 4, 1, 3, "fast")
     worst, _ = run("autowah", 4, 1, 2, "fast")
-    assert worst <= 1e-5
+    assert worst <= 5e-5
 
 
 @pytest.mark.parametrize("wet_chans,order", [(4, 1), (1, 1), (9, 2), (9, 3)], ids=["first_order", "mono", "second_order", "upsampled_to_third"])
@@ -257,3 +258,19 @@ def test_chorus_and_pitch_shifter_on_context_slots(synth_mhr):
         e.close()
     for r in refs:
         R.oal_effect_destroy(r)
+
+
+@pytest.mark.parametrize("rate", [44100, 192000])
+def test_other_device_rates(rate):
+    """everything update() derives from the device rate -- delay-line lengths, LFO periods, filter designs, the chorus'
+    history window in LDS (6150 samples at 192 kHz) -- at the rates either side of 48 kHz"""
+    for name in ("chorus_triangle", "distortion", "vmorpher_triangle", "fshifter"):
+        run(name, 4, 1, 4, "fast", rate)
+    run("chorus_triangle", 9, 2, 4, "fast", rate)          # with the up-sampler's splitter at that rate
+    worst, _ = run("autowah", 4, 1, 4, "fast", rate)
+    # the filter's pole sits at cos(w0) with w0 down to 2 pi 20 Hz / rate: in float, one ulp of that cosine is a third of
+    # (1 - cos w0) at 192 kHz -- the reference's own coefficients are that coarse, and so is the effect of a last-bit
+    # difference between libm's cosf and the correctly rounded value
+    assert worst <= (2e-4 if rate > 100000 else 5e-5), worst
+    worst, _ = run("pshifter", 4, 1, 4, "fast", rate)
+    assert worst <= 1e-4
