@@ -76,16 +76,17 @@ def targets_for(L, kind, props, slot_gain, nlines):
     return None, ((np.float32(1.0) * coeffs[:nlines]) * np.float32(np.float32(slot_gain) * np.float32(props[1]))).astype(np.float32)
 
 
-@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("mode,rate", [("exact", 48000), ("fast", 48000), ("fast", 44100), ("fast", 192000)],
+                         ids=["exact", "fast", "fast_44k1", "fast_192k"])
 @pytest.mark.parametrize("kind,schedule", [(0, EQ), (1, MOD), (2, ECHO), (3, DED), (4, COMP)],
                          ids=["equalizer", "modulator", "echo", "dedicated", "compressor"])
-def test_effect_matches_reference(kind, schedule, mode):
+def test_effect_matches_reference(kind, schedule, mode, rate):
     import oalgpu
     assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
     L, R = _ref()
-    ref = R.oal_effect_create(kind, 48000, NLINES, 0, -1)
+    ref = R.oal_effect_create(kind, rate, NLINES, 0, -1)
     assert ref
-    fx = oalgpu.Effect(kind, NLINES, 4, 48000, oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
+    fx = oalgpu.Effect(kind, NLINES, 4, rate, oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
     x = wet_blocks(40 + kind, len(schedule))
     if kind == 4:
         x *= 6.0                   # the compressor's envelope moves between amplitudes 0.5 and 2
