@@ -290,6 +290,30 @@ int oalgpu_voice_init_queue(oalgpu_context *ctx, uint32_t voice, int first_buffe
     uint32_t position_frac);
 int oalgpu_voice_queue_state(oalgpu_context *ctx, uint32_t voice, int32_t *current_buffer, uint32_t *buffers_done);
 
+/* ---- callback sources (AL_SOFT_callback_buffer) ----------------------------------------------------------------
+ * BufferStorage::mCallback / VoiceBufferItem::mCallback (core/buffer_storage.h:48, core/voice.h:85): the source's
+ * samples come from a function the mixer calls in the middle of Voice::mix, for exactly the blocks the voice's
+ * position needs (voice.cpp:726-752), into a storage of MixerLineSize*MaxPitch + MaxResamplerEdge frames
+ * (al/buffer.cpp:474) whose consumed blocks Voice::mix drops afterwards (:1155-1180).  Calling user code is host
+ * work by definition: oalgpu_mix_update calls `fn` on the calling thread BEFORE the update's voice kernel is
+ * launched, with the byte counts the reference would ask for (the library mirrors the voice's integer state --
+ * mPositionFrac, mStep, mNumCallbackBlocks, mCallbackBlockOffset, VoiceFlag::CallbackStopped -- on the host), uploads
+ * the storage in stream order and hands it to the voice kernels as a static, non-looping buffer of
+ * mNumCallbackBlocks samples read from mCallbackBlockOffset: LoadBufferCallback (:546-561) and the non-looping
+ * LoadBufferStatic (:504-519) are the same function of (length, position), and both kinds of voice end when the
+ * position reaches the length.  Mono PCM formats (one sample per block).  A callback that returns fewer bytes than
+ * asked stops being called (CallbackStopped); the voice plays what it has, holds the last sample, and ends.
+ * fn: `int32_t fn(void *userptr, void *data, int32_t num_bytes)` -> bytes written. */
+typedef int32_t (*oalgpu_callback_fn)(void *userptr, void *data, int32_t num_bytes);
+int oalgpu_voice_init_callback(oalgpu_context *ctx, uint32_t voice, int fmt_type, uint32_t position_frac,
+    oalgpu_callback_fn fn, void *userptr);
+typedef struct oalgpu_callback_state {
+    int32_t position;                   /* Voice::mPosition (the device-side position is relative to the storage) */
+    uint32_t position_frac, num_blocks, block_offset;
+    int32_t stopped, play_state, has_buffer;
+} oalgpu_callback_state;
+int oalgpu_voice_callback_state(oalgpu_context *ctx, uint32_t voice, oalgpu_callback_state *out);
+
 /* IMA4 / MS ADPCM data (FmtIMA4 / FmtMSADPCM, core/buffer_storage.h:35-43; LoadSamples, core/voice.cpp:288-484):
  * `data` = ceil(sample_len / samples_per_block) blocks of ((samples_per_block-1)/2 + 4) * channels (IMA4)
  * or ((samples_per_block-2)/2 + 7) * channels (MS) bytes.  Decoded once, on the GPU, into interleaved

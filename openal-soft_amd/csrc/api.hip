@@ -158,6 +158,19 @@ struct oalgpu_context {
     std::vector<ParamRecord> paramHost;
     DevBuf<VoiceInitRecord> initDev;
     std::vector<VoiceInitRecord> initPending;
+    // callback sources (oalgpu_voice_init_callback): the host's mirror of what Voice::mix keeps for them
+    struct CbVoice {
+        uint32_t voice{0}; int32_t buffer{-1}; uint32_t frameBytes{4}, capacityFrames{0};
+        oalgpu_callback_fn fn{nullptr}; void *user{nullptr};
+        std::vector<char> data;                    // BufferStorage::mData of the callback buffer: numBlocks blocks valid
+        uint32_t numBlocks{0}, blockOffset{0};     // Voice::mNumCallbackBlocks / mCallbackBlockOffset (samples per block = 1)
+        bool stopped{false};                       // VoiceFlag::CallbackStopped
+        int32_t position{0}; uint32_t frac{0}, step{0};        // mPosition / mPositionFrac / mStep
+        int state{OALGPU_VOICE_PLAYING}; bool hasBuffer{true}; // mPlayState / mCurrentBuffer != nullptr
+        char *pinned[2]{nullptr, nullptr}; hipEvent_t copied[2]{nullptr, nullptr}; uint32_t slot{0};
+    };
+    std::vector<CbVoice> cbVoices;
+    std::vector<int32_t> cbOfVoice;                // [voice] index into cbVoices, -1 = not a callback source
 
     ~oalgpu_context()
     {
@@ -173,6 +186,15 @@ struct oalgpu_context {
 };
 
 namespace {
+
+// a callback voice's mStep, wherever parameters pass through the host
+void NoteCallbackSteps(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params, size_t count)
+{
+    if(c->cbVoices.empty()) return;
+    for(size_t i = 0; i < count; ++i)
+        if(voices[i] < c->cbOfVoice.size() && c->cbOfVoice[voices[i]] >= 0)
+            c->cbVoices[size_t(c->cbOfVoice[voices[i]])].step = params[i].step;
+}
 
 int FlushInits(oalgpu_context *c)
 {
@@ -700,6 +722,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.buffers = c->buffers.p;
     c->bufferData.assign(std::max<uint32_t>(desc->max_buffers, 1u), nullptr);
     c->bufferLoopLen.assign(std::max<uint32_t>(desc->max_buffers, 1u), 0u);
+    c->cbOfVoice.assign(std::max<uint32_t>(desc->max_voices, 1u), -1);
 
     const size_t nv = desc->max_voices;
     HIP_TRY(c->ctl.alloc(nv)); HIP_TRY(c->ctl.zero()); L.ctl = c->ctl.p;
@@ -765,6 +788,12 @@ void oalgpu_context_destroy(oalgpu_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if(ctx->postStream) (void)hipStreamSynchronize(ctx->postStream);
     if(ctx->comm) (void)Rccl().commDestroy(static_cast<ncclComm_t>(ctx->comm));
+    for(auto &cb : ctx->cbVoices)
+        for(int k = 0; k < 2; ++k)
+        {
+            if(cb.pinned[k]) (void)hipHostFree(cb.pinned[k]);
+            if(cb.copied[k]) (void)hipEventDestroy(cb.copied[k]);
+        }
     delete ctx;
 }
 
@@ -993,6 +1022,7 @@ int oalgpu_buffer_register_adpcm(oalgpu_context *c, const void *data, int adpcm_
 int oalgpu_voice_set_start_delay(oalgpu_context *c, uint32_t voice, uint32_t samples)
 {
     if(!c || voice >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_start_delay: bad voice");
+    if(c->cbOfVoice[voice] >= 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_start_delay: not for callback voices");
     if(samples >= c->desc.sample_rate)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_start_delay: a start a second or more ahead is not scheduled yet (voice.cpp:1036-1038)");
     if(int rc = UseDevice(c->desc.device)) return rc;
@@ -1124,6 +1154,7 @@ int oalgpu_voice_set_params(oalgpu_context *c, const uint32_t *voices, const oal
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(int rc = BuildParamRecords(c, voices, params, count, c->paramHost)) return rc;
+    NoteCallbackSteps(c, voices, params, count);
     if(c->paramDev.n < count) HIP_TRY(c->paramDev.alloc(count));
     HIP_TRY(hipMemcpyAsync(c->paramDev.p, c->paramHost.data(), count * sizeof(ParamRecord), hipMemcpyHostToDevice, c->stream));
     LaunchApplyParams(c->stream, c->L, c->hrtfDev, c->paramDev.p, uint32_t(count));
@@ -1136,6 +1167,7 @@ struct oalgpu_param_block {
     DevBuf<ParamRecord> recs;
     uint32_t count{0};
     int device{0};
+    std::vector<std::pair<uint32_t, uint32_t>> cbSteps;     // (voice, mStep) of the callback voices in the block
 };
 
 int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params,
@@ -1151,6 +1183,8 @@ int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const o
     b->device = c->desc.device;
     HIP_TRY(b->recs.alloc(count));
     HIP_TRY(b->recs.upload(recs.data(), count));
+    for(size_t i = 0; i < count; ++i)
+        if(c->cbOfVoice[voices[i]] >= 0) b->cbSteps.emplace_back(voices[i], params[i].step);
     *out = b.release();
     return OALGPU_OK;
 }
@@ -1163,6 +1197,8 @@ int oalgpu_param_block_apply(oalgpu_context *c, oalgpu_param_block *b)
     if(int rc = FlushInits(c)) return rc;
     LaunchApplyParams(c->stream, c->L, c->hrtfDev, b->recs.p, b->count);
     HIP_TRY(hipGetLastError());
+    for(const auto &vs : b->cbSteps)
+        if(vs.first < c->cbOfVoice.size() && c->cbOfVoice[vs.first] >= 0) c->cbVoices[size_t(c->cbOfVoice[vs.first])].step = vs.second;
     return OALGPU_OK;
 }
 
@@ -1256,6 +1292,7 @@ int oalgpu_voice_set_state(oalgpu_context *c, uint32_t voice, int play_state)
     const int32_t st = play_state;
     HIP_TRY(hipMemcpyAsync(&c->ctl.p[voice].playState, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if(c->cbOfVoice[voice] >= 0) c->cbVoices[size_t(c->cbOfVoice[voice])].state = play_state;
     return OALGPU_OK;
 }
 
@@ -1307,6 +1344,154 @@ static int JoinPost(oalgpu_context *c)
     return OALGPU_OK;
 }
 
+
+// ---- callback sources: what Voice::mix does for VoiceFlag::IsCallback, mirrored on the host ---------------------
+namespace {
+
+// CalculateBufferSize, core/voice.cpp:600-640
+void CalcBufferSizeHost(uint32_t fracPos, uint32_t increment, uint32_t dstRemaining, uint32_t &dst, uint32_t &src)
+{
+    constexpr uint32_t srcMax = kResampleDataSize - kMaxEdge;
+    const uint32_t ext = increment <= kFracOne ? 1u : 0u;
+    const uint64_t srcSize = ((uint64_t{dstRemaining - ext} * increment + fracPos) >> kFracBits) + ext + kMaxEdge;
+    if(srcSize <= srcMax) { dst = dstRemaining; src = uint32_t(srcSize); return; }
+    const uint64_t dstSize = ((uint64_t{srcMax - kMaxEdge} << kFracBits) - fracPos) / increment;
+    if(dstSize < dstRemaining) { dst = uint32_t(dstSize) & ~3u; src = srcMax; return; }
+    dst = dstRemaining; src = srcMax;
+}
+
+// Before the update's voice kernel: the requests LoadResampledSamples would make (voice.cpp:726-752), the storage to
+// the device, the voice's window; then what Voice::mix does to the voice's position and blocks afterwards (:1121-1180)
+int ServiceCallbacks(oalgpu_context *c, uint32_t samplesToDo)
+{
+    for(auto &cb : c->cbVoices)
+    {
+        if(cb.state != OALGPU_VOICE_PLAYING && cb.state != OALGPU_VOICE_STOPPING) continue;
+        if(!cb.hasBuffer)
+        {   // an ended voice renders once more, fading out (voice.cpp:1224-1232), with no buffer to load from
+            if(cb.state == OALGPU_VOICE_STOPPING) cb.state = OALGPU_VOICE_STOPPED;
+            continue;
+        }
+        if(cb.step == 0) return Fail(OALGPU_ERR_INVALID, "a callback voice is mixed before its first oalgpu_voice_set_params (mStep = 0)");
+        uint32_t frac = cb.frac, off = cb.blockOffset;
+        for(uint32_t loaded = 0; loaded < samplesToDo;)
+        {
+            uint32_t dst, src;
+            CalcBufferSizeHost(frac, cb.step, samplesToDo - loaded, dst, src);
+            const uint32_t needBlocks = off + src;                      // one sample per block; the position is not negative
+            if(needBlocks > cb.capacityFrames)
+                return Fail(OALGPU_ERR_CAPACITY, "callback voice: the update needs more frames than the callback storage holds");
+            if(!cb.stopped && needBlocks > cb.numBlocks)
+            {
+                const size_t byteOffset = size_t{cb.numBlocks} * cb.frameBytes;
+                const uint32_t needBytes = (needBlocks - cb.numBlocks) * cb.frameBytes;
+                const int32_t ret = cb.fn(cb.user, cb.data.data() + byteOffset, int32_t(needBytes));
+                const uint32_t got = ret < 0 ? 0u : uint32_t(ret);      // al::saturate_cast<unsigned>
+                cb.stopped = got != needBytes;
+                if(got <= needBytes) cb.numBlocks += got / cb.frameBytes;
+            }
+            loaded += dst;
+            if(loaded < samplesToDo)
+            {
+                frac += dst * cb.step;
+                off += frac >> kFracBits;
+                frac &= kFracOne - 1u;
+            }
+        }
+        // the storage, in stream order behind the previous update's voice kernel
+        const uint32_t slot = cb.slot; cb.slot ^= 1u;
+        HIP_TRY(hipEventSynchronize(cb.copied[slot]));                  // the staging slot's last copy has left it
+        const size_t bytes = size_t{cb.numBlocks} * cb.frameBytes;
+        if(bytes)
+        {
+            std::memcpy(cb.pinned[slot], cb.data.data(), bytes);
+            HIP_TRY(hipMemcpyAsync(c->bufferData[size_t(cb.buffer)], cb.pinned[slot], bytes, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipEventRecord(cb.copied[slot], c->stream));
+        LaunchSetVoiceWindow(c->stream, c->L, cb.voice, cb.buffer, cb.numBlocks, int32_t(cb.blockOffset));
+        HIP_TRY(hipGetLastError());
+
+        if(cb.state == OALGPU_VOICE_STOPPING) { cb.state = OALGPU_VOICE_STOPPED; continue; }    // no position update when stopping
+        const uint64_t total = uint64_t{cb.frac} + uint64_t{cb.step} * samplesToDo;
+        const uint32_t samplesDone = uint32_t(total >> kFracBits);
+        cb.frac = uint32_t(total) & (kFracOne - 1u);
+        const int64_t pos = int64_t{cb.position} + samplesDone;
+        cb.position = pos > 2147483647ll ? 2147483647 : int32_t(pos);
+        if(cb.position > 0)
+        {
+            const uint32_t endOffset = cb.blockOffset + std::min(samplesDone, uint32_t(cb.position));
+            const uint32_t blocksDone = endOffset;                      // / mSamplesPerBlock
+            if(blocksDone == 0) cb.blockOffset = endOffset;
+            else if(blocksDone < cb.numBlocks)
+            {
+                std::memmove(cb.data.data(), cb.data.data() + size_t{blocksDone} * cb.frameBytes,
+                    size_t{cb.numBlocks - blocksDone} * cb.frameBytes);
+                cb.numBlocks -= blocksDone;
+                cb.blockOffset = endOffset - blocksDone;
+            }
+            else
+            {   // the voice just ended: Stopping, so that the next render fades any residual to 0
+                cb.hasBuffer = false; cb.numBlocks = 0; cb.blockOffset = 0;
+                cb.state = OALGPU_VOICE_STOPPING;
+            }
+        }
+    }
+    return OALGPU_OK;
+}
+
+} // namespace
+
+int oalgpu_voice_init_callback(oalgpu_context *c, uint32_t voice, int fmt_type, uint32_t position_frac,
+    oalgpu_callback_fn fn, void *userptr)
+{
+    static const uint32_t bytesPer[7] = {1, 2, 4, 4, 8, 1, 1};
+    if(!c || !fn || voice >= c->L.numVoices || fmt_type < 0 || fmt_type > OALGPU_FMT_ALAW || position_frac >= kFracOne)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: bad arguments");
+    if(c->comm) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: not on a sharded context");
+    if(c->cbOfVoice[voice] >= 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: the voice already is a callback source");
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    oalgpu_context::CbVoice cb;
+    cb.voice = voice; cb.fn = fn; cb.user = userptr;
+    cb.frameBytes = bytesPer[fmt_type];
+    cb.capacityFrames = uint32_t(kLine + 256) * 10u + uint32_t(kMaxEdge);      // MixerLineSize*MaxPitch + MaxResamplerEdge, al/buffer.cpp:474
+    const size_t nbytes = size_t{cb.capacityFrames} * cb.frameBytes;
+    cb.data.assign(nbytes, 0);
+    cb.frac = position_frac;
+    void *dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, nbytes + 16));
+    HIP_TRY(hipMemset(dev, 0, nbytes + 16));
+    for(int k = 0; k < 2; ++k)
+    {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&cb.pinned[k]), nbytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&cb.copied[k], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(cb.copied[k], c->stream));
+    }
+    const uint32_t h = c->numBuffers++;
+    c->bufferData[h] = dev;
+    c->bufferLoopLen[h] = 0u;
+    cb.buffer = int32_t(h);
+    // one frame long until the first update hands the voice its window (a static buffer has at least one)
+    BufferItem item{dev, fmt_type, 1u, 1u, 0u, 0u, 0};
+    HIP_TRY(hipMemcpy(c->buffers.p + h, &item, sizeof(item), hipMemcpyHostToDevice));
+    c->initPending.push_back(VoiceInitRecord{voice, int32_t(h), 0, 0, position_frac, 0});
+    c->cbOfVoice[voice] = int32_t(c->cbVoices.size());
+    c->cbVoices.push_back(std::move(cb));
+    return OALGPU_OK;
+}
+
+int oalgpu_voice_callback_state(oalgpu_context *c, uint32_t voice, oalgpu_callback_state *out)
+{
+    if(!c || !out || voice >= c->L.numVoices || c->cbOfVoice[voice] < 0)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_callback_state: not a callback voice");
+    const auto &cb = c->cbVoices[size_t(c->cbOfVoice[voice])];
+    out->position = cb.position; out->position_frac = cb.frac;
+    out->num_blocks = cb.numBlocks; out->block_offset = cb.blockOffset;
+    out->stopped = cb.stopped ? 1 : 0; out->play_state = cb.state; out->has_buffer = cb.hasBuffer ? 1 : 0;
+    return OALGPU_OK;
+}
+
 int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
@@ -1314,6 +1499,7 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(int rc = JoinPost(c)) return rc;
+    if(!c->cbVoices.empty()) { if(int rc = ServiceCallbacks(c, samples_to_do)) return rc; }
     if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
     if(c->useWave) HIP_TRY(LaunchVoiceWave(c->stream, c->L, samples_to_do));
     else HIP_TRY(LaunchVoiceMix(c->stream, c->exact, c->L, samples_to_do, c->carryAccum));
@@ -1382,6 +1568,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
+    if(!c->cbVoices.empty()) { if(int rc = ServiceCallbacks(c, samples_to_do)) return rc; }
     const uint32_t p = c->parity;
     DeviceLayout L = c->L;
     L.partHrtf = c->partHrtfBuf[p];
@@ -1441,6 +1628,8 @@ int oalgpu_update_graph_create(oalgpu_context *c, oalgpu_param_block *const *par
     if(!c || !out || count == 0 || (count & 1u) || count > 4096 || samples_to_do == 0 || samples_to_do > kLine)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: count must be even and 1 <= samples_to_do <= 1024");
     *out = nullptr;
+    if(!c->cbVoices.empty())
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: a callback source's user function runs on the host every update");
     if(!(c->useWave && c->ownStream) || c->serialOnly || c->comm || c->timing)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: needs an unsharded FAST context (wavefront kernel) on its own streams, timing off");
     for(uint32_t s = 0; s < c->L.numSlots; ++s)

@@ -281,6 +281,7 @@ struct PanRecord { uint32_t voice; float dir[3]; float spread; float dryGain; fl
 void LaunchPanGains(hipStream_t s, const DeviceLayout &L, const PanRecord *recs, uint32_t count, const AmbiMapEntry *dryMap,
     const AmbiMapEntry *wetMaps);
 void LaunchSetStartDelay(hipStream_t s, const DeviceLayout &L, uint32_t voice, uint32_t samples);
+void LaunchSetVoiceWindow(hipStream_t s, const DeviceLayout &L, uint32_t voice, int32_t buffer, uint32_t sampleLen, int32_t position);
 
 // ---- launcher (adpcm_kernels.hip): IMA4 / MS ADPCM blocks -> interleaved 16-bit PCM, one thread per block and channel ----
 void LaunchDecodeAdpcm(hipStream_t s, bool msadpcm, const uint8_t *src, int16_t *dst, uint32_t numBlocks, uint32_t samplesPerBlock,

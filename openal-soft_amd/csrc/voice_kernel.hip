@@ -104,6 +104,18 @@ __global__ void SetStartDelayKernel(DeviceLayout L, uint32_t v, uint32_t samples
     else L.ctl[v].flags &= ~kFlagDelayed;
 }
 
+// A callback source's storage as the voice sees it this update (voice.cpp:726-752): mNumCallbackBlocks valid blocks,
+// read from mCallbackBlockOffset -- to every voice kernel a static, non-looping buffer of that length and position
+__global__ void SetVoiceWindowKernel(DeviceLayout L, uint32_t v, int32_t buffer, uint32_t sampleLen, int32_t position)
+{
+    const_cast<BufferItem*>(L.buffers)[buffer].sampleLen = sampleLen;      // (a callback buffer's descriptor is the one that is not immutable)
+    L.ctl[v].buf.sampleLen = sampleLen;
+    L.ctl[v].position = position;
+}
+
+void LaunchSetVoiceWindow(hipStream_t s, const DeviceLayout &L, uint32_t voice, int32_t buffer, uint32_t sampleLen, int32_t position)
+{ hipLaunchKernelGGL(SetVoiceWindowKernel, dim3(1), dim3(1), 0, s, L, voice, buffer, sampleLen, position); }
+
 void LaunchSetStartDelay(hipStream_t s, const DeviceLayout &L, uint32_t voice, uint32_t samples)
 { hipLaunchKernelGGL(SetStartDelayKernel, dim3(1), dim3(1), 0, s, L, voice, samples); }
 

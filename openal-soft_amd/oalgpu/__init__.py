@@ -363,6 +363,41 @@ class Scene:
         self.nvoices += 1
         return v
 
+    # callback sources: `stream` (bytes-like / numpy array) is what the user function hands out, in the order asked
+    def add_callback_voice(self, stream, fmt, frac=0, frequency=44100):
+        CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32)
+        raw = np.ascontiguousarray(stream).view(np.uint8).ravel().copy()
+        st = {"pos": 0, "calls": 0}
+
+        def read(_user, data, nbytes):
+            st["calls"] += 1
+            n = max(0, min(int(nbytes), raw.size - st["pos"]))
+            if n:
+                C.memmove(data, raw.ctypes.data + st["pos"], n)
+            st["pos"] += n
+            return n
+
+        fn = CB(read)
+        if not hasattr(self, "_callbacks"):
+            self._callbacks = {}
+        lib.oalgpu_voice_init_callback.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, CB, C.c_void_p]
+        v = self.nvoices
+        check(lib.oalgpu_voice_init_callback(self.h, v, fmt, frac, fn, None), "oalgpu_voice_init_callback")
+        self._callbacks[v] = (fn, raw, st)          # keep the thunk and the stream alive
+        self.nvoices += 1
+        return v
+
+    def callback_state(self, voice):
+        """(mNumCallbackBlocks, mCallbackBlockOffset, CallbackStopped, calls of the user function)"""
+        class CbState(C.Structure):
+            _fields_ = [("position", C.c_int32), ("position_frac", C.c_uint32), ("num_blocks", C.c_uint32),
+                        ("block_offset", C.c_uint32), ("stopped", C.c_int32), ("play_state", C.c_int32), ("has_buffer", C.c_int32)]
+        out = CbState()
+        lib.oalgpu_voice_callback_state.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(CbState)]
+        check(lib.oalgpu_voice_callback_state(self.h, voice, C.byref(out)), "oalgpu_voice_callback_state")
+        self._cb_mirror = out
+        return out.num_blocks, out.block_offset, out.stopped, self._callbacks[voice][2]["calls"]
+
     def queue_state(self, voice):
         lib.oalgpu_voice_queue_state.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
         cur, done = C.c_int32(0), C.c_uint32(0)

@@ -222,6 +222,9 @@ int oal_scene_add_buffer_adpcm(oal_scene *s, const void *data, int adpcm_type, u
     uint32_t samples_per_block, uint32_t sample_len, uint32_t loop_start, uint32_t loop_end);
 int oal_scene_link_buffers(oal_scene *s, int buffer, int next);
 int oal_scene_add_queue_voice(oal_scene *s, const oal_voice_desc *desc);
+int oal_scene_add_callback_voice(oal_scene *s, const void *stream, size_t stream_bytes, int fmt_type,
+    uint32_t position_frac, uint32_t frequency);
+int oal_scene_callback_state(oal_scene *s, int voice, uint32_t out[4]);
 int oal_scene_voice_current_buffer(oal_scene *s, int voice);
 /* sum of the AsyncBufferCompleteEvent counts the voice has posted (voice.cpp:1207-1218) */
 unsigned oal_scene_voice_buffers_done(oal_scene *s, int voice);

@@ -145,6 +145,22 @@ struct BufferData {
     Item item;
 };
 
+/* what a callback buffer's user function reads from: a byte stream that simply ends */
+struct CbStream {
+    std::vector<std::byte> bytes;
+    size_t pos{0};
+    unsigned calls{0};
+};
+int CbRead(void *user, void *data, int nbytes) noexcept
+{
+    auto *st = static_cast<CbStream*>(user);
+    ++st->calls;
+    auto const n = std::min(static_cast<size_t>(std::max(nbytes, 0)), st->bytes.size() - st->pos);
+    std::memcpy(data, st->bytes.data() + st->pos, n);
+    st->pos += n;
+    return static_cast<int>(n);
+}
+
 } // namespace
 
 struct oal_scene {
@@ -156,6 +172,8 @@ struct oal_scene {
     std::vector<int> vstate;
     std::vector<unsigned> buffersDone;     /* summed AsyncBufferCompleteEvent counts per voice */
     std::deque<EffectSlotBase> slots;
+    std::deque<CbStream> streams;
+    std::vector<int> streamOfVoice;        /* [voice] index into streams, -1 = not a callback source */
     HrtfStorePtr hrtf;
 };
 
@@ -569,6 +587,61 @@ int oal_scene_add_queue_voice(oal_scene *s, const oal_voice_desc *desc)
     if(vi < 0) return vi;
     s->voices.at(static_cast<size_t>(vi)).mFlags.reset(VoiceFlag::IsStatic);
     return vi;
+}
+
+/* a callback source (AL_SOFT_callback_buffer): a buffer whose mCallback reads `stream` (al/buffer.cpp PrepareCallback:
+ * storage of MixerLineSize*MaxPitch + MaxResamplerEdge frames, mSampleLen 0) and a voice with VoiceFlag::IsCallback */
+int oal_scene_add_callback_voice(oal_scene *s, const void *stream, size_t stream_bytes, int fmt_type,
+    uint32_t position_frac, uint32_t frequency)
+{
+    static constexpr std::array<size_t,7> bps{1, 2, 4, 4, 8, 1, 1};
+    constexpr auto line_size = size_t{DeviceBase::MixerLineSize}*MaxPitch + MaxResamplerEdge;
+    auto &st = s->streams.emplace_back();
+    st.bytes.assign(static_cast<const std::byte*>(stream), static_cast<const std::byte*>(stream) + stream_bytes);
+    auto const dummy = std::vector<std::byte>(bps.at(static_cast<size_t>(fmt_type)));
+    auto const bi = oal_scene_add_buffer(s, dummy.data(), fmt_type, 1u, 1u, 0u, 0u);
+    if(bi < 0) return -1;
+    auto &b = s->buffers.at(static_cast<size_t>(bi));
+    b.bytes.assign(line_size*bps.at(static_cast<size_t>(fmt_type)) + 16, std::byte{});
+    auto *p = b.bytes.data();
+    /* NOLINTBEGIN */
+    switch(fmt_type)
+    {
+    case OAL_FMT_UBYTE: b.item.mSamples = std::span{reinterpret_cast<u8*>(p), line_size}; break;
+    case OAL_FMT_SHORT: b.item.mSamples = std::span{reinterpret_cast<i16*>(p), line_size}; break;
+    case OAL_FMT_INT: b.item.mSamples = std::span{reinterpret_cast<i32*>(p), line_size}; break;
+    case OAL_FMT_FLOAT: b.item.mSamples = std::span{reinterpret_cast<f32*>(p), line_size}; break;
+    case OAL_FMT_DOUBLE: b.item.mSamples = std::span{reinterpret_cast<f64*>(p), line_size}; break;
+    case OAL_FMT_MULAW: b.item.mSamples = std::span{reinterpret_cast<MulawSample*>(p), line_size}; break;
+    default: b.item.mSamples = std::span{reinterpret_cast<AlawSample*>(p), line_size}; break;
+    }
+    /* NOLINTEND */
+    b.bytes.back() = static_cast<std::byte>(1);
+    b.bytes[b.bytes.size()-2] = static_cast<std::byte>(fmt_type);
+    b.item.mSampleLen = 0;
+    b.item.mCallback = CbRead;
+    b.item.mUserData = &st;
+    auto const desc = oal_voice_desc{bi, 0, 0, position_frac, frequency};
+    auto const vi = oal_scene_add_voice(s, &desc);
+    if(vi < 0) return vi;
+    auto &v = s->voices.at(static_cast<size_t>(vi));
+    v.mFlags.reset(VoiceFlag::IsStatic);
+    v.mFlags.set(VoiceFlag::IsCallback);
+    s->streamOfVoice.resize(s->voices.size(), -1);
+    s->streamOfVoice[static_cast<size_t>(vi)] = static_cast<int>(s->streams.size()) - 1;
+    return vi;
+}
+
+/* mNumCallbackBlocks, mCallbackBlockOffset, CallbackStopped, and how often the user function was called */
+int oal_scene_callback_state(oal_scene *s, int voice, uint32_t out[4])
+{
+    auto &v = s->voices.at(static_cast<size_t>(voice));
+    out[0] = v.mNumCallbackBlocks; out[1] = v.mCallbackBlockOffset;
+    out[2] = v.mFlags.test(VoiceFlag::CallbackStopped) ? 1u : 0u;
+    out[3] = 0u;
+    if(static_cast<size_t>(voice) < s->streamOfVoice.size() && s->streamOfVoice[static_cast<size_t>(voice)] >= 0)
+        out[3] = s->streams[static_cast<size_t>(s->streamOfVoice[static_cast<size_t>(voice)])].calls;
+    return 0;
 }
 
 unsigned oal_scene_voice_buffers_done(oal_scene *s, int voice)

@@ -420,6 +420,23 @@ class Scene:
         self.nvoices += 1
         return v
 
+    def add_callback_voice(self, stream, fmt, frac=0, frequency=44100):
+        raw = np.ascontiguousarray(stream).view(np.uint8).ravel()
+        f = self.lib.L.oal_scene_add_callback_voice
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32]
+        v = f(self.h, raw.ctypes.data_as(C.c_void_p), raw.size, fmt, frac, frequency)
+        assert v >= 0
+        self.nvoices += 1
+        return v
+
+    def callback_state(self, voice):
+        """(mNumCallbackBlocks, mCallbackBlockOffset, CallbackStopped, calls of the user function)"""
+        f = self.lib.L.oal_scene_callback_state
+        out = (C.c_uint32 * 4)()
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
+        assert f(self.h, voice, out) == 0
+        return tuple(int(x) for x in out)
+
     def current_buffer(self, voice):
         f = self.lib.L.oal_scene_voice_current_buffer
         f.argtypes = [C.c_void_p, C.c_int]
