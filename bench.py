@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="issue the steps as hipGraphs of G (even) updates each (oalgpu_update_graph_*): one host launch per G "
                          "steps; configs 2 and 3 on one GPU; G must divide --steps and --warmup")
+    ap.add_argument("--run", type=int, default=0, metavar="B",
+                    help="submit the steps B at a time through oalgpu_mix_update_run (one library call per B updates "
+                         "instead of two per update); B must divide --steps and --warmup; 0 = one update per call")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -293,7 +296,15 @@ def main():
 
     graphs = [sc.update_graph(blocks[j:j + G], UPDATE_SAMPLES, post) for j in range(0, nblocks, G)] if G else []
 
+    B = args.run
+    if B and (G or args.steps % B or args.warmup % B):
+        raise SystemExit("--run B: B must divide --steps and --warmup, and excludes --graph")
+
     def step(k):
+        if B:                        # B updates per library call
+            if k % B == 0:
+                sc.mix_run([blocks[(k + j) % nblocks] for j in range(B)], UPDATE_SAMPLES, post)
+            return
         if G:                        # the same steps, G at a time: graph j covers blocks [jG, jG + G)
             if k % G == 0:
                 graphs[(k // G) % len(graphs)].launch()
@@ -313,6 +324,8 @@ def main():
     preroll = max(0, 400 - args.warmup)
     if G:
         preroll -= preroll % G
+    if B:
+        preroll -= preroll % B
     for k in range(preroll):
         step(k)
     fence()

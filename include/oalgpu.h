@@ -340,6 +340,10 @@ typedef struct oalgpu_param_block oalgpu_param_block;
 int  oalgpu_param_block_create(oalgpu_context *ctx, const uint32_t *voices,
     const oalgpu_voice_params *params, size_t count, oalgpu_param_block **out);
 int  oalgpu_param_block_apply(oalgpu_context *ctx, oalgpu_param_block *block);
+/* `count` consecutive updates submitted by one call: update i applies param_blocks[i] (the array or an entry may be
+ * NULL), then oalgpu_mix_update(samples_to_do, post_process) -- what a host's render loop does, in one call */
+int  oalgpu_mix_update_run(oalgpu_context *ctx, oalgpu_param_block *const *param_blocks, uint32_t count,
+    uint32_t samples_to_do, int post_process);
 void oalgpu_param_block_destroy(oalgpu_param_block *block);
 /* ProcessVoiceChanges side (alc/alu.cpp:2057-2151): Playing / Stopping / Stopped. */
 int oalgpu_voice_set_state(oalgpu_context *ctx, uint32_t voice, int play_state);

@@ -1560,6 +1560,20 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
     return oalgpu_post_process_overlapped(c, samples_to_do, post_process && c->commRank == 0);
 }
 
+/* `count` consecutive updates in one call: update i applies param_blocks[i] (the array or an entry may be NULL) and mixes
+ * -- the loop a C++ host would write, without a language binding's per-call cost between the submissions */
+int oalgpu_mix_update_run(oalgpu_context *c, oalgpu_param_block *const *param_blocks, uint32_t count, uint32_t samples_to_do,
+    int post_process)
+{
+    if(!c || count == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_mix_update_run: bad arguments");
+    for(uint32_t i = 0; i < count; ++i)
+    {
+        if(param_blocks && param_blocks[i]) { if(int rc = oalgpu_param_block_apply(c, param_blocks[i])) return rc; }
+        if(int rc = oalgpu_mix_update(c, samples_to_do, post_process)) return rc;
+    }
+    return OALGPU_OK;
+}
+
 int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");

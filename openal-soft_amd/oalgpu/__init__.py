@@ -478,6 +478,12 @@ class Scene:
     def apply_block(self, block):
         check(lib.oalgpu_param_block_apply(self.h, block), "oalgpu_param_block_apply")
 
+    def mix_run(self, blocks, samples_to_do=BUFFER_LINE, post_process=False):
+        """len(blocks) consecutive updates in one call (oalgpu_mix_update_run); blocks[i] may be None"""
+        arr = (C.c_void_p * len(blocks))(*[b if b is not None else None for b in blocks])
+        lib.oalgpu_mix_update_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int]
+        check(lib.oalgpu_mix_update_run(self.h, arr, len(blocks), samples_to_do, 1 if post_process else 0), "oalgpu_mix_update_run")
+
     def update_graph(self, blocks, samples_to_do=BUFFER_LINE, post_process=True):
         """`len(blocks)` (even) updates as one hipGraph: update i applies blocks[i] (None: no change) and mixes"""
         return UpdateGraph(self, blocks, samples_to_do, post_process)

@@ -95,3 +95,33 @@ def test_graph_refusals():
     with pytest.raises(RuntimeError):
         exact.update_graph([None, None])            # the workgroup-per-voice-group kernel runs on one stream
     exact.close(); rev.close(); sc.close()
+
+
+def test_update_run_equals_update_by_update():
+    """oalgpu_mix_update_run: `count` updates submitted by one call are the updates issued one by one"""
+    import oalgpu
+    from oalgpu import synth
+    import bench
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    mhr = synth.synth_mhr_bytes()
+    api._mhr = mhr
+    voices = 512
+
+    def build():
+        sc, script = bench.build_scene(oalgpu, synth, api, 3, voices, 0, mhr, 0)
+        allv = list(range(voices))
+        moving = [v for v in allv if script.is_moving(v)]
+        sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
+        return sc, [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(6)]
+
+    a, ab = build()
+    b, bb = build()
+    a.mix_run([ab[0], None, ab[2], ab[3], None, ab[5]], 1024, True)
+    for k, blk in enumerate(bb):
+        if k not in (1, 4):
+            b.apply_block(blk)
+        b.mix(1024, post_process=True)
+    assert np.abs(b.dry()).max() > 1e-3
+    assert np.array_equal(_bits(a.dry()), _bits(b.dry()))
+    assert np.array_equal(_bits(a.hrtf_accum()), _bits(b.hrtf_accum()))
+    a.close(); b.close()
