@@ -187,6 +187,16 @@ struct oalgpu_context {
 
 namespace {
 
+// the voice slot is re-initialised as another kind of source: its callback is not asked any more
+void RetireCallbackVoice(oalgpu_context *c, uint32_t voice)
+{
+    if(voice < c->cbOfVoice.size() && c->cbOfVoice[voice] >= 0)
+    {
+        c->cbVoices[size_t(c->cbOfVoice[voice])].state = OALGPU_VOICE_STOPPED;
+        c->cbOfVoice[voice] = -1;
+    }
+}
+
 // a callback voice's mStep, wherever parameters pass through the host
 void NoteCallbackSteps(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params, size_t count)
 {
@@ -936,6 +946,7 @@ int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(d->looping && c->bufferLoopLen[size_t(d->buffer)] == 0)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: a looping voice needs a buffer registered with loop_end > loop_start");
+    RetireCallbackVoice(c, voice);
     c->initPending.push_back(VoiceInitRecord{voice, d->buffer, d->looping ? 1 : 0, d->position, d->position_frac, 0});
     return OALGPU_OK;
 }
@@ -963,6 +974,7 @@ int oalgpu_voice_init_queue(oalgpu_context *c, uint32_t voice, int first_buffer,
     if(!c || voice >= c->L.numVoices || first_buffer < 0 || uint32_t(first_buffer) >= c->numBuffers || position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_queue: bad arguments");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    RetireCallbackVoice(c, voice);
     c->initPending.push_back(VoiceInitRecord{voice, first_buffer, looping ? 1 : 0, position, position_frac, 1});
     return OALGPU_OK;
 }
