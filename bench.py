@@ -224,10 +224,6 @@ def main():
     ap.add_argument("--run", type=int, default=0, metavar="B",
                     help="submit the steps B at a time through oalgpu_mix_update_run (one library call per B updates "
                          "instead of two per update); B must divide --steps and --warmup; 0 = one update per call")
-    ap.add_argument("--resident", type=int, default=0, metavar="U",
-                    help="measurement aid: U updates per launch of the voice kernel (oalgpu_debug_resident_run; config 3; the "
-                         "parameter block is applied once per launch); U must divide --steps and --warmup")
-    ap.add_argument("--resident-barrier", type=int, default=1, help="with --resident: a grid-wide barrier between updates (1) or none (0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -304,16 +300,7 @@ def main():
     if B and (G or args.steps % B or args.warmup % B):
         raise SystemExit("--run B: B must divide --steps and --warmup, and excludes --graph")
 
-    RU = args.resident
-    if RU and (G or B or args.config != 3 or world > 1 or args.steps % RU or args.warmup % RU):
-        raise SystemExit("--resident U: config 3 on one GPU, U a divisor of --steps and --warmup")
-
     def step(k):
-        if RU:                       # U updates per launch of the voice kernel
-            if k % RU == 0:
-                sc.apply_block(blocks[(k // RU) % nblocks])
-                sc.resident_run(RU, UPDATE_SAMPLES, post, bool(args.resident_barrier))
-            return
         if B:                        # B updates per library call
             if k % B == 0:
                 sc.mix_run([blocks[(k + j) % nblocks] for j in range(B)], UPDATE_SAMPLES, post)
@@ -339,8 +326,6 @@ def main():
         preroll -= preroll % G
     if B:
         preroll -= preroll % B
-    if RU:
-        preroll -= preroll % RU
     for k in range(preroll):
         step(k)
     fence()
@@ -398,14 +383,6 @@ def main():
     vk = []
     tot = []
     for k in range(args.steps):
-        if RU:                       # the launch's duration shared by its U updates
-            if k % RU == 0:
-                sc.apply_block(blocks[(k // RU) % nblocks])
-                sc.resident_run(RU, UPDATE_SAMPLES, post, bool(args.resident_barrier))
-                a, b = sc.last_update_ms()
-                tot.append(a / RU)
-                vk.append(b / RU)
-            continue
         sc.apply_block(blocks[(args.warmup + args.steps + k) % nblocks])
         sc.mix_voices(UPDATE_SAMPLES)
         a, b = sc.last_update_ms()

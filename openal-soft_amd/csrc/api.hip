@@ -158,8 +158,6 @@ struct oalgpu_context {
     std::vector<ParamRecord> paramHost;
     DevBuf<VoiceInitRecord> initDev;
     std::vector<VoiceInitRecord> initPending;
-    DevBuf<float> residentPart;            // oalgpu_debug_resident_run: the partial buses of every update of a run
-    DevBuf<uint32_t> residentSync;         // [0] barrier counter, [1] status
     // callback sources (oalgpu_voice_init_callback): the host's mirror of what Voice::mix keeps for them
     struct CbVoice {
         uint32_t voice{0}; int32_t buffer{-1}; uint32_t frameBytes{4}, capacityFrames{0};
@@ -1932,54 +1930,6 @@ int oalgpu_last_update_ms(oalgpu_context *c, float *total_ms, float *voice_kerne
     if(int rc = oalgpu_sync(c)) return rc;
     if(total_ms) HIP_TRY(hipEventElapsedTime(total_ms, c->evStart, c->evEnd));
     if(voice_kernel_ms) HIP_TRY(hipEventElapsedTime(voice_kernel_ms, c->evStart, c->evVoice));
-    return OALGPU_OK;
-}
-
-/* Measurement aid (not part of the public header): `updates` consecutive updates of an HRTF context without sends mixed by
- * ONE launch of the voice kernel -- every wavefront stays on its voices from update to update, as a kernel that never
- * exits would between two doorbells (use_barrier: with a grid-wide barrier per update in the doorbell's place) -- then the
- * reductions and post-processes of those updates, in order.  The parameters do not change inside the run.  Results equal
- * `updates` calls of oalgpu_mix_update (tests/test_gpu_update_graph.py); the voice kernel's time is read through
- * oalgpu_set_timing / oalgpu_last_update_ms. */
-int oalgpu_debug_resident_run(oalgpu_context *c, uint32_t updates, uint32_t samples_to_do, int post_process, int use_barrier)
-{
-    if(!c || updates < 2 || updates > 32 || samples_to_do == 0 || samples_to_do > kLine)
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_resident_run: 2..32 updates of 1..1024 samples");
-    if(!c->useWave || !c->L.hrtf || c->L.numSends || c->L.firMfma || c->L.irStride > 64 || c->L.blockVoices || c->comm || !c->cbVoices.empty())
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_resident_run: an unsharded FAST HRTF context without sends (IrSize <= 64)");
-    if(c->L.numGroups > 512u) return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_resident_run: more workgroups than the machine holds at once");
-    if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(int rc = UseDevice(c->desc.device)) return rc;
-    if(int rc = FlushInits(c)) return rc;
-    if(int rc = JoinPost(c)) return rc;
-    const size_t perUpdate = size_t{c->L.numGroups} * (kLine + kHrirLen) * 2u;
-    if(c->residentPart.n < perUpdate * updates) HIP_TRY(c->residentPart.alloc(perUpdate * updates));
-    if(!c->residentSync.p) HIP_TRY(c->residentSync.alloc(2));
-    HIP_TRY(hipMemsetAsync(c->residentSync.p, 0, 2 * sizeof(uint32_t), c->stream));
-    DeviceLayout L = c->L;
-    L.partHrtf = c->residentPart.p;
-    L.residentUpdates = updates;
-    L.residentBarrier = use_barrier ? c->residentSync.p : nullptr;
-    L.residentStatus = c->residentSync.p + 1;
-    if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
-    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do));
-    if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
-    for(uint32_t u = 0; u < updates; ++u)
-    {
-        DeviceLayout R = c->L;
-        R.partHrtf = c->residentPart.p + perUpdate * u;
-        LaunchBusReduce(c->stream, R, samples_to_do, c->carryAccum, false);
-        HIP_TRY(hipGetLastError());
-        if(post_process) { if(int rc = oalgpu_post_process(c, samples_to_do)) return rc; }
-    }
-    if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
-    uint32_t status[2] = {0, 0};
-    if(use_barrier)
-    {
-        HIP_TRY(hipMemcpyAsync(status, c->residentSync.p, sizeof(status), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if(status[1]) return Fail(OALGPU_ERR_HIP, "oalgpu_debug_resident_run: a workgroup gave up waiting at the update barrier");
-    }
     return OALGPU_OK;
 }
 

@@ -89,10 +89,6 @@ struct DeviceLayout {
     uint32_t firMfma;                       // voice_wave.hip: the HRTF FIR on the matrix pipe (env OALGPU_FIR=mfma)
     unsigned long long *phaseTimes;         // profiling aid (env OALGPU_PHASE_TIMES): [voice][8] s_memtime stamps, or null
     uint32_t mixLines;                      // lines accumulated by the voice kernel
-    // measurement aid (oalgpu_debug_resident_run): one launch mixes residentUpdates consecutive updates, the partial buses
-    // of update u at partHrtf + u * numGroups * (1024 + 128) pairs; residentBarrier: a grid-wide barrier between updates
-    uint32_t residentUpdates;
-    uint32_t *residentBarrier, *residentStatus;
     // tables + buffers
     const float *tables;                    // [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
     const BufferItem *buffers;

@@ -197,13 +197,10 @@ __device__ __forceinline__ void WgMixRows(uint32_t *lds, const DeviceLayout &L, 
 // MF: the dual-ear FIR of HRTF voices (IrSize <= 64) on the matrix pipe (FirMfma64, dev_wave.hpp) instead
 // of packed VALU FMAs: the matrix pipe then works for one wavefront of a SIMD while the other's
 // resampler and filters own the VALU issue slots.
-// RESIDENT (measurement aid): the launch mixes L.residentUpdates consecutive updates of its voices, wavefronts staying
-// on their voices -- what a kernel that never exits would do between two doorbells, without the cold start.
-template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool RESIDENT = false>
+template<int R, int TAPS, int NL, bool SENDS, bool MF = false>
 __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo)
 {
     static_assert(!MF || (R == 17 && TAPS == 64 && NL == 0), "the matrix-pipe FIR is the 64-tap HRTF form");
-    static_assert(!RESIDENT || (NL == 0 && !SENDS && !MF), "the resident run is the plain HRTF form");
     using WL = WaveLds<R, TAPS, MF>;
     __shared__ WgLds<R, TAPS, MF> sm;
     const uint32_t t = threadIdx.x;
@@ -239,8 +236,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     const bool rev = group >= (gridDim.x + 1u) / 2u;
     auto voiceAt = [&](uint32_t j) { return vBegin + 2u * (rev ? vCount - 1u - j : j); };
 
-    for(uint32_t upd = 0; upd < (RESIDENT ? L.residentUpdates : 1u); ++upd)
-    {
     // Voices are processed in passes; pass 0 only requests the first voice's source window and
     // stages the workgroup's resampler rows.  The request for the NEXT voice's window sits at one
     // point of the pass -- after this voice's FIR inputs are built, before its FIR runs -- so the
@@ -917,7 +912,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             dump[lane0 + 64 * q] = f2{cur.x + accO[q].x, cur.y + accO[q].y};
         }
         __syncthreads();
-        f2 *ph = reinterpret_cast<f2*>(L.partHrtf) + (size_t{group} + (RESIDENT ? size_t{upd} * gridDim.x : size_t{0})) * (kLine + kHrirLen);
+        f2 *ph = reinterpret_cast<f2*>(L.partHrtf) + size_t{group} * (kLine + kHrirLen);
         for(uint32_t k = t; k < uint32_t(kLine + kHrirLen); k += kWThreads)
         {
             f2 s = {0.0f, 0.0f};
@@ -932,31 +927,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     }
     waveStamp(3);
     if constexpr (SENDS) mixRows();
-    if constexpr (RESIDENT)
-    {
-        if(upd + 1u < L.residentUpdates)
-        {   // A wavefront's next update reads what ITS OWN stores of this update wrote -- its voices' control lines through
-            // the scalar cache, which does not see vector stores: wait for the stores to reach L2, then invalidate that
-            // cache.  (Nothing crosses workgroups: no fence of wider scope -- a device-scope release writes the whole L2
-            // back.)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();
-            if(L.residentBarrier && t == 0)
-            {   // what a doorbell per update would cost at least: every workgroup meets every other one
-                __hip_atomic_fetch_add(L.residentBarrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t want = (upd + 1u) * gridDim.x;
-                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-                while(__hip_atomic_load(L.residentBarrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
-                {
-                    __builtin_amdgcn_s_sleep(4);
-                    if(__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) { *L.residentStatus = 1u; break; }   // 20 ms
-                }
-            }
-            __syncthreads();
-            __builtin_amdgcn_s_dcache_inv();
-        }
-    }
-    }
 }
 
 } // namespace
@@ -1003,7 +973,6 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     else if(L.irStride <= 64)
     {
         if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, L, samplesToDo);
-        else if(L.residentUpdates > 1u) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true>), grid, block, 0, s, L, samplesToDo);
         else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false>), grid, block, 0, s, L, samplesToDo);
     }
     else

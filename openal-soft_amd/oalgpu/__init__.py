@@ -478,12 +478,6 @@ class Scene:
     def apply_block(self, block):
         check(lib.oalgpu_param_block_apply(self.h, block), "oalgpu_param_block_apply")
 
-    def resident_run(self, updates, samples_to_do=BUFFER_LINE, post_process=True, barrier=True):
-        """measurement aid: `updates` updates mixed by ONE launch of the voice kernel (oalgpu_debug_resident_run)"""
-        lib.oalgpu_debug_resident_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
-        check(lib.oalgpu_debug_resident_run(self.h, updates, samples_to_do, 1 if post_process else 0, 1 if barrier else 0),
-              "oalgpu_debug_resident_run")
-
     def mix_run(self, blocks, samples_to_do=BUFFER_LINE, post_process=False):
         """len(blocks) consecutive updates in one call (oalgpu_mix_update_run); blocks[i] may be None"""
         arr = (C.c_void_p * len(blocks))(*[b if b is not None else None for b in blocks])

@@ -125,39 +125,3 @@ def test_update_run_equals_update_by_update():
     assert np.array_equal(_bits(a.dry()), _bits(b.dry()))
     assert np.array_equal(_bits(a.hrtf_accum()), _bits(b.hrtf_accum()))
     a.close(); b.close()
-
-
-@pytest.mark.parametrize("barrier", [True, False], ids=["barrier", "free_running"])
-def test_resident_run_equals_update_by_update(barrier):
-    """the measurement aid behind profiles/r2/resident_run.txt: several updates mixed by one launch of the voice kernel
-    (wavefronts staying on their voices, the caches invalidated between updates) leave the buses, the carried
-    accumulator and the voices exactly where the same updates one by one leave them"""
-    import oalgpu
-    from oalgpu import synth
-    import bench
-    api = oalgpu.Api(oalgpu.MATH_FAST)
-    mhr = synth.synth_mhr_bytes()
-    api._mhr = mhr
-    voices = 4096
-
-    def build():
-        sc, script = bench.build_scene(oalgpu, synth, api, 3, voices, 0, mhr, 0)
-        allv = list(range(voices))
-        moving = [v for v in allv if script.is_moving(v)]
-        sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
-        return sc, [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(2)]
-
-    a, ab = build()
-    b, bb = build()
-    for r in range(2):
-        a.apply_block(ab[r]); b.apply_block(bb[r])
-        a.resident_run(5, 1024, True, barrier)
-        for _ in range(5):
-            b.mix(1024, post_process=True)
-        assert np.abs(b.dry()).max() > 1e-3
-        assert np.array_equal(_bits(a.dry()), _bits(b.dry())), r
-        assert np.array_equal(_bits(a.hrtf_accum()), _bits(b.hrtf_accum())), r
-        for v in range(0, voices, 97):
-            sa, sb = a.voice_state(v), b.voice_state(v)
-            assert (sa.position, sa.position_frac, sa.play_state) == (sb.position, sb.position_frac, sb.play_state), (r, v)
-    a.close(); b.close()
