@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="issue the steps as hipGraphs of G (even) updates each (oalgpu_update_graph_*): one host launch per G "
                          "steps; configs 2 and 3 on one GPU; G must divide --steps and --warmup")
+    ap.add_argument("--fir", default="mfma", choices=("mfma", "valu"),
+                    help="HRTF voices' dual-ear FIR: the matrix pipe in split half precision (the product default) or "
+                         "packed fp32 VALU FMAs (OALGPU_CTX_FIR_VALU), for A/B runs")
     ap.add_argument("--run", type=int, default=0, metavar="B",
                     help="submit the steps B at a time through oalgpu_mix_update_run (one library call per B updates "
                          "instead of two per update); B must divide --steps and --warmup; 0 = one update per call")
@@ -241,7 +244,8 @@ def main():
     if oalgpu.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
     torch.cuda.set_device(local_rank)
-    api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank)
+    api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank,
+                     ctx_flags=oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0)
     real_mhr = os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr")
     use_real = args.mhr == "default" and os.path.exists(real_mhr)
     if use_real:
@@ -326,9 +330,10 @@ def main():
         preroll -= preroll % G
     if B:
         preroll -= preroll % B
+    # (no fence between pre-roll and warm-up: a drained pipeline and an idle GPU right before the W warm-up
+    # steps made the contract's block the slowest one of a short run -- 61.5 against 57.1 us per step at K = 20)
     for k in range(preroll):
         step(k)
-    fence()
     for k in range(args.warmup):
         step(k)
     fence()

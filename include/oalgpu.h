@@ -174,7 +174,15 @@ typedef struct oalgpu_context_desc {
     uint32_t max_voices;
     uint32_t max_buffers;
     uint32_t voices_per_group;    /* 0 = choose automatically (tuning knob) */
+    uint32_t flags;               /* OALGPU_CTX_* below; 0 = the product configuration */
 } oalgpu_context_desc;
+/* oalgpu_context_desc::flags -- kernel variants are chosen here, never from the environment */
+#define OALGPU_CTX_FIR_VALU 1u    /* FAST HRTF voices (IrSize <= 64): the dual-ear FIR as packed fp32 VALU FMAs
+                                   * instead of the matrix pipe in split half precision */
+#define OALGPU_CTX_PROFILE  2u    /* the voice kernel's measurement variant: per-phase cycle stamps
+                                   * (oalgpu_debug_phase_times) and stage ablation (oalgpu_debug_set_ablate) */
+#define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
+                                   * post-process with the next update's voices): a measurement aid */
 
 int  oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out);
 void oalgpu_context_destroy(oalgpu_context *ctx);

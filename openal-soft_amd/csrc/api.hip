@@ -126,11 +126,12 @@ struct oalgpu_context {
     DevBuf<AmbiScaleState> ambi;
     DevBuf<NfcState> nfc;
     NfcDesign nfcDevice{};                   // DeviceBase::mNFCtrlFilter (after init(w1))
-    DevBuf<unsigned long long> phaseTimes;  // profiling aid, env OALGPU_PHASE_TIMES
+    DevBuf<unsigned long long> phaseTimes;  // OALGPU_CTX_PROFILE: the measurement variant's stamps
+    WaveProf prof{nullptr, 0u};
+    const WaveProf *profArg() const { return prof.times ? &prof : nullptr; }
     DevBuf<AmbiMapEntry> dryMap, wetMaps;   // MixParams::AmbiMap of the dry bus / of every slot's wet bus
     DevBuf<PanRecord> panRecs;
-    bool serialOnly{false};                // profiling aid, env OALGPU_SERIAL: no two-stream pipeline
-    uint32_t waveGroups{0};                // partial buses of the wavefront kernel (the fallback of voice_block.hip)
+    bool serialOnly{false};                // OALGPU_CTX_SERIAL: no two-stream pipeline
     // multi-GPU (oalgpu_comm_init): this rank's RCCL communicator; the bus block is sum-reduced to rank 0
     // right behind the partial-bus reduction, on the stream that runs it
     void *comm{nullptr};
@@ -243,7 +244,12 @@ RcclApi &Rccl()
             for(const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
                 if((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
         }
-        if(!h) { a.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return a; }
+        if(!h)
+        {   // dlerror() clears the pending message: read it once
+            const char *e = dlerror();
+            a.why = std::string("librccl.so not found: ") + (e ? e : "");
+            return a;
+        }
         a.getUniqueId = reinterpret_cast<decltype(a.getUniqueId)>(dlsym(h, "ncclGetUniqueId"));
         a.commInitRank = reinterpret_cast<decltype(a.commInitRank)>(dlsym(h, "ncclCommInitRank"));
         a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(h, "ncclCommDestroy"));
@@ -689,14 +695,10 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.voicesPerGroup = vpg;
     L.numGroups = std::max<uint32_t>(1u, (desc->max_voices + vpg - 1u) / vpg);
     L.waveVoices = 0;
-    L.ablate = 0;
-    if(const char *ab = std::getenv("OALGPU_ABLATE")) L.ablate = uint32_t(std::strtoul(ab, nullptr, 0));
-    // the HRTF FIR of the wavefront kernel: packed-VALU FMAs (default: measured 45.6 vs 47.5 us per 4096-voice
-    // update, profiles/r2/) or the matrix-pipe Toeplitz form (OALGPU_FIR=mfma)
-    L.firMfma = 0u;
-    if(const char *fm = std::getenv("OALGPU_FIR")) L.firMfma = std::strcmp(fm, "mfma") == 0;
-    L.phaseTimes = nullptr;
-    c->serialOnly = std::getenv("OALGPU_SERIAL") != nullptr;
+    // the HRTF FIR of the wavefront kernel (IrSize <= 64): the matrix pipe in split half precision
+    // (FirMfmaH, dev_wave.hpp) unless the host asks for packed fp32 VALU FMAs
+    L.firMfma = (desc->flags & OALGPU_CTX_FIR_VALU) ? 0u : 1u;
+    c->serialOnly = (desc->flags & OALGPU_CTX_SERIAL) != 0;
     c->useWave = WaveKernelApplies(c->exact, L);
     if(c->useWave)
     {
@@ -706,25 +708,6 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
             : std::max<uint32_t>(1u, (desc->max_voices + 2047u) / 2048u);
         L.numGroups = std::max<uint32_t>(1u, WaveKernelGroups(L));
     }
-    // FAST HRTF contexts without sends can also run one WORKGROUP per voice (voice_block.hip; four
-    // workgroups per CU -> ~1024 workgroups, voices_per_group is then voices per workgroup): opt-in with
-    // OALGPU_VOICE_KERNEL=block -- measured 62 us against the wavefront kernel's 46 us per 4096-voice
-    // update.  Final once the data set is loaded (IrSize <= 64).
-    L.blockVoices = 0; L.blockWaves = 0;
-    c->waveGroups = L.numGroups;
-    {
-        const char *vk = std::getenv("OALGPU_VOICE_KERNEL");
-        if(c->useWave && L.hrtf && L.numSends == 0 && vk && std::strcmp(vk, "block") == 0)
-        {
-            L.blockWaves = 4;
-            if(const char *bw = std::getenv("OALGPU_BLOCK_WAVES")) L.blockWaves = std::atoi(bw) == 3 ? 3u : 4u;
-            const uint32_t want = 256u * L.blockWaves;           // workgroups that are resident at once
-            L.blockVoices = desc->voices_per_group ? desc->voices_per_group
-                : std::max<uint32_t>(1u, (desc->max_voices + want - 1u) / want);
-            L.numGroups = std::max<uint32_t>(1u, WaveKernelGroups(L));
-        }
-    }
-
     const TableBlob &blob = Blob();
     HIP_TRY(c->tables.alloc(blob.data.size())); HIP_TRY(c->tables.upload(blob.data.data(), blob.data.size()));
     L.tables = c->tables.p;
@@ -775,10 +758,10 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->partHrtf2.alloc(c->useWave && L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
     c->partHrtfBuf[0] = c->partHrtf.p; c->partHrtfBuf[1] = c->partHrtf2.p;
     HIP_TRY(c->bus.alloc(BusFloats(L))); HIP_TRY(c->bus.zero()); L.bus = c->bus.p;
-    if(std::getenv("OALGPU_PHASE_TIMES"))
+    if(desc->flags & OALGPU_CTX_PROFILE)
     {
         HIP_TRY(c->phaseTimes.alloc(nv * 12)); HIP_TRY(c->phaseTimes.zero());   // [voice][8] | [wavefront][4]
-        L.phaseTimes = c->phaseTimes.p;
+        c->prof.times = c->phaseTimes.p;
     }
     // HRTF voice filters are sized when the data set is loaded
     L.hrtfOld = nullptr; L.hrtfTgt = nullptr;
@@ -839,13 +822,6 @@ int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
     DeviceLayout &L = c->L;
     L.irSize = h.irSize;
     L.irStride = (h.irSize + 15u) & ~15u;
-    if(L.blockVoices && L.irStride > 64u)
-    {   // the workgroup-per-voice kernel is the 64-tap form: longer responses stay on the wavefront kernel
-        if(int rc = oalgpu_sync(c)) return rc;
-        L.blockVoices = 0;
-        L.numGroups = c->waveGroups;
-        if(!L.streams) L.numLineGroups = L.numGroups;
-    }
     if(L.hrtf)
     {
         const size_t n = size_t{L.numVoices} * L.irStride * 2;
@@ -1513,7 +1489,7 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
     if(int rc = JoinPost(c)) return rc;
     if(!c->cbVoices.empty()) { if(int rc = ServiceCallbacks(c, samples_to_do)) return rc; }
     if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
-    if(c->useWave) HIP_TRY(LaunchVoiceWave(c->stream, c->L, samples_to_do));
+    if(c->useWave) HIP_TRY(LaunchVoiceWave(c->stream, c->L, samples_to_do, c->profArg()));
     else HIP_TRY(LaunchVoiceMix(c->stream, c->exact, c->L, samples_to_do, c->carryAccum));
     if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
     // the wavefront kernel leaves the carried HRTF accumulator tail to the reduction
@@ -1603,7 +1579,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     // of two updates ago
     HIP_TRY(hipStreamWaitEvent(c->stream, c->evReduceDone[p], 0));
     if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
-    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do));
+    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg()));
     if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
     HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
     // post stream: the reduction (adds the carried HRTF accumulator tail); whatever follows on that stream -- a collective, the effects, the post-process -- runs beside
@@ -1689,7 +1665,7 @@ int oalgpu_update_graph_create(oalgpu_context *c, oalgpu_param_block *const *par
         // this update's partial buses were last read by the reduction of two updates ago (the first two
         // updates of the graph start from a drained context)
         if(i >= 2) ok(hipStreamWaitEvent(c->stream, g->evReduce[p], 0));
-        ok(LaunchVoiceWave(c->stream, L, samples_to_do));
+        ok(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg()));
         ok(hipEventRecord(g->evVoice[p], c->stream));
         ok(hipStreamWaitEvent(c->postStream, g->evVoice[p], 0));        // the post stream joins the capture here
         LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum && L.hrtf, true);
@@ -1933,8 +1909,17 @@ int oalgpu_last_update_ms(oalgpu_context *c, float *total_ms, float *voice_kerne
     return OALGPU_OK;
 }
 
-/* Profiling aid (not part of the public header): copies the [voice][8] s_memtime stamps the
- * wavefront kernel recorded when the context was created with OALGPU_PHASE_TIMES set. */
+/* Measurement aid, OALGPU_CTX_PROFILE contexts: which stages the voice kernel's measurement variant skips
+ * (1 FIR, 2 resampler, 8 direct filter, 16 FIR input build); 0 = none. */
+int oalgpu_debug_set_ablate(oalgpu_context *c, uint32_t mask)
+{
+    if(!c || !c->phaseTimes.p) return Fail(OALGPU_ERR_INVALID, "not an OALGPU_CTX_PROFILE context");
+    c->prof.ablate = mask;
+    return OALGPU_OK;
+}
+
+/* Measurement aid: copies the [voice][8] s_memtime stamps the voice kernel's measurement variant
+ * recorded (contexts created with OALGPU_CTX_PROFILE). */
 int oalgpu_debug_phase_times(oalgpu_context *c, unsigned long long *out)
 {
     if(!c || !out || !c->phaseTimes.p) return Fail(OALGPU_ERR_INVALID, "phase times were not enabled");

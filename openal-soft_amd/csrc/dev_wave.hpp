@@ -178,124 +178,126 @@ __device__ __forceinline__ void FirMainPk(f2 (&acc)[R], const X *xw, cf16 *co16)
     }
 }
 
-// ---- dual-ear FIR on the matrix pipe: the Toeplitz form of MixHrtf ------------------------------
-// core/mixer/hrtfbase.h:17-89 computes, per ear, y[n] = sum_{j < IrSize} h[j] * x'[n - j] over one
-// update (x' = the delayed, gain-ramped input).  Cut the output into blocks of 16 frames
-// (n = 64 a + 16 b + r; a < 16 = matrix row, b < 4 = tile, r < 16 = matrix column) and the taps into
-// j = 16 k + r - c (k < 5, c < 16): then
-//     Y_b[a][r] = sum_{k, c} x'[64 a + 16 (b - k) + c] * h[16 k + r - c]
-// is a dense (16 x 80) x (80 x 16) product per tile and ear -- 20 v_mfma_f32_16x16x4_f32 each, 64 of
-// the 80 K-rows useful (the k = 0 and k = 4 Toeplitz tiles are complementary triangles).  The
-// instruction is an exact k-ordered fp32 fma chain, so the result is fp32 like the packed-VALU form.
-// Operands: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; with the K index of MFMA (k, t)
-// chosen as c = 4 kk + t (kk = l >> 4) the four A fragments of one (b - k) are ONE ds_read_b128
-// (x'[64 a + 16 (b - k) + 4 kk .. + 3]), 8 of them per ear, each reused by up to four tiles; the
-// 20 B fragments per ear are h[16 k + (l & 15) - 4 kk - t] out of a zero-padded LDS copy of the HRIR.
-// The 64-frame ring-out (frames 1024 + 16 b' + r) is a fifth tile whose rows are b' < 4:
-//     Y_t[b'][r] = sum_{k > b', c} x'[1024 + 16 (b' - k) + c] * h[16 k + r - c]   (16 MFMAs per ear).
-// acc[e][b]: lane l, element i = frame 64 (4 (l >> 4) + i) + 16 b + (l & 15) of ear e;
-// acc[e][4]: lanes < 16, element i = frame 1024 + 16 i + l.
+// ---- dual-ear FIR on the matrix pipe: the Toeplitz form of MixHrtf in split half precision -----
+// core/mixer/hrtfbase.h:17-89 computes, per ear, y[m] = sum_{t < IrSize} h[t] * x'[m - t] over one update
+// (x' = the delayed, gain-ramped input).  Cut the output into blocks of 16 frames, m = 16 n + i: then
+//     Y[i][n] = sum_{k < 96} T[i][k] * X[k][n],   T[i][k] = h[i + 64 - k],   X[k][n] = x'[16 n - 64 + k]
+// is a (16 x 96) x (96 x 16) product per 16 blocks (= 256 frames) and ear: three v_mfma_f32_16x16x32_f16
+// (64 of the 96 K-rows carry taps).  gfx950 has no reduced-precision fp32 MFMA (no xf32), and the fp32-input
+// form runs at the vector rate -- round 2 measured it slower than packed VALU FMAs -- but the f16 form runs
+// at 16x that rate, so both operands are split into two halves each, v = hi + lo (hi = the value rounded
+// toward zero to f16, lo = the remainder rounded to f16; a power-of-two scale per voice keeps both inside
+// f16's range), and the product is taken as hi*hi + hi*lo + lo*hi: 22 of fp32's 24 significant bits per
+// factor, products exact and accumulated in fp32 inside the instruction.  Measured against double precision
+// the result is as close as the reference's own serial fp32 sum (4e-7 of the block's maximum;
+// tests/test_tolerance_model.py).  9 MFMAs per tile and ear, 90 per voice (5 tiles: 4 x 256 frames + the
+// 64-frame ring-out) = 1.4 K cycles of the matrix pipe against 8.7 K cycles of packed FMAs.
+// Operands (the K slot of element idx of lane l is 8 (l >> 4) + idx for A and B alike):
+//   A: lane l, row i = l & 15: T[i][32 c + 8 g + idx] = r[16 - i + 32 c + 8 g + idx] with r[u] = h[80 - u]
+//      (zero outside u in [17, 80]): eight consecutive halves of the REVERSED response, read as five dwords
+//      and shifted down by one half (v_alignbyte_b32) in the lanes whose offset is odd;
+//   B: lane l, column j = l & 15: x'[16 (16 T + j) - 64 + 32 c + 8 g + idx]: one aligned ds_read_b128.
+// acc[e][T]: lane l, element r = frame 16 (16 T + (l & 15)) + 4 (l >> 4) + r of ear e (T = 4: the ring-out,
+// columns < 4).
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-template<int XS /* row stride of xp in floats */, int HPLEN>
-__device__ __forceinline__ void FirMfma64(f4 (&acc)[2][5], const float *xp0, const float *xp1, const float *hp0,
-    const float *hp1, uint32_t lane)
+constexpr int kXhHalves = 64 + 1024 + 80;              // x' halves per ear and part: frames -64 .. 1103
+constexpr int kXhDw = kXhHalves / 2;
+constexpr int kHrHalves = 120;                         // r[u], u < 112, and the fifth dword of the last fragment
+constexpr int kHrDw = kHrHalves / 2;
+static_assert(kXhDw % 4 == 0 && kHrDw % 4 == 0, "16-byte rows");
+
+// LDS images (WaveLds, wave_common.hpp): xh[ear][hi | lo][kXhDw] = x' * scale, two frames per dword;
+// hr[ear][hi | lo][kHrDw] = r[u] * scale
+// the power-of-two scale that brings a block whose largest magnitude has the bit pattern `maxBits` into
+// [2^14, 2^15), and its inverse (both within 2^+-60, so that a product of two inverses stays finite)
+__device__ __forceinline__ void HalfScale(uint32_t maxBits, float &scale, float &inv)
 {
-    const uint32_t a = lane & 15u, kk = lane >> 4;
-#pragma unroll
-    for(int e = 0; e < 2; ++e)
-    {
-        const float *xp = e ? xp1 : xp0;
-        const float *hp = e ? hp1 : hp0;
-        f4 A[8];
-        const float *xa = xp + XS * a + 4u * kk;
-#pragma unroll
-        for(int d = 0; d < 8; ++d)                       // d = (b - k) + 4; rows shift by one from d = 4 on
-            A[d] = *reinterpret_cast<const f4*>(xa + XS * (d >= 4 ? 1 : 0) + 16 * (d & 3));
-        float B[5][4];
-        const float *hb = hp + 16 + a - 4u * kk;         // (l & 15) doubles as the column r here
-#pragma unroll
-        for(int k = 0; k < 5; ++k)
-#pragma unroll
-            for(int t = 0; t < 4; ++t) B[k][t] = hb[16 * k - t];
-        // the ring-out tile's inputs: row b' = l & 15 (< k), x'[1024 - 16 (k - b') + 4 kk ..]
-        f4 T[4];
-#pragma unroll
-        for(int k = 1; k < 5; ++k)
-        {
-            const bool valid = a < uint32_t(k);
-            const uint32_t i64 = valid ? 1088u - 16u * (uint32_t(k) - a) + 4u * kk : 1024u;
-            const f4 v = *reinterpret_cast<const f4*>(xp + i64 + 4u * (i64 >> 6) /* = XS-strided rows */);
-            T[k - 1] = valid ? v : f4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        static_assert(XS == 68, "i64 + 4*(i64 >> 6) is the stride-68 row layout");
-#pragma unroll
-        for(int k = 0; k < 5; ++k)
-#pragma unroll
-            for(int t = 0; t < 4; ++t)
-            {
-#pragma unroll
-                for(int b = 0; b < 4; ++b)
-                    acc[e][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b - k + 4][t], B[k][t], acc[e][b], 0, 0, 0);
-                if(k >= 1)
-                    acc[e][4] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[k - 1][t], B[k][t], acc[e][4], 0, 0, 0);
-            }
-    }
+    int32_t sb = 268 - int32_t(maxBits >> 23);
+    sb = sb < 67 ? 67 : (sb > 187 ? 187 : sb);
+    scale = __builtin_bit_cast(float, uint32_t(sb) << 23);
+    inv = __builtin_bit_cast(float, uint32_t(254 - sb) << 23);
+}
+// (v0, v1) -> the packed f16 pair of their leading halves and of the remainders
+__device__ __forceinline__ void SplitHalf2(float v0, float v1, uint32_t &hi, uint32_t &lo)
+{
+    const auto h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v0 - float(h[0]), v1 - float(h[1])));
+}
+// maximum over the wavefront of non-negative floats given as bit patterns, by DPP (no LDS round trips)
+__device__ __forceinline__ uint32_t WaveMaxBits(uint32_t v)
+{
+#define OALGPU_DPP_MAX(ctrl) do { const uint32_t o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), ctrl, 0xF, 0xF, true)); v = o > v ? o : v; } while(0)
+    OALGPU_DPP_MAX(0xB1);     // quad_perm [1,0,3,2]
+    OALGPU_DPP_MAX(0x4E);     // quad_perm [2,3,0,1]
+    OALGPU_DPP_MAX(0x141);    // row_half_mirror
+    OALGPU_DPP_MAX(0x140);    // row_mirror: every lane of a row of 16 holds the row's maximum
+#undef OALGPU_DPP_MAX
+    const uint32_t a = uint32_t(__builtin_amdgcn_readlane(int(v), 0)), b = uint32_t(__builtin_amdgcn_readlane(int(v), 16));
+    const uint32_t c = uint32_t(__builtin_amdgcn_readlane(int(v), 32)), d = uint32_t(__builtin_amdgcn_readlane(int(v), 48));
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
-// One wavefront's share of the same product when a 4-wavefront workgroup works on ONE voice
-// (voice_block.hip): tile b (frames 64 a + 16 b + r) of both ears, and the k = b + 1 part of the
-// ring-out tile.  Per ear the 20 + 4 MFMAs run as three independent accumulator chains (even /
-// odd K steps of the main tile, ring-out), so none waits for the 40-cycle dependent latency.
-// accM[e][p]: lane l, element i = partial p of frame 64 (4 (l >> 4) + i) + 16 b + (l & 15);
-// accT[e]: lanes < 16, element i = this wave's part of frame 1024 + 16 i + l.
-template<int XS>
-__device__ __forceinline__ void FirMfmaTile(f4 (&accM)[2][2], f4 (&accT)[2], const float *xp0, const float *xp1,
-    const float *hp0, const float *hp1, uint32_t lane, uint32_t b /* wave-uniform */)
+__device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2][2][kXhDw], const uint32_t (&hr)[2][2][kHrDw],
+    float inv, uint32_t lane)
 {
-    static_assert(XS == 68, "i64 + 4*(i64 >> 6) is the stride-68 row layout");
-    const uint32_t a = lane & 15u, kk = lane >> 4;
-    const uint32_t kt = b + 1u;                           // the ring-out part this wave computes
-    const bool valid = a < kt;
-    const uint32_t i64 = valid ? 1088u - 16u * (kt - a) + 4u * kk : 1024u;
+    const uint32_t i = lane & 15u, g = lane >> 4;
+    const uint32_t u0 = 16u - i + 8u * g, shift = (u0 & 1u) * 2u, ud = u0 >> 1;
+    const f4 vinv = {inv, inv, inv, inv};
 #pragma unroll
     for(int e = 0; e < 2; ++e)
-    {
-        const float *xp = e ? xp1 : xp0;
-        const float *hp = e ? hp1 : hp0;
-        // every fragment of this ear is requested before the first MFMA (44 registers): one LDS round
-        // trip per ear instead of one per K step
-        f4 A[5];
-        const float *xa = xp + XS * a + 4u * kk;
+    {   // one ear at a time: 6 A fragments live across the ear's five tiles, 6 B fragments per tile
+        h8 A[2][3];
 #pragma unroll
-        for(int k = 0; k < 5; ++k)
-        {
-            const uint32_t d = b + 4u - uint32_t(k);      // (b - k) + 4
-            A[k] = *reinterpret_cast<const f4*>(xa + (d >= 4u ? uint32_t(XS) : 0u) + 16u * (d & 3u));
-        }
-        f4 T = *reinterpret_cast<const f4*>(xp + i64 + 4u * (i64 >> 6));
-        float B[5][4];
-        const float *hb = hp + 16 + a - 4u * kk;
+        for(int s = 0; s < 2; ++s)
 #pragma unroll
-        for(int k = 0; k < 5; ++k)
-#pragma unroll
-            for(int t = 0; t < 4; ++t) B[k][t] = hb[16 * k - t];
-        float Bt[4];                                      // = B[kt][.]: the ring-out part's taps (kt is wave-uniform)
-        const float *hbt = hb + 16u * kt;
-#pragma unroll
-        for(int t = 0; t < 4; ++t) Bt[t] = hbt[-t];
-        if(!valid) T = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        __builtin_amdgcn_sched_barrier(0);                // (the loads stay in front of the MFMAs)
-#pragma unroll
-        for(int k = 0; k < 5; ++k)
-#pragma unroll
-            for(int t = 0; t < 4; ++t)
-            {
-                accM[e][t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[k][t], B[k][t], accM[e][t & 1], 0, 0, 0);
-                if(k == 2) accT[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t], Bt[t], accT[e], 0, 0, 0);
+            for(int c = 0; c < 3; ++c)
+            {   // eight halves from half offset u0 + 32 c: five dwords, shifted down by one half when u0 is odd
+                const uint32_t *p = hr[e][s] + ud + 16 * c;
+                const uint32_t q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+                const u4 q = {__builtin_amdgcn_alignbyte(q1, q0, shift), __builtin_amdgcn_alignbyte(q2, q1, shift),
+                    __builtin_amdgcn_alignbyte(q3, q2, shift), __builtin_amdgcn_alignbyte(q4, q3, shift)};
+                A[s][c] = __builtin_bit_cast(h8, q);
             }
-        // one ear's fragment registers at a time: keep the other ear's loads behind this ear's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
+        // the tiles' B fragments one tile ahead of their use; per tile three independent accumulator chains
+        // (lo*hi, hi*lo, hi*hi: three MFMAs each) so that the nine issue back to back
+        auto loadB = [&](h8 (&B)[2][3], int T)
+        {
+            const uint32_t j = (T == 4 && i > 3u) ? 3u : i;          // the ring-out tile has four columns
+#pragma unroll
+            for(int s = 0; s < 2; ++s)
+            {
+                const u4 *p = reinterpret_cast<const u4*>(xh[e][s]) + 32 * T + 2u * j + g;
+#pragma unroll
+                for(int c = 0; c < 3; ++c) B[s][c] = __builtin_bit_cast(h8, p[4 * c]);
+            }
+        };
+        h8 B[2][3], Bn[2][3];
+        loadB(B, 0);
+#pragma unroll
+        for(int T = 0; T < 5; ++T)
+        {
+            if(T + 1 < 5) loadB(Bn, T + 1);
+            f4 ta = {0.0f, 0.0f, 0.0f, 0.0f}, tb = ta, tc = ta;
+#pragma unroll
+            for(int c = 0; c < 3; ++c)
+            {
+                ta = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1][c], B[0][c], ta, 0, 0, 0);
+                tb = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0][c], B[1][c], tb, 0, 0, 0);
+                tc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0][c], B[0][c], tc, 0, 0, 0);
+            }
+            acc[e][T] = __builtin_elementwise_fma((ta + tb) + tc, vinv, acc[e][T]);
+            if(T + 1 < 5)
+            {
+#pragma unroll
+                for(int s = 0; s < 2; ++s)
+#pragma unroll
+                    for(int c = 0; c < 3; ++c) B[s][c] = Bn[s][c];
+            }
+        }
     }
 }
 

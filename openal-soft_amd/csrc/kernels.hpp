@@ -83,11 +83,8 @@ struct DeviceLayout {
     uint32_t hrtf, irSize, irStride;       // irStride: taps stored per voice filter (irSize rounded up to 8)
     uint32_t voicesPerGroup, numGroups;
     uint32_t waveVoices;                    // voice_wave.hip: voices per wavefront (0 = not used)
-    uint32_t blockVoices;                   // voice_block.hip: voices per workgroup (0 = that kernel is not used)
-    uint32_t blockWaves;                    // voice_block.hip: workgroups per CU the kernel variant is built for (3 or 4)
-    uint32_t ablate;                        // profiling aid (env OALGPU_ABLATE): stages to skip, 0 in production
-    uint32_t firMfma;                       // voice_wave.hip: the HRTF FIR on the matrix pipe (env OALGPU_FIR=mfma)
-    unsigned long long *phaseTimes;         // profiling aid (env OALGPU_PHASE_TIMES): [voice][8] s_memtime stamps, or null
+    uint32_t firMfma;                       // voice_wave.hip: the HRTF FIR (IrSize <= 64) on the matrix pipe in split half
+                                            // precision (default) instead of packed VALU FMAs (OALGPU_CTX_FIR_VALU)
     uint32_t mixLines;                      // lines accumulated by the voice kernel
     // tables + buffers
     const float *tables;                    // [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
@@ -289,11 +286,9 @@ void LaunchDecodeAdpcm(hipStream_t s, bool msadpcm, const uint8_t *src, int16_t 
 bool WaveKernelApplies(bool exact, const DeviceLayout &L);
 const char *WaveKernelName(const DeviceLayout &L);
 uint32_t WaveKernelGroups(const DeviceLayout &L);
-hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo);
-
-// ---- launchers (voice_block.hip): FAST HRTF voices without sends, one workgroup per voice; reached
-// through LaunchVoiceWave / WaveKernelGroups / WaveKernelName when L.blockVoices != 0 ----
-uint32_t BlockKernelGroups(const DeviceLayout &L);
-hipError_t LaunchVoiceBlock(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo);
+// the measurement variant's extras (OALGPU_CTX_PROFILE, tools/phase_times.py): s_memtime stamps
+// [voice][8] | [wavefront][4], and the stages to skip; production launches pass null
+struct WaveProf { unsigned long long *times; uint32_t ablate; };
+hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof = nullptr);
 
 } // namespace oalgpu

@@ -24,7 +24,7 @@ struct oalgpu_reverb {
     DevBuf<float> samples, scratch, cubic, hostIn, hostOut;
     DevBuf<oalgpu_reverb_pipeline> pipe;
     DevBuf<RvPipeState> state;
-    DevBuf<unsigned long long> stamps;      // profiling aid, env OALGPU_PHASE_TIMES
+    DevBuf<unsigned long long> stamps;      // measurement aid (oalgpu_reverb_debug_enable_phase_times)
     RvLayout L{};
 };
 
@@ -91,11 +91,7 @@ int oalgpu_reverb_create(int device, uint32_t sample_rate, uint32_t num_out_line
     L.lateOut = r->scratch.p + size_t{2} * 4 * OALGPU_BUFFER_LINE_SIZE;
     L.cubic = r->cubic.p;
     L.nlines = num_out_lines;
-    if(std::getenv("OALGPU_PHASE_TIMES"))
-    {
-        HIP_TRY(r->stamps.alloc(4 * 8 * 8)); HIP_TRY(r->stamps.zero());
-        L.stamps = r->stamps.p;
-    }
+    L.stamps = nullptr;
     *out = r.release();
     return OALGPU_OK;
 }
@@ -255,7 +251,18 @@ int oalgpu_reverb_process_device(oalgpu_reverb *r, const float *wet_in_dev, floa
     return OALGPU_OK;
 }
 
-/* profiling aid: the cycle-counter stamps of the last launch, [4 roles][8 sub-blocks][8] */
+/* measurement aid: cycle-counter stamps of the launches from here on, [4 roles][8 sub-blocks][8]
+ * (tools/reverb_phase_times.py; a device instance only) */
+int oalgpu_reverb_debug_enable_phase_times(oalgpu_reverb *r)
+{
+    if(!r || r->device < 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_debug_enable_phase_times: needs a device instance");
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->stamps.alloc(4 * 8 * 8)); HIP_TRY(r->stamps.zero());
+    r->L.stamps = r->stamps.p;
+    return OALGPU_OK;
+}
+
+/* measurement aid: the stamps of the last launch */
 int oalgpu_reverb_debug_phase_times(oalgpu_reverb *r, unsigned long long *out)
 {
     if(!r || !out || !r->stamps.p) return Fail(OALGPU_ERR_INVALID, "phase times were not enabled");

@@ -45,7 +45,7 @@ struct RvLayout {
     uint32_t upmix;                // mUpmixOutput: MixOutAmbiUp instead of MixOutPlain
     float orderScale[2];           // mOrderScales[0], [1]
     float splitCoeff;              // BandSplitter{device->mXOverFreq / frequency}.mCoeff
-    unsigned long long *stamps;    // profiling aid (env OALGPU_PHASE_TIMES): [4 roles][8 sub-blocks][8]
+    unsigned long long *stamps;    // measurement aid (oalgpu_reverb_debug_enable_phase_times), null in production: [4 roles][8 sub-blocks][8]
 };
 
 // several instances adding into the same target lines in one launch (see ReverbProcessBody)

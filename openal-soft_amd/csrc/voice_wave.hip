@@ -194,11 +194,13 @@ __device__ __forceinline__ void WgMixRows(uint32_t *lds, const DeviceLayout &L, 
 // stream row too -- the unfiltered resampled samples shared by all sends (and the direct path)
 // whose filter is inactive, or its own filtered copy -- with a gain block over the wet lines.
 // Stream rows of a voice: [0] unfiltered, [1] direct-filtered (dry-line contexts), [2+i] send i filtered.
-// MF: the dual-ear FIR of HRTF voices (IrSize <= 64) on the matrix pipe (FirMfma64, dev_wave.hpp) instead
-// of packed VALU FMAs: the matrix pipe then works for one wavefront of a SIMD while the other's
-// resampler and filters own the VALU issue slots.
-template<int R, int TAPS, int NL, bool SENDS, bool MF = false>
-__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo)
+// MF: the dual-ear FIR of HRTF voices (IrSize <= 64) on the matrix pipe in split half precision (FirMfmaH,
+// dev_wave.hpp) instead of packed VALU FMAs: 90 MFMAs (1.4 K cycles of the matrix pipe) per voice in the place
+// of 1088 v_pk_fma_f32 (8.7 K cycles of the VALU), beside the other wavefront's resampler and filters.
+// PROF: the measurement variant (tools/phase_times.py): s_memtime stamps per phase and stage ablation; the
+// product variants carry none of it.
+template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool PROF = false>
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo, WaveProf prof)
 {
     static_assert(!MF || (R == 17 && TAPS == 64 && NL == 0), "the matrix-pipe FIR is the 64-tap HRTF form");
     using WL = WaveLds<R, TAPS, MF>;
@@ -220,12 +222,16 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     const uint32_t vBegin = group * kWWaves * vpw + (wave & 1u) + 2u * (wave >> 1) * vpw;
     const uint32_t vEnd = (vBegin + 2u * vpw < L.numVoices) ? vBegin + 2u * vpw : L.numVoices;   // v = vBegin + 2k < vEnd
     const uint32_t vCount = vBegin < vEnd ? (vEnd - vBegin + 1u) / 2u : 0u;
-    // profiling aid (OALGPU_PHASE_TIMES): per-wavefront stamps behind the per-voice ones
+    // PROF: per-wavefront stamps behind the per-voice ones
     auto waveStamp = [&](int slot)
     {
-        if(L.phaseTimes && lane0 == 0)
-            L.phaseTimes[size_t{L.numVoices} * 8 + size_t{group * kWWaves + wave} * 4 + slot] = __builtin_readcyclecounter();
+        if constexpr (PROF)
+        {
+            if(prof.times && lane0 == 0)
+                prof.times[size_t{L.numVoices} * 8 + size_t{group * kWWaves + wave} * 4 + slot] = __builtin_readcyclecounter();
+        }
     };
+    const uint32_t ablate = PROF ? prof.ablate : 0u;
     waveStamp(0);
     // Two workgroups share a CU, and the launch fills the machine exactly once: workgroup g and
     // g + gridDim/2 land on the same CU (the dispatcher deals the first half one per CU, then the
@@ -260,7 +266,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     f2 acc[MF ? 1 : R];
 #pragma unroll
     for(int r = 0; r < (MF ? 1 : R); ++r) acc[r] = f2{0.0f, 0.0f};
-    f4 accM[2][5];                                   // MF: FirMfma64's tiles, ear x (4 main + ring-out)
+    float invH = 1.0f;                               // MF: 1 / scale of the parked (next) voice's response
+    f4 accM[2][5];                                   // MF: FirMfmaH's tiles, ear x (4 x 256 frames + ring-out)
 #pragma unroll
     for(int e = 0; e < 2; ++e)
 #pragma unroll
@@ -394,8 +401,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
         auto stamp = [&](int slot)
         {
-            if(L.phaseTimes && lane == 0) L.phaseTimes[size_t{v} * 8 + slot] = __builtin_readcyclecounter();
+            if constexpr (PROF) { if(prof.times && lane == 0) prof.times[size_t{v} * 8 + slot] = __builtin_readcyclecounter(); }
         };
+        float invX = 1.0f;                            // MF: 1 / scale of this voice's FIR inputs
         if(active)
         {
             stamp(0);
@@ -406,7 +414,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             // filter's old coefficients (w.cold) and the source window were parked by the last pass
             const float fstv = fstC;
             const SrcPlan plan = planN;
-            LoadResampledWave(sm, w, L, v, lane, head, playing, N - outPos, N - outPos, bufferItem, looping, plan, outPos);
+            LoadResampledWave<false, PROF>(sm, w, L, v, lane, head, playing, N - outPos, N - outPos, bufferItem, looping, plan, outPos, prof);
             asm volatile("" : "+v"(lane));      // addresses used from here on are rebuilt, not carried across the resampler
             if constexpr (NL > 0) requestNext();
             if(head.flags & kFlagAmbiScale)
@@ -422,7 +430,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             stamp(1);
             counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
 
-            const bool directFilter = (head.flags & kFlagDirectFilter) && !(L.ablate & 8u);
+            const bool directFilter = (head.flags & kFlagDirectFilter) && !(ablate & 8u);
             if constexpr (SENDS || NL > 0)
             {   // ---- stream rows that must leave before the direct filter overwrites w.in
                 const uint32_t ls = L.lineStride, spv = L.streamsPerVoice, numSends = L.numSends, wetCh = L.wetChannels;
@@ -595,27 +603,68 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             const bool merged = !dirty;
 
             // x'[i] = (In[64 - dL + i], In[64 - dR + i]) * g(i); zero pads on both sides
-            // (MF: planar per ear, frame i at xp[e][68 (i/64 + 1) + i%64]; lane + 64 j -> 68 (j + 1) + lane)
-            auto putX = [&](uint32_t j /* frame = lane + 64 j */, float xl, float xr)
-            {
-                if constexpr (MF) { w.xp[0][kXpStride * (j + 1u) + lane] = xl; w.xp[1][kXpStride * (j + 1u) + lane] = xr; }
-                else w.x2[TAPS + lane + 64u * j] = f2{xl, xr};
-            };
+            const float *inL = w.in + (kHist - dL), *inR = w.in + (kHist - dR);
+            const float gbase = gainAfterBlend - mainStep * float(fademix);
             if constexpr (MF)
-            {
-                w.xp[0][lane] = 0.0f; w.xp[1][lane] = 0.0f;
-                // frames N..1023 (short updates): the lane's first frame at or after N
-                for(uint32_t i = N + ((lane + 64u - (N & 63u)) & 63u); i < uint32_t(kLine); i += 64) putX(i >> 6, 0.0f, 0.0f);
+            {   // per ear, as packed f16 pairs: lane l owns the frame pairs l + 64 j (frames 2 (l + 64 j), + 1), so
+                // that a pair is one dword.  First the products and their largest magnitude, then the power-of-
+                // two scale that puts that magnitude into [2^14, 2^15), the split and the stores.
+                float xl[kLine / 128][2], xr[kLine / 128][2];
+#pragma unroll
+                for(int j = 0; j < kLine / 128; ++j)
+#pragma unroll
+                    for(int k = 0; k < 2; ++k)
+                    {   // 2 (lane + 64 j) + k <= 1023: inside w.in for any N
+                        const uint32_t i = 2u * (lane + 64u * uint32_t(j)) + uint32_t(k);
+                        xl[j][k] = inL[i]; xr[j][k] = inR[i];
+                    }
+                uint32_t mx = 0u;
+#pragma unroll
+                for(int j = 0; j < kLine / 128; ++j)
+#pragma unroll
+                    for(int k = 0; k < 2; ++k)
+                    {
+                        const uint32_t i = 2u * (lane + 64u * uint32_t(j)) + uint32_t(k);
+                        float g = __builtin_fmaf(mainStep, float(i), gbase);
+                        if(j == 0 && i < fademix)
+                        {   // only the first 64 frames can lie inside the fade
+                            g = newOn ? newStep * float(i) : 0.0f;
+                            if(merged && oldOn) g += oldStep * float(fademix - i);
+                        }
+                        const float a = (i < N) ? xl[j][k] * g : 0.0f, b = (i < N) ? xr[j][k] * g : 0.0f;
+                        xl[j][k] = a; xr[j][k] = b;
+                        const uint32_t ua = __builtin_bit_cast(uint32_t, a) & 0x7fffffffu, ub = __builtin_bit_cast(uint32_t, b) & 0x7fffffffu;
+                        mx = ua > mx ? ua : mx; mx = ub > mx ? ub : mx;
+                    }
+                float sx;
+                HalfScale(WaveMaxBits(mx), sx, invX);
+                if(lane < 32u)
+                {   // frames -64 .. -1
+                    w.xh[0][0][lane] = 0u; w.xh[0][1][lane] = 0u; w.xh[1][0][lane] = 0u; w.xh[1][1][lane] = 0u;
+                }
+                if(lane < uint32_t(kXhDw - 32 - kLine / 2))
+                {   // frames 1024 .. 1103
+                    const uint32_t d = 32u + kLine / 2 + lane;
+                    w.xh[0][0][d] = 0u; w.xh[0][1][d] = 0u; w.xh[1][0][d] = 0u; w.xh[1][1][d] = 0u;
+                }
+#pragma unroll
+                for(int j = 0; j < kLine / 128; ++j)
+                {
+                    const uint32_t d = 32u + lane + 64u * uint32_t(j);
+                    uint32_t hi, lo;
+                    SplitHalf2(xl[j][0] * sx, xl[j][1] * sx, hi, lo);
+                    w.xh[0][0][d] = hi; w.xh[0][1][d] = lo;
+                    SplitHalf2(xr[j][0] * sx, xr[j][1] * sx, hi, lo);
+                    w.xh[1][0][d] = hi; w.xh[1][1][d] = lo;
+                }
             }
             else
             {
             w.x2[lane] = f2{0.0f, 0.0f};
             if(TAPS > 64) w.x2[64 + lane] = f2{0.0f, 0.0f};
             for(uint32_t k = TAPS + N + lane; k < uint32_t(WL::kX); k += 64) w.x2[k] = f2{0.0f, 0.0f};
-            }
-            if(!(L.ablate & 16u))
+            if(!(ablate & 16u))
             {
-                const float *inL = w.in + (kHist - dL), *inR = w.in + (kHist - dR);
                 if(lane < N)
                 {   // i = lane: the only pass that can touch the fade (fademix <= 64)
                     const uint32_t i = lane;
@@ -626,9 +675,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                         if(merged && oldOn) g += oldStep * float(fademix - i);
                     }
                     else g = gainAfterBlend + mainStep * float(i - fademix);
-                    putX(0u, inL[i] * g, inR[i] * g);
+                    w.x2[TAPS + lane] = f2{inL[i] * g, inR[i] * g};
                 }
-                const float gbase = gainAfterBlend - mainStep * float(fademix);
                 // all reads first, then all writes: in and x2 are members of one LDS object, so
                 // the compiler keeps a read behind every earlier write (one LDS round trip per
                 // frame row otherwise).  lane + 64 j <= 1023: inside w.in for any N.
@@ -644,8 +692,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 {
                     const uint32_t i = lane + 64u * uint32_t(j + 1);
                     const float g = __builtin_fmaf(mainStep, float(i), gbase);
-                    if(i < N) putX(uint32_t(j + 1), xl[j] * g, xr[j] * g);
+                    if(i < N) w.x2[TAPS + lane + 64u * uint32_t(j + 1)] = f2{xl[j] * g, xr[j] * g};
                 }
+            }
             }
             // old-filter fade-out inputs (one per lane) and coefficients, replaced filters only
             oldPass = !merged && oldOn;
@@ -725,8 +774,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             // zero padding of the old-filter coefficient array (never overwritten)
             for(uint32_t k = lane; k < uint32_t(TAPS + 128); k += 64) w.cold[k] = f2{0.0f, 0.0f};
             if constexpr (MF)
-            {   // zero padding of the HRIR copies: hp[e][0..15] and hp[e][80..95]
-                if(lane < 16u) { w.hp[0][lane] = 0.0f; w.hp[1][lane] = 0.0f; w.hp[0][80u + lane] = 0.0f; w.hp[1][80u + lane] = 0.0f; }
+            {   // zero padding of the reversed responses (every voice rewrites u in [17, 80] only)
+                uint32_t *hz = &w.hr[0][0][0];
+                for(uint32_t k = lane; k < uint32_t(4 * kHrDw); k += 64) hz[k] = 0u;
             }
             __syncthreads();
         }
@@ -736,9 +786,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         {
             stamp(4);
             cf16 *co = (cf16*)(uintptr_t)(L.hrtfTgt + size_t{v} * irStride * 2);
-            if(NL > 0 || (L.ablate & 1u)) {}
+            if(NL > 0 || (ablate & 1u)) {}
             else if constexpr (MF)
-                FirMfma64<kXpStride, kHpLen>(accM, w.xp[0], w.xp[1], w.hp[0], w.hp[1], lane);
+                FirMfmaH(accM, w.xh, w.hr, invX * invH, lane);
             else if(irStride == uint32_t(TAPS))
                 FirMainPk<R, TAPS>(acc, &w.x2[TAPS + R * lane], co);
             else
@@ -747,7 +797,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 for(uint32_t seg = 0; seg * 16u < irStride; ++seg)
                     FirMainPk<R, 16>(acc, xw - 16 * seg, co + 2 * seg);
             }
-            if(NL == 0 && oldPass && !(L.ablate & 1u))
+            if(NL == 0 && oldPass && !(ablate & 1u))
             {   // frames lane + 64q receive cOld[lane + 64q - i] * xo[i], i < 64
 #pragma unroll 1
                 for(int i0 = 0; i0 < 64; i0 += 8)
@@ -786,7 +836,18 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             if constexpr (NL == 0)
             {
                 w.in[lane] = histN;
-                if constexpr (MF) { w.hp[0][16u + lane] = hN.x; w.hp[1][16u + lane] = hN.y; }
+                if constexpr (MF)
+                {   // the response, tap = lane, as r[80 - lane] (FirMfmaH)
+                    const uint32_t ux = __builtin_bit_cast(uint32_t, hN.x) & 0x7fffffffu, uy = __builtin_bit_cast(uint32_t, hN.y) & 0x7fffffffu;
+                    float sh;
+                    HalfScale(WaveMaxBits(ux > uy ? ux : uy), sh, invH);
+                    uint32_t hi, lo;
+                    SplitHalf2(hN.x * sh, hN.y * sh, hi, lo);       // (left, right) leading halves / remainders
+                    uint16_t *hz = reinterpret_cast<uint16_t*>(&w.hr[0][0][0]);
+                    const uint32_t u = 80u - lane;
+                    hz[0 * kHrHalves + u] = uint16_t(hi); hz[1 * kHrHalves + u] = uint16_t(lo);
+                    hz[2 * kHrHalves + u] = uint16_t(hi >> 16); hz[3 * kHrHalves + u] = uint16_t(lo >> 16);
+                }
                 if(dirtyN)
                 {
 #pragma unroll
@@ -886,17 +947,17 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         f2 *dump = w.x2;                     // [frame] = (L, R), frames < 64R
         WaveSync();
         if constexpr (MF)
-        {   // FirMfma64's tiles -> frames
-            const uint32_t rr = lane0 & 15u, q4 = lane0 >> 4;
+        {   // FirMfmaH's tiles -> frames
+            const uint32_t jc = lane0 & 15u, q4 = lane0 >> 4;
 #pragma unroll
-            for(int b = 0; b < 4; ++b)
+            for(int T = 0; T < 4; ++T)
 #pragma unroll
-                for(int i = 0; i < 4; ++i)
-                    dump[64u * (4u * q4 + uint32_t(i)) + 16u * uint32_t(b) + rr] = f2{accM[0][b][i], accM[1][b][i]};
-            if(lane0 < 16u)
+                for(int r = 0; r < 4; ++r)
+                    dump[16u * (16u * uint32_t(T) + jc) + 4u * q4 + uint32_t(r)] = f2{accM[0][T][r], accM[1][T][r]};
+            if(jc < 4u)
             {
 #pragma unroll
-                for(int i = 0; i < 4; ++i) dump[1024u + 16u * uint32_t(i) + lane0] = f2{accM[0][4][i], accM[1][4][i]};
+                for(int r = 0; r < 4; ++r) dump[1024u + 16u * jc + 4u * q4 + uint32_t(r)] = f2{accM[0][4][r], accM[1][4][r]};
             }
         }
         else
@@ -940,7 +1001,6 @@ bool WaveKernelApplies(bool exact, const DeviceLayout &L)
 
 const char *WaveKernelName(const DeviceLayout &L)
 {
-    if(L.blockVoices) return "VoiceBlockKernel";
     const bool sends = L.numSends != 0;
     if(!L.hrtf) return sends ? "VoiceWaveKernel<17, 64, 1, true>" : "VoiceWaveKernel<17, 64, 1, false>";
     if(L.irStride <= 64 && L.firMfma) return sends ? "VoiceWaveKernel<17, 64, 0, true, true>" : "VoiceWaveKernel<17, 64, 0, false, true>";
@@ -950,35 +1010,40 @@ const char *WaveKernelName(const DeviceLayout &L)
 
 uint32_t WaveKernelGroups(const DeviceLayout &L)
 {
-    if(L.blockVoices) return BlockKernelGroups(L);
     return (L.numVoices + kWWaves * L.waveVoices - 1u) / (kWWaves * L.waveVoices);
 }
 
-hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo)
+// prof: null in production; the measurement variants exist for the HRTF kernels without sends only
+hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof)
 {
-    if(L.blockVoices) return LaunchVoiceBlock(s, L, samplesToDo);
     const uint32_t groups = WaveKernelGroups(L);
     const bool sends = L.numSends != 0;
     const dim3 grid(groups), block(kWThreads);
-    if(!L.hrtf)
+    const WaveProf none{nullptr, 0u};
+    if(prof && L.hrtf && !sends && L.irStride <= 64)
     {
-        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, L, samplesToDo);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false>), grid, block, 0, s, L, samplesToDo);
+        if(L.firMfma) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true>), grid, block, 0, s, L, samplesToDo, *prof);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true>), grid, block, 0, s, L, samplesToDo, *prof);
+    }
+    else if(!L.hrtf)
+    {
+        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, L, samplesToDo, none);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false>), grid, block, 0, s, L, samplesToDo, none);
     }
     else if(L.irStride <= 64 && L.firMfma)
     {
-        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true>), grid, block, 0, s, L, samplesToDo);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true>), grid, block, 0, s, L, samplesToDo);
+        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true>), grid, block, 0, s, L, samplesToDo, none);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true>), grid, block, 0, s, L, samplesToDo, none);
     }
     else if(L.irStride <= 64)
     {
-        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, L, samplesToDo);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false>), grid, block, 0, s, L, samplesToDo);
+        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, L, samplesToDo, none);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false>), grid, block, 0, s, L, samplesToDo, none);
     }
     else
     {
-        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, L, samplesToDo);
-        else hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false>), grid, block, 0, s, L, samplesToDo);
+        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, L, samplesToDo, none);
+        else hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false>), grid, block, 0, s, L, samplesToDo, none);
     }
     return hipGetLastError();
 }

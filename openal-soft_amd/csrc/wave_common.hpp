@@ -1,5 +1,5 @@
-// Building blocks shared by the voice kernels that stage a voice in LDS (voice_wave.hip: one wavefront
-// per voice; voice_block.hip: one 4-wavefront workgroup per voice): scalar-cache views of VoiceCtl, the
+// Building blocks of the voice kernel that stages a voice in LDS (voice_wave.hip: one wavefront per voice):
+// scalar-cache views of VoiceCtl, the
 // LDS layouts, the register gather of the source window, the staged-row resampler, the wave-level
 // LoadResampledSamples / DoFilters (core/voice.cpp:642-824, :255-267) and the filter scans.
 #pragma once
@@ -65,14 +65,9 @@ __device__ __forceinline__ BufferItem LoadCtlBufferScalar(const VoiceCtl *p)
     return u.b;
 }
 
-// MF: the dual-ear FIR runs on the matrix pipe (FirMfma64 below); its inputs are staged planar,
-// one array per ear, as 17 rows of 64 frames (row 0 = the 64 zero frames in front of the update)
-// with a row stride of kXpStride floats: a lane's ds_read_b128 of four consecutive frames of row a
-// then falls on bank group (4a + 4kk) mod 64, distinct within every 16-lane service group.
-constexpr int kXpStride = 68;
-constexpr int kXpFloats = 17 * kXpStride;
-constexpr int kHpLen = 16 + 64 + 16;                    // hp[e][16 + j] = Coeffs[j][e], j in [-16, 80): zero outside [0, IrSize)
-
+// MF: the dual-ear FIR runs on the matrix pipe (FirMfmaH, dev_wave.hpp); its inputs are staged per ear as
+// packed f16 pairs, leading halves and remainders (xh, in the place of x2), and the next voice's reversed
+// response is parked in hr while this voice's registers are still busy with its write-back.
 template<int R, int TAPS, bool MF = false>
 struct alignas(16) WaveLds {
     static constexpr int kFrames = 64 * R;
@@ -80,7 +75,7 @@ struct alignas(16) WaveLds {
     static constexpr int kQ = TAPS / 64 + 1;            // old-filter fade: frames l + 64q, q < kQ
     union {
         f2 x2[kX];                                      // FIR inputs (both ears), zero padded
-        float xp[2][MF ? kXpFloats : 1];                // MF: FIR inputs per ear, planar (see above)
+        uint32_t xh[2][2][MF ? kXhDw : 1];              // MF: FIR inputs [ear][hi | lo], two frames per dword
         float rd[kResampleDataSize + 8];                // DeviceBase::mResampleData (dead before x2 is built)
     };
     float in[kHist + kLine];                            // [Hrtf.History | resampled, filtered samples]
@@ -89,7 +84,7 @@ struct alignas(16) WaveLds {
     float fst[32];                                      // the voice's two BiquadSlots (2 x 16 dwords)
     int32_t best;
     uint32_t pad[3];
-    float hp[MF ? 2 : 1][MF ? kHpLen : 4];              // MF: the target HRIR per ear, zero padded both sides
+    uint32_t hr[2][2][MF ? kHrDw : 1];                  // MF: the target HRIR reversed [ear][hi | lo], see FirMfmaH
 };
 
 template<int R, int TAPS, bool MF = false>
@@ -432,10 +427,10 @@ __device__ __forceinline__ void ResampleRunStagedM(const SM &sm, const float *rd
 // set the first chunk's source samples are already on their way in `pre` (GatherStatic) and
 // `prevv` holds mPrevSamples[lane].
 // LEAN: the register-lean staged resampler (kernels that run at four wavefronts per SIMD).
-template<bool LEAN = false, class SM, class WV>
+template<bool LEAN = false, bool PROF = false, class SM, class WV>
 __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const DeviceLayout &L,
     uint32_t v, uint32_t lane, const VoiceHead &h, bool playing, uint32_t samplesToLoad, uint32_t samplesToMix,
-    int32_t bufferItem, bool looping, const SrcPlan &plan, uint32_t mixOffset = 0)
+    int32_t bufferItem, bool looping, const SrcPlan &plan, uint32_t mixOffset = 0, const WaveProf &prof = WaveProf{nullptr, 0u})
 {
     float *rdata = w.rd;
     float *srcBuffer = rdata + kMaxEdge;
@@ -516,10 +511,10 @@ __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const DeviceLay
         }
         firstPass = false;
         WaveSync();
-        if(L.phaseTimes && lane == 0 && loaded == 0) L.phaseTimes[size_t{v} * 8 + 7] = __builtin_readcyclecounter();
+        if constexpr (PROF) { if(prof.times && lane == 0 && loaded == 0) prof.times[size_t{v} * 8 + 7] = __builtin_readcyclecounter(); }
 
         // voice.cpp:764-769
-        if((increment == kFracOne && fracPos == 0) || (L.ablate & 2u))
+        if((increment == kFracOne && fracPos == 0) || (PROF && (prof.ablate & 2u)))
         {
             for(uint32_t k = lane; k < bdst; k += 64) mixing[loaded + k] = srcBuffer[k];
         }

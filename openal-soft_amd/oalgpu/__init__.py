@@ -69,7 +69,11 @@ class ContextDesc(C.Structure):
                 ("num_dry_channels", C.c_uint32), ("num_real_channels", C.c_uint32),
                 ("num_aux_sends", C.c_uint32), ("num_slots", C.c_uint32),
                 ("wet_channels", C.c_uint32), ("hrtf", C.c_int32), ("max_voices", C.c_uint32),
-                ("max_buffers", C.c_uint32), ("voices_per_group", C.c_uint32)]
+                ("max_buffers", C.c_uint32), ("voices_per_group", C.c_uint32), ("flags", C.c_uint32)]
+
+
+# oalgpu_context_desc::flags
+CTX_FIR_VALU, CTX_PROFILE, CTX_SERIAL = 1, 2, 4
 
 
 class VoiceDesc(C.Structure):
@@ -188,9 +192,10 @@ class Api:
     so the parity tests can drive oracle and product through one code path."""
     kind = "oalgpu"
 
-    def __init__(self, mode=MATH_EXACT, device=0):
+    def __init__(self, mode=MATH_EXACT, device=0, ctx_flags=0):
         self.mode = mode
         self.device = device
+        self.ctx_flags = ctx_flags      # oalgpu_context_desc::flags of the scenes made from this Api
         self._mhr = None
 
     # ---- tables (host side) ----
@@ -272,12 +277,12 @@ class Scene:
     """Batched path: one device context, driven like tests/oracle_lib.Scene."""
 
     def __init__(self, api, sample_rate=48000, num_dry=3, num_real=0, num_sends=0, num_slots=0,
-                 wet_channels=4, hrtf=False, max_voices=64, max_buffers=64, voices_per_group=0):
+                 wet_channels=4, hrtf=False, max_voices=64, max_buffers=64, voices_per_group=0, flags=None):
         self.h = None
         self.api = api
         self.desc = ContextDesc(api.device, api.mode, sample_rate, num_dry, num_real, num_sends,
                                 num_slots, wet_channels, 1 if hrtf else 0, max_voices, max_buffers,
-                                voices_per_group)
+                                voices_per_group, api.ctx_flags if flags is None else flags)
         h = C.c_void_p()
         check(lib.oalgpu_context_create(C.byref(self.desc), C.byref(h)), "oalgpu_context_create")
         self.h = h

@@ -120,11 +120,11 @@ def test_reference_callback_scene_is_meaningful(synth_mhr):
 
 
 CASES = {
-    "dry lines exact (generic kernel)": dict(hrtf=False, exact=True, env={}),
-    "dry lines fast (stream rows)": dict(hrtf=False, exact=False, env={}),
-    "hrtf fast (wavefront kernel)": dict(hrtf=True, exact=False, env={}),
-    "hrtf fast (workgroup kernel)": dict(hrtf=True, exact=False, env={"OALGPU_VOICE_KERNEL": "block"}),
-    "hrtf exact (generic kernel)": dict(hrtf=True, exact=True, env={}),
+    "dry lines exact (generic kernel)": dict(hrtf=False, exact=True, flags=0),
+    "dry lines fast (stream rows)": dict(hrtf=False, exact=False, flags=0),
+    "hrtf fast (wavefront kernel, matrix-pipe FIR)": dict(hrtf=True, exact=False, flags=0),
+    "hrtf fast (wavefront kernel, packed-VALU FIR)": dict(hrtf=True, exact=False, flags=1),
+    "hrtf exact (generic kernel)": dict(hrtf=True, exact=True, flags=0),
 }
 
 
@@ -136,16 +136,7 @@ def test_callback_voices_match_the_reference(case, synth_mhr):
     L = _ref()
     cfg = CASES[case]
     want, wi = run(L, synth_mhr, cfg["hrtf"], 12)
-    old = {k: os.environ.get(k) for k in cfg["env"]}
-    os.environ.update(cfg["env"])
-    try:
-        got, gi = run(oalgpu.Api(oalgpu.MATH_EXACT if cfg["exact"] else oalgpu.MATH_FAST), synth_mhr, cfg["hrtf"], 12, max_voices=16)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    got, gi = run(oalgpu.Api(oalgpu.MATH_EXACT if cfg["exact"] else oalgpu.MATH_FAST, ctx_flags=cfg["flags"]), synth_mhr, cfg["hrtf"], 12, max_voices=16)
     for k, (a, b) in enumerate(zip(got, want)):
         assert gi[k] == wi[k], (case, k, [(x, y) for x, y in zip(gi[k], wi[k]) if x != y][:3])
         assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-3) + 1e-7, (case, k, float(np.abs(a - b).max()))

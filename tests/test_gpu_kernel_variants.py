@@ -1,9 +1,6 @@
-"""The alternative forms of the HRTF voice kernel against the oracle (same scenes, same tolerances as
-tests/test_gpu_parity.py): the matrix-pipe Toeplitz FIR inside the wavefront kernel (OALGPU_FIR=mfma)
-and the workgroup-per-voice kernel (OALGPU_VOICE_KERNEL=block, at three and four workgroups per CU).
-The variant is chosen when a context is created (csrc/api.hip reads the environment there)."""
-import os
-
+"""The forms of the HRTF voice kernel against the oracle (same scenes, same tolerances as
+tests/test_gpu_parity.py): the dual-ear FIR on the matrix pipe in split half precision (the default) and as
+packed fp32 VALU FMAs (OALGPU_CTX_FIR_VALU).  The variant is chosen by oalgpu_context_desc::flags."""
 import numpy as np
 import pytest
 
@@ -13,9 +10,8 @@ from scenes import run_scene
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {
-    "wave+mfma": ({"OALGPU_FIR": "mfma"}, "VoiceWaveKernel<17, 64, 0, false, true>"),
-    "block4": ({"OALGPU_VOICE_KERNEL": "block", "OALGPU_BLOCK_WAVES": "4"}, "VoiceBlockKernel"),
-    "block3": ({"OALGPU_VOICE_KERNEL": "block", "OALGPU_BLOCK_WAVES": "3"}, "VoiceBlockKernel"),
+    "wave+mfma-f16x2": (0, "VoiceWaveKernel<17, 64, 0, false, true>"),
+    "wave+valu": (1, "VoiceWaveKernel<17, 64, 0, false>"),
 }
 CASES = [
     dict(fmt=ol.FMT_FLOAT, resampler=ol.RS_BSINC24, steps=[60211], n_updates=4, nvoices=24),
@@ -29,21 +25,7 @@ CASES = [
 ]
 
 
-@pytest.fixture
-def variant_env(request):
-    env, _ = VARIANTS[request.param]
-    old = {k: os.environ.get(k) for k in ("OALGPU_FIR", "OALGPU_VOICE_KERNEL", "OALGPU_BLOCK_WAVES")}
-    for k in old:
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    yield request.param
-    for k, v in old.items():
-        os.environ.pop(k, None)
-        if v is not None:
-            os.environ[k] = v
-
-
-@pytest.mark.parametrize("variant_env", list(VARIANTS), indirect=True)
+@pytest.mark.parametrize("variant_env", list(VARIANTS))
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_variant_matches_the_oracle(variant_env, case, synth_mhr):
     import oalgpu
@@ -54,7 +36,7 @@ def test_variant_matches_the_oracle(variant_env, case, synth_mhr):
     cfg = dict(hrtf=True, **CASES[case])
     names = []
     ref_f, ref_i = run_scene(oracle, synth_mhr, rng_seed=11 + case, **cfg)
-    got_f, got_i = run_scene(oalgpu.Api(oalgpu.MATH_FAST), synth_mhr, rng_seed=11 + case, kernel_names=names, **cfg)
+    got_f, got_i = run_scene(oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=VARIANTS[variant_env][0]), synth_mhr, rng_seed=11 + case, kernel_names=names, **cfg)
     assert names and all(n == VARIANTS[variant_env][1] for n in names), names
     assert got_i == ref_i, "integer voice state differs from the oracle"
     err = float(np.max(np.abs(got_f.astype(np.float64) - ref_f)))

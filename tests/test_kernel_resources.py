@@ -52,28 +52,18 @@ def voice_kernel(tmp_path_factory):
 
 def test_wavefront_voice_kernels_do_not_spill(voice_wave):
     waves = {n: m for n, m in voice_wave.items() if "VoiceWaveKernel" in n}
-    assert len(waves) == 8, sorted(voice_wave)      # 6 packed-VALU variants + the two matrix-pipe FIR ones
+    # 6 packed-VALU variants + the two matrix-pipe FIR ones + the measurement (PROF) builds of the two HRTF forms
+    assert len(waves) == 10, sorted(voice_wave)
     for name, m in waves.items():
         assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
-        assert m["vgpr_count"] <= 256, (name, m)                       # two wavefronts per SIMD
+        assert m["vgpr_count"] + m.get("agpr_count", 0) <= 256, (name, m)   # two wavefronts per SIMD (one unified file)
         assert 2 * m["group_segment_fixed_size"] <= 160 * 1024, (name, m)   # two workgroups per CU
-
-
-def test_workgroup_per_voice_kernel_budgets(tmp_path_factory):
-    """voice_block.hip: the three-workgroups-per-CU build must not touch scratch at all, the
-    four-workgroups-per-CU build (128 VGPRs) at most a few dwords; four workgroups' LDS fit on a CU."""
-    meta = kernel_metadata(tmp_path_factory.mktemp("kres3"), "voice_block.hip", ["-mllvm", "-amdgpu-load-store-vectorizer=0"])
-    b3 = next(m for n, m in meta.items() if "VoiceBlockKernelILi3E" in n)
-    b4 = next(m for n, m in meta.items() if "VoiceBlockKernelILi4E" in n)
-    assert b3["vgpr_spill_count"] == 0 and b3["private_segment_fixed_size"] == 0 and b3["vgpr_count"] <= 168, b3
-    assert b4["vgpr_count"] <= 128 and b4["private_segment_fixed_size"] <= 128, b4
-    assert 4 * b4["group_segment_fixed_size"] <= 160 * 1024, b4
 
 
 def test_reduction_fits_beside_the_hrtf_voice_kernel(voice_wave, voice_kernel):
     reduce4 = next(m for n, m in voice_kernel.items() if "BusReduceKernelILi4E" in n)
     assert reduce4["vgpr_spill_count"] == 0
-    for variant in ("VoiceWaveKernelILi17ELi64ELi0ELb0ELb0E", "VoiceWaveKernelILi17ELi64ELi0ELb0ELb1E"):   # VALU / matrix-pipe FIR
+    for variant in ("VoiceWaveKernelILi17ELi64ELi0ELb0ELb0ELb0E", "VoiceWaveKernelILi17ELi64ELi0ELb0ELb1ELb0E"):   # VALU / matrix-pipe FIR
         voice = next(m for n, m in voice_wave.items() if variant in n)
         # per SIMD lane: one wavefront of each of the two voice workgroups + one of the reduction's four
         assert 2 * granule(voice["vgpr_count"]) + granule(reduce4["vgpr_count"]) <= 512, (voice, reduce4)

@@ -152,12 +152,12 @@ def run(lib, mhr, hrtf, sends, nvoices=16):
 
 
 CASES = {
-    "hrtf fast (wavefront kernel)": dict(hrtf=True, sends=0, exact=False, env={}),
-    "hrtf fast (workgroup kernel)": dict(hrtf=True, sends=0, exact=False, env={"OALGPU_VOICE_KERNEL": "block"}),
-    "hrtf fast + sends (stream rows)": dict(hrtf=True, sends=2, exact=False, env={}),
-    "hrtf exact (generic kernel)": dict(hrtf=True, sends=0, exact=True, env={}),
-    "dry lines fast (stream rows)": dict(hrtf=False, sends=0, exact=False, env={}),
-    "dry lines + sends exact": dict(hrtf=False, sends=2, exact=True, env={}),
+    "hrtf fast (wavefront kernel, matrix-pipe FIR)": dict(hrtf=True, sends=0, exact=False, flags=0),
+    "hrtf fast (wavefront kernel, packed-VALU FIR)": dict(hrtf=True, sends=0, exact=False, flags=1),
+    "hrtf fast + sends (stream rows)": dict(hrtf=True, sends=2, exact=False, flags=0),
+    "hrtf exact (generic kernel)": dict(hrtf=True, sends=0, exact=True, flags=0),
+    "dry lines fast (stream rows)": dict(hrtf=False, sends=0, exact=False, flags=0),
+    "dry lines + sends exact": dict(hrtf=False, sends=2, exact=True, flags=0),
 }
 
 
@@ -169,15 +169,7 @@ def test_streaming_and_compressed_voices_match_the_reference(case, synth_mhr):
     L = _ref()
     cfg = CASES[case]
     want, wi = run(L, synth_mhr, cfg["hrtf"], cfg["sends"])
-    old = {k: os.environ.get(k) for k in cfg["env"]}
-    os.environ.update(cfg["env"])
-    try:
-        got, gi = run(oalgpu.Api(oalgpu.MATH_EXACT if cfg["exact"] else oalgpu.MATH_FAST), synth_mhr, cfg["hrtf"], cfg["sends"])
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
+    got, gi = run(oalgpu.Api(oalgpu.MATH_EXACT if cfg["exact"] else oalgpu.MATH_FAST, ctx_flags=cfg["flags"]), synth_mhr, cfg["hrtf"], cfg["sends"])
     for k in range(len(TODO)):
         assert gi[k] == wi[k], (case, k, [(v, a, b) for v, (a, b) in enumerate(zip(gi[k], wi[k])) if a != b][:4])
         err = np.abs(got[k] - want[k]).max()

@@ -1,7 +1,6 @@
-"""Profiling aid: per-phase s_memtime deltas of the wavefront voice kernel (OALGPU_PHASE_TIMES=1)."""
+"""Profiling aid: per-phase s_memtime deltas of the wavefront voice kernel's measurement variant
+(contexts created with OALGPU_CTX_PROFILE | OALGPU_CTX_SERIAL; add 1 = OALGPU_CTX_FIR_VALU as argv[1])."""
 import os, sys, ctypes as C
-os.environ["OALGPU_PHASE_TIMES"] = "1"
-os.environ.setdefault("OALGPU_SERIAL", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np
@@ -9,7 +8,7 @@ import oalgpu
 from oalgpu import synth
 import bench
 V = 4096
-api = oalgpu.Api(oalgpu.MATH_FAST)
+api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_PROFILE | oalgpu.CTX_SERIAL | (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
 mhr = synth.synth_mhr_bytes(); api._mhr = mhr
 sc, script = bench.build_scene(oalgpu, synth, api, 3, V, 0, mhr, 0)
 allv = list(range(V)); moving = [v for v in allv if script.is_moving(v)]

@@ -1,5 +1,5 @@
 """Profiling aid: per-phase cycle-counter deltas of the reverb kernel's four role wavefronts
-(OALGPU_PHASE_TIMES=1): early = taps, biquad, all-pass, reflect+fence, delay/scatter;
+(oalgpu_reverb_debug_enable_phase_times): early = taps, biquad, all-pass, reflect+fence, delay/scatter;
 late = mod+cubic taps, T60 biquad, wait for early, late-in add, vector all-pass, out+feedback."""
 import ctypes as C
 import os
@@ -7,12 +7,13 @@ import sys
 
 import numpy as np
 
-os.environ["OALGPU_PHASE_TIMES"] = "1"
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "openal-soft_amd"))
 import oalgpu  # noqa: E402
 
 rng = np.random.default_rng(0)
 g = oalgpu.Reverb(4)
+oalgpu.lib.oalgpu_reverb_debug_enable_phase_times.argtypes = [C.c_void_p]
+assert oalgpu.lib.oalgpu_reverb_debug_enable_phase_times(g.h) == 0
 g.update(oalgpu.ReverbProps.make(modulation_depth=0.5))
 x = (rng.standard_normal((4, 1024)) * 0.1).astype(np.float32)
 o = np.zeros((4, 1024), np.float32)
