@@ -569,6 +569,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             }
 
             stamp(2);
+            // (matrix-pipe FIR: the next voice's request leaves now -- the FIR is too short to cover it, the
+            // build of its inputs in front of it makes up for that)
+            if constexpr (MF) requestNext();
             if constexpr (NL == 0)
             {
             // ---- DoHrtfMix, voice.cpp:827-902
@@ -714,9 +717,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
 
         // ---------------- the next voice's source window leaves HBM now ----------------
-        // NL == 0: before the FIR, whose ~1100 packed FMAs cover the latency.  NL > 0 (no FIR in
-        // this kernel): right after the resampler, ahead of the filters and the stream-row stores.
-        if constexpr (NL > 0) { if(!active) requestNext(); }
+        // NL == 0: before the FIR, whose ~1100 packed FMAs cover the latency (matrix-pipe FIR: before the build
+        // of its inputs, above).  NL > 0 (no FIR in this kernel): right after the resampler, ahead of the
+        // filters and the stream-row stores.
+        if constexpr (NL > 0 || MF) { if(!active) requestNext(); }
         else requestNext();
 
         if(first)
@@ -727,7 +731,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             const uint32_t gBegin = group * kWWaves * vpw;
             const int kK = headK.rsKind;
             const uint32_t mK = kK == 2 ? 4u : headK.rsM, lK = kK == 2 ? 1u : headK.rsL;
-            const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24 || mK == 48)))
+            constexpr uint32_t kMaxM = 2u * uint32_t(WgLds<R, TAPS, MF>::kPairs);
+            const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24 || mK == 48) && mK <= kMaxM))
                 && (headK.playState == OALGPU_VOICE_PLAYING || headK.playState == OALGPU_VOICE_STOPPING);
             uint32_t key = headK.rsFilterOffset * 8u + uint32_t(kK), m = mK;
             if(eligK) { if(t == 0) { sm.tabKey = key; sm.tabM = mK; sm.tabL = lK; } }
@@ -744,7 +749,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     const VoiceCtl &c = L.ctl[cand];
                     kind = c.rsKind; off = c.rsFilterOffset; m = c.rsM; l = c.rsL;
                     if(kind == 2) { m = 4; l = 1; }
-                    eligible = (kind == 2 || (kind == 3 && (m == 12 || m == 24 || m == 48)))
+                    eligible = (kind == 2 || (kind == 3 && (m == 12 || m == 24 || m == 48) && m <= kMaxM))
                         && (c.playState == OALGPU_VOICE_PLAYING || c.playState == OALGPU_VOICE_STOPPING);
                 }
                 const unsigned long long mask = __ballot(eligible);
@@ -838,9 +843,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 w.in[lane] = histN;
                 if constexpr (MF)
                 {   // the response, tap = lane, as r[80 - lane] (FirMfmaH)
-                    const uint32_t ux = __builtin_bit_cast(uint32_t, hN.x) & 0x7fffffffu, uy = __builtin_bit_cast(uint32_t, hN.y) & 0x7fffffffu;
                     float sh;
-                    HalfScale(WaveMaxBits(ux > uy ? ux : uy), sh, invH);
+                    HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, __builtin_fmaxf(__builtin_fabsf(hN.x), __builtin_fabsf(hN.y)))), sh, invH);
                     uint32_t hi, lo;
                     SplitHalf2(hN.x * sh, hN.y * sh, hi, lo);       // (left, right) leading halves / remainders
                     uint16_t *hz = reinterpret_cast<uint16_t*>(&w.hr[0][0][0]);
@@ -944,20 +948,24 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     if constexpr (NL > 0) { mixRows(); return; }
     // ---- one partial per workgroup: waves dump their accumulators, then a fixed-order sum
     {
-        f2 *dump = w.x2;                     // [frame] = (L, R), frames < 64R
+        // [frame] = (L, R), frames < 64R (the matrix-pipe kernels: 17 entries per 16 frames, in the place of xh)
+        auto dumpOf = [&](int ww) { return MF ? reinterpret_cast<f2*>(&sm.w[ww].xh[0][0][0]) : sm.w[ww].x2; };
+        static_assert(!MF || sizeof(w.xh) >= (WL::kFrames + WL::kFrames / 16) * sizeof(f2), "the padded dump fits in xh");
+        f2 *dump = dumpOf(int(wave));
         WaveSync();
         if constexpr (MF)
-        {   // FirMfmaH's tiles -> frames
+        {   // FirMfmaH's tiles -> frames; frame f at dump[f + f / 16]: lanes of one column then are 17 entries
+            // (34 banks) apart instead of 16 (all on the same two banks)
             const uint32_t jc = lane0 & 15u, q4 = lane0 >> 4;
 #pragma unroll
             for(int T = 0; T < 4; ++T)
 #pragma unroll
                 for(int r = 0; r < 4; ++r)
-                    dump[16u * (16u * uint32_t(T) + jc) + 4u * q4 + uint32_t(r)] = f2{accM[0][T][r], accM[1][T][r]};
+                    dump[17u * (16u * uint32_t(T) + jc) + 4u * q4 + uint32_t(r)] = f2{accM[0][T][r], accM[1][T][r]};
             if(jc < 4u)
             {
 #pragma unroll
-                for(int r = 0; r < 4; ++r) dump[1024u + 16u * jc + 4u * q4 + uint32_t(r)] = f2{accM[0][4][r], accM[1][4][r]};
+                for(int r = 0; r < 4; ++r) dump[17u * (64u + jc) + 4u * q4 + uint32_t(r)] = f2{accM[0][4][r], accM[1][4][r]};
             }
         }
         else
@@ -966,11 +974,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         for(int r = 0; r < R; ++r) dump[R * lane0 + r] = acc[r];
         }
         WaveSync();
+        auto dumpAt = [](uint32_t f) { return MF ? f + (f >> 4) : f; };
 #pragma unroll
         for(int q = 0; q < WL::kQ; ++q)
         {
-            const f2 cur = dump[lane0 + 64 * q];
-            dump[lane0 + 64 * q] = f2{cur.x + accO[q].x, cur.y + accO[q].y};
+            const f2 cur = dump[dumpAt(lane0 + 64 * q)];
+            dump[dumpAt(lane0 + 64 * q)] = f2{cur.x + accO[q].x, cur.y + accO[q].y};
         }
         __syncthreads();
         f2 *ph = reinterpret_cast<f2*>(L.partHrtf) + size_t{group} * (kLine + kHrirLen);
@@ -979,9 +988,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             f2 s = {0.0f, 0.0f};
             if(k < uint32_t(WL::kFrames))
             {
-                s = sm.w[0].x2[k];
+                s = dumpOf(0)[dumpAt(k)];
 #pragma unroll
-                for(int ww = 1; ww < kWWaves; ++ww) { const f2 o = sm.w[ww].x2[k]; s.x += o.x; s.y += o.y; }
+                for(int ww = 1; ww < kWWaves; ++ww) { const f2 o = dumpOf(ww)[dumpAt(k)]; s.x += o.x; s.y += o.y; }
             }
             ph[k] = s;
         }

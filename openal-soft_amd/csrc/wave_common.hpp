@@ -12,7 +12,7 @@ namespace {
 
 constexpr int kWWaves = 4;                    // wavefronts (= concurrent voices) per workgroup
 constexpr int kWThreads = kWWaves * 64;
-constexpr int kTabPairs = 24;                 // staged resampler rows: up to 48 taps
+constexpr int kTabPairs = 24;                 // staged resampler rows: up to 48 taps (matrix-pipe kernels: 12, see WgLds)
 
 constexpr int kPre = 17;                      // prefetched source samples per lane (17*64 = 1088)
 
@@ -89,9 +89,13 @@ struct alignas(16) WaveLds {
 
 template<int R, int TAPS, bool MF = false>
 struct WgLds {
+    // The matrix-pipe kernels stage rows of up to 24 taps only (bsinc48 voices take the unstaged path there):
+    // with 48-tap rows their workgroup would not leave room on a CU for the post-stream reduction beside two
+    // of them (LDS is allocated in granules of 1280 bytes: 2 x 62 + 4 granules = 160 KB).
+    static constexpr int kPairs = MF ? 12 : kTabPairs;
     WaveLds<R, TAPS, MF> w[kWWaves];
-    f2 tabF[kTabPairs * 32];                            // [tap pair][phase] = fil[2p], fil[2p+1]
-    f2 tabP[kTabPairs * 32];                            //                    = phd[2p], phd[2p+1]
+    f2 tabF[kPairs * 32];                               // [tap pair][phase] = fil[2p], fil[2p+1]
+    f2 tabP[kPairs * 32];                               //                    = phd[2p], phd[2p+1]
     uint32_t tabKey, tabM, tabL;
     uint32_t pad;
 };

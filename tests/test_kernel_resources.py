@@ -67,4 +67,5 @@ def test_reduction_fits_beside_the_hrtf_voice_kernel(voice_wave, voice_kernel):
         voice = next(m for n, m in voice_wave.items() if variant in n)
         # per SIMD lane: one wavefront of each of the two voice workgroups + one of the reduction's four
         assert 2 * granule(voice["vgpr_count"]) + granule(reduce4["vgpr_count"]) <= 512, (voice, reduce4)
-        assert 2 * voice["group_segment_fixed_size"] + reduce4["group_segment_fixed_size"] <= 160 * 1024
+        # LDS is allocated in granules of 1280 bytes on gfx950
+        assert 2 * granule(voice["group_segment_fixed_size"], 1280) + granule(reduce4["group_segment_fixed_size"], 1280) <= 160 * 1024
