@@ -741,6 +741,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.numLineGroups = L.numGroups;
     L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0; L.streamsPerVoice = 0;
     L.nfc = nullptr; L.nfcOrders = 0;
+    L.hrirs = nullptr;
     for(uint32_t &n : L.chansPerOrder) n = 0;
     if(c->useWave && (!L.hrtf || L.numSends))
     {   // stream rows, mixed onto the lines by the voice kernel's tail: one partial bus per workgroup
@@ -820,6 +821,7 @@ int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
     c->hrtfLoaded = true;
 
     DeviceLayout &L = c->L;
+    L.hrirs = c->hCoeffs.p;
     L.irSize = h.irSize;
     L.irStride = (h.irSize + 15u) & ~15u;
     if(L.hrtf)
@@ -1100,6 +1102,16 @@ static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oa
 {
     const TableBlob &blob = Blob();
     recs.resize(count);
+    HrtfStoreDev hostStore{};
+    if(c->L.hrtf && c->hrtfLoaded)
+    {
+        const HrtfData &h = c->hrtfHost;
+        hostStore.irSize = h.irSize; hostStore.numFields = uint32_t(h.fieldDistance.size());
+        hostStore.numElevs = uint32_t(h.elevAzCount.size()); hostStore.numIrs = h.numIrs();
+        hostStore.fieldDistance = h.fieldDistance.data(); hostStore.fieldEvCount = h.fieldEvCount.data();
+        hostStore.elevAzCount = h.elevAzCount.data(); hostStore.elevIrOffset = h.elevIrOffset.data();
+        hostStore.coeffs = h.coeffs.data(); hostStore.delays = h.delays.data();
+    }
     for(size_t i = 0; i < count; ++i)
     {
         const oalgpu_voice_params &p = params[i];
@@ -1129,6 +1141,13 @@ static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oa
         }
         r.hrtfDir[0] = p.hrtf_ev; r.hrtfDir[1] = p.hrtf_az; r.hrtfDir[2] = p.hrtf_dist; r.hrtfDir[3] = p.hrtf_spread;
         r.hrtfGain = p.hrtf_gain;
+        if(c->L.hrtf && c->hrtfLoaded)
+        {   // the index half of HrtfStore::getCoeffs (core/hrtf.cpp:192-245) on the host's copy of the store
+            const HrirBlend b = HrtfBlendFor(hostStore, p.hrtf_ev, p.hrtf_az, p.hrtf_dist, p.hrtf_spread);
+            for(int k = 0; k < 4; ++k) { r.hrtfIdx[k] = b.idx[k]; r.hrtfW[k] = b.w[k]; }
+            r.hrtfPass = b.passthru;
+            r.hrtfDelay[0] = b.delay[0]; r.hrtfDelay[1] = b.delay[1];
+        }
         std::memcpy(r.dryGains, p.dry_gains, sizeof(r.dryGains));
     }
     return OALGPU_OK;
@@ -1145,7 +1164,7 @@ int oalgpu_voice_set_params(oalgpu_context *c, const uint32_t *voices, const oal
     NoteCallbackSteps(c, voices, params, count);
     if(c->paramDev.n < count) HIP_TRY(c->paramDev.alloc(count));
     HIP_TRY(hipMemcpyAsync(c->paramDev.p, c->paramHost.data(), count * sizeof(ParamRecord), hipMemcpyHostToDevice, c->stream));
-    LaunchApplyParams(c->stream, c->L, c->hrtfDev, c->paramDev.p, uint32_t(count));
+    LaunchApplyParams(c->stream, c->L, c->paramDev.p, uint32_t(count));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));   // paramHost is reused by the next call
     return OALGPU_OK;
@@ -1183,7 +1202,7 @@ int oalgpu_param_block_apply(oalgpu_context *c, oalgpu_param_block *b)
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
-    LaunchApplyParams(c->stream, c->L, c->hrtfDev, b->recs.p, b->count);
+    LaunchApplyParams(c->stream, c->L, b->recs.p, b->count);
     HIP_TRY(hipGetLastError());
     for(const auto &vs : b->cbSteps)
         if(vs.first < c->cbOfVoice.size() && c->cbOfVoice[vs.first] >= 0) c->cbVoices[size_t(c->cbOfVoice[vs.first])].step = vs.second;
@@ -1659,7 +1678,7 @@ int oalgpu_update_graph_create(oalgpu_context *c, oalgpu_param_block *const *par
         if(L.streams) L.partLines = c->partLinesBuf[p];
         if(param_blocks && param_blocks[i])
         {
-            LaunchApplyParams(c->stream, L0, c->hrtfDev, param_blocks[i]->recs.p, param_blocks[i]->count);
+            LaunchApplyParams(c->stream, L0, param_blocks[i]->recs.p, param_blocks[i]->count);
             ok(hipGetLastError());
         }
         // this update's partial buses were last read by the reduction of two updates ago (the first two

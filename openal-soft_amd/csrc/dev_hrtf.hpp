@@ -61,7 +61,7 @@ struct HrtfStoreDev {
 
 struct HrirBlend { uint32_t idx[4]; float w[4]; float passthru; uint32_t delay[2]; };
 
-__device__ __forceinline__ HrirBlend HrtfBlendFor(const HrtfStoreDev &st, float elevation, float azimuth,
+__host__ __device__ __forceinline__ HrirBlend HrtfBlendFor(const HrtfStoreDev &st, float elevation, float azimuth,
     float distance, float spread)
 {
     constexpr float invPi = 0.318309886183790671538f;

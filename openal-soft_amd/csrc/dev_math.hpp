@@ -36,10 +36,11 @@ __device__ __forceinline__ float madd(float a, float b, float c)
 
 __device__ __forceinline__ float lerpf(float a, float b, float mu) { return a + (b - a) * mu; }
 
-// float2uint, common/alnumeric.h:223-240: truncation with clamping.
-__device__ __forceinline__ uint32_t float2uint(float f)
+// float2uint, common/alnumeric.h:223-240: truncation with clamping.  (Host-callable: the host evaluates
+// HrtfStore::getCoeffs' index arithmetic for parameter blocks with the very same operations.)
+__host__ __device__ __forceinline__ uint32_t float2uint(float f)
 {
-    const int32_t bits = __float_as_int(f);
+    const int32_t bits = __builtin_bit_cast(int32_t, f);
     const uint32_t keep = static_cast<uint32_t>(bits >> 31) ^ 0xffffffffu;
     const int shift = ((bits >> 23) & 0xff) - (127 + 23);
     if(shift < -23) return 0u;
@@ -49,6 +50,13 @@ __device__ __forceinline__ uint32_t float2uint(float f)
 }
 
 // fastf2u, common/alnumeric.h:163-189: cvtss2si = round to nearest even.
-__device__ __forceinline__ uint32_t fastf2u(float f) { return static_cast<uint32_t>(__float2int_rn(f)); }
+__host__ __device__ __forceinline__ uint32_t fastf2u(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<uint32_t>(__float2int_rn(f));
+#else
+    return static_cast<uint32_t>(static_cast<int32_t>(__builtin_lrintf(f)));    // the default rounding mode: to nearest even
+#endif
+}
 
 } // namespace oalgpu

@@ -77,6 +77,32 @@ static_assert(sizeof(BiquadSlot) == 64, "BiquadSlot");
 // ramp).  live == 0: nothing to mix from this row in this update.
 __host__ __device__ inline uint32_t LineBlockDwords(uint32_t lineStride) { return 3u * lineStride + 8u; }
 
+// Parameter block applied on the GPU by ApplyParamsKernel (one per changed voice).
+struct ParamRecord {
+    uint32_t voice;
+    uint32_t step;
+    int32_t rsKind;
+    uint32_t rsM, rsL;
+    float rsSf;
+    uint32_t rsFilterOffset;
+    uint32_t flags;                 // kFlagDirectFilter | send filter bits
+    int32_t sendSlot[6];
+    float dirLp[5], dirHp[5];       // designed biquad coefficients (host libm)
+    float sendLp[6][5], sendHp[6][5];
+    float hrtfDir[4];               // elevation, azimuth, distance, spread
+    float hrtfGain;
+    float dryGains[32];
+    float sendGains[6][25];
+    // HrtfStore::getCoeffs' index half (core/hrtf.cpp:192-245), evaluated by the host when the record is built
+    // (HrtfBlendFor, the same operations as on the device): the four HRIRs, their weights, the pass-through
+    // tap and the blended delays -- what is left for the GPU is one round of loads and the weighted sum
+    uint32_t hrtfIdx[4];
+    float hrtfW[4];
+    float hrtfPass;
+    uint32_t hrtfDelay[2];
+    uint32_t pad;
+};
+
 struct DeviceLayout {
     // configuration
     uint32_t numVoices, numDry, numReal, numSends, numSlots, wetChannels;
@@ -114,6 +140,7 @@ struct DeviceLayout {
     uint32_t streamsPerVoice;               // stream rows per voice: 2 + numSends (see voice_wave.hip)
     // final bus block: [(numDry+numReal) x 1024 | numSlots*wetChannels x 1024 | 1152 x 2]
     float *bus;
+    const float *hrirs;                     // HrtfStoreDev::coeffs: the store's HRIRs (ApplyRecordWave)
 };
 
 __host__ __device__ inline size_t BusWetOffset(const DeviceLayout &L) { return size_t{L.numDry + L.numReal} * kLine; }
@@ -122,23 +149,54 @@ __host__ __device__ inline size_t BusAccumOffset(const DeviceLayout &L)
 __host__ __device__ inline size_t BusFloats(const DeviceLayout &L)
 { return BusAccumOffset(L) + size_t{kLine + kHrirLen} * 2; }
 
-// Parameter block applied on the GPU by ApplyParamsKernel (one per changed voice).
-struct ParamRecord {
-    uint32_t voice;
-    uint32_t step;
-    int32_t rsKind;
-    uint32_t rsM, rsL;
-    float rsSf;
-    uint32_t rsFilterOffset;
-    uint32_t flags;                 // kFlagDirectFilter | send filter bits
-    int32_t sendSlot[6];
-    float dirLp[5], dirHp[5];       // designed biquad coefficients (host libm)
-    float sendLp[6][5], sendHp[6][5];
-    float hrtfDir[4];               // elevation, azimuth, distance, spread
-    float hrtfGain;
-    float dryGains[32];
-    float sendGains[6][25];
-};
+// One parameter record applied by one wavefront (ApplyParamsKernel): the CalcVoiceParams results scattered into
+// the voice arrays, the weighted sum of HrtfStore::getCoeffs (core/hrtf.cpp:247-259) and the
+// BiquadInterpFilter::setParams state machine (biquad.cpp:131-149).
+__device__ __forceinline__ void ApplyRecordWave(const DeviceLayout &L, const ParamRecord &r, uint32_t lane)
+{
+    const uint32_t v = r.voice;
+    VoiceCtl &ctl = L.ctl[v];
+    if(lane == 0)
+    {
+        ctl.step = r.step;
+        ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
+        ctl.rsFilterOffset = r.rsFilterOffset;
+        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue);
+        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue))
+            | (L.hrtf ? (kFlagHasHrtf | kFlagHrtfDirty) : 0u);
+        for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
+        if(L.hrtf)
+        {
+            ctl.hrtfTgtDelay[0] = r.hrtfDelay[0]; ctl.hrtfTgtDelay[1] = r.hrtfDelay[1];
+            ctl.hrtfTgtGain = r.hrtfGain;
+        }
+    }
+    if(lane == 1) BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
+    if(lane == 2) BiquadSetTarget(L.dfilt[size_t{v} * 2 + 1].f, r.dirHp);
+    if(lane >= 8 && lane < 8 + 2 * L.numSends)
+    {
+        const uint32_t i = (lane - 8) >> 1, hp = (lane - 8) & 1u;
+        BiquadSetTarget(L.sfilt[(size_t{v} * L.numSends + i) * 2 + hp].f, hp ? r.sendHp[i] : r.sendLp[i]);
+    }
+    if(L.hrtf)
+    {
+        const uint32_t i0 = r.hrtfIdx[0], i1 = r.hrtfIdx[1], i2 = r.hrtfIdx[2], i3 = r.hrtfIdx[3];
+        const float w0 = r.hrtfW[0], w1 = r.hrtfW[1], w2 = r.hrtfW[2], w3 = r.hrtfW[3], pass = r.hrtfPass;
+        for(uint32_t e = lane; e < L.irStride * 2; e += 64)
+        {   // hrtf.cpp:247-259: the pass-through tap (elements 0, 1) or 0, then the four weighted HRIRs in order
+            float x = (e < 2) ? pass : 0.0f;
+            x = L.hrirs[size_t{i0} * (kHrirLen * 2) + e] * w0 + x;
+            x = L.hrirs[size_t{i1} * (kHrirLen * 2) + e] * w1 + x;
+            x = L.hrirs[size_t{i2} * (kHrirLen * 2) + e] * w2 + x;
+            x = L.hrirs[size_t{i3} * (kHrirLen * 2) + e] * w3 + x;
+            L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = x;
+        }
+    }
+    else if(lane < L.numDry)
+        L.gainTgt[size_t{v} * L.numDry + lane] = r.dryGains[lane];
+    for(uint32_t k = lane; k < L.numSends * L.wetChannels; k += 64)
+        L.sendTgt[size_t{v} * L.numSends * L.wetChannels + k] = r.sendGains[k / L.wetChannels][k % L.wetChannels];
+}
 
 struct VoiceInitRecord { uint32_t voice; int32_t buffer, looping, position; uint32_t positionFrac; int32_t queue; };
 
@@ -260,8 +318,7 @@ void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
 
 // ---- launchers (voice_kernel.hip) ----
 void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);
-void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev &st, const ParamRecord *recs,
-    uint32_t count);
+void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count);
 // returns hipSuccess or the launch error
 hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum);
 // besideVoiceKernel: the post-stream shape (4-wave workgroups of <= 32 VGPRs that fit on a CU next to

@@ -48,45 +48,9 @@ struct alignas(16) SharedMem {
 // ---------------------------------------------------------------------------------------------
 // Parameter side
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ApplyParamsKernel(DeviceLayout L, HrtfStoreDev st, const ParamRecord *__restrict__ recs)
+__global__ void __launch_bounds__(64) ApplyParamsKernel(DeviceLayout L, const ParamRecord *__restrict__ recs)
 {
-    const ParamRecord &r = recs[blockIdx.x];
-    const uint32_t v = r.voice;
-    const uint32_t t = threadIdx.x;
-    VoiceCtl &ctl = L.ctl[v];
-    if(t == 0)
-    {
-        ctl.step = r.step;
-        ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
-        ctl.rsFilterOffset = r.rsFilterOffset;
-        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue);
-        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue))
-            | (L.hrtf ? (kFlagHasHrtf | kFlagHrtfDirty) : 0u);
-        for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
-        BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
-        BiquadSetTarget(L.dfilt[size_t{v} * 2 + 1].f, r.dirHp);
-    }
-    if(t >= 64 && t < 64 + L.numSends)
-    {
-        const uint32_t i = t - 64;
-        BiquadSetTarget(L.sfilt[(size_t{v} * L.numSends + i) * 2 + 0].f, r.sendLp[i]);
-        BiquadSetTarget(L.sfilt[(size_t{v} * L.numSends + i) * 2 + 1].f, r.sendHp[i]);
-    }
-    if(L.hrtf)
-    {
-        const HrirBlend b = HrtfBlendFor(st, r.hrtfDir[0], r.hrtfDir[1], r.hrtfDir[2], r.hrtfDir[3]);
-        if(t < L.irStride * 2)
-            L.hrtfTgt[size_t{v} * L.irStride * 2 + t] = HrtfBlendElement(st, b, t);
-        if(t == 0)
-        {
-            ctl.hrtfTgtDelay[0] = b.delay[0]; ctl.hrtfTgtDelay[1] = b.delay[1];
-            ctl.hrtfTgtGain = r.hrtfGain;
-        }
-    }
-    else if(t < L.numDry)
-        L.gainTgt[size_t{v} * L.numDry + t] = r.dryGains[t];
-    for(uint32_t k = t; k < L.numSends * L.wetChannels; k += blockDim.x)
-        L.sendTgt[size_t{v} * L.numSends * L.wetChannels + k] = r.sendGains[k / L.wetChannels][k % L.wetChannels];
+    ApplyRecordWave(L, recs[blockIdx.x], threadIdx.x);
 }
 
 // VoiceFlag::IsAmbisonic + the channel's splitter and scales (Voice::prepare, voice.cpp:1353-1380)
@@ -190,9 +154,9 @@ void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecor
     if(count) hipLaunchKernelGGL(InitVoicesKernel, dim3(count), dim3(64), 0, s, L, recs);
 }
 
-void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev &st, const ParamRecord *recs, uint32_t count)
+void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count)
 {
-    if(count) hipLaunchKernelGGL(ApplyParamsKernel, dim3(count), dim3(256), 0, s, L, st, recs);
+    if(count) hipLaunchKernelGGL(ApplyParamsKernel, dim3(count), dim3(64), 0, s, L, recs);
 }
 
 // ---------------------------------------------------------------------------------------------
