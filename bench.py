@@ -41,9 +41,10 @@ BYTES_PER_VOICE_UPDATE = {3: 3956 + 384 + 16 + 512 + 512, 2: 3956 + 384 + 16 + 2
                           4: 3956 + 384 + 16 + 3 * 4 * 5 + 2 * 3 * 4 * 4, 5: 3956 + 384 + 16 + 512 + 512 + 3 * 4 * 4}
 
 
-def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, vpg, num_real=None):
+def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, vpg, num_real=None, voice_map=None):
     """num_real: real output lines of a non-HRTF context (8 = a 7.1 device: the dry lines are then decoded
-    to speaker feeds by the reference's X71 decoder in the post-process); None = no output stage."""
+    to speaker feeds by the reference's X71 decoder in the post-process); None = no output stage.
+    voice_map: the global voice index of every local voice (a shard dealt by cost class) instead of voice_base."""
     hrtf = config_id in (3, 5)
     nsends = {4: 4, 5: 1}.get(config_id, 0)
     if num_real is None:
@@ -71,9 +72,9 @@ def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, v
         cc = np.zeros((4, 128, 2), np.float32)
         cc[:, :64] = rng.uniform(-0.2, 0.2, (4, 64, 2)) * np.exp(-np.arange(64) / 12.0)[None, :, None]
         sc.set_direct_hrtf(cc, [1.0, 0.8, 0.8, 0.8], 400.0 / 48000.0, 64)
-    bufs = synth.scene_buffers(config_id, nvoices)
+    bufs = synth.scene_buffers(config_id, nvoices if voice_map is None else 256)
     handles = [sc.add_buffer(b, oalgpu.FMT_FLOAT) for b in bufs]
-    script = synth.SceneScript(config_id, nvoices, voice_base)
+    script = synth.SceneScript(config_id, nvoices, voice_base, voice_map)
     for v in range(nvoices):
         sc.add_voice(handles[script.buffer_of(v, len(handles))], True, position=script.start_position(v))
     return sc, script

@@ -432,6 +432,12 @@ int oalgpu_set_carry_accum(oalgpu_context *ctx, int enable);
  * calls these needs no RCCL.  `size` is the size of the id buffer (>= 128). */
 int oalgpu_comm_unique_id(void *unique_id, size_t size);
 int oalgpu_comm_init(oalgpu_context *ctx, const void *unique_id, size_t size, int rank, int world);
+/* The same exchange over the library's second transport, host-staged: every rank's bus block goes through pinned
+ * memory into a shared-memory ring (`name`: a POSIX shared-memory object name, "/...", the same on every rank;
+ * rank 0 creates it) and rank 0's stream sums the blocks in rank order -- all in stream order, nothing synchronises
+ * with the host.  For ranks RCCL cannot connect: several processes sharing ONE GPU.  Everything else of a sharded
+ * update (which rank runs effects and post-process, which carries the accumulator) is the same code as with RCCL. */
+int oalgpu_comm_init_host(oalgpu_context *ctx, const char *name, int rank, int world);
 int oalgpu_comm_destroy(oalgpu_context *ctx);
 
 /* Mixing state of one voice after the last update (the fields Voice::mix mutates). */

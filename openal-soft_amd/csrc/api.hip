@@ -7,8 +7,16 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and enums only: the library itself is resolved with dlopen/dlsym
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <functional>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -132,9 +140,9 @@ struct oalgpu_context {
     DevBuf<AmbiMapEntry> dryMap, wetMaps;   // MixParams::AmbiMap of the dry bus / of every slot's wet bus
     DevBuf<PanRecord> panRecs;
     bool serialOnly{false};                // OALGPU_CTX_SERIAL: no two-stream pipeline
-    // multi-GPU (oalgpu_comm_init): this rank's RCCL communicator; the bus block is sum-reduced to rank 0
+    // multi-GPU (oalgpu_comm_init / oalgpu_comm_init_host): how this rank's bus block gets summed into rank 0's,
     // right behind the partial-bus reduction, on the stream that runs it
-    void *comm{nullptr};
+    struct BusTransport *comm{nullptr};
     int commRank{0}, commWorld{1};
     // the stage behind the buses (output_kernels.hip): AmbiDecPostProcess of non-HRTF contexts, dither, PCM
     bool decOn{false}, decDual{false};
@@ -268,15 +276,132 @@ int FailRccl(const char *what, ncclResult_t r)
     return Fail(OALGPU_ERR_HIP, std::string(what) + ": " + (a.getErrorString ? a.getErrorString(r) : "RCCL error"));
 }
 
+} // namespace
+
 // The one exchange of a sharded update: the bus block [dry + real lines | wet buses |
-// HrtfAccumData] of every rank is summed into rank 0's, in place, on the stream that just produced it.
+// HrtfAccumData] of every rank is summed into rank 0's, in place, on the stream that just produced it.  Two
+// transports behind one interface: RCCL (ncclReduce over xGMI, one process per GPU) and a host-staged one
+// (every rank's block through pinned memory into a shared-memory ring, summed by rank 0's stream in rank order)
+// for ranks that RCCL cannot serve -- several processes on ONE GPU, which is how the N > 1 code of this library
+// is exercised on a one-GPU box (tests/test_multi_rank.py).
+struct BusTransport {
+    virtual ~BusTransport() = default;
+    virtual int reduceToRoot(oalgpu_context *c, hipStream_t s) = 0;
+};
+
+namespace {
+
+struct RcclTransport final : BusTransport {
+    ncclComm_t comm{nullptr};
+    ~RcclTransport() override { if(comm) (void)Rccl().commDestroy(comm); }
+    int reduceToRoot(oalgpu_context *c, hipStream_t s) override
+    {
+        const ncclResult_t r = Rccl().reduce(c->L.bus, c->L.bus, BusFloats(c->L), ncclFloat32, ncclSum, 0, comm, s);
+        if(r != ncclSuccess) return FailRccl("ncclReduce", r);
+        return OALGPU_OK;
+    }
+};
+
+__global__ void AddBusKernel(float *__restrict__ bus, const float *__restrict__ add, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n) bus[i] = bus[i] + add[i];
+}
+
+// Shared-memory ring: kSlots updates deep, so that ranks may run that far ahead of rank 0 (the pipelined update
+// never synchronises with the host).  produced[r] = updates of rank r whose block is in the ring; consumed =
+// updates rank 0 has summed.  Host functions in stream order (hipLaunchHostFunc) move the data; they only touch
+// host memory.
+struct HostTransport final : BusTransport {
+    static constexpr uint32_t kSlots = 4, kMaxWorld = 16;
+    struct Header {
+        std::atomic<uint32_t> magic;
+        uint32_t world, floats;
+        std::atomic<uint64_t> produced[kMaxWorld];
+        std::atomic<uint64_t> consumed;
+        std::atomic<uint32_t> failed;
+    };
+    std::string name;
+    int fd{-1}, rank{0}, world{1};
+    size_t bytes{0}, floats{0};
+    Header *hdr{nullptr};
+    float *ring{nullptr};                          // [rank][slot][floats]
+    float *pinned[kSlots]{};                       // this rank's staging: D2H target (rank > 0), H2D source (rank 0)
+    DevBuf<float> devSum;                          // rank 0: the other ranks' sum on the device
+    uint64_t seq{0};
+    struct Job { HostTransport *t; uint64_t seq; };
+    Job jobs[kSlots]{};
+
+    float *slot(int r, uint64_t q) const { return ring + (size_t(r) * kSlots + size_t(q % kSlots)) * floats; }
+
+    static bool WaitFor(const std::function<bool()> &ok, std::atomic<uint32_t> &failed)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for(uint32_t spins = 0; !ok(); ++spins)
+        {
+            if(failed.load(std::memory_order_relaxed)) return false;
+            if(spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+            { failed.store(1u); return false; }
+        }
+        return true;
+    }
+    static void Produce(void *p)
+    {   // rank > 0: this update's block (already in pinned memory) into the ring
+        Job *j = static_cast<Job*>(p);
+        HostTransport *t = j->t;
+        const uint64_t q = j->seq;
+        if(!WaitFor([&] { return q < t->hdr->consumed.load(std::memory_order_acquire) + kSlots; }, t->hdr->failed)) return;
+        std::memcpy(t->slot(t->rank, q), t->pinned[q % kSlots], t->floats * sizeof(float));
+        t->hdr->produced[t->rank].store(q + 1, std::memory_order_release);
+    }
+    static void Gather(void *p)
+    {   // rank 0: the other ranks' blocks of this update, summed in rank order
+        Job *j = static_cast<Job*>(p);
+        HostTransport *t = j->t;
+        const uint64_t q = j->seq;
+        float *dst = t->pinned[q % kSlots];
+        for(int r = 1; r < t->world; ++r)
+        {
+            if(!WaitFor([&] { return t->hdr->produced[r].load(std::memory_order_acquire) > q; }, t->hdr->failed))
+            { std::memset(dst, 0, t->floats * sizeof(float)); return; }
+            const float *src = t->slot(r, q);
+            if(r == 1) std::memcpy(dst, src, t->floats * sizeof(float));
+            else for(size_t i = 0; i < t->floats; ++i) dst[i] += src[i];
+        }
+        t->hdr->consumed.store(q + 1, std::memory_order_release);
+    }
+    int reduceToRoot(oalgpu_context *c, hipStream_t s) override
+    {
+        if(hdr->failed.load()) return Fail(OALGPU_ERR_HIP, "host transport: a rank timed out waiting for its peers");
+        const uint64_t q = seq++;
+        jobs[q % kSlots] = Job{this, q};
+        if(rank != 0)
+        {
+            HIP_TRY(hipMemcpyAsync(pinned[q % kSlots], c->L.bus, bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipLaunchHostFunc(s, Produce, &jobs[q % kSlots]));
+            return OALGPU_OK;
+        }
+        if(world == 1) return OALGPU_OK;
+        HIP_TRY(hipLaunchHostFunc(s, Gather, &jobs[q % kSlots]));
+        HIP_TRY(hipMemcpyAsync(devSum.p, pinned[q % kSlots], bytes, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(AddBusKernel, dim3(uint32_t((floats + 255) / 256)), dim3(256), 0, s, c->L.bus, devSum.p, uint32_t(floats));
+        HIP_TRY(hipGetLastError());
+        return OALGPU_OK;
+    }
+    ~HostTransport() override
+    {
+        for(float *p : pinned) if(p) (void)hipHostFree(p);
+        if(hdr) munmap(hdr, sizeof(Header) + size_t(world) * kSlots * bytes);
+        if(fd >= 0) close(fd);
+        if(rank == 0 && !name.empty()) shm_unlink(name.c_str());
+    }
+};
+
 int CommReduceBus(oalgpu_context *c, hipStream_t s)
 {
     if(!c->comm) return OALGPU_OK;
-    const ncclResult_t r = Rccl().reduce(c->L.bus, c->L.bus, BusFloats(c->L), ncclFloat32, ncclSum, 0,
-        static_cast<ncclComm_t>(c->comm), s);
-    if(r != ncclSuccess) return FailRccl("ncclReduce", r);
-    return OALGPU_OK;
+    return c->comm->reduceToRoot(c, s);
 }
 
 } // namespace
@@ -307,17 +432,73 @@ int oalgpu_comm_init(oalgpu_context *c, const void *unique_id, size_t size, int 
     if(!c || !unique_id || size < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init: bad arguments");
     if(c->comm) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init: the context already has a communicator");
+    if(!c->cbVoices.empty()) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init: not on a context with callback sources");
     RcclApi &a = Rccl();
     if(!a.ok) return Fail(OALGPU_ERR_NO_DEVICE, a.why);
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof(id));
-    ncclComm_t comm = nullptr;
-    const ncclResult_t r = a.commInitRank(&comm, world, id, rank);
+    auto t = std::make_unique<RcclTransport>();
+    const ncclResult_t r = a.commInitRank(&t->comm, world, id, rank);
     if(r != ncclSuccess) return FailRccl("ncclCommInitRank", r);
-    c->comm = comm; c->commRank = rank; c->commWorld = world;
+    c->comm = t.release(); c->commRank = rank; c->commWorld = world;
     c->carryAccum = rank == 0;          // exactly one rank continues the carried HRTF accumulator
+    return OALGPU_OK;
+}
+
+/* The same sharded update over the host-staged transport: `name` = a POSIX shared-memory object name ("/..."),
+ * the same on every rank; rank 0 creates it, the others attach (they wait for it to appear).  For ranks that RCCL
+ * cannot connect -- several processes on one GPU. */
+int oalgpu_comm_init_host(oalgpu_context *c, const char *name, int rank, int world)
+{
+    if(!c || !name || name[0] != '/' || world < 1 || world > int(HostTransport::kMaxWorld) || rank < 0 || rank >= world)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: bad arguments");
+    if(c->comm) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: the context already has a communicator");
+    if(!c->cbVoices.empty()) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: not on a context with callback sources");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    auto t = std::make_unique<HostTransport>();
+    t->name = name; t->rank = rank; t->world = world;
+    t->floats = BusFloats(c->L); t->bytes = t->floats * sizeof(float);
+    const size_t total = sizeof(HostTransport::Header) + size_t(world) * HostTransport::kSlots * t->bytes;
+    if(rank == 0)
+    {
+        shm_unlink(name);
+        t->fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if(t->fd < 0 || ftruncate(t->fd, off_t(total)) != 0) return Fail(OALGPU_ERR_HIP, std::string("shm_open/ftruncate ") + name + " failed");
+    }
+    else
+    {
+        for(int tries = 0; tries < 3000 && t->fd < 0; ++tries)
+        {
+            t->fd = shm_open(name, O_RDWR, 0600);
+            struct stat st{};
+            if(t->fd >= 0 && (fstat(t->fd, &st) != 0 || size_t(st.st_size) < total)) { close(t->fd); t->fd = -1; }
+            if(t->fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        if(t->fd < 0) return Fail(OALGPU_ERR_HIP, std::string("shm_open ") + name + ": rank 0's segment did not appear");
+    }
+    void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
+    if(m == MAP_FAILED) return Fail(OALGPU_ERR_HIP, "mmap of the shared segment failed");
+    t->hdr = static_cast<HostTransport::Header*>(m);
+    t->ring = reinterpret_cast<float*>(static_cast<char*>(m) + sizeof(HostTransport::Header));
+    if(rank == 0)
+    {   // (a fresh segment is zero-filled: produced, consumed, failed start at 0)
+        t->hdr->world = uint32_t(world); t->hdr->floats = uint32_t(t->floats);
+        t->hdr->magic.store(0x0a16b05u, std::memory_order_release);
+        HIP_TRY(t->devSum.alloc(t->floats));
+    }
+    else
+    {
+        for(int tries = 0; tries < 3000 && t->hdr->magic.load(std::memory_order_acquire) != 0x0a16b05u; ++tries)
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        if(t->hdr->magic.load() != 0x0a16b05u || t->hdr->world != uint32_t(world) || t->hdr->floats != uint32_t(t->floats))
+            return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: the ranks' contexts differ (world size or bus block)");
+    }
+    for(float *&p : t->pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p), t->bytes, hipHostMallocDefault));
+    c->comm = t.release(); c->commRank = rank; c->commWorld = world;
+    c->carryAccum = rank == 0;
     return OALGPU_OK;
 }
 
@@ -326,7 +507,7 @@ int oalgpu_comm_destroy(oalgpu_context *c)
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(!c->comm) return OALGPU_OK;
     if(int rc = oalgpu_sync(c)) return rc;
-    (void)Rccl().commDestroy(static_cast<ncclComm_t>(c->comm));
+    delete c->comm;
     c->comm = nullptr; c->commRank = 0; c->commWorld = 1; c->carryAccum = true;
     return OALGPU_OK;
 }
@@ -781,7 +962,7 @@ void oalgpu_context_destroy(oalgpu_context *ctx)
     (void)hipSetDevice(ctx->desc.device);
     (void)hipStreamSynchronize(ctx->stream);
     if(ctx->postStream) (void)hipStreamSynchronize(ctx->postStream);
-    if(ctx->comm) (void)Rccl().commDestroy(static_cast<ncclComm_t>(ctx->comm));
+    delete ctx->comm;
     for(auto &cb : ctx->cbVoices)
         for(int k = 0; k < 2; ++k)
         {

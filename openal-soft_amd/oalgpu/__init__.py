@@ -520,6 +520,11 @@ class Scene:
         lib.oalgpu_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int]
         check(lib.oalgpu_comm_init(self.h, unique_id, len(unique_id), rank, world), "oalgpu_comm_init")
 
+    def comm_init_host(self, name, rank, world):
+        """the host-staged transport (shared-memory ring `name`): ranks RCCL cannot connect, e.g. on one GPU"""
+        lib.oalgpu_comm_init_host.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        check(lib.oalgpu_comm_init_host(self.h, name.encode(), rank, world), "oalgpu_comm_init_host")
+
     def comm_destroy(self):
         lib.oalgpu_comm_destroy.argtypes = [C.c_void_p]
         check(lib.oalgpu_comm_destroy(self.h), "oalgpu_comm_destroy")

@@ -132,33 +132,38 @@ class SceneScript:
     slots, every third send low-passed) or config 5 (config 3 voices with one send into a
     convolution slot)."""
 
-    def __init__(self, config_id, nvoices, voice_base=0):
+    def __init__(self, config_id, nvoices, voice_base=0, voice_map=None):
         self.config_id = config_id
         self.nvoices = nvoices
         self.voice_base = voice_base          # global index of local voice 0 (multi-GPU shards)
+        self.voice_map = voice_map            # or: the global index of every local voice (shards by cost class)
+
+    def gv(self, v):
+        """global index of local voice v"""
+        return self.voice_map[v] if self.voice_map is not None else self.voice_base + v
         self.hrtf = config_id in (3, 5)
 
     def _rng(self, gv, update):
         return Lcg(0x5EED0000 + self.config_id + 7919 * gv + 104729 * update)
 
     def start_position(self, v):
-        return ((self.voice_base + v) * 7919) % BUFFER_FRAMES
+        return (self.gv(v) * 7919) % BUFFER_FRAMES
 
     def buffer_of(self, v, nbuf):
-        return (self.voice_base + v) % nbuf
+        return self.gv(v) % nbuf
 
     def direction(self, v, update):
-        r = self._rng(self.voice_base + v, update if self.is_moving(v) else 0)
+        r = self._rng(self.gv(v), update if self.is_moving(v) else 0)
         az = r.uniform(-np.pi, np.pi)
         ev = float(np.arcsin(r.uniform(-1.0, 1.0)))
         gain = 10.0 ** (r.uniform(-60.0, -20.0) / 20.0)
         return ev, az, gain
 
     def is_moving(self, v):
-        return (self.voice_base + v) % 4 == 0
+        return self.gv(v) % 4 == 0
 
     def filter_active(self, v):
-        return (self.voice_base + v) % 4 == 1
+        return self.gv(v) % 4 == 1
 
     def fill(self, p, v, update):
         """p: a ctypes struct with the oalgpu_voice_params / oal_voice_params layout."""
@@ -177,14 +182,14 @@ class SceneScript:
             p.send_filter[i].hf_norm = 5000.0 / DEV_RATE
             p.send_filter[i].gain_lf = 1.0
             p.send_filter[i].lf_norm = 250.0 / DEV_RATE
-        nsends = {4: (self.voice_base + v) % 5, 5: 1}.get(self.config_id, 0)
+        nsends = {4: self.gv(v) % 5, 5: 1}.get(self.config_id, 0)
         if nsends:
             # first-order encode of the direction onto the slot's 4-line wet bus, -10 dB
             x, y, z = np.cos(az) * np.cos(ev), np.sin(az) * np.cos(ev), np.sin(ev)
             wet = [1.0, y * 1.7320508, z * 1.7320508, x * 1.7320508]
             for i in range(nsends):
                 p.send_slot[i] = i
-                if (self.voice_base + v + i) % 3 == 0 and self.config_id == 4:
+                if (self.gv(v) + i) % 3 == 0 and self.config_id == 4:
                     p.send_filter[i].active = 1
                     p.send_filter[i].gain_hf = 0.7
                 for c in range(4):

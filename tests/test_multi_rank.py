@@ -87,3 +87,49 @@ def test_library_comm_single_rank_rccl(synth_mhr):
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:]
     assert "overlapped ok" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [3, 4])
+def test_library_sharded_update_two_processes_one_gpu(synth_mhr, tmp_path, config):
+    """The library's N > 1 path itself: two processes share the GPU, each with a context of its own, connected by
+    oalgpu_comm_init_host (RCCL refuses two ranks on one device; the host-staged transport sits behind the same
+    interface as the ncclReduce).  Rank 1 mixes its shard without effects, post-process or accumulator carry and
+    hands its bus block over; rank 0 sums, runs the slots' effects and the post-process.  Six pipelined updates
+    (the first four without a host synchronisation), voices dealt by cost class; rank 0's buses and every
+    voice's integer state must equal the scene mixed unsharded.  Config 3 (HRTF) and config 4 (dry lines + sends
+    into four EAX reverb slots)."""
+    import numpy as np
+    total = 600
+    name = f"/oalgpu_test_{os.getpid()}_{config}"
+    prefix = str(tmp_path / f"c{config}")
+    procs = []
+    for rank in range(2):
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "host_transport_worker.py"), str(config), str(rank), "2",
+                                       name, str(total), prefix, synth_mhr], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+    r0 = np.load(prefix + "_rank0.npz")
+    r1 = np.load(prefix + "_rank1.npz")
+    assert sorted(list(r0["voices"]) + list(r1["voices"])) == list(range(total)) and len(r1["voices"]) > total // 4
+    checked = 0
+    for key in r0.files:
+        if key.startswith("whole_") and key != "whole_ints":
+            got, want = r0[key[len("whole_"):]].astype(np.float64), r0[key].astype(np.float64)
+            scale = np.abs(want).max()
+            err = np.abs(got - want).max()
+            assert err <= 2e-5 * scale + 1e-7, (config, key, err, scale)
+            checked += scale > 1e-4
+    assert checked >= 2, "the compared buses must carry sound"
+    whole = {int(r[0]): tuple(int(x) for x in r[1:]) for r in r0["whole_ints"]}
+    for r in list(r0["ints"]) + list(r1["ints"]):
+        assert whole[int(r[0])] == tuple(int(x) for x in r[1:]), (config, r)
