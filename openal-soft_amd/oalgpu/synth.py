@@ -137,11 +137,11 @@ class SceneScript:
         self.nvoices = nvoices
         self.voice_base = voice_base          # global index of local voice 0 (multi-GPU shards)
         self.voice_map = voice_map            # or: the global index of every local voice (shards by cost class)
+        self.hrtf = config_id in (3, 5)
 
     def gv(self, v):
         """global index of local voice v"""
         return self.voice_map[v] if self.voice_map is not None else self.voice_base + v
-        self.hrtf = config_id in (3, 5)
 
     def _rng(self, gv, update):
         return Lcg(0x5EED0000 + self.config_id + 7919 * gv + 104729 * update)
