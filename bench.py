@@ -68,10 +68,9 @@ def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, v
         sc.set_slot_convolution(0, conv)
         sc.effects.append(conv)
     if hrtf:
-        rng = np.random.default_rng(1234)
-        cc = np.zeros((4, 128, 2), np.float32)
-        cc[:, :64] = rng.uniform(-0.2, 0.2, (4, 64, 2)) * np.exp(-np.arange(64) / 12.0)[None, :, None]
-        sc.set_direct_hrtf(cc, [1.0, 0.8, 0.8, 0.8], 400.0 / 48000.0, 64)
+        # the post-process's ambisonic-to-binaural decoder as InitHrtfPanning builds it for a first-order HRTF device
+        # (alc/panning.cpp:1100-1134): DirectHrtfState::build on the loaded data set, the cube layout, 400 Hz crossover
+        sc.set_direct_hrtf_from_store(synth.AMBI_POINTS_1O, synth.AMBI_MATRIX_1O, synth.AMBI_ORDER_HF_GAIN_1O, 400.0)
     bufs = synth.scene_buffers(config_id, nvoices if voice_map is None else 256)
     handles = [sc.add_buffer(b, oalgpu.FMT_FLOAT) for b in bufs]
     script = synth.SceneScript(config_id, nvoices, voice_base, voice_map)
@@ -99,6 +98,11 @@ def _cpu_mix_worker(config_id, voice_base, nvoices, mhr_path, updates, target_se
     if hrtf:
         L.hrtf_load(mhr_path)
     sc = ol.Scene(L, num_dry=4 if hrtf else 5, num_real=2 if hrtf else 0, hrtf=hrtf)
+    if hrtf and L.kind == "reference":
+        info = L.hrtf_raw()["info"]
+        cc, hf, irsize = L.direct_hrtf_build(info.ir_size, False, synth.AMBI_POINTS_1O, synth.AMBI_MATRIX_1O, 4, 400.0,
+                                             synth.AMBI_ORDER_HF_GAIN_1O)
+        sc.set_direct_hrtf(cc, hf, 400.0 / info.sample_rate, irsize)
     bufs = synth.scene_buffers(config_id, max(nvoices, 256))
     handles = [sc.add_buffer(b, ol.FMT_FLOAT) for b in bufs]
     script = synth.SceneScript(config_id, nvoices, voice_base)

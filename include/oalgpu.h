@@ -207,6 +207,20 @@ int oalgpu_hrtf_get_coeffs(oalgpu_context *ctx, const float *dirs, size_t count,
  * one-time init and stays with the caller). */
 int oalgpu_set_direct_hrtf(oalgpu_context *ctx, const float *chan_coeffs /* ndry x 128 x 2 */,
     const float *hfscales, float xover_norm, uint32_t irsize);
+/* DirectHrtfState::build (core/hrtf.cpp:266-366), the decoder design itself, on the context's data set: from the
+ * host's virtual-speaker layout -- points = num_points x {elevation, azimuth} (radians), matrix = num_points x 16
+ * (the AmbiMatrix rows), order_hf_gain[5] (alc/panning.cpp:861-1038 holds the reference's tables; InitHrtfPanning
+ * passes ir_size = the store's IrSize (0 here) and per_hrir_min for orders >= 3).  One-time host work in double
+ * precision; ends in oalgpu_set_direct_hrtf. */
+int oalgpu_set_direct_hrtf_from_store(oalgpu_context *ctx, const float *points, const float *matrix, uint32_t num_points,
+    const float *order_hf_gain, float xover_freq, uint32_t ir_size, int per_hrir_min);
+/* Host-only (no device needed): a .mhr brought to device_rate as GetLoadedHrtf does (core/hrtf.cpp:539-606; 0 = the
+ * set's own rate) -- info, and coeffs (num_irs x 128 x 2) / delays (num_irs x 2) when not NULL -- and the decoder
+ * build on it.  oalgpu_hrtf_load_mhr does the same resampling when the context's rate differs from the set's. */
+int oalgpu_hrtf_parse_host(const void *mhr, size_t size, uint32_t device_rate, oalgpu_hrtf_info *info, float *coeffs, uint8_t *delays);
+int oalgpu_hrtf_build_direct_host(const void *mhr, size_t size, uint32_t device_rate, uint32_t ir_size, int per_hrir_min,
+    const float *points, const float *matrix, uint32_t num_points, uint32_t num_chans, float xover_freq, const float *order_hf_gain,
+    float *out_coeffs, float *out_hfscales, float *out_xover_norm, uint32_t *out_irsize);
 
 /* al::Buffer storage / VoiceBufferItem (core/voice.h:84-98): sample data is copied to HBM once.
  * frame_step = interleaved samples per frame; mono voices read channel 0.  Returns the handle

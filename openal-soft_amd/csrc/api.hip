@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../host/mhr.hpp"
+#include "../host/hrtf_build.hpp"
 #include "../host/params.hpp"
 #include "../host/tables.hpp"
 #include "api_util.hpp"
@@ -979,12 +980,9 @@ int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
     HrtfData parsed;
     const std::string err = ParseMhr(data, size, parsed);
     if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
-    // The reference resamples a data set whose rate differs from the device's (GetLoadedHrtf,
-    // core/hrtf.cpp:539-606: coefficients through a polyphase resampler, delays rescaled); that is
-    // not built here, and mixing with mistuned HRIRs silently would be wrong: refuse.
-    if(parsed.sampleRate != c->desc.sample_rate)
-        return Fail(OALGPU_ERR_INVALID, "mhr: data set at " + std::to_string(parsed.sampleRate) + " Hz, context at "
-            + std::to_string(c->desc.sample_rate) + " Hz (resample the data set to the device rate first)");
+    // a data set at another rate than the device's is brought to the device's rate as GetLoadedHrtf does
+    // (core/hrtf.cpp:539-606: every HRIR through the polyphase resampler, delays and IrSize rescaled)
+    if(parsed.sampleRate != c->desc.sample_rate) ResampleHrtfData(parsed, c->desc.sample_rate);
     if(int rc = oalgpu_sync(c)) return rc;           // a second load replaces buffers the streams may still read
     c->hrtfHost = std::move(parsed);
     const HrtfData &h = c->hrtfHost;
@@ -1069,9 +1067,66 @@ int oalgpu_set_direct_hrtf(oalgpu_context *c, const float *chan_coeffs, const fl
     for(auto &s : sp) { s.coeff = SplitterCoeff(xover_norm); s.lpZ1 = s.lpZ2 = s.apZ1 = 0.0f; }
     HIP_TRY(c->dSplit.upload(sp.data(), nd));
     HIP_TRY(c->dHfScale.upload(hfscales, nd));
-    HIP_TRY(c->dCoeffs.upload(chan_coeffs, size_t{nd} * kHrirLen * 2));
+    {   // MixDirectHrtf applies IrSize taps (rounded up to even: ApplyCoeffs works on pairs); the decoder of a resampled
+        // data set carries non-zero taps beyond that, which the fixed-length FIR of the FAST post-process must not see
+        std::vector<float> cc(chan_coeffs, chan_coeffs + size_t{nd} * kHrirLen * 2);
+        const uint32_t live = (irsize + 1u) & ~1u;
+        for(uint32_t ch = 0; ch < nd; ++ch)
+            for(uint32_t k = live; k < uint32_t(kHrirLen); ++k) { cc[(size_t{ch} * kHrirLen + k) * 2] = 0.0f; cc[(size_t{ch} * kHrirLen + k) * 2 + 1] = 0.0f; }
+        HIP_TRY(c->dCoeffs.upload(cc.data(), cc.size()));
+    }
     c->dIrSize = irsize;
     c->directSet = true;
+    return OALGPU_OK;
+}
+
+/* DirectHrtfState::build (core/hrtf.cpp:266-366) on the context's data set: the ambisonic-to-binaural decoder of the
+ * HRTF post-process from the host's virtual-speaker layout (alc/panning.cpp:861-1038 holds the reference's: AmbiPoints,
+ * AmbiMatrix rows of 16, AmbiOrderHFGain[5]; InitHrtfPanning passes device->mIrSize = the store's IrSize and
+ * perHrirMin for orders >= 3).  One-time host work in double precision, then oalgpu_set_direct_hrtf. */
+int oalgpu_set_direct_hrtf_from_store(oalgpu_context *c, const float *points, const float *matrix, uint32_t num_points,
+    const float *order_hf_gain, float xover_freq, uint32_t ir_size, int per_hrir_min)
+{
+    if(!c || !points || !matrix || !order_hf_gain || num_points == 0 || c->L.numDry > 16)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_set_direct_hrtf_from_store: bad arguments");
+    if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "oalgpu_set_direct_hrtf_from_store: no data set loaded");
+    const DirectHrtfBuild b = BuildDirectHrtf(c->hrtfHost, ir_size ? ir_size : c->hrtfHost.irSize, per_hrir_min != 0, points, matrix,
+        num_points, c->L.numDry, xover_freq, order_hf_gain);
+    return oalgpu_set_direct_hrtf(c, b.coeffs.data(), b.hfScale.data(), b.xoverNorm, std::max<uint32_t>(b.irSize, 8u));
+}
+
+/* The same two pieces of one-time HRTF set-up as pure host functions (no device): a data set brought to `device_rate`
+ * (0: its own) -- info, and coeffs (num_irs x 128 x 2) / delays (num_irs x 2) when not NULL -- and the decoder build. */
+int oalgpu_hrtf_parse_host(const void *mhr, size_t size, uint32_t device_rate, oalgpu_hrtf_info *info, float *coeffs, uint8_t *delays)
+{
+    if(!mhr || !info) return Fail(OALGPU_ERR_INVALID, "null argument");
+    HrtfData h;
+    const std::string err = ParseMhr(mhr, size, h);
+    if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
+    if(device_rate) ResampleHrtfData(h, device_rate);
+    info->sample_rate = h.sampleRate; info->ir_size = h.irSize; info->num_fields = uint32_t(h.fieldDistance.size());
+    info->num_elevs = uint32_t(h.elevAzCount.size()); info->num_irs = h.numIrs();
+    if(coeffs) std::memcpy(coeffs, h.coeffs.data(), h.coeffs.size() * sizeof(float));
+    if(delays) std::memcpy(delays, h.delays.data(), h.delays.size());
+    return OALGPU_OK;
+}
+
+int oalgpu_hrtf_build_direct_host(const void *mhr, size_t size, uint32_t device_rate, uint32_t ir_size, int per_hrir_min,
+    const float *points, const float *matrix, uint32_t num_points, uint32_t num_chans, float xover_freq, const float *order_hf_gain,
+    float *out_coeffs, float *out_hfscales, float *out_xover_norm, uint32_t *out_irsize)
+{
+    if(!mhr || !points || !matrix || !order_hf_gain || !out_coeffs || !out_hfscales || num_chans < 1 || num_chans > 16 || num_points == 0)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_hrtf_build_direct_host: bad arguments");
+    HrtfData h;
+    const std::string err = ParseMhr(mhr, size, h);
+    if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
+    if(device_rate) ResampleHrtfData(h, device_rate);
+    const DirectHrtfBuild b = BuildDirectHrtf(h, ir_size ? ir_size : h.irSize, per_hrir_min != 0, points, matrix, num_points,
+        num_chans, xover_freq, order_hf_gain);
+    std::memcpy(out_coeffs, b.coeffs.data(), b.coeffs.size() * sizeof(float));
+    std::memcpy(out_hfscales, b.hfScale.data(), b.hfScale.size() * sizeof(float));
+    if(out_xover_norm) *out_xover_norm = b.xoverNorm;
+    if(out_irsize) *out_irsize = b.irSize;
     return OALGPU_OK;
 }
 

@@ -182,6 +182,10 @@ __device__ __forceinline__ void ApplyRecordWave(const DeviceLayout &L, const Par
     {
         const uint32_t i0 = r.hrtfIdx[0], i1 = r.hrtfIdx[1], i2 = r.hrtfIdx[2], i3 = r.hrtfIdx[3];
         const float w0 = r.hrtfW[0], w1 = r.hrtfW[1], w2 = r.hrtfW[2], w3 = r.hrtfW[3], pass = r.hrtfPass;
+        // The mixers apply IrSize taps (rounded up to even: ApplyCoeffs works on pairs, mixer_sse.cpp:46-51); a data
+        // set resampled to the device's rate carries non-zero taps beyond that (GetLoadedHrtf resamples whole
+        // HrirArrays), which the voice kernels' fixed-length FIRs must not see
+        const uint32_t live = ((L.irSize + 1u) & ~1u) * 2u;
         for(uint32_t e = lane; e < L.irStride * 2; e += 64)
         {   // hrtf.cpp:247-259: the pass-through tap (elements 0, 1) or 0, then the four weighted HRIRs in order
             float x = (e < 2) ? pass : 0.0f;
@@ -189,7 +193,7 @@ __device__ __forceinline__ void ApplyRecordWave(const DeviceLayout &L, const Par
             x = L.hrirs[size_t{i1} * (kHrirLen * 2) + e] * w1 + x;
             x = L.hrirs[size_t{i2} * (kHrirLen * 2) + e] * w2 + x;
             x = L.hrirs[size_t{i3} * (kHrirLen * 2) + e] * w3 + x;
-            L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = x;
+            L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = (e < live) ? x : 0.0f;
         }
     }
     else if(lane < L.numDry)

@@ -335,7 +335,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 {
                     histN = L.hist[size_t{vn} * kHist + lane];
                     if constexpr (MF)
-                        hN = (lane < L.irSize) ? reinterpret_cast<const f2*>(L.hrtfTgt + size_t{vn} * irStride * 2)[lane] : f2{0.0f, 0.0f};
+                        hN = (lane < irStride) ? reinterpret_cast<const f2*>(L.hrtfTgt + size_t{vn} * irStride * 2)[lane] : f2{0.0f, 0.0f};    // (taps beyond IrSize are stored as zeros)
                     dirtyN = (headN.flags & kFlagHrtfDirty) != 0;
                     const f2 *oc = reinterpret_cast<const f2*>(L.hrtfOld + size_t{vn} * irStride * 2);
     #pragma unroll

@@ -545,6 +545,19 @@ class Scene:
         check(lib.oalgpu_set_direct_hrtf(self.h, _fp(cc), _fp(hf), xover_norm, irsize),
               "oalgpu_set_direct_hrtf")
 
+    def set_direct_hrtf_from_store(self, points, matrix, order_hf_gain, xover_freq, ir_size=0, per_hrir_min=False):
+        """DirectHrtfState::build on the context's data set (oalgpu_set_direct_hrtf_from_store)"""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        mat = np.zeros((len(pts), 16), np.float32)
+        m = np.asarray(matrix, np.float32)
+        mat[:, :m.shape[1]] = m
+        g = np.zeros(5, np.float32)
+        g[:len(order_hf_gain)] = order_hf_gain
+        lib.oalgpu_set_direct_hrtf_from_store.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32,
+                                                          C.POINTER(C.c_float), C.c_float, C.c_uint32, C.c_int]
+        check(lib.oalgpu_set_direct_hrtf_from_store(self.h, _fp(pts), _fp(mat), len(pts), _fp(g), xover_freq, ir_size,
+                                                    1 if per_hrir_min else 0), "oalgpu_set_direct_hrtf_from_store")
+
     # the stage behind the buses: BFormatDec, dither, output PCM (include/oalgpu.h)
     def set_bformat_decoder(self, coeffs_hf, coeffs_lf=None, xover_norm=400.0 / 48000.0):
         lib.oalgpu_set_bformat_decoder.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, C.c_float]

@@ -237,3 +237,15 @@ def x71_decoder():
         hf[line, :5] = row * hf_gain[order]
         lf[line, :5] = row
     return hf, lf
+
+
+# ---- InitHrtfPanning's first-order virtual-speaker layout (alc/panning.cpp:861-869, :941-950, :1021-1023): the cube's
+# eight corners, the decoder rows (W, Y, Z, X in ACN order) and the per-order high-frequency gains
+_D35 = np.float32(6.154797087e-01)
+_D45 = np.float32(np.float32(np.pi) / np.float32(2.0)) / np.float32(2.0)       # Deg_90 / 2.0f
+_D135 = np.float32(_D45 * np.float32(3.0))                                     # Deg_45 * 3.0f
+AMBI_POINTS_1O = np.array([(_D35, -_D45), (_D35, -_D135), (_D35, _D45), (_D35, _D135),
+                           (-_D35, -_D45), (-_D35, -_D135), (-_D35, _D45), (-_D35, _D135)], np.float32)
+AMBI_MATRIX_1O = 0.125 * np.array([(1, 1, 1, 1), (1, 1, 1, -1), (1, -1, 1, 1), (1, -1, 1, -1),
+                                   (1, 1, -1, 1), (1, 1, -1, -1), (1, -1, -1, 1), (1, -1, -1, -1)], np.float32)
+AMBI_ORDER_HF_GAIN_1O = np.array([2.0, 1.154700538, 0.0, 0.0, 0.0], np.float32)

@@ -127,6 +127,11 @@ void oal_biquad_dual_process(oal_biquad *f0, oal_biquad *f1, const float *src, f
 /* ---------- HRTF data set (core/hrtf_loader.cpp, core/hrtf.cpp) ---------- */
 /* Loads a .mhr file; returns 0 on success.  One data set at a time. */
 int oal_hrtf_load(const char *path);
+/* GetLoadedHrtf on the first .mhr under `dir` for a device at `devrate` (resampled when the rates differ) */
+int oal_hrtf_load_for_rate(const char *dir, uint32_t devrate);
+/* DirectHrtfState::build on the current store */
+int oal_direct_hrtf_build(uint32_t irsize, int per_hrir_min, const float *points, const float *matrix, uint32_t npoints,
+    uint32_t nchans, float xover_freq, const float *order_hf_gain, float *out_coeffs, float *out_hfscale, uint32_t *out_irsize);
 typedef struct oal_hrtf_info {
     uint32_t sample_rate, ir_size, num_fields, num_elevs, num_irs;
 } oal_hrtf_info;

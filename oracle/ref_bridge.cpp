@@ -73,6 +73,7 @@
 #include "alc/alu.h"
 
 #include "../include/oalgpu.h"
+#include "../include/oalgpu_openal.hpp"    /* THE PRODUCT'S host adapter: this file only drives it */
 
 extern "C" {
 void oalbridge_voice_mix_cpu(void *voice, int vstate, void *context, long long device_ns, unsigned samples_to_do);
@@ -108,14 +109,8 @@ struct oalbridge {
     std::unique_ptr<Ctx> ctx;
     std::deque<BufferData> buffers;
     std::vector<Voice*> sources;            /* the context's voices, in creation order */
-    /* ---- the GPU side */
-    oalgpu_context *gpu{nullptr};
-    std::map<const VoiceBufferItem*, int> bufferHandle;
-    std::map<const Voice*, uint32_t> voiceIndex;
-    std::map<const Voice*, int> lastState;
-    /* ---- one update of the voice loop */
-    unsigned expected{0}, seen{0};
-    std::vector<std::pair<Voice*, Voice::State>> batch;
+    /* ---- the GPU side: include/oalgpu_openal.hpp's batched voice loop */
+    std::unique_ptr<oalgpu_openal::BatchMixer> batch;
     int error{0};
     std::string errorText;
     /* test aid for the output stage (ApplyDither / Write<T>, alu.cpp:2309-2408, are file-local): lines added
@@ -127,149 +122,6 @@ struct oalbridge {
 namespace {
 
 oalbridge *gActive = nullptr;               /* the bridge whose renderSamples is running (one mixer thread) */
-int gResamplerKind = OALGPU_RESAMPLER_LINEAR;   /* of the voice Voice::mix_cpu is working on (ADAPTERS) */
-int gMathMode = OALGPU_MATH_EXACT;
-
-/* ---- ADAPTERS: the reference's function-pointer signatures on top of the per-call C-ABI ------------------- */
-void Resample_GPU(InterpState const*, std::span<float const> src, unsigned frac, unsigned increment,
-    std::span<float> dst) noexcept
-{
-    /* `src` is DeviceBase::mResampleData as voice.cpp:768 hands it over: it begins MaxResamplerEdge samples
-     * before the first source sample, which is the convention of oalgpu_resample too */
-    oalgpu_resample(0, gMathMode, gResamplerKind, increment, src.data(), src.size(), frac, dst.data(), dst.size());
-}
-
-void Mix_GPU(std::span<float const> in, std::span<FloatBufferLine> out, std::span<float> cur,
-    std::span<float const> tgt, std::size_t counter, std::size_t outpos) noexcept
-{
-    oalgpu_mix(0, in.data(), in.size(), out[0].data(), out.size(), cur.data(), tgt.data(), counter, outpos);
-}
-
-void MixHrtf_GPU(std::span<float const> in, std::span<f32x2> accum, unsigned irSize, MixHrtfFilter const *f,
-    std::size_t n) noexcept
-{
-    const uint32_t delay[2]{f->Delay[0], f->Delay[1]};
-    oalgpu_mix_hrtf(0, gMathMode, in.data(), &accum[0][0], irSize, &f->Coeffs[0][0], delay, f->Gain, f->GainStep, n);
-}
-
-void MixHrtfBlend_GPU(std::span<float const> in, std::span<f32x2> accum, unsigned irSize, HrtfFilter const *oldp,
-    MixHrtfFilter const *newp, std::size_t n) noexcept
-{
-    const uint32_t od[2]{oldp->Delay[0], oldp->Delay[1]}, nd[2]{newp->Delay[0], newp->Delay[1]};
-    oalgpu_mix_hrtf_blend(0, gMathMode, in.data(), &accum[0][0], irSize, &oldp->Coeffs[0][0], od, oldp->Gain,
-        &newp->Coeffs[0][0], nd, newp->GainStep, n);
-}
-
-/* ---- BATCH: the descriptor builder of INTEGRATION.md section 3 ---------------------------------------------- */
-int Fail(oalbridge *b, int rc, const char *what)
-{
-    if(!b->error) { b->error = rc; b->errorText = std::string(what) + ": " + oalgpu_last_error(); }
-    return rc;
-}
-
-/* the shelf gains CalcPanningAndFilters designed the voice's direct filters with (alu.cpp:1619-1637):
- * BiquadFilter::SetParams (biquad.cpp:48-129) builds the shelves with A = gain, so a high shelf answers
- * gain^2 at Nyquist and a low shelf gain^2 at DC */
-float ShelfGainAt(const BiquadInterpFilter &f, float z /* +1: DC, -1: Nyquist */)
-{
-    const auto &c = f.mTargetCoeffs;
-    return std::sqrt(std::max((c.mB0 + c.mB1*z + c.mB2) / (1.0f + c.mA1*z + c.mA2), 0.0f));
-}
-
-int FlushBatch(oalbridge *b, ContextBase *context, unsigned samplesToDo)
-{
-    auto &dev = *b->dev;
-    if(!b->gpu)
-    {
-        oalgpu_context_desc d{};
-        d.device = 0; d.math_mode = b->mathMode; d.sample_rate = dev.mSampleRate;
-        d.num_dry_channels = uint32_t(dev.Dry.Buffer.size());
-        d.num_real_channels = uint32_t(dev.RealOut.Buffer.size());
-        d.num_aux_sends = 0; d.num_slots = 0; d.wet_channels = 4; d.hrtf = 0;
-        d.max_voices = 1024; d.max_buffers = 256; d.voices_per_group = 0;
-        if(int rc = oalgpu_context_create(&d, &b->gpu)) return Fail(b, rc, "oalgpu_context_create");
-    }
-    std::vector<uint32_t> ids;
-    std::vector<oalgpu_voice_params> params;
-    for(auto &[voice, vstate] : b->batch)
-    {
-        auto it = b->voiceIndex.find(voice);
-        if(it == b->voiceIndex.end())
-        {   /* a voice that starts playing: register its buffer once, InitVoice (al/source.cpp:639-670) */
-            auto *item = voice->mCurrentBuffer.load(std::memory_order_relaxed);
-            if(!item) continue;
-            auto hb = b->bufferHandle.find(item);
-            if(hb == b->bufferHandle.end())
-            {
-                auto const *span = std::get_if<std::span<f32>>(&item->mSamples);
-                if(!span) return Fail(b, OALGPU_ERR_INVALID, "bridge: float buffers only");
-                const int h = oalgpu_buffer_register(b->gpu, span->data(), OALGPU_FMT_FLOAT, voice->mFrameStep,
-                    item->mSampleLen, item->mLoopStart, item->mLoopEnd);
-                if(h < 0) return Fail(b, h, "oalgpu_buffer_register");
-                hb = b->bufferHandle.emplace(item, h).first;
-            }
-            const uint32_t idx = uint32_t(b->voiceIndex.size());
-            oalgpu_voice_desc vd{hb->second, voice->mLoopBuffer.load(std::memory_order_relaxed) != nullptr,
-                voice->mPosition.load(std::memory_order_relaxed), voice->mPositionFrac.load(std::memory_order_relaxed),
-                voice->mFrequency};
-            if(int rc = oalgpu_voice_init(b->gpu, idx, &vd)) return Fail(b, rc, "oalgpu_voice_init");
-            it = b->voiceIndex.emplace(voice, idx).first;
-            b->lastState[voice] = Voice::Playing;
-        }
-        if(b->lastState[voice] != int(vstate))
-        {   /* ProcessVoiceChanges' play-state changes (alu.cpp:2057-2151) */
-            if(int rc = oalgpu_voice_set_state(b->gpu, it->second, int(vstate))) return Fail(b, rc, "oalgpu_voice_set_state");
-            b->lastState[voice] = int(vstate);
-        }
-        /* what CalcVoiceParams left in the Voice (alu.cpp:1512-1710, :2012-2031) */
-        oalgpu_voice_params p{};
-        p.step = voice->mStep;
-        p.resampler = int(voice->mProps.mResampler);
-        auto &chan = voice->mChans[0];
-        const float inv_rate = 1.0f / float(dev.mSampleRate);
-        p.direct_filter.active = voice->mDirect.FilterActive ? 1 : 0;
-        p.direct_filter.hf_norm = voice->mProps.Direct.HFReference * inv_rate;
-        p.direct_filter.lf_norm = voice->mProps.Direct.LFReference * inv_rate;
-        p.direct_filter.gain_hf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.LowPass, -1.0f) : 1.0f;
-        p.direct_filter.gain_lf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.HighPass, 1.0f) : 1.0f;
-        for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c) p.dry_gains[c] = chan.mDryParams.Gains.Target[c];
-        for(int s{0}; s < OALGPU_MAX_SENDS; ++s)
-        {
-            p.send_slot[s] = -1;
-            p.send_filter[s] = oalgpu_filter_params{0, 1.0f, 5000.0f*inv_rate, 1.0f, 250.0f*inv_rate};
-        }
-        ids.push_back(it->second);
-        params.push_back(p);
-    }
-    if(!ids.empty())
-        if(int rc = oalgpu_voice_set_params(b->gpu, ids.data(), params.data(), ids.size())) return Fail(b, rc, "oalgpu_voice_set_params");
-    /* the voice loop: one batched update, then the dry lines join the device's mixing buffer */
-    if(int rc = oalgpu_mix_update(b->gpu, samplesToDo, 0)) return Fail(b, rc, "oalgpu_mix_update");
-    std::vector<float> lines((dev.Dry.Buffer.size() + dev.RealOut.Buffer.size()) * BufferLineSize);
-    if(int rc = oalgpu_read_dry(b->gpu, lines.data())) return Fail(b, rc, "oalgpu_read_dry");
-    for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c)
-        for(size_t i{0}; i < samplesToDo; ++i)
-            dev.Dry.Buffer[c][i] += lines[c*BufferLineSize + i];
-    /* the state the reference mutates in place stays authoritative on the device; what the rest of the
-     * reference looks at (GetSourceOffset, the play state) is read back */
-    for(auto &[voice, vstate] : b->batch)
-    {
-        auto it = b->voiceIndex.find(voice);
-        if(it == b->voiceIndex.end()) continue;
-        oalgpu_voice_state st{};
-        if(int rc = oalgpu_voice_readback(b->gpu, it->second, &st)) return Fail(b, rc, "oalgpu_voice_readback");
-        voice->mPosition.store(st.position, std::memory_order_relaxed);
-        voice->mPositionFrac.store(st.position_frac, std::memory_order_relaxed);
-        if(st.fading) voice->mFlags.set(VoiceFlag::IsFading);
-        if(st.play_state != int(vstate))
-        {
-            voice->mPlayState.store(static_cast<Voice::State>(st.play_state), std::memory_order_release);
-            b->lastState[voice] = st.play_state;
-        }
-    }
-    (void)context;
-    return 0;
-}
 
 } // namespace
 
@@ -295,33 +147,19 @@ void Voice::mix(State const vstate, ContextBase *const context, std::chrono::nan
     {
         /* per voice: CalcVoiceParams chose mResampler with PrepareResampler (alu.cpp:1686, :2000); the
          * adapter of the same ResamplerFunc type takes its place for this call */
-        gResamplerKind = int(mProps.mResampler);
+        oalgpu_openal::Adapters().resamplerKind = int(mProps.mResampler);
         auto const saved = mResampler;
-        mResampler = Resample_GPU;
+        mResampler = oalgpu_openal::Resample;
         oalbridge_voice_mix_cpu(this, int(vstate), context, deviceTime.count(), samplesToDo);
         mResampler = saved;
         return;
     }
-    /* BATCH */
-    if(b->seen == 0)
-    {
-        b->expected = 0;
-        for(Voice *v : context->getVoicesSpanAcquired())
-        {
-            auto const st = v->mPlayState.load(std::memory_order_acquire);
-            if(st != Voice::Stopped && st != Voice::Pending) ++b->expected;
-        }
-        b->batch.clear();
-    }
-    b->batch.emplace_back(this, vstate);
-    if(++b->seen == b->expected)
-    {
-        b->seen = 0;
-        if(FlushBatch(b, context, samplesToDo) != 0)
-        {   /* "on error the caller runs the CPU loop for that update"  */
-            for(auto &[voice, st] : b->batch)
-                oalbridge_voice_mix_cpu(voice, int(st), context, deviceTime.count(), samplesToDo);
-        }
+    /* BATCH: oalgpu_openal::BatchMixer collects the update's voices and mixes them with the last one */
+    if(!b->batch->mix(this, vstate, context, *b->dev, samplesToDo) && b->batch->error() && b->batch->batchComplete())
+    {   /* "on error the caller runs the CPU loop for that update"  */
+        if(!b->error) { b->error = b->batch->error(); b->errorText = b->batch->errorText(); }
+        for(auto &[voice, st] : b->batch->batch())
+            oalbridge_voice_mix_cpu(voice, int(st), context, deviceTime.count(), samplesToDo);
     }
 }
 
@@ -334,6 +172,7 @@ oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
     auto b = std::make_unique<oalbridge>();
     b->mode = static_cast<Mode>(mode);
     b->mathMode = math_mode;
+    b->batch = std::make_unique<oalgpu_openal::BatchMixer>(math_mode, 0);
     b->dev = std::make_unique<Dev>();
     auto &dev = *b->dev;
     /* a stereo loopback device as alc/alc.cpp + alc/panning.cpp set it up (InitPanning with
@@ -391,9 +230,9 @@ oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
     }
     if(mode == ModeAdapters)
     {   /* installed the way Voice::InitMixer installs the CPU variants (core/voice.cpp:139-193) */
-        gMathMode = math_mode;
-        MixSamplesOut = Mix_GPU;
-        oalbridge_set_hrtf_mixers(reinterpret_cast<void*>(MixHrtf_GPU), reinterpret_cast<void*>(MixHrtfBlend_GPU));
+        oalgpu_openal::Adapters().mathMode = math_mode;
+        MixSamplesOut = oalgpu_openal::Mix;
+        oalbridge_set_hrtf_mixers(reinterpret_cast<void*>(oalgpu_openal::MixHrtf), reinterpret_cast<void*>(oalgpu_openal::MixHrtfBlend));
     }
     return b.release();
 }
@@ -403,7 +242,6 @@ void oalbridge_destroy(oalbridge *b)
     if(!b) return;
     if(gActive == b) gActive = nullptr;
     if(b->mode == ModeAdapters) Voice::InitMixer(std::nullopt);      /* the reference's own kernels again */
-    if(b->gpu) oalgpu_context_destroy(b->gpu);
     delete b;
 }
 
@@ -513,7 +351,7 @@ int oalbridge_stop_source(oalbridge *b, int source)
 int oalbridge_render(oalbridge *b, float *interleaved, uint32_t frames)
 {
     gActive = b;
-    b->seen = 0;
+    b->batch->reset();
     b->dev->renderSamples(interleaved, frames, 2u);
     gActive = nullptr;
     return b->error;

@@ -100,6 +100,7 @@ void oalref_apply_simd() { ApplySimd(); }
 namespace {
 
 std::unique_ptr<HrtfStore> gHrtfOwner;
+HrtfStorePtr gHrtfLoaded;                   /* a store GetLoadedHrtf returned (oal_hrtf_load_for_rate) */
 HrtfStore *gHrtf = nullptr;
 
 BSincTable const *GetBsinc(int which)
@@ -415,6 +416,57 @@ int oal_hrtf_load(const char *path)
         gHrtf = gHrtfOwner.get();
     }
     catch(...) { return -3; }
+    return 0;
+}
+
+/* GetLoadedHrtf (core/hrtf.cpp:471-620) as it is, on a data set found the way the reference finds one:
+ * EnumerateHrtf lists the .mhr files under ALSOFT_LOCAL_PATH (`dir`), GetLoadedHrtf loads the first and -- when the
+ * set's rate differs from devrate -- resamples every HRIR with PPhaseResampler and rescales delays and IrSize
+ * (:539-606).  The loaded store becomes the harness's current one (oal_hrtf_raw reads it out). */
+int oal_hrtf_load_for_rate(const char *dir, uint32_t devrate)
+{
+    setenv("ALSOFT_LOCAL_PATH", dir, 1);
+    try {
+        auto const names = EnumerateHrtf(std::nullopt);
+        if(names.empty()) return -1;
+        gHrtfLoaded = GetLoadedHrtf(names[0], devrate);
+        if(!gHrtfLoaded) return -2;
+        gHrtfOwner.reset();
+        gHrtf = gHrtfLoaded.get();
+    }
+    catch(...) { return -3; }
+    return 0;
+}
+
+/* DirectHrtfState::build (core/hrtf.cpp:266-366) on the current store, with the caller's AmbiPoints / AmbiMatrix /
+ * AmbiOrderHFGain (alc/panning.cpp:861-1038 holds the reference's own): points = npoints x {elevation, azimuth}
+ * radians, matrix = npoints x 16 (the first 16 of a ChannelCoeffs row), out_coeffs = nchans x 128 x 2, out_hfscale = nchans. */
+int oal_direct_hrtf_build(uint32_t irsize, int per_hrir_min, const float *points, const float *matrix, uint32_t npoints,
+    uint32_t nchans, float xover_freq, const float *order_hf_gain, float *out_coeffs, float *out_hfscale, uint32_t *out_irsize)
+{
+    if(!gHrtf || nchans < 1 || nchans > 16) return -1;
+    auto pts = std::vector<AngularPoint>{};
+    auto mat = std::vector<std::array<float, MaxAmbiChannels>>(npoints);
+    for(uint32_t i{0}; i < npoints; ++i)
+    {
+        pts.push_back(AngularPoint{EvRadians{points[i*2]}, AzRadians{points[i*2 + 1]}});
+        mat[i].fill(0.0f);
+        for(size_t c{0}; c < 16; ++c) mat[i][c] = matrix[i*16 + c];      /* rows of 16: orders up to 3 */
+    }
+    auto gains = std::array<float, MaxAmbiOrder+1>{};
+    for(size_t o{0}; o <= MaxAmbiOrder; ++o) gains[o] = order_hf_gain[o];
+    auto state = DirectHrtfState::Create(nchans);
+    state->build(gHrtf, irsize, per_hrir_min != 0, pts, mat, xover_freq, gains);
+    for(uint32_t c{0}; c < nchans; ++c)
+    {
+        out_hfscale[c] = state->mChannels[c].mHfScale;
+        for(size_t k{0}; k < HrirLength; ++k)
+        {
+            out_coeffs[(c*HrirLength + k)*2 + 0] = state->mChannels[c].mCoeffs[k][0];
+            out_coeffs[(c*HrirLength + k)*2 + 1] = state->mChannels[c].mCoeffs[k][1];
+        }
+    }
+    *out_irsize = state->mIrSize;
     return 0;
 }
 

@@ -327,6 +327,30 @@ class OracleLib:
         return dict(info=info, field_distance=fd, field_evcount=fe, elev_azcount=az,
                     elev_iroffset=io, coeffs=co, delays=de)
 
+    def hrtf_load_for_rate(self, directory, devrate):
+        """GetLoadedHrtf (core/hrtf.cpp:471-620) on the first .mhr found under `directory` (compiled reference only)"""
+        rc = self.L.oal_hrtf_load_for_rate(directory.encode(), int(devrate))
+        assert rc == 0, f"oal_hrtf_load_for_rate({directory}, {devrate}) = {rc}"
+        info = HrtfInfo()
+        assert self.L.oal_hrtf_info_get(C.byref(info)) == 0
+        return info
+
+    def direct_hrtf_build(self, irsize, per_hrir_min, points, matrix, nchans, xover_freq, order_hf_gain):
+        """DirectHrtfState::build (core/hrtf.cpp:266-366) on the current store (compiled reference only)"""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        mat = np.zeros((len(pts), 16), np.float32)
+        m = np.asarray(matrix, np.float32)
+        mat[:, :m.shape[1]] = m
+        gains = np.zeros(5, np.float32)
+        gains[:len(order_hf_gain)] = order_hf_gain
+        co = np.zeros((nchans, HRIR_LEN, 2), np.float32)
+        hf = np.zeros(nchans, np.float32)
+        ir = C.c_uint32(0)
+        rc = self.L.oal_direct_hrtf_build(C.c_uint32(irsize), C.c_int(1 if per_hrir_min else 0), _fp(pts), _fp(mat), C.c_uint32(len(pts)),
+                                          C.c_uint32(nchans), C.c_float(xover_freq), _fp(gains), _fp(co), _fp(hf), C.byref(ir))
+        assert rc == 0, rc
+        return co, hf, ir.value
+
     def hrtf_get_coeffs(self, ev, az, dist, spread):
         co = np.zeros((HRIR_LEN, 2), np.float32)
         d = (C.c_uint32 * 2)()

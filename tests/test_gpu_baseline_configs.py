@@ -45,6 +45,15 @@ def _oracle():
     return L
 
 
+def set_reference_decoder(L, sc, synth):
+    """the post-process's decoder as the REFERENCE builds it (DirectHrtfState::build on its own store, InitHrtfPanning's
+    first-order layout, alc/panning.cpp:1100-1134) -- what bench.build_scene asks the product to build"""
+    info = L.hrtf_raw()["info"]
+    cc, hf, irsize = L.direct_hrtf_build(info.ir_size, False, synth.AMBI_POINTS_1O, synth.AMBI_MATRIX_1O, 4, 400.0,
+                                         synth.AMBI_ORDER_HF_GAIN_1O)
+    sc.set_direct_hrtf(cc, hf, 400.0 / info.sample_rate, irsize)
+
+
 def build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir=None, num_real=None):
     """bench.build_scene, restated on the reference: same buffers, voices, direct-HRTF decoder."""
     hrtf = config in (3, 5)
@@ -66,10 +75,7 @@ def build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir=None, num
         conv.update(1.0)
         effects.append(conv)
     if hrtf:
-        rng = np.random.default_rng(1234)
-        cc = np.zeros((4, 128, 2), np.float32)
-        cc[:, :64] = rng.uniform(-0.2, 0.2, (4, 64, 2)) * np.exp(-np.arange(64) / 12.0)[None, :, None]
-        sc.set_direct_hrtf(cc, [1.0, 0.8, 0.8, 0.8], 400.0 / 48000.0, 64)
+        set_reference_decoder(L, sc, synth)
     bufs = synth.scene_buffers(config, nvoices)
     handles = [sc.add_buffer(b, ol.FMT_FLOAT) for b in bufs]
     script = synth.SceneScript(config, nvoices, 0)

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from test_gpu_baseline_configs import REAL_MHR, _oracle, build_reference_scene
+from test_gpu_baseline_configs import REAL_MHR, _oracle, build_reference_scene, set_reference_decoder
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -32,10 +32,7 @@ def _chunk_truth(L, synth, bufs, v0, todo):
     """voices [v0, v0 + CHUNK) of the bench scene alone on the reference: RealOut L/R per update and the carried
     accumulator after the last one (float32 results of a 16-voice mix)"""
     sc = ol.Scene(L, sample_rate=48000, num_dry=4, num_real=2, num_sends=0, num_slots=0, wet_channels=4, hrtf=True)
-    rng = np.random.default_rng(1234)
-    cc = np.zeros((4, 128, 2), np.float32)
-    cc[:, :64] = rng.uniform(-0.2, 0.2, (4, 64, 2)) * np.exp(-np.arange(64) / 12.0)[None, :, None]
-    sc.set_direct_hrtf(cc, [1.0, 0.8, 0.8, 0.8], 400.0 / 48000.0, 64)
+    set_reference_decoder(L, sc, synth)
     script = synth.SceneScript(3, CHUNK, v0)
     handles = {}
     for i in range(CHUNK):
