@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--fir", default="mfma", choices=("mfma", "valu"),
                     help="HRTF voices' dual-ear FIR: the matrix pipe in split half precision (the product default) or "
                          "packed fp32 VALU FMAs (OALGPU_CTX_FIR_VALU), for A/B runs")
+    ap.add_argument("--xflags", type=int, default=0, help="experiment bits or-ed into oalgpu_context_desc::flags")
     ap.add_argument("--run", type=int, default=0, metavar="B",
                     help="submit the steps B at a time through oalgpu_mix_update_run (one library call per B updates "
                          "instead of two per update); B must divide --steps and --warmup; 0 = one update per call")
@@ -250,7 +251,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
     torch.cuda.set_device(local_rank)
     api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank,
-                     ctx_flags=oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0)
+                     ctx_flags=(oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0) | args.xflags)
     real_mhr = os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr")
     use_real = args.mhr == "default" and os.path.exists(real_mhr)
     if use_real:

@@ -795,7 +795,7 @@ int oalgpu_mix_direct_hrtf(int device, int mode, float *left, float *right, cons
             uint32_t(irsize), uint32_t(n), dTemp.p);
     else
         LaunchPostDirectHrtfFast(nullptr, dL.p, dR.p, dIn.p, uint32_t(nch), dAcc.p, dSp.p, dHf.p, dCo.p,
-            uint32_t(irsize), uint32_t(n));
+            uint32_t(irsize), uint32_t(n), dTemp.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(dL.download(left, kLine)); HIP_TRY(dR.download(right, kLine));
@@ -1782,7 +1782,7 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
             c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
     else
         LaunchPostDirectHrtfFast(c->stream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
-            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do);
+            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
     HIP_TRY(hipGetLastError());
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
     return OALGPU_OK;
@@ -1930,7 +1930,7 @@ int oalgpu_update_graph_create(oalgpu_context *c, oalgpu_param_block *const *par
         {
             float *left = L.bus + size_t{L.numDry} * kLine;
             LaunchPostDirectHrtfFast(c->postStream, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
-                c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do);
+                c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
             ok(hipGetLastError());
         }
         if(post_process && !L.hrtf && c->decOn)
@@ -1980,7 +1980,7 @@ int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, in
         float *left = L.bus + size_t{L.numDry} * kLine;
         float *right = left + kLine;
         LaunchPostDirectHrtfFast(c->postStream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
-            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do);
+            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
         HIP_TRY(hipGetLastError());
     }
     if(post_process && !L.hrtf && c->decOn)

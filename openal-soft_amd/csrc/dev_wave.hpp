@@ -127,6 +127,55 @@ __device__ __forceinline__ void SplitterScan(SplitterState &st, float *buf, uint
     st.lpZ1 = __shfl(start.a, lastLane); st.lpZ2 = __shfl(start.b, lastLane); st.apZ1 = __shfl(start.c, lastLane);
 }
 
+// The same scan of processHfScale with the structure of its recurrence used: the state (lpZ1, lpZ2, apZ1) evolves
+// by a matrix that is lower triangular in (lpZ1, lpZ2) and decoupled in apZ1 -- [[p, 0, 0], [q, r, 0], [0, 0, s]] --
+// so a run's transition and its powers are four numbers instead of nine ([[p,0],[q,r]]^2 = [[p^2,0],[q(p+r),r^2]]).
+// Same arithmetic per sample (SplitStep), ~20 VGPRs instead of ~50: the HRTF post-process runs it beside the voice
+// kernel, in the 32 registers per SIMD lane two voice wavefronts leave (post_wave.hip).
+struct Tri3 { float p, q, r, s; };
+__device__ __forceinline__ Sp3 TriVec(const Tri3 &m, const Sp3 &v)
+{ return Sp3{m.p * v.a, __builtin_fmaf(m.q, v.a, m.r * v.b), m.s * v.c}; }
+__device__ __forceinline__ void SplitterScanHfTri(SplitterState &st, float *buf, uint32_t n, float hf, uint32_t lane)
+{
+    const float apCoeff = st.coeff, lpCoeff = st.coeff * 0.5f + 0.5f;
+    const uint32_t seg = ((n + 63u) / 64u) | 1u;
+    const uint32_t begin = lane * seg < n ? lane * seg : n;
+    const uint32_t end = (begin + seg < n) ? begin + seg : n;
+    Sp3 ba{1.0f, 0.0f, 0.0f}, bb{0.0f, 1.0f, 0.0f}, bc{0.0f, 0.0f, 1.0f};
+#pragma unroll 1
+    for(uint32_t i = 0; i < seg; ++i)
+    {
+        SplitStep<true>(ba, 0.0f, apCoeff, lpCoeff, hf, 1.0f); SplitStep<true>(bb, 0.0f, apCoeff, lpCoeff, hf, 1.0f);
+        SplitStep<true>(bc, 0.0f, apCoeff, lpCoeff, hf, 1.0f);
+    }
+    Tri3 P{ba.a, ba.b, bb.b, bc.c};
+    Sp3 e{0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for(uint32_t i = begin; i < end; ++i) SplitStep<true>(e, buf[i], apCoeff, lpCoeff, hf, 1.0f);
+    Sp3 s0{st.lpZ1, st.lpZ2, st.apZ1};
+#pragma unroll 1
+    for(int step = 0; step < 6; ++step)
+    {
+        const int d = 1 << step;
+        Sp3 o;
+        o.a = __shfl_up(e.a, d); o.b = __shfl_up(e.b, d); o.c = __shfl_up(e.c, d);
+        const Sp3 mo = TriVec(P, o);
+        if(int(lane) >= d) { e.a += mo.a; e.b += mo.b; e.c += mo.c; }
+        const Sp3 ms = TriVec(P, s0);
+        if(lane & uint32_t(d)) s0 = ms;
+        P = Tri3{P.p * P.p, P.q * (P.p + P.r), P.r * P.r, P.s * P.s};
+    }
+    Sp3 start = s0;
+    {
+        const float pa = __shfl_up(e.a, 1), pb = __shfl_up(e.b, 1), pc = __shfl_up(e.c, 1);
+        if(lane > 0) { start.a += pa; start.b += pb; start.c += pc; }
+    }
+#pragma unroll 1
+    for(uint32_t i = begin; i < end; ++i) buf[i] = SplitStep<true>(start, buf[i], apCoeff, lpCoeff, hf, 1.0f);
+    const int lastLane = int((n - 1u) / seg);
+    st.lpZ1 = __shfl(start.a, lastLane); st.lpZ2 = __shfl(start.b, lastLane); st.apZ1 = __shfl(start.c, lastLane);
+}
+
 // ---- dual-ear FIR, packed over the ears -------------------------------------------------------
 // acc[r] = (L,R) of output frame R*lane + r.  xw points at the x' entry of the lane's first
 // frame; co16[b] = taps 8b..8b+7 as (Coeffs[j][0], Coeffs[j][1]) pairs, one s_load_dwordx16

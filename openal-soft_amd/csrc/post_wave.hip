@@ -1,17 +1,20 @@
 // HRTF post-process of one update, FAST mode: DeviceBase::Process(HrtfPostProcess),
 // alc/alu.cpp:289-298 -> MixDirectHrtf_* (MixDirectHrtfBase, core/mixer/hrtfbase.h:91-133).
 //
-// One workgroup, one wavefront per dry (ambisonic) channel -- channels wrap around when there are
-// more than 16.  Per channel:
-//   1. BandSplitter::processHfScale (core/filters/splitter.cpp:65-97) is a 3-state linear
-//      recurrence; the wavefront runs it as a block scan (each lane owns a run of samples, block
-//      start states by a 6-step Kogge-Stone scan over the lanes) instead of 1024 serial steps;
-//   2. the channel's decoder HRIR (same input for both ears) is applied with the ear-packed
-//      v_pk_fma_f32 FIR of voice_wave.hip: lane l owns output frames [18l, 18l+18) of the
-//      1152-frame accumulator, coefficients come through the scalar cache.
-// Then the per-wave accumulators are summed in channel order together with the carried
-// HrtfAccumData, the first n frames are added to RealOut L/R, and the accumulator is shifted
-// (hrtfbase.h:119-132).  EXACT mode keeps the term-by-term kernel in percall_kernels.hip.
+// The post-process runs on the context's post stream BESIDE the next update's voice kernel, which fills the machine
+// exactly once (two workgroups per CU, 2 x 240 of 512 VGPRs per SIMD lane, 2 x 58 of 128 LDS granules): whatever
+// does not fit into what is left of a CU waits until a voice workgroup leaves one and then holds that CU against
+// the next launch.  Round 2's form -- ONE workgroup of a wavefront per channel with 147 KB of LDS and a
+// register-tiled FIR -- was such an intruder (16 us with a 64-tap decoder, 38 us with the 87 taps InitHrtfPanning's
+// real decoder has).  It is now three launches of small pieces that fit into the gaps (<= 32 VGPRs, <= 6.4 KB LDS):
+//   PostSplitKernel   one wavefront per dry (ambisonic) channel: BandSplitter::processHfScale
+//                     (core/filters/splitter.cpp:65-97), a 3-state linear recurrence, as a block scan;
+//   PostFirKernel     one wavefront per 16 output frames: every channel's decoder HRIR (the same input for both
+//                     ears, hrtfbase.h:104-117) from LDS copies of the channels' windows and coefficients;
+//                     lane = (frame, ear, half of the taps);
+//   PostShiftKernel   carried HrtfAccumData + the channels' sum -> RealOut L/R, and the accumulator's shift
+//                     (hrtfbase.h:119-132).
+// EXACT mode keeps the term-by-term kernel in percall_kernels.hip.
 #include "dev_wave.hpp"
 
 #pragma clang fp contract(off)
@@ -19,94 +22,120 @@
 namespace oalgpu {
 namespace {
 
-constexpr int kPostMaxWaves = 16;
-constexpr int kPostR = 18;                                  // 64 * 18 = 1152 = kLine + kHrirLen
-constexpr int kPostFrames = kLine + kHrirLen;
+constexpr int kPostFrames = kLine + kHrirLen;             // HrtfAccumData: 1152 frames
+constexpr int kPostGroup = 4;                               // channels staged at a time
 
-struct PostWaveLds {
-    union {
-        float x[128 + kPostFrames];             // x[k] = filtered channel sample k - 128, zero padded
-        f2 dump[kPostFrames];                   // end of kernel: this wave's accumulator
-    };
-};
-
-template<int TAPS>
-__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kPostMaxWaves * 64) PostDirectHrtfKernel(float *__restrict__ left,
-    float *__restrict__ right, const float *__restrict__ in, uint32_t nch, float *__restrict__ accum,
-    SplitterState *__restrict__ splitters, const float *__restrict__ hfscales, const float *__restrict__ chanCoeffs,
-    uint32_t n)
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) PostSplitKernel(const float *__restrict__ in, float *__restrict__ xf,
+    SplitterState *__restrict__ splitters, const float *__restrict__ hfscales, uint32_t n)
 {
-    __shared__ PostWaveLds sm[kPostMaxWaves];
-    const uint32_t t = threadIdx.x, lane = t & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const uint32_t nwaves = blockDim.x >> 6;
-    PostWaveLds &w = sm[wave];
-
-    f2 acc[kPostR];
-#pragma unroll
-    for(int r = 0; r < kPostR; ++r) acc[r] = f2{0.0f, 0.0f};
-
-    for(uint32_t c = wave; c < nch; c += nwaves)
-    {
-        WaveSync();
-        for(uint32_t k = lane; k < 128u; k += 64) w.x[k] = 0.0f;
-        for(uint32_t k = lane; k < uint32_t(kPostFrames); k += 64) w.x[128 + k] = (k < n) ? in[size_t{c} * kLine + k] : 0.0f;
-        WaveSync();
-        SplitterState st = splitters[c];
-        SplitterScan<true>(st, w.x + 128, n, hfscales[c], 1.0f, lane);
-        if(lane == 0) splitters[c] = st;
-        WaveSync();
-        cf16 *co = (cf16*)(uintptr_t)(chanCoeffs + size_t{c} * kHrirLen * 2);
-        FirMainPk<kPostR, TAPS>(acc, &w.x[128 + kPostR * lane], co);
-    }
-
+    __shared__ float x[kLine + 64];
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    for(uint32_t k = lane; k < uint32_t(kLine); k += 64) x[k] = (k < n) ? in[size_t{c} * kLine + k] : 0.0f;
     WaveSync();
-#pragma unroll
-    for(int r = 0; r < kPostR; ++r) w.dump[kPostR * lane + r] = acc[r];
-    __syncthreads();
-    // total[o] = carried accumulator + channel contributions (wave order); outputs and the shift
-    const f2 *acc2 = reinterpret_cast<const f2*>(accum);
-    f2 *accOut = reinterpret_cast<f2*>(accum);
-    f2 tot[2];
-    uint32_t oidx[2];
-    int cnt = 0;
-    for(uint32_t o = t; o < uint32_t(kPostFrames); o += blockDim.x)
+    SplitterState st = splitters[c];
+    SplitterScanHfTri(st, x, n, hfscales[c], lane);
+    if(lane == 0) splitters[c] = st;
+    WaveSync();
+    for(uint32_t k = lane; k < uint32_t(kLine); k += 64) xf[size_t{c} * kLine + k] = (k < n) ? x[k] : 0.0f;
+}
+
+// tmp[o] = sum over the channels c and the taps t < taps of coeffs[c][t] * x_c[o - t], o in [16 b, 16 b + 16) (kPostBlock = 16)
+template<int kPostBlock /* output frames per workgroup: 8 or 16 */>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) PostFirKernel(const float *__restrict__ xf, uint32_t nch, const float *__restrict__ chanCoeffs,
+    uint32_t taps /* multiple of 16, <= 128 */, float *__restrict__ tmp)
+{
+    __shared__ float xs[kPostGroup][kHrirLen + kPostBlock];            // x_c[16 b - 128 + j]
+    __shared__ float cs[kPostGroup][kHrirLen][2];
+    constexpr uint32_t kSplit = 32u / uint32_t(kPostBlock);       // the taps go over 2 or 4 groups of lanes
+    const uint32_t lane = threadIdx.x, f = lane & uint32_t(kPostBlock - 1), e = (lane / uint32_t(kPostBlock)) & 1u,
+        hq = lane / uint32_t(2 * kPostBlock);                      // frame, ear, part of the taps
+    const int32_t base = int32_t(blockIdx.x) * kPostBlock - kHrirLen;
+    const uint32_t half = taps / kSplit;
+    float acc = 0.0f;
+    for(uint32_t c0 = 0; c0 < nch; c0 += kPostGroup)
     {
-        f2 s = acc2[o];
-        for(uint32_t ww = 0; ww < nwaves && ww < nch; ++ww) { const f2 v = sm[ww].dump[o]; s.x += v.x; s.y += v.y; }
-        if(o < n) { left[o] = left[o] + s.x; right[o] = right[o] + s.y; }
-        tot[cnt] = s; oidx[cnt] = o; ++cnt;
+        const uint32_t gc = (nch - c0 < uint32_t(kPostGroup)) ? nch - c0 : uint32_t(kPostGroup);
+        __syncthreads();
+        for(uint32_t c = 0; c < gc; ++c)
+        {   // (no index arithmetic with divisions: the kernel has to stay inside 32 VGPRs)
+            for(uint32_t j = lane; j < uint32_t(kHrirLen + kPostBlock); j += 64)
+            {
+                const int32_t fr = base + int32_t(j);
+                xs[c][j] = (fr >= 0 && fr < kLine) ? xf[size_t{c0 + c} * kLine + uint32_t(fr)] : 0.0f;
+            }
+            for(uint32_t r = lane; r < taps * 2u; r += 64) (&cs[c][0][0])[r] = chanCoeffs[size_t{c0 + c} * kHrirLen * 2 + r];
+        }
+        __syncthreads();
+        for(uint32_t c = 0; c < gc; ++c)
+        {
+            const float *xw = &xs[c][kHrirLen + f] - hq * half;       // x_c[o - t], t = hq * half + k
+            const float *cw = &cs[c][hq * half][e];
+            // (four taps in flight: the kernel has to fit into the 32 VGPRs per SIMD lane two voice wavefronts leave)
+#pragma unroll 1
+            for(uint32_t k = 0; k < half; k += 4)
+            {
+                const float c0 = cw[2u * k], c1 = cw[2u * k + 2u], c2 = cw[2u * k + 4u], c3 = cw[2u * k + 6u];
+                const float x0 = xw[-int32_t(k)], x1 = xw[-int32_t(k) - 1], x2 = xw[-int32_t(k) - 2], x3 = xw[-int32_t(k) - 3];
+                acc = __builtin_fmaf(c0, x0, acc); acc = __builtin_fmaf(c1, x1, acc);
+                acc = __builtin_fmaf(c2, x2, acc); acc = __builtin_fmaf(c3, x3, acc);
+            }
+        }
+    }
+    if constexpr (kSplit == 4u) acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if(lane < uint32_t(2 * kPostBlock)) tmp[(size_t{blockIdx.x} * kPostBlock + f) * 2u + e] = acc;
+}
+
+__global__ void __launch_bounds__(256) PostShiftKernel(float *__restrict__ left, float *__restrict__ right, float *__restrict__ accum,
+    const float *__restrict__ tmp, uint32_t n)
+{
+    const uint32_t t = threadIdx.x;
+    const f2 *acc2 = reinterpret_cast<const f2*>(accum), *tmp2 = reinterpret_cast<const f2*>(tmp);
+    f2 *accOut = reinterpret_cast<f2*>(accum);
+    constexpr int kPer = (kPostFrames + 255) / 256;
+    f2 tot[kPer];
+#pragma unroll
+    for(int k = 0; k < kPer; ++k)
+    {
+        const uint32_t o = t + 256u * uint32_t(k);
+        f2 s = {0.0f, 0.0f};
+        if(o < uint32_t(kPostFrames))
+        {
+            const f2 a = acc2[o], b = tmp2[o];
+            s = f2{a.x + b.x, a.y + b.y};
+            if(o < n) { left[o] = left[o] + s.x; right[o] = right[o] + s.y; }
+        }
+        tot[k] = s;
     }
     __syncthreads();                           // every thread has read the old accumulator
-    // hrtfbase.h:127-132: frames [n, n+128) move to the front, the following n frames are cleared,
-    // anything beyond stays
-    for(int k = 0; k < cnt; ++k)
+    // hrtfbase.h:127-132: frames [n, n+128) move to the front, the following n frames are cleared, anything beyond stays
+#pragma unroll
+    for(int k = 0; k < kPer; ++k)
     {
-        const uint32_t o = oidx[k];
-        if(o >= n && o < n + kHrirLen) accOut[o - n] = tot[k];
+        const uint32_t o = t + 256u * uint32_t(k);
+        if(o >= n && o < n + kHrirLen && o < uint32_t(kPostFrames)) accOut[o - n] = tot[k];
     }
     __syncthreads();
-    for(int k = 0; k < cnt; ++k)
+#pragma unroll
+    for(int k = 0; k < kPer; ++k)
     {
-        const uint32_t o = oidx[k];
-        if(o >= uint32_t(kHrirLen) && o < kHrirLen + n) accOut[o] = f2{0.0f, 0.0f};
+        const uint32_t o = t + 256u * uint32_t(k);
+        if(o >= uint32_t(kHrirLen) && o < kHrirLen + n && o < uint32_t(kPostFrames)) accOut[o] = f2{0.0f, 0.0f};
     }
 }
 
 } // namespace
 
+// temp: nch x 1024 filtered channels, then 1152 x 2 channel sums
 void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, float *accum,
-    SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n)
+    SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n, float *temp)
 {
-    const uint32_t waves = nch < uint32_t(kPostMaxWaves) ? nch : uint32_t(kPostMaxWaves);
-    // at least as many threads as needed to cover the 1152 frames in two passes
-    const uint32_t threads = (waves < 9u ? 9u : waves) * 64u;
-    if(irsize <= 64)
-        hipLaunchKernelGGL(PostDirectHrtfKernel<64>, dim3(1), dim3(threads), 0, s, left, right, in, nch, accum, splitters,
-            hfscales, chanCoeffs, n);
-    else
-        hipLaunchKernelGGL(PostDirectHrtfKernel<128>, dim3(1), dim3(threads), 0, s, left, right, in, nch, accum, splitters,
-            hfscales, chanCoeffs, n);
+    float *xf = temp, *tmp = temp + size_t{nch} * kLine;
+    const uint32_t taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
+    hipLaunchKernelGGL(PostSplitKernel, dim3(nch), dim3(64), 0, s, in, xf, splitters, hfscales, n);
+    // (16 frames per workgroup: 47.5 us per step against 49.0 with 8 and 50.5 with round 2's single workgroup, one box)
+    hipLaunchKernelGGL(PostFirKernel<16>, dim3(kPostFrames / 16), dim3(64), 0, s, xf, nch, chanCoeffs, taps, tmp);
+    hipLaunchKernelGGL(PostShiftKernel, dim3(1), dim3(256), 0, s, left, right, accum, tmp, n);
 }
 
 } // namespace oalgpu
