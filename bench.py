@@ -223,9 +223,6 @@ def main():
     ap.add_argument("--mhr", default="default", choices=("default", "synth"),
                     help="HRTF data set: the reference's Default HRTF.mhr (tests/golden/default_hrtf.mhr) or the synthetic one")
     ap.add_argument("--repeats", type=int, default=5, help="extra K-step blocks timed after the contract's one (spread)")
-    ap.add_argument("--graph", type=int, default=0, metavar="G",
-                    help="issue the steps as hipGraphs of G (even) updates each (oalgpu_update_graph_*): one host launch per G "
-                         "steps; configs 2 and 3 on one GPU; G must divide --steps and --warmup")
     ap.add_argument("--fir", default="mfma", choices=("mfma", "valu"),
                     help="HRTF voices' dual-ear FIR: the matrix pipe in split half precision (the product default) or "
                          "packed fp32 VALU FMAs (OALGPU_CTX_FIR_VALU), for A/B runs")
@@ -280,11 +277,6 @@ def main():
     # long run needs neither gigabytes of records nor minutes of host-side preparation
     total_steps = args.warmup + 2 * args.steps
     nblocks = min(total_steps, 96)
-    G = args.graph
-    if G:
-        if world > 1 or args.config not in (2, 3) or G % 2 or args.steps % G or args.warmup % G:
-            raise SystemExit("--graph G: one GPU, config 2 or 3, G even and a divisor of --steps and --warmup")
-        nblocks = G * max(1, 96 // G)
     blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(nblocks)]
 
     # N > 1: the library's own multi-GPU path (RCCL inside liboalgpu.so: oalgpu_comm_init, then every
@@ -304,20 +296,14 @@ def main():
         dist.broadcast(idt, src=0)
         sc.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
-    graphs = [sc.update_graph(blocks[j:j + G], UPDATE_SAMPLES, post) for j in range(0, nblocks, G)] if G else []
-
     B = args.run
-    if B and (G or args.steps % B or args.warmup % B):
-        raise SystemExit("--run B: B must divide --steps and --warmup, and excludes --graph")
+    if B and (args.steps % B or args.warmup % B):
+        raise SystemExit("--run B: B must divide --steps and --warmup")
 
     def step(k):
         if B:                        # B updates per library call
             if k % B == 0:
                 sc.mix_run([blocks[(k + j) % nblocks] for j in range(B)], UPDATE_SAMPLES, post)
-            return
-        if G:                        # the same steps, G at a time: graph j covers blocks [jG, jG + G)
-            if k % G == 0:
-                graphs[(k // G) % len(graphs)].launch()
             return
         sc.apply_block(blocks[k % nblocks])
         sc.mix(UPDATE_SAMPLES, post_process=post)
@@ -332,8 +318,6 @@ def main():
     # pipeline full, GPU clocks up) before the W warm-up and the K timed steps the contract names;
     # without it a short run (K = 50 is 3 ms) measures the clock ramp: 58.9 vs 54.9 us per step.
     preroll = max(0, 400 - args.warmup)
-    if G:
-        preroll -= preroll % G
     if B:
         preroll -= preroll % B
     # (no fence between pre-roll and warm-up: a drained pipeline and an idle GPU right before the W warm-up
@@ -446,7 +430,7 @@ def main():
                                    + {4: ", v%5 sends into 4 reverb slots", 5: ", one send into a 65536-tap convolution slot"}.get(args.config, "")
                                    + "), 25% filtered, every 4th voice moving",
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
-                       "preroll_steps": preroll, "update_graph": G, "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
+                       "preroll_steps": preroll, "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
                        "e2e_ms_per_update": e2e_ms, "e2e_ms_per_update_p90": e2e_p90_ms if e2e_ms is not None else None,
                        "e2e_note": "one update alone through the C-ABI from host memory: oalgpu_voice_set_params of the "
                                    f"{len(moving)} moving voices (host biquad design + H2D) + oalgpu_mix_update + "

@@ -561,23 +561,6 @@ uint32_t oalgpu_converter_available_out(const oalgpu_converter *conv, uint32_t s
 int  oalgpu_converter_convert(oalgpu_converter *conv, const void **src, uint32_t *src_frames, void *dst,
     uint32_t dst_frames);
 
-/* ---- a run of updates as ONE hipGraph --------------------------------------------------------------------
- * `count` (even) consecutive updates -- update i applies param_blocks[i] (the array or an entry may be NULL:
- * no parameter change), then does what oalgpu_mix_update(samples_to_do, post_process) does -- captured from
- * the context's two streams into one graph: inside it the voice kernel of update i+1 still runs beside the
- * reduction and post-process of update i, and the host pays one launch for the run instead of ~8 runtime
- * calls per update (offline / loopback rendering, where the parameter blocks of the coming updates are known).
- * Kernel arguments are frozen at capture; what changes between updates must live in device memory (voice
- * state and parameter blocks do).  The effects' launch arguments advance on the host every update, so
- * contexts with an effect attached to a slot are refused, as are sharded contexts (oalgpu_comm_init) and
- * caller-owned streams.  The parameter blocks must outlive the graph.  oalgpu_update_graph_launch is
- * asynchronous on the context's main stream and may be mixed freely with oalgpu_mix_update. */
-typedef struct oalgpu_update_graph oalgpu_update_graph;
-int  oalgpu_update_graph_create(oalgpu_context *ctx, oalgpu_param_block *const *param_blocks, uint32_t count,
-    uint32_t samples_to_do, int post_process, oalgpu_update_graph **out);
-int  oalgpu_update_graph_launch(oalgpu_update_graph *graph);
-void oalgpu_update_graph_destroy(oalgpu_update_graph *graph);
-
 /* Name of the HIP kernel oalgpu_mix_voices launches for this context (as a profiler shows it). */
 const char *oalgpu_voice_kernel_name(oalgpu_context *ctx);
 

@@ -178,6 +178,8 @@ struct oalgpu_context {
         int32_t position{0}; uint32_t frac{0}, step{0};        // mPosition / mPositionFrac / mStep
         int state{OALGPU_VOICE_PLAYING}; bool hasBuffer{true}; // mPlayState / mCurrentBuffer != nullptr
         char *pinned[2]{nullptr, nullptr}; hipEvent_t copied[2]{nullptr, nullptr}; uint32_t slot{0};
+        size_t allocBytes{0};                      // of the device buffer and each pinned one
+        bool retired{false};                       // its voice slot became another source: the entry may be reused
     };
     std::vector<CbVoice> cbVoices;
     std::vector<int32_t> cbOfVoice;                // [voice] index into cbVoices, -1 = not a callback source
@@ -202,7 +204,9 @@ void RetireCallbackVoice(oalgpu_context *c, uint32_t voice)
 {
     if(voice < c->cbOfVoice.size() && c->cbOfVoice[voice] >= 0)
     {
-        c->cbVoices[size_t(c->cbOfVoice[voice])].state = OALGPU_VOICE_STOPPED;
+        auto &cb = c->cbVoices[size_t(c->cbOfVoice[voice])];
+        cb.state = OALGPU_VOICE_STOPPED;
+        cb.retired = true;                          // buffer slot, device and pinned memory wait for the next callback source
         c->cbOfVoice[voice] = -1;
     }
 }
@@ -1691,36 +1695,81 @@ int oalgpu_voice_init_callback(oalgpu_context *c, uint32_t voice, int fmt_type, 
     if(!c || !fn || voice >= c->L.numVoices || fmt_type < 0 || fmt_type > OALGPU_FMT_ALAW || position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: bad arguments");
     if(c->comm) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: not on a sharded context");
-    if(c->cbOfVoice[voice] >= 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: the voice already is a callback source");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
     if(int rc = UseDevice(c->desc.device)) return rc;
-    oalgpu_context::CbVoice cb;
-    cb.voice = voice; cb.fn = fn; cb.user = userptr;
-    cb.frameBytes = bytesPer[fmt_type];
-    cb.capacityFrames = uint32_t(kLine + 256) * 10u + uint32_t(kMaxEdge);      // MixerLineSize*MaxPitch + MaxResamplerEdge, al/buffer.cpp:474
-    const size_t nbytes = size_t{cb.capacityFrames} * cb.frameBytes;
-    cb.data.assign(nbytes, 0);
-    cb.frac = position_frac;
-    void *dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, nbytes + 16));
-    HIP_TRY(hipMemset(dev, 0, nbytes + 16));
-    for(int k = 0; k < 2; ++k)
-    {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&cb.pinned[k]), nbytes, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&cb.copied[k], hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(cb.copied[k], c->stream));
+    if(c->cbOfVoice[voice] >= 0)
+    {   // the voice is a callback source already: only one that has ended may start over
+        if(c->cbVoices[size_t(c->cbOfVoice[voice])].state != OALGPU_VOICE_STOPPED)
+            return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: the voice already is a playing callback source");
+        RetireCallbackVoice(c, voice);
     }
-    const uint32_t h = c->numBuffers++;
-    c->bufferData[h] = dev;
-    c->bufferLoopLen[h] = 0u;
-    cb.buffer = int32_t(h);
+    const uint32_t capacityFrames = uint32_t(kLine + 256) * 10u + uint32_t(kMaxEdge);      // MixerLineSize*MaxPitch + MaxResamplerEdge, al/buffer.cpp:474
+    const size_t nbytes = size_t{capacityFrames} * bytesPer[fmt_type];
+    // a retired entry's buffer-table slot, device buffer, pinned staging and events serve the new source
+    int32_t reuse = -1;
+    for(size_t j = 0; j < c->cbVoices.size(); ++j)
+        if(c->cbVoices[j].retired) { reuse = int32_t(j); break; }
+    if(reuse < 0 && c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    oalgpu_context::CbVoice fresh;
+    oalgpu_context::CbVoice &cb = reuse >= 0 ? c->cbVoices[size_t(reuse)] : fresh;
+    if(reuse >= 0)
+    {
+        if(int rc = oalgpu_sync(c)) return rc;                     // nothing in flight reads the old source's data any more
+        if(cb.allocBytes < nbytes)
+        {   // a wider sample type than the entry was made for
+            (void)hipFree(c->bufferData[size_t(cb.buffer)]); c->bufferData[size_t(cb.buffer)] = nullptr;
+            for(int k = 0; k < 2; ++k) { (void)hipHostFree(cb.pinned[k]); cb.pinned[k] = nullptr; }
+            cb.allocBytes = 0;
+        }
+    }
+    struct Undo {       // what a failure below must not leave behind
+        oalgpu_context *c; oalgpu_context::CbVoice *cb; void *dev{nullptr}; bool armed{true};
+        ~Undo()
+        {
+            if(!armed) return;
+            if(dev) (void)hipFree(dev);
+            for(int k = 0; k < 2; ++k)
+            {
+                if(cb->pinned[k]) { (void)hipHostFree(cb->pinned[k]); cb->pinned[k] = nullptr; }
+                if(cb->copied[k]) { (void)hipEventDestroy(cb->copied[k]); cb->copied[k] = nullptr; }
+            }
+            cb->allocBytes = 0;
+        }
+    } undo{c, &cb};
+    void *dev = cb.allocBytes ? c->bufferData[size_t(cb.buffer)] : nullptr;
+    if(!cb.allocBytes)
+    {
+        HIP_TRY(hipMalloc(&dev, nbytes + 16));
+        undo.dev = dev;
+        for(int k = 0; k < 2; ++k)
+        {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&cb.pinned[k]), nbytes, hipHostMallocDefault));
+            if(!cb.copied[k]) HIP_TRY(hipEventCreateWithFlags(&cb.copied[k], hipEventDisableTiming));
+        }
+    }
+    HIP_TRY(hipMemset(dev, 0, nbytes + 16));
+    for(int k = 0; k < 2; ++k) HIP_TRY(hipEventRecord(cb.copied[k], c->stream));
+    const uint32_t h = reuse >= 0 ? uint32_t(cb.buffer) : c->numBuffers;
     // one frame long until the first update hands the voice its window (a static buffer has at least one)
     BufferItem item{dev, fmt_type, 1u, 1u, 0u, 0u, 0};
     HIP_TRY(hipMemcpy(c->buffers.p + h, &item, sizeof(item), hipMemcpyHostToDevice));
+    undo.armed = false;
+    if(reuse < 0) ++c->numBuffers;
+    c->bufferData[h] = dev;
+    c->bufferLoopLen[h] = 0u;
+    cb.voice = voice; cb.fn = fn; cb.user = userptr; cb.buffer = int32_t(h);
+    cb.frameBytes = bytesPer[fmt_type]; cb.capacityFrames = capacityFrames;
+    if(!cb.allocBytes) cb.allocBytes = nbytes;
+    cb.data.assign(nbytes, 0);
+    cb.numBlocks = 0; cb.blockOffset = 0; cb.stopped = false; cb.position = 0; cb.frac = position_frac; cb.step = 0;
+    cb.state = OALGPU_VOICE_PLAYING; cb.hasBuffer = true; cb.slot = 0; cb.retired = false;
     c->initPending.push_back(VoiceInitRecord{voice, int32_t(h), 0, 0, position_frac, 0});
-    c->cbOfVoice[voice] = int32_t(c->cbVoices.size());
-    c->cbVoices.push_back(std::move(cb));
+    if(reuse >= 0) c->cbOfVoice[voice] = reuse;
+    else
+    {
+        c->cbOfVoice[voice] = int32_t(c->cbVoices.size());
+        c->cbVoices.push_back(std::move(fresh));
+    }
     return OALGPU_OK;
 }
 
@@ -1851,120 +1900,6 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
 }
 
 void *oalgpu_post_stream(oalgpu_context *c) { return c ? static_cast<void*>(c->postStream) : nullptr; }
-
-/* ---- a run of updates as ONE hipGraph --------------------------------------------------------------------
- * `count` consecutive updates -- update i applies param_blocks[i] (NULL entries: none), then does what
- * oalgpu_mix_update(samples_to_do, post_process) does -- captured from the context's two streams into one
- * graph: the voice kernel of update i+1 still runs beside the reduction and the post-process of update i
- * (fork / join through events of the graph's own), but the host pays ONE launch for the whole run instead
- * of ~8 runtime calls per update.  Kernel arguments are frozen at capture: everything the kernels read that
- * changes between updates lives in device memory (voice state, parameter blocks), except the effects'
- * (delay-line offsets, ring positions, pipeline states advance on the host) -- contexts with an effect
- * attached to a slot, sharded contexts and caller-owned streams are refused. */
-struct oalgpu_update_graph {
-    oalgpu_context *ctx{nullptr};
-    hipGraph_t graph{nullptr};
-    hipGraphExec_t exec{nullptr};
-    hipEvent_t evVoice[2]{nullptr, nullptr}, evReduce[2]{nullptr, nullptr}, evJoin{nullptr};
-    uint32_t count{0};
-};
-
-void oalgpu_update_graph_destroy(oalgpu_update_graph *g)
-{
-    if(!g) return;
-    if(g->ctx) { (void)hipSetDevice(g->ctx->desc.device); (void)oalgpu_sync(g->ctx); }
-    if(g->exec) (void)hipGraphExecDestroy(g->exec);
-    if(g->graph) (void)hipGraphDestroy(g->graph);
-    for(hipEvent_t e : {g->evVoice[0], g->evVoice[1], g->evReduce[0], g->evReduce[1], g->evJoin}) if(e) (void)hipEventDestroy(e);
-    delete g;
-}
-
-int oalgpu_update_graph_create(oalgpu_context *c, oalgpu_param_block *const *param_blocks, uint32_t count,
-    uint32_t samples_to_do, int post_process, oalgpu_update_graph **out)
-{
-    if(!c || !out || count == 0 || (count & 1u) || count > 4096 || samples_to_do == 0 || samples_to_do > kLine)
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: count must be even and 1 <= samples_to_do <= 1024");
-    *out = nullptr;
-    if(!c->cbVoices.empty())
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: a callback source's user function runs on the host every update");
-    if(!(c->useWave && c->ownStream) || c->serialOnly || c->comm || c->timing)
-        return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: needs an unsharded FAST context (wavefront kernel) on its own streams, timing off");
-    for(uint32_t s = 0; s < c->L.numSlots; ++s)
-        if(c->slotConv[s] || c->slotReverb[s] || c->slotEffect[s])
-            return Fail(OALGPU_ERR_INVALID, "oalgpu_update_graph_create: an effect's launch arguments advance on the host every update; detach the slots' effects");
-    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(post_process && c->L.hrtf && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
-    if(int rc = UseDevice(c->desc.device)) return rc;
-    if(int rc = FlushInits(c)) return rc;
-    if(int rc = oalgpu_sync(c)) return rc;
-    std::unique_ptr<oalgpu_update_graph, void(*)(oalgpu_update_graph*)> g(new oalgpu_update_graph, oalgpu_update_graph_destroy);
-    g->ctx = c; g->count = count;
-    for(hipEvent_t *e : {&g->evVoice[0], &g->evVoice[1], &g->evReduce[0], &g->evReduce[1], &g->evJoin})
-        HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventDisableSystemFence));
-
-    const DeviceLayout &L0 = c->L;
-    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t err = hipSuccess;
-    auto ok = [&](hipError_t e) { if(err == hipSuccess && e != hipSuccess) err = e; return err == hipSuccess; };
-    for(uint32_t i = 0; i < count && err == hipSuccess; ++i)
-    {
-        const uint32_t p = (c->parity + i) & 1u;
-        DeviceLayout L = L0;
-        L.partHrtf = c->partHrtfBuf[p];
-        if(L.streams) L.partLines = c->partLinesBuf[p];
-        if(param_blocks && param_blocks[i])
-        {
-            LaunchApplyParams(c->stream, L0, param_blocks[i]->recs.p, param_blocks[i]->count);
-            ok(hipGetLastError());
-        }
-        // this update's partial buses were last read by the reduction of two updates ago (the first two
-        // updates of the graph start from a drained context)
-        if(i >= 2) ok(hipStreamWaitEvent(c->stream, g->evReduce[p], 0));
-        ok(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg()));
-        ok(hipEventRecord(g->evVoice[p], c->stream));
-        ok(hipStreamWaitEvent(c->postStream, g->evVoice[p], 0));        // the post stream joins the capture here
-        LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum && L.hrtf, true);
-        ok(hipGetLastError());
-        ok(hipEventRecord(g->evReduce[p], c->postStream));
-        if(post_process && L.hrtf)
-        {
-            float *left = L.bus + size_t{L.numDry} * kLine;
-            LaunchPostDirectHrtfFast(c->postStream, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
-                c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
-            ok(hipGetLastError());
-        }
-        if(post_process && !L.hrtf && c->decOn)
-        {
-            LaunchBFormatDecode(c->postStream, c->exact, L.bus + size_t{L.numDry} * kLine, L.bus, c->decSplit.p, c->decBands.p,
-                c->decGainsHf.p, c->decDual ? c->decGainsLf.p : nullptr, L.numDry, c->decOut, samples_to_do);
-            ok(hipGetLastError());
-        }
-    }
-    // the post stream's branch rejoins the stream the capture began on
-    ok(hipEventRecord(g->evJoin, c->postStream));
-    ok(hipStreamWaitEvent(c->stream, g->evJoin, 0));
-    hipGraph_t graph = nullptr;
-    const hipError_t endErr = hipStreamEndCapture(c->stream, &graph);
-    g->graph = graph;
-    if(err != hipSuccess) return Fail(OALGPU_ERR_HIP, std::string("oalgpu_update_graph_create (capture): ") + hipGetErrorString(err));
-    HIP_TRY(endErr);
-    HIP_TRY(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
-    *out = g.release();
-    return OALGPU_OK;
-}
-
-int oalgpu_update_graph_launch(oalgpu_update_graph *g)
-{
-    if(!g || !g->ctx || !g->exec) return Fail(OALGPU_ERR_INVALID, "null argument");
-    oalgpu_context *c = g->ctx;
-    if(int rc = UseDevice(c->desc.device)) return rc;
-    if(int rc = FlushInits(c)) return rc;
-    // whatever a pipelined oalgpu_mix_update left on the post stream comes first: the graph's first two
-    // updates take both partial-bus buffers as free
-    if(int rc = JoinPost(c)) return rc;
-    HIP_TRY(hipGraphLaunch(g->exec, c->stream));
-    return OALGPU_OK;   // the graph ends joined on the main stream: nothing is left pending on the post stream
-}
 
 int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, int post_process)
 {

@@ -25,6 +25,7 @@ struct oalgpu_reverb {
     DevBuf<oalgpu_reverb_pipeline> pipe;
     DevBuf<RvPipeState> state;
     DevBuf<unsigned long long> stamps;      // measurement aid (oalgpu_reverb_debug_enable_phase_times)
+    bool upmixStale{false};                 // set_upmix changed the output mode: the panning gains in use were designed for the other one
     RvLayout L{};
 };
 
@@ -104,6 +105,7 @@ int oalgpu_reverb_create(int device, uint32_t sample_rate, uint32_t num_out_line
 int oalgpu_reverb_set_upmix(oalgpu_reverb *r, const float order_scales[2], const float *first_order_up, float xover_norm)
 {
     if(!r) return Fail(OALGPU_ERR_INVALID, "null argument");
+    r->upmixStale = true;                   // process() is refused until an update() has designed gains for this mode
     if(!order_scales || !first_order_up)
     {
         r->host.upmix = false; r->L.upmix = 0u;
@@ -150,6 +152,7 @@ int oalgpu_reverb_update(oalgpu_reverb *r, const oalgpu_reverb_props *props, flo
     r->host = trial;
     r->dirty[r->host.params.current_pipeline] = true;
     if(full) r->dirty[!r->host.params.current_pipeline] = true;
+    r->upmixStale = false;
     return OALGPU_OK;
 }
 
@@ -176,6 +179,7 @@ int oalgpu_reverb_set_params(oalgpu_reverb *r, const oalgpu_reverb_params *param
     const bool full = r->host.install(*params);
     r->dirty[r->host.params.current_pipeline] = true;
     if(full) r->dirty[!r->host.params.current_pipeline] = true;
+    r->upmixStale = false;
     return OALGPU_OK;
 }
 
@@ -202,6 +206,8 @@ static int PrepareBlock(oalgpu_reverb *r, const float *wet_in_dev, float *out_li
         return Fail(OALGPU_ERR_NO_DEVICE, "oalgpu_reverb_process: parameter-only instance (created with device < 0)");
     if(r->host.params.pipeline_state == OALGPU_REVERB_DEVICE_CLEAR)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_process: no update() yet (the delay offsets are still zero)");
+    if(r->upmixStale)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_process: oalgpu_reverb_set_upmix takes effect with an update(); none has followed it");
     if(int rc = UseDevice(r->device)) return rc;
     const ReverbHost::Step st = r->host.begin(n);
     if(st.oldMode == 2 || st.oldMode == 3) r->dirty[!st.current] = true;   // targets dropped / scalars cleared

@@ -369,7 +369,8 @@ class Scene:
         return v
 
     # callback sources: `stream` (bytes-like / numpy array) is what the user function hands out, in the order asked
-    def add_callback_voice(self, stream, fmt, frac=0, frequency=44100):
+    def add_callback_voice(self, stream, fmt, frac=0, frequency=44100, voice=None):
+        """voice: re-initialise that voice slot (a callback source that has ended starts over) instead of the next new one"""
         CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32)
         raw = np.ascontiguousarray(stream).view(np.uint8).ravel().copy()
         st = {"pos": 0, "calls": 0}
@@ -386,10 +387,11 @@ class Scene:
         if not hasattr(self, "_callbacks"):
             self._callbacks = {}
         lib.oalgpu_voice_init_callback.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, CB, C.c_void_p]
-        v = self.nvoices
+        v = self.nvoices if voice is None else voice
         check(lib.oalgpu_voice_init_callback(self.h, v, fmt, frac, fn, None), "oalgpu_voice_init_callback")
         self._callbacks[v] = (fn, raw, st)          # keep the thunk and the stream alive
-        self.nvoices += 1
+        if voice is None:
+            self.nvoices += 1
         return v
 
     def callback_state(self, voice):
@@ -488,10 +490,6 @@ class Scene:
         arr = (C.c_void_p * len(blocks))(*[b if b is not None else None for b in blocks])
         lib.oalgpu_mix_update_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int]
         check(lib.oalgpu_mix_update_run(self.h, arr, len(blocks), samples_to_do, 1 if post_process else 0), "oalgpu_mix_update_run")
-
-    def update_graph(self, blocks, samples_to_do=BUFFER_LINE, post_process=True):
-        """`len(blocks)` (even) updates as one hipGraph: update i applies blocks[i] (None: no change) and mixes"""
-        return UpdateGraph(self, blocks, samples_to_do, post_process)
 
     def set_stream(self, stream_ptr):
         check(lib.oalgpu_set_stream(self.h, stream_ptr), "oalgpu_set_stream")
@@ -639,44 +637,6 @@ class Scene:
         a, b = C.c_float(), C.c_float()
         check(lib.oalgpu_last_update_ms(self.h, C.byref(a), C.byref(b)), "oalgpu_last_update_ms")
         return a.value, b.value
-
-
-class UpdateGraph:
-    """oalgpu_update_graph: a run of updates captured into one hipGraph (keeps its parameter blocks alive)."""
-
-    def __init__(self, scene, blocks, samples_to_do, post_process):
-        lib.oalgpu_update_graph_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int,
-                                                   C.POINTER(C.c_void_p)]
-        lib.oalgpu_update_graph_launch.argtypes = [C.c_void_p]
-        lib.oalgpu_update_graph_destroy.argtypes = [C.c_void_p]
-        lib.oalgpu_update_graph_destroy.restype = None
-        self.scene, self.blocks, self.count = scene, list(blocks), len(blocks)
-        arr = (C.c_void_p * self.count)(*[(b.value if isinstance(b, C.c_void_p) else b) for b in self.blocks])
-        h = C.c_void_p()
-        self.h = None
-        check(lib.oalgpu_update_graph_create(scene.h, arr, self.count, samples_to_do, 1 if post_process else 0, C.byref(h)),
-              "oalgpu_update_graph_create")
-        self.h = h
-
-    def launch(self):
-        check(lib.oalgpu_update_graph_launch(self.h), "oalgpu_update_graph_launch")
-
-    def close(self):
-        if self.h:
-            lib.oalgpu_update_graph_destroy(self.h)
-            self.h = None
-
-    def __del__(self):
-        if lib is not None:
-            self.close()
-
-
-def comm_unique_id():
-    """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)."""
-    buf = C.create_string_buffer(128)
-    lib.oalgpu_comm_unique_id.argtypes = [C.c_char_p, C.c_size_t]
-    check(lib.oalgpu_comm_unique_id(buf, 128), "oalgpu_comm_unique_id")
-    return buf.raw
 
 
 class Convolution:

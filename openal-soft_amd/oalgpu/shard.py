@@ -33,10 +33,11 @@ def voice_cost(hrtf, resampler_taps=24, active_sends=0, filtered=False):
 
 
 def weighted_shards(costs, world, rank0_extra=0.0):
-    """Static assignment of voices to ranks by cost class: voices are dealt round-robin
-    WITHIN each class of equal cost, every class continuing where the previous one stopped, so each
-    rank receives the same number (+-1) of voices of every class.  ``rank0_extra`` is work only rank 0
-    has (effect slots, post-process), in the units of ``costs``: rank 0 is dealt that much less.
+    """Static assignment of voices to ranks by cost: longest-processing-time first -- the voices
+    in order of falling cost, each onto the rank that carries the least so far (ties: the lowest rank).  Loads end
+    within one voice's cost of each other; since voices of one class cost the same, every rank also ends up with
+    close to the same number of each class, but that is a consequence, not a guarantee.  ``rank0_extra`` is work
+    only rank 0 has (effect slots, post-process), in the units of ``costs``: rank 0 starts that far ahead.
     Returns one sorted voice-index list per rank."""
     order = sorted(range(len(costs)), key=lambda v: (-costs[v], v))
     load = [float(rank0_extra)] + [0.0] * (world - 1)

@@ -167,3 +167,38 @@ def test_one_callback_voice_bit_exact(fmt, synth_mhr):
     for k, ((a, ia), (b, ib)) in enumerate(zip(got, want)):
         assert ia == ib, (k, ia, ib)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, float(np.abs(a - b).max()))
+
+
+@pytest.mark.gpu
+def test_callback_sources_are_recycled(synth_mhr):
+    """A callback source that has ended starts over on the same voice slot, and a voice slot that becomes another
+    kind of source hands its callback entry on: buffer-table slot, device and pinned memory are reused -- a context
+    with room for three buffers plays fifteen short streams, each bit for bit what the first one was."""
+    import oalgpu
+    api = oalgpu.Api(oalgpu.MATH_EXACT)
+    sc = api.make_scene(num_dry=5, num_real=0, num_sends=0, num_slots=0, wet_channels=4, hrtf=False, max_voices=4, max_buffers=3)
+    static = sc.add_buffer(np.zeros(64, np.float32), ol.FMT_FLOAT)
+    stream = stream_for(3, ol.FMT_SHORT, 1500)
+    first = None
+    for rep in range(15):
+        v = sc.add_callback_voice(stream, ol.FMT_SHORT, frac=0, voice=0 if rep else None)
+        assert v == 0
+        sc.set_params(0, ol.make_voice_params(65536, ol.RS_LINEAR, dry_gains=[0.5, 0.25, 0.1, 0.0, 0.3]))
+        out = []
+        for _ in range(3):                              # 1500 frames at unit pitch: the stream ends inside the second update
+            sc.mix(1024)
+            out.append(sc.dry().copy())
+        assert sc.voice_state(0).play_state == ol.VOICE_STOPPED
+        if first is None:
+            first = out
+            assert np.abs(out[0]).max() > 1e-3
+        else:
+            for a, b in zip(out, first):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), rep
+        if rep % 5 == 4:                                # the slot becomes a static source in between: the entry is handed on
+            sc.add_voice(static, looping=False) if sc.nvoices < 2 else None
+            import ctypes as C
+            desc = oalgpu.VoiceDesc(static, 0, 0, 0, 44100)
+            oalgpu.check(oalgpu.lib.oalgpu_voice_init(sc.h, 0, C.byref(desc)), "oalgpu_voice_init")
+            sc.mix(64)
+    sc.close()

@@ -29,14 +29,3 @@ for k in range(N):
     sc.mix(1024, post_process=True)
 t1 = time.perf_counter(); sc.sync(); t2 = time.perf_counter()
 print("mix only: host %.1f us, total %.1f us" % ((t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6))
-# the same 400 steps as hipGraphs of 20 updates (oalgpu_update_graph_*)
-G = 20
-graphs = [sc.update_graph(blocks[j:j + G], 1024, True) for j in range(0, 40, G)]
-for g in graphs:
-    g.launch()
-sc.sync()
-t0 = time.perf_counter()
-for k in range(N // G):
-    graphs[k % len(graphs)].launch()
-t1 = time.perf_counter(); sc.sync(); t2 = time.perf_counter()
-print("graphs of %d: host submit per step %.1f us; total per step incl. drain: %.1f us" % (G, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6))
