@@ -947,7 +947,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->bus.alloc(BusFloats(L))); HIP_TRY(c->bus.zero()); L.bus = c->bus.p;
     if(desc->flags & OALGPU_CTX_PROFILE)
     {
-        HIP_TRY(c->phaseTimes.alloc(nv * 12)); HIP_TRY(c->phaseTimes.zero());   // [voice][8] | [wavefront][4]
+        HIP_TRY(c->phaseTimes.alloc(nv * 16)); HIP_TRY(c->phaseTimes.zero());   // [voice][8] | [wavefront][8]
         c->prof.times = c->phaseTimes.p;
     }
     // HRTF voice filters are sized when the data set is loaded
@@ -2119,12 +2119,13 @@ int oalgpu_debug_phase_times(oalgpu_context *c, unsigned long long *out)
 }
 
 /* Same aid: the [wavefront][4] stamps behind them (kernel entry, first voice requested and parked,
- * last voice done, partial bus stored); `out` holds numVoices*4 words, *waves receives the count. */
+ * last voice done, partial bus stored; then pass 0 in detail: first control line in registers, first request issued,
+ * workgroup through the table-staging barrier); `out` holds numVoices*8 words ([wavefront][8]), *waves receives the count. */
 int oalgpu_debug_wave_times(oalgpu_context *c, unsigned long long *out, uint32_t *waves)
 {
     if(!c || !out || !waves || !c->phaseTimes.p) return Fail(OALGPU_ERR_INVALID, "phase times were not enabled");
     if(int rc = oalgpu_sync(c)) return rc;
-    HIP_TRY(hipMemcpy(out, c->phaseTimes.p + size_t{c->L.numVoices} * 8, size_t{c->L.numVoices} * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, c->phaseTimes.p + size_t{c->L.numVoices} * 8, size_t{c->L.numVoices} * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     *waves = WaveKernelGroups(c->L) * 4u;
     return OALGPU_OK;
 }

@@ -199,9 +199,30 @@ __device__ __forceinline__ void WgMixRows(uint32_t *lds, const DeviceLayout &L, 
 // of 1088 v_pk_fma_f32 (8.7 K cycles of the VALU), beside the other wavefront's resampler and filters.
 // PROF: the measurement variant (tools/phase_times.py): s_memtime stamps per phase and stage ablation; the
 // product variants carry none of it.
-template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool PROF = false>
-__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(DeviceLayout L, uint32_t samplesToDo, WaveProf prof)
+// LT: the kernel's argument block.  The dry-line and send variants take the whole DeviceLayout; the HRTF variants
+// without sends -- the hot path -- take WaveArgsHrtf, the 16 fields they read: a by-value DeviceLayout is ~70 dwords
+// of kernel arguments, preloaded into SGPRs at entry and spilled from there into VGPR lanes one pair at a time
+// (the pass loop used to be entered 4 K cycles into a 90 K-cycle wavefront).
+struct WaveArgsHrtf {
+    uint32_t numVoices, waveVoices, irStride, pad;
+    const float *tables;
+    const BufferItem *buffers;
+    VoiceCtl *ctl;
+    float *prev;
+    BiquadSlot *dfilt;
+    float *hrtfOld, *hrtfTgt, *hist;
+    AmbiScaleState *ambi;
+    uint32_t *startDelay, *queueDone;
+    float *partHrtf;
+    explicit WaveArgsHrtf(const DeviceLayout &L) : numVoices{L.numVoices}, waveVoices{L.waveVoices}, irStride{L.irStride}, pad{0},
+        tables{L.tables}, buffers{L.buffers}, ctl{L.ctl}, prev{L.prev}, dfilt{L.dfilt}, hrtfOld{L.hrtfOld}, hrtfTgt{L.hrtfTgt},
+        hist{L.hist}, ambi{L.ambi}, startDelay{L.startDelay}, queueDone{L.queueDone}, partHrtf{L.partHrtf} { }
+};
+
+template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool PROF = false, class LT = DeviceLayout>
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(LT L, uint32_t samplesToDo, WaveProf prof)
 {
+    static_assert(std::is_same<LT, DeviceLayout>::value || (NL == 0 && !SENDS), "the lean argument block is the HRTF variants'");
     static_assert(!MF || (R == 17 && TAPS == 64 && NL == 0), "the matrix-pipe FIR is the 64-tap HRTF form");
     using WL = WaveLds<R, TAPS, MF>;
     __shared__ WgLds<R, TAPS, MF> sm;
@@ -228,7 +249,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         if constexpr (PROF)
         {
             if(prof.times && lane0 == 0)
-                prof.times[size_t{L.numVoices} * 8 + size_t{group * kWWaves + wave} * 4 + slot] = __builtin_readcyclecounter();
+                prof.times[size_t{L.numVoices} * 8 + size_t{group * kWWaves + wave} * 8 + slot] = __builtin_readcyclecounter();
         }
     };
     const uint32_t ablate = PROF ? prof.ablate : 0u;
@@ -257,6 +278,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         headN = LoadHeadScalar(L.ctl + voiceAt(0)); bufN = LoadCtlBufferScalar(L.ctl + voiceAt(0));
         if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + voiceAt(0));
     }
+    if constexpr (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); waveStamp(4); }
     // the voice whose resampler rows the workgroup stages (see the prologue below): every wavefront
     // reads its head itself, so that the choice needs no barrier
     const uint32_t keyVoice = group * kWWaves * vpw;
@@ -722,6 +744,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         // filters and the stream-row stores.
         if constexpr (NL > 0 || MF) { if(!active) requestNext(); }
         else requestNext();
+        if constexpr (PROF) { if(first) waveStamp(5); }
 
         if(first)
         {   // ---- workgroup prologue: pick and stage the resampler rows most voices will use
@@ -784,6 +807,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 for(uint32_t k = lane; k < uint32_t(4 * kHrDw); k += 64) hz[k] = 0u;
             }
             __syncthreads();
+            waveStamp(6);
         }
 
         // ---------------- part 2: FIR and state write-back ----------------
@@ -830,12 +854,15 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             if(planN.prefetch)
             {
                 const bool isShort = bufN.fmt == OALGPU_FMT_SHORT;
-                if(lane < kMaxPad) w.rd[lane] = prevN;
+                if(lane < kMaxPad) { w.rd[lane] = prevN; if(lane) w.rd2[lane - 1u] = prevN; }
 #pragma unroll
                 for(int i = 0; i < kPre; ++i)
                 {
-                    // all kPre*64 words (rd has room; the resampler never reads past bsrc + padding)
-                    w.rd[kMaxEdge + lane + 64u * uint32_t(i)] = GatherDecode(preN[i], isShort);
+                    // all kPre*64 words (rd has room; the resampler never reads past bsrc + padding), and the
+                    // same one sample on (rd2[i] = rd[i + 1])
+                    const float sv = GatherDecode(preN[i], isShort);
+                    w.rd[kMaxEdge + lane + 64u * uint32_t(i)] = sv;
+                    w.rd2[kMaxEdge - 1u + lane + 64u * uint32_t(i)] = sv;
                 }
             }
             if constexpr (NL == 0)
@@ -936,6 +963,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     // behind the accumulator dump, whose registers are free by then)
     auto mixRows = [&]()
     {
+        if constexpr (NL > 0 || SENDS)
+        {
         static_assert(sizeof(sm) >= (kMixListMax + 4u + kMixGainDwords) * sizeof(uint32_t), "the row mix stages its gain blocks in the voices' LDS");
         uint32_t *lds = reinterpret_cast<uint32_t*>(&sm);
         const uint32_t vWg = group * kWWaves * vpw;
@@ -944,6 +973,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         else if(L.lineStride <= 16u) WgMixRows<16>(lds, L, group, vWg, nvWg, t, N);
         else WgMixRows<32>(lds, L, group, vWg, nvWg, t, N);
         waveStamp(3);
+        }
     };
     if constexpr (NL > 0) { mixRows(); return; }
     // ---- one partial per workgroup: waves dump their accumulators, then a fixed-order sum
@@ -1031,8 +1061,8 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     const WaveProf none{nullptr, 0u};
     if(prof && L.hrtf && !sends && L.irStride <= 64)
     {
-        if(L.firMfma) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true>), grid, block, 0, s, L, samplesToDo, *prof);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true>), grid, block, 0, s, L, samplesToDo, *prof);
+        if(L.firMfma) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, *prof);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, *prof);
     }
     else if(!L.hrtf)
     {
@@ -1042,17 +1072,17 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     else if(L.irStride <= 64 && L.firMfma)
     {
         if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true>), grid, block, 0, s, L, samplesToDo, none);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true>), grid, block, 0, s, L, samplesToDo, none);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, false, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, none);
     }
     else if(L.irStride <= 64)
     {
         if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, L, samplesToDo, none);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false>), grid, block, 0, s, L, samplesToDo, none);
+        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, none);
     }
     else
     {
         if(sends) hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, L, samplesToDo, none);
-        else hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false>), grid, block, 0, s, L, samplesToDo, none);
+        else hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, none);
     }
     return hipGetLastError();
 }

@@ -68,6 +68,15 @@ __device__ __forceinline__ BufferItem LoadCtlBufferScalar(const VoiceCtl *p)
 // MF: the dual-ear FIR runs on the matrix pipe (FirMfmaH, dev_wave.hpp); its inputs are staged per ear as
 // packed f16 pairs, leading halves and remainders (xh, in the place of x2), and the next voice's reversed
 // response is parked in hr while this voice's registers are still busy with its write-back.
+// The resampler reads its source samples in pairs; a pair at an even index of rd is one aligned ds_read_b64, a pair at
+// an odd index would be a ds_read2_b32 (half the LDS rate) -- so a prefetched window is parked twice, rd and rd2 = rd
+// shifted by one sample, and an odd pair is read from rd2 at the even index below it.  rd2 starts 32 banks away from rd
+// (1376 = 21 x 64 + 32 dwords): the lanes of a wavefront read pairs within ~60 consecutive samples, the even ones out
+// of rd, the odd ones out of rd2, on disjoint halves of the 64 banks.
+constexpr int kRdFloats = 1376;
+constexpr int kRd2Floats = kMaxEdge + kPre * 64 + 8;
+static_assert(kRdFloats >= kResampleDataSize + 8 && kRdFloats % 64 == 32, "rd2 sits half the banks away from rd");
+
 template<int R, int TAPS, bool MF = false>
 struct alignas(16) WaveLds {
     static constexpr int kFrames = 64 * R;
@@ -76,7 +85,11 @@ struct alignas(16) WaveLds {
     union {
         f2 x2[kX];                                      // FIR inputs (both ears), zero padded
         uint32_t xh[2][2][MF ? kXhDw : 1];              // MF: FIR inputs [ear][hi | lo], two frames per dword
-        float rd[kResampleDataSize + 8];                // DeviceBase::mResampleData (dead before x2 is built)
+        struct {
+            float rd[kRdFloats];                        // DeviceBase::mResampleData (dead before x2 is built)
+            float rd2[kRd2Floats];                      // rd2[i] = rd[i + 1]: the same window one sample on, so that a source
+                                                        // PAIR at an odd index is an aligned 8-byte read too (see ResampleRunStaged)
+        };
     };
     float in[kHist + kLine];                            // [Hrtf.History | resampled, filtered samples]
     f2 cold[TAPS + 128];                                // cold[k] = Hrtf.Old.Coeffs[k - 64], zero padded
@@ -235,9 +248,10 @@ __device__ __forceinline__ SrcPlan PlanSource(const VoiceHead &h, uint32_t sampl
 // group is multiplied.  Every lane runs every pass of the loop (the store is predicated), so the
 // look-ahead reads need no branch; past the last output they read unused words of this wave's
 // own LDS block.  rdb = rd + MaxResamplerEdge - l.
-template<int M>
+// DUAL: the window is parked twice (WaveLds::rd2): rdb points into rd, rd2b to the same index of rd2.
+template<int M, bool DUAL = false>
 __device__ __forceinline__ void ResampleRunStaged(const f2 *tabF, const f2 *tabP, const float *rdb, uint32_t frac0,
-    uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane)
+    uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane, const float *rd2b = nullptr, uint32_t rdbIndex = 0)
 {
     // Two complete outputs are in flight: while the 3*NP LDS reads of one are outstanding
     // (rows F, P and the source pairs S) the other is multiplied, which covers the LDS latency
@@ -258,8 +272,19 @@ __device__ __forceinline__ void ResampleRunStaged(const f2 *tabF, const f2 *tabP
             F[q] = tf[(g * NP + q) * 32];
             P[q] = tp[(g * NP + q) * 32];
         }
+        if constexpr (DUAL)
+        {   // the pair (s[2j], s[2j+1]) as ONE aligned 8-byte read: out of rd when it starts at an even index, else out of rd2
+            const uint32_t pos = tt >> kFracBits;
+            const bool odd = ((rdbIndex + pos) & 1u) != 0u;
+            const f2 *sp = reinterpret_cast<const f2*>(odd ? rd2b + pos - 1u : s);
+#pragma unroll
+            for(int q = 0; q < NP; ++q) S[q] = sp[g * NP + q];
+        }
+        else
+        {
 #pragma unroll
         for(int q = 0; q < NP; ++q) S[q] = f2{s[2 * (g * NP + q)], s[2 * (g * NP + q) + 1]};
+        }
     };
     auto compute = [&](const f2 (&F)[NP], const f2 (&P)[NP], const f2 (&S)[NP], uint32_t tt, f2 &r0, f2 &r1)
     {
@@ -414,8 +439,14 @@ __device__ __forceinline__ void ResampleRunBlockM(const SM &sm, const float *rdb
 
 template<class SM>
 __device__ __forceinline__ void ResampleRunStagedM(const SM &sm, const float *rdb, uint32_t m,
-    uint32_t frac0, uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane)
+    uint32_t frac0, uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane, const float *rd2b = nullptr,
+    uint32_t rdbIndex = 0)
 {
+    if(rd2b)
+    {   // the window was parked twice: source pairs as aligned 8-byte reads (the 24- and 12-tap kernels)
+        if(m == 24) { ResampleRunStaged<24, true>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane, rd2b, rdbIndex); return; }
+        if(m == 12) { ResampleRunStaged<12, true>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane, rd2b, rdbIndex); return; }
+    }
     switch(m)
     {
     case 4: ResampleRunStaged<4>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane); break;
@@ -431,8 +462,8 @@ __device__ __forceinline__ void ResampleRunStagedM(const SM &sm, const float *rd
 // set the first chunk's source samples are already on their way in `pre` (GatherStatic) and
 // `prevv` holds mPrevSamples[lane].
 // LEAN: the register-lean staged resampler (kernels that run at four wavefronts per SIMD).
-template<bool LEAN = false, bool PROF = false, class SM, class WV>
-__device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const DeviceLayout &L,
+template<bool LEAN = false, bool PROF = false, class SM, class WV, class LT>
+__device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const LT &L,
     uint32_t v, uint32_t lane, const VoiceHead &h, bool playing, uint32_t samplesToLoad, uint32_t samplesToMix,
     int32_t bufferItem, bool looping, const SrcPlan &plan, uint32_t mixOffset = 0, const WaveProf &prof = WaveProf{nullptr, 0u})
 {
@@ -527,8 +558,12 @@ __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const DeviceLay
             if constexpr (LEAN)
                 ResampleRunBlockM<64>(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded, lane);
             else
+            {
+                // (the first chunk of a prefetched window is in rd AND rd2)
+                const bool dual = plan.prefetch && loaded == 0;
                 ResampleRunStagedM(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded,
-                    reinterpret_cast<float*>(&w.pad[0]), lane);
+                    reinterpret_cast<float*>(&w.pad[0]), lane, dual ? w.rd2 + (kMaxEdge - sL) : nullptr, uint32_t(kMaxEdge) - sL);
+            }
         }
         else
         {

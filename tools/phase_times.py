@@ -60,13 +60,15 @@ half = dw.shape[0] // 2
 print("workgroups of the first half: mean of max=%.0f max=%.0f; second half: mean of max=%.0f max=%.0f" % (wgmax[:half].mean(), wgmax[:half].max(), wgmax[half:].mean(), wgmax[half:].max()))
 
 # per-wavefront stamps: entry, first voice requested+parked (pass 0), voices done, partial stored
-wt = np.zeros((V, 4), np.uint64); nw = C.c_uint32(0)
+wt = np.zeros((V, 8), np.uint64); nw = C.c_uint32(0)
 oalgpu.lib.oalgpu_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
 rc = oalgpu.lib.oalgpu_debug_wave_times(sc.h, wt.ctypes.data_as(C.c_void_p), C.byref(nw)); assert rc == 0, rc
 wt = wt[:nw.value].astype(np.int64)
 d0 = wt[:, 1] - wt[:, 0]; d1 = wt[:, 2] - wt[:, 1]; d2 = wt[:, 3] - wt[:, 2]; tot = wt[:, 3] - wt[:, 0]
 for nm, x in (("pass 0 (first head/buffer/window + table staging)", d0), ("voices", d1), ("dump + partial store", d2), ("wave lifetime", tot)):
     print("%-52s mean=%.0f p50=%.0f p99=%.0f max=%.0f" % (nm, x.mean(), np.median(x), np.percentile(x, 99), x.max()))
+print("pass 0 in detail (cycles after entry): control line in registers %.0f, request issued %.0f, staging barrier passed %.0f, first voice parked %.0f"
+      % ((wt[:, 4] - wt[:, 0]).mean(), (wt[:, 5] - wt[:, 0]).mean(), (wt[:, 6] - wt[:, 0]).mean(), d0.mean()))
 h2 = nw.value // 2
 print("wave lifetime, first-half workgroups: mean=%.0f max=%.0f; second half: mean=%.0f max=%.0f" % (tot[:h2].mean(), tot[:h2].max(), tot[h2:].mean(), tot[h2:].max()))
 
