@@ -639,6 +639,14 @@ class Scene:
         return a.value, b.value
 
 
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    lib.oalgpu_comm_unique_id.argtypes = [C.c_char_p, C.c_size_t]
+    check(lib.oalgpu_comm_unique_id(buf, 128), "oalgpu_comm_unique_id")
+    return buf.raw
+
+
 class Convolution:
     """oalgpu_convolution: ConvolutionState (alc/effects/convolution.cpp); ir = [frames] (mono) or
     [frames, channels] at ir_rate (None: the device's rate)."""
