@@ -1,0 +1,108 @@
+// Packed-fp32 VOP3P ops with op_sel on gfx950, while another wavefront of the SIMD runs MFMAs:
+// does an instruction that overwrites a source of the packed op right behind it change the packed op's result?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <cmath>
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+#define TEST(NAME, ASM) \
+__device__ __forceinline__ void NAME(float a0, float a1, float b0, float b1, float c0, float c1, float &r0, float &r1) \
+{ \
+    asm volatile( \
+        "v_mov_b32 v10, %2\n\tv_mov_b32 v11, %3\n\tv_mov_b32 v12, %4\n\tv_mov_b32 v13, %5\n\tv_mov_b32 v14, %6\n\tv_mov_b32 v15, %7\n\t" \
+        "s_nop 4\n\t" ASM "\n\ts_nop 4\n\tv_mov_b32 %0, v16\n\tv_mov_b32 %1, v17\n\ts_nop 1" \
+        : "=v"(r0), "=v"(r1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c0), "v"(c1) \
+        : "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19"); \
+}
+// A = v[10:11], B = v[12:13], C = v[14:15] -> D = v[16:17]
+TEST(t_plain,      "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15]")                                                        // no op_sel, nothing behind
+TEST(t_plain_war,  "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel_hi:[0,1,1]")
+TEST(t_sel,        "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel:[0,1,0]")
+TEST(t_sel_warC,   "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel:[0,1,0]\n\tv_mov_b32 v14, 0")
+TEST(t_sel_warC1,  "v_pk_add_f32 v[16:17], v[10:11], v[12:13] op_sel:[0,1]")
+TEST(t_sel_warB,   "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel:[0,0,1]")
+TEST(t_sel_warA,   "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel:[0,1,0] op_sel_hi:[1,0,1]")
+TEST(t_sel_dppC,   "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel:[1,1,0]")
+TEST(t_sel_inpl,   "v_mov_b32 v16, v12\n\tv_mov_b32 v17, v13\n\ts_nop 4\n\tv_pk_fma_f32 v[16:17], v[10:11], v[16:17], v[14:15] op_sel:[0,1,0]")   // dst = src1
+TEST(t_sel0_warC,  "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel:[1,0,0]\n\tv_mov_b32 v14, 0\n\tv_mov_b32 v15, 0")
+TEST(t_selhi_warC, "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel_hi:[1,0,1]\n\tv_mov_b32 v14, 0\n\tv_mov_b32 v15, 0")
+TEST(t_mulsel_warA,"v_pk_mul_f32 v[16:17], v[10:11], v[12:13] op_sel:[0,1]\n\tv_pk_mul_f32 v[10:11], v[14:15], v[14:15]")
+
+__global__ void __launch_bounds__(256) k(uint32_t *bad, uint32_t reps, uint32_t mode)
+{
+    __shared__ float ballast[18000];            // 72 KB: two workgroups per CU
+    if(reps == 0xffffffffu) ballast[threadIdx.x] = 1.0f;
+    if(((blockIdx.x >> 8) & 1u) && mode)
+    {
+        h8v a, b; f4v c = {0, 0, 0, 0};
+        for(int i = 0; i < 8; ++i) { a[i] = _Float16(float(threadIdx.x + i) * 1e-3f); b[i] = _Float16(float(threadIdx.x * 3 + i) * 1e-3f); }
+        for(uint32_t r = 0; r < reps * 30u; ++r)
+        {
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c, 0, 0, 0);
+        }
+        if(c[0] == 12345.0f) bad[63] = uint32_t(c[1]);
+        return;
+    }
+    const float l = float(threadIdx.x);
+    uint32_t cnt[12] = {}, ignoredSel = 0, hiWrong = 0;
+    for(uint32_t r = 0; r < reps; ++r)
+    {
+        const float a0 = 1.0f + l + float(r), a1 = 2.0f + l, b0 = 3.0f + l * 0.5f, b1 = 5.0f + float(r & 7u), c0 = 7.0f + l, c1 = 11.0f - l;
+        float r0, r1;
+#define CHECK(i, F, e0, e1) F(a0, a1, b0, b1, c0, c1, r0, r1); if(r0 != (e0) || r1 != (e1)) ++cnt[i];
+        CHECK(0, t_plain,       __builtin_fmaf(a0, b0, c0), __builtin_fmaf(a1, b1, c1))
+        CHECK(1, t_plain_war,   __builtin_fmaf(a0, b0, c0), __builtin_fmaf(a0, b1, c1))
+        CHECK(2, t_sel,         __builtin_fmaf(a0, b1, c0), __builtin_fmaf(a1, b1, c1))
+        if(r0 == __builtin_fmaf(a0, b0, c0) && r1 == __builtin_fmaf(a1, b1, c1)) ++ignoredSel;
+        if(r1 != __builtin_fmaf(a1, b1, c1)) ++hiWrong;
+        {
+            const float want = __builtin_fmaf(a0, b1, c0);
+            if(r0 != want)
+            {
+                const uint32_t ulps = uint32_t(abs(int(__builtin_bit_cast(uint32_t, r0) - __builtin_bit_cast(uint32_t, want))));
+                atomicMax(&bad[22], ulps);
+                if(atomicAdd(&bad[23], 1u) < 6u)
+                {
+                    float *ex = reinterpret_cast<float*>(bad + 32) + 8 * (atomicAdd(&bad[24], 1u) % 3u);
+                    ex[0] = a0; ex[1] = a1; ex[2] = b0; ex[3] = b1; ex[4] = c0; ex[5] = c1; ex[6] = r0; ex[7] = want;
+                }
+            }
+        }
+        CHECK(3, t_sel_warC,    __builtin_fmaf(a0, b1, c0), __builtin_fmaf(a1, b1, c1))
+        CHECK(4, t_sel_warC1,   a0 + b1, a1 + b1)
+        CHECK(5, t_sel_warB,    __builtin_fmaf(a0, b0, c1), __builtin_fmaf(a1, b1, c1))
+        CHECK(6, t_sel_warA,    __builtin_fmaf(a0, b1, c0), __builtin_fmaf(a1, b0, c1))
+        CHECK(7, t_sel_dppC,    __builtin_fmaf(a1, b1, c0), __builtin_fmaf(a1, b1, c1))
+        CHECK(8, t_sel_inpl,    __builtin_fmaf(a0, b1, c0), __builtin_fmaf(a1, b1, c1))
+        CHECK(9, t_sel0_warC,   __builtin_fmaf(a1, b0, c0), __builtin_fmaf(a1, b1, c1))
+        CHECK(10, t_selhi_warC, __builtin_fmaf(a0, b0, c0), __builtin_fmaf(a1, b0, c1))
+        CHECK(11, t_mulsel_warA, a0 * b1, a1 * b1)
+    }
+    for(int i = 0; i < 12; ++i) if(cnt[i]) atomicAdd(&bad[i], cnt[i]);
+    if(ignoredSel) atomicAdd(&bad[20], ignoredSel);
+    if(hiWrong) atomicAdd(&bad[21], hiWrong);
+}
+int main(int argc, char **argv)
+{
+    const char *names[12] = {"plain", "pk_fma op_sel_hi:[0,1,1]", "op_sel:[0,1,0]", "op_sel:[0,1,0], C.lo overwritten behind", "pk_add op_sel:[0,1]",
+        "pk_fma op_sel:[0,0,1]", "pk_fma op_sel:[0,1,0] op_sel_hi:[1,0,1]", "pk_fma op_sel:[1,1,0]", "op_sel:[0,1,0], dst = src1",
+        "op_sel:[1,0,0], C overwritten behind", "op_sel_hi:[1,0,1], C overwritten behind", "pk_mul op_sel:[0,1], A overwritten by a pk_mul behind"};
+    for(uint32_t mode = 0; mode < 2; ++mode)
+    {
+        uint32_t *d; (void)hipMalloc(&d, 512); (void)hipMemset(d, 0, 512);
+        k<<<512, 256>>>(d, 20000, mode); (void)hipDeviceSynchronize();
+        uint32_t h[128]; (void)hipMemcpy(h, d, 512, hipMemcpyDeviceToHost);
+        printf("%s:\n", mode ? "half of the workgroups run MFMAs" : "no MFMAs on the machine");
+        printf("  of the wrong op_sel:[0,1,0] results: %u are the result WITHOUT op_sel (low lane read src1.lo); high lane wrong %u times\n", h[20], h[21]);
+        printf("  largest deviation of a wrong low-lane result: %u ulps\n", h[22]);
+        if(mode) for(int e = 0; e < 3; ++e) { const float *x = reinterpret_cast<const float*>(h + 32) + 8 * e;
+            printf("    A = (%g, %g) B = (%g, %g) C = (%g, %g): low lane %.9g, want A.lo * B.hi + C.lo = %.9g [A.lo*B.lo+C.lo = %.9g, A.hi*B.hi+C.lo = %.9g, A.lo*B.hi+C.hi = %.9g]\n", x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7],
+                fmaf(x[0], x[2], x[4]), fmaf(x[1], x[3], x[4]), fmaf(x[0], x[3], x[5])); }
+        for(int i = 0; i < 12; ++i) printf("  %-60s wrong results: %u\n", names[i], h[i]);
+    }
+    return 0;
+}
