@@ -604,11 +604,11 @@ __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const LT &L,
 
 // ---- wave-parallel dual biquad (time-invariant coefficients) ---------------------------------
 // BiquadFilter::dualProcess (core/filters/biquad.cpp:254-282) is two transposed-direct-form-II
-// sections in cascade; each is linear in its state s = (z1, z2): s' = A s + B x with
-// A = [[-a1, 1], [-a2, 0]].  Lane l owns the run of samples [l*seg, (l+1)*seg) -- seg odd, so
+// sections in cascade; each is linear in its state s = (z1, z2): s' = A s + Bv x with
+// A = [[-a1, 1], [-a2, 0]].  Lane l owns the run of samples [17 l, 17 l + 17) -- an odd length, so
 // the per-lane runs hit distinct LDS banks -- and keeps it in registers for both sections:
-//   (1) M = A^seg;  (2) forced response q_l of the run from a zero state;  (3) run-start states
-//   S_l = M^l S_0 + sum_{k<l} M^(l-1-k) q_k by a 6-step Kogge-Stone scan with M, M^2, .. M^32;
+//   (1) M = A^17;  (2) forced response q_l of the run from a zero state;  (3) run-start states
+//   S_l = M^l S_0 + sum_{k<l} M^(l-1-k) q_k by a scan over the lanes (ScanLinear2);
 //   (4) the true recurrence from S_l.  Lanes past the last sample only produce values nobody
 // reads.  The serial loop of the reference differs from this by rounding only.
 constexpr int kBqSeg = 17;                    // ceil(1024 / 64) | 1
@@ -669,45 +669,68 @@ __device__ __forceinline__ S2 ScanLinear2(S2 e, S2 m0, S2 m1, uint32_t lane)
     return e;
 }
 
-// one section over the lane's run x[0..cnt); z1/z2: state in, state after the last sample out
-__device__ __forceinline__ void BiquadWaveScan(float (&x)[kBqSeg], uint32_t cnt, uint32_t seg, const BiquadState &f,
+// one section over the lane's run x[0..17) (zeros past the end of the data); z1/z2: state in, state after the last
+// sample out.  cnt = this lane's samples of the run, lastLane = the lane that holds sample n - 1.
+//   * the forced response is NOT the recurrence run once more: the run's end state from a zero state is
+//     sum_i x[i] A^(16-i) Bv, Bv = (b1 - a1 b0, b2 - a2 b0), and c_j = A^j Bv comes out of the loop that raises A to
+//     M = A^17 anyway -- 17 independent FMA pairs behind a chain that is one operation per step, where the recurrence
+//     is a chain of two per step and sample;
+//   * the recurrence itself keeps x b1 + z2 off the chain: out -> z1 is ONE dependent FMA.
+__device__ __forceinline__ void BiquadWaveScan(float (&x)[kBqSeg], uint32_t cnt, const BiquadState &f,
     float &z1, float &z2, uint32_t lane, int lastLane)
 {
     const float b0 = f.b0, b1 = f.b1, b2 = f.b2, a1 = f.a1, a2 = f.a2;
-    S2 m0{1.0f, 0.0f}, m1{0.0f, 1.0f};                 // columns of M = A^seg
-    for(uint32_t i = 0; i < seg; ++i)
+    S2 m0{1.0f, 0.0f}, m1{0.0f, 1.0f};                // columns of A^j
+    S2 c{__builtin_fmaf(-a1, b0, b1), __builtin_fmaf(-a2, b0, b2)};      // A^j Bv
+    S2 ea{0.0f, 0.0f}, eb{0.0f, 0.0f};                // two partial sums: the additions are a chain too
+#pragma unroll
+    for(int j = 0; j < kBqSeg; ++j)
     {
+        const float xv = x[kBqSeg - 1 - j];
+        if(j & 1) { eb.a = __builtin_fmaf(xv, c.a, eb.a); eb.b = __builtin_fmaf(xv, c.b, eb.b); }
+        else { ea.a = __builtin_fmaf(xv, c.a, ea.a); ea.b = __builtin_fmaf(xv, c.b, ea.b); }
+        c = S2{__builtin_fmaf(-a1, c.a, c.b), -a2 * c.a};
         m0 = S2{__builtin_fmaf(-a1, m0.a, m0.b), -a2 * m0.a};
         m1 = S2{__builtin_fmaf(-a1, m1.a, m1.b), -a2 * m1.a};
     }
-    // the run's end state from a zero state -- lane 0 from the filter's state, so that the scan carries it along
-    S2 e{lane == 0u ? z1 : 0.0f, lane == 0u ? z2 : 0.0f};
-#pragma unroll
-    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < seg) BqStep(e, x[i], b0, b1, b2, a1, a2);
+    S2 e{ea.a + eb.a, ea.b + eb.b};
+    {   // lane 0 starts from the filter's state: the scan carries it along
+        const S2 mz = Mv2(m0, m1, S2{z1, z2});
+        if(lane == 0u) { e.a += mz.a; e.b += mz.b; }
+    }
     e = ScanLinear2(e, m0, m1, lane);
     // the run's start state: the end state of the lane before (wave_shr:1; lane 0 keeps the filter's state)
     S2 st;
     st.a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, z1), __builtin_bit_cast(int, e.a), 0x138, 0xF, 0xF, false));
     st.b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, z2), __builtin_bit_cast(int, e.b), 0x138, 0xF, 0xF, false));
+    S2 zc = st;                                       // the state after this lane's last sample
 #pragma unroll
     for(int i = 0; i < kBqSeg; ++i)
-        if(uint32_t(i) < cnt) x[i] = BqStep(st, x[i], b0, b1, b2, a1, a2);
-    z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.a), lastLane));
-    z2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.b), lastLane));
+    {
+        const float xv = x[i];
+        const float t1 = __builtin_fmaf(xv, b1, st.b);
+        const float y = __builtin_fmaf(xv, b0, st.a);
+        st.a = __builtin_fmaf(-y, a1, t1);
+        st.b = __builtin_fmaf(xv, b2, -y * a2);
+        x[i] = y;
+        if(uint32_t(i) + 1u == cnt) zc = st;
+    }
+    z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zc.a), lastLane));
+    z2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zc.b), lastLane));
 }
 
 __device__ __forceinline__ void BiquadDualWaveScan(BiquadState &f0, BiquadState &f1, float *buf /* in place */,
     uint32_t n, uint32_t lane)
 {
-    const uint32_t seg = ((n + 63u) / 64u) | 1u;      // <= kBqSeg for n <= 1024
-    const uint32_t begin = lane * seg < n ? lane * seg : n;
-    const uint32_t cnt = (begin + seg < n) ? seg : n - begin;
-    const int lastLane = int((n - 1u) / seg);
+    // runs of 17 whatever n is: nothing in the scan then depends on a run length, and a short block is short anyway
+    const uint32_t begin = lane * uint32_t(kBqSeg) < n ? lane * uint32_t(kBqSeg) : n;
+    const uint32_t cnt = (begin + uint32_t(kBqSeg) < n) ? uint32_t(kBqSeg) : n - begin;
+    const int lastLane = int((n - 1u) / uint32_t(kBqSeg));
     float x[kBqSeg];
 #pragma unroll
     for(int i = 0; i < kBqSeg; ++i) x[i] = (uint32_t(i) < cnt) ? buf[begin + i] : 0.0f;
-    BiquadWaveScan(x, cnt, seg, f0, f0.z1, f0.z2, lane, lastLane);
-    BiquadWaveScan(x, cnt, seg, f1, f1.z1, f1.z2, lane, lastLane);
+    BiquadWaveScan(x, cnt, f0, f0.z1, f0.z2, lane, lastLane);
+    BiquadWaveScan(x, cnt, f1, f1.z1, f1.z2, lane, lastLane);
 #pragma unroll
     for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < cnt) buf[begin + i] = x[i];
 }

@@ -41,6 +41,8 @@ __global__ void __launch_bounds__(256) k(const float *in, float *out, const Biqu
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     float *x = xs[wv]; float *fst = fsts[wv]; BiquadSlot *slots = slotss[wv];
     uint32_t h0 = 0;
+    const uint64_t t0 = __builtin_readcyclecounter();
+    uint64_t tf = 0;
     for(uint32_t r = 0; r < reps; ++r)
     {
         for(uint32_t i = lane; i < n; i += 64) x[i] = in[i];
@@ -48,8 +50,10 @@ __global__ void __launch_bounds__(256) k(const float *in, float *out, const Biqu
         WaveSync();
         if(lane < 32) fst[lane] = reinterpret_cast<const float*>(&slots[lane >> 4])[lane & 15];
         WaveSync();
+        const uint64_t ta = __builtin_readcyclecounter();
         WaveDoFilters(fst, slots, true, x, n, lane);
         WaveSync();
+        tf += __builtin_readcyclecounter() - ta;
         uint32_t h = 0;
         for(uint32_t i = lane; i < n; i += 64) h ^= __builtin_bit_cast(uint32_t, x[i]) * (i + 1u);
         h ^= __builtin_bit_cast(uint32_t, slots[1].f.z1) ^ __builtin_bit_cast(uint32_t, slots[0].f.z2);
@@ -58,6 +62,7 @@ __global__ void __launch_bounds__(256) k(const float *in, float *out, const Biqu
         WaveSync();
     }
     const size_t w = size_t{blockIdx.x} * 4 + wv;
+    if(lane == 0) { fout[size_t{gridDim.x} * 8 + 1 + w].z1 = float(tf) / float(reps); fout[size_t{gridDim.x} * 8 + 1 + w].z2 = float(__builtin_readcyclecounter() - t0) / float(reps); }
     for(uint32_t i = lane; i < n; i += 64) out[w * 1024 + i] = x[i];
     if(lane < 2) { fout[w * 2 + lane] = slots[lane].f; }
 }
@@ -88,7 +93,7 @@ int main(int argc, char **argv)
             y[i] = v;
         }
         float *dx, *dy; BiquadState *df, *dfo;
-        (void)hipMalloc(&dx, n * 4); (void)hipMalloc(&dy, size_t{G} * 4 * 1024 * 4); (void)hipMalloc(&df, sizeof(f)); (void)hipMalloc(&dfo, sizeof(f) * G * 4 + 64); (void)hipMemset(dfo, 0, sizeof(f) * G * 4 + 64);
+        (void)hipMalloc(&dx, n * 4); (void)hipMalloc(&dy, size_t{G} * 4 * 1024 * 4); (void)hipMalloc(&df, sizeof(f)); const size_t dfoBytes = sizeof(BiquadState) * (size_t{G} * 8 + 2 + size_t{G} * 4); (void)hipMalloc(&dfo, dfoBytes); (void)hipMemset(dfo, 0, dfoBytes);
         (void)hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice); (void)hipMemcpy(df, f, sizeof(f), hipMemcpyHostToDevice);
         if(argc > 2)
         {   // the kernel out of a separately assembled code object (hand-edited ISA)
@@ -112,6 +117,9 @@ int main(int argc, char **argv)
             err = fmax(err, we);
         }
         uint32_t mism = 0; (void)hipMemcpy(&mism, reinterpret_cast<char*>(dfo) + sizeof(BiquadState) * G * 8, 4, hipMemcpyDeviceToHost);
+        { std::vector<BiquadState> tm(size_t{G} * 4); (void)hipMemcpy(tm.data(), dfo + size_t{G} * 8 + 1, tm.size() * sizeof(BiquadState), hipMemcpyDeviceToHost);
+          double a = 0; size_t c = 0; for(size_t w = 0; w < tm.size(); ++w) if(tm[w].z1 > 0) { a += tm[w].z1; ++c; }
+          printf("filter pair over %u samples: %.0f cycles (s_memtime) per call, mean of %zu wavefronts\n", n, c ? a / c : 0.0, c); }
         printf("repetitions that differ from the first: %u lanes\n", mism);
         printf("n=%u: %u waves, max err %.3e of max %.3e, state err %.3e, bad waves %zu\n", n, G * 4, err, mx, zerr, bad);
     }
