@@ -290,6 +290,7 @@ __device__ __forceinline__ uint32_t WaveMaxBits(uint32_t v)
     return ab > cd ? ab : cd;
 }
 
+template<int TILES = 5, bool LOW8 = false>
 __device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2][2][kXhDw], const uint32_t (&hr)[2][2][kHrDw],
     float inv, uint32_t lane)
 {
@@ -327,9 +328,9 @@ __device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2
         h8 B[2][3], Bn[2][3];
         loadB(B, 0);
 #pragma unroll
-        for(int T = 0; T < 5; ++T)
+        for(int T = 0; T < TILES; ++T)
         {
-            if(T + 1 < 5) loadB(Bn, T + 1);
+            if(T + 1 < TILES) loadB(Bn, T + 1);
             f4 ta = {0.0f, 0.0f, 0.0f, 0.0f}, tb = ta, tc = ta;
 #pragma unroll
             for(int c = 0; c < 3; ++c)
@@ -338,8 +339,9 @@ __device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2
                 tb = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0][c], B[1][c], tb, 0, 0, 0);
                 tc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0][c], B[0][c], tc, 0, 0, 0);
             }
-            acc[e][T] = __builtin_elementwise_fma((ta + tb) + tc, vinv, acc[e][T]);
-            if(T + 1 < 5)
+            const f4 sum = __builtin_elementwise_fma((ta + tb) + tc, vinv, acc[e][T]);
+            if(!LOW8 || i < 8u) acc[e][T] = sum;      // LOW8: only the columns of frames 0..127 hold this product
+            if(T + 1 < TILES)
             {
 #pragma unroll
                 for(int s = 0; s < 2; ++s)

@@ -289,6 +289,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
 #pragma unroll
     for(int r = 0; r < (MF ? 1 : R); ++r) acc[r] = f2{0.0f, 0.0f};
     float invH = 1.0f;                               // MF: 1 / scale of the parked (next) voice's response
+    float invHO = 1.0f;                              // MF: and of its replaced (old) response, if it has one
+    float xoL = 0.0f, xoR = 0.0f;                    // MF: this voice's old-filter fade-out inputs, frame = lane
     f4 accM[2][5];                                   // MF: FirMfmaH's tiles, ear x (4 x 256 frames + ring-out)
 #pragma unroll
     for(int e = 0; e < 2; ++e)
@@ -731,7 +733,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     const float g = oldStep * float(fademix - lane);
                     xo = f2{w.in[kHist - odL + lane] * g, w.in[kHist - odR + lane] * g};
                 }
-                w.xo[lane] = xo;
+                if constexpr (MF) { xoL = xo.x; xoR = xo.y; }      // staged over the main inputs once the main FIR is through
+                else w.xo[lane] = xo;
             }
             WaveSync();
             }
@@ -800,12 +803,13 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 }
             }
             // zero padding of the old-filter coefficient array (never overwritten)
-            for(uint32_t k = lane; k < uint32_t(TAPS + 128); k += 64) w.cold[k] = f2{0.0f, 0.0f};
             if constexpr (MF)
             {   // zero padding of the reversed responses (every voice rewrites u in [17, 80] only)
-                uint32_t *hz = &w.hr[0][0][0];
-                for(uint32_t k = lane; k < uint32_t(4 * kHrDw); k += 64) hz[k] = 0u;
+                uint32_t *hz = &w.hr[0][0][0], *ho = &w.hro[0][0][0];
+                for(uint32_t k = lane; k < uint32_t(4 * kHrDw); k += 64) { hz[k] = 0u; ho[k] = 0u; }
             }
+            else
+                for(uint32_t k = lane; k < uint32_t(TAPS + 128); k += 64) w.cold[k] = f2{0.0f, 0.0f};
             __syncthreads();
             waveStamp(6);
         }
@@ -817,7 +821,28 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             cf16 *co = (cf16*)(uintptr_t)(L.hrtfTgt + size_t{v} * irStride * 2);
             if(NL > 0 || (ablate & 1u)) {}
             else if constexpr (MF)
+            {
                 FirMfmaH(accM, w.xh, w.hr, invX * invH, lane);
+                if(oldPass)
+                {   // the replaced filter's fade-out (MixHrtfBlend, hrtfbase.h:54-70): 64 inputs x IrSize taps land in
+                    // frames 0..126 -- the first eight columns of tile 0.  Its inputs go over the main inputs' first
+                    // 104 dwords (frames -64..143; the main FIR has read them), as halves like those: frame = lane.
+                    float sxo, invXo;
+                    HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, __builtin_fmaxf(__builtin_fabsf(xoL), __builtin_fabsf(xoR)))), sxo, invXo);
+                    uint32_t hi, lo;
+                    SplitHalf2(xoL * sxo, xoR * sxo, hi, lo);
+                    WaveSync();
+                    uint16_t *xz = reinterpret_cast<uint16_t*>(&w.xh[0][0][0]);
+                    xz[0 * kXhHalves + 64u + lane] = uint16_t(hi); xz[1 * kXhHalves + 64u + lane] = uint16_t(lo);
+                    xz[2 * kXhHalves + 64u + lane] = uint16_t(hi >> 16); xz[3 * kXhHalves + 64u + lane] = uint16_t(lo >> 16);
+                    if(lane < 40u)
+                    {
+                        w.xh[0][0][64u + lane] = 0u; w.xh[0][1][64u + lane] = 0u; w.xh[1][0][64u + lane] = 0u; w.xh[1][1][64u + lane] = 0u;
+                    }
+                    WaveSync();
+                    FirMfmaH<1, true>(accM, w.xh, w.hro, invXo * invHO, lane);
+                }
+            }
             else if(irStride == uint32_t(TAPS))
                 FirMainPk<R, TAPS>(acc, &w.x2[TAPS + R * lane], co);
             else
@@ -826,7 +851,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 for(uint32_t seg = 0; seg * 16u < irStride; ++seg)
                     FirMainPk<R, 16>(acc, xw - 16 * seg, co + 2 * seg);
             }
-            if(NL == 0 && oldPass && !(ablate & 1u))
+            if(NL == 0 && !MF && oldPass && !(ablate & 1u))
             {   // frames lane + 64q receive cOld[lane + 64q - i] * xo[i], i < 64
 #pragma unroll 1
                 for(int i0 = 0; i0 < 64; i0 += 8)
@@ -881,8 +906,22 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 }
                 if(dirtyN)
                 {
+                    if constexpr (MF)
+                    {   // the replaced response, like the target's above
+                        float sh;
+                        HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, __builtin_fmaxf(__builtin_fabsf(oldN[0].x), __builtin_fabsf(oldN[0].y)))), sh, invHO);
+                        uint32_t hi, lo;
+                        SplitHalf2(oldN[0].x * sh, oldN[0].y * sh, hi, lo);
+                        uint16_t *hz = reinterpret_cast<uint16_t*>(&w.hro[0][0][0]);
+                        const uint32_t u = 80u - lane;
+                        hz[0 * kHrHalves + u] = uint16_t(hi); hz[1 * kHrHalves + u] = uint16_t(lo);
+                        hz[2 * kHrHalves + u] = uint16_t(hi >> 16); hz[3 * kHrHalves + u] = uint16_t(lo >> 16);
+                    }
+                    else
+                    {
 #pragma unroll
                     for(int q = 0; q < TAPS / 64; ++q) w.cold[64 + lane + 64 * q] = oldN[q];
+                    }
                 }
             }
             if constexpr (SENDS) fstC = fstN;
@@ -1005,11 +1044,14 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
         WaveSync();
         auto dumpAt = [](uint32_t f) { return MF ? f + (f >> 4) : f; };
+        if constexpr (!MF)
+        {   // (the matrix-pipe kernels add a replaced filter's fade-out straight into tile 0)
 #pragma unroll
         for(int q = 0; q < WL::kQ; ++q)
         {
             const f2 cur = dump[dumpAt(lane0 + 64 * q)];
             dump[dumpAt(lane0 + 64 * q)] = f2{cur.x + accO[q].x, cur.y + accO[q].y};
+        }
         }
         __syncthreads();
         f2 *ph = reinterpret_cast<f2*>(L.partHrtf) + size_t{group} * (kLine + kHrirLen);

@@ -92,8 +92,9 @@ struct alignas(16) WaveLds {
         };
     };
     float in[kHist + kLine];                            // [Hrtf.History | resampled, filtered samples]
-    f2 cold[TAPS + 128];                                // cold[k] = Hrtf.Old.Coeffs[k - 64], zero padded
-    f2 xo[64];                                          // old-filter fade-out inputs (i < 64), both ears
+    f2 cold[MF ? 1 : TAPS + 128];                       // cold[k] = Hrtf.Old.Coeffs[k - 64], zero padded
+    f2 xo[MF ? 1 : 64];                                 // old-filter fade-out inputs (i < 64), both ears
+    uint32_t hro[2][2][MF ? kHrDw : 1];                 // MF: a replaced filter's OLD response, reversed like hr
     float fst[32];                                      // the voice's two BiquadSlots (2 x 16 dwords)
     int32_t best;
     uint32_t pad[3];
