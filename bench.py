@@ -210,6 +210,18 @@ def cpu_baseline(config_id, nvoices, mhr_path, target_seconds=10.0):
     return out
 
 
+def mfma_block(kernel, voices, kernel_ms, moving):
+    """What the matrix pipe executes per launch of the matrix-pipe HRTF voice kernel: per voice 2 ears x 5 tiles x 3
+    K-chunks x 3 split-half products of v_mfma_f32_16x16x32_f16 (16 x 16 x 32 x 2 flop each), one more tile for a voice
+    whose filter was replaced; against the dense f16 peak (MI355X_MICROARCH.md: 2.5 PFLOP/s)."""
+    if not kernel.endswith("true>") or "VoiceWaveKernel<17, 64, 0" not in kernel:
+        return None
+    per = 16 * 16 * 32 * 2
+    n = voices * 90 + moving * 18
+    tf = n * per / (kernel_ms * 1e-3) / 1e12
+    return {"instructions_per_launch": n, "executed_tflops": tf, "dense_f16_peak": 2500.0, "frac_of_dense_f16_peak": tf / 2500.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +259,9 @@ def main():
     if oalgpu.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
     torch.cuda.set_device(local_rank)
+    # torch's lazy CUDA initialisation (hundreds of ms) happens HERE, not inside the first fence: there it left the GPU idle
+    # right before the timed block, whose 20 steps then ran on ramping clocks (63 against 48.7 us per step at K = 20)
+    torch.cuda.synchronize()
     api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank,
                      ctx_flags=(oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0) | args.xflags)
     real_mhr = os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr")
@@ -388,6 +403,9 @@ def main():
     sc.sync()
     sc.set_timing(False)
     vk_ms = float(np.mean(vk))
+    # the same clock around an EMPTY kernel: what the dispatch-bound events include besides a kernel's own run time
+    # (rocprofv3's kernel trace reports the voice kernel about this much shorter, profiles/README.md)
+    event_floor_ms = sc.event_floor_ms(200) if sc.voice_kernel_name().startswith("VoiceWaveKernel") else None
 
     if rank == 0:
         nvoices_total = V * world
@@ -438,13 +456,17 @@ def main():
                        "repeat_ms_per_step": {"n": len(extra), "median": float(np.median(extra)) if extra else None,
                                               "min": min(extra) if extra else None, "max": max(extra) if extra else None},
                        "parallelism": f"voice-shard x{world}" + (" + ncclReduce of the bus block to rank 0, issued by the library" if world > 1 else "")},
-            # 68 flop/B: the path sits above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B), so the
-            # binding roofline is the fp32 FMA rate of the vector pipes (the kernel issues v_pk_fma_f32;
-            # the MFMA variant of the FIR has the same fp32 peak and measured slower);
-            # `hbm_frac` is the "fraction of HBM roofline" BASELINE's metric string names
-            "roofline": {"bound": "fp32-valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            # 68 flop/B: the path sits above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B), so the binding
+            # roofline is arithmetic.  `achieved` prices the ALGORITHMIC fp32 flops of the path against
+            # the fp32 peak, 157.3 TFLOP/s -- the same figure for v_pk_fma_f32 and for fp32 MFMA on gfx950 -- as
+            # rounds 1 and 2 did.  The HRTF kernel's FIR (73 % of those flops) runs on the matrix pipe in split half
+            # precision (three v_mfma_f32_16x16x32_f16 products per fp32 product, Toeplitz tiles: DESIGN.md 3.1);
+            # what the pipe EXECUTES for it is under `mfma`.  `hbm_frac` is the "fraction of HBM roofline"
+            # BASELINE's metric string names.  kernel_ms: HIP events bound to the dispatch (hipExtLaunchKernel).
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": sc.voice_kernel_name(), "kernel_ms": vk_ms,
+                         "kernel": sc.voice_kernel_name(), "kernel_ms": vk_ms, "event_floor_ms": event_floor_ms,
+                         "mfma": mfma_block(sc.voice_kernel_name(), V, vk_ms, len(moving)),
                          "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
                          "hbm_achieved": hbm_achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s",
                          "hbm_frac": hbm_achieved / HBM_PEAK_GBS},

@@ -477,6 +477,10 @@ int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_stat
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);
 /* Enables/disables the event timing above (off by default: it adds two event records). */
 int oalgpu_set_timing(oalgpu_context *ctx, int enable);
+/* The floor of that clock: an EMPTY kernel (one wavefront that returns) dispatched on the context's stream and timed
+ * the same way as the voice kernel -- HIP events bound to the dispatch (hipExtLaunchKernel); the median of `reps`
+ * dispatches.  Whatever the events include besides a kernel's own run time is in this figure too. */
+int oalgpu_debug_event_floor_ms(oalgpu_context *ctx, uint32_t reps, float *ms);
 /* ---- the EffectStates of alc/effects/ besides the reverbs -----------------------------------------
  * EffectState::deviceUpdate / update / process (core/effects/base.h:197-209) of alc/effects/{equalizer,modulator,
  * echo,dedicated}.cpp.  create = deviceUpdate; update takes the effect's EFX properties (core/effects/base.h:

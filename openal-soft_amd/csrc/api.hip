@@ -5,6 +5,7 @@
 #include "../../include/oalgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>          // types and enums only: the library itself is resolved with dlopen/dlsym
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -1792,10 +1793,14 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
     if(int rc = FlushInits(c)) return rc;
     if(int rc = JoinPost(c)) return rc;
     if(!c->cbVoices.empty()) { if(int rc = ServiceCallbacks(c, samples_to_do)) return rc; }
-    if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
-    if(c->useWave) HIP_TRY(LaunchVoiceWave(c->stream, c->L, samples_to_do, c->profArg()));
-    else HIP_TRY(LaunchVoiceMix(c->stream, c->exact, c->L, samples_to_do, c->carryAccum));
-    if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
+    if(c->useWave)    // (timing: the two events are bound to the dispatch itself -- the kernel's own start and end)
+        HIP_TRY(LaunchVoiceWave(c->stream, c->L, samples_to_do, c->profArg(), c->timing ? c->evStart : nullptr, c->timing ? c->evVoice : nullptr));
+    else
+    {
+        if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
+        HIP_TRY(LaunchVoiceMix(c->stream, c->exact, c->L, samples_to_do, c->carryAccum));
+        if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
+    }
     // the wavefront kernel leaves the carried HRTF accumulator tail to the reduction
     LaunchBusReduce(c->stream, c->L, samples_to_do, c->useWave && c->carryAccum);
     HIP_TRY(hipGetLastError());
@@ -1882,9 +1887,8 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     // main stream: this update's voices; its partial-bus buffer was last read by the reduction
     // of two updates ago
     HIP_TRY(hipStreamWaitEvent(c->stream, c->evReduceDone[p], 0));
-    if(c->timing) HIP_TRY(hipEventRecord(c->evStart, c->stream));
-    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg()));
-    if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
+    // (timing: the two events are bound to the dispatch itself -- the kernel's own start and end)
+    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg(), c->timing ? c->evStart : nullptr, c->timing ? c->evVoice : nullptr));
     HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
     // post stream: the reduction (adds the carried HRTF accumulator tail); whatever follows on that stream -- a collective, the effects, the post-process -- runs beside
     // the next update's parameter and voice kernels
@@ -2096,6 +2100,26 @@ int oalgpu_last_update_ms(oalgpu_context *c, float *total_ms, float *voice_kerne
     if(int rc = oalgpu_sync(c)) return rc;
     if(total_ms) HIP_TRY(hipEventElapsedTime(total_ms, c->evStart, c->evEnd));
     if(voice_kernel_ms) HIP_TRY(hipEventElapsedTime(voice_kernel_ms, c->evStart, c->evVoice));
+    return OALGPU_OK;
+}
+
+__global__ void EmptyKernel() {}
+
+int oalgpu_debug_event_floor_ms(oalgpu_context *c, uint32_t reps, float *ms)
+{
+    if(!c || !ms || reps == 0 || reps > 4096) return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_event_floor_ms: bad arguments");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    std::vector<float> each(reps);
+    for(uint32_t r = 0; r < reps; ++r)
+    {
+        hipExtLaunchKernelGGL(EmptyKernel, dim3(1), dim3(64), 0, c->stream, c->evStart, c->evVoice, 0u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventSynchronize(c->evVoice));
+        HIP_TRY(hipEventElapsedTime(&each[r], c->evStart, c->evVoice));
+    }
+    std::sort(each.begin(), each.end());
+    *ms = each[reps / 2];
     return OALGPU_OK;
 }
 

@@ -350,6 +350,7 @@ uint32_t WaveKernelGroups(const DeviceLayout &L);
 // the measurement variant's extras (OALGPU_CTX_PROFILE, tools/phase_times.py): s_memtime stamps
 // [voice][8] | [wavefront][4], and the stages to skip; production launches pass null
 struct WaveProf { unsigned long long *times; uint32_t ablate; };
-hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof = nullptr);
+hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof = nullptr,
+    hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
 
 } // namespace oalgpu

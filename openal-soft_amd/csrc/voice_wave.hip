@@ -29,6 +29,7 @@
 // the tolerance stated in DESIGN.md; all integer state (positions, loop wrap, play state,
 // delays, fade counters) is bit-exact.  EXACT mode and every other configuration (sends, non-HRTF
 // buses) run voice_kernel.hip.
+#include <hip/hip_ext.h>
 #include "wave_common.hpp"
 
 #pragma clang fp contract(off)
@@ -1095,7 +1096,9 @@ uint32_t WaveKernelGroups(const DeviceLayout &L)
 }
 
 // prof: null in production; the measurement variants exist for the HRTF kernels without sends only
-hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof)
+// evStart / evStop (both or neither): HIP events bound to the DISPATCH (hipExtLaunchKernel) -- the kernel's own start and end,
+// what rocprofv3's kernel trace reports, without the command-processor time an event recorded around the launch includes
+hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop)
 {
     const uint32_t groups = WaveKernelGroups(L);
     const bool sends = L.numSends != 0;
@@ -1103,28 +1106,28 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     const WaveProf none{nullptr, 0u};
     if(prof && L.hrtf && !sends && L.irStride <= 64)
     {
-        if(L.firMfma) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, *prof);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, *prof);
+        if(L.firMfma) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof);
     }
     else if(!L.hrtf)
     {
-        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, L, samplesToDo, none);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false>), grid, block, 0, s, L, samplesToDo, none);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
     }
     else if(L.irStride <= 64 && L.firMfma)
     {
-        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true>), grid, block, 0, s, L, samplesToDo, none);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, false, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, none);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none);
     }
     else if(L.irStride <= 64)
     {
-        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, L, samplesToDo, none);
-        else hipLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, none);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none);
     }
     else
     {
-        if(sends) hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, L, samplesToDo, none);
-        else hipLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, WaveArgsHrtf{L}, samplesToDo, none);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none);
     }
     return hipGetLastError();
 }

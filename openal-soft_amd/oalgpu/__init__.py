@@ -171,6 +171,7 @@ def _load():
     L.oalgpu_voice_readback.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(VoiceState)]
     L.oalgpu_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.oalgpu_last_update_ms.argtypes = [C.c_void_p, f32p, f32p]
+    L.oalgpu_debug_event_floor_ms.argtypes = [C.c_void_p, C.c_uint32, f32p]
     return L
 
 
@@ -637,6 +638,12 @@ class Scene:
         a, b = C.c_float(), C.c_float()
         check(lib.oalgpu_last_update_ms(self.h, C.byref(a), C.byref(b)), "oalgpu_last_update_ms")
         return a.value, b.value
+
+    def event_floor_ms(self, reps=200):
+        """what the dispatch-bound HIP events report for an EMPTY kernel (median of `reps`)"""
+        a = C.c_float()
+        check(lib.oalgpu_debug_event_floor_ms(self.h, reps, C.byref(a)), "oalgpu_debug_event_floor_ms")
+        return a.value
 
 
 def comm_unique_id():

@@ -29,3 +29,13 @@ for k in range(N):
     sc.mix(1024, post_process=True)
 t1 = time.perf_counter(); sc.sync(); t2 = time.perf_counter()
 print("mix only: host %.1f us, total %.1f us" % ((t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6))
+def timed(label, fn, n=400):
+    sc.sync(); t0 = time.perf_counter()
+    for k in range(n): fn(k)
+    t1 = time.perf_counter(); sc.sync(); t2 = time.perf_counter()
+    print("%-44s host %.1f us, total %.1f us per call" % (label, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
+timed("apply_block only", lambda k: sc.apply_block(blocks[k % 40]))
+timed("mix(post_process=False) only", lambda k: sc.mix(1024, post_process=False))
+timed("mix(post_process=True) only", lambda k: sc.mix(1024, post_process=True))
+timed("apply + mix(post_process=True)", lambda k: (sc.apply_block(blocks[k % 40]), sc.mix(1024, post_process=True)))
+timed("apply + mix(post_process=False)", lambda k: (sc.apply_block(blocks[k % 40]), sc.mix(1024, post_process=False)))

@@ -1,10 +1,14 @@
 # kernel timeline of a few steady-state updates (rocprofv3 kernel trace).  gpurun -- "bash tools/r3_trace.sh [bench args]"
 export TMPDIR=/tmp
 O=gpurun_out/r3t; mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof -o p -- python bench.py --steps 60 --warmup 10 --repeats 0 --no-cpu-baseline "$@" < /dev/null > $O/prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/prof -o p -- python bench.py --steps 60 --warmup 10 --repeats 0 --no-cpu-baseline "$@" < /dev/null > $O/prof.log 2>&1
 python - <<'PY'
 import csv
-rows = list(csv.DictReader(open("gpurun_out/r3t/prof/p_kernel_trace.csv")))
+import glob
+rows = list(csv.DictReader(open(glob.glob("gpurun_out/r3t/prof/**/p_kernel_trace.csv", recursive=True)[0])))
+for c in glob.glob("gpurun_out/r3t/prof/**/p_memory_copy_trace.csv", recursive=True):
+    for r in csv.DictReader(open(c)):
+        rows.append({"Kernel_Name": "COPY " + r.get("Direction", ""), "Start_Timestamp": r["Start_Timestamp"], "End_Timestamp": r["End_Timestamp"], "Queue_Id": "-"})
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     for k in ("VoiceWave", "StageParams", "ApplyParams", "BusReduce", "PostDirect"):
