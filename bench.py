@@ -238,6 +238,7 @@ def main():
     ap.add_argument("--fir", default="mfma", choices=("mfma", "valu"),
                     help="HRTF voices' dual-ear FIR: the matrix pipe in split half precision (the product default) or "
                          "packed fp32 VALU FMAs (OALGPU_CTX_FIR_VALU), for A/B runs")
+    ap.add_argument("--preroll", type=int, default=None, help="untimed steps in front of the W warm-up steps, W included (default 2000)")
     ap.add_argument("--xflags", type=int, default=0, help="experiment bits or-ed into oalgpu_context_desc::flags")
     ap.add_argument("--run", type=int, default=0, metavar="B",
                     help="submit the steps B at a time through oalgpu_mix_update_run (one library call per B updates "
@@ -331,8 +332,10 @@ def main():
 
     # Pre-roll: the scene is brought to its steady state (every voice mid-buffer, the two-stream
     # pipeline full, GPU clocks up) before the W warm-up and the K timed steps the contract names;
-    # without it a short run (K = 50 is 3 ms) measures the clock ramp: 58.9 vs 54.9 us per step.
-    preroll = max(0, 400 - args.warmup)
+    # without it a short run (K = 20 is 1 ms) measures the clock ramp, which takes tens of milliseconds:
+    # the K = 20 block after 5 / 50 / 150 / 400 / 1500 untimed steps ran at 59 / 54 / 51 / 51 / 48 us per step
+    # (two runs each, profiles/r3/preroll_sweep.txt).
+    preroll = max(0, (2000 if args.preroll is None else args.preroll) - args.warmup)
     if B:
         preroll -= preroll % B
     # (no fence between pre-roll and warm-up: a drained pipeline and an idle GPU right before the W warm-up
