@@ -391,6 +391,49 @@ def main():
         e2e_ms = each[len(each) // 2]         # the median of 40: a host that is pre-empted once does not decide the figure
         e2e_p90_ms = each[(len(each) * 9) // 10]
 
+    # ---- end-to-end THROUGHPUT through the pipelined boundary: per update the moving voices' 24-byte move records go
+    # in from host memory (oalgpu_voice_move_async: the index half of getCoeffs on the host into a pinned ring slot,
+    # H2D on a copy stream beside the update that is mixing, the installing kernel in front of the next voice kernel),
+    # the update runs with its post-process, the stereo output comes back (oalgpu_read_output_async into a pinned ring
+    # slot, collected two updates late).  Nothing waits for anything but the output of two updates ago.
+    e2e_tput = None
+    if world == 1 and moving and hrtf and not B:
+        def moves_of(update):
+            m = np.zeros(len(moving), oalgpu.MOVE_DTYPE)
+            for i, v in enumerate(moving):
+                ev, az, gain = script.direction(v, update)
+                m[i] = (v, ev, az, 2.0, 0.0, gain)
+            return m
+        mv = [moves_of(700 + k) for k in range(8)]
+        outbuf = np.empty((2, 1024), np.float32)
+
+        def run(n):
+            tickets = []
+            busy = 0.0
+            sc.sync()
+            t0 = time.perf_counter()
+            for k in range(n):
+                h0 = time.perf_counter()
+                sc.move_async(mv[k % len(mv)])
+                sc.mix(UPDATE_SAMPLES, post_process=post)
+                tickets.append(sc.read_output_async())
+                busy += time.perf_counter() - h0
+                if k >= 2:
+                    sc.output_wait(tickets[k - 2], outbuf)
+            for t in tickets[-2:]:
+                sc.output_wait(t, outbuf)
+            return time.perf_counter() - t0, busy
+        run(50)
+        n_tp = 400
+        each = sorted(run(n_tp) for _ in range(3))
+        dt, busy = each[1]
+        e2e_tput = {"e2e_voices_per_s": V * n_tp / dt, "ms_per_update": dt / n_tp * 1e3, "host_submit_share": busy / dt,
+                    "updates": n_tp, "moved_voices_per_update": len(moving),
+                    "note": "median of 3 runs; per update: oalgpu_voice_move_async (host HRIR-blend indices + H2D on the copy stream + "
+                            "ApplyMovesKernel) + oalgpu_mix_update + post-process + oalgpu_read_output_async, output collected "
+                            "two updates late (oalgpu_output_wait); host_submit_share = the calling thread's time inside those "
+                            "three calls / wall time (python + ctypes included)"}
+
     # ---- instrumented pass: HIP events on the context's stream around each voice-kernel launch
     sc.set_timing(True)
     vk = []
@@ -453,6 +496,7 @@ def main():
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
                        "preroll_steps": preroll, "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
                        "e2e_ms_per_update": e2e_ms, "e2e_ms_per_update_p90": e2e_p90_ms if e2e_ms is not None else None,
+                       "e2e_throughput": e2e_tput,
                        "e2e_note": "one update alone through the C-ABI from host memory: oalgpu_voice_set_params of the "
                                    f"{len(moving)} moving voices (host biquad design + H2D) + oalgpu_mix_update + "
                                    "oalgpu_read_dry (D2H, sync); no overlap -- a latency, not the throughput `value` is",

@@ -472,6 +472,24 @@ typedef struct oalgpu_voice_state {
 } oalgpu_voice_state;
 int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_state *out);
 
+/* ---- the pipelined host boundary: an update's moved voices in, its output lines out, nothing waits ---------------------
+ * What CalcPanningAndFilters (alc/alu.cpp:1512-1657) hands over for a voice whose direction moved while its filter
+ * targets stayed: the HRTF direction and gain.  oalgpu_voice_move_async evaluates the index half of
+ * HrtfStore::getCoeffs (core/hrtf.cpp:192-245) on the host into a pinned ring slot, copies the records over on a copy
+ * stream of its own (beside the update that is mixing) and queues the kernel that installs them in front of the
+ * next oalgpu_mix_update; it returns without waiting for any of that.  HRTF contexts only. */
+typedef struct oalgpu_voice_move {
+    uint32_t voice;
+    float hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread;   /* as in oalgpu_voice_params */
+    float hrtf_gain;
+} oalgpu_voice_move;
+int oalgpu_voice_move_async(oalgpu_context *ctx, const oalgpu_voice_move *moves, size_t count);
+/* Queues the copy of the update's output lines -- the real lines of an HRTF / decoded context (left, right, ...), else
+ * the dry lines; [line][1024] floats -- into a pinned ring slot behind the update's post-process and returns a ticket;
+ * oalgpu_output_wait blocks until that copy has landed and hands the lines over.  Four tickets may be outstanding. */
+int oalgpu_read_output_async(oalgpu_context *ctx, uint32_t *ticket);
+int oalgpu_output_wait(oalgpu_context *ctx, uint32_t ticket, float *out, size_t out_floats);
+
 /* Timing of the last oalgpu_mix_update/mix_voices launch sequence, measured with HIP events on
  * the context's stream: total milliseconds, and the share of the voice kernel. */
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);

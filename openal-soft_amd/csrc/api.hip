@@ -107,6 +107,17 @@ struct oalgpu_context {
     hipEvent_t evVoiceDone[2]{nullptr, nullptr}, evReduceDone[2]{nullptr, nullptr}, evPostDone{nullptr};
     uint32_t parity{0};
     bool postPending{false};
+    // the pipelined host boundary (oalgpu_voice_move_async / oalgpu_read_output_async): pinned ring slots
+    static constexpr uint32_t kIoSlots = 4;
+    hipStream_t copyStream{nullptr};
+    MoveRecord *panHost[kIoSlots]{}, *panDev[kIoSlots]{};
+    size_t panCap{0};
+    hipEvent_t panCopied[kIoSlots]{}, panApplied[kIoSlots]{};
+    uint32_t panNext{0};
+    float *outHost[kIoSlots]{};
+    hipEvent_t outDone[kIoSlots]{};
+    uint32_t outNext{0};
+    size_t outFloats{0};
     float *partHrtfBuf[2]{nullptr, nullptr};
     float *partLinesBuf[2]{nullptr, nullptr};
     bool timing{false}, timed{false};
@@ -188,6 +199,14 @@ struct oalgpu_context {
     ~oalgpu_context()
     {
         for(void *p : bufferData) if(p) (void)hipFree(p);
+        for(uint32_t k = 0; k < kIoSlots; ++k)
+        {
+            if(panHost[k]) (void)hipHostFree(panHost[k]);
+            if(panDev[k]) (void)hipFree(panDev[k]);
+            if(outHost[k]) (void)hipHostFree(outHost[k]);
+            for(hipEvent_t e : {panCopied[k], panApplied[k], outDone[k]}) if(e) (void)hipEventDestroy(e);
+        }
+        if(copyStream) (void)hipStreamDestroy(copyStream);
         if(evStart) (void)hipEventDestroy(evStart);
         if(evVoice) (void)hipEventDestroy(evVoice);
         if(evEnd) (void)hipEventDestroy(evEnd);
@@ -1338,21 +1357,25 @@ int oalgpu_buffer_channel_view(oalgpu_context *c, int buffer, uint32_t channel)
     return int(c->numBuffers++);
 }
 
+// the host's view of the loaded store, for HrtfBlendFor
+static HrtfStoreDev HostStoreView(const HrtfData &h)
+{
+    HrtfStoreDev st{};
+    st.irSize = h.irSize; st.numFields = uint32_t(h.fieldDistance.size());
+    st.numElevs = uint32_t(h.elevAzCount.size()); st.numIrs = h.numIrs();
+    st.fieldDistance = h.fieldDistance.data(); st.fieldEvCount = h.fieldEvCount.data();
+    st.elevAzCount = h.elevAzCount.data(); st.elevIrOffset = h.elevIrOffset.data();
+    st.coeffs = h.coeffs.data(); st.delays = h.delays.data();
+    return st;
+}
+
 static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params,
     size_t count, std::vector<ParamRecord> &recs)
 {
     const TableBlob &blob = Blob();
     recs.resize(count);
     HrtfStoreDev hostStore{};
-    if(c->L.hrtf && c->hrtfLoaded)
-    {
-        const HrtfData &h = c->hrtfHost;
-        hostStore.irSize = h.irSize; hostStore.numFields = uint32_t(h.fieldDistance.size());
-        hostStore.numElevs = uint32_t(h.elevAzCount.size()); hostStore.numIrs = h.numIrs();
-        hostStore.fieldDistance = h.fieldDistance.data(); hostStore.fieldEvCount = h.fieldEvCount.data();
-        hostStore.elevAzCount = h.elevAzCount.data(); hostStore.elevIrOffset = h.elevIrOffset.data();
-        hostStore.coeffs = h.coeffs.data(); hostStore.delays = h.delays.data();
-    }
+    if(c->L.hrtf && c->hrtfLoaded) hostStore = HostStoreView(c->hrtfHost);
     for(size_t i = 0; i < count; ++i)
     {
         const oalgpu_voice_params &p = params[i];
@@ -1455,6 +1478,100 @@ void oalgpu_param_block_destroy(oalgpu_param_block *b)
     if(!b) return;
     (void)hipSetDevice(b->device);
     delete b;
+}
+
+int oalgpu_voice_move_async(oalgpu_context *c, const oalgpu_voice_move *pans, size_t count)
+{
+    if(!c || !pans) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(count == 0) return OALGPU_OK;
+    if(!c->L.hrtf) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: HRTF contexts only");
+    if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(count > c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: more records than voices");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(!c->copyStream) HIP_TRY(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+    if(c->panCap < count)
+    {   // (grows only while nothing is in flight: the first call, or a larger batch than ever before)
+        if(int rc = oalgpu_sync(c)) return rc;
+        HIP_TRY(hipStreamSynchronize(c->copyStream));
+        for(uint32_t k = 0; k < oalgpu_context::kIoSlots; ++k)
+        {
+            if(c->panHost[k]) { HIP_TRY(hipHostFree(c->panHost[k])); c->panHost[k] = nullptr; }
+            if(c->panDev[k]) { HIP_TRY(hipFree(c->panDev[k])); c->panDev[k] = nullptr; }
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->panHost[k]), c->L.numVoices * sizeof(MoveRecord), hipHostMallocDefault));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->panDev[k]), c->L.numVoices * sizeof(MoveRecord)));
+            if(!c->panCopied[k]) HIP_TRY(hipEventCreateWithFlags(&c->panCopied[k], hipEventDisableTiming));
+            if(!c->panApplied[k]) HIP_TRY(hipEventCreateWithFlags(&c->panApplied[k], hipEventDisableTiming));
+        }
+        c->panCap = c->L.numVoices;
+        c->panNext = 0;
+    }
+    const uint32_t slot = c->panNext % oalgpu_context::kIoSlots;
+    if(c->panNext >= oalgpu_context::kIoSlots) HIP_TRY(hipEventSynchronize(c->panApplied[slot]));   // its last use, four batches ago
+    MoveRecord *recs = c->panHost[slot];
+    const HrtfStoreDev store = HostStoreView(c->hrtfHost);
+    for(size_t i = 0; i < count; ++i)
+    {
+        const oalgpu_voice_move &p = pans[i];
+        if(p.voice >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: bad voice index");
+        MoveRecord &r = recs[i];
+        const HrirBlend b = HrtfBlendFor(store, p.hrtf_ev, p.hrtf_az, p.hrtf_dist, p.hrtf_spread);
+        r.voice = p.voice;
+        for(int k = 0; k < 4; ++k) { r.hrtfIdx[k] = b.idx[k]; r.hrtfW[k] = b.w[k]; }
+        r.hrtfPass = b.passthru;
+        r.hrtfDelay[0] = b.delay[0]; r.hrtfDelay[1] = b.delay[1];
+        r.hrtfGain = p.hrtf_gain;
+    }
+    HIP_TRY(hipMemcpyAsync(c->panDev[slot], recs, count * sizeof(MoveRecord), hipMemcpyHostToDevice, c->copyStream));
+    HIP_TRY(hipEventRecord(c->panCopied[slot], c->copyStream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->panCopied[slot], 0));
+    LaunchApplyMoves(c->stream, c->L, c->panDev[slot], uint32_t(count));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->panApplied[slot], c->stream));
+    ++c->panNext;
+    return OALGPU_OK;
+}
+
+static size_t OutputLineFloats(const oalgpu_context *c)
+{
+    return size_t{c->L.numReal ? c->L.numReal : c->L.numDry} * kLine;
+}
+
+int oalgpu_read_output_async(oalgpu_context *c, uint32_t *ticket)
+{
+    if(!c || !ticket) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    const size_t floats = OutputLineFloats(c);
+    if(c->outFloats != floats)
+    {
+        for(uint32_t k = 0; k < oalgpu_context::kIoSlots; ++k)
+        {
+            if(c->outHost[k]) { HIP_TRY(hipHostFree(c->outHost[k])); c->outHost[k] = nullptr; }
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->outHost[k]), floats * sizeof(float), hipHostMallocDefault));
+            if(!c->outDone[k]) HIP_TRY(hipEventCreateWithFlags(&c->outDone[k], hipEventDisableTiming));
+        }
+        c->outFloats = floats;
+    }
+    const uint32_t slot = c->outNext % oalgpu_context::kIoSlots;
+    // behind whatever produced the lines: the post stream of a pipelined context, else the main one
+    hipStream_t s = (c->useWave && c->ownStream && !c->serialOnly && c->postStream) ? c->postStream : c->stream;
+    const float *src = c->L.numReal ? c->L.bus + size_t{c->L.numDry} * kLine : c->L.bus;
+    HIP_TRY(hipMemcpyAsync(c->outHost[slot], src, floats * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(c->outDone[slot], s));
+    *ticket = c->outNext++;
+    return OALGPU_OK;
+}
+
+int oalgpu_output_wait(oalgpu_context *c, uint32_t ticket, float *out, size_t out_floats)
+{
+    if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(ticket >= c->outNext || c->outNext - ticket > oalgpu_context::kIoSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_output_wait: the ticket's slot was reused (four may be outstanding)");
+    if(out_floats < c->outFloats) return Fail(OALGPU_ERR_INVALID, "oalgpu_output_wait: the buffer is smaller than the output lines");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    const uint32_t slot = ticket % oalgpu_context::kIoSlots;
+    HIP_TRY(hipEventSynchronize(c->outDone[slot]));
+    std::memcpy(out, c->outHost[slot], c->outFloats * sizeof(float));
+    return OALGPU_OK;
 }
 
 int oalgpu_set_stream(oalgpu_context *c, void *hip_stream)

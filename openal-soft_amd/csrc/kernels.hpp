@@ -103,6 +103,19 @@ struct ParamRecord {
     uint32_t pad;
 };
 
+// What is left of a ParamRecord when only a voice's DIRECTION moved (the common case of an update: CalcPanningAndFilters,
+// alc/alu.cpp:1512-1657, with unchanged filter targets): the HRIR blend and the gain.  ApplyMovesKernel.
+struct MoveRecord {
+    uint32_t voice;
+    uint32_t hrtfIdx[4];
+    float hrtfW[4];
+    float hrtfPass;
+    uint32_t hrtfDelay[2];
+    float hrtfGain;
+    uint32_t pad[3];
+};
+static_assert(sizeof(MoveRecord) == 64, "MoveRecord");
+
 struct DeviceLayout {
     // configuration
     uint32_t numVoices, numDry, numReal, numSends, numSlots, wetChannels;
@@ -149,6 +162,27 @@ __host__ __device__ inline size_t BusAccumOffset(const DeviceLayout &L)
 __host__ __device__ inline size_t BusFloats(const DeviceLayout &L)
 { return BusAccumOffset(L) + size_t{kLine + kHrirLen} * 2; }
 
+// The weighted sum of HrtfStore::getCoeffs (core/hrtf.cpp:247-259) into voice v's target filter, by one wavefront.
+__device__ __forceinline__ void ApplyHrtfTargetWave(const DeviceLayout &L, uint32_t v, const uint32_t (&idx)[4], const float (&w)[4],
+    float pass, uint32_t lane)
+{
+    const uint32_t i0 = idx[0], i1 = idx[1], i2 = idx[2], i3 = idx[3];
+    const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    // The mixers apply IrSize taps (rounded up to even: ApplyCoeffs works on pairs, mixer_sse.cpp:46-51); a data
+    // set resampled to the device's rate carries non-zero taps beyond that (GetLoadedHrtf resamples whole
+    // HrirArrays), which the voice kernels' fixed-length FIRs must not see
+    const uint32_t live = ((L.irSize + 1u) & ~1u) * 2u;
+    for(uint32_t e = lane; e < L.irStride * 2; e += 64)
+    {   // hrtf.cpp:247-259: the pass-through tap (elements 0, 1) or 0, then the four weighted HRIRs in order
+        float x = (e < 2) ? pass : 0.0f;
+        x = L.hrirs[size_t{i0} * (kHrirLen * 2) + e] * w0 + x;
+        x = L.hrirs[size_t{i1} * (kHrirLen * 2) + e] * w1 + x;
+        x = L.hrirs[size_t{i2} * (kHrirLen * 2) + e] * w2 + x;
+        x = L.hrirs[size_t{i3} * (kHrirLen * 2) + e] * w3 + x;
+        L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = (e < live) ? x : 0.0f;
+    }
+}
+
 // One parameter record applied by one wavefront (ApplyParamsKernel): the CalcVoiceParams results scattered into
 // the voice arrays, the weighted sum of HrtfStore::getCoeffs (core/hrtf.cpp:247-259) and the
 // BiquadInterpFilter::setParams state machine (biquad.cpp:131-149).
@@ -178,24 +212,7 @@ __device__ __forceinline__ void ApplyRecordWave(const DeviceLayout &L, const Par
         const uint32_t i = (lane - 8) >> 1, hp = (lane - 8) & 1u;
         BiquadSetTarget(L.sfilt[(size_t{v} * L.numSends + i) * 2 + hp].f, hp ? r.sendHp[i] : r.sendLp[i]);
     }
-    if(L.hrtf)
-    {
-        const uint32_t i0 = r.hrtfIdx[0], i1 = r.hrtfIdx[1], i2 = r.hrtfIdx[2], i3 = r.hrtfIdx[3];
-        const float w0 = r.hrtfW[0], w1 = r.hrtfW[1], w2 = r.hrtfW[2], w3 = r.hrtfW[3], pass = r.hrtfPass;
-        // The mixers apply IrSize taps (rounded up to even: ApplyCoeffs works on pairs, mixer_sse.cpp:46-51); a data
-        // set resampled to the device's rate carries non-zero taps beyond that (GetLoadedHrtf resamples whole
-        // HrirArrays), which the voice kernels' fixed-length FIRs must not see
-        const uint32_t live = ((L.irSize + 1u) & ~1u) * 2u;
-        for(uint32_t e = lane; e < L.irStride * 2; e += 64)
-        {   // hrtf.cpp:247-259: the pass-through tap (elements 0, 1) or 0, then the four weighted HRIRs in order
-            float x = (e < 2) ? pass : 0.0f;
-            x = L.hrirs[size_t{i0} * (kHrirLen * 2) + e] * w0 + x;
-            x = L.hrirs[size_t{i1} * (kHrirLen * 2) + e] * w1 + x;
-            x = L.hrirs[size_t{i2} * (kHrirLen * 2) + e] * w2 + x;
-            x = L.hrirs[size_t{i3} * (kHrirLen * 2) + e] * w3 + x;
-            L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = (e < live) ? x : 0.0f;
-        }
-    }
+    if(L.hrtf) ApplyHrtfTargetWave(L, v, r.hrtfIdx, r.hrtfW, r.hrtfPass, lane);
     else if(lane < L.numDry)
         L.gainTgt[size_t{v} * L.numDry + lane] = r.dryGains[lane];
     for(uint32_t k = lane; k < L.numSends * L.wetChannels; k += 64)
@@ -323,6 +340,7 @@ void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
 // ---- launchers (voice_kernel.hip) ----
 void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);
 void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count);
+void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count);
 // returns hipSuccess or the launch error
 hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum);
 // besideVoiceKernel: the post-stream shape (4-wave workgroups of <= 32 VGPRs that fit on a CU next to

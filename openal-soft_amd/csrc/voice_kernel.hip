@@ -159,6 +159,26 @@ void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *
     if(count) hipLaunchKernelGGL(ApplyParamsKernel, dim3(count), dim3(64), 0, s, L, recs);
 }
 
+// A moved voice of an HRTF context: new target filter, delays and gain; the filter is marked as replaced.
+__global__ void __launch_bounds__(64) ApplyMovesKernel(DeviceLayout L, const MoveRecord *__restrict__ recs)
+{
+    const MoveRecord &r = recs[blockIdx.x];
+    const uint32_t v = r.voice, lane = threadIdx.x;
+    if(lane == 0)
+    {
+        VoiceCtl &ctl = L.ctl[v];
+        ctl.flags |= kFlagHasHrtf | kFlagHrtfDirty;
+        ctl.hrtfTgtDelay[0] = r.hrtfDelay[0]; ctl.hrtfTgtDelay[1] = r.hrtfDelay[1];
+        ctl.hrtfTgtGain = r.hrtfGain;
+    }
+    ApplyHrtfTargetWave(L, v, r.hrtfIdx, r.hrtfW, r.hrtfPass, lane);
+}
+
+void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count)
+{
+    if(count) hipLaunchKernelGGL(ApplyMovesKernel, dim3(count), dim3(64), 0, s, L, recs);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Voice kernel
 // ---------------------------------------------------------------------------------------------

@@ -29,6 +29,9 @@ FMT_DTYPES = {FMT_UBYTE: np.uint8, FMT_SHORT: np.int16, FMT_INT: np.int32, FMT_F
 VOICE_STOPPED, VOICE_PLAYING, VOICE_STOPPING, VOICE_PENDING = range(4)
 
 f32p = C.POINTER(C.c_float)
+# oalgpu_voice_move
+MOVE_DTYPE = np.dtype([("voice", np.uint32), ("hrtf_ev", np.float32), ("hrtf_az", np.float32), ("hrtf_dist", np.float32),
+                       ("hrtf_spread", np.float32), ("hrtf_gain", np.float32)])
 u32p = C.POINTER(C.c_uint32)
 
 
@@ -474,6 +477,27 @@ class Scene:
         check(lib.oalgpu_voice_set_params(self.h, voices.ctypes.data_as(u32p),
                                           C.cast(params_array, C.c_void_p), len(voices)),
               "oalgpu_voice_set_params")
+
+    def move_async(self, moves):
+        """moves: structured array of MOVE_DTYPE (voice, hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread, hrtf_gain): the moved voices of
+        the next update; returns without waiting (oalgpu_voice_move_async)"""
+        moves = np.ascontiguousarray(moves, MOVE_DTYPE)
+        lib.oalgpu_voice_move_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        check(lib.oalgpu_voice_move_async(self.h, moves.ctypes.data_as(C.c_void_p), len(moves)), "oalgpu_voice_move_async")
+
+    def read_output_async(self):
+        lib.oalgpu_read_output_async.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        t = C.c_uint32()
+        check(lib.oalgpu_read_output_async(self.h, C.byref(t)), "oalgpu_read_output_async")
+        return t.value
+
+    def output_wait(self, ticket, out=None):
+        n = self.desc.num_real_channels or self.desc.num_dry_channels
+        if out is None:
+            out = np.empty((n, BUFFER_LINE), np.float32)
+        lib.oalgpu_output_wait.argtypes = [C.c_void_p, C.c_uint32, f32p, C.c_size_t]
+        check(lib.oalgpu_output_wait(self.h, ticket, _fp(out), out.size), "oalgpu_output_wait")
+        return out
 
     def param_block(self, voices, params_array):
         voices = np.ascontiguousarray(voices, np.uint32)

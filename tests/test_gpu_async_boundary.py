@@ -1,0 +1,67 @@
+"""The pipelined host boundary (oalgpu_voice_move_async / oalgpu_read_output_async / oalgpu_output_wait): six updates of
+a config-3 scene whose moving voices are moved through it, outputs collected two updates late, against the same scene
+driven through oalgpu_voice_set_params + oalgpu_read_dry with a synchronisation after every update.  A moved voice's
+record carries the same direction and gain as its full parameter record, so the two must agree to the bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _moves(oalgpu, script, voices, update):
+    m = np.zeros(len(voices), oalgpu.MOVE_DTYPE)
+    for i, v in enumerate(voices):
+        ev, az, gain = script.direction(v, update)
+        m[i] = (v, ev, az, 2.0, 0.0, gain)
+    return m
+
+
+def test_async_boundary_matches_the_synchronous_one(synth_mhr):
+    import oalgpu
+    from oalgpu import synth
+    import bench
+    mhr = open(synth_mhr, "rb").read()
+    V, updates = 512, 6
+    outs = {}
+    for mode in ("sync", "async"):
+        api = oalgpu.Api(oalgpu.MATH_FAST)
+        api._mhr = mhr
+        sc, script = bench.build_scene(oalgpu, synth, api, 3, V, 0, mhr, 0)
+        allv = list(range(V))
+        moving = [v for v in allv if script.is_moving(v)]
+        sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
+        got = []
+        if mode == "sync":
+            for k in range(updates):
+                if k:
+                    sc.set_params_batch(moving, bench.param_array(oalgpu, script, moving, k))
+                sc.mix(1024, post_process=True)
+                got.append(sc.dry()[4:6].copy())
+        else:
+            tickets = []
+            for k in range(updates):
+                if k:
+                    sc.move_async(_moves(oalgpu, script, moving, k))
+                sc.mix(1024, post_process=True)
+                tickets.append(sc.read_output_async())
+                if k >= 2:
+                    got.append(sc.output_wait(tickets[k - 2]).copy())
+            for t in tickets[-2:]:
+                got.append(sc.output_wait(t).copy())
+            with pytest.raises(oalgpu.OalgpuError):
+                sc.output_wait(tickets[0])        # that slot has been reused: four tickets may be outstanding
+        outs[mode] = got
+        sc.close()
+    assert len(outs["sync"]) == len(outs["async"]) == updates
+    sounded = 0.0
+    for k in range(updates):
+        a, b = outs["sync"][k], outs["async"][k]
+        assert a.shape == b.shape == (2, 1024)
+        sounded = max(sounded, float(np.abs(a).max()))
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+    assert sounded > 1e-3
