@@ -338,10 +338,23 @@ def main():
     preroll = max(0, (2000 if args.preroll is None else args.preroll) - args.warmup)
     if B:
         preroll -= preroll % B
-    # (no fence between pre-roll and warm-up: a drained pipeline and an idle GPU right before the W warm-up
-    # steps made the contract's block the slowest one of a short run -- 61.5 against 57.1 us per step at K = 20)
+    # The step loop gains only ~10 us on the GPU per step (host 32 us, GPU 42.5 us), so a block that starts from an empty
+    # queue -- as the contract's does -- has no lead to absorb a hiccup of the submitting thread.  Two sources were found:
+    # (1) the interpreter's garbage collector (the scene's parameter arrays are ~10^5 ctypes objects to walk; nothing in
+    # the loop creates cycles: collect once, then keep it off); (2) the HIP runtime, which reclaims the commands of
+    # everything submitted since the last device-wide synchronisation inside one of the first calls AFTER the next one
+    # -- behind 2000 unsynchronised pre-roll steps that was a single 150-270 us call within the first ten steps of the
+    # timed block (63 / 52 / 57 / 71 us per step at K = 20 on some runs, 47 on others; the repeat blocks, 20 steps
+    # behind their fence, never showed it).  The pre-roll therefore synchronises every 25 steps: K = 20 blocks then
+    # measure 45.2-46.7 us per step in six of six runs (profiles/r3/contract_block.txt).
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for k in range(preroll):
         step(k)
+        if k % 25 == 24:
+            fence()
     for k in range(args.warmup):
         step(k)
     fence()

@@ -2005,16 +2005,17 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     // of two updates ago
     HIP_TRY(hipStreamWaitEvent(c->stream, c->evReduceDone[p], 0));
     // (timing: the two events are bound to the dispatch itself -- the kernel's own start and end)
-    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg(), c->timing ? c->evStart : nullptr, c->timing ? c->evVoice : nullptr));
-    HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
+    // The event the post stream waits for is bound to the voice kernel's dispatch (hipExtLaunchKernel's stop event: one
+    // runtime call less per update than a record behind the launch).  Timing runs use that slot for their own event.
+    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg(), c->timing ? c->evStart : nullptr, c->timing ? c->evVoice : c->evVoiceDone[p]));
+    if(c->timing) HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
     // post stream: the reduction (adds the carried HRTF accumulator tail); whatever follows on that stream -- a collective, the effects, the post-process -- runs beside
     // the next update's parameter and voice kernels
     HIP_TRY(hipStreamWaitEvent(c->postStream, c->evVoiceDone[p], 0));
     // (4-wavefront workgroups: they find room on a CU as soon as ONE of the next update's voice workgroups
     // has left it; the 16-wavefront form waits for a whole CU -- measured 62 against 53 us per config-2 step)
-    LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum && L.hrtf, true);
+    LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum && L.hrtf, true, c->evReduceDone[p]);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->evReduceDone[p], c->postStream));
     if(int rc = CommReduceBus(c, c->postStream)) return rc;      // beside the next update's voice kernel
     c->parity = p ^ 1u;
     return OALGPU_OK;

@@ -345,7 +345,8 @@ void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *re
 hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum);
 // besideVoiceKernel: the post-stream shape (4-wave workgroups of <= 32 VGPRs that fit on a CU next to
 // the wavefront voice kernel's two workgroups)
-void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry, bool besideVoiceKernel = false);
+void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry, bool besideVoiceKernel = false,
+    hipEvent_t evDone = nullptr);
 
 // ---- launchers (voice_wave.hip): the FAST HRTF hot path, one wavefront per voice ----
 void LaunchSetAmbiScale(hipStream_t s, const DeviceLayout &L, uint32_t voice, const AmbiScaleState &st);

@@ -15,6 +15,7 @@
 //   BusReduceKernel    sums the per-group partials in group order into the bus block.
 //
 // Deterministic by construction: fixed voice->group mapping, fixed summation order, no atomics.
+#include <hip/hip_ext.h>
 #include "kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -1030,14 +1031,15 @@ hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint
     return LaunchVoiceMixT<false, 32>(s, L, samplesToDo, carryAccum);
 }
 
-void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry, bool besideVoiceKernel)
+// evDone: an event bound to the dispatch's completion (null: none)
+void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry, bool besideVoiceKernel, hipEvent_t evDone)
 {
     const uint32_t total = uint32_t(BusFloats(L));
     (void)samplesToDo;
     if(besideVoiceKernel)
-        hipLaunchKernelGGL(BusReduceKernel<4>, dim3((total + 63u) / 64u), dim3(4 * 64), 0, s, L, addCarry ? 1u : 0u);
+        hipExtLaunchKernelGGL(BusReduceKernel<4>, dim3((total + 63u) / 64u), dim3(4 * 64), 0, s, nullptr, evDone, 0u, L, addCarry ? 1u : 0u);
     else
-        hipLaunchKernelGGL(BusReduceKernel<16>, dim3((total + 63u) / 64u), dim3(16 * 64), 0, s, L, addCarry ? 1u : 0u);
+        hipExtLaunchKernelGGL(BusReduceKernel<16>, dim3((total + 63u) / 64u), dim3(16 * 64), 0, s, nullptr, evDone, 0u, L, addCarry ? 1u : 0u);
 }
 
 } // namespace oalgpu
