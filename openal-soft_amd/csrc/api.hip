@@ -2003,7 +2003,12 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     if(L.streams) L.partLines = c->partLinesBuf[p];
     // main stream: this update's voices; its partial-bus buffer was last read by the reduction
     // of two updates ago
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->evReduceDone[p], 0));
+    // (almost always long done: then no barrier packet goes into the main queue in front of the voice kernel)
+    {
+        const hipError_t q = hipEventQuery(c->evReduceDone[p]);
+        if(q == hipErrorNotReady) HIP_TRY(hipStreamWaitEvent(c->stream, c->evReduceDone[p], 0));
+        else HIP_TRY(q);
+    }
     // (timing: the two events are bound to the dispatch itself -- the kernel's own start and end)
     // The event the post stream waits for is bound to the voice kernel's dispatch (hipExtLaunchKernel's stop event: one
     // runtime call less per update than a record behind the launch).  Timing runs use that slot for their own event.
