@@ -104,3 +104,72 @@ def test_pan_on_gpu_equals_host_computed_gains(mode, order, spread_on, hrtf, syn
             assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max(), (k, float(np.abs(a - b).max()))
         else:
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("mode,order,spread_on", [("fast", 2, False), ("fast", 3, True), ("exact", 2, True)])
+def test_pan_on_gpu_against_an_oracle_mixed_scene(mode, order, spread_on, synth_mhr):
+    """The direct comparison: the same voices mixed by the REFERENCE (Voice::mix of the compiled reference, or the pinned
+    restatement) with line gains the reference's own CalcDirectionCoeffs / ComputePanGains arithmetic produced, against the
+    GPU scene that was only told directions, spreads and gains (oalgpu_voice_set_pan).  Buses after every update, to the
+    multi-voice figure of every other scene test."""
+    import oalgpu
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    which = "ref" if ol.available("ref") else "port"
+    L = ol.load(which)
+    api = oalgpu.Api(oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
+    rng = np.random.default_rng(77 + order)
+    ndry = min(ACN_COUNT[order], 24)
+    nvoices, sends = 11, 2
+    gsc = api.make_scene(num_dry=ndry, num_real=0, num_sends=sends, num_slots=2, wet_channels=4, hrtf=False, max_voices=nvoices)
+    osc = ol.Scene(L, sample_rate=48000, num_dry=ndry, num_real=0, num_sends=sends, num_slots=2, wet_channels=4, hrtf=False)
+    dry_idx = rng.permutation(ACN_COUNT[order])[:ndry].astype(np.uint8)
+    dry_scale = rng.uniform(0.5, 1.5, ndry).astype(np.float32)
+    wet_idx = [np.arange(4, dtype=np.uint8), np.array([0, 3, 1, 2], np.uint8)]
+    wet_scale = [np.ones(4, np.float32), rng.uniform(0.5, 1.5, 4).astype(np.float32)]
+    gsc.set_ambi_map(dry_idx, dry_scale)
+    for s in range(2):
+        gsc.set_slot_ambi_map(s, wet_idx[s], wet_scale[s])
+    data = rng.uniform(-1, 1, 6000).astype(np.float32)
+    gbuf = gsc.add_buffer(data, ol.FMT_FLOAT, loop_start=0, loop_end=6000)
+    obuf = osc.add_buffer(data, ol.FMT_FLOAT, loop_start=0, loop_end=6000)
+    for v in range(nvoices):
+        gsc.add_voice(gbuf, looping=True, position=(v * 577) % 5000, frac=(v * 4001) % 65536)
+        osc.add_voice(obuf, True, position=(v * 577) % 5000, frac=(v * 4001) % 65536)
+    worst = 0.0
+    for k in range(4):
+        r = np.random.default_rng(500 * k + 3)
+        voices, pans = [], []
+        for v in range(nvoices):
+            d = r.standard_normal(3)
+            d = (d / np.linalg.norm(d)).astype(np.float32)
+            spread = np.float32(r.uniform(0.1, 6.0)) if (spread_on and v % 2 == 0) else np.float32(0.0)
+            dry_gain = np.float32(r.uniform(0.05, 0.6))
+            send_gain = r.uniform(0.05, 0.5, 6).astype(np.float32)
+            slots = [(v + i) % 3 - 1 for i in range(sends)]
+            coeffs = L.direction_coeffs(d, float(spread))
+            dry = (dry_scale * coeffs[dry_idx]) * dry_gain
+            snd_o, snd_g = [], []
+            for i in range(sends):
+                g = np.zeros(4, np.float32)
+                if slots[i] >= 0:
+                    g = (wet_scale[slots[i]] * coeffs[wet_idx[slots[i]]]) * send_gain[i]
+                filt = ol.default_filter(active=(v + i) % 2, gain_hf=0.6)
+                snd_o.append((slots[i], g, filt))
+                snd_g.append((slots[i], np.zeros(4, np.float32), filt))
+            df = ol.default_filter(active=v % 2, gain_hf=0.5)
+            osc.set_params(v, ol.make_voice_params(60211, ol.RS_BSINC24, dry_gains=dry, direct_filter=df, sends=snd_o))
+            gsc.set_params(v, ol.make_voice_params(60211, ol.RS_BSINC24, dry_gains=np.zeros(ndry), direct_filter=df, sends=snd_g))
+            voices.append(v)
+            pans.append(list(d) + [spread, dry_gain] + list(send_gain))
+        gsc.set_pan(voices, pans)
+        gsc.mix(1024, post_process=False)
+        osc.mix(1024, post_process=False)
+        for name, got, want in [("dry", gsc.dry()[:ndry], osc.dry_view()[:ndry])] + [(f"wet{s}", gsc.wet(s), osc.wet(s)) for s in range(2)]:
+            scale = float(np.abs(want).max())
+            err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+            assert scale > 1e-3, (k, name)
+            assert err <= 2e-5 * scale + 1e-7, (k, name, err, scale)
+            worst = max(worst, err / scale)
+    print(f"panning against the oracle-mixed scene ({mode}, order {order}, spread {spread_on}): worst {worst:.2e} of the bus maximum")
+    gsc.close()
+    osc.close()
