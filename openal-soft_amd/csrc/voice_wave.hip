@@ -291,6 +291,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     for(int r = 0; r < (MF ? 1 : R); ++r) acc[r] = f2{0.0f, 0.0f};
     float invH = 1.0f;                               // MF: 1 / scale of the parked (next) voice's response
     float invHO = 1.0f;                              // MF: and of its replaced (old) response, if it has one
+    bool fstClean = false;                           // the parked voice's direct filter pair is at rest (nothing to clear)
     float xoL = 0.0f, xoR = 0.0f;                    // MF: this voice's old-filter fade-out inputs, frame = lane
     f4 accM[2][5];                                   // MF: FirMfmaH's tiles, ear x (4 x 256 frames + ring-out)
 #pragma unroll
@@ -538,7 +539,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             {
                 if constexpr (SENDS) { if(lane < 32u) w.fst[lane] = fstv; }
                 WaveSync();
-                WaveDoFilters(w.fst, &L.dfilt[size_t{v} * 2], directFilter, w.in + kHist + outPos, N - outPos, lane);
+                if(directFilter || !fstClean)
+                    WaveDoFilters(w.fst, &L.dfilt[size_t{v} * 2], directFilter, w.in + kHist + outPos, N - outPos, lane);
                 WaveSync();
             }
             if constexpr (NL > 0)
@@ -927,6 +929,18 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             }
             if constexpr (SENDS) fstC = fstN;
             else if(lane < 32u) w.fst[lane] = fstN;
+            {   // Is the pair at rest -- states and counter zero, current == target coefficients (what WaveDoFilters checks
+                // before it clears an INACTIVE pair, voice.cpp:264-265)?  Decided here, on the words in flight, so that the
+                // three voices in four without an active filter do not pay an LDS round trip to find nothing to do.
+                const uint32_t li = lane & 15u;
+                const uint32_t bits = __builtin_bit_cast(uint32_t, fstN);
+                const float ahead = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, int(bits), 0x105, 0xF, 0xF, true));   // row_shl:5
+                bool ok = true;
+                if(li < 2u) ok = fstN == 0.0f;
+                else if(li < 7u) ok = fstN == ahead;
+                else if(li == 12u) ok = bits == 0u;
+                fstClean = __ballot(!ok && lane < 32u) == 0ull;
+            }
             WaveSync();
         }
 
