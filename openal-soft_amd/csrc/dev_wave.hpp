@@ -273,7 +273,8 @@ __device__ __forceinline__ void SplitHalf2(float v0, float v1, uint32_t &hi, uin
 {
     const auto h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
     hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v0 - float(h[0]), v1 - float(h[1])));
+    // (v - float(h) as fma(float(h), -1, v): the product is exact, and the compiler has v_fma_mix_f32 for the form)
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(float(h[0]), -1.0f, v0), __builtin_fmaf(float(h[1]), -1.0f, v1)));
 }
 // maximum over the wavefront of non-negative floats given as bit patterns, by DPP (no LDS round trips)
 __device__ __forceinline__ uint32_t WaveMaxBits(uint32_t v)

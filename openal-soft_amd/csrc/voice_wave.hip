@@ -639,35 +639,48 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             {   // per ear, as packed f16 pairs: lane l owns the frame pairs l + 64 j (frames 2 (l + 64 j), + 1), so
                 // that a pair is one dword.  First the products and their largest magnitude, then the power-of-
                 // two scale that puts that magnitude into [2^14, 2^15), the split and the stores.
-                float xl[kLine / 128][2], xr[kLine / 128][2];
+                // Two frames are one register pair all the way: gains, products and scaling are packed operations, the
+                // block maximum a v_max3 with |.| modifiers per two values (the scalar form was 5 VALU operations per
+                // value here and 4 more in the split; this is 1.5 and 2.5).
+                f2 xl[kLine / 128], xr[kLine / 128];
 #pragma unroll
                 for(int j = 0; j < kLine / 128; ++j)
-#pragma unroll
-                    for(int k = 0; k < 2; ++k)
-                    {   // 2 (lane + 64 j) + k <= 1023: inside w.in for any N
-                        const uint32_t i = 2u * (lane + 64u * uint32_t(j)) + uint32_t(k);
-                        xl[j][k] = inL[i]; xr[j][k] = inR[i];
-                    }
-                uint32_t mx = 0u;
+                {   // 2 (lane + 64 j) + 1 <= 1023: inside w.in for any N
+                    const uint32_t i = 2u * (lane + 64u * uint32_t(j));
+                    xl[j] = f2{inL[i], inL[i + 1u]}; xr[j] = f2{inR[i], inR[i + 1u]};
+                }
+                const float fi0 = float(2u * lane);
+                const f2 step2 = splat(mainStep), base2 = splat(gbase);
+                float mxf = 0.0f;
 #pragma unroll
                 for(int j = 0; j < kLine / 128; ++j)
+                {
+                    const uint32_t i = 2u * (lane + 64u * uint32_t(j));
+                    const f2 fi = f2{fi0 + float(128 * j), fi0 + float(128 * j + 1)};       // exact
+                    f2 g = pkfma(step2, fi, base2);
+                    if(j == 0)
+                    {   // only the first 64 frames can lie inside the fade
 #pragma unroll
-                    for(int k = 0; k < 2; ++k)
-                    {
-                        const uint32_t i = 2u * (lane + 64u * uint32_t(j)) + uint32_t(k);
-                        float g = __builtin_fmaf(mainStep, float(i), gbase);
-                        if(j == 0 && i < fademix)
-                        {   // only the first 64 frames can lie inside the fade
-                            g = newOn ? newStep * float(i) : 0.0f;
-                            if(merged && oldOn) g += oldStep * float(fademix - i);
-                        }
-                        const float a = (i < N) ? xl[j][k] * g : 0.0f, b = (i < N) ? xr[j][k] * g : 0.0f;
-                        xl[j][k] = a; xr[j][k] = b;
-                        const uint32_t ua = __builtin_bit_cast(uint32_t, a) & 0x7fffffffu, ub = __builtin_bit_cast(uint32_t, b) & 0x7fffffffu;
-                        mx = ua > mx ? ua : mx; mx = ub > mx ? ub : mx;
+                        for(int k = 0; k < 2; ++k)
+                            if(i + uint32_t(k) < fademix)
+                            {
+                                float gf = newOn ? newStep * float(i + uint32_t(k)) : 0.0f;
+                                if(merged && oldOn) gf += oldStep * float(fademix - (i + uint32_t(k)));
+                                g[k] = gf;
+                            }
                     }
+                    if(N < uint32_t(kLine))
+                    {   // (a short block: frames from N on are silence)
+                        if(i >= N) g.x = 0.0f;
+                        if(i + 1u >= N) g.y = 0.0f;
+                    }
+                    const f2 a = xl[j] * g, b = xr[j] * g;
+                    xl[j] = a; xr[j] = b;
+                    mxf = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), mxf);
+                    mxf = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(b.x), __builtin_fabsf(b.y)), mxf);
+                }
                 float sx;
-                HalfScale(WaveMaxBits(mx), sx, invX);
+                HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, mxf)), sx, invX);
                 if(lane < 32u)
                 {   // frames -64 .. -1
                     w.xh[0][0][lane] = 0u; w.xh[0][1][lane] = 0u; w.xh[1][0][lane] = 0u; w.xh[1][1][lane] = 0u;
@@ -677,14 +690,16 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     const uint32_t d = 32u + kLine / 2 + lane;
                     w.xh[0][0][d] = 0u; w.xh[0][1][d] = 0u; w.xh[1][0][d] = 0u; w.xh[1][1][d] = 0u;
                 }
+                const f2 sx2 = splat(sx);
 #pragma unroll
                 for(int j = 0; j < kLine / 128; ++j)
                 {
                     const uint32_t d = 32u + lane + 64u * uint32_t(j);
                     uint32_t hi, lo;
-                    SplitHalf2(xl[j][0] * sx, xl[j][1] * sx, hi, lo);
+                    const f2 a = xl[j] * sx2, b = xr[j] * sx2;
+                    SplitHalf2(a.x, a.y, hi, lo);
                     w.xh[0][0][d] = hi; w.xh[0][1][d] = lo;
-                    SplitHalf2(xr[j][0] * sx, xr[j][1] * sx, hi, lo);
+                    SplitHalf2(b.x, b.y, hi, lo);
                     w.xh[1][0][d] = hi; w.xh[1][1][d] = lo;
                 }
             }
