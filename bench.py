@@ -440,7 +440,12 @@ def main():
         n_tp = 400
         each = sorted(run(n_tp) for _ in range(3))
         dt, busy = each[1]
+        sc.pipelined_run(mv, 50, UPDATE_SAMPLES, post)
+        native = sorted(sc.pipelined_run(mv, n_tp, UPDATE_SAMPLES, post) for _ in range(3))[1]
         e2e_tput = {"e2e_voices_per_s": V * n_tp / dt, "ms_per_update": dt / n_tp * 1e3, "host_submit_share": busy / dt,
+                    "native_loop": {"e2e_voices_per_s": V * n_tp / native[0], "ms_per_update": native[0] / n_tp * 1e3,
+                                    "host_submit_share": native[1] / native[0],
+                                    "note": "the same loop written in C++ (oalgpu_debug_pipelined_run): no python / ctypes per call"},
                     "updates": n_tp, "moved_voices_per_update": len(moving),
                     "note": "median of 3 runs; per update: oalgpu_voice_move_async (host HRIR-blend indices + H2D on the copy stream + "
                             "ApplyMovesKernel) + oalgpu_mix_update + post-process + oalgpu_read_output_async, output collected "

@@ -490,6 +490,14 @@ int oalgpu_voice_move_async(oalgpu_context *ctx, const oalgpu_voice_move *moves,
 int oalgpu_read_output_async(oalgpu_context *ctx, uint32_t *ticket);
 int oalgpu_output_wait(oalgpu_context *ctx, uint32_t ticket, float *out, size_t out_floats);
 
+/* Measurement aid: `updates` pipelined updates driven from C++ exactly as section 3c of INTEGRATION.md writes them
+ * (oalgpu_voice_move_async of moves[u % move_sets] -- `count` records each --, oalgpu_mix_update, oalgpu_read_output_async,
+ * oalgpu_output_wait of the update two back into `out`), so that the boundary's throughput can be stated without a
+ * language binding's per-call cost.  wall_s: the loop's duration; busy_s: the calling thread's time outside
+ * oalgpu_output_wait. */
+int oalgpu_debug_pipelined_run(oalgpu_context *ctx, const oalgpu_voice_move *moves, size_t count, uint32_t move_sets,
+    uint32_t updates, uint32_t samples_to_do, int post_process, float *out, size_t out_floats, double *wall_s, double *busy_s);
+
 /* Timing of the last oalgpu_mix_update/mix_voices launch sequence, measured with HIP events on
  * the context's stream: total milliseconds, and the share of the voice kernel. */
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);

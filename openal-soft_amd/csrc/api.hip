@@ -1574,6 +1574,39 @@ int oalgpu_output_wait(oalgpu_context *c, uint32_t ticket, float *out, size_t ou
     return OALGPU_OK;
 }
 
+int oalgpu_debug_pipelined_run(oalgpu_context *c, const oalgpu_voice_move *moves, size_t count, uint32_t move_sets,
+    uint32_t updates, uint32_t samples_to_do, int post_process, float *out, size_t out_floats, double *wall_s, double *busy_s)
+{
+    if(!c || !moves || !out || count == 0 || move_sets == 0 || updates < 3) return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_pipelined_run: bad arguments");
+    if(int rc = oalgpu_sync(c)) return rc;
+    using clk = std::chrono::steady_clock;
+    std::vector<uint32_t> tickets(updates);
+    double waited = 0.0;
+    const auto t0 = clk::now();
+    for(uint32_t u = 0; u < updates; ++u)
+    {
+        if(int rc = oalgpu_voice_move_async(c, moves + size_t{u % move_sets} * count, count)) return rc;
+        if(int rc = oalgpu_mix_update(c, samples_to_do, post_process)) return rc;
+        if(int rc = oalgpu_read_output_async(c, &tickets[u])) return rc;
+        if(u >= 2)
+        {
+            const auto w0 = clk::now();
+            if(int rc = oalgpu_output_wait(c, tickets[u - 2], out, out_floats)) return rc;
+            waited += std::chrono::duration<double>(clk::now() - w0).count();
+        }
+    }
+    for(uint32_t u = updates - 2; u < updates; ++u)
+    {
+        const auto w0 = clk::now();
+        if(int rc = oalgpu_output_wait(c, tickets[u], out, out_floats)) return rc;
+        waited += std::chrono::duration<double>(clk::now() - w0).count();
+    }
+    const double wall = std::chrono::duration<double>(clk::now() - t0).count();
+    if(wall_s) *wall_s = wall;
+    if(busy_s) *busy_s = wall - waited;
+    return OALGPU_OK;
+}
+
 int oalgpu_set_stream(oalgpu_context *c, void *hip_stream)
 {
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");

@@ -485,6 +485,20 @@ class Scene:
         lib.oalgpu_voice_move_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         check(lib.oalgpu_voice_move_async(self.h, moves.ctypes.data_as(C.c_void_p), len(moves)), "oalgpu_voice_move_async")
 
+    def pipelined_run(self, move_sets, updates, samples=BUFFER_LINE, post_process=True):
+        """oalgpu_debug_pipelined_run: the section-3c loop in C++; move_sets: list of equally long MOVE_DTYPE arrays.
+        Returns (wall seconds, seconds of the calling thread outside oalgpu_output_wait)."""
+        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(m, MOVE_DTYPE) for m in move_sets]))
+        n = self.desc.num_real_channels or self.desc.num_dry_channels
+        out = np.empty((n, BUFFER_LINE), np.float32)
+        wall, busy = C.c_double(), C.c_double()
+        lib.oalgpu_debug_pipelined_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                                   f32p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        check(lib.oalgpu_debug_pipelined_run(self.h, flat.ctypes.data_as(C.c_void_p), len(move_sets[0]), len(move_sets), updates, samples,
+                                             1 if post_process else 0, _fp(out), out.size, C.byref(wall), C.byref(busy)),
+              "oalgpu_debug_pipelined_run")
+        return wall.value, busy.value
+
     def read_output_async(self):
         lib.oalgpu_read_output_async.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         t = C.c_uint32()
