@@ -406,7 +406,7 @@ def main():
 
     # ---- end-to-end THROUGHPUT through the pipelined boundary: per update the moving voices' 24-byte move records go
     # in from host memory (oalgpu_voice_move_async: the index half of getCoeffs on the host into a pinned ring slot,
-    # H2D on a copy stream beside the update that is mixing, the installing kernel in front of the next voice kernel),
+    # the installing kernel -- in front of the next voice kernel -- reads it over PCIe),
     # the update runs with its post-process, the stereo output comes back (oalgpu_read_output_async into a pinned ring
     # slot, collected two updates late).  Nothing waits for anything but the output of two updates ago.
     e2e_tput = None
@@ -447,8 +447,8 @@ def main():
                                     "host_submit_share": native[1] / native[0],
                                     "note": "the same loop written in C++ (oalgpu_debug_pipelined_run): no python / ctypes per call"},
                     "updates": n_tp, "moved_voices_per_update": len(moving),
-                    "note": "median of 3 runs; per update: oalgpu_voice_move_async (host HRIR-blend indices + H2D on the copy stream + "
-                            "ApplyMovesKernel) + oalgpu_mix_update + post-process + oalgpu_read_output_async, output collected "
+                    "note": "median of 3 runs; per update: oalgpu_voice_move_async (host HRIR-blend indices + "
+                            "ApplyMovesKernel reading the pinned slot) + oalgpu_mix_update + post-process + oalgpu_read_output_async, output collected "
                             "two updates late (oalgpu_output_wait); host_submit_share = the calling thread's time inside those "
                             "three calls / wall time (python + ctypes included)"}
 

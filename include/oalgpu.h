@@ -475,9 +475,9 @@ int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_stat
 /* ---- the pipelined host boundary: an update's moved voices in, its output lines out, nothing waits ---------------------
  * What CalcPanningAndFilters (alc/alu.cpp:1512-1657) hands over for a voice whose direction moved while its filter
  * targets stayed: the HRTF direction and gain.  oalgpu_voice_move_async evaluates the index half of
- * HrtfStore::getCoeffs (core/hrtf.cpp:192-245) on the host into a pinned ring slot, copies the records over on a copy
- * stream of its own (beside the update that is mixing) and queues the kernel that installs them in front of the
- * next oalgpu_mix_update; it returns without waiting for any of that.  HRTF contexts only. */
+ * HrtfStore::getCoeffs (core/hrtf.cpp:192-245) on the host into a pinned ring slot and queues the kernel that installs
+ * the records in front of the next oalgpu_mix_update -- it reads them straight out of the pinned slot, 64 bytes per moved
+ * voice over PCIe: one runtime call --; it returns without waiting for any of that.  HRTF contexts only. */
 typedef struct oalgpu_voice_move {
     uint32_t voice;
     float hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread;   /* as in oalgpu_voice_params */

@@ -340,7 +340,7 @@ void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
 // ---- launchers (voice_kernel.hip) ----
 void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);
 void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count);
-void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count);
+void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count, hipEvent_t evDone = nullptr);
 // returns hipSuccess or the launch error
 hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum);
 // besideVoiceKernel: the post-stream shape (4-wave workgroups of <= 32 VGPRs that fit on a CU next to

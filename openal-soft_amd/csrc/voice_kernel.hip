@@ -175,9 +175,10 @@ __global__ void __launch_bounds__(64) ApplyMovesKernel(DeviceLayout L, const Mov
     ApplyHrtfTargetWave(L, v, r.hrtfIdx, r.hrtfW, r.hrtfPass, lane);
 }
 
-void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count)
+// evDone: an event bound to the dispatch's completion (null: none); recs may be pinned host memory
+void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count, hipEvent_t evDone)
 {
-    if(count) hipLaunchKernelGGL(ApplyMovesKernel, dim3(count), dim3(64), 0, s, L, recs);
+    if(count) hipExtLaunchKernelGGL(ApplyMovesKernel, dim3(count), dim3(64), 0, s, nullptr, evDone, 0u, L, recs);
 }
 
 // ---------------------------------------------------------------------------------------------
