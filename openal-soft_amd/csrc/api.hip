@@ -2061,14 +2061,17 @@ int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, in
     if(post_process && c->L.hrtf && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
     if(int rc = UseDevice(c->desc.device)) return rc;
     const DeviceLayout &L = c->L;
+    bool postDoneBound = false;
     if(post_process) { if(int rc = RunEffects(c, c->postStream, samples_to_do)) return rc; }
     if(post_process && L.hrtf)
     {
         float *left = L.bus + size_t{L.numDry} * kLine;
         float *right = left + kLine;
+        // (the update's last launch on this stream, unless timing asks for an event of its own behind it: evPostDone rides on it)
         LaunchPostDirectHrtfFast(c->postStream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
-            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
+            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->timing ? nullptr : c->evPostDone);
         HIP_TRY(hipGetLastError());
+        postDoneBound = !c->timing;
     }
     if(post_process && !L.hrtf && c->decOn)
     {   // DeviceBase::Process(AmbiDecPostProcess), alc/alu.cpp:282-287: dry lines -> speaker feeds
@@ -2077,7 +2080,7 @@ int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, in
         HIP_TRY(hipGetLastError());
     }
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->postStream)); c->timed = true; }
-    HIP_TRY(hipEventRecord(c->evPostDone, c->postStream));
+    if(!postDoneBound) HIP_TRY(hipEventRecord(c->evPostDone, c->postStream));
     c->postPending = true;
     return OALGPU_OK;
 }

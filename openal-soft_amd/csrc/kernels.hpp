@@ -238,7 +238,8 @@ void LaunchGetCoeffs(hipStream_t s, const HrtfStoreDev &st, const float *dirs, u
 
 // ---- launcher (post_wave.hip): FAST MixDirectHrtf, one wavefront per dry channel ----
 void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, float *accum,
-    SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n, float *temp);
+    SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n, float *temp,
+    hipEvent_t evDone = nullptr);
 
 // ---- launchers (output_kernels.hip): BFormatDec, ApplyDither, Write<T> behind the buses ----
 // gainsHf / gainsLf: [dry line][32] (column = output line); gainsLf null = single-band decoder; bands =

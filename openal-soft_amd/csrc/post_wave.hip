@@ -15,6 +15,7 @@
 //   PostShiftKernel   carried HrtfAccumData + the channels' sum -> RealOut L/R, and the accumulator's shift
 //                     (hrtfbase.h:119-132).
 // EXACT mode keeps the term-by-term kernel in percall_kernels.hip.
+#include <hip/hip_ext.h>
 #include "dev_wave.hpp"
 
 #pragma clang fp contract(off)
@@ -127,15 +128,16 @@ __global__ void __launch_bounds__(256) PostShiftKernel(float *__restrict__ left,
 } // namespace
 
 // temp: nch x 1024 filtered channels, then 1152 x 2 channel sums
+// evDone: an event bound to the completion of the last of the three dispatches (null: none)
 void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, float *accum,
-    SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n, float *temp)
+    SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n, float *temp, hipEvent_t evDone)
 {
     float *xf = temp, *tmp = temp + size_t{nch} * kLine;
     const uint32_t taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
     hipLaunchKernelGGL(PostSplitKernel, dim3(nch), dim3(64), 0, s, in, xf, splitters, hfscales, n);
     // (16 frames per workgroup: 47.5 us per step against 49.0 with 8 and 50.5 with round 2's single workgroup, one box)
     hipLaunchKernelGGL(PostFirKernel<16>, dim3(kPostFrames / 16), dim3(64), 0, s, xf, nch, chanCoeffs, taps, tmp);
-    hipLaunchKernelGGL(PostShiftKernel, dim3(1), dim3(256), 0, s, left, right, accum, tmp, n);
+    hipExtLaunchKernelGGL(PostShiftKernel, dim3(1), dim3(256), 0, s, nullptr, evDone, 0u, left, right, accum, tmp, n);
 }
 
 } // namespace oalgpu
