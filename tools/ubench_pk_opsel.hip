@@ -31,6 +31,22 @@ TEST(t_sel0_warC,  "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel:[
 TEST(t_selhi_warC, "v_pk_fma_f32 v[16:17], v[10:11], v[12:13], v[14:15] op_sel_hi:[1,0,1]\n\tv_mov_b32 v14, 0\n\tv_mov_b32 v15, 0")
 TEST(t_mulsel_warA,"v_pk_mul_f32 v[16:17], v[10:11], v[12:13] op_sel:[0,1]\n\tv_pk_mul_f32 v[10:11], v[14:15], v[14:15]")
 
+// 16-bit packed forms, same selection (low lane = src0.lo op src1.hi): operands and result as raw dwords
+__device__ __forceinline__ uint32_t t_pk_add_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm volatile("v_mov_b32 v10, %1\n\tv_mov_b32 v12, %2\n\ts_nop 4\n\tv_pk_add_u16 v16, v10, v12 op_sel:[0,1]\n\ts_nop 4\n\tv_mov_b32 %0, v16\n\ts_nop 1"
+        : "=v"(r) : "v"(a), "v"(b) : "v10", "v12", "v16");
+    return r;
+}
+__device__ __forceinline__ uint32_t t_pk_mul_f16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm volatile("v_mov_b32 v10, %1\n\tv_mov_b32 v12, %2\n\ts_nop 4\n\tv_pk_mul_f16 v16, v10, v12 op_sel:[0,1]\n\ts_nop 4\n\tv_mov_b32 %0, v16\n\ts_nop 1"
+        : "=v"(r) : "v"(a), "v"(b) : "v10", "v12", "v16");
+    return r;
+}
+
 __global__ void __launch_bounds__(256) k(uint32_t *bad, uint32_t reps, uint32_t mode)
 {
     __shared__ float ballast[18000];            // 72 KB: two workgroups per CU
@@ -48,7 +64,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *bad, uint32_t reps, uint32_t 
         return;
     }
     const float l = float(threadIdx.x);
-    uint32_t cnt[12] = {}, ignoredSel = 0, hiWrong = 0;
+    uint32_t cnt[12] = {}, ignoredSel = 0, hiWrong = 0, c16[2] = {};
     for(uint32_t r = 0; r < reps; ++r)
     {
         const float a0 = 1.0f + l + float(r), a1 = 2.0f + l, b0 = 3.0f + l * 0.5f, b1 = 5.0f + float(r & 7u), c0 = 7.0f + l, c1 = 11.0f - l;
@@ -81,8 +97,20 @@ __global__ void __launch_bounds__(256) k(uint32_t *bad, uint32_t reps, uint32_t 
         CHECK(9, t_sel0_warC,   __builtin_fmaf(a1, b0, c0), __builtin_fmaf(a1, b1, c1))
         CHECK(10, t_selhi_warC, __builtin_fmaf(a0, b0, c0), __builtin_fmaf(a1, b0, c1))
         CHECK(11, t_mulsel_warA, a0 * b1, a1 * b1)
+        {   // u16: (a.lo + b.hi) | (a.hi + b.hi) << 16
+            const uint32_t ua = (threadIdx.x * 7u + r) & 0xffffu | ((threadIdx.x * 3u + 11u) & 0xffffu) << 16, ub = (r * 5u + 1u) & 0xffffu | ((threadIdx.x + 1000u + r) & 0xffffu) << 16;
+            const uint32_t want = ((ua + (ub >> 16)) & 0xffffu) | (((ua >> 16) + (ub >> 16)) & 0xffffu) << 16;
+            if(t_pk_add_u16(ua, ub) != want) ++c16[0];
+            // f16: small integers, exact products
+            const _Float16 x0 = _Float16(float(threadIdx.x & 15u) + 1.0f), x1 = _Float16(3.0f), y0 = _Float16(5.0f), y1 = _Float16(float(r & 7u) + 2.0f);
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 A = {x0, x1}, B = {y0, y1}, Wn = {x0 * y1, x1 * y1};
+            if(t_pk_mul_f16(__builtin_bit_cast(uint32_t, A), __builtin_bit_cast(uint32_t, B)) != __builtin_bit_cast(uint32_t, Wn)) ++c16[1];
+        }
     }
     for(int i = 0; i < 12; ++i) if(cnt[i]) atomicAdd(&bad[i], cnt[i]);
+    if(c16[0]) atomicAdd(&bad[25], c16[0]);
+    if(c16[1]) atomicAdd(&bad[26], c16[1]);
     if(ignoredSel) atomicAdd(&bad[20], ignoredSel);
     if(hiWrong) atomicAdd(&bad[21], hiWrong);
 }
@@ -102,6 +130,7 @@ int main(int argc, char **argv)
         if(mode) for(int e = 0; e < 3; ++e) { const float *x = reinterpret_cast<const float*>(h + 32) + 8 * e;
             printf("    A = (%g, %g) B = (%g, %g) C = (%g, %g): low lane %.9g, want A.lo * B.hi + C.lo = %.9g [A.lo*B.lo+C.lo = %.9g, A.hi*B.hi+C.lo = %.9g, A.lo*B.hi+C.hi = %.9g]\n", x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7],
                 fmaf(x[0], x[2], x[4]), fmaf(x[1], x[3], x[4]), fmaf(x[0], x[3], x[5])); }
+        printf("  %-60s wrong results: %u\n  %-60s wrong results: %u\n", "v_pk_add_u16 op_sel:[0,1]", h[25], "v_pk_mul_f16 op_sel:[0,1]", h[26]);
         for(int i = 0; i < 12; ++i) printf("  %-60s wrong results: %u\n", names[i], h[i]);
     }
     return 0;
