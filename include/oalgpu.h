@@ -218,6 +218,12 @@ int oalgpu_set_direct_hrtf_from_store(oalgpu_context *ctx, const float *points, 
  * set's own rate) -- info, and coeffs (num_irs x 128 x 2) / delays (num_irs x 2) when not NULL -- and the decoder
  * build on it.  oalgpu_hrtf_load_mhr does the same resampling when the context's rate differs from the set's. */
 int oalgpu_hrtf_parse_host(const void *mhr, size_t size, uint32_t device_rate, oalgpu_hrtf_info *info, float *coeffs, uint8_t *delays);
+/* Host-only: the index half of HrtfStore::getCoeffs (core/hrtf.cpp:192-245) as oalgpu_voice_set_params and
+ * oalgpu_voice_move_async evaluate it when they build a record -- for `count` directions (elevation, azimuth, distance,
+ * spread each) the four HRIR indices, their weights, the pass-through tap and the two blended delays
+ * (idx / w: count x 4, pass: count, delays: count x 2). */
+int oalgpu_hrtf_blend_host(const void *mhr, size_t size, uint32_t device_rate, const float *dirs, size_t count,
+    uint32_t *idx, float *w, float *pass, uint32_t *delays);
 int oalgpu_hrtf_build_direct_host(const void *mhr, size_t size, uint32_t device_rate, uint32_t ir_size, int per_hrir_min,
     const float *points, const float *matrix, uint32_t num_points, uint32_t num_chans, float xover_freq, const float *order_hf_gain,
     float *out_coeffs, float *out_hfscales, float *out_xover_norm, uint32_t *out_irsize);

@@ -1132,6 +1132,37 @@ int oalgpu_hrtf_parse_host(const void *mhr, size_t size, uint32_t device_rate, o
     return OALGPU_OK;
 }
 
+// the host's view of the loaded store, for HrtfBlendFor
+static HrtfStoreDev HostStoreView(const HrtfData &h)
+{
+    HrtfStoreDev st{};
+    st.irSize = h.irSize; st.numFields = uint32_t(h.fieldDistance.size());
+    st.numElevs = uint32_t(h.elevAzCount.size()); st.numIrs = h.numIrs();
+    st.fieldDistance = h.fieldDistance.data(); st.fieldEvCount = h.fieldEvCount.data();
+    st.elevAzCount = h.elevAzCount.data(); st.elevIrOffset = h.elevIrOffset.data();
+    st.coeffs = h.coeffs.data(); st.delays = h.delays.data();
+    return st;
+}
+
+int oalgpu_hrtf_blend_host(const void *mhr, size_t size, uint32_t device_rate, const float *dirs, size_t count,
+    uint32_t *idx, float *w, float *pass, uint32_t *delays)
+{
+    if(!mhr || !dirs || !idx || !w || !pass || !delays) return Fail(OALGPU_ERR_INVALID, "null argument");
+    HrtfData h;
+    const std::string err = ParseMhr(mhr, size, h);
+    if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
+    if(device_rate) ResampleHrtfData(h, device_rate);
+    const HrtfStoreDev store = HostStoreView(h);
+    for(size_t i = 0; i < count; ++i)
+    {
+        const HrirBlend b = HrtfBlendFor(store, dirs[4 * i], dirs[4 * i + 1], dirs[4 * i + 2], dirs[4 * i + 3]);
+        for(int k = 0; k < 4; ++k) { idx[4 * i + k] = b.idx[k]; w[4 * i + k] = b.w[k]; }
+        pass[i] = b.passthru;
+        delays[2 * i] = b.delay[0]; delays[2 * i + 1] = b.delay[1];
+    }
+    return OALGPU_OK;
+}
+
 int oalgpu_hrtf_build_direct_host(const void *mhr, size_t size, uint32_t device_rate, uint32_t ir_size, int per_hrir_min,
     const float *points, const float *matrix, uint32_t num_points, uint32_t num_chans, float xover_freq, const float *order_hf_gain,
     float *out_coeffs, float *out_hfscales, float *out_xover_norm, uint32_t *out_irsize)
@@ -1352,18 +1383,6 @@ int oalgpu_buffer_channel_view(oalgpu_context *c, int buffer, uint32_t channel)
     c->bufferData[c->numBuffers] = nullptr;               // the storage belongs to `buffer`
     c->bufferLoopLen[c->numBuffers] = c->bufferLoopLen[size_t(buffer)];
     return int(c->numBuffers++);
-}
-
-// the host's view of the loaded store, for HrtfBlendFor
-static HrtfStoreDev HostStoreView(const HrtfData &h)
-{
-    HrtfStoreDev st{};
-    st.irSize = h.irSize; st.numFields = uint32_t(h.fieldDistance.size());
-    st.numElevs = uint32_t(h.elevAzCount.size()); st.numIrs = h.numIrs();
-    st.fieldDistance = h.fieldDistance.data(); st.fieldEvCount = h.fieldEvCount.data();
-    st.elevAzCount = h.elevAzCount.data(); st.elevIrOffset = h.elevIrOffset.data();
-    st.coeffs = h.coeffs.data(); st.delays = h.delays.data();
-    return st;
 }
 
 static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params,
