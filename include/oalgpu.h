@@ -715,6 +715,11 @@ int  oalgpu_reverb_set_upmix(oalgpu_reverb *rev, const float order_scales[2], co
 /* The stream update() and process() enqueue on (NULL = the default stream).  A reverb attached
  * to a context slot uses the context's effect stream. */
 int  oalgpu_reverb_set_stream(oalgpu_reverb *rev, void *hip_stream);
+/* OALGPU_MATH_EXACT (default of a free-standing instance): bit-identical to ReverbState::process.  OALGPU_MATH_FAST: the
+ * master band-pass and the T60 damping filters (the two serial recurrences that are most of a block's time) run as
+ * block scans -- the reference's output to rounding level.  An instance attached to a slot of a FAST context
+ * (oalgpu_slot_set_reverb) is switched to FAST, one attached to an EXACT context to EXACT. */
+int  oalgpu_reverb_set_math_mode(oalgpu_reverb *rev, int math_mode);
 /* ReverbState::update, :1222-1351, for an identity first-order target map
  * (ComputePanGains with AmbiMap[i] = {1, i}, core/mixer.cpp:93-103). */
 int  oalgpu_reverb_update(oalgpu_reverb *rev, const oalgpu_reverb_props *props, float slot_gain);

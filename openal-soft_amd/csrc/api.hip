@@ -2353,6 +2353,7 @@ int oalgpu_slot_set_reverb(oalgpu_context *c, uint32_t slot, oalgpu_reverb *rev)
     if(rev && ReverbOutLines(rev) > c->L.numDry)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_reverb: the effect mixes into more lines than the context has dry lines");
     if(int rc = oalgpu_sync(c)) return rc;
+    if(rev) { if(int rc = oalgpu_reverb_set_math_mode(rev, c->exact ? OALGPU_MATH_EXACT : OALGPU_MATH_FAST)) return rc; }
     c->slotReverb[slot] = rev;
     return OALGPU_OK;
 }

@@ -291,6 +291,74 @@ __device__ __forceinline__ uint32_t WaveMaxBits(uint32_t v)
     return ab > cd ? ab : cd;
 }
 
+// ---- linear recurrences over the lanes of a wavefront (the biquad block scans of the voice kernels and of the EAX reverb) ----
+constexpr int kBqSeg = 17;                    // ceil(1024 / 64) | 1
+struct S2 { float a, b; };
+
+__device__ __forceinline__ float BqStep(S2 &s, float x, float b0, float b1, float b2, float a1, float a2)
+{
+    const float y = __builtin_fmaf(x, b0, s.a);
+    s.a = __builtin_fmaf(x, b1, __builtin_fmaf(-y, a1, s.b));
+    s.b = __builtin_fmaf(x, b2, -y * a2);
+    return y;
+}
+__device__ __forceinline__ S2 Mv2(S2 c0, S2 c1, S2 v)          // [c0 c1] * v
+{ return S2{__builtin_fmaf(c1.a, v.b, c0.a * v.a), __builtin_fmaf(c1.b, v.b, c0.b * v.a)}; }
+
+// E_l = sum_{k <= l} M^(l - k) e_k over the 64 lanes of a wavefront, M = [m0 m1] (columns): a Kogge-Stone scan with M,
+// M^2, M^4, M^8 inside the rows of 16 lanes by DPP row shifts (no LDS round trips: ds_bpermute costs ~150 cycles a piece
+// and the scan's twelve were a third of the filter's time), then three row carries: row r takes M^((lane & 15) + 1)
+// times the finished total of row r - 1 (lane 16 r - 1, read with v_readlane).
+__device__ __forceinline__ float DppRowShr(float v, int d)
+{
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch(d)
+    {
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); break;
+    case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); break;
+    }
+    return __builtin_bit_cast(float, r);
+}
+// the in-row part alone: E_l = sum over the lanes k <= l OF THE SAME ROW of 16 -- four independent scans per wavefront
+// (the EAX reverb runs one of its four lines per row); q0/q1 return M^((lane & 15) + 1) for a caller that chains rows
+__device__ __forceinline__ S2 ScanLinear2Row(S2 e, S2 m0, S2 m1, uint32_t lane, S2 &q0, S2 &q1)
+{
+    S2 p0 = m0, p1 = m1;                               // M^(2^step)
+    q0 = S2{1.0f, 0.0f}; q1 = S2{0.0f, 1.0f};          // -> M^((lane & 15) + 1)
+    const uint32_t exp = (lane & 15u) + 1u;
+#pragma unroll
+    for(int step = 0; step < 4; ++step)
+    {
+        const int d = 1 << step;
+        const S2 o{DppRowShr(e.a, d), DppRowShr(e.b, d)};     // lanes whose source lies in another row receive 0
+        const S2 mo = Mv2(p0, p1, o);
+        e.a += mo.a; e.b += mo.b;
+        const S2 r0 = Mv2(p0, p1, q0), r1 = Mv2(p0, p1, q1);
+        if(exp & uint32_t(d)) { q0 = r0; q1 = r1; }
+        const S2 n0 = Mv2(p0, p1, p0), n1 = Mv2(p0, p1, p1); p0 = n0; p1 = n1;
+    }
+    if(exp == 16u) { q0 = p0; q1 = p1; }               // M^16
+    return e;
+}
+__device__ __forceinline__ S2 ScanLinear2(S2 e, S2 m0, S2 m1, uint32_t lane)
+{
+    S2 q0, q1;
+    e = ScanLinear2Row(e, m0, m1, lane, q0, q1);
+#pragma unroll
+    for(int r = 1; r < 4; ++r)
+    {
+        const S2 c{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.a), 16 * r - 1)),
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.b), 16 * r - 1))};
+        const S2 mc = Mv2(q0, q1, c);
+        if((lane >> 4) == uint32_t(r)) { e.a += mc.a; e.b += mc.b; }
+    }
+    return e;
+}
+
+
 template<int TILES = 5, bool LOW8 = false>
 __device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2][2][kXhDw], const uint32_t (&hr)[2][2][kHrDw],
     float inv, uint32_t lane)

@@ -259,6 +259,13 @@ int oalgpu_reverb_process_device(oalgpu_reverb *r, const float *wet_in_dev, floa
 
 /* measurement aid: cycle-counter stamps of the launches from here on, [4 roles][8 sub-blocks][8]
  * (tools/reverb_phase_times.py; a device instance only) */
+int oalgpu_reverb_set_math_mode(oalgpu_reverb *r, int math_mode)
+{
+    if(!r || (math_mode != OALGPU_MATH_EXACT && math_mode != OALGPU_MATH_FAST)) return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_set_math_mode: bad arguments");
+    r->L.fast = math_mode == OALGPU_MATH_FAST ? 1u : 0u;
+    return OALGPU_OK;
+}
+
 int oalgpu_reverb_debug_enable_phase_times(oalgpu_reverb *r)
 {
     if(!r || r->device < 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_debug_enable_phase_times: needs a device instance");

@@ -45,6 +45,7 @@ struct RvLayout {
     uint32_t upmix;                // mUpmixOutput: MixOutAmbiUp instead of MixOutPlain
     float orderScale[2];           // mOrderScales[0], [1]
     float splitCoeff;              // BandSplitter{device->mXOverFreq / frequency}.mCoeff
+    uint32_t fast;                 // OALGPU_MATH_FAST: the dual-biquad sections as block scans (rounding-level differences)
     unsigned long long *stamps;    // measurement aid (oalgpu_reverb_debug_enable_phase_times), null in production: [4 roles][8 sub-blocks][8]
 };
 

@@ -113,6 +113,77 @@ __device__ __forceinline__ void DualBiquadSerial(float *row, uint32_t todo, cons
     z[0] = Z1.x; z[1] = Z2.x; z[2] = Z1.y; z[3] = Z2.y;
 }
 
+// FAST mode: the same two sections over the four lines of the scratch as block scans -- one DPP row of 16 lanes per
+// line, a run of 17 samples per lane (an odd pitch: the lanes of a row hit different LDS banks), the run-start states
+// by a Kogge-Stone scan inside the row (ScanLinear2Row, dev_wave.hpp); the forced response as sum x[i] A^(16-i) Bv out
+// of the loop that raises A to M = A^17, like the voice kernels' BiquadWaveScan.  The serial form is a chain of ~4
+// dependent operations per sample on 4 of the wavefront's 64 lanes (10 K cycles per 256-sample sub-block and section
+// pair); this is ~100 dependent operations per section.  Differs from the reference's loop by rounding only.
+__device__ __forceinline__ void BiquadRowScan(float (&x)[kBqSeg], uint32_t cnt, const oalgpu_bq_coeffs &f, float &z1, float &z2,
+    uint32_t lane, bool last)
+{
+    const float b0 = f.b0, b1 = f.b1, b2 = f.b2, a1 = f.a1, a2 = f.a2;
+    S2 m0{1.0f, 0.0f}, m1{0.0f, 1.0f};
+    S2 c{__builtin_fmaf(-a1, b0, b1), __builtin_fmaf(-a2, b0, b2)};
+    S2 ea{0.0f, 0.0f}, eb{0.0f, 0.0f};
+#pragma unroll
+    for(int j = 0; j < kBqSeg; ++j)
+    {
+        const float xv = x[kBqSeg - 1 - j];
+        if(j & 1) { eb.a = __builtin_fmaf(xv, c.a, eb.a); eb.b = __builtin_fmaf(xv, c.b, eb.b); }
+        else { ea.a = __builtin_fmaf(xv, c.a, ea.a); ea.b = __builtin_fmaf(xv, c.b, ea.b); }
+        c = S2{__builtin_fmaf(-a1, c.a, c.b), -a2 * c.a};
+        m0 = S2{__builtin_fmaf(-a1, m0.a, m0.b), -a2 * m0.a};
+        m1 = S2{__builtin_fmaf(-a1, m1.a, m1.b), -a2 * m1.a};
+    }
+    S2 e{ea.a + eb.a, ea.b + eb.b};
+    {   // the row's first lane starts from the line's filter state
+        const S2 mz = Mv2(m0, m1, S2{z1, z2});
+        if((lane & 15u) == 0u) { e.a += mz.a; e.b += mz.b; }
+    }
+    S2 q0, q1;
+    e = ScanLinear2Row(e, m0, m1, lane, q0, q1);
+    // the run's start state: the end state of the lane before in the row (row_shr:1; a row's first lane keeps the line's state)
+    S2 st;
+    st.a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, z1), __builtin_bit_cast(int, e.a), 0x111, 0xF, 0xF, false));
+    st.b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, z2), __builtin_bit_cast(int, e.b), 0x111, 0xF, 0xF, false));
+    S2 zc = st;
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i)
+    {
+        const float xv = x[i];
+        const float t1 = __builtin_fmaf(xv, b1, st.b);
+        const float y = __builtin_fmaf(xv, b0, st.a);
+        st.a = __builtin_fmaf(-y, a1, t1);
+        st.b = __builtin_fmaf(xv, b2, -y * a2);
+        x[i] = y;
+        if(uint32_t(i) + 1u == cnt) zc = st;
+    }
+    if(last) { z1 = zc.a; z2 = zc.b; }       // (only the lane that holds the line's last sample keeps the new state)
+}
+
+// temp: the 4-line scratch (pitch kRow); c0 / c1: THIS LANE's line's coefficients (line = lane >> 4); z: that line's four
+// state words {section 0: z1, z2; section 1: z1, z2}
+__device__ __forceinline__ void DualBiquadRowsFast(float *temp, uint32_t todo, const oalgpu_bq_coeffs &c0, const oalgpu_bq_coeffs &c1,
+    float *z, uint32_t lane)
+{
+    const uint32_t l = lane & 15u;
+    float *row = temp + (lane >> 4) * kRow;
+    const uint32_t begin = l * uint32_t(kBqSeg) < todo ? l * uint32_t(kBqSeg) : todo;
+    const uint32_t cnt = (begin + uint32_t(kBqSeg) < todo) ? uint32_t(kBqSeg) : todo - begin;
+    const bool last = todo != 0u && l == (todo - 1u) / uint32_t(kBqSeg);
+    float x[kBqSeg];
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) x[i] = (uint32_t(i) < cnt) ? row[begin + i] : 0.0f;
+    float s0 = z[0], s1 = z[1], s2 = z[2], s3 = z[3];
+    BiquadRowScan(x, cnt, c0, s0, s1, lane, last);
+    BiquadRowScan(x, cnt, c1, s2, s3, lane, last);
+    WaveSync();                                  // every lane of the row has read the old state
+    if(last) { z[0] = s0; z[1] = s1; z[2] = s2; z[3] = s3; }
+#pragma unroll
+    for(int i = 0; i < kBqSeg; ++i) if(uint32_t(i) < cnt) row[begin + i] = x[i];
+}
+
 // ---- early reflections: ReverbPipeline::processEarly, :1558-1660 -------------------------------
 __device__ void EarlyWave(const RvLayout &L, const int p, EarlyLds &w, uint32_t *progress, const uint32_t lane)
 {
@@ -169,7 +240,8 @@ __device__ void EarlyWave(const RvLayout &L, const int p, EarlyLds &w, uint32_t 
         }
         WaveSync();
         RV_STAMP(role, sub, 1);
-        if(lane < 4)                                            // mFilter[j].process, :1611
+        if(L.fast) DualBiquadRowsFast(w.temp, todo, P.filter_lp, P.filter_hp, &S.z[lane >> 4][0], lane);
+        else if(lane < 4)                                       // mFilter[j].process, :1611
             DualBiquadSerial(&w.temp[lane * kRow], todo, P.filter_lp, P.filter_hp, &S.z[lane][0]);
         WaveSync();
         RV_STAMP(role, sub, 2);
@@ -321,7 +393,8 @@ __device__ void LateWave(const RvLayout &L, const int p, LateLds &w, uint32_t *p
         }
         WaveSync();
         RV_STAMP(role, sub, 1);
-        if(lane < 4)                                            // mLate.T60[j].process, :1749
+        if(L.fast) DualBiquadRowsFast(w.temp, todo, P.t60_hf[lane >> 4], P.t60_lf[lane >> 4], &S.z[lane >> 4][4], lane);
+        else if(lane < 4)                                       // mLate.T60[j].process, :1749
             DualBiquadSerial(&w.temp[lane * kRow], todo, P.t60_hf[lane], P.t60_lf[lane], &S.z[lane][4]);
         WaveSync();
         RV_STAMP(role, sub, 2);
@@ -544,13 +617,22 @@ __device__ __forceinline__ void ReverbProcessBody(const RvLayout &L, RvLds &sm, 
         }
         __syncthreads();
     }
-    if(ticket)
+    // FAST mode, several instances in the launch: an instance's eight (sixteen) inputs are summed per target line
+    // BEFORE it takes its turn at the lines, and the turn is one add per output sample -- the instances' mix-outs, a
+    // tenth of the kernel each, no longer queue behind each other.  (EXACT keeps the reference's term-by-term sum into
+    // the line, which needs the line as the previous instance left it.)
+    constexpr uint32_t kPreLines = 8;
+    const bool preMix = ticket && L.fast && L.nlines <= kPreLines;
+    float pre[kPreLines][4];
+    auto takeTurn = [&]()
     {
+        if(!ticket) return;
         if(t == 0)
             while(__hip_atomic_load(ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != order) __builtin_amdgcn_s_sleep(8);
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every wave drops what it may hold of the lines
-    }
+    };
+    if(!preMix) takeTurn();
 
     // MixOutPlain, :637-656: current pipeline first, then the old one (:1845,1878).  MixLine with
     // Counter == n (core/mixer/mixer_c.cpp:150-186): per (input, target line) the gain either
@@ -598,7 +680,7 @@ __device__ __forceinline__ void ReverbProcessBody(const RvLayout &L, RvLds &sm, 
         {
             float acc[4];
 #pragma unroll
-            for(uint32_t k = 0; k < 4; ++k) acc[k] = L.outLines[c * kLine + ((t + 256u * k) < n ? t + 256u * k : 0u)];
+            for(uint32_t k = 0; k < 4; ++k) acc[k] = preMix ? 0.0f : L.outLines[c * kLine + ((t + 256u * k) < n ? t + 256u * k : 0u)];
 #pragma unroll
             for(uint32_t q = 0; q < 2; ++q)
             {
@@ -619,9 +701,28 @@ __device__ __forceinline__ void ReverbProcessBody(const RvLayout &L, RvLds &sm, 
                     }
                 }
             }
+            if(preMix)
+            {
+#pragma unroll
+                for(uint32_t cc = 0; cc < kPreLines; ++cc)
+                    if(cc == c) { pre[cc][0] = acc[0]; pre[cc][1] = acc[1]; pre[cc][2] = acc[2]; pre[cc][3] = acc[3]; }
+                continue;
+            }
 #pragma unroll
             for(uint32_t k = 0; k < 4; ++k)
                 if(t + 256u * k < n) L.outLines[c * kLine + t + 256u * k] = acc[k];
+        }
+        if(preMix)
+        {
+            takeTurn();
+#pragma unroll
+            for(uint32_t cc = 0; cc < kPreLines; ++cc)
+            {
+                if(cc >= L.nlines) break;
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k)
+                    if(t + 256u * k < n) L.outLines[cc * kLine + t + 256u * k] += pre[cc][k];
+            }
         }
     }
     if(ticket) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this wave's line stores are out

@@ -878,6 +878,11 @@ class Reverb:
         check(lib.oalgpu_reverb_create(device, sample_rate, num_out_lines, C.byref(h)), "oalgpu_reverb_create")
         self.h = h
 
+    def set_math_mode(self, mode):
+        """MATH_EXACT (default): bit-identical to ReverbState::process; MATH_FAST: the filter sections as block scans"""
+        lib.oalgpu_reverb_set_math_mode.argtypes = [C.c_void_p, C.c_int]
+        check(lib.oalgpu_reverb_set_math_mode(self.h, mode), "oalgpu_reverb_set_math_mode")
+
     def set_upmix(self, order_scales, first_order_up, xover_norm):
         """a device above first order: MixOutAmbiUp (see oalgpu_reverb_set_upmix); None = MixOutPlain"""
         lib.oalgpu_reverb_set_upmix.argtypes = [C.c_void_p, f32p, f32p, C.c_float]

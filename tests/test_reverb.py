@@ -281,6 +281,77 @@ def test_gpu_matches_oracle(name, schedule):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,schedule", CASES, ids=IDS)
+def test_gpu_fast_mode_matches_oracle(name, schedule):
+    """OALGPU_MATH_FAST: the master band-pass and the T60 filters as block scans.  Same schedules as above (ragged
+    updates, parameter changes, cross-fades), against the oracle fed the same parameter blocks: the output of every
+    update to 2e-5 of the RUN's maximum -- the feedback network recirculates rounding differences, so the bound is
+    stated over the run, like the pitch shifter's."""
+    oalgpu = _gpu()
+    g = oalgpu.Reverb(4)
+    g.set_math_mode(oalgpu.MATH_FAST)
+    if ol.available("ref"):
+        orc = ol.load("ref").make_reverb(4)
+        host = None
+    else:
+        orc = ol.load("port").make_reverb(4)
+        host = oalgpu.Reverb(4, device=-1)
+    x = wet_input(SEED[name] + 1, len(schedule))
+    outs = []
+    for u, st in enumerate(schedule):
+        if st["props"] is not None:
+            if host is None:
+                orc.update(ol.ReverbProps.make(**st["props"]), st["slot_gain"])
+                blk = orc.get_params()
+            else:
+                host.update(oalgpu.ReverbProps.make(**st["props"]), st["slot_gain"])
+                blk = as_oracle_params(block_bytes(host.get_params()))
+                orc.set_params(blk)
+            g.set_params(blk)
+        a, b = out_init(4), out_init(4)
+        g.process_n(x[u], a, st["n"])
+        orc.process_n(x[u], b, st["n"])
+        if host is not None:
+            host.skip(st["n"])
+        outs.append((a.astype(np.float64), b.astype(np.float64)))
+    scale = max(float(np.abs(b).max()) for _, b in outs)
+    worst = max(float(np.abs(a - b).max()) for a, b in outs)
+    assert scale > 1e-4, (name, scale)
+    assert worst <= 2e-5 * scale + 1e-7, (name, worst, scale)
+    g.close(); orc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_fast_mode_long_run():
+    """60 updates of continuous noise through a modulated, long-decay preset with two parameter changes: FAST mode must
+    stay within 1e-4 of the run's maximum of the reference (measured: printed)."""
+    oalgpu = _gpu()
+    if not ol.available("ref"):
+        pytest.skip("needs the compiled reference")
+    orc = ol.load("ref").make_reverb(4)
+    g = oalgpu.Reverb(4)
+    g.set_math_mode(oalgpu.MATH_FAST)
+    rng = np.random.default_rng(99)
+    changes = {0: dict(modulation_depth=1.0, modulation_time=0.3, decay_time=4.0, late_reverb_pan=(0.2, 0.3, -0.5)),
+               20: dict(modulation_depth=0.4, modulation_time=1.3, decay_time=2.0, density=0.3),
+               41: dict(modulation_depth=0.4, modulation_time=1.3, decay_time=2.0, density=0.3, gain=0.1)}
+    worst = scale = 0.0
+    for u in range(60):
+        if u in changes:
+            orc.update(ol.ReverbProps.make(**changes[u]), 0.9)
+            g.update(oalgpu.ReverbProps.make(**changes[u]), 0.9)
+        x = (rng.standard_normal((4, BUFFER_LINE)) * 0.1).astype(np.float32)
+        a, b = out_init(4), out_init(4)
+        g.process(x, a)
+        orc.process(x, b)
+        worst = max(worst, float(np.abs(a.astype(np.float64) - b).max()))
+        scale = max(scale, float(np.abs(b).max()))
+    print(f"FAST reverb over 60 updates: worst {worst:.3e} = {worst / scale:.2e} of the run's maximum {scale:.3e}")
+    assert worst <= 1e-4 * scale, (worst, scale)
+    g.close(); orc.close()
+
+
+@pytest.mark.gpu
 def test_gpu_wide_target_and_long_run():
     """A 16-line target bus and 60 updates of continuous noise through a modulated, panned preset
     with two parameter changes on the way: the feedback network must stay bit-identical (any

@@ -12,6 +12,8 @@ import oalgpu  # noqa: E402
 
 rng = np.random.default_rng(0)
 g = oalgpu.Reverb(4)
+if len(sys.argv) > 1 and sys.argv[1] == "fast":
+    g.set_math_mode(oalgpu.MATH_FAST)
 oalgpu.lib.oalgpu_reverb_debug_enable_phase_times.argtypes = [C.c_void_p]
 assert oalgpu.lib.oalgpu_reverb_debug_enable_phase_times(g.h) == 0
 g.update(oalgpu.ReverbProps.make(modulation_depth=0.5))
