@@ -364,31 +364,38 @@ __device__ void LateWave(const RvLayout &L, const int p, LateLds &w, uint32_t *p
             w.modDelays[i] = uint32_t((lfo + 1.0f) * depth);
         }
         WaveSync();
-        // modulated feedback taps, cubic-interpolated (:1718-1747)
-        for(uint32_t j = 0; j < 4; ++j)
+        // modulated feedback taps, cubic-interpolated (:1718-1747).  All four lines' 64 taps are requested before the first
+        // is used: one round trip to the feedback lines per sub-block on the late line's chain instead of four.
         {
-            const float *input = ln.ldelay + size_t{j} * ln.ldelayStride;
-            const float midGain = P.t60_mid_gain[j];
-            const uint32_t tap = offset - P.late_offset[j];
-            float o[4][4];
+            float o[4][4][4];
             uint32_t doff[4];
 #pragma unroll
             for(uint32_t k = 0; k < 4; ++k)
             {
                 const uint32_t i = lane + 64u * k;
                 const uint32_t idelay = w.modDelays[i < todo ? i : 0u];
-                const uint32_t delay = tap + i - (idelay >> kCubicBits);
                 doff[k] = idelay & kCubicMask;
 #pragma unroll
-                for(uint32_t m = 0; m < 4; ++m) o[k][m] = input[(delay - m) & ldMask];
+                for(uint32_t j = 0; j < 4; ++j)
+                {
+                    const float *input = ln.ldelay + size_t{j} * ln.ldelayStride;
+                    const uint32_t delay = (offset - P.late_offset[j]) + i - (idelay >> kCubicBits);
+#pragma unroll
+                    for(uint32_t m = 0; m < 4; ++m) o[j][k][m] = input[(delay - m) & ldMask];
+                }
             }
 #pragma unroll
-            for(uint32_t k = 0; k < 4; ++k)
+            for(uint32_t j = 0; j < 4; ++j)
             {
-                const uint32_t i = lane + 64u * k;
-                const float out = o[k][0] * cubic[kCubicSteps + doff[k]] + o[k][1] * cubic[doff[k]]
-                    + o[k][2] * cubic[kCubicSteps - doff[k]] + o[k][3] * cubic[kCubicSteps * 2u - doff[k]];
-                if(i < todo) w.temp[j * kRow + i] = out * midGain;
+                const float midGain = P.t60_mid_gain[j];
+#pragma unroll
+                for(uint32_t k = 0; k < 4; ++k)
+                {
+                    const uint32_t i = lane + 64u * k;
+                    const float out = o[j][k][0] * cubic[kCubicSteps + doff[k]] + o[j][k][1] * cubic[doff[k]]
+                        + o[j][k][2] * cubic[kCubicSteps - doff[k]] + o[j][k][3] * cubic[kCubicSteps * 2u - doff[k]];
+                    if(i < todo) w.temp[j * kRow + i] = out * midGain;
+                }
             }
         }
         WaveSync();
