@@ -41,10 +41,11 @@ BYTES_PER_VOICE_UPDATE = {3: 3956 + 384 + 16 + 512 + 512, 2: 3956 + 384 + 16 + 2
                           4: 3956 + 384 + 16 + 3 * 4 * 5 + 2 * 3 * 4 * 4, 5: 3956 + 384 + 16 + 512 + 512 + 3 * 4 * 4}
 
 
-def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, vpg, num_real=None, voice_map=None):
+def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, vpg, num_real=None, voice_map=None, sample_fmt="f32"):
     """num_real: real output lines of a non-HRTF context (8 = a 7.1 device: the dry lines are then decoded
     to speaker feeds by the reference's X71 decoder in the post-process); None = no output stage.
-    voice_map: the global voice index of every local voice (a shard dealt by cost class) instead of voice_base."""
+    voice_map: the global voice index of every local voice (a shard dealt by cost class) instead of voice_base.
+    sample_fmt: "f32" or "i16" source buffers (SURVEY.md 8d names both)."""
     hrtf = config_id in (3, 5)
     nsends = {4: 4, 5: 1}.get(config_id, 0)
     if num_real is None:
@@ -71,8 +72,8 @@ def build_scene(oalgpu, synth, api, config_id, nvoices, voice_base, mhr_bytes, v
         # the post-process's ambisonic-to-binaural decoder as InitHrtfPanning builds it for a first-order HRTF device
         # (alc/panning.cpp:1100-1134): DirectHrtfState::build on the loaded data set, the cube layout, 400 Hz crossover
         sc.set_direct_hrtf_from_store(synth.AMBI_POINTS_1O, synth.AMBI_MATRIX_1O, synth.AMBI_ORDER_HF_GAIN_1O, 400.0)
-    bufs = synth.scene_buffers(config_id, nvoices if voice_map is None else 256)
-    handles = [sc.add_buffer(b, oalgpu.FMT_FLOAT) for b in bufs]
+    bufs = synth.scene_buffers(config_id, nvoices if voice_map is None else 256, sample_fmt)
+    handles = [sc.add_buffer(b, oalgpu.FMT_SHORT if sample_fmt == "i16" else oalgpu.FMT_FLOAT) for b in bufs]
     script = synth.SceneScript(config_id, nvoices, voice_base, voice_map)
     for v in range(nvoices):
         sc.add_voice(handles[script.buffer_of(v, len(handles))], True, position=script.start_position(v))

@@ -179,8 +179,8 @@ typedef struct oalgpu_context_desc {
 /* oalgpu_context_desc::flags -- kernel variants are chosen here, never from the environment */
 #define OALGPU_CTX_FIR_VALU 1u    /* FAST HRTF voices (IrSize <= 64): the dual-ear FIR as packed fp32 VALU FMAs
                                    * instead of the matrix pipe in split half precision */
-#define OALGPU_CTX_PROFILE  2u    /* the voice kernel's measurement variant: per-phase cycle stamps
-                                   * (oalgpu_debug_phase_times) and stage ablation (oalgpu_debug_set_ablate) */
+#define OALGPU_CTX_PROFILE  2u    /* the voice kernel's measurement variant: per-phase cycle stamps and stage ablation,
+                                   * read and set through include/oalgpu_debug.h */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 
@@ -190,6 +190,12 @@ void oalgpu_context_destroy(oalgpu_context *ctx);
 /* LoadHrtf(std::istream&), core/hrtf_loader.hpp:10 (format v3 "MinPHR03",
  * core/hrtf_loader.cpp:583-721); the store is uploaded to HBM.  Must precede any HRTF voice. */
 int oalgpu_hrtf_load_mhr(oalgpu_context *ctx, const void *data, size_t size);
+/* The same from an HrtfStore already in memory (core/hrtf.h:22-59): what DeviceBase::mHrtf holds once GetLoadedHrtf
+ * (core/hrtf.cpp:471-620) has loaded -- and resampled -- a data set; the arrays are those oalgpu_hrtf_raw hands out
+ * (mFields: distance / evCount, mElev: azCount / irOffset, mCoeffs: num_irs x 128 x 2, mDelays: num_irs x 2). */
+int oalgpu_hrtf_load_store(oalgpu_context *ctx, uint32_t sample_rate, uint32_t ir_size, const float *field_distance,
+    const uint8_t *field_evcount, uint32_t num_fields, const uint16_t *elev_azcount, const uint16_t *elev_iroffset,
+    uint32_t num_elevs, const float *coeffs, const uint8_t *delays, uint32_t num_irs);
 typedef struct oalgpu_hrtf_info {
     uint32_t sample_rate, ir_size, num_fields, num_elevs, num_irs;
 } oalgpu_hrtf_info;
@@ -280,12 +286,23 @@ typedef struct oalgpu_voice_params {
     int32_t  resampler;                              /* props.mResampler */
     oalgpu_filter_params direct_filter;              /* alc/alu.cpp:1619-1637 */
     float    dry_gains[OALGPU_MAX_OUTPUT_CHANNELS];  /* mDryParams.Gains.Target */
-    float    hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread; /* getCoeffs arguments, alu.cpp:1214 */
+    float    hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread; /* getCoeffs arguments, alu.cpp:1214; hrtf_dist =
+                                                      * OALGPU_HRTF_KEEP_TARGET: the voice's HRTF target, delays and gain
+                                                      * stay as they are (see oalgpu_voice_set_hrtf_targets) */
     float    hrtf_gain;                              /* Hrtf.Target.Gain */
     int32_t  send_slot[OALGPU_MAX_SENDS];            /* -1: mSend[i].Buffer empty */
     oalgpu_filter_params send_filter[OALGPU_MAX_SENDS];
     float    send_gains[OALGPU_MAX_SENDS][OALGPU_MAX_AMBI_CHANNELS]; /* mWetParams[i].Gains.Target */
 } oalgpu_voice_params;
+#define OALGPU_HRTF_KEEP_TARGET (-1.0f)
+/* For a host that keeps the reference's own parameter stage (CalcVoiceParams as it is): Hrtf.Target of `count` voices as
+ * CalcHrtfPanning left it in the Voice (HrtfFilter, core/mixer/hrtfdefs.h:36-40; alc/alu.cpp:1214-1216, :1256-1258,
+ * :1296-1298) -- coeffs = count x 128 x 2 (the blended HrirArray), delays = count x 2, gains = count -- installed as the
+ * voices' target filter (marked as replaced: the next mix cross-fades from Hrtf.Old, voice.cpp:846-873).  The voices'
+ * other parameters go through oalgpu_voice_set_params with hrtf_dist = OALGPU_HRTF_KEEP_TARGET. */
+int oalgpu_voice_set_hrtf_targets(oalgpu_context *ctx, const uint32_t *voices, const float *coeffs, const uint32_t *delays,
+    const float *gains, size_t count);
+
 /* ---- panning on the GPU: CalcDirectionCoeffs + ComputePanGains -----------------------------
  * What CalcPanningAndFilters does for a point source (alc/alu.cpp; core/mixer.h:68-73, core/ambidefs.h:219-271,
  * core/mixer.cpp:16-102): coeffs = CalcDirectionCoeffs(dir, spread), then ComputePanGains(&Device->Dry, coeffs,
@@ -477,6 +494,17 @@ typedef struct oalgpu_voice_state {
     oalgpu_biquad send_lp[OALGPU_MAX_SENDS], send_hp[OALGPU_MAX_SENDS];
 } oalgpu_voice_state;
 int oalgpu_voice_readback(oalgpu_context *ctx, uint32_t voice, oalgpu_voice_state *out);
+/* The part of it the rest of the reference looks at after an update -- GetSourceOffset's position, the play state,
+ * whether the source ran out of buffer (Voice::mix then sets mCurrentBuffer = nullptr and the state Stopping,
+ * core/voice.cpp:1201-1232), VoiceFlag::IsFading -- for `count` voices in one device-to-host copy. */
+typedef struct oalgpu_voice_brief {
+    int32_t  play_state;
+    int32_t  position;
+    uint32_t position_frac;
+    int32_t  has_buffer;
+    int32_t  fading;
+} oalgpu_voice_brief;
+int oalgpu_voices_readback(oalgpu_context *ctx, const uint32_t *voices, size_t count, oalgpu_voice_brief *out);
 
 /* ---- the pipelined host boundary: an update's moved voices in, its output lines out, nothing waits ---------------------
  * What CalcPanningAndFilters (alc/alu.cpp:1512-1657) hands over for a voice whose direction moved while its filter
@@ -496,23 +524,11 @@ int oalgpu_voice_move_async(oalgpu_context *ctx, const oalgpu_voice_move *moves,
 int oalgpu_read_output_async(oalgpu_context *ctx, uint32_t *ticket);
 int oalgpu_output_wait(oalgpu_context *ctx, uint32_t ticket, float *out, size_t out_floats);
 
-/* Measurement aid: `updates` pipelined updates driven from C++ exactly as section 3c of INTEGRATION.md writes them
- * (oalgpu_voice_move_async of moves[u % move_sets] -- `count` records each --, oalgpu_mix_update, oalgpu_read_output_async,
- * oalgpu_output_wait of the update two back into `out`), so that the boundary's throughput can be stated without a
- * language binding's per-call cost.  wall_s: the loop's duration; busy_s: the calling thread's time outside
- * oalgpu_output_wait. */
-int oalgpu_debug_pipelined_run(oalgpu_context *ctx, const oalgpu_voice_move *moves, size_t count, uint32_t move_sets,
-    uint32_t updates, uint32_t samples_to_do, int post_process, float *out, size_t out_floats, double *wall_s, double *busy_s);
-
 /* Timing of the last oalgpu_mix_update/mix_voices launch sequence, measured with HIP events on
  * the context's stream: total milliseconds, and the share of the voice kernel. */
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);
 /* Enables/disables the event timing above (off by default: it adds two event records). */
 int oalgpu_set_timing(oalgpu_context *ctx, int enable);
-/* The floor of that clock: an EMPTY kernel (one wavefront that returns) dispatched on the context's stream and timed
- * the same way as the voice kernel -- HIP events bound to the dispatch (hipExtLaunchKernel); the median of `reps`
- * dispatches.  Whatever the events include besides a kernel's own run time is in this figure too. */
-int oalgpu_debug_event_floor_ms(oalgpu_context *ctx, uint32_t reps, float *ms);
 /* ---- the EffectStates of alc/effects/ besides the reverbs -----------------------------------------
  * EffectState::deviceUpdate / update / process (core/effects/base.h:197-209) of alc/effects/{equalizer,modulator,
  * echo,dedicated}.cpp.  create = deviceUpdate; update takes the effect's EFX properties (core/effects/base.h:

@@ -2,8 +2,9 @@
  * drops into the tree to put the GPU behind alc/alu.cpp's voice loop (INTEGRATION.md sections 3 and 4).
  *
  * It needs the reference's own headers (include it from a translation unit that already has core/voice.h,
- * core/device.h, core/mixer.h, core/mixer/defs.h, core/mixer/hrtfdefs.h and core/filters/biquad.h) and nothing
- * else of this repository besides oalgpu.h.  Two layers:
+ * core/device.h, core/context.h, core/effectslot.h, core/hrtf.h, core/async_event.h, ringbuffer.h, core/mixer.h,
+ * core/mixer/defs.h, core/mixer/hrtfdefs.h and core/filters/biquad.h) and nothing else of this repository besides
+ * oalgpu.h.  Two layers:
  *
  *  (1) adapters with the reference's function-pointer signatures on top of the per-call C-ABI --
  *        ResamplerFunc        core/mixer/defs.h:71-72     -> oalgpu_resample
@@ -14,22 +15,34 @@
  *
  *  (2) BatchMixer: the voice loop itself.  ProcessContexts calls voice->mix() for every playing voice
  *      (alc/alu.cpp:2201-2206); with the GPU behind it the calls of one update are collected and, with the last
- *      one, described to the device context -- oalgpu_voice_params filled from the Voice AFTER the reference's own
- *      CalcVoiceParams computed mStep, the pan gains and the filter targets (alu.cpp:1512-1710) -- and mixed by
- *      ONE oalgpu_mix_update; the dry lines are added into DeviceBase::MixBuffer and the state the rest of the
- *      reference looks at (positions, play state, fade flag) is read back.
+ *      one, described to the device context -- from the Voice AFTER the reference's own CalcVoiceParams computed
+ *      mStep, the pan gains, the filter targets and, on an HRTF device, Hrtf.Target (alu.cpp:1512-1710) -- and
+ *      mixed by ONE oalgpu_mix_update.  What the voices produced joins the reference's own mixing buffers exactly
+ *      where Voice::mix would have put it: the dry lines into DeviceBase::Dry (MixSamples, voice.cpp:962-963), the
+ *      dual-ear FIR's output into DeviceBase::HrtfAccumData (DoHrtfMix, voice.cpp:827-902), every send into its
+ *      slot's wet buffer (voice.cpp:966-979); the reference carries on with its effect slots (alu.cpp:2209-2257) and
+ *      its post-process (DeviceBase::Process(HrtfPostProcess) / (AmbiDecPostProcess), alu.cpp:282-298), which also
+ *      owns the HRTF accumulator's tail.  The state the rest of the reference looks at (positions, play state, the
+ *      end of a source) is read back.
+ *
+ * Scope: mono, static (VoiceFlag::IsStatic) sources of every PCM sample type and of both ADPCM types, on a device in
+ * RenderMode::Normal (ambisonic dry lines) or RenderMode::Hrtf, with up to MaxSendCount auxiliary sends into the
+ * context's active effect slots.  Anything else (multi-channel or streaming sources, direct channels, delayed
+ * starts) makes mix() report an error and the caller runs the reference's own loop for that update.
  *
  * BiquadInterpFilter keeps its target coefficients private; the shelf gains are recovered from them
  * (ShelfGainAt), so the including translation unit must see them -- upstream that is one friend declaration in
- * core/filters/biquad.h; this repository's compiled bridge (oracle/ref_bridge.cpp) opens the class instead.
- * Mono float32 static buffers, no auxiliary sends: the scope of BASELINE configs[0]. */
+ * core/filters/biquad.h; this repository's compiled bridge (oracle/ref_bridge.cpp) opens the class instead. */
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <span>
 #include <string>
 #include <utility>
+#include <variant>
 #include <vector>
 
 #include "oalgpu.h"
@@ -41,6 +54,7 @@ struct AdapterState {
     int device{0};
     int mathMode{OALGPU_MATH_EXACT};
     int resamplerKind{OALGPU_RESAMPLER_LINEAR};      /* of the voice Voice::mix is working on */
+    uint64_t calls[4]{};                             /* resample, mix, mix_hrtf, mix_hrtf_blend: invocations so far */
 };
 inline AdapterState &Adapters() { static AdapterState s; return s; }
 
@@ -49,13 +63,15 @@ inline AdapterState &Adapters() { static AdapterState s; return s; }
 inline void Resample(InterpState const*, std::span<float const> src, unsigned frac, unsigned increment,
     std::span<float> dst) noexcept
 {
-    const AdapterState &a = Adapters();
+    AdapterState &a = Adapters();
+    ++a.calls[0];
     oalgpu_resample(a.device, a.mathMode, a.resamplerKind, increment, src.data(), src.size(), frac, dst.data(), dst.size());
 }
 
 inline void Mix(std::span<float const> in, std::span<FloatBufferLine> out, std::span<float> cur,
     std::span<float const> tgt, std::size_t counter, std::size_t outpos) noexcept
 {
+    ++Adapters().calls[1];
     oalgpu_mix(Adapters().device, in.data(), in.size(), out[0].data(), out.size(), cur.data(), tgt.data(), counter, outpos);
 }
 
@@ -63,6 +79,7 @@ inline void MixHrtf(std::span<float const> in, std::span<f32x2> accum, unsigned 
     std::size_t n) noexcept
 {
     const uint32_t delay[2]{f->Delay[0], f->Delay[1]};
+    ++Adapters().calls[2];
     oalgpu_mix_hrtf(Adapters().device, Adapters().mathMode, in.data(), &accum[0][0], irSize, &f->Coeffs[0][0], delay,
         f->Gain, f->GainStep, n);
 }
@@ -71,12 +88,13 @@ inline void MixHrtfBlend(std::span<float const> in, std::span<f32x2> accum, unsi
     MixHrtfFilter const *newp, std::size_t n) noexcept
 {
     const uint32_t od[2]{oldp->Delay[0], oldp->Delay[1]}, nd[2]{newp->Delay[0], newp->Delay[1]};
+    ++Adapters().calls[3];
     oalgpu_mix_hrtf_blend(Adapters().device, Adapters().mathMode, in.data(), &accum[0][0], irSize, &oldp->Coeffs[0][0], od,
         oldp->Gain, &newp->Coeffs[0][0], nd, newp->GainStep, n);
 }
 
 /* ---- (2) the batched voice loop ------------------------------------------------------------------------------ */
-/* the shelf gains CalcPanningAndFilters designed the voice's direct filters with (alu.cpp:1619-1637):
+/* the shelf gains CalcPanningAndFilters designed the voice's filters with (alu.cpp:1619-1657):
  * BiquadFilter::SetParams (biquad.cpp:48-129) builds the shelves with A = gain, so a high shelf answers
  * gain^2 at Nyquist and a low shelf gain^2 at DC */
 inline float ShelfGainAt(const BiquadInterpFilter &f, float z /* +1: DC, -1: Nyquist */)
@@ -87,7 +105,8 @@ inline float ShelfGainAt(const BiquadInterpFilter &f, float z /* +1: DC, -1: Nyq
 
 class BatchMixer {
 public:
-    explicit BatchMixer(int mathMode = OALGPU_MATH_FAST, int device = 0) : mMathMode{mathMode}, mDevice{device} { }
+    explicit BatchMixer(int mathMode = OALGPU_MATH_FAST, int device = 0, unsigned maxVoices = 4096)
+        : mMathMode{mathMode}, mDevice{device}, mMaxVoices{maxVoices} { }
     BatchMixer(const BatchMixer&) = delete;
     BatchMixer &operator=(const BatchMixer&) = delete;
     ~BatchMixer() { if(mGpu) oalgpu_context_destroy(mGpu); }
@@ -113,62 +132,178 @@ public:
         mBatch.emplace_back(voice, vstate);
         if(++mSeen != mExpected) return false;
         mSeen = 0;
-        return flush(dev, samplesToDo) == 0;
+        return flush(context, dev, samplesToDo) == 0;
     }
     bool batchComplete() const { return mSeen == 0; }
     void reset() { mSeen = 0; }                     /* a new update begins (DeviceBase::renderSamples) */
     const std::vector<std::pair<Voice*, Voice::State>> &batch() const { return mBatch; }
+    size_t liveVoices() const { return mVoices.size(); }
 
 private:
+    struct Entry {
+        uint32_t index{0};
+        int lastState{int(Voice::Playing)};
+        unsigned sourceId{0};
+        bool haveParams{false};
+        oalgpu_voice_params params{};
+        bool haveTarget{false};
+        HrtfFilter target{};                        /* the Hrtf.Target the device context was last given */
+    };
+
     int fail(int rc, const char *what)
     {
         if(!mError) { mError = rc; mErrorText = std::string(what) + ": " + oalgpu_last_error(); }
         return rc;
     }
-
-    int flush(DeviceBase &dev, unsigned samplesToDo)
+    int failText(int rc, const char *what)
     {
-        if(!mGpu)
+        if(!mError) { mError = rc; mErrorText = what; }
+        return rc;
+    }
+
+    /* DeviceBase -> oalgpu_context_desc; an HRTF device hands over the store it renders with (DeviceBase::mHrtf) */
+    int createContext(ContextBase *context, DeviceBase &dev)
+    {
+        auto const auxspan = std::span{*context->mActiveAuxSlots.load(std::memory_order_acquire)};
+        auto const auxslots = auxspan.first(auxspan.size() >> 1);
+        mHrtf = dev.mRenderMode == RenderMode::Hrtf;
+        oalgpu_context_desc d{};
+        d.device = mDevice; d.math_mode = mMathMode; d.sample_rate = dev.mSampleRate;
+        d.num_dry_channels = uint32_t(dev.Dry.Buffer.size());
+        d.num_real_channels = dev.RealOut.Buffer.data() != dev.Dry.Buffer.data() ? uint32_t(dev.RealOut.Buffer.size()) : 0u;
+        d.num_aux_sends = dev.NumAuxSends;
+        d.num_slots = dev.NumAuxSends ? uint32_t(std::max<size_t>(auxslots.size(), 1)) : 0u;
+        d.wet_channels = 4;
+        if(dev.NumAuxSends && !auxslots.empty())
         {
-            oalgpu_context_desc d{};
-            d.device = mDevice; d.math_mode = mMathMode; d.sample_rate = dev.mSampleRate;
-            d.num_dry_channels = uint32_t(dev.Dry.Buffer.size());
-            d.num_real_channels = uint32_t(dev.RealOut.Buffer.size());
-            d.num_aux_sends = 0; d.num_slots = 0; d.wet_channels = 4; d.hrtf = 0;
-            d.max_voices = 1024; d.max_buffers = 256; d.voices_per_group = 0; d.flags = 0;
-            if(int rc = oalgpu_context_create(&d, &mGpu)) return fail(rc, "oalgpu_context_create");
+            d.wet_channels = uint32_t(auxslots[0]->Wet.Buffer.size());
+            for(EffectSlotBase *slot : auxslots)
+                if(slot->Wet.Buffer.size() != d.wet_channels)
+                    return failText(OALGPU_ERR_INVALID, "oalgpu_openal: the effect slots' wet buses differ in size");
         }
-        std::vector<uint32_t> ids;
+        d.hrtf = mHrtf ? 1 : 0;
+        d.max_voices = mMaxVoices; d.max_buffers = 1024; d.voices_per_group = 0; d.flags = 0;
+        if(int rc = oalgpu_context_create(&d, &mGpu)) return fail(rc, "oalgpu_context_create");
+        mNumSlots = d.num_slots; mWetChannels = d.wet_channels;
+        if(mHrtf)
+        {
+            HrtfStore const *store = dev.mHrtf.get();
+            if(!store) return failText(OALGPU_ERR_NO_HRTF, "oalgpu_openal: RenderMode::Hrtf without DeviceBase::mHrtf");
+            std::vector<float> dist; std::vector<uint8_t> evc; std::vector<uint16_t> azc, iro; std::vector<uint8_t> delays;
+            for(auto const &f : store->mFields) { dist.push_back(f.distance); evc.push_back(f.evCount.c_val); }
+            for(auto const &e : store->mElev) { azc.push_back(e.azCount.c_val); iro.push_back(e.irOffset.c_val); }
+            for(auto const &dl : store->mDelays) { delays.push_back(dl[0].c_val); delays.push_back(dl[1].c_val); }
+            /* (DeviceBase::mIrSize: the taps the mixers apply -- the store's IrSize unless "hrtf-size" shortened it,
+             * alc/panning.cpp:1345-1350) */
+            if(int rc = oalgpu_hrtf_load_store(mGpu, store->mSampleRate, dev.mIrSize, dist.data(), evc.data(), uint32_t(dist.size()),
+                azc.data(), iro.data(), uint32_t(azc.size()), &store->mCoeffs[0][0][0], delays.data(), uint32_t(store->mCoeffs.size())))
+                return fail(rc, "oalgpu_hrtf_load_store");
+            /* DeviceBase::HrtfAccumData and its tail stay the reference's: MixDirectHrtf runs there (alu.cpp:289-298) */
+            if(int rc = oalgpu_set_carry_accum(mGpu, 0)) return fail(rc, "oalgpu_set_carry_accum");
+        }
+        for(uint32_t i = 0; i < mMaxVoices; ++i) mFreeIndex.push_back(mMaxVoices - 1u - i);
+        return 0;
+    }
+
+    /* al::Buffer storage behind a VoiceBufferItem, registered once (InitVoice, al/source.cpp:639-670) */
+    int bufferHandle(const Voice *voice, const VoiceBufferItem *item)
+    {
+        auto hb = mBufferHandle.find(item);
+        if(hb != mBufferHandle.end()) return hb->second;
+        /* SampleVariant (core/buffer_storage.h:35-43) and oalgpu_fmt_type list the PCM types in the same order */
+        const size_t kind = item->mSamples.index();
+        const void *data = std::visit([](auto const &s) -> const void* { return s.data(); }, item->mSamples);
+        int h;
+        if(kind <= size_t(OALGPU_FMT_ALAW))
+            h = oalgpu_buffer_register(mGpu, data, int(kind), voice->mFrameStep, item->mSampleLen, item->mLoopStart, item->mLoopEnd);
+        else
+            h = oalgpu_buffer_register_adpcm(mGpu, data, kind == 7 ? OALGPU_ADPCM_IMA4 : OALGPU_ADPCM_MS, voice->mFrameStep,
+                item->mBlockAlign, item->mSampleLen, item->mLoopStart, item->mLoopEnd);
+        if(h < 0) return fail(h, "oalgpu_buffer_register");
+        mBufferHandle.emplace(item, h);
+        return h;
+    }
+
+    int slotOf(std::span<EffectSlotBase*const> auxslots, std::span<FloatBufferLine> target) const
+    {
+        for(size_t s{0}; s < auxslots.size(); ++s)
+            if(auxslots[s]->Wet.Buffer.data() == target.data()) return int(s);
+        return -1;
+    }
+
+    /* what Voice::mix does when a voice reaches the end of its buffer (core/voice.cpp:1201-1232) */
+    static void endOfSource(Voice *voice, ContextBase *context)
+    {
+        auto const sourceID = voice->mSourceID.load(std::memory_order_relaxed);
+        voice->mCurrentBuffer.store(nullptr, std::memory_order_release);
+        voice->mLoopBuffer.store(nullptr, std::memory_order_relaxed);
+        voice->mSourceID.store(0u, std::memory_order_release);
+        voice->mPlayState.store(Voice::Stopping, std::memory_order_release);
+        if(context->mEnabledEvts.load(std::memory_order_acquire).test(AsyncEnableBits::SourceState))
+        {   /* SendSourceStoppedEvent, core/voice.cpp:195-208 */
+            auto *ring = context->mAsyncEvents.get();
+            if(auto const evt_vec = ring->getWriteVector(); !evt_vec[0].empty())
+            {
+                auto &evt = InitAsyncEvent<AsyncSourceStateEvent>(evt_vec[0].front());
+                evt.mId = sourceID;
+                evt.mState = AsyncSrcState::Stop;
+                ring->writeAdvance(1);
+            }
+        }
+    }
+
+    int flush(ContextBase *context, DeviceBase &dev, unsigned samplesToDo)
+    {
+        if(!mGpu) { if(int rc = createContext(context, dev)) return rc; }
+        auto const auxspan = std::span{*context->mActiveAuxSlots.load(std::memory_order_acquire)};
+        auto const auxslots = auxspan.first(auxspan.size() >> 1);
+        if(dev.NumAuxSends && auxslots.size() > mNumSlots)
+            return failText(OALGPU_ERR_CAPACITY, "oalgpu_openal: more active effect slots than the device context was created for");
+
+        std::vector<uint32_t> ids, tgtIds, tgtDelays;
         std::vector<oalgpu_voice_params> params;
+        std::vector<float> tgtCoeffs, tgtGains;
+        std::vector<std::pair<Voice*, Entry*>> mixed;
         for(auto &[voice, vstate] : mBatch)
         {
-            auto it = mVoiceIndex.find(voice);
-            if(it == mVoiceIndex.end())
-            {   /* a voice that starts playing: register its buffer once, InitVoice (al/source.cpp:639-670) */
+            /* (a mono voice mixes mChans[0] alone unless panning duplicates it, voice.cpp:1058-1059) */
+            if(voice->mFmtChannels != FmtMono || voice->mDuplicateMono || !voice->mFlags.test(VoiceFlag::IsStatic)
+                || voice->mFlags.test(VoiceFlag::IsAmbisonic) || voice->mFlags.test(VoiceFlag::HasNfc))
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: mono static sources only");
+            auto it = mVoices.find(voice);
+            if(it != mVoices.end() && it->second.sourceId != voice->mSourceID.load(std::memory_order_relaxed)
+                && voice->mSourceID.load(std::memory_order_relaxed) != 0u)
+            {   /* the Voice object now plays another source (voices are pooled, core/context.h:159-160) */
+                mFreeIndex.push_back(it->second.index);
+                mVoices.erase(it);
+                it = mVoices.end();
+            }
+            if(it == mVoices.end())
+            {   /* a voice that starts playing: InitVoice (al/source.cpp:639-670) */
                 auto *item = voice->mCurrentBuffer.load(std::memory_order_relaxed);
-                if(!item) continue;
-                auto hb = mBufferHandle.find(item);
-                if(hb == mBufferHandle.end())
-                {
-                    auto const *span = std::get_if<std::span<f32>>(&item->mSamples);
-                    if(!span) return fail(OALGPU_ERR_INVALID, "oalgpu_openal: float buffers only");
-                    const int h = oalgpu_buffer_register(mGpu, span->data(), OALGPU_FMT_FLOAT, voice->mFrameStep,
-                        item->mSampleLen, item->mLoopStart, item->mLoopEnd);
-                    if(h < 0) return fail(h, "oalgpu_buffer_register");
-                    hb = mBufferHandle.emplace(item, h).first;
+                if(!item)
+                {   /* nothing the device context ever saw: a voice told to stop before its first mix (voice.cpp:1002-1010) */
+                    if(vstate == Voice::Stopping) voice->mPlayState.store(Voice::Stopped, std::memory_order_release);
+                    continue;
                 }
-                const uint32_t idx = uint32_t(mVoiceIndex.size());
-                oalgpu_voice_desc vd{hb->second, voice->mLoopBuffer.load(std::memory_order_relaxed) != nullptr,
+                const int h = bufferHandle(voice, item);
+                if(h < 0) return h;
+                if(mFreeIndex.empty()) return failText(OALGPU_ERR_CAPACITY, "oalgpu_openal: more playing voices than max_voices");
+                Entry e;
+                e.index = mFreeIndex.back(); mFreeIndex.pop_back();
+                e.sourceId = voice->mSourceID.load(std::memory_order_relaxed);
+                oalgpu_voice_desc vd{h, voice->mLoopBuffer.load(std::memory_order_relaxed) != nullptr,
                     voice->mPosition.load(std::memory_order_relaxed), voice->mPositionFrac.load(std::memory_order_relaxed),
                     voice->mFrequency};
-                if(int rc = oalgpu_voice_init(mGpu, idx, &vd)) return fail(rc, "oalgpu_voice_init");
-                it = mVoiceIndex.emplace(voice, idx).first;
-                mLastState[voice] = Voice::Playing;
+                if(int rc = oalgpu_voice_init(mGpu, e.index, &vd)) return fail(rc, "oalgpu_voice_init");
+                it = mVoices.emplace(voice, e).first;
             }
-            if(mLastState[voice] != int(vstate))
+            Entry &e = it->second;
+            mixed.emplace_back(voice, &e);
+            if(e.lastState != int(vstate))
             {   /* ProcessVoiceChanges' play-state changes (alu.cpp:2057-2151) */
-                if(int rc = oalgpu_voice_set_state(mGpu, it->second, int(vstate))) return fail(rc, "oalgpu_voice_set_state");
-                mLastState[voice] = int(vstate);
+                if(int rc = oalgpu_voice_set_state(mGpu, e.index, int(vstate))) return fail(rc, "oalgpu_voice_set_state");
+                e.lastState = int(vstate);
             }
             /* what CalcVoiceParams left in the Voice (alu.cpp:1512-1710, :2012-2031) */
             oalgpu_voice_params p{};
@@ -181,52 +316,133 @@ private:
             p.direct_filter.lf_norm = voice->mProps.Direct.LFReference * inv_rate;
             p.direct_filter.gain_hf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.LowPass, -1.0f) : 1.0f;
             p.direct_filter.gain_lf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.HighPass, 1.0f) : 1.0f;
-            for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c) p.dry_gains[c] = chan.mDryParams.Gains.Target[c];
-            for(int s{0}; s < OALGPU_MAX_SENDS; ++s)
+            const bool hrtfVoice = voice->mFlags.test(VoiceFlag::HasHrtf);
+            if(hrtfVoice != mHrtf || (!mHrtf && voice->mDirect.Buffer.data() != dev.Dry.Buffer.data()))
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: direct-channel voices are not batched");
+            if(mHrtf) p.hrtf_dist = OALGPU_HRTF_KEEP_TARGET;       /* Hrtf.Target itself is handed over below */
+            else for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c) p.dry_gains[c] = chan.mDryParams.Gains.Target[c];
+            for(unsigned s{0}; s < unsigned(OALGPU_MAX_SENDS); ++s)
             {
                 p.send_slot[s] = -1;
                 p.send_filter[s] = oalgpu_filter_params{0, 1.0f, 5000.0f*inv_rate, 1.0f, 250.0f*inv_rate};
+                if(s >= dev.NumAuxSends || voice->mSend[s].Buffer.empty()) continue;
+                /* mSend[s].Buffer = the slot's Wet.Buffer (alu.cpp:1676-1683, :1729-1736) */
+                p.send_slot[s] = slotOf(auxslots, voice->mSend[s].Buffer);
+                if(p.send_slot[s] < 0) return failText(OALGPU_ERR_INVALID, "oalgpu_openal: a send targets a buffer that is no active slot's");
+                auto &wet = chan.mWetParams[s];
+                const bool on = voice->mSend[s].FilterActive;
+                p.send_filter[s].active = on ? 1 : 0;
+                p.send_filter[s].hf_norm = voice->mProps.Send[s].HFReference * inv_rate;
+                p.send_filter[s].lf_norm = voice->mProps.Send[s].LFReference * inv_rate;
+                p.send_filter[s].gain_hf = on ? ShelfGainAt(wet.LowPass, -1.0f) : 1.0f;
+                p.send_filter[s].gain_lf = on ? ShelfGainAt(wet.HighPass, 1.0f) : 1.0f;
+                for(uint32_t c{0}; c < mWetChannels; ++c) p.send_gains[s][c] = wet.Gains.Target[c];
             }
-            ids.push_back(it->second);
-            params.push_back(p);
+            /* only what changed goes over: CalcVoiceParams ran for the voices with pending properties, and
+             * BiquadInterpFilter::setParams with unchanged targets is a no-op (biquad.cpp:131-149) */
+            if(!e.haveParams || std::memcmp(&e.params, &p, sizeof(p)) != 0)
+            {
+                e.params = p; e.haveParams = true;
+                ids.push_back(e.index);
+                params.push_back(p);
+            }
+            if(mHrtf)
+            {
+                auto const &tg = chan.mDryParams.Hrtf.Target;
+                if(!e.haveTarget || tg.Gain != e.target.Gain || tg.Delay[0] != e.target.Delay[0] || tg.Delay[1] != e.target.Delay[1]
+                    || std::memcmp(&tg.Coeffs, &e.target.Coeffs, sizeof(tg.Coeffs)) != 0)
+                {
+                    e.target = tg; e.haveTarget = true;
+                    tgtIds.push_back(e.index);
+                    tgtDelays.push_back(tg.Delay[0]); tgtDelays.push_back(tg.Delay[1]);
+                    tgtGains.push_back(tg.Gain);
+                    tgtCoeffs.insert(tgtCoeffs.end(), &tg.Coeffs[0][0], &tg.Coeffs[0][0] + HrirLength*2);
+                }
+            }
         }
         if(!ids.empty())
             if(int rc = oalgpu_voice_set_params(mGpu, ids.data(), params.data(), ids.size())) return fail(rc, "oalgpu_voice_set_params");
-        /* the voice loop: one batched update, then the dry lines join the device's mixing buffer */
+        if(!tgtIds.empty())
+            if(int rc = oalgpu_voice_set_hrtf_targets(mGpu, tgtIds.data(), tgtCoeffs.data(), tgtDelays.data(), tgtGains.data(), tgtIds.size()))
+                return fail(rc, "oalgpu_voice_set_hrtf_targets");
+
+        /* the voice loop: one batched update; its buses join the reference's mixing buffers */
         if(int rc = oalgpu_mix_update(mGpu, samplesToDo, 0)) return fail(rc, "oalgpu_mix_update");
-        mLines.resize((dev.Dry.Buffer.size() + dev.RealOut.Buffer.size()) * BufferLineSize);
-        if(int rc = oalgpu_read_dry(mGpu, mLines.data())) return fail(rc, "oalgpu_read_dry");
-        for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c)
-            for(size_t i{0}; i < samplesToDo; ++i)
-                dev.Dry.Buffer[c][i] += mLines[c*BufferLineSize + i];
-        /* the state the reference mutates in place stays authoritative on the device; what the rest of the
-         * reference looks at (GetSourceOffset, the play state) is read back */
-        for(auto &[voice, vstate] : mBatch)
+        if(!mHrtf)
         {
-            auto it = mVoiceIndex.find(voice);
-            if(it == mVoiceIndex.end()) continue;
-            oalgpu_voice_state st{};
-            if(int rc = oalgpu_voice_readback(mGpu, it->second, &st)) return fail(rc, "oalgpu_voice_readback");
+            mLines.resize((dev.Dry.Buffer.size() + dev.RealOut.Buffer.size()) * BufferLineSize);
+            if(int rc = oalgpu_read_dry(mGpu, mLines.data())) return fail(rc, "oalgpu_read_dry");
+            for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c)
+                for(size_t i{0}; i < samplesToDo; ++i)
+                    dev.Dry.Buffer[c][i] += mLines[c*BufferLineSize + i];
+        }
+        else
+        {   /* DoHrtfMix's target (voice.cpp:832): frames [0, samplesToDo + IrSize) of this update's contributions */
+            mLines.resize((BufferLineSize + HrirLength) * 2);
+            if(int rc = oalgpu_read_hrtf_accum(mGpu, mLines.data())) return fail(rc, "oalgpu_read_hrtf_accum");
+            const size_t frames = std::min<size_t>(samplesToDo + dev.mIrSize, dev.HrtfAccumData.size());
+            for(size_t i{0}; i < frames; ++i)
+            {
+                dev.HrtfAccumData[i][0] += mLines[i*2 + 0];
+                dev.HrtfAccumData[i][1] += mLines[i*2 + 1];
+            }
+        }
+        if(dev.NumAuxSends)
+        {
+            mLines.resize(size_t{mWetChannels} * BufferLineSize);
+            for(size_t s{0}; s < auxslots.size(); ++s)
+            {
+                if(int rc = oalgpu_read_wet(mGpu, uint32_t(s), mLines.data())) return fail(rc, "oalgpu_read_wet");
+                auto wet = auxslots[s]->Wet.Buffer;
+                for(size_t c{0}; c < wet.size(); ++c)
+                    for(size_t i{0}; i < samplesToDo; ++i)
+                        wet[c][i] += mLines[c*BufferLineSize + i];
+            }
+        }
+
+        /* the state the reference mutates in place stays authoritative on the device; what the rest of the
+         * reference looks at (GetSourceOffset, the play state, the end of a source) is read back */
+        std::vector<uint32_t> rb;
+        for(auto &ve : mixed) rb.push_back(ve.second->index);
+        mBrief.resize(rb.size());
+        if(!rb.empty())
+            if(int rc = oalgpu_voices_readback(mGpu, rb.data(), rb.size(), mBrief.data())) return fail(rc, "oalgpu_voices_readback");
+        for(size_t k{0}; k < mixed.size(); ++k)
+        {
+            Voice *voice = mixed[k].first;
+            Entry &e = *mixed[k].second;
+            const oalgpu_voice_brief &st = mBrief[k];
+            if(st.fading) voice->mFlags.set(VoiceFlag::IsFading);
+            if(e.lastState == int(Voice::Stopping))
+            {   /* voice.cpp:1119-1123: faded out; the Voice object returns to the pool */
+                voice->mPlayState.store(Voice::Stopped, std::memory_order_release);
+                mFreeIndex.push_back(e.index);
+                mVoices.erase(voice);
+                continue;
+            }
             voice->mPosition.store(st.position, std::memory_order_relaxed);
             voice->mPositionFrac.store(st.position_frac, std::memory_order_relaxed);
-            if(st.fading) voice->mFlags.set(VoiceFlag::IsFading);
-            if(st.play_state != int(vstate))
+            if(!st.has_buffer)
             {
-                voice->mPlayState.store(static_cast<Voice::State>(st.play_state), std::memory_order_release);
-                mLastState[voice] = st.play_state;
+                endOfSource(voice, context);
+                e.lastState = int(Voice::Stopping);     /* (the device context set it itself) */
             }
         }
         return 0;
     }
 
     int mMathMode, mDevice;
+    unsigned mMaxVoices;
     oalgpu_context *mGpu{nullptr};
+    bool mHrtf{false};
+    uint32_t mNumSlots{0}, mWetChannels{4};
     std::map<const VoiceBufferItem*, int> mBufferHandle;
-    std::map<const Voice*, uint32_t> mVoiceIndex;
-    std::map<const Voice*, int> mLastState;
+    std::map<const Voice*, Entry> mVoices;
+    std::vector<uint32_t> mFreeIndex;
     unsigned mExpected{0}, mSeen{0};
     std::vector<std::pair<Voice*, Voice::State>> mBatch;
     std::vector<float> mLines;
+    std::vector<oalgpu_voice_brief> mBrief;
     int mError{0};
     std::string mErrorText;
 };

@@ -3,6 +3,7 @@
 // thread (resampler state, biquad design), and kernel launches on the context's stream.
 // No CPU fallback exists anywhere in this file: without a HIP device every entry point fails.
 #include "../../include/oalgpu.h"
+#include "../../include/oalgpu_debug.h"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -124,6 +125,7 @@ struct oalgpu_context {
     HrtfStoreDev hrtfDev{};
     HrtfData hrtfHost;
     bool hrtfLoaded{false};
+    uint32_t hrtfGeneration{0};            // bumped by every oalgpu_hrtf_load_mhr: parameter blocks carry HRIR indices of ONE store
     bool carryAccum{true};
     bool useWave{false};                   // FAST contexts without sends (HRTF, or <= 8 dry lines): voice_wave.hip
     std::vector<oalgpu_convolution*> slotConv;   // per effect slot: attached convolution reverb (not owned)
@@ -151,6 +153,9 @@ struct oalgpu_context {
     const WaveProf *profArg() const { return prof.times ? &prof : nullptr; }
     DevBuf<AmbiMapEntry> dryMap, wetMaps;   // MixParams::AmbiMap of the dry bus / of every slot's wet bus
     DevBuf<PanRecord> panRecs;
+    std::vector<VoiceCtl> ctlHost;          // oalgpu_voices_readback: staging
+    DevBuf<TargetRecord> tgtRecs;           // oalgpu_voice_set_hrtf_targets: staging
+    DevBuf<float> tgtCoeffs;
     bool serialOnly{false};                // OALGPU_CTX_SERIAL: no two-stream pipeline
     // multi-GPU (oalgpu_comm_init / oalgpu_comm_init_host): how this rank's bus block gets summed into rank 0's,
     // right behind the partial-bus reduction, on the stream that runs it
@@ -342,6 +347,7 @@ struct HostTransport final : BusTransport {
         std::atomic<uint64_t> produced[kMaxWorld];
         std::atomic<uint64_t> consumed;
         std::atomic<uint32_t> failed;
+        std::atomic<uint64_t> hello[kMaxWorld], ack[kMaxWorld];     // the attach handshake (oalgpu_comm_init_host)
     };
     std::string name;
     int fd{-1}, rank{0}, world{1};
@@ -350,9 +356,11 @@ struct HostTransport final : BusTransport {
     float *ring{nullptr};                          // [rank][slot][floats]
     float *pinned[kSlots]{};                       // this rank's staging: D2H target (rank > 0), H2D source (rank 0)
     DevBuf<float> devSum;                          // rank 0: the other ranks' sum on the device
-    uint64_t seq{0};
-    struct Job { HostTransport *t; uint64_t seq; };
-    Job jobs[kSlots]{};
+    // Host functions of one stream run in stream order, so each side counts the updates it has EXECUTED itself: a
+    // sequence number handed over through a reusable host slot would be overwritten by a host that is kSlots or
+    // more updates ahead of its stream (nothing throttles it: oalgpu_mix_update never synchronises)
+    uint64_t executed{0};
+    uint64_t submitted{0};                         // updates enqueued by the host (selects the staging slot)
 
     float *slot(int r, uint64_t q) const { return ring + (size_t(r) * kSlots + size_t(q % kSlots)) * floats; }
 
@@ -370,18 +378,16 @@ struct HostTransport final : BusTransport {
     }
     static void Produce(void *p)
     {   // rank > 0: this update's block (already in pinned memory) into the ring
-        Job *j = static_cast<Job*>(p);
-        HostTransport *t = j->t;
-        const uint64_t q = j->seq;
+        HostTransport *t = static_cast<HostTransport*>(p);
+        const uint64_t q = t->executed++;
         if(!WaitFor([&] { return q < t->hdr->consumed.load(std::memory_order_acquire) + kSlots; }, t->hdr->failed)) return;
         std::memcpy(t->slot(t->rank, q), t->pinned[q % kSlots], t->floats * sizeof(float));
         t->hdr->produced[t->rank].store(q + 1, std::memory_order_release);
     }
     static void Gather(void *p)
     {   // rank 0: the other ranks' blocks of this update, summed in rank order
-        Job *j = static_cast<Job*>(p);
-        HostTransport *t = j->t;
-        const uint64_t q = j->seq;
+        HostTransport *t = static_cast<HostTransport*>(p);
+        const uint64_t q = t->executed++;
         float *dst = t->pinned[q % kSlots];
         for(int r = 1; r < t->world; ++r)
         {
@@ -396,16 +402,17 @@ struct HostTransport final : BusTransport {
     int reduceToRoot(oalgpu_context *c, hipStream_t s) override
     {
         if(hdr->failed.load()) return Fail(OALGPU_ERR_HIP, "host transport: a rank timed out waiting for its peers");
-        const uint64_t q = seq++;
-        jobs[q % kSlots] = Job{this, q};
+        // (the pinned slot of update q is next written by the copy of update q + kSlots, which the stream runs behind
+        // Produce / the H2D copy of update q: stream order alone keeps the staging slots apart)
+        const uint64_t q = submitted++;
         if(rank != 0)
         {
             HIP_TRY(hipMemcpyAsync(pinned[q % kSlots], c->L.bus, bytes, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipLaunchHostFunc(s, Produce, &jobs[q % kSlots]));
+            HIP_TRY(hipLaunchHostFunc(s, Produce, this));
             return OALGPU_OK;
         }
         if(world == 1) return OALGPU_OK;
-        HIP_TRY(hipLaunchHostFunc(s, Gather, &jobs[q % kSlots]));
+        HIP_TRY(hipLaunchHostFunc(s, Gather, this));
         HIP_TRY(hipMemcpyAsync(devSum.p, pinned[q % kSlots], bytes, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(AddBusKernel, dim3(uint32_t((floats + 255) / 256)), dim3(256), 0, s, c->L.bus, devSum.p, uint32_t(floats));
         HIP_TRY(hipGetLastError());
@@ -484,41 +491,77 @@ int oalgpu_comm_init_host(oalgpu_context *c, const char *name, int rank, int wor
     t->name = name; t->rank = rank; t->world = world;
     t->floats = BusFloats(c->L); t->bytes = t->floats * sizeof(float);
     const size_t total = sizeof(HostTransport::Header) + size_t(world) * HostTransport::kSlots * t->bytes;
+    using clk = std::chrono::steady_clock;
+    const auto deadline = clk::now() + std::chrono::seconds(60);
+    // everything that can fail on this side comes first: a rank never announces itself and then falls over an allocation
+    for(float *&p : t->pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p), t->bytes, hipHostMallocDefault));
     if(rank == 0)
     {
+        HIP_TRY(t->devSum.alloc(t->floats));
         shm_unlink(name);
         t->fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if(t->fd < 0 || ftruncate(t->fd, off_t(total)) != 0) return Fail(OALGPU_ERR_HIP, std::string("shm_open/ftruncate ") + name + " failed");
+        void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
+        if(m == MAP_FAILED) return Fail(OALGPU_ERR_HIP, "mmap of the shared segment failed");
+        t->hdr = static_cast<HostTransport::Header*>(m);
+        t->ring = reinterpret_cast<float*>(static_cast<char*>(m) + sizeof(HostTransport::Header));
+        // (a fresh segment is zero-filled: produced, consumed, failed, hello, ack start at 0)
+        t->hdr->world = uint32_t(world); t->hdr->floats = uint32_t(t->floats);
+        t->hdr->magic.store(0x0a16b05u, std::memory_order_release);
+        // The attach is a handshake, so that no rank can sit on a segment a crashed earlier run left under the same
+        // name (rank 0 only unlinks in its destructor): every other rank writes a token of its own into hello[r] and
+        // trusts the segment only once THIS rank 0 has echoed it into ack[r]; a stale segment never answers.
+        for(int r = 1; r < world; ++r)
+        {
+            uint64_t tok = 0;
+            while((tok = t->hdr->hello[r].load(std::memory_order_acquire)) == 0)
+            {
+                if(clk::now() > deadline) return Fail(OALGPU_ERR_HIP, "oalgpu_comm_init_host: a rank did not attach within 60 s");
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            t->hdr->ack[r].store(tok, std::memory_order_release);
+        }
     }
     else
     {
-        for(int tries = 0; tries < 3000 && t->fd < 0; ++tries)
+        const uint64_t token = ((uint64_t(getpid()) << 32) ^ uint64_t(clk::now().time_since_epoch().count()) ^ (uint64_t(rank) << 56)) | 1ull;
+        bool attached = false;
+        std::string why = "rank 0's segment did not appear";
+        while(!attached && clk::now() < deadline)
         {
             t->fd = shm_open(name, O_RDWR, 0600);
             struct stat st{};
             if(t->fd >= 0 && (fstat(t->fd, &st) != 0 || size_t(st.st_size) < total)) { close(t->fd); t->fd = -1; }
-            if(t->fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            if(t->fd < 0) { std::this_thread::sleep_for(std::chrono::milliseconds(10)); continue; }
+            void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
+            if(m == MAP_FAILED) return Fail(OALGPU_ERR_HIP, "mmap of the shared segment failed");
+            auto *hdr = static_cast<HostTransport::Header*>(m);
+            const auto patience = clk::now() + std::chrono::seconds(3);     // a live rank 0 answers within milliseconds
+            bool said = false;
+            while(clk::now() < patience && clk::now() < deadline)
+            {
+                if(hdr->magic.load(std::memory_order_acquire) == 0x0a16b05u)
+                {
+                    if(hdr->world != uint32_t(world) || hdr->floats != uint32_t(t->floats)) { why = "the ranks' contexts differ (world size or bus block)"; break; }
+                    if(!said) { hdr->hello[rank].store(token, std::memory_order_release); said = true; }
+                    if(hdr->ack[rank].load(std::memory_order_acquire) == token) { attached = true; break; }
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            if(attached)
+            {
+                t->hdr = hdr;
+                t->ring = reinterpret_cast<float*>(static_cast<char*>(m) + sizeof(HostTransport::Header));
+            }
+            else
+            {   // nobody answered: a segment left behind by an earlier run (rank 0 replaces it), or a mismatch
+                munmap(m, total); close(t->fd); t->fd = -1;
+                if(why.find("differ") != std::string::npos) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: " + why);
+                why = "no live rank 0 answered on the segment";
+            }
         }
-        if(t->fd < 0) return Fail(OALGPU_ERR_HIP, std::string("shm_open ") + name + ": rank 0's segment did not appear");
+        if(!attached) return Fail(OALGPU_ERR_HIP, std::string("shm_open ") + name + ": " + why);
     }
-    void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, t->fd, 0);
-    if(m == MAP_FAILED) return Fail(OALGPU_ERR_HIP, "mmap of the shared segment failed");
-    t->hdr = static_cast<HostTransport::Header*>(m);
-    t->ring = reinterpret_cast<float*>(static_cast<char*>(m) + sizeof(HostTransport::Header));
-    if(rank == 0)
-    {   // (a fresh segment is zero-filled: produced, consumed, failed start at 0)
-        t->hdr->world = uint32_t(world); t->hdr->floats = uint32_t(t->floats);
-        t->hdr->magic.store(0x0a16b05u, std::memory_order_release);
-        HIP_TRY(t->devSum.alloc(t->floats));
-    }
-    else
-    {
-        for(int tries = 0; tries < 3000 && t->hdr->magic.load(std::memory_order_acquire) != 0x0a16b05u; ++tries)
-            std::this_thread::sleep_for(std::chrono::milliseconds(10));
-        if(t->hdr->magic.load() != 0x0a16b05u || t->hdr->world != uint32_t(world) || t->hdr->floats != uint32_t(t->floats))
-            return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: the ranks' contexts differ (world size or bus block)");
-    }
-    for(float *&p : t->pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p), t->bytes, hipHostMallocDefault));
     c->comm = t.release(); c->commRank = rank; c->commWorld = world;
     c->carryAccum = rank == 0;
     return OALGPU_OK;
@@ -994,13 +1037,9 @@ void oalgpu_context_destroy(oalgpu_context *ctx)
     delete ctx;
 }
 
-int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
+// the parsed (or handed-over) store becomes the context's: host copy, HBM copy, voice filter arrays
+static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
 {
-    if(!c || !data) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(int rc = UseDevice(c->desc.device)) return rc;
-    HrtfData parsed;
-    const std::string err = ParseMhr(data, size, parsed);
-    if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
     // a data set at another rate than the device's is brought to the device's rate as GetLoadedHrtf does
     // (core/hrtf.cpp:539-606: every HRIR through the polyphase resampler, delays and IrSize rescaled)
     if(parsed.sampleRate != c->desc.sample_rate) ResampleHrtfData(parsed, c->desc.sample_rate);
@@ -1019,6 +1058,7 @@ int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
     d.fieldDistance = c->hFieldDist.p; d.fieldEvCount = c->hEvCount.p; d.elevAzCount = c->hAzCount.p;
     d.elevIrOffset = c->hIrOffset.p; d.coeffs = c->hCoeffs.p; d.delays = c->hDelays.p;
     c->hrtfLoaded = true;
+    ++c->hrtfGeneration;
 
     DeviceLayout &L = c->L;
     L.hrirs = c->hCoeffs.p;
@@ -1032,6 +1072,49 @@ int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
         if(!c->directSet) c->dIrSize = h.irSize;
     }
     return OALGPU_OK;
+}
+
+int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
+{
+    if(!c || !data) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    HrtfData parsed;
+    const std::string err = ParseMhr(data, size, parsed);
+    if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
+    return InstallHrtfData(c, std::move(parsed));
+}
+
+/* An HrtfStore already in memory (core/hrtf.h:22-59), as the device holds it in DeviceBase::mHrtf once
+ * GetLoadedHrtf (core/hrtf.cpp:471-620) has loaded -- and resampled -- a data set: the same arrays oalgpu_hrtf_raw
+ * hands out. */
+int oalgpu_hrtf_load_store(oalgpu_context *c, uint32_t sample_rate, uint32_t ir_size, const float *field_distance,
+    const uint8_t *field_evcount, uint32_t num_fields, const uint16_t *elev_azcount, const uint16_t *elev_iroffset,
+    uint32_t num_elevs, const float *coeffs, const uint8_t *delays, uint32_t num_irs)
+{
+    if(!c || !field_distance || !field_evcount || !elev_azcount || !elev_iroffset || !coeffs || !delays)
+        return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(sample_rate == 0 || ir_size < 8 || ir_size > kHrirLen || num_fields == 0 || num_elevs == 0 || num_irs == 0)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_hrtf_load_store: bad sizes");
+    uint32_t evs = 0;
+    for(uint32_t f = 0; f < num_fields; ++f)
+    {
+        if(field_evcount[f] < 2) return Fail(OALGPU_ERR_INVALID, "oalgpu_hrtf_load_store: a field needs at least two elevations");
+        evs += field_evcount[f];
+    }
+    if(evs != num_elevs) return Fail(OALGPU_ERR_INVALID, "oalgpu_hrtf_load_store: the fields' elevation counts do not add up to num_elevs");
+    for(uint32_t e = 0; e < num_elevs; ++e)
+        if(elev_azcount[e] == 0 || uint32_t(elev_iroffset[e]) + elev_azcount[e] > num_irs)
+            return Fail(OALGPU_ERR_INVALID, "oalgpu_hrtf_load_store: an elevation's HRIRs lie outside the store");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    HrtfData h;
+    h.sampleRate = sample_rate; h.irSize = ir_size;
+    h.fieldDistance.assign(field_distance, field_distance + num_fields);
+    h.fieldEvCount.assign(field_evcount, field_evcount + num_fields);
+    h.elevAzCount.assign(elev_azcount, elev_azcount + num_elevs);
+    h.elevIrOffset.assign(elev_iroffset, elev_iroffset + num_elevs);
+    h.coeffs.assign(coeffs, coeffs + size_t{num_irs} * kHrirLen * 2);
+    h.delays.assign(delays, delays + size_t{num_irs} * 2);
+    return InstallHrtfData(c, std::move(h));
 }
 
 int oalgpu_hrtf_info_get(oalgpu_context *c, oalgpu_hrtf_info *out)
@@ -1421,7 +1504,8 @@ static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oa
         }
         r.hrtfDir[0] = p.hrtf_ev; r.hrtfDir[1] = p.hrtf_az; r.hrtfDir[2] = p.hrtf_dist; r.hrtfDir[3] = p.hrtf_spread;
         r.hrtfGain = p.hrtf_gain;
-        if(c->L.hrtf && c->hrtfLoaded)
+        r.keepHrtf = (c->L.hrtf && p.hrtf_dist < 0.0f) ? 1u : 0u;       // OALGPU_HRTF_KEEP_TARGET
+        if(c->L.hrtf && c->hrtfLoaded && !r.keepHrtf)
         {   // the index half of HrtfStore::getCoeffs (core/hrtf.cpp:192-245) on the host's copy of the store
             const HrirBlend b = HrtfBlendFor(hostStore, p.hrtf_ev, p.hrtf_az, p.hrtf_dist, p.hrtf_spread);
             for(int k = 0; k < 4; ++k) { r.hrtfIdx[k] = b.idx[k]; r.hrtfW[k] = b.w[k]; }
@@ -1450,10 +1534,39 @@ int oalgpu_voice_set_params(oalgpu_context *c, const uint32_t *voices, const oal
     return OALGPU_OK;
 }
 
+/* Hrtf.Target of `count` voices as the reference's parameter stage left it in the Voice (HrtfFilter: Coeffs, Delay, Gain,
+ * core/mixer/hrtfdefs.h:36-40, written by CalcHrtfPanning, alc/alu.cpp:1214-1216 / :1256-1258 / :1296-1298). */
+int oalgpu_voice_set_hrtf_targets(oalgpu_context *c, const uint32_t *voices, const float *coeffs, const uint32_t *delays,
+    const float *gains, size_t count)
+{
+    if(!c || !voices || !coeffs || !delays || !gains) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(count == 0) return OALGPU_OK;
+    if(!c->L.hrtf) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_hrtf_targets: HRTF contexts only");
+    if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    std::vector<TargetRecord> recs(count);
+    for(size_t i = 0; i < count; ++i)
+    {
+        if(voices[i] >= c->L.numVoices || delays[2 * i] > 63u || delays[2 * i + 1] > 63u)
+            return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_hrtf_targets: bad voice index or delay (MaxHrirDelay = 63)");
+        recs[i] = TargetRecord{voices[i], {delays[2 * i], delays[2 * i + 1]}, gains[i]};
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));           // (the staging buffers of the previous call may still be read)
+    if(c->tgtRecs.n < count) { HIP_TRY(c->tgtRecs.alloc(count)); HIP_TRY(c->tgtCoeffs.alloc(count * kHrirLen * 2)); }
+    HIP_TRY(hipMemcpyAsync(c->tgtRecs.p, recs.data(), count * sizeof(TargetRecord), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tgtCoeffs.p, coeffs, count * kHrirLen * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    LaunchApplyTargets(c->stream, c->L, c->tgtRecs.p, c->tgtCoeffs.p, uint32_t(count));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));           // the caller's arrays and `recs` are free again
+    return OALGPU_OK;
+}
+
 struct oalgpu_param_block {
     DevBuf<ParamRecord> recs;
     uint32_t count{0};
     int device{0};
+    uint32_t hrtfGeneration{0};                             // of the store the records' HRIR indices and weights were taken from
     std::vector<std::pair<uint32_t, uint32_t>> cbSteps;     // (voice, mStep) of the callback voices in the block
 };
 
@@ -1462,12 +1575,15 @@ int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const o
 {
     if(!c || !voices || !params || !out || count == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_param_block_create: bad arguments");
     *out = nullptr;
+    // the records carry the index half of getCoeffs, evaluated now against the loaded store
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "oalgpu_param_block_create: HRTF context without a data set");
     if(int rc = UseDevice(c->desc.device)) return rc;
     std::vector<ParamRecord> recs;
     if(int rc = BuildParamRecords(c, voices, params, count, recs)) return rc;
     auto b = std::make_unique<oalgpu_param_block>();
     b->count = uint32_t(count);
     b->device = c->desc.device;
+    b->hrtfGeneration = c->hrtfGeneration;
     HIP_TRY(b->recs.alloc(count));
     HIP_TRY(b->recs.upload(recs.data(), count));
     for(size_t i = 0; i < count; ++i)
@@ -1480,6 +1596,8 @@ int oalgpu_param_block_apply(oalgpu_context *c, oalgpu_param_block *b)
 {
     if(!c || !b) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(c->L.hrtf && b->hrtfGeneration != c->hrtfGeneration)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_param_block_apply: the block was built against another HRTF data set (its HRIR indices are that store's); create it again");
     if(int rc = UseDevice(c->desc.device)) return rc;
     if(int rc = FlushInits(c)) return rc;
     LaunchApplyParams(c->stream, c->L, b->recs.p, b->count);
@@ -2252,6 +2370,31 @@ int oalgpu_voice_readback(oalgpu_context *c, uint32_t v, oalgpu_voice_state *out
             std::memcpy(&out->send_hp[s], &slots[s * 2 + 1].f, sizeof(oalgpu_biquad));
             std::memcpy(out->send_current[s], cur.data() + size_t{s} * L.wetChannels, L.wetChannels * sizeof(float));
         }
+    }
+    return OALGPU_OK;
+}
+
+int oalgpu_voices_readback(oalgpu_context *c, const uint32_t *voices, size_t count, oalgpu_voice_brief *out)
+{
+    if(!c || !voices || !out) return Fail(OALGPU_ERR_INVALID, "oalgpu_voices_readback: null argument");
+    if(count == 0) return OALGPU_OK;
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    // one copy of the control lines the voices span (128 bytes each), not one round trip per voice
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for(size_t i = 0; i < count; ++i)
+    {
+        if(voices[i] >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voices_readback: bad voice index");
+        lo = std::min(lo, voices[i]); hi = std::max(hi, voices[i]);
+    }
+    c->ctlHost.resize(size_t{hi - lo} + 1u);
+    HIP_TRY(hipMemcpy(c->ctlHost.data(), c->L.ctl + lo, c->ctlHost.size() * sizeof(VoiceCtl), hipMemcpyDeviceToHost));
+    for(size_t i = 0; i < count; ++i)
+    {
+        const VoiceCtl &ctl = c->ctlHost[voices[i] - lo];
+        out[i] = oalgpu_voice_brief{ctl.playState, ctl.position, ctl.positionFrac, ctl.curBuffer >= 0 ? 1 : 0,
+            (ctl.flags & kFlagFading) ? 1 : 0};
     }
     return OALGPU_OK;
 }

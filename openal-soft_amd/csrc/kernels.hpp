@@ -100,7 +100,7 @@ struct ParamRecord {
     float hrtfW[4];
     float hrtfPass;
     uint32_t hrtfDelay[2];
-    uint32_t pad;
+    uint32_t keepHrtf;              // the HRTF target stays as it is (handed over by oalgpu_voice_set_hrtf_targets)
 };
 
 // What is left of a ParamRecord when only a voice's DIRECTION moved (the common case of an update: CalcPanningAndFilters,
@@ -195,11 +195,12 @@ __device__ __forceinline__ void ApplyRecordWave(const DeviceLayout &L, const Par
         ctl.step = r.step;
         ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
         ctl.rsFilterOffset = r.rsFilterOffset;
-        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue);
+        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue
+            | (r.keepHrtf ? uint32_t(kFlagHrtfDirty) : 0u));
         ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue))
-            | (L.hrtf ? (kFlagHasHrtf | kFlagHrtfDirty) : 0u);
+            | (L.hrtf ? (kFlagHasHrtf | (r.keepHrtf ? 0u : uint32_t(kFlagHrtfDirty))) : 0u);
         for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = (uint32_t(i) < L.numSends) ? r.sendSlot[i] : -1;
-        if(L.hrtf)
+        if(L.hrtf && !r.keepHrtf)
         {
             ctl.hrtfTgtDelay[0] = r.hrtfDelay[0]; ctl.hrtfTgtDelay[1] = r.hrtfDelay[1];
             ctl.hrtfTgtGain = r.hrtfGain;
@@ -212,7 +213,7 @@ __device__ __forceinline__ void ApplyRecordWave(const DeviceLayout &L, const Par
         const uint32_t i = (lane - 8) >> 1, hp = (lane - 8) & 1u;
         BiquadSetTarget(L.sfilt[(size_t{v} * L.numSends + i) * 2 + hp].f, hp ? r.sendHp[i] : r.sendLp[i]);
     }
-    if(L.hrtf) ApplyHrtfTargetWave(L, v, r.hrtfIdx, r.hrtfW, r.hrtfPass, lane);
+    if(L.hrtf) { if(!r.keepHrtf) ApplyHrtfTargetWave(L, v, r.hrtfIdx, r.hrtfW, r.hrtfPass, lane); }
     else if(lane < L.numDry)
         L.gainTgt[size_t{v} * L.numDry + lane] = r.dryGains[lane];
     for(uint32_t k = lane; k < L.numSends * L.wetChannels; k += 64)
@@ -342,6 +343,9 @@ void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
 void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);
 void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count);
 void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count, hipEvent_t evDone = nullptr);
+// Hrtf.Target handed over as the reference's parameter stage left it: coeffs = [count][128][2] (HrirArray)
+struct TargetRecord { uint32_t voice; uint32_t delay[2]; float gain; };
+void LaunchApplyTargets(hipStream_t s, const DeviceLayout &L, const TargetRecord *recs, const float *coeffs, uint32_t count);
 // returns hipSuccess or the launch error
 hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum);
 // besideVoiceKernel: the post-stream shape (4-wave workgroups of <= 32 VGPRs that fit on a CU next to

@@ -181,6 +181,33 @@ void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *re
     if(count) hipExtLaunchKernelGGL(ApplyMovesKernel, dim3(count), dim3(64), 0, s, nullptr, evDone, 0u, L, recs);
 }
 
+// A voice's HRTF target as the reference's own parameter stage computed it (Hrtf.Target after CalcHrtfPanning,
+// alc/alu.cpp:1214-1216 / :1256-1258 / :1296-1298): coefficients copied, not blended here; the filter is marked as replaced.
+__global__ void __launch_bounds__(64) ApplyTargetsKernel(DeviceLayout L, const TargetRecord *__restrict__ recs,
+    const float *__restrict__ coeffs)
+{
+    const TargetRecord &r = recs[blockIdx.x];
+    const uint32_t v = r.voice, lane = threadIdx.x;
+    if(lane == 0)
+    {
+        VoiceCtl &ctl = L.ctl[v];
+        ctl.flags |= kFlagHasHrtf | kFlagHrtfDirty;
+        ctl.hrtfTgtDelay[0] = r.delay[0]; ctl.hrtfTgtDelay[1] = r.delay[1];
+        ctl.hrtfTgtGain = r.gain;
+    }
+    // (the mixers apply IrSize taps rounded up to even, mixer_sse.cpp:46-51: what lies beyond must not reach the
+    // fixed-length FIRs -- see ApplyHrtfTargetWave)
+    const uint32_t live = ((L.irSize + 1u) & ~1u) * 2u;
+    const float *src = coeffs + size_t{blockIdx.x} * (kHrirLen * 2);
+    for(uint32_t e = lane; e < L.irStride * 2; e += 64)
+        L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = (e < live) ? src[e] : 0.0f;
+}
+
+void LaunchApplyTargets(hipStream_t s, const DeviceLayout &L, const TargetRecord *recs, const float *coeffs, uint32_t count)
+{
+    if(count) hipLaunchKernelGGL(ApplyTargetsKernel, dim3(count), dim3(64), 0, s, L, recs, coeffs);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Voice kernel
 // ---------------------------------------------------------------------------------------------

@@ -670,9 +670,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                             }
                     }
                     if(N < uint32_t(kLine))
-                    {   // (a short block: frames from N on are silence)
-                        if(i >= N) g.x = 0.0f;
-                        if(i + 1u >= N) g.y = 0.0f;
+                    {   // (a short block: frames from N on are silence.  Selected, not multiplied away: w.in beyond N is
+                        // whatever an earlier voice left there, and 0 * Inf or 0 * NaN would reach the ring-out frames)
+                        if(i >= N) { g.x = 0.0f; xl[j].x = 0.0f; xr[j].x = 0.0f; }
+                        if(i + 1u >= N) { g.y = 0.0f; xl[j].y = 0.0f; xr[j].y = 0.0f; }
                     }
                     const f2 a = xl[j] * g, b = xr[j] * g;
                     xl[j] = a; xr[j] = b;
@@ -1138,6 +1139,13 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
         if(L.firMfma) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof);
         else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof);
     }
+    else if(prof && !L.hrtf)
+    {
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true, false, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
+    }
+    else if(prof && sends && L.irStride <= 64 && L.firMfma)
+        hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
     else if(!L.hrtf)
     {
         if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);

@@ -23,8 +23,12 @@
  *                    filled from the Voice AFTER the reference's CalcVoiceParams computed mStep, the pan
  *                    gains and the filter targets), mixed by ONE oalgpu_mix_update, and the dry lines are
  *                    added into DeviceBase::MixBuffer; the reference carries on with its post-process.
- * The scene is BASELINE configs[0]: mono sources, linear resampler, a stereo device (3 first-order 2D
- * ambisonic dry lines decoded to 2 speakers by the reference's BFormatDec with panning.cpp's StereoConfig).
+ * Two devices: BASELINE configs[0] -- mono sources, linear resampler, a stereo device (3 first-order 2D ambisonic
+ * dry lines decoded to 2 speakers by the reference's BFormatDec with panning.cpp's StereoConfig) -- and BASELINE
+ * configs[2]'s: a RenderMode::Hrtf device set up the way aluInitRenderer / InitHrtfPanning do (alc/panning.cpp:
+ * 1327-1354, :847-1138: GetLoadedHrtf, first-order full-HRTF rendering, DirectHrtfState::build with the cube layout,
+ * 700 Hz crossover, HrtfPostProcess), with auxiliary sends into effect slots that carry the reference's own
+ * ReverbState (alc/effects/reverb.cpp, reached through its factory).
  */
 #include "config.h"
 #include "config_simd.h"
@@ -71,6 +75,9 @@
 #include "core/async_event.h"
 #include "ringbuffer.h"
 #include "alc/alu.h"
+#include "alc/effects/base.h"
+#include "core/effects/base.h"
+#include "oalref.h"                        /* oal_reverb_props: the C view of ReverbProps the tests fill */
 
 #include "../include/oalgpu.h"
 #include "../include/oalgpu_openal.hpp"    /* THE PRODUCT'S host adapter: this file only drives it */
@@ -88,7 +95,8 @@ enum Mode { ModeCpu = 0, ModeAdapters = 1, ModeBatch = 2 };
 struct Dev final : DeviceBase { Dev() : DeviceBase{DeviceType::Loopback} { } };
 struct Ctx final : ContextBase { explicit Ctx(DeviceBase *d) : ContextBase{d} { } };
 struct Item final : VoiceBufferItem { };
-struct BufferData { std::vector<float> samples; Item item; };
+struct BufferData { std::vector<float> samples; std::vector<int16_t> samples16; Item item; };
+struct SlotData { EffectSlotBase slot; };
 
 bool gInit = false;
 void EnsureInit()
@@ -108,7 +116,9 @@ struct oalbridge {
     std::unique_ptr<Dev> dev;
     std::unique_ptr<Ctx> ctx;
     std::deque<BufferData> buffers;
+    std::deque<SlotData> slots;             /* the context's effect slots (al/auxeffectslot.cpp's ALeffectslot, core part) */
     std::vector<Voice*> sources;            /* the context's voices, in creation order */
+    unsigned nextSourceId{100000u};         /* ids of restarted sources (oalbridge_restart_source) */
     /* ---- the GPU side: include/oalgpu_openal.hpp's batched voice loop */
     std::unique_ptr<oalgpu_openal::BatchMixer> batch;
     int error{0};
@@ -165,8 +175,20 @@ void Voice::mix(State const vstate, ContextBase *const context, std::chrono::nan
 
 extern "C" {
 
-/* mode: 0 CPU, 1 ADAPTERS, 2 BATCH; math_mode: oalgpu_math_mode of the GPU side */
-oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
+/* the cube of virtual speakers InitHrtfPanning decodes first-order ambisonics with, its decoder matrix and
+ * per-order HF gains (alc/panning.cpp:861-870, :941-950, :1021-1023: function-local tables there) */
+static constexpr float kDeg35 = 6.154797087e-01f, kDeg45 = std::numbers::pi_v<float> / 4.0f, kDeg135 = kDeg45 * 3.0f;
+static constexpr std::array kAmbiPoints1O{
+    AngularPoint{EvRadians{ kDeg35}, AzRadians{-kDeg45}}, AngularPoint{EvRadians{ kDeg35}, AzRadians{-kDeg135}},
+    AngularPoint{EvRadians{ kDeg35}, AzRadians{ kDeg45}}, AngularPoint{EvRadians{ kDeg35}, AzRadians{ kDeg135}},
+    AngularPoint{EvRadians{-kDeg35}, AzRadians{-kDeg45}}, AngularPoint{EvRadians{-kDeg35}, AzRadians{-kDeg135}},
+    AngularPoint{EvRadians{-kDeg35}, AzRadians{ kDeg45}}, AngularPoint{EvRadians{-kDeg35}, AzRadians{ kDeg135}},
+};
+static constexpr std::array<float, MaxAmbiOrder+1> kAmbiOrderHFGain1O{2.000000000e+00f, 1.154700538e+00f};
+
+/* mode: 0 CPU, 1 ADAPTERS, 2 BATCH; math_mode: oalgpu_math_mode of the GPU side; hrtf: a RenderMode::Hrtf device on the
+ * first .mhr under mhr_dir (else the stereo device); num_sends: DeviceBase::NumAuxSends */
+oalbridge *oalbridge_create_ex(int mode, uint32_t sample_rate, int math_mode, int hrtf, const char *mhr_dir, uint32_t num_sends)
 {
     EnsureInit();
     auto b = std::make_unique<oalbridge>();
@@ -175,30 +197,31 @@ oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
     b->batch = std::make_unique<oalgpu_openal::BatchMixer>(math_mode, 0);
     b->dev = std::make_unique<Dev>();
     auto &dev = *b->dev;
-    /* a stereo loopback device as alc/alc.cpp + alc/panning.cpp set it up (InitPanning with
-     * StereoConfig, panning.cpp:548-556, :719-850): 3 first-order 2D ambisonic dry lines (W, Y, X)
-     * decoded by a single-band BFormatDec to FrontLeft / FrontRight */
     dev.mSampleRate = sample_rate;
     dev.mUpdateSize = BufferLineSize;
     dev.mBufferSize = BufferLineSize;
     dev.FmtChans = DevFmtStereo;
     dev.FmtType = DevFmtFloat;
-    dev.NumAuxSends = 0;
-    dev.mAmbiOrder = 1;
-    dev.m2DMixing = true;
-    dev.mRenderMode = RenderMode::Normal;
+    dev.NumAuxSends = num_sends;
     dev.AvgSpeakerDist = 0.0f;
-    dev.mXOverFreq = 400.0f;
-    constexpr size_t ambicount = 3, realcount = 2;
-    dev.MixBuffer.resize(ambicount + realcount);
-    dev.Dry.Buffer = std::span{dev.MixBuffer}.first(ambicount);
-    dev.RealOut.Buffer = std::span{dev.MixBuffer}.subspan(ambicount);
-    for(size_t i{0}; i < ambicount; ++i)
-        dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, AmbiIndex::FromACN2D[i].c_val};
-    dev.RealOut.ChannelIndex[FrontLeft] = 0_u8;
-    dev.RealOut.ChannelIndex[FrontRight] = 1_u8;
-    dev.NumChannelsPerOrder = {1u, 2u, 0u, 0u, 0u};
+    if(!hrtf)
     {
+        /* a stereo loopback device as alc/alc.cpp + alc/panning.cpp set it up (InitPanning with
+         * StereoConfig, panning.cpp:548-556, :719-850): 3 first-order 2D ambisonic dry lines (W, Y, X)
+         * decoded by a single-band BFormatDec to FrontLeft / FrontRight */
+        dev.mAmbiOrder = 1;
+        dev.m2DMixing = true;
+        dev.mRenderMode = RenderMode::Normal;
+        dev.mXOverFreq = 400.0f;
+        constexpr size_t ambicount = 3, realcount = 2;
+        dev.MixBuffer.resize(ambicount + realcount);
+        dev.Dry.Buffer = std::span{dev.MixBuffer}.first(ambicount);
+        dev.RealOut.Buffer = std::span{dev.MixBuffer}.subspan(ambicount);
+        for(size_t i{0}; i < ambicount; ++i)
+            dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, AmbiIndex::FromACN2D[i].c_val};
+        dev.RealOut.ChannelIndex[FrontLeft] = 0_u8;
+        dev.RealOut.ChannelIndex[FrontRight] = 1_u8;
+        dev.NumChannelsPerOrder = {1u, 2u, 0u, 0u, 0u};
         auto coeffs = std::vector<ChannelDec>(2);
         coeffs[0] = ChannelDec{}; coeffs[1] = ChannelDec{};
         coeffs[0][0] = 5.00000000e-1f; coeffs[0][1] =  2.88675135e-1f; coeffs[0][2] = 5.52305643e-2f;
@@ -206,6 +229,47 @@ oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
         auto dec = std::make_unique<BFormatDec>(ambicount, coeffs, std::span<const ChannelDec>{},
             dev.mXOverFreq / float(sample_rate));
         dev.mPostProcess.emplace<AmbiDecPostProcess>(AmbiDecPostProcess{std::move(dec)});
+    }
+    else
+    {
+        /* aluInitRenderer's HRTF branch (alc/panning.cpp:1327-1354): the data set through GetLoadedHrtf (found the way the
+         * reference finds one: EnumerateHrtf over ALSOFT_LOCAL_PATH), mIrSize, then InitHrtfPanning (:847-1138) for the
+         * default "full" mode -- first order, RenderMode::Hrtf, 700 Hz crossover, ACN dry lines, stereo real output,
+         * DirectHrtfState::build on the cube -- and the HrtfPostProcess */
+        if(!mhr_dir) return nullptr;
+        setenv("ALSOFT_LOCAL_PATH", mhr_dir, 1);
+        try {
+            auto const names = EnumerateHrtf(std::nullopt);
+            if(names.empty()) return nullptr;
+            dev.mHrtf = GetLoadedHrtf(names[0], sample_rate);
+        }
+        catch(...) { return nullptr; }
+        if(!dev.mHrtf) return nullptr;
+        dev.mIrSize = dev.mHrtf->mIrSize;
+        dev.mXOverFreq = 700.0f;
+        dev.mRenderMode = RenderMode::Hrtf;
+        dev.mAmbiOrder = 1;
+        dev.m2DMixing = false;
+        constexpr size_t count = 4, realcount = 2;              /* AmbiChannelsFromOrder(1); channelsFromFmt() of DevFmtStereo */
+        for(size_t i{0}; i < count; ++i)
+            dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, AmbiIndex::FromACN[i].c_val};
+        dev.MixBuffer.resize(count + realcount);                /* AllocChannels, panning.cpp:174-195 */
+        dev.Dry.Buffer = std::span{dev.MixBuffer}.first(count);
+        dev.RealOut.Buffer = std::span{dev.MixBuffer}.subspan(count);
+        dev.RealOut.ChannelIndex[FrontLeft] = 0_u8;
+        dev.RealOut.ChannelIndex[FrontRight] = 1_u8;
+        auto matrix = std::vector<std::array<float, MaxAmbiChannels>>(8);
+        for(size_t i{0}; i < 8; ++i)
+        {   /* AmbiMatrix1O: +-1/8 by the sign of the point's y (left), z (up), x (front) -- ACN W, Y, Z, X */
+            matrix[i].fill(0.0f);
+            matrix[i][0] = 0.125f;
+            matrix[i][1] = (i & 2) ? -0.125f : 0.125f;
+            matrix[i][2] = (i & 4) ? -0.125f : 0.125f;
+            matrix[i][3] = (i & 1) ? -0.125f : 0.125f;
+        }
+        auto hrtfstate = DirectHrtfState::Create(count);
+        hrtfstate->build(dev.mHrtf.get(), dev.mIrSize, false, kAmbiPoints1O, matrix, dev.mXOverFreq, kAmbiOrderHFGain1O);
+        dev.mPostProcess.emplace<HrtfPostProcess>(HrtfPostProcess{std::move(hrtfstate)});
     }
 
     /* the context, registered with the device as alc/context.cpp:219-273 does */
@@ -237,6 +301,55 @@ oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
     return b.release();
 }
 
+oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
+{ return oalbridge_create_ex(mode, sample_rate, math_mode, 0, nullptr, 0); }
+
+/* An effect slot of the context carrying the reference's own EAX reverb: what alGenAuxiliaryEffectSlots + alAuxiliaryEffectSloti
+ * (al/auxeffectslot.cpp) leave in the core part -- a first-order wet bus, the ReverbState from its factory after
+ * deviceUpdate and update -- registered in ContextBase::mActiveAuxSlots (first half: the slots, second half: the
+ * sorted copy ProcessContexts fills, alu.cpp:2186-2188).  Returns the slot's index. */
+int oalbridge_add_reverb_slot(oalbridge *b, const oal_reverb_props *p, float gain)
+{
+    auto &sd = b->slots.emplace_back();
+    auto &slot = sd.slot;
+    auto &dev = *b->dev;
+    slot.InUse = true;
+    slot.mWetBuffer.resize(4);
+    slot.Wet.Buffer = slot.mWetBuffer;
+    for(uint32_t i{0}; i < 4; ++i) slot.Wet.AmbiMap[i] = BFChannelConfig{1.0f, AmbiIndex::FromACN[i].c_val};
+    auto rp = ReverbProps{};
+    rp.Density = p->density; rp.Diffusion = p->diffusion; rp.Gain = p->gain; rp.GainHF = p->gain_hf;
+    rp.GainLF = p->gain_lf; rp.DecayTime = p->decay_time; rp.DecayHFRatio = p->decay_hf_ratio;
+    rp.DecayLFRatio = p->decay_lf_ratio; rp.ReflectionsGain = p->reflections_gain;
+    rp.ReflectionsDelay = p->reflections_delay;
+    rp.ReflectionsPan = {p->reflections_pan[0], p->reflections_pan[1], p->reflections_pan[2]};
+    rp.LateReverbGain = p->late_reverb_gain; rp.LateReverbDelay = p->late_reverb_delay;
+    rp.LateReverbPan = {p->late_reverb_pan[0], p->late_reverb_pan[1], p->late_reverb_pan[2]};
+    rp.EchoTime = p->echo_time; rp.EchoDepth = p->echo_depth; rp.ModulationTime = p->modulation_time;
+    rp.ModulationDepth = p->modulation_depth; rp.AirAbsorptionGainHF = p->air_absorption_gain_hf;
+    rp.HFReference = p->hf_reference; rp.LFReference = p->lf_reference;
+    rp.RoomRolloffFactor = p->room_rolloff_factor; rp.DecayHFLimit = p->decay_hf_limit != 0;
+    /* CalcEffectSlotParams (alu.cpp:565-640) */
+    slot.Gain = gain;
+    slot.AuxSendAuto = true;
+    slot.Target = nullptr;
+    slot.EffectType = EffectSlotType::Reverb;
+    slot.mEffectProps = rp;
+    slot.RoomRolloff = rp.RoomRolloffFactor;
+    slot.AirAbsorptionGainHF = rp.AirAbsorptionGainHF;
+    slot.DecayTime = rp.DecayTime; slot.DecayLFRatio = rp.DecayLFRatio; slot.DecayHFRatio = rp.DecayHFRatio;
+    slot.DecayHFLimit = rp.DecayHFLimit;
+    slot.mEffectState = ReverbStateFactory_getFactory()->create();
+    slot.mEffectState->deviceUpdate(&dev, nullptr);
+    slot.mEffectState->update(b->ctx.get(), &slot, &slot.mEffectProps, EffectTarget{&dev.Dry, &dev.RealOut});
+    /* the active-slot array, twice the slots long */
+    const size_t n = b->slots.size();
+    auto arr = ContextBase::EffectSlotArray::Create(n * 2);
+    for(size_t i{0}; i < n; ++i) { (*arr)[i] = &b->slots[i].slot; (*arr)[n + i] = nullptr; }
+    b->ctx->mActiveAuxSlots.store(std::move(arr), std::memory_order_release);
+    return int(n - 1);
+}
+
 void oalbridge_destroy(oalbridge *b)
 {
     if(!b) return;
@@ -258,6 +371,20 @@ int oalbridge_add_buffer(oalbridge *b, const float *data, uint32_t frames, uint3
     return int(b->buffers.size() - 1);
 }
 
+/* the same with 16-bit samples (FmtShort: SampleInfo<i16>::to_float = s / 32768, core/fmt_traits.h) */
+int oalbridge_add_buffer_i16(oalbridge *b, const int16_t *data, uint32_t frames, uint32_t loop_start, uint32_t loop_end)
+{
+    auto &buf = b->buffers.emplace_back();
+    buf.samples16.assign(data, data + frames);
+    buf.samples16.resize(frames + 8);
+    buf.item.mSamples = std::span<i16>{reinterpret_cast<i16*>(buf.samples16.data()), frames};
+    buf.item.mBlockAlign = 1;
+    buf.item.mSampleLen = frames;
+    buf.item.mLoopStart = loop_start;
+    buf.item.mLoopEnd = loop_end;
+    return int(b->buffers.size() - 1);
+}
+
 static VoicePropsItem *NewProps(oalbridge *b)
 {   /* al/source.cpp UpdateSourceProps: an item off the context's free list */
     auto &ctx = *b->ctx;
@@ -269,7 +396,8 @@ static VoicePropsItem *NewProps(oalbridge *b)
     return props;
 }
 
-static void FillProps(VoiceProps &p, float gain, float x, float y, float z, int resampler, float pitch, float gain_hf)
+static void FillProps(oalbridge *b, VoiceProps &p, float gain, float x, float y, float z, int resampler, float pitch, float gain_hf,
+    int send_slot = -1, float send_gain = 1.0f, float send_gain_hf = 1.0f)
 {   /* the defaults of a new AL source (al/source.cpp: ALsource::ALsource) with the fields the test moves */
     p = VoiceProps{};
     p.Pitch = pitch; p.Gain = gain; p.OuterGain = 0.0f; p.MinGain = 0.0f; p.MaxGain = 1.0f;
@@ -289,11 +417,14 @@ static void FillProps(VoiceProps &p, float gain, float x, float y, float z, int 
     p.Radius = 0.0f; p.EnhWidth = 0.593f; p.Panning = 0.0f;
     p.Direct = {1.0f, gain_hf, 5000.0f, 1.0f, 250.0f};
     for(auto &s : p.Send) s = {nullptr, 1.0f, 1.0f, 5000.0f, 1.0f, 250.0f};
+    /* alSource3i(AL_AUXILIARY_SEND_FILTER): send 0 into the slot, with the send filter's gains */
+    if(send_slot >= 0 && size_t(send_slot) < b->slots.size())
+        p.Send[0] = {&b->slots[size_t(send_slot)].slot, send_gain, send_gain_hf, 5000.0f, 1.0f, 250.0f};
 }
 
 /* a playing mono source: a voice of the context with pending VoiceProps, as al/source.cpp leaves it */
-int oalbridge_add_source(oalbridge *b, int buffer, int looping, int position, float gain, float x, float y, float z,
-    int resampler, float pitch, float gain_hf)
+int oalbridge_add_source_ex(oalbridge *b, int buffer, int looping, int position, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf, int send_slot, float send_gain, float send_gain_hf)
 {
     auto &ctx = *b->ctx;
     auto &buf = b->buffers.at(size_t(buffer));
@@ -305,7 +436,7 @@ int oalbridge_add_source(oalbridge *b, int buffer, int looping, int position, fl
     v->mFmtChannels = FmtMono;
     v->mFrequency = 44100;
     v->mFrameStep = 1;
-    v->mBytesPerBlock = 4;
+    v->mBytesPerBlock = std::holds_alternative<std::span<i16>>(buf.item.mSamples) ? 2u : 4u;
     v->mSamplesPerBlock = 1;
     v->mAmbiOrder = 0;
     v->mFlags.reset();
@@ -319,7 +450,7 @@ int oalbridge_add_source(oalbridge *b, int buffer, int looping, int position, fl
     v->mStartTime = {};
     v->mSourceID.store(unsigned(n + 1), std::memory_order_relaxed);
     auto *props = NewProps(b);
-    FillProps(*props, gain, x, y, z, resampler, pitch, gain_hf);
+    FillProps(b, *props, gain, x, y, z, resampler, pitch, gain_hf, send_slot, send_gain, send_gain_hf);
     v->mUpdate.store(props, std::memory_order_release);
     v->mPlayState.store(Voice::Playing, std::memory_order_release);
     ctx.mActiveVoiceCount.store(n + 1, std::memory_order_release);
@@ -327,17 +458,54 @@ int oalbridge_add_source(oalbridge *b, int buffer, int looping, int position, fl
     return int(n);
 }
 
+/* The pooled Voice object of a source that has stopped starts over as ANOTHER source (what alSourcePlay does with a
+ * free voice of the context's clusters, al/source.cpp:3046-3121): InitVoice again, a new source id, fresh properties. */
+int oalbridge_restart_source(oalbridge *b, int source, int buffer, int looping, int position, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf, int send_slot, float send_gain, float send_gain_hf)
+{
+    Voice *v = b->sources.at(size_t(source));
+    if(v->mPlayState.load(std::memory_order_acquire) != Voice::Stopped) return -1;
+    auto &buf = b->buffers.at(size_t(buffer));
+    v->mLoopBuffer.store(looping ? &buf.item : nullptr, std::memory_order_relaxed);
+    v->mBytesPerBlock = std::holds_alternative<std::span<i16>>(buf.item.mSamples) ? 2u : 4u;
+    v->mFlags.reset();
+    v->mFlags.set(VoiceFlag::IsStatic);
+    v->prepare(b->dev.get());
+    v->mPosition.store(position, std::memory_order_relaxed);
+    v->mPositionFrac.store(0u, std::memory_order_relaxed);
+    v->mCurrentBuffer.store(&buf.item, std::memory_order_relaxed);
+    v->mStartTime = {};
+    v->mSourceID.store(++b->nextSourceId, std::memory_order_relaxed);
+    auto *props = NewProps(b);
+    FillProps(b, *props, gain, x, y, z, resampler, pitch, gain_hf, send_slot, send_gain, send_gain_hf);
+    if(auto *old = v->mUpdate.exchange(props, std::memory_order_acq_rel))
+        AtomicReplaceHead(b->ctx->mFreeVoiceProps, old);
+    v->mPlayState.store(Voice::Playing, std::memory_order_release);
+    return 0;
+}
+
+/* voices the batched mixer currently keeps a device-side slot for (stopped voices give theirs back) */
+int oalbridge_batch_live_voices(oalbridge *b) { return int(b->batch->liveVoices()); }
+
+int oalbridge_add_source(oalbridge *b, int buffer, int looping, int position, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf)
+{ return oalbridge_add_source_ex(b, buffer, looping, position, gain, x, y, z, resampler, pitch, gain_hf, -1, 1.0f, 1.0f); }
+
 /* new source properties for the next update (a moved source): CalcVoiceParams picks them up */
-int oalbridge_update_source(oalbridge *b, int source, float gain, float x, float y, float z, int resampler, float pitch,
-    float gain_hf)
+int oalbridge_update_source_ex(oalbridge *b, int source, float gain, float x, float y, float z, int resampler, float pitch,
+    float gain_hf, int send_slot, float send_gain, float send_gain_hf)
 {
     Voice *v = b->sources.at(size_t(source));
     auto *props = NewProps(b);
-    FillProps(*props, gain, x, y, z, resampler, pitch, gain_hf);
+    FillProps(b, *props, gain, x, y, z, resampler, pitch, gain_hf, send_slot, send_gain, send_gain_hf);
     if(auto *old = v->mUpdate.exchange(props, std::memory_order_acq_rel))
         AtomicReplaceHead(b->ctx->mFreeVoiceProps, old);
     return 0;
 }
+
+int oalbridge_update_source(oalbridge *b, int source, float gain, float x, float y, float z, int resampler, float pitch,
+    float gain_hf)
+{ return oalbridge_update_source_ex(b, source, gain, x, y, z, resampler, pitch, gain_hf, -1, 1.0f, 1.0f); }
 
 int oalbridge_stop_source(oalbridge *b, int source)
 {   /* what ProcessVoiceChanges does for VChangeState::Stop (alu.cpp:2081-2100) */
@@ -367,6 +535,23 @@ int oalbridge_source_state(oalbridge *b, int source, int32_t out[4])
     out[1] = v->mPosition.load(std::memory_order_relaxed);
     out[2] = int32_t(v->mPositionFrac.load(std::memory_order_relaxed));
     out[3] = int32_t(v->mStep);
+    return 0;
+}
+
+/* ... and what else Voice::mix leaves behind: whether a buffer is still attached, VoiceFlag::IsFading, HasHrtf */
+int oalbridge_source_flags(oalbridge *b, int source, int32_t out[3])
+{
+    Voice *v = b->sources.at(size_t(source));
+    out[0] = v->mCurrentBuffer.load(std::memory_order_relaxed) != nullptr;
+    out[1] = v->mFlags.test(VoiceFlag::IsFading);
+    out[2] = v->mFlags.test(VoiceFlag::HasHrtf);
+    return 0;
+}
+
+/* how many per-call adapter invocations ran (mode ADAPTERS): [resample, mix, mix_hrtf, mix_hrtf_blend] */
+int oalbridge_adapter_calls(uint64_t out[4])
+{
+    for(int i{0}; i < 4; ++i) out[i] = oalgpu_openal::Adapters().calls[i];
     return 0;
 }
 

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(ROOT, "oracle", "_ref", "liboalbridge.so")
 MODE_CPU, MODE_ADAPTERS, MODE_BATCH = 0, 1, 2
 RS_LINEAR = 1
+RS_BSINC24 = 7
+GOLDEN = os.path.join(ROOT, "tests", "golden")          # holds default_hrtf.mhr, the reference's own Default HRTF.mhr
 f32p = C.POINTER(C.c_float)
 
 
@@ -27,6 +29,19 @@ def lib():
         L = C.CDLL(PATH)
         L.oalbridge_create.restype = C.c_void_p
         L.oalbridge_create.argtypes = [C.c_int, C.c_uint32, C.c_int]
+        L.oalbridge_create_ex.restype = C.c_void_p
+        L.oalbridge_create_ex.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_uint32]
+        L.oalbridge_add_reverb_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        L.oalbridge_add_buffer_i16.argtypes = [C.c_void_p, C.POINTER(C.c_int16), C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oalbridge_add_source_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float,
+                                                                                                      C.c_int, C.c_float, C.c_float]
+        L.oalbridge_update_source_ex.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float,
+                                                                                         C.c_int, C.c_float, C.c_float]
+        L.oalbridge_restart_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_float] * 4 + [
+            C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
+        L.oalbridge_batch_live_voices.argtypes = [C.c_void_p]
+        L.oalbridge_source_flags.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+        L.oalbridge_adapter_calls.argtypes = [C.POINTER(C.c_uint64)]
         L.oalbridge_destroy.argtypes = [C.c_void_p]
         L.oalbridge_add_buffer.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.oalbridge_add_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float]
@@ -43,9 +58,41 @@ def lib():
 
 
 class Bridge:
-    def __init__(self, mode, math_mode=1, sample_rate=48000):
-        self.h = lib().oalbridge_create(mode, sample_rate, math_mode)
-        assert self.h
+    def __init__(self, mode, math_mode=1, sample_rate=48000, hrtf=False, num_sends=0, mhr_dir=GOLDEN):
+        """hrtf: a RenderMode::Hrtf device on the .mhr under mhr_dir (the reference's InitHrtfPanning set-up);
+        num_sends: DeviceBase::NumAuxSends."""
+        self.h = lib().oalbridge_create_ex(mode, sample_rate, math_mode, 1 if hrtf else 0, mhr_dir.encode(), num_sends)
+        assert self.h, "oalbridge_create_ex failed (no .mhr under mhr_dir?)"
+
+    def add_reverb_slot(self, props, gain=1.0):
+        """props: an oracle_lib.ReverbProps (the C view of ReverbProps); returns the slot index."""
+        return lib().oalbridge_add_reverb_slot(self.h, C.byref(props), gain)
+
+    def add_buffer_i16(self, data, loop_start=0, loop_end=None):
+        data = np.ascontiguousarray(data, np.int16)
+        return lib().oalbridge_add_buffer_i16(self.h, data.ctypes.data_as(C.POINTER(C.c_int16)), data.size, loop_start,
+                                              data.size if loop_end is None else loop_end)
+
+    def add_source_ex(self, buffer, looping, position, gain, pos, resampler, pitch, gain_hf, send_slot, send_gain, send_gain_hf):
+        return lib().oalbridge_add_source_ex(self.h, buffer, 1 if looping else 0, position, gain, *pos, resampler, pitch, gain_hf,
+                                             send_slot, send_gain, send_gain_hf)
+
+    def update_source_ex(self, source, gain, pos, resampler, pitch, gain_hf, send_slot, send_gain, send_gain_hf):
+        lib().oalbridge_update_source_ex(self.h, source, gain, *pos, resampler, pitch, gain_hf, send_slot, send_gain, send_gain_hf)
+
+    def restart_source(self, source, buffer, looping, position, gain, pos, resampler, pitch, gain_hf, send_slot, send_gain, send_gain_hf):
+        """The (Stopped) source's Voice object starts over as another source."""
+        rc = lib().oalbridge_restart_source(self.h, source, buffer, 1 if looping else 0, position, gain, *pos, resampler, pitch,
+                                            gain_hf, send_slot, send_gain, send_gain_hf)
+        assert rc == 0, "the source's voice is not Stopped"
+
+    def batch_live_voices(self):
+        return lib().oalbridge_batch_live_voices(self.h)
+
+    def source_flags(self, source):
+        st = (C.c_int32 * 3)()
+        lib().oalbridge_source_flags(self.h, source, st)
+        return tuple(st)
 
     def close(self):
         if self.h:
@@ -112,3 +159,45 @@ def move_some(b, srcs, k, seed=0x5EED0001, resampler=RS_LINEAR):
         dist = rng.uniform(1.0, 4.0)
         b.update_source(v, float(10 ** (rng.uniform(-40, -12) / 20)),
                         (float(np.sin(az) * dist), 0.0, float(-np.cos(az) * dist)), resampler=resampler)
+
+
+def adapter_calls():
+    """Invocations of the four per-call adapters so far (process-wide): resample, mix, mix_hrtf, mix_hrtf_blend."""
+    out = (C.c_uint64 * 4)()
+    lib().oalbridge_adapter_calls(out)
+    return tuple(out)
+
+
+def _direction(rng):
+    az = rng.uniform(-np.pi, np.pi)
+    ev = np.arcsin(rng.uniform(-1.0, 1.0))
+    d = 2.0                                        # SURVEY.md 8(d): sources 2 m away
+    return (float(np.sin(az) * np.cos(ev) * d), float(np.sin(ev) * d), float(-np.cos(az) * np.cos(ev) * d))
+
+
+def build_config3(b, nsources=256, seed=0x5EED0003, i16=False, slot=0):
+    """BASELINE configs[2] behind the reference's own voice loop: `nsources` mono sources at 44.1 kHz on the 48 kHz HRTF
+    device, bsinc24, random directions 2 m away, gains 10^(U(-60,-20)/20), a quarter of them filtered (gainHF 0.5), every
+    source with send 0 into effect slot `slot` (a quarter of those through the send's own filter)."""
+    rng = np.random.default_rng(seed)
+    bufs = []
+    for _ in range(8):
+        x = rng.uniform(-1, 1, 48000).astype(np.float32)
+        bufs.append(b.add_buffer_i16(np.round(x * 32767.0).astype(np.int16)) if i16 else b.add_buffer(x))
+    srcs = []
+    for v in range(nsources):
+        gain = float(10 ** (rng.uniform(-60, -20) / 20))
+        # one source in sixteen does not loop and is about to run out of buffer: it ends inside the third update
+        # (Voice::mix then drops the buffer, sets Stopping and the source fades out, voice.cpp:1201-1232)
+        ends = v % 16 == 5
+        srcs.append(b.add_source_ex(bufs[v % 8], not ends, 48000 - 2200 - v if ends else (v * 7919) % 48000, gain, _direction(rng),
+                                    RS_BSINC24, 1.0, 0.5 if v % 4 == 1 else 1.0, slot, 0.5, 0.7 if v % 4 == 2 else 1.0))
+    return srcs
+
+
+def move_config3(b, srcs, k, seed=0x5EED0003, slot=0):
+    """every 4th source gets a new direction and gain (CalcVoiceParams runs for those: a new Hrtf.Target, MixHrtfBlend)"""
+    rng = np.random.default_rng(seed + 1000 * k)
+    for v in srcs[::4]:
+        b.update_source_ex(v, float(10 ** (rng.uniform(-60, -20) / 20)), _direction(rng), RS_BSINC24, 1.0,
+                           0.5 if v % 4 == 1 else 1.0, slot, 0.5, 0.7 if v % 4 == 2 else 1.0)

@@ -18,8 +18,9 @@ from oalgpu import synth                       # noqa: E402
 from oalgpu.shard import voice_cost, weighted_shards   # noqa: E402
 import bench                                   # noqa: E402
 
-SIZES = (1024, 1024, 1024, 1024, 700, 1024)
-READ_AFTER = (3, 5)                            # the reads drain the pipeline: four updates back to back first
+SIZES = (1024, 1024, 1024, 1024, 700, 1024, 1024, 1024, 1024, 1024)
+READ_AFTER = (7, 9)                            # the reads drain the pipeline: eight updates back to back first -- twice the
+                                               # depth of the transport's ring, so the ranks do throttle each other
 
 
 def run(sc, script, nslots, hrtf):

@@ -1,4 +1,4 @@
-"""The COMPILED reference-side binding (oracle/ref_bridge.cpp -> oracle/_ref/liboalbridge.so): BASELINE
+"""The COMPILED reference-side binding (oracle/ref_bridge.cpp -> oracle/_ref/liboalbridge.so).  First BASELINE
 configs[0] -- 64 mono sources, linear resampler, stereo device, no effects -- rendered through the
 reference's REAL plumbing (DeviceBase::renderSamples -> ProcessContexts -> CalcVoiceParams for every source
 with pending properties -> the voice loop -> BFormatDec -> Write<float>), three ways:
@@ -11,6 +11,12 @@ with pending properties -> the voice loop -> BFormatDec -> Write<float>), three 
             oalgpu_voice_params the descriptor builder fills from the Voice objects AFTER the reference's
             CalcVoiceParams: the rendered PCM within the multi-voice tolerance,
             every source's position / fraction / play state identical.
+
+Then the headline configuration, BASELINE configs[2], the same three ways (the second half of this file): a
+RenderMode::Hrtf device set up as InitHrtfPanning does on the reference's own Default HRTF.mhr, 256 bsinc24 sources
+whose Hrtf.Target the reference's CalcHrtfPanning / getCoeffs computed (alc/alu.cpp:1207-1217), every 4th moving
+(MixHrtfBlend), a quarter filtered, every source with a send into an effect slot that carries the reference's own
+ReverbState, DeviceBase::Process(HrtfPostProcess) behind it; f32 and 16-bit buffers.
 """
 import numpy as np
 import pytest
@@ -70,3 +76,97 @@ def test_batched_update_behind_the_reference_voice_loop(math_mode, scene):
     err = float(np.abs(got.astype(np.float64) - want).max())
     bound = 2e-5 * float(np.abs(want).max()) + 1e-7
     assert err <= bound, (err, bound)
+
+
+# ---- BASELINE configs[2]: the HRTF device, sends into a reverb slot ------------------------------------------------
+HRTF_TODO = (1024, 1024, 640, 1024)
+
+
+def render_hrtf(mode, math_mode=1, nsources=256, i16=False, todo=HRTF_TODO, slot_gain=1.0, stop=False, restart=False):
+    import oracle_lib as ol
+    b = bl.Bridge(mode, math_mode, hrtf=True, num_sends=1)
+    slot = b.add_reverb_slot(ol.ReverbProps.make(), slot_gain)
+    srcs = bl.build_config3(b, nsources, i16=i16, slot=slot)
+    out, live = [], []
+    for k, n in enumerate(todo):
+        if k:
+            bl.move_config3(b, srcs, k, slot=slot)
+        if stop and k == 1:
+            for v in srcs[1::9]:
+                b.stop_source(v)
+        if restart and k == 3:
+            # the voices stopped at update 1 faded out during it and are Stopped: they start over as other sources
+            for j, v in enumerate(srcs[1::9]):
+                b.restart_source(v, (j + 3) % 8, True, 1000 + 37 * j, 0.05, (1.0, 0.5 * (j % 3 - 1), -1.5), bl.RS_BSINC24, 1.0,
+                                 0.5 if j % 2 else 1.0, slot, 0.5, 1.0)
+        out.append(b.render(n))
+        live.append(b.batch_live_voices())
+    states = [b.source_state(v) + b.source_flags(v) for v in srcs]
+    b.close()
+    return np.concatenate(out), states, live
+
+
+needs_bridge = pytest.mark.skipif(not bl.available(), reason="needs oracle/_ref/liboalbridge.so (built where /root/reference is mounted)")
+
+
+@needs_bridge
+def test_reference_plumbing_renders_the_hrtf_device_on_the_cpu():
+    """No GPU involved: the reference's renderSamples on the RenderMode::Hrtf device the bridge builds, its own
+    Voice::mix, ReverbState and MixDirectHrtf."""
+    a, sa, _ = render_hrtf(bl.MODE_CPU, nsources=64)
+    b, sb, _ = render_hrtf(bl.MODE_CPU, nsources=64)
+    assert a.shape == (sum(HRTF_TODO), 2) and np.array_equal(a, b) and sa == sb
+    assert np.abs(a).max() > 0.02 and np.abs(a[:, 0] - a[:, 1]).max() > 0.005
+    for v, s in enumerate(sa):
+        if v % 16 == 5:         # ran out of buffer inside the third update, faded out in the fourth: Stopped, no buffer
+            assert s[0] == 0 and s[4:] == (0, 1, 1), (v, s)
+        else:                   # Playing, mStep = fastf2u(44100/48000 * 65536), buffer / IsFading / HasHrtf
+            assert s[0] == 1 and s[3] == 60211 and s[4:] == (1, 1, 1), (v, s)
+    # the slot's reverb is part of the render: without the slot's gain the output differs
+    dry, _, _ = render_hrtf(bl.MODE_CPU, nsources=64, slot_gain=0.0)
+    assert np.abs(a - dry).max() > 1e-4
+
+
+@pytest.mark.gpu
+@needs_bridge
+@pytest.mark.parametrize("i16", [False, True])
+def test_hrtf_adapters_under_the_reference_voice_mix_are_bit_exact(i16):
+    """EXACT-mode per-call kernels behind the reference's function-pointer surface, under the reference's own
+    Voice::mix on the HRTF device: ResamplerFunc (bsinc24), HrtfMixerFunc / HrtfMixerBlendFunc (DoHrtfMix) and
+    MixerOutFunc (the sends, and the ReverbState's own mix-outs) all run on the GPU -- and the render equals the
+    pure CPU render bit for bit."""
+    import oalgpu
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    want, sw, _ = render_hrtf(bl.MODE_CPU, i16=i16)
+    before = bl.adapter_calls()
+    got, sg, _ = render_hrtf(bl.MODE_ADAPTERS, math_mode=oalgpu.MATH_EXACT, i16=i16)
+    calls = [a - b for a, b in zip(bl.adapter_calls(), before)]
+    assert sg == sw
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), float(np.abs(got - want).max())
+    # every kind of adapter ran: 256 resamples per update, MixHrtf for every voice, MixHrtfBlend for every fading voice
+    assert calls[0] >= 256 * len(HRTF_TODO) and calls[1] > 0 and calls[2] >= 256 * (len(HRTF_TODO) - 1) and calls[3] >= 256, calls
+
+
+@pytest.mark.gpu
+@needs_bridge
+@pytest.mark.parametrize("math_mode", ["fast", "exact"])
+@pytest.mark.parametrize("i16", [False, True])
+def test_hrtf_batched_update_behind_the_reference_voice_loop(math_mode, i16):
+    """ONE oalgpu_mix_update per update behind the reference's voice loop on the HRTF device: the descriptor builder of
+    include/oalgpu_openal.hpp hands over mStep, the filter targets, Hrtf.Target (coefficients, delays, gain) and the
+    sends' slots, filters and gains from the Voice objects after the reference's CalcVoiceParams; the HRTF
+    accumulator and the slot's wet bus join the reference's buffers, whose ReverbState and MixDirectHrtf finish the
+    update.  Sources stop, and their pooled Voice objects start over as other sources."""
+    import oalgpu
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    kw = dict(i16=i16, stop=True, restart=True, todo=HRTF_TODO + (1024,))
+    want, sw, _ = render_hrtf(bl.MODE_CPU, **kw)
+    got, sg, live = render_hrtf(bl.MODE_BATCH, math_mode=oalgpu.MATH_FAST if math_mode == "fast" else oalgpu.MATH_EXACT, **kw)
+    assert sg == sw, [(i, a, b) for i, (a, b) in enumerate(zip(sg, sw)) if a != b][:4]
+    err = float(np.abs(got.astype(np.float64) - want).max())
+    bound = 2e-5 * float(np.abs(want).max()) + 1e-7
+    assert err <= bound, (err, bound)
+    # stopped voices gave their device-side slots back, restarted ones took slots again: never more than the sources
+    stopped = set(range(1, 256, 9))
+    ended = {v for v in range(256) if v % 16 == 5}          # ran out of buffer in the third update, Stopped after the fourth
+    assert live[0] == 256 and live[1] == 256 - len(stopped) and live[-1] == 256 - len(ended - stopped), live

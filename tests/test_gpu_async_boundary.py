@@ -65,3 +65,55 @@ def test_async_boundary_matches_the_synchronous_one(synth_mhr):
         sounded = max(sounded, float(np.abs(a).max()))
         assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
     assert sounded > 1e-3
+
+
+def test_async_boundary_against_the_reference(synth_mhr):
+    """The pipelined boundary against the ORACLE itself (not only against the synchronous boundary): ten updates of a
+    config-3 scene, the moving voices handed over as 24-byte oalgpu_voice_move records (their HRIR blend indices
+    evaluated on the host, installed by ApplyMovesKernel in front of the next voice kernel), the stereo lines collected
+    two updates late -- compared with the compiled reference's Voice::mix + MixDirectHrtf of the same scene update by
+    update, and every voice's integer state at the end (core/voice.cpp:1126-1154)."""
+    import oalgpu
+    import oracle_lib as ol
+    from oalgpu import synth
+    import bench
+    from test_gpu_baseline_configs import build_reference_scene, close_to
+    if not ol.available("ref"):
+        pytest.skip("needs the compiled reference (oracle/_ref)")
+    L = ol.load("ref")
+    L.L.oal_set_simd(1)
+    mhr = open(synth_mhr, "rb").read()
+    V, updates = 512, 10
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    api._mhr = mhr
+    sc, script = bench.build_scene(oalgpu, synth, api, 3, V, 0, mhr, 0)
+    osc, oscript, _ = build_reference_scene(L, synth, 3, V, synth_mhr)
+    allv = list(range(V))
+    moving = [v for v in allv if script.is_moving(v)]
+    sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
+    for v in allv:
+        osc.set_params(v, oscript.fill(ol.VoiceParams(), v, 0))
+    tickets, got, want = [], [], []
+    for k in range(updates):
+        if k:
+            sc.move_async(_moves(oalgpu, script, moving, k))
+            for v in moving:
+                osc.set_params(v, oscript.fill(ol.VoiceParams(), v, k))
+        sc.mix(1024, post_process=True)
+        tickets.append(sc.read_output_async())
+        if k >= 2:
+            got.append(sc.output_wait(tickets[k - 2]).copy())
+        osc.mix(1024, post_process=True)
+        want.append(osc.dry()[4:6].copy())
+    for t in tickets[-2:]:
+        got.append(sc.output_wait(t).copy())
+    sounded = 0.0
+    for k in range(updates):
+        sounded = max(sounded, close_to(got[k], want[k], f"async boundary, update {k}: stereo lines", (V, 64)))
+    assert sounded > 1e-3
+    for v in allv:
+        g, o = sc.voice_state(v), osc.voice_state(v)
+        assert (g.play_state, g.position, g.position_frac, g.has_buffer, g.fading) == \
+            (o.play_state, o.position, o.position_frac, o.has_buffer, o.fading), v
+    sc.close()
+    osc.close()

@@ -54,7 +54,7 @@ def set_reference_decoder(L, sc, synth):
     sc.set_direct_hrtf(cc, hf, 400.0 / info.sample_rate, irsize)
 
 
-def build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir=None, num_real=None):
+def build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir=None, num_real=None, sample_fmt="f32"):
     """bench.build_scene, restated on the reference: same buffers, voices, direct-HRTF decoder."""
     hrtf = config in (3, 5)
     nsends = {4: 4, 5: 1}.get(config, 0)
@@ -76,8 +76,8 @@ def build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir=None, num
         effects.append(conv)
     if hrtf:
         set_reference_decoder(L, sc, synth)
-    bufs = synth.scene_buffers(config, nvoices)
-    handles = [sc.add_buffer(b, ol.FMT_FLOAT) for b in bufs]
+    bufs = synth.scene_buffers(config, nvoices, sample_fmt)
+    handles = [sc.add_buffer(b, ol.FMT_SHORT if sample_fmt == "i16" else ol.FMT_FLOAT) for b in bufs]
     script = synth.SceneScript(config, nvoices, 0)
     for v in range(nvoices):
         sc.add_voice(handles[script.buffer_of(v, len(handles))], True, position=script.start_position(v))
@@ -95,7 +95,9 @@ def close_to(got, want, what, terms=(1, 1)):
     return scale
 
 
-def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024)):
+def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_at=None, sample_fmt="f32"):
+    """check_at: the updates (0-based) after which buses and voice states are compared (None: every one).  Between
+    checkpoints nothing of the product is read: its two-stream pipeline runs on unsynchronised, as in the bench."""
     import oalgpu
     from oalgpu import synth
     import bench
@@ -108,7 +110,7 @@ def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024)):
     hrtf = config in (3, 5)
     nslots = {4: 4, 5: 1}.get(config, 0)
 
-    gsc, gscript = bench.build_scene(oalgpu, synth, api, config, nvoices, 0, mhr, 0)
+    gsc, gscript = bench.build_scene(oalgpu, synth, api, config, nvoices, 0, mhr, 0, sample_fmt=sample_fmt)
     conv_ir = None
     if config == 5:
         # the reference pans a mono response to the front (ConvolutionProps orientation, convolution.cpp:511-620)
@@ -116,7 +118,7 @@ def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024)):
         conv_ir = np.array([lcg.uniform(-1.0, 1.0) for _ in range(65536)], np.float32)
         conv_ir *= np.exp(-np.arange(65536) / 12000.0).astype(np.float32) * 0.05
         gsc.effects[0].set_target_gains(L.direction_coeffs([0.0, 0.0, -1.0])[:4])
-    osc, oscript, oeffects = build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir)
+    osc, oscript, oeffects = build_reference_scene(L, synth, config, nvoices, mhr_path, conv_ir, sample_fmt=sample_fmt)
 
     allv = list(range(nvoices))
     moving = [v for v in allv if gscript.is_moving(v)]
@@ -140,6 +142,8 @@ def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024)):
             oeffects[0].process(wets[0][0, :n], dry[:4])
         if hrtf:
             osc.post_process(n)
+        if check_at is not None and k not in check_at:
+            continue
         want_dry = osc.dry()
         got_dry = gsc.dry()
         hrtf_terms = (nvoices, 64) if hrtf else (nvoices, 1)      # RealOut L/R come out of the HRTF accumulator
@@ -189,3 +193,21 @@ def test_config4_8192_voices_four_reverb_slots(synth_mhr):
 
 def test_config5_4096_hrtf_voices_and_a_65536_tap_convolution(synth_mhr):
     run_config(5, 4096, synth_mhr)
+
+
+# ---- SURVEY.md 8(d) "Parity check in the same run": after updates 1, 2, 8 and 50, f32 and i16 sources ----------------
+# Fifty updates carry every voice's filter, fade, history and loop state (the 48 000-frame buffers wrap after 51 updates
+# at 941 frames each; start positions (v * 7919) % 48000 put a wrap into the run for most voices) far past the four
+# updates of the tests above: drift of any of it against core/voice.cpp:1126-1154, :1224-1232 shows up here.
+SCHEDULE = (0, 1, 7, 49)
+
+
+@pytest.mark.parametrize("sample_fmt", ["f32", "i16"])
+def test_config2_parity_after_updates_1_2_8_50(synth_mhr, sample_fmt):
+    run_config(2, 4096, synth_mhr, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt)
+
+
+@pytest.mark.parametrize("sample_fmt", ["f32", "i16"])
+def test_config3_parity_after_updates_1_2_8_50(sample_fmt):
+    assert os.path.exists(REAL_MHR), "tests/golden/default_hrtf.mhr is a committed fixture"
+    run_config(3, 4096, REAL_MHR, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt)

@@ -90,15 +90,17 @@ def test_library_comm_single_rank_rccl(synth_mhr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config", [3, 4])
+@pytest.mark.parametrize("config", [3, 4, 5])
 def test_library_sharded_update_two_processes_one_gpu(synth_mhr, tmp_path, config):
     """The library's N > 1 path itself: two processes share the GPU, each with a context of its own, connected by
     oalgpu_comm_init_host (RCCL refuses two ranks on one device; the host-staged transport sits behind the same
     interface as the ncclReduce).  Rank 1 mixes its shard without effects, post-process or accumulator carry and
-    hands its bus block over; rank 0 sums, runs the slots' effects and the post-process.  Six pipelined updates
-    (the first four without a host synchronisation), voices dealt by cost class; rank 0's buses and every
-    voice's integer state must equal the scene mixed unsharded.  Config 3 (HRTF) and config 4 (dry lines + sends
-    into four EAX reverb slots)."""
+    hands its bus block over; rank 0 sums, runs the slots' effects and the post-process.  Ten pipelined updates
+    (the first eight without a host synchronisation: twice the depth of the transport's ring), voices dealt by cost
+    class; rank 0's buses and every voice's integer state must equal the scene mixed unsharded.  Config 3 (HRTF),
+    config 4 (dry lines + sends into four EAX reverb slots) and config 5 -- BASELINE configs[4]'s sharded shape: rank 1's
+    send rows reach the wet bus of rank 0's 65 536-tap convolution slot through the reduce
+    (alc/effects/convolution.cpp:623-716 runs where the summed wet bus is)."""
     import numpy as np
     total = 600
     name = f"/oalgpu_test_{os.getpid()}_{config}"
