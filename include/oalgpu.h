@@ -181,6 +181,9 @@ typedef struct oalgpu_context_desc {
                                    * instead of the matrix pipe in split half precision */
 #define OALGPU_CTX_PROFILE  2u    /* the voice kernel's measurement variant: per-phase cycle stamps and stage ablation,
                                    * read and set through include/oalgpu_debug.h */
+#define OALGPU_CTX_STREAM_ROWS 8u  /* FAST dry-line / send contexts with <= 8 mix lines: leave stream rows in HBM and mix them in the
+                                   * voice kernel's tail (the path of contexts with more lines) instead of accumulating the
+                                   * lines in the wavefronts' registers: for A/B runs and tests of the row path */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 

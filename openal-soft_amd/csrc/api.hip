@@ -889,6 +889,8 @@ int oalgpu_biquad_dual_process(int device, oalgpu_biquad *f0, oalgpu_biquad *f1,
 }
 
 // ---------------------------------------------------------------- context
+static int AllocStreamRows(oalgpu_context *c);
+
 int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
 {
     if(!desc || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
@@ -989,17 +991,18 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.nfc = nullptr; L.nfcOrders = 0;
     L.hrirs = nullptr;
     for(uint32_t &n : L.chansPerOrder) n = 0;
+    L.accLines = 0;
+    if(c->useWave && !(desc->flags & OALGPU_CTX_STREAM_ROWS)) L.accLines = WaveKernelAccLines(L);
     if(c->useWave && (!L.hrtf || L.numSends))
-    {   // stream rows, mixed onto the lines by the voice kernel's tail: one partial bus per workgroup
+    {   // one partial bus per workgroup, from the wavefronts' line accumulators (accLines) or from stream rows mixed by the
+        // voice kernel's tail
         L.lineStride = L.mixLines <= 8 ? 8u : (L.mixLines <= 16 ? 16u : 32u);
         L.streamsPerVoice = 2u + L.numSends;
-        HIP_TRY(c->streams.alloc(nv * L.streamsPerVoice * kLine)); HIP_TRY(c->streams.zero()); L.streams = c->streams.p;
-        HIP_TRY(c->lineGains.alloc(nv * L.streamsPerVoice * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
-        L.lineGains = c->lineGains.p;
     }
+    if(c->useWave && (!L.hrtf || L.numSends) && !L.accLines) { if(int rc = AllocStreamRows(c.get())) return rc; }
     HIP_TRY(c->partLines.alloc(size_t{L.numLineGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
     // the two-stream pipeline of oalgpu_mix_update alternates between two sets of partial buses
-    HIP_TRY(c->partLines2.alloc(c->useWave && L.streams ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
+    HIP_TRY(c->partLines2.alloc(c->useWave && (L.streams || L.accLines) ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
     c->partLinesBuf[0] = c->partLines.p; c->partLinesBuf[1] = c->partLines2.p;
     HIP_TRY(c->partHrtf.alloc(L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0)); L.partHrtf = c->partHrtf.p;
     HIP_TRY(c->partHrtf2.alloc(c->useWave && L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
@@ -1037,6 +1040,17 @@ void oalgpu_context_destroy(oalgpu_context *ctx)
     delete ctx;
 }
 
+// stream rows [voice][streamsPerVoice][1024] and their gain blocks, for the contexts whose voice kernel mixes them in its tail
+static int AllocStreamRows(oalgpu_context *c)
+{
+    DeviceLayout &L = c->L;
+    const size_t nv = L.numVoices;
+    HIP_TRY(c->streams.alloc(nv * L.streamsPerVoice * kLine)); HIP_TRY(c->streams.zero()); L.streams = c->streams.p;
+    HIP_TRY(c->lineGains.alloc(nv * L.streamsPerVoice * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
+    L.lineGains = c->lineGains.p;
+    return OALGPU_OK;
+}
+
 // the parsed (or handed-over) store becomes the context's: host copy, HBM copy, voice filter arrays
 static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
 {
@@ -1070,6 +1084,12 @@ static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
         HIP_TRY(c->hrtfOld.alloc(n)); HIP_TRY(c->hrtfOld.zero()); L.hrtfOld = c->hrtfOld.p;
         HIP_TRY(c->hrtfTgt.alloc(n)); HIP_TRY(c->hrtfTgt.zero()); L.hrtfTgt = c->hrtfTgt.p;
         if(!c->directSet) c->dIrSize = h.irSize;
+    }
+    // (a set with more than 64 taps: the send rows of such an HRTF context go through stream rows)
+    if(L.accLines && WaveKernelAccLines(L) == 0)
+    {
+        L.accLines = 0;
+        if(int rc = AllocStreamRows(c)) return rc;
     }
     return OALGPU_OK;
 }
@@ -1423,7 +1443,8 @@ int oalgpu_context_set_nfc(oalgpu_context *c, float w1, const uint32_t channels_
     const size_t nv = L.numVoices;
     HIP_TRY(c->nfc.alloc(nv)); HIP_TRY(c->nfc.zero());
     if(c->useWave)
-    {   // the wavefront kernel: every order adds one stream row per voice
+    {   // the wavefront kernel: every order adds one stream row per voice (near-field contexts mix through stream rows)
+        L.accLines = 0;
         const uint32_t spv = 2u + L.numSends + orders;
         HIP_TRY(c->streams.alloc(nv * spv * kLine)); HIP_TRY(c->streams.zero());
         HIP_TRY(c->lineGains.alloc(nv * spv * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
@@ -2162,7 +2183,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     const uint32_t p = c->parity;
     DeviceLayout L = c->L;
     L.partHrtf = c->partHrtfBuf[p];
-    if(L.streams) L.partLines = c->partLinesBuf[p];
+    if(L.streams || L.accLines) L.partLines = c->partLinesBuf[p];
     // main stream: this update's voices; its partial-bus buffer was last read by the reduction
     // of two updates ago
     // (almost always long done: then no barrier packet goes into the main queue in front of the voice kernel)

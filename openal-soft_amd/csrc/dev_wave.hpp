@@ -359,7 +359,9 @@ __device__ __forceinline__ S2 ScanLinear2(S2 e, S2 m0, S2 m1, uint32_t lane)
 }
 
 
-template<int TILES = 5, bool LOW8 = false>
+// AHEAD: the tiles' B fragments are fetched one tile ahead of their use (24 more registers; the kernels that also hold
+// line accumulators fetch them when they need them)
+template<int TILES = 5, bool LOW8 = false, bool AHEAD = true>
 __device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2][2][kXhDw], const uint32_t (&hr)[2][2][kHrDw],
     float inv, uint32_t lane)
 {
@@ -369,6 +371,7 @@ __device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2
 #pragma unroll
     for(int e = 0; e < 2; ++e)
     {   // one ear at a time: 6 A fragments live across the ear's five tiles, 6 B fragments per tile
+        if constexpr (!AHEAD) __builtin_amdgcn_sched_barrier(0);      // (nor the next ear's fragments over this ear's tiles)
         h8 A[2][3];
 #pragma unroll
         for(int s = 0; s < 2; ++s)
@@ -394,12 +397,12 @@ __device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2
                 for(int c = 0; c < 3; ++c) B[s][c] = __builtin_bit_cast(h8, p[4 * c]);
             }
         };
-        h8 B[2][3], Bn[2][3];
+        h8 B[2][3], Bn[AHEAD ? 2 : 1][AHEAD ? 3 : 1];
         loadB(B, 0);
 #pragma unroll
         for(int T = 0; T < TILES; ++T)
         {
-            if(T + 1 < TILES) loadB(Bn, T + 1);
+            if constexpr (AHEAD) { if(T + 1 < TILES) loadB(Bn, T + 1); }
             f4 ta = {0.0f, 0.0f, 0.0f, 0.0f}, tb = ta, tc = ta;
 #pragma unroll
             for(int c = 0; c < 3; ++c)
@@ -410,12 +413,20 @@ __device__ __forceinline__ void FirMfmaH(f4 (&acc)[2][5], const uint32_t (&xh)[2
             }
             const f4 sum = __builtin_elementwise_fma((ta + tb) + tc, vinv, acc[e][T]);
             if(!LOW8 || i < 8u) acc[e][T] = sum;      // LOW8: only the columns of frames 0..127 hold this product
+            if constexpr (AHEAD)
+            {
             if(T + 1 < TILES)
             {
 #pragma unroll
                 for(int s = 0; s < 2; ++s)
 #pragma unroll
                     for(int c = 0; c < 3; ++c) B[s][c] = Bn[s][c];
+            }
+            }
+            else if(T + 1 < TILES)
+            {   // (and the scheduler must not pull the next tile's reads up over this tile's products either)
+                __builtin_amdgcn_sched_barrier(0);
+                loadB(B, T + 1);
             }
         }
     }

@@ -125,6 +125,8 @@ struct DeviceLayout {
     uint32_t firMfma;                       // voice_wave.hip: the HRTF FIR (IrSize <= 64) on the matrix pipe in split half
                                             // precision (default) instead of packed VALU FMAs (OALGPU_CTX_FIR_VALU)
     uint32_t mixLines;                      // lines accumulated by the voice kernel
+    uint32_t accLines;                      // voice_wave.hip: the mix lines accumulate in the wavefronts' registers (<= 8 lines;
+                                            // the kernel's ACCL: 4, 6 or 8) instead of leaving stream rows; 0 = stream rows
     // tables + buffers
     const float *tables;                    // [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
     const BufferItem *buffers;
@@ -369,6 +371,7 @@ void LaunchSetVoiceWindow(hipStream_t s, const DeviceLayout &L, uint32_t voice, 
 void LaunchDecodeAdpcm(hipStream_t s, bool msadpcm, const uint8_t *src, int16_t *dst, uint32_t numBlocks, uint32_t samplesPerBlock,
     uint32_t channels, uint32_t sampleLen);
 bool WaveKernelApplies(bool exact, const DeviceLayout &L);
+uint32_t WaveKernelAccLines(const DeviceLayout &L);     // the ACCL the wavefront kernel would run this layout with (0: stream rows)
 const char *WaveKernelName(const DeviceLayout &L);
 uint32_t WaveKernelGroups(const DeviceLayout &L);
 // the measurement variant's extras (OALGPU_CTX_PROFILE, tools/phase_times.py): s_memtime stamps

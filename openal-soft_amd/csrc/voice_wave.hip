@@ -34,6 +34,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef OALGPU_WAVE_MIN_WG
+#define OALGPU_WAVE_MIN_WG 2              // workgroups per CU the kernels are built for (experiments: 1 shows the unconstrained budget)
+#endif
+
 namespace oalgpu {
 namespace {
 // One line's share of a stream row's gain block (kernels.hpp LineBlockDwords): contributions of
@@ -68,6 +72,57 @@ __device__ __forceinline__ void StoreRowBlock(uint32_t *blk, uint32_t ls, uint32
     const uint32_t mask = ((m & 0xFFull) ? 1u : 0u) | ((m & 0xFF00ull) ? 2u : 0u) | ((m & 0xFF0000ull) ? 4u : 0u)
         | ((m & 0xFF000000ull) ? 8u : 0u);
     if(lane < 8u) blk[3u * ls + lane] = lane == 0u ? (live ? mask : 0u) : (lane == 1u ? maxFade : 0u);
+}
+
+// ---- MixSamples straight out of LDS into the wavefront's own line accumulators (contexts with <= 8 mix lines) ----
+// The resampled / filtered samples of a voice are in LDS when DoFilters ends; with few enough lines the wavefront keeps
+// N lines x 64R frames of accumulator in registers (lane l owns frames [R l, R l + R) of every line, like the HRTF
+// accumulator) and MixSamples (core/mixer/mixer_c.cpp:150-186, as Voice::mix calls it, voice.cpp:934-984) becomes R x N
+// FMAs per lane with the line's gain in an SGPR: no stream row, no gain block and no row mix in the kernel's tail --
+// the row never leaves the CU.  rg: the row's merged gains, lane = line (RowLineGain); frames below the ramp's length
+// use cur + step * frame instead of the constant (MixLine with Counter <= 64: only lanes 0..3 can hold such frames).
+template<int ACCL, int R>
+__device__ __forceinline__ void MixRowAcc(float (&accL)[ACCL][R], float (&accRamp)[ACCL], const float *row, uint32_t N, const RowLineGain &rg,
+    uint32_t lane)
+{
+    const bool hasRamp = rg.fadeLen != 0u && lane < uint32_t(ACCL);
+    const float rampA = hasRamp ? rg.cur - rg.gain : 0.0f, rampB = hasRamp ? rg.step : 0.0f;
+    const bool nz = lane < uint32_t(ACCL) && (rg.gain != 0.0f || rampA != 0.0f || rampB != 0.0f);
+    const unsigned long long live = __ballot(nz);
+    if(live == 0ull) return;
+    uint32_t maxFade = hasRamp ? rg.fadeLen : 0u;
+#pragma unroll
+    for(int d = 32; d >= 1; d >>= 1) { const uint32_t o = uint32_t(__shfl_xor(int(maxFade), d)); maxFade = o > maxFade ? o : maxFade; }
+    {
+        float x[R];
+#pragma unroll
+        for(int r = 0; r < R; ++r)
+        {
+            const uint32_t f = uint32_t(R) * lane + uint32_t(r);
+            x[r] = (f < N) ? row[f] : 0.0f;
+        }
+#pragma unroll
+        for(int c = 0; c < ACCL; ++c)
+        {
+            if(!((live >> c) & 1ull)) continue;                 // (uniform: the ballot is a scalar)
+            const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rg.gain), c));
+#pragma unroll
+            for(int r = 0; r < R; ++r) accL[c][r] = __builtin_fmaf(x[r], g, accL[c][r]);
+        }
+    }
+    if(maxFade != 0u)
+    {   // the ramp's distance from the constant, frames < maxFade <= 64: frame = lane, in accumulators of their own
+        // (added to the lines when the accumulators are dumped)
+        const float xf = (lane < maxFade && lane < N) ? row[lane] : 0.0f;
+        const float fl = float(lane);
+#pragma unroll
+        for(int c = 0; c < ACCL; ++c)
+        {
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rampA), c));
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rampB), c));
+            accRamp[c] = __builtin_fmaf(xf, __builtin_fmaf(b, fl, a), accRamp[c]);
+        }
+    }
 }
 
 // ---- MixSamples of the workgroup's stream rows onto the mix lines (core/mixer/mixer_c.cpp:183-215 as
@@ -220,10 +275,13 @@ struct WaveArgsHrtf {
         hist{L.hist}, ambi{L.ambi}, startDelay{L.startDelay}, queueDone{L.queueDone}, partHrtf{L.partHrtf} { }
 };
 
-template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool PROF = false, class LT = DeviceLayout>
-__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKernel(LT L, uint32_t samplesToDo, WaveProf prof)
+// ACCL > 0: the context's mix lines (dry lines and / or the slots' wet lines, <= ACCL of them) accumulate in the
+// wavefront's registers (MixRowAcc) instead of leaving stream rows; such kernels run the register-lean resampler.
+template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool PROF = false, class LT = DeviceLayout, int ACCL = 0>
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MIN_WG) VoiceWaveKernel(LT L, uint32_t samplesToDo, WaveProf prof)
 {
     static_assert(std::is_same<LT, DeviceLayout>::value || (NL == 0 && !SENDS), "the lean argument block is the HRTF variants'");
+    static_assert(ACCL == 0 || NL > 0 || SENDS, "line accumulators belong to kernels that mix onto lines");
     static_assert(!MF || (R == 17 && TAPS == 64 && NL == 0), "the matrix-pipe FIR is the 64-tap HRTF form");
     using WL = WaveLds<R, TAPS, MF>;
     __shared__ WgLds<R, TAPS, MF> sm;
@@ -253,7 +311,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 prof.times[size_t{L.numVoices} * 8 + size_t{group * kWWaves + wave} * 8 + slot] = __builtin_readcyclecounter();
         }
     };
+#ifdef OALGPU_EXP_ABLATE
+    const uint32_t ablate = OALGPU_EXP_ABLATE;
+#else
     const uint32_t ablate = PROF ? prof.ablate : 0u;
+#endif
     waveStamp(0);
     // Two workgroups share a CU, and the launch fills the machine exactly once: workgroup g and
     // g + gridDim/2 land on the same CU (the dispatcher deals the first half one per CU, then the
@@ -301,6 +363,14 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
     f2 accO[WL::kQ];
 #pragma unroll
     for(int q = 0; q < WL::kQ; ++q) accO[q] = f2{0.0f, 0.0f};
+    float accRamp[ACCL > 0 ? ACCL : 1];                // ACCL: the gain ramps' share of the lines' first 64 frames, frame = lane
+#pragma unroll
+    for(int c = 0; c < (ACCL > 0 ? ACCL : 1); ++c) accRamp[c] = 0.0f;
+    float accL[ACCL > 0 ? ACCL : 1][R];                // ACCL: the mix lines, lane l owns frames [R l, R l + R)
+#pragma unroll
+    for(int c = 0; c < (ACCL > 0 ? ACCL : 1); ++c)
+#pragma unroll
+        for(int r = 0; r < R; ++r) accL[c][r] = 0.0f;
 
     for(uint32_t pass = 0; pass <= vCount; ++pass)
     {
@@ -347,7 +417,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                         || !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd));
                     planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
                 }
-                if(headN.flags & (kFlagDelayed | kFlagQueue)) planN.prefetch = false;   // a delayed start's window depends on where in
+                if(headN.flags & (kFlagDelayed | kFlagQueue)) planN.prefetch = false;
+#ifdef OALGPU_EXP_NOPREFETCH
+                planN.prefetch = false;
+#endif   // a delayed start's window depends on where in
                                                                                    // the update it starts; a queue's spans several buffers
                 // (the window first: each gather variant starts by waiting for older loads into its
                 // registers -- the variants share them -- and must not find a fresh one in front of it)
@@ -419,7 +492,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     for(uint32_t k = lane; k < outPos; k += 64) w.in[kHist + k] = 0.0f;
                 }
             }
-            if constexpr (SENDS || NL > 0)
+            if constexpr ((SENDS || NL > 0) && ACCL == 0)
             {   // nothing to mix for this voice in this update
                 if(!active && lane < L.streamsPerVoice)
                     L.lineGains[(size_t{v} * L.streamsPerVoice + lane) * LineBlockDwords(L.lineStride) + 3u * L.lineStride] = 0u;
@@ -440,7 +513,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             // filter's old coefficients (w.cold) and the source window were parked by the last pass
             const float fstv = fstC;
             const SrcPlan plan = planN;
-            LoadResampledWave<false, PROF>(sm, w, L, v, lane, head, playing, N - outPos, N - outPos, bufferItem, looping, plan, outPos, prof);
+            LoadResampledWave<(ACCL > 0), PROF>(sm, w, L, v, lane, head, playing, N - outPos, N - outPos, bufferItem, looping, plan, outPos, prof);
             asm volatile("" : "+v"(lane));      // addresses used from here on are rebuilt, not carried across the resampler
             if constexpr (NL > 0) requestNext();
             if(head.flags & kFlagAmbiScale)
@@ -461,8 +534,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             {   // ---- stream rows that must leave before the direct filter overwrites w.in
                 const uint32_t ls = L.lineStride, spv = L.streamsPerVoice, numSends = L.numSends, wetCh = L.wetChannels;
                 const uint32_t wetBase = L.hrtf ? 0u : L.numDry;
-                float *rowsV = L.streams + size_t{v} * spv * kLine;
-                uint32_t *blkV = L.lineGains + size_t{v} * spv * LineBlockDwords(ls);
+                float *rowsV = ACCL ? nullptr : L.streams + size_t{v} * spv * kLine;
+                uint32_t *blkV = ACCL ? nullptr : L.lineGains + size_t{v} * spv * LineBlockDwords(ls);
                 RowLineGain row0;                       // the unfiltered row's merged gains, line = lane
                 bool row0Live = false;
                 if constexpr (NL > 0)
@@ -487,8 +560,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     for(uint32_t si = 0; si < numSends; ++si)
                     {
                         const int32_t slot = L.ctl[v].sendSlot[si];
-                        uint32_t *blkS = blkV + size_t{2u + si} * LineBlockDwords(ls);
-                        if(slot < 0) { if(lane == 0) blkS[3u * ls] = 0u; continue; }
+                        uint32_t *blkS = ACCL ? nullptr : blkV + size_t{2u + si} * LineBlockDwords(ls);
+                        if(slot < 0) { if(ACCL == 0 && lane == 0) blkS[3u * ls] = 0u; continue; }
                         const bool sendFilter = (head.flags >> (kFlagSendFilterShift + si)) & 1u;
                         // the send's gains onto its slot's wet lines (voice.cpp:978-979)
                         const uint32_t base = wetBase + uint32_t(slot) * wetCh;
@@ -514,24 +587,35 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                             WaveSync();
                             WaveDoFilters(w.fst, slots, true, tmp + outPos, N - outPos, lane);
                             WaveSync();
-                            float *dst = rowsV + size_t{2u + si} * kLine;
-                            for(uint32_t k = lane; k < uint32_t(kLine); k += 64) dst[k] = (k < N) ? tmp[k] : 0.0f;
                             RowLineGain r;
                             if(mine) r.add(g);
+                            if constexpr (ACCL > 0) MixRowAcc<(ACCL > 0 ? ACCL : 1), R>(accL, accRamp, tmp, N, r, lane);
+                            else
+                            {
+                            float *dst = rowsV + size_t{2u + si} * kLine;
+                            for(uint32_t k = lane; k < uint32_t(kLine); k += 64) dst[k] = (k < N) ? tmp[k] : 0.0f;
                             StoreRowBlock(blkS, ls, lane, r, true);
+                            }
                         }
                         else
                         {
                             WaveDoFilters(w.fst, slots, false, w.in + kHist, N, lane);
                             if(mine) row0.add(g);
                             row0Live = true;
-                            if(lane == 0) blkS[3u * ls] = 0u;
+                            if(ACCL == 0 && lane == 0) blkS[3u * ls] = 0u;
                         }
                     }
                 }
+                if constexpr (ACCL > 0)
+                {
+                    if(row0Live) { WaveSync(); MixRowAcc<(ACCL > 0 ? ACCL : 1), R>(accL, accRamp, w.in + kHist, N, row0, lane); }
+                }
+                else
+                {
                 if(row0Live)
                     for(uint32_t k = lane; k < uint32_t(kLine); k += 64) rowsV[k] = (k < N) ? w.in[kHist + k] : 0.0f;
                 StoreRowBlock(blkV, ls, lane, row0, row0Live);
+                }
                 WaveSync();
             }
 
@@ -547,11 +631,14 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             {   // the direct-filtered row (voice.cpp:962-963 after an active DoFilters)
                 const bool nfcV = L.nfc && (head.flags & kFlagNfc);
                 const uint32_t ls = L.lineStride, spv = L.streamsPerVoice, nd = nfcV ? 1u : L.numDry;
-                uint32_t *blk1 = L.lineGains + (size_t{v} * spv + 1u) * LineBlockDwords(ls);
+                uint32_t *blk1 = ACCL ? nullptr : L.lineGains + (size_t{v} * spv + 1u) * LineBlockDwords(ls);
                 if(directFilter)
                 {
+                    if constexpr (ACCL == 0)
+                    {
                     float *dst = L.streams + (size_t{v} * spv + 1u) * kLine;
                     for(uint32_t k = lane; k < uint32_t(kLine); k += 64) dst[k] = (k < N) ? w.in[kHist + k] : 0.0f;
+                    }
                     float tg = 0.0f, cu = 0.0f;
                     if(lane < nd)
                     {
@@ -561,10 +648,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
                     RowLineGain r;
                     if(lane < nd) { L.gainCur[size_t{v} * L.numDry + lane] = g.newCur; r.add(g); }
-                    StoreRowBlock(blk1, ls, lane, r, true);
+                    if constexpr (ACCL > 0) MixRowAcc<(ACCL > 0 ? ACCL : 1), R>(accL, accRamp, w.in + kHist, N, r, lane);
+                    else StoreRowBlock(blk1, ls, lane, r, true);
                 }
-                else if(lane == 0) blk1[3u * ls] = 0u;
-                if(L.nfc)
+                else if(ACCL == 0 && lane == 0) blk1[3u * ls] = 0u;
+                if(ACCL == 0 && L.nfc)
                 {   // DoNfcMix, voice.cpp:911-931: one row per ambisonic order above 0, the voice's
                     // (direct-filtered) samples through that order's NFC section
                     const uint32_t rowBase = 2u + L.numSends, ndAll = L.numDry;
@@ -598,7 +686,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             stamp(2);
             // (matrix-pipe FIR: the next voice's request leaves now -- the FIR is too short to cover it, the
             // build of its inputs in front of it makes up for that)
+#ifndef OALGPU_EXP_LATE_REQUEST
             if constexpr (MF) requestNext();
+#endif
             if constexpr (NL == 0)
             {
             // ---- DoHrtfMix, voice.cpp:827-902
@@ -764,7 +854,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         // NL == 0: before the FIR, whose ~1100 packed FMAs cover the latency (matrix-pipe FIR: before the build
         // of its inputs, above).  NL > 0 (no FIR in this kernel): right after the resampler, ahead of the
         // filters and the stream-row stores.
+#ifndef OALGPU_EXP_LATE_REQUEST
         if constexpr (NL > 0 || MF) { if(!active) requestNext(); }
+#endif
         else requestNext();
         if constexpr (PROF) { if(first) waveStamp(5); }
 
@@ -780,7 +872,13 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24 || mK == 48) && mK <= kMaxM))
                 && (headK.playState == OALGPU_VOICE_PLAYING || headK.playState == OALGPU_VOICE_STOPPING);
             uint32_t key = headK.rsFilterOffset * 8u + uint32_t(kK), m = mK;
-            if(eligK) { if(t == 0) { sm.tabKey = key; sm.tabM = mK; sm.tabL = lK; } }
+            if(eligK)
+            {   // (the values to store are made here, behind an opaque move: as loop invariants the compiler kept them
+                // in VGPRs across every pass for the one store of pass 0)
+                uint32_t k0 = key, k1 = mK, k2 = lK;
+                asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2));
+                if(t == 0) { sm.tabKey = k0; sm.tabM = k1; sm.tabL = k2; }
+            }
             else
             {
             if(wave == 0)
@@ -841,8 +939,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             if(NL > 0 || (ablate & 1u)) {}
             else if constexpr (MF)
             {
-                FirMfmaH(accM, w.xh, w.hr, invX * invH, lane);
+                FirMfmaH<5, false, (ACCL == 0)>(accM, w.xh, w.hr, invX * invH, lane);
+#ifdef OALGPU_EXP_NOOLDPASS
+                if(false)
+#else
                 if(oldPass)
+#endif
                 {   // the replaced filter's fade-out (MixHrtfBlend, hrtfbase.h:54-70): 64 inputs x IrSize taps land in
                     // frames 0..126 -- the first eight columns of tile 0.  Its inputs go over the main inputs' first
                     // 104 dwords (frames -64..143; the main FIR has read them), as halves like those: frame = lane.
@@ -859,7 +961,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                         w.xh[0][0][64u + lane] = 0u; w.xh[0][1][64u + lane] = 0u; w.xh[1][0][64u + lane] = 0u; w.xh[1][1][64u + lane] = 0u;
                     }
                     WaveSync();
-                    FirMfmaH<1, true>(accM, w.xh, w.hro, invXo * invHO, lane);
+                    FirMfmaH<1, true, (ACCL == 0)>(accM, w.xh, w.hro, invXo * invHO, lane);
                 }
             }
             else if(irStride == uint32_t(TAPS))
@@ -887,6 +989,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
             }
         }
 
+#ifdef OALGPU_EXP_LATE_REQUEST
+        requestNext();
+#endif
         // ---------------- the next voice's state is parked in LDS ----------------
         // After the FIR every LDS word the next pass starts from is free (rd shares x2; in[0..63],
         // fst and cold were last read above), and what was requested before the FIR has landed.
@@ -916,6 +1021,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                 {   // the response, tap = lane, as r[80 - lane] (FirMfmaH)
                     float sh;
                     HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, __builtin_fmaxf(__builtin_fabsf(hN.x), __builtin_fabsf(hN.y)))), sh, invH);
+                    invH = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invH)));    // (uniform: stays in an SGPR across the pass)
                     uint32_t hi, lo;
                     SplitHalf2(hN.x * sh, hN.y * sh, hi, lo);       // (left, right) leading halves / remainders
                     uint16_t *hz = reinterpret_cast<uint16_t*>(&w.hr[0][0][0]);
@@ -929,6 +1035,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
                     {   // the replaced response, like the target's above
                         float sh;
                         HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, __builtin_fmaxf(__builtin_fabsf(oldN[0].x), __builtin_fabsf(oldN[0].y)))), sh, invHO);
+                        invHO = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invHO)));
                         uint32_t hi, lo;
                         SplitHalf2(oldN[0].x * sh, oldN[0].y * sh, hi, lo);
                         uint16_t *hz = reinterpret_cast<uint16_t*>(&w.hro[0][0][0]);
@@ -1045,7 +1152,43 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         waveStamp(3);
         }
     };
-    if constexpr (NL > 0) { mixRows(); return; }
+    // ACCL: the wavefronts' line accumulators -> one partial bus per workgroup, two lines at a time through the (now free)
+    // FIR-input area of every wavefront's LDS, summed in wavefront order like the HRTF accumulator below
+    auto dumpLines = [&]()
+    {
+        if constexpr (ACCL > 0)
+        {
+        auto areaOf = [&](int ww) { return MF ? reinterpret_cast<f2*>(&sm.w[ww].xh[0][0][0]) : sm.w[ww].x2; };
+        static_assert(!MF || sizeof(w.xh) >= size_t(WL::kFrames) * sizeof(f2), "a line pair fits in the FIR-input area");
+        const uint32_t nlines = L.mixLines;
+        float *pl = L.partLines + size_t{group} * nlines * kLine;
+#pragma unroll
+        for(int c = 0; c < ACCL; c += 2)
+        {
+            if(uint32_t(c) >= nlines) break;
+            __syncthreads();
+            f2 *area = areaOf(int(wave));
+#pragma unroll
+            for(int r = 0; r < R; ++r) area[R * lane0 + r] = f2{accL[c][r], (c + 1 < ACCL) ? accL[c + 1 < ACCL ? c + 1 : c][r] : 0.0f};
+            WaveSync();
+            {   // the ramps' share: frame = lane
+                const f2 cur = area[lane0];
+                area[lane0] = f2{cur.x + accRamp[c], cur.y + ((c + 1 < ACCL) ? accRamp[c + 1 < ACCL ? c + 1 : c] : 0.0f)};
+            }
+            __syncthreads();
+            for(uint32_t k = t; k < uint32_t(kLine); k += kWThreads)
+            {
+                f2 sum = areaOf(0)[k];
+#pragma unroll
+                for(int ww = 1; ww < kWWaves; ++ww) { const f2 o = areaOf(ww)[k]; sum.x += o.x; sum.y += o.y; }
+                pl[size_t(c) * kLine + k] = (k < N) ? sum.x : 0.0f;
+                if(uint32_t(c) + 1u < nlines) pl[size_t(c + 1) * kLine + k] = (k < N) ? sum.y : 0.0f;
+            }
+        }
+        waveStamp(3);
+        }
+    };
+    if constexpr (NL > 0) { if constexpr (ACCL > 0) dumpLines(); else mixRows(); return; }
     // ---- one partial per workgroup: waves dump their accumulators, then a fixed-order sum
     {
         // [frame] = (L, R), frames < 64R (the matrix-pipe kernels: 17 entries per 16 frames, in the place of xh)
@@ -1099,11 +1242,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceWaveKe
         }
     }
     waveStamp(3);
-    if constexpr (SENDS) mixRows();
+    if constexpr (SENDS) { if constexpr (ACCL > 0) dumpLines(); else mixRows(); }
 }
 
 } // namespace
 
+#ifndef OALGPU_WAVE_NO_LAUNCHER          // (register-budget experiments instantiate single variants of the kernel: tools/kernel_regs.sh)
 bool WaveKernelApplies(bool exact, const DeviceLayout &L)
 {
     if(exact || L.mixLines > 32 || L.numSends > 6) return false;
@@ -1111,9 +1255,24 @@ bool WaveKernelApplies(bool exact, const DeviceLayout &L)
     return L.numDry >= 1;
 }
 
+// Few enough mix lines (the dry lines of a non-HRTF context plus every slot's wet lines) accumulate in registers.  Near-field
+// control adds rows per ambisonic order and stays on the stream-row path (oalgpu_context_set_nfc clears accLines).
+uint32_t WaveKernelAccLines(const DeviceLayout &L)
+{
+    // The register budget (256 per lane at two wavefronts per SIMD) decides which shapes exist: 6 lines beside the
+    // resampler and the filter scans of a dry-line context without sends; 4 wet lines -- one first-order slot -- beside the
+    // HRTF accumulator tiles.  More lines, or dry lines AND sends, go through stream rows.
+    if(L.nfc || L.mixLines == 0) return 0;
+    if(!L.hrtf) return (L.numSends == 0 && L.mixLines <= 6) ? 6u : 0u;
+    if(L.numSends && L.irStride <= 64 && L.firMfma && L.mixLines <= 4) return 4u;
+    return 0;
+}
+
 const char *WaveKernelName(const DeviceLayout &L)
 {
     const bool sends = L.numSends != 0;
+    if(L.accLines)
+        return !L.hrtf ? "VoiceWaveKernel<17, 64, 1, false, false, false, DeviceLayout, 6>" : "VoiceWaveKernel<17, 64, 0, true, true, false, DeviceLayout, 4>";
     if(!L.hrtf) return sends ? "VoiceWaveKernel<17, 64, 1, true>" : "VoiceWaveKernel<17, 64, 1, false>";
     if(L.irStride <= 64 && L.firMfma) return sends ? "VoiceWaveKernel<17, 64, 0, true, true>" : "VoiceWaveKernel<17, 64, 0, false, true>";
     if(L.irStride <= 64) return sends ? "VoiceWaveKernel<17, 64, 0, true>" : "VoiceWaveKernel<17, 64, 0, false>";
@@ -1138,6 +1297,16 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     {
         if(L.firMfma) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof);
         else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof);
+    }
+    else if(L.accLines && !L.hrtf)
+    {   // (the measurement variant of these: the same kernel with PROF)
+        if(prof) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, true, DeviceLayout, 6>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, false, DeviceLayout, 6>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
+    }
+    else if(L.accLines && L.hrtf)
+    {
+        if(prof) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, true, DeviceLayout, 4>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, false, DeviceLayout, 4>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
     }
     else if(prof && !L.hrtf)
     {
@@ -1168,5 +1337,6 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     }
     return hipGetLastError();
 }
+#endif
 
 } // namespace oalgpu

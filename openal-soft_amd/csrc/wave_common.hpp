@@ -15,6 +15,9 @@ constexpr int kWThreads = kWWaves * 64;
 constexpr int kTabPairs = 24;                 // staged resampler rows: up to 48 taps (matrix-pipe kernels: 12, see WgLds)
 
 constexpr int kPre = 17;                      // prefetched source samples per lane (17*64 = 1088)
+#ifndef OALGPU_EXP_NORESAMPLE
+#define OALGPU_EXP_NORESAMPLE false
+#endif
 
 // ---- scalar-cache views of the per-voice control block and the buffer table -------------------
 // VoiceCtl (kernels.hpp) in two pieces: the head (bytes 0..47: everything needed to locate and
@@ -425,6 +428,109 @@ __device__ __forceinline__ void ResampleRunBlock(const f2 *tabF, const f2 *tabP,
     }
 }
 
+// ---- resampler, staged rows, a ring of register sets ----------------------------------------------------------------
+// The same outputs as ResampleRunStaged (lane, lane + 64, ...) for the kernels that also hold line accumulators in
+// registers: the taps of an output go in groups of NP <= 6 pairs through a RING of SETS register sets -- while one group
+// is multiplied the reads of the next SETS - 1 groups are in flight (SETS = 3: 36 reads, as many as ResampleRunStaged
+// keeps outstanding with its two complete outputs, in 108 registers instead of 144).  The loop is unrolled over
+// lcm(G, SETS) groups so that every set and tap group has a static index.  Source pairs come as aligned 8-byte reads
+// out of rd / rd2 when the window was parked twice (DUAL).  Outputs past bdst go to `sink`; their look-ahead reads are
+// clamped to the last output's position.
+template<int M, int SETS, bool DUAL>
+__device__ __forceinline__ void ResampleRunRing(const f2 *tabF, const f2 *tabP, const float *rdb, uint32_t frac0,
+    uint32_t increment, uint32_t bdst, float *out, float *sink, uint32_t lane, const float *rd2b, uint32_t rdbIndex)
+{
+    constexpr int NP = (M / 2 >= 6) ? 6 : M / 2;
+    constexpr int G = (M / 2) / NP;               // 1 (cubic, bsinc12), 2 (bsinc24), 4 (bsinc48)
+    constexpr int U = (G % SETS == 0) ? G : ((SETS % G == 0) ? SETS : G * SETS);      // lcm for G in {1, 2, 4}, SETS in {2, 3}
+    static_assert(U % G == 0 && U % SETS == 0, "the unrolled body covers whole outputs and whole turns of the ring");
+    f2 F[SETS][NP], P[SETS][NP], S[SETS][NP];
+    const uint32_t tstep = 64u * increment;
+    const uint32_t tlast = frac0 + (bdst - 1u) * increment;
+    const uint32_t nOut = (bdst + 63u) / 64u;
+    auto load = [&](int set, uint32_t tt, int g)
+    {
+        tt = tt < tlast ? tt : tlast;
+        const uint32_t pi = (tt >> 11) & 31u;
+        const f2 *tf = tabF + pi, *tp = tabP + pi;
+        const uint32_t pos = tt >> kFracBits;
+#pragma unroll
+        for(int q = 0; q < NP; ++q)
+        {
+            F[set][q] = tf[(g * NP + q) * 32];
+            P[set][q] = tp[(g * NP + q) * 32];
+        }
+        if constexpr (DUAL)
+        {
+            const bool odd = ((rdbIndex + pos) & 1u) != 0u;
+            const f2 *sp = reinterpret_cast<const f2*>(odd ? rd2b + pos - 1u : rdb + pos);
+#pragma unroll
+            for(int q = 0; q < NP; ++q) S[set][q] = sp[g * NP + q];
+        }
+        else
+        {
+            const float *s = rdb + pos;
+#pragma unroll
+            for(int q = 0; q < NP; ++q) S[set][q] = f2{s[2 * (g * NP + q)], s[2 * (g * NP + q) + 1]};
+        }
+    };
+    uint32_t tb = frac0 + lane * increment;       // time of the output the unrolled body starts with
+    // prologue: groups 0 .. SETS-2
+#pragma unroll
+    for(int j = 0; j < SETS - 1; ++j) load(j % SETS, tb + uint32_t(j / G) * tstep, j % G);
+#pragma unroll 1
+    for(uint32_t ob = 0; ob < nOut; ob += uint32_t(U / G))
+    {
+        f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
+#pragma unroll
+        for(int u = 0; u < U; ++u)
+        {
+            constexpr int dummy = 0; (void)dummy;
+            const int ahead = u + SETS - 1;
+            load(ahead % SETS, tb + uint32_t(ahead / G) * tstep, ahead % G);
+            const uint32_t tt = tb + uint32_t(u / G) * tstep;
+            const f2 pf = splat(float(tt & 2047u) * (1.0f / 2048.0f));
+            if(u % G == 0) { r0 = f2{0.0f, 0.0f}; r1 = f2{0.0f, 0.0f}; }
+#pragma unroll
+            for(int q = 0; q < NP; ++q)
+            {
+                const f2 c = pkfma(pf, P[u % SETS][q], F[u % SETS][q]);
+                if(q & 1) r1 = pkfma(c, S[u % SETS][q], r1);
+                else r0 = pkfma(c, S[u % SETS][q], r0);
+            }
+            if(u % G == G - 1)
+            {
+                const uint32_t k = (ob + uint32_t(u / G)) * 64u + lane;
+                float *dst = (k < bdst) ? out + k : sink;
+                *dst = (r0.x + r0.y) + (r1.x + r1.y);
+            }
+        }
+        tb += uint32_t(U / G) * tstep;
+    }
+}
+
+#ifndef OALGPU_RING_SETS
+#define OALGPU_RING_SETS 2
+#endif
+template<class SM>
+__device__ __forceinline__ void ResampleRunRingM(const SM &sm, const float *rdb, uint32_t m, uint32_t frac0, uint32_t increment,
+    uint32_t bdst, float *out, float *sink, uint32_t lane, const float *rd2b, uint32_t rdbIndex)
+{
+    constexpr int SETS = OALGPU_RING_SETS;
+    if(rd2b)
+    {
+        if(m == 24) { ResampleRunRing<24, SETS, true>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane, rd2b, rdbIndex); return; }
+        if(m == 12) { ResampleRunRing<12, SETS, true>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane, rd2b, rdbIndex); return; }
+    }
+    switch(m)
+    {
+    case 4: ResampleRunRing<4, SETS, false>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane, nullptr, 0u); break;
+    case 12: ResampleRunRing<12, SETS, false>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane, nullptr, 0u); break;
+    case 24: ResampleRunRing<24, SETS, false>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane, nullptr, 0u); break;
+    default: ResampleRunRing<48, SETS, false>(sm.tabF, sm.tabP, rdb, frac0, increment, bdst, out, sink, lane, nullptr, 0u); break;
+    }
+}
+
 template<int NT, class SM>
 __device__ __forceinline__ void ResampleRunBlockM(const SM &sm, const float *rdb, uint32_t m, uint32_t frac0,
     uint32_t increment, uint32_t bdst, float *out, uint32_t tid)
@@ -550,23 +656,32 @@ __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const LT &L,
         if constexpr (PROF) { if(prof.times && lane == 0 && loaded == 0) prof.times[size_t{v} * 8 + 7] = __builtin_readcyclecounter(); }
 
         // voice.cpp:764-769
-        if((increment == kFracOne && fracPos == 0) || (PROF && (prof.ablate & 2u)))
+        if((increment == kFracOne && fracPos == 0) || (PROF && (prof.ablate & 2u)) || OALGPU_EXP_NORESAMPLE)
         {
             for(uint32_t k = lane; k < bdst; k += 64) mixing[loaded + k] = srcBuffer[k];
         }
+#if defined(OALGPU_EXP_NOSTAGED)
+        else if(false)
+#else
         else if(staged)
+#endif
         {
+            // (the first chunk of a prefetched window is in rd AND rd2)
+            const bool dual = plan.prefetch && loaded == 0;
             if constexpr (LEAN)
-                ResampleRunBlockM<64>(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded, lane);
+                ResampleRunRingM(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded,
+                    reinterpret_cast<float*>(&w.pad[0]), lane, dual ? w.rd2 + (kMaxEdge - sL) : nullptr, uint32_t(kMaxEdge) - sL);
             else
             {
-                // (the first chunk of a prefetched window is in rd AND rd2)
-                const bool dual = plan.prefetch && loaded == 0;
                 ResampleRunStagedM(sm, rdata + (kMaxEdge - sL), sM, fracPos, increment, bdst, mixing + loaded,
                     reinterpret_cast<float*>(&w.pad[0]), lane, dual ? w.rd2 + (kMaxEdge - sL) : nullptr, uint32_t(kMaxEdge) - sL);
             }
         }
+#if defined(OALGPU_EXP_NOGENERIC)
+        else if(false)
+#else
         else
+#endif
         {
             const TabLayout lay = ReferenceTabLayout(rsM);
             for(uint32_t k = lane; k < bdst; k += 64)
