@@ -184,6 +184,9 @@ typedef struct oalgpu_context_desc {
 #define OALGPU_CTX_STREAM_ROWS 8u  /* FAST dry-line / send contexts with <= 8 mix lines: leave stream rows in HBM and mix them in the
                                    * voice kernel's tail (the path of contexts with more lines) instead of accumulating the
                                    * lines in the wavefronts' registers: for A/B runs and tests of the row path */
+#define OALGPU_CTX_EAGER    16u   /* oalgpu_mix_update launches at once.  By default a pipelined HRTF context submits an update with the
+                                   * NEXT library call on the context: when that is oalgpu_param_block_apply, the update's voice kernel
+                                   * installs the block itself and no parameter kernel stands between two voice kernels */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 

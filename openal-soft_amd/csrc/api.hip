@@ -108,6 +108,10 @@ struct oalgpu_context {
     hipEvent_t evVoiceDone[2]{nullptr, nullptr}, evReduceDone[2]{nullptr, nullptr}, evPostDone{nullptr};
     uint32_t parity{0};
     bool postPending{false};
+    // A pipelined oalgpu_mix_update is SUBMITTED one library call late: if that next call is oalgpu_param_block_apply, the block's
+    // records are installed by the update's own voice kernel -- every wavefront applies the records of the voices it has just
+    // mixed, in its epilogue -- and neither ApplyParamsKernel nor its two dispatch gaps stand between two voice kernels.
+    struct { bool active{false}; uint32_t samples{0}; int post{0}; } pendingMix;
     // the pipelined host boundary (oalgpu_voice_move_async / oalgpu_read_output_async): pinned ring slots
     static constexpr uint32_t kIoSlots = 4;
     MoveRecord *panHost[kIoSlots]{};
@@ -175,7 +179,17 @@ struct oalgpu_context {
     DevBuf<uint8_t> hEvCount, hDelays;
     DevBuf<uint16_t> hAzCount, hIrOffset;
     // DirectHrtfState
-    DevBuf<SplitterState> dSplit;
+    DevBuf<SplitterState> dSplit, dSplit2;  // the post-process's splitter states; the fused FAST post-process reads one and files the other
+    uint32_t dSplitCur{0};                  // which of the two holds the current states
+    DevBuf<float> carryBuf;                 // HrtfAccumData as the fused post-process leaves it (1152 x 2): the next reduction's carry
+    float dSplitCoeff{0.0f};                // the splitters' coefficient (one crossover for all channels) ...
+    float runPower[4]{1.0f, 0.0f, 1.0f, 1.0f};  // ... and their transition over a run of runPowerSeg samples (SplitterRunPowers)
+    uint32_t runPowerSeg{0};
+    DevBuf<uint32_t> postArrived;           // the fused post-process's channel counter (only ever grows) ...
+    uint32_t postEpoch{0};                  // ... and the value it has reached after the last launch
+    const ParamRecord *nextRecs{nullptr};   // the block the voice kernel being launched installs in its epilogue (RunMixUpdate)
+    const int32_t *nextMap{nullptr};
+    bool carryInBuf{false};                 // the carried accumulator is in carryBuf (else: in the bus block's accumulator region)
     DevBuf<float> dHfScale, dCoeffs, dTemp;
     uint32_t dIrSize{0};
     bool directSet{false};
@@ -218,6 +232,14 @@ struct oalgpu_context {
         if(stream && ownStream) (void)hipStreamDestroy(stream);
     }
 };
+
+static int FlushPendingMix(oalgpu_context *c, struct oalgpu_param_block *next = nullptr);
+// every entry point that enqueues work on a context or reads its state goes through here: the device, and the deferred update
+static int UseCtx(oalgpu_context *c)
+{
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    return FlushPendingMix(c);
+}
 
 namespace {
 
@@ -464,7 +486,7 @@ int oalgpu_comm_init(oalgpu_context *c, const void *unique_id, size_t size, int 
     if(!c->cbVoices.empty()) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init: not on a context with callback sources");
     RcclApi &a = Rccl();
     if(!a.ok) return Fail(OALGPU_ERR_NO_DEVICE, a.why);
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof(id));
@@ -485,7 +507,7 @@ int oalgpu_comm_init_host(oalgpu_context *c, const char *name, int rank, int wor
         return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: bad arguments");
     if(c->comm) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: the context already has a communicator");
     if(!c->cbVoices.empty()) return Fail(OALGPU_ERR_INVALID, "oalgpu_comm_init_host: not on a context with callback sources");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     auto t = std::make_unique<HostTransport>();
     t->name = name; t->rank = rank; t->world = world;
@@ -1017,6 +1039,9 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.hrtfOld = nullptr; L.hrtfTgt = nullptr;
 
     HIP_TRY(c->dSplit.alloc(L.numDry)); HIP_TRY(c->dSplit.zero());
+    HIP_TRY(c->dSplit2.alloc(L.numDry)); HIP_TRY(c->dSplit2.zero());
+    HIP_TRY(c->carryBuf.alloc(size_t{kLine + kHrirLen} * 2)); HIP_TRY(c->carryBuf.zero());
+    HIP_TRY(c->postArrived.alloc(1)); HIP_TRY(c->postArrived.zero());
     HIP_TRY(c->dHfScale.alloc(L.numDry)); HIP_TRY(c->dHfScale.zero());
     HIP_TRY(c->dCoeffs.alloc(size_t{L.numDry} * kHrirLen * 2)); HIP_TRY(c->dCoeffs.zero());
     HIP_TRY(c->dTemp.alloc(size_t{L.numDry} * kLine + (kLine + kHrirLen) * 2));
@@ -1028,6 +1053,7 @@ void oalgpu_context_destroy(oalgpu_context *ctx)
 {
     if(!ctx) return;
     (void)hipSetDevice(ctx->desc.device);
+    (void)FlushPendingMix(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if(ctx->postStream) (void)hipStreamSynchronize(ctx->postStream);
     delete ctx->comm;
@@ -1097,7 +1123,7 @@ static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
 int oalgpu_hrtf_load_mhr(oalgpu_context *c, const void *data, size_t size)
 {
     if(!c || !data) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     HrtfData parsed;
     const std::string err = ParseMhr(data, size, parsed);
     if(!err.empty()) return Fail(OALGPU_ERR_INVALID, "mhr: " + err);
@@ -1125,7 +1151,7 @@ int oalgpu_hrtf_load_store(oalgpu_context *c, uint32_t sample_rate, uint32_t ir_
     for(uint32_t e = 0; e < num_elevs; ++e)
         if(elev_azcount[e] == 0 || uint32_t(elev_iroffset[e]) + elev_azcount[e] > num_irs)
             return Fail(OALGPU_ERR_INVALID, "oalgpu_hrtf_load_store: an elevation's HRIRs lie outside the store");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     HrtfData h;
     h.sampleRate = sample_rate; h.irSize = ir_size;
     h.fieldDistance.assign(field_distance, field_distance + num_fields);
@@ -1167,7 +1193,7 @@ int oalgpu_hrtf_get_coeffs(oalgpu_context *c, const float *dirs, size_t count, f
 {
     if(!c || !dirs || !coeffs || !delays || count == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_hrtf_get_coeffs: bad arguments");
     if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "no HRTF data set loaded");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     DevBuf<float> dDirs, dCo;
     DevBuf<uint32_t> dDel;
     HIP_TRY(dDirs.alloc(count * 4)); HIP_TRY(dDirs.upload(dirs, count * 4));
@@ -1185,11 +1211,15 @@ int oalgpu_set_direct_hrtf(oalgpu_context *c, const float *chan_coeffs, const fl
     uint32_t irsize)
 {
     if(!c || !chan_coeffs || !hfscales || irsize < 8 || irsize > kHrirLen) return Fail(OALGPU_ERR_INVALID, "oalgpu_set_direct_hrtf: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     const uint32_t nd = c->L.numDry;
     std::vector<SplitterState> sp(nd);
     for(auto &s : sp) { s.coeff = SplitterCoeff(xover_norm); s.lpZ1 = s.lpZ2 = s.apZ1 = 0.0f; }
+    if(int rc = oalgpu_sync(c)) return rc;
     HIP_TRY(c->dSplit.upload(sp.data(), nd));
+    HIP_TRY(c->dSplit2.upload(sp.data(), nd));
+    c->dSplitCur = 0;
+    c->dSplitCoeff = SplitterCoeff(xover_norm); c->runPowerSeg = 0;
     HIP_TRY(c->dHfScale.upload(hfscales, nd));
     {   // MixDirectHrtf applies IrSize taps (rounded up to even: ApplyCoeffs works on pairs); the decoder of a resampled
         // data set carries non-zero taps beyond that, which the fixed-length FIR of the FAST post-process must not see
@@ -1293,7 +1323,7 @@ int oalgpu_buffer_register(oalgpu_context *c, const void *data, int fmt_type, ui
         || loop_end > sample_len || loop_start >= (loop_end ? loop_end : 1u))
         return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_register: bad arguments");
     if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     const size_t nbytes = size_t{sample_len} * frame_step * bytesPer[fmt_type];
     void *dev = nullptr;
     HIP_TRY(hipMalloc(&dev, nbytes + 16));
@@ -1309,6 +1339,7 @@ int oalgpu_buffer_register(oalgpu_context *c, const void *data, int fmt_type, ui
 
 int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc *d)
 {
+    if(c) { if(int rc = FlushPendingMix(c)) return rc; }
     if(!c || !d || voice >= c->L.numVoices || d->buffer < 0 || uint32_t(d->buffer) >= c->numBuffers
         || d->position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: bad arguments");
@@ -1329,7 +1360,7 @@ int oalgpu_buffer_queue_link(oalgpu_context *c, int buffer, int next_buffer)
 {
     if(!c || buffer < 0 || uint32_t(buffer) >= c->numBuffers || next_buffer >= int(c->numBuffers))
         return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_queue_link: bad buffer");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     const int32_t next = next_buffer < 0 ? 0 : next_buffer + 1;
     HIP_TRY(hipMemcpy(reinterpret_cast<char*>(c->buffers.p + buffer) + offsetof(BufferItem, next), &next, sizeof(next),
@@ -1340,6 +1371,7 @@ int oalgpu_buffer_queue_link(oalgpu_context *c, int buffer, int next_buffer)
 int oalgpu_voice_init_queue(oalgpu_context *c, uint32_t voice, int first_buffer, int looping, int32_t position,
     uint32_t position_frac)
 {
+    if(c) { if(int rc = FlushPendingMix(c)) return rc; }
     if(!c || voice >= c->L.numVoices || first_buffer < 0 || uint32_t(first_buffer) >= c->numBuffers || position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_queue: bad arguments");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
@@ -1354,7 +1386,7 @@ int oalgpu_voice_queue_state(oalgpu_context *c, uint32_t voice, int32_t *current
 {
     if(!c || voice >= c->L.numVoices || !current_buffer || !buffers_done)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_queue_state: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     HIP_TRY(hipMemcpy(current_buffer, &c->ctl.p[voice].curBuffer, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1373,7 +1405,7 @@ int oalgpu_buffer_register_adpcm(oalgpu_context *c, const void *data, int adpcm_
         || samples_per_block < (adpcm_type == OALGPU_ADPCM_MS ? 3u : 2u) || samples_per_block > 65536u)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_register_adpcm: bad arguments");
     if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     const uint32_t numBlocks = (sample_len + samples_per_block - 1u) / samples_per_block;
     const size_t blockBytes = adpcm_type == OALGPU_ADPCM_MS ? size_t{(samples_per_block - 2u) / 2u + 7u} * channels
         : size_t{(samples_per_block - 1u) / 2u + 4u} * channels;
@@ -1406,7 +1438,7 @@ int oalgpu_voice_set_start_delay(oalgpu_context *c, uint32_t voice, uint32_t sam
     if(c->cbOfVoice[voice] >= 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_start_delay: not for callback voices");
     if(samples >= c->desc.sample_rate)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_start_delay: a start a second or more ahead is not scheduled yet (voice.cpp:1036-1038)");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     LaunchSetStartDelay(c->stream, c->L, voice, samples);
     HIP_TRY(hipGetLastError());
@@ -1417,7 +1449,7 @@ int oalgpu_voice_set_ambi_scale(oalgpu_context *c, uint32_t voice, float xover_n
 {
     if(!c || voice >= c->L.numVoices || !(xover_norm > 0.0f) || !(xover_norm < 0.5f))
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_ambi_scale: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     AmbiScaleState st{};
     st.coeff = SplitterCoeff(xover_norm);
@@ -1437,7 +1469,7 @@ int oalgpu_context_set_nfc(oalgpu_context *c, float w1, const uint32_t channels_
     if(channels_per_order[0] != 1) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: channels_per_order[0] must be 1 (W)");
     for(uint32_t o = 1; o < 5 && channels_per_order[o]; ++o) { lines += channels_per_order[o]; ++orders; }
     if(orders == 0 || lines > c->L.numDry) return Fail(OALGPU_ERR_INVALID, "oalgpu_context_set_nfc: orders do not fit the dry bus");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     DeviceLayout &L = c->L;
     const size_t nv = L.numVoices;
@@ -1461,7 +1493,7 @@ int oalgpu_voice_set_nfc(oalgpu_context *c, uint32_t voice, float w0)
 {
     if(!c || voice >= c->L.numVoices || !(w0 >= 0.0f)) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_nfc: bad arguments");
     if(!c->L.nfc) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_nfc: oalgpu_context_set_nfc first");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     NfcDesign d = c->nfcDevice;                  // chandata.NFCtrlFilter = device->mNFCtrlFilter, then adjust(w0)
     NfcAdjust(w0, d);
@@ -1477,7 +1509,7 @@ int oalgpu_buffer_channel_view(oalgpu_context *c, int buffer, uint32_t channel)
 {
     if(!c || buffer < 0 || uint32_t(buffer) >= c->numBuffers) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_channel_view: bad buffer");
     if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     static const size_t bytesPer[7] = {1, 2, 4, 4, 8, 1, 1};
     BufferItem item{};
     HIP_TRY(hipMemcpy(&item, c->buffers.p + buffer, sizeof(item), hipMemcpyDeviceToHost));
@@ -1543,7 +1575,7 @@ int oalgpu_voice_set_params(oalgpu_context *c, const uint32_t *voices, const oal
     if(!c || !voices || !params) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(count == 0) return OALGPU_OK;
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(int rc = BuildParamRecords(c, voices, params, count, c->paramHost)) return rc;
     NoteCallbackSteps(c, voices, params, count);
@@ -1564,7 +1596,7 @@ int oalgpu_voice_set_hrtf_targets(oalgpu_context *c, const uint32_t *voices, con
     if(count == 0) return OALGPU_OK;
     if(!c->L.hrtf) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_hrtf_targets: HRTF contexts only");
     if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     std::vector<TargetRecord> recs(count);
     for(size_t i = 0; i < count; ++i)
@@ -1588,6 +1620,9 @@ struct oalgpu_param_block {
     uint32_t count{0};
     int device{0};
     uint32_t hrtfGeneration{0};                             // of the store the records' HRIR indices and weights were taken from
+    DevBuf<int32_t> voiceToRec;                             // [voice of the context] -> index of its record in the block, or -1: how a
+                                                            // voice kernel's wavefront finds the records of the voices it mixed
+    uint32_t mapVoices{0};
     std::vector<std::pair<uint32_t, uint32_t>> cbSteps;     // (voice, mStep) of the callback voices in the block
 };
 
@@ -1598,7 +1633,7 @@ int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const o
     *out = nullptr;
     // the records carry the index half of getCoeffs, evaluated now against the loaded store
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "oalgpu_param_block_create: HRTF context without a data set");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     std::vector<ParamRecord> recs;
     if(int rc = BuildParamRecords(c, voices, params, count, recs)) return rc;
     auto b = std::make_unique<oalgpu_param_block>();
@@ -1607,6 +1642,17 @@ int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const o
     b->hrtfGeneration = c->hrtfGeneration;
     HIP_TRY(b->recs.alloc(count));
     HIP_TRY(b->recs.upload(recs.data(), count));
+    {
+        std::vector<int32_t> map(c->L.numVoices, -1);
+        bool unique = true;
+        for(size_t i = 0; i < count; ++i) { unique = unique && map[voices[i]] < 0; map[voices[i]] = int32_t(i); }
+        if(unique)      // (a block that names a voice twice is applied by ApplyParamsKernel, record by record)
+        {
+            HIP_TRY(b->voiceToRec.alloc(map.size()));
+            HIP_TRY(b->voiceToRec.upload(map.data(), map.size()));
+            b->mapVoices = uint32_t(map.size());
+        }
+    }
     for(size_t i = 0; i < count; ++i)
         if(c->cbOfVoice[voices[i]] >= 0) b->cbSteps.emplace_back(voices[i], params[i].step);
     *out = b.release();
@@ -1619,10 +1665,18 @@ int oalgpu_param_block_apply(oalgpu_context *c, oalgpu_param_block *b)
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(c->L.hrtf && b->hrtfGeneration != c->hrtfGeneration)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_param_block_apply: the block was built against another HRTF data set (its HRIR indices are that store's); create it again");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(c->pendingMix.active && b->mapVoices == c->L.numVoices && WaveKernelAppliesRecords(c->L) && c->initPending.empty())
+    {   // the update submitted last has not been launched yet: its voice kernel installs this block (see pendingMix)
+        if(int rc = UseDevice(c->desc.device)) return rc;
+        if(int rc = FlushPendingMix(c, b)) return rc;
+    }
+    else
+    {
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     LaunchApplyParams(c->stream, c->L, b->recs.p, b->count);
     HIP_TRY(hipGetLastError());
+    }
     for(const auto &vs : b->cbSteps)
         if(vs.first < c->cbOfVoice.size() && c->cbOfVoice[vs.first] >= 0) c->cbVoices[size_t(c->cbOfVoice[vs.first])].step = vs.second;
     return OALGPU_OK;
@@ -1642,7 +1696,7 @@ int oalgpu_voice_move_async(oalgpu_context *c, const oalgpu_voice_move *pans, si
     if(!c->L.hrtf) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: HRTF contexts only");
     if(!c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(count > c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: more records than voices");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(c->panCap < count)
     {   // (grows only while nothing is in flight: the first call, or a larger batch than ever before)
@@ -1690,7 +1744,7 @@ static size_t OutputLineFloats(const oalgpu_context *c)
 int oalgpu_read_output_async(oalgpu_context *c, uint32_t *ticket)
 {
     if(!c || !ticket) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     const size_t floats = OutputLineFloats(c);
     if(c->outFloats != floats)
     {
@@ -1717,7 +1771,7 @@ int oalgpu_output_wait(oalgpu_context *c, uint32_t ticket, float *out, size_t ou
     if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(ticket >= c->outNext || c->outNext - ticket > oalgpu_context::kIoSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_output_wait: the ticket's slot was reused (four may be outstanding)");
     if(out_floats < c->outFloats) return Fail(OALGPU_ERR_INVALID, "oalgpu_output_wait: the buffer is smaller than the output lines");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     const uint32_t slot = ticket % oalgpu_context::kIoSlots;
     HIP_TRY(hipEventSynchronize(c->outDone[slot]));
     std::memcpy(out, c->outHost[slot], c->outFloats * sizeof(float));
@@ -1760,7 +1814,7 @@ int oalgpu_debug_pipelined_run(oalgpu_context *c, const oalgpu_voice_move *moves
 int oalgpu_set_stream(oalgpu_context *c, void *hip_stream)
 {
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if(c->postStream) HIP_TRY(hipStreamSynchronize(c->postStream));
     c->postPending = false;
@@ -1793,7 +1847,7 @@ static int UploadAmbiMap(DevBuf<AmbiMapEntry> &dst, size_t at, const uint8_t *in
 int oalgpu_context_set_ambi_map(oalgpu_context *c, const uint8_t *index, const float *scale)
 {
     if(!c || !index || !scale) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     return UploadAmbiMap(c->dryMap, 0, index, scale, c->L.numDry);
 }
@@ -1801,7 +1855,7 @@ int oalgpu_context_set_ambi_map(oalgpu_context *c, const uint8_t *index, const f
 int oalgpu_slot_set_ambi_map(oalgpu_context *c, uint32_t slot, const uint8_t *index, const float *scale)
 {
     if(!c || !index || !scale || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_ambi_map: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     return UploadAmbiMap(c->wetMaps, size_t{slot} * c->L.wetChannels, index, scale, c->L.wetChannels);
 }
@@ -1809,7 +1863,7 @@ int oalgpu_slot_set_ambi_map(oalgpu_context *c, uint32_t slot, const uint8_t *in
 int oalgpu_voice_set_pan(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_pan *pans, size_t count)
 {
     if(!c || !voices || !pans || count == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_pan: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     std::vector<PanRecord> recs(count);
     for(size_t i = 0; i < count; ++i)
@@ -1835,7 +1889,7 @@ int oalgpu_voice_set_state(oalgpu_context *c, uint32_t voice, int play_state)
 {
     if(!c || voice >= c->L.numVoices || play_state < OALGPU_VOICE_STOPPED || play_state > OALGPU_VOICE_PENDING)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_set_state: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     const int32_t st = play_state;
     HIP_TRY(hipMemcpyAsync(&c->ctl.p[voice].playState, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
@@ -1880,6 +1934,57 @@ static int RunEffects(oalgpu_context *c, hipStream_t s, uint32_t samples_to_do)
         if(++count == kRvBatchMax) { if(int rc = flush()) return rc; }
     }
     if(int rc = flush()) return rc;
+    return OALGPU_OK;
+}
+
+// Where the reduction finds the carried HrtfAccumData: in the bus block's accumulator region (in place: the serial post-process
+// and contexts that leave the post-process to their caller work there) or where the fused post-process filed it.
+static const float *CarrySource(oalgpu_context *c, bool carry)
+{
+    const float *src = nullptr;
+    if(carry && c->L.hrtf) src = c->carryInBuf ? c->carryBuf.p : c->L.bus + BusAccumOffset(c->L);
+    c->carryInBuf = false;                  // the reduction's result -- partial sums + carry -- is in the bus block again
+    return src;
+}
+
+// BandSplitter::processHfScale's state transition over a run of `seg` samples of silence (core/filters/splitter.cpp:65-97: the
+// recurrence SplitStep<true> of dev_wave.hpp, same operations): lower triangular in (lp_z1, lp_z2), decoupled in ap_z1 --
+// [[p, 0, 0], [q, r, 0], [0, 0, s]].  Data independent and the same for every channel: raised here, once per update size, instead
+// of by every wavefront that scans a channel.
+static void SplitterRunPowers(float coeff, uint32_t seg, float out[4])
+{
+    const float ap = coeff, lp = coeff * 0.5f + 0.5f;
+    float st[3][3] = {{1.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f}, {0.0f, 0.0f, 1.0f}};
+    for(uint32_t i = 0; i < seg; ++i)
+        for(auto &v : st)
+        {
+            const float d0 = (0.0f - v[0]) * lp;
+            const float lpY0 = v[0] + d0;
+            v[0] = std::fmaf(d0, lp, lpY0);
+            const float d1 = (lpY0 - v[1]) * lp;
+            const float lpY1 = v[1] + d1;
+            v[1] = lpY1 + d1;
+            const float apY = std::fmaf(0.0f, ap, v[2]);
+            v[2] = std::fmaf(-apY, ap, 0.0f);
+        }
+    out[0] = st[0][0]; out[1] = st[0][1]; out[2] = st[1][1]; out[3] = st[2][2];
+}
+
+// MixDirectHrtf of a FAST wavefront-kernel context in one launch (post_wave.hip): reads the bus block's accumulator, leaves the
+// shifted accumulator in carryBuf and the new splitter states in the other state buffer
+static int PostDirectHrtfFused(oalgpu_context *c, hipStream_t s, uint32_t samples_to_do, hipEvent_t evDone)
+{
+    const DeviceLayout &L = c->L;
+    float *left = L.bus + size_t{L.numDry} * kLine;
+    SplitterState *spIn = c->dSplitCur ? c->dSplit2.p : c->dSplit.p, *spOut = c->dSplitCur ? c->dSplit.p : c->dSplit2.p;
+    c->postEpoch += L.numDry;               // what the channel counter reads when this update's channels have all arrived
+    const uint32_t seg = ((samples_to_do + 63u) / 64u) | 1u;
+    if(c->runPowerSeg != seg) { SplitterRunPowers(c->dSplitCoeff, seg, c->runPower); c->runPowerSeg = seg; }
+    LaunchPostDirectHrtfFused(s, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->carryBuf.p, spIn, spOut,
+        c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, c->postEpoch, c->runPower, evDone);
+    HIP_TRY(hipGetLastError());
+    c->dSplitCur ^= 1u;
+    c->carryInBuf = true;
     return OALGPU_OK;
 }
 
@@ -1997,7 +2102,7 @@ int oalgpu_voice_init_callback(oalgpu_context *c, uint32_t voice, int fmt_type, 
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: bad arguments");
     if(c->comm) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_callback: not on a sharded context");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(c->cbOfVoice[voice] >= 0)
     {   // the voice is a callback source already: only one that has ended may start over
         if(c->cbVoices[size_t(c->cbOfVoice[voice])].state != OALGPU_VOICE_STOPPED)
@@ -2089,7 +2194,7 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(int rc = JoinPost(c)) return rc;
     if(!c->cbVoices.empty()) { if(int rc = ServiceCallbacks(c, samples_to_do)) return rc; }
@@ -2102,7 +2207,7 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
         if(c->timing) HIP_TRY(hipEventRecord(c->evVoice, c->stream));
     }
     // the wavefront kernel leaves the carried HRTF accumulator tail to the reduction
-    LaunchBusReduce(c->stream, c->L, samples_to_do, c->useWave && c->carryAccum);
+    LaunchBusReduce(c->stream, c->L, samples_to_do, CarrySource(c, c->useWave && c->carryAccum));
     HIP_TRY(hipGetLastError());
     if(int rc = CommReduceBus(c, c->stream)) return rc;
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
@@ -2112,7 +2217,7 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
 int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = JoinPost(c)) return rc;
     if(int rc = RunEffects(c, c->stream, samples_to_do)) return rc;
     if(!c->L.hrtf)
@@ -2131,20 +2236,48 @@ int oalgpu_post_process(oalgpu_context *c, uint32_t samples_to_do)
     if(L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
     float *left = L.bus + size_t{L.numDry} * kLine;
     float *right = left + kLine;
+    // (the wavefront-kernel contexts carry the accumulator through their reduction: the one-launch form; the others mix it in place)
+    SplitterState *spCur = c->dSplitCur ? c->dSplit2.p : c->dSplit.p;
     if(c->exact)
-        LaunchMixDirectHrtf(c->stream, true, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
+        LaunchMixDirectHrtf(c->stream, true, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), spCur,
             c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
+    else if(c->useWave) { if(int rc = PostDirectHrtfFused(c, c->stream, samples_to_do, nullptr)) return rc; }
     else
-        LaunchPostDirectHrtfFast(c->stream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
+        LaunchPostDirectHrtfFast(c->stream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), spCur,
             c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p);
     HIP_TRY(hipGetLastError());
     if(c->timing) { HIP_TRY(hipEventRecord(c->evEnd, c->stream)); c->timed = true; }
     return OALGPU_OK;
 }
 
+static int RunMixUpdate(oalgpu_context *c, uint32_t samples_to_do, int post_process, oalgpu_param_block *next);
+
 int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_process)
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
+    if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(int rc = UseCtx(c)) return rc;                // (submits the update deferred before this one)
+    if(c->useWave && c->ownStream && !c->serialOnly && !c->timing && !(c->desc.flags & OALGPU_CTX_EAGER) && WaveKernelAppliesRecords(c->L))
+    {   // submitted with the next library call on this context (see pendingMix); whatever goes wrong then is that call's error
+        c->pendingMix.active = true; c->pendingMix.samples = samples_to_do; c->pendingMix.post = post_process;
+        return OALGPU_OK;
+    }
+    return RunMixUpdate(c, samples_to_do, post_process, nullptr);
+}
+
+static int FlushPendingMix(oalgpu_context *c, oalgpu_param_block *next)
+{
+    if(!c->pendingMix.active) return OALGPU_OK;
+    c->pendingMix.active = false;
+    return RunMixUpdate(c, c->pendingMix.samples, c->pendingMix.post, next);
+}
+
+// next: a parameter block the update's voice kernel installs behind the voices it mixed (null: none)
+static int RunMixUpdate(oalgpu_context *c, uint32_t samples_to_do, int post_process, oalgpu_param_block *next)
+{
+    c->nextRecs = next ? next->recs.p : nullptr;
+    c->nextMap = next ? next->voiceToRec.p : nullptr;
+    struct Clear { oalgpu_context *c; ~Clear() { c->nextRecs = nullptr; c->nextMap = nullptr; } } clear{c};
     if(!(c->useWave && c->ownStream) || c->serialOnly)
     {   // one stream: the workgroup-per-voice-group kernel reads the carried accumulator itself,
         // and a caller-owned stream (RCCL ordering) is never forked
@@ -2177,7 +2310,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     if(!(c->useWave && c->ownStream))
         return Fail(OALGPU_ERR_INVALID, "oalgpu_mix_voices_overlapped: needs a FAST context (wavefront kernel) on its own streams");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(!c->cbVoices.empty()) { if(int rc = ServiceCallbacks(c, samples_to_do)) return rc; }
     const uint32_t p = c->parity;
@@ -2195,14 +2328,15 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     // (timing: the two events are bound to the dispatch itself -- the kernel's own start and end)
     // The event the post stream waits for is bound to the voice kernel's dispatch (hipExtLaunchKernel's stop event: one
     // runtime call less per update than a record behind the launch).  Timing runs use that slot for their own event.
-    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg(), c->timing ? c->evStart : nullptr, c->timing ? c->evVoice : c->evVoiceDone[p]));
+    HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg(), c->timing ? c->evStart : nullptr, c->timing ? c->evVoice : c->evVoiceDone[p],
+        c->nextRecs, c->nextMap));
     if(c->timing) HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
     // post stream: the reduction (adds the carried HRTF accumulator tail); whatever follows on that stream -- a collective, the effects, the post-process -- runs beside
     // the next update's parameter and voice kernels
     HIP_TRY(hipStreamWaitEvent(c->postStream, c->evVoiceDone[p], 0));
     // (4-wavefront workgroups: they find room on a CU as soon as ONE of the next update's voice workgroups
     // has left it; the 16-wavefront form waits for a whole CU -- measured 62 against 53 us per config-2 step)
-    LaunchBusReduce(c->postStream, L, samples_to_do, c->carryAccum && L.hrtf, true, c->evReduceDone[p]);
+    LaunchBusReduce(c->postStream, L, samples_to_do, CarrySource(c, c->carryAccum && L.hrtf), true, c->evReduceDone[p]);
     HIP_TRY(hipGetLastError());
     if(int rc = CommReduceBus(c, c->postStream)) return rc;      // beside the next update's voice kernel
     c->parity = p ^ 1u;
@@ -2217,18 +2351,14 @@ int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, in
     if(!(c->useWave && c->ownStream))
         return Fail(OALGPU_ERR_INVALID, "oalgpu_post_process_overlapped: needs a FAST context (wavefront kernel) on its own streams");
     if(post_process && c->L.hrtf && c->L.numReal < 2) return Fail(OALGPU_ERR_INVALID, "HRTF post-process needs two real output lines");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     const DeviceLayout &L = c->L;
     bool postDoneBound = false;
     if(post_process) { if(int rc = RunEffects(c, c->postStream, samples_to_do)) return rc; }
     if(post_process && L.hrtf)
     {
-        float *left = L.bus + size_t{L.numDry} * kLine;
-        float *right = left + kLine;
         // (the update's last launch on this stream, unless timing asks for an event of its own behind it: evPostDone rides on it)
-        LaunchPostDirectHrtfFast(c->postStream, left, right, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->dSplit.p,
-            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->timing ? nullptr : c->evPostDone);
-        HIP_TRY(hipGetLastError());
+        if(int rc = PostDirectHrtfFused(c, c->postStream, samples_to_do, c->timing ? nullptr : c->evPostDone)) return rc;
         postDoneBound = !c->timing;
     }
     if(post_process && !L.hrtf && c->decOn)
@@ -2246,7 +2376,7 @@ int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, in
 int oalgpu_sync(oalgpu_context *c)
 {
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if(c->postStream) HIP_TRY(hipStreamSynchronize(c->postStream));
     c->postPending = false;
@@ -2267,7 +2397,7 @@ int oalgpu_set_bformat_decoder(oalgpu_context *c, uint32_t num_out, const float 
 {
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(c->L.hrtf) return Fail(OALGPU_ERR_INVALID, "oalgpu_set_bformat_decoder: an HRTF context post-processes with MixDirectHrtf");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     if(num_out == 0 || !coeffs_hf) { c->decOn = false; return OALGPU_OK; }
     if(num_out > c->L.numReal || num_out > 32u)
@@ -2296,6 +2426,7 @@ int oalgpu_set_bformat_decoder(oalgpu_context *c, uint32_t num_out, const float 
 /* the device's output format: DevFmtType (core/devformat.h:56-64), DitherDepth / DitherSeed (alc/alc.cpp) */
 int oalgpu_set_output(oalgpu_context *c, int sample_type, float dither_depth, uint32_t dither_seed)
 {
+    if(c) { if(int rc = FlushPendingMix(c)) return rc; }
     if(!c || sample_type < OALGPU_OUT_I8 || sample_type > OALGPU_OUT_F32 || dither_depth < 0.0f)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_set_output: bad arguments");
     c->outType = sample_type; c->ditherDepth = dither_depth; c->ditherSeed = dither_seed;
@@ -2309,7 +2440,7 @@ int oalgpu_read_output(oalgpu_context *c, void *out, uint32_t samples_to_do, uin
     static const size_t bytesPer[7] = {1, 1, 2, 2, 4, 4, 4};
     if(!c || !out || samples_to_do == 0 || samples_to_do > kLine || frame_step == 0 || frame_step > 64)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_read_output: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = JoinPost(c)) return rc;
     const DeviceLayout &L = c->L;
     // RealOut: the real output lines, or the dry lines themselves where the device has none (core/device.h:300)
@@ -2343,12 +2474,14 @@ int oalgpu_read_hrtf_accum(oalgpu_context *c, float *out)
 {
     if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
     if(int rc = oalgpu_sync(c)) return rc;
-    HIP_TRY(hipMemcpy(out, c->L.bus + BusAccumOffset(c->L), size_t{kLine + kHrirLen} * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    // HrtfAccumData as the last update left it: shifted by the post-process (the fused one files it in carryBuf)
+    HIP_TRY(hipMemcpy(out, c->carryInBuf ? c->carryBuf.p : c->L.bus + BusAccumOffset(c->L), size_t{kLine + kHrirLen} * 2 * sizeof(float), hipMemcpyDeviceToHost));
     return OALGPU_OK;
 }
 
 int oalgpu_bus_device_ptr(oalgpu_context *c, void **ptr, size_t *nfloats, void **hip_stream)
 {
+    if(c) { if(int rc = FlushPendingMix(c)) return rc; }
     if(!c || !ptr || !nfloats) return Fail(OALGPU_ERR_INVALID, "null argument");
     *ptr = c->L.bus;
     *nfloats = BusFloats(c->L);
@@ -2360,7 +2493,7 @@ int oalgpu_bus_device_ptr(oalgpu_context *c, void **ptr, size_t *nfloats, void *
 int oalgpu_voice_readback(oalgpu_context *c, uint32_t v, oalgpu_voice_state *out)
 {
     if(!c || !out || v >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_readback: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     const DeviceLayout &L = c->L;
@@ -2399,7 +2532,7 @@ int oalgpu_voices_readback(oalgpu_context *c, const uint32_t *voices, size_t cou
 {
     if(!c || !voices || !out) return Fail(OALGPU_ERR_INVALID, "oalgpu_voices_readback: null argument");
     if(count == 0) return OALGPU_OK;
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     // one copy of the control lines the voices span (128 bytes each), not one round trip per voice
@@ -2422,6 +2555,7 @@ int oalgpu_voices_readback(oalgpu_context *c, const uint32_t *voices, size_t cou
 
 int oalgpu_set_timing(oalgpu_context *c, int enable)
 {
+    if(c) { if(int rc = FlushPendingMix(c)) return rc; }
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
     c->timing = enable != 0;
     c->timed = false;
@@ -2442,7 +2576,7 @@ __global__ void EmptyKernel() {}
 int oalgpu_debug_event_floor_ms(oalgpu_context *c, uint32_t reps, float *ms)
 {
     if(!c || !ms || reps == 0 || reps > 4096) return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_event_floor_ms: bad arguments");
-    if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
     std::vector<float> each(reps);
     for(uint32_t r = 0; r < reps; ++r)
@@ -2533,6 +2667,7 @@ const char *oalgpu_voice_kernel_name(oalgpu_context *c)
  * (exactly one rank must, the one that runs the post-process on the reduced buses). */
 int oalgpu_set_carry_accum(oalgpu_context *c, int enable)
 {
+    if(c) { if(int rc = FlushPendingMix(c)) return rc; }
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
     c->carryAccum = enable != 0;
     return OALGPU_OK;

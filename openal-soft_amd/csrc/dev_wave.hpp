@@ -176,6 +176,64 @@ __device__ __forceinline__ void SplitterScanHfTri(SplitterState &st, float *buf,
     st.lpZ1 = __shfl(start.a, lastLane); st.lpZ2 = __shfl(start.b, lastLane); st.apZ1 = __shfl(start.c, lastLane);
 }
 
+// The same scan once more for the one place where its latency is on a critical path (the fused HRTF post-process, post_wave.hip):
+//   * the run's transition P = A^seg is data independent and the same for every channel: the HOST raises it (SplitterRunPowers,
+//     api.hip) -- three of the five serial passes over a run gone;
+//   * the scan over the lanes runs in the rows of 16 lanes by DPP row shifts with P, P^2, P^4, P^8, then three row carries with
+//     P^((lane & 15) + 1) through v_readlane (the construction of ScanLinear2): no LDS round trips (__shfl_up is ds_bpermute).
+__device__ __forceinline__ float DppRowShrF(float v, int d);
+__device__ __forceinline__ Tri3 TriMul(const Tri3 &a, const Tri3 &b)       // powers of one matrix: the product commutes
+{ return Tri3{a.p * b.p, __builtin_fmaf(a.q, b.p, a.r * b.q), a.r * b.r, a.s * b.s}; }
+__device__ __forceinline__ void SplitterScanHfDpp(SplitterState &st, float *buf, uint32_t n, float hf, uint32_t lane, Tri3 P)
+{
+    const float apCoeff = st.coeff, lpCoeff = st.coeff * 0.5f + 0.5f;
+    const uint32_t seg = ((n + 63u) / 64u) | 1u;
+    const uint32_t begin = lane * seg < n ? lane * seg : n;
+    const uint32_t end = (begin + seg < n) ? begin + seg : n;
+    Sp3 e{0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for(uint32_t i = begin; i < end; ++i) SplitStep<true>(e, buf[i], apCoeff, lpCoeff, hf, 1.0f);
+    const Sp3 s0{st.lpZ1, st.lpZ2, st.apZ1};
+    {   // lane 0's run starts from the filter's state: the scan carries it along
+        const Sp3 ms = TriVec(P, s0);
+        if(lane == 0u) { e.a += ms.a; e.b += ms.b; e.c += ms.c; }
+    }
+    Tri3 pw = P, Q{1.0f, 0.0f, 1.0f, 1.0f};
+    const uint32_t exp = (lane & 15u) + 1u;
+#pragma unroll
+    for(int step = 0; step < 4; ++step)
+    {
+        const int d = 1 << step;
+        const Sp3 o{DppRowShrF(e.a, d), DppRowShrF(e.b, d), DppRowShrF(e.c, d)};     // 0 where the source lies in another row
+        const Sp3 mo = TriVec(pw, o);
+        e.a += mo.a; e.b += mo.b; e.c += mo.c;
+        const Tri3 qn = TriMul(pw, Q);
+        if(exp & uint32_t(d)) Q = qn;
+        pw = TriMul(pw, pw);
+    }
+    if(exp == 16u) Q = pw;                              // P^16
+#pragma unroll
+    for(int r = 1; r < 4; ++r)
+    {
+        const Sp3 c{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.a), 16 * r - 1)),
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.b), 16 * r - 1)),
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.c), 16 * r - 1))};
+        const Sp3 mc = TriVec(Q, c);
+        if((lane >> 4) == uint32_t(r)) { e.a += mc.a; e.b += mc.b; e.c += mc.c; }
+    }
+    // the run's start state: the end state of the lane before (wave_shr:1; lane 0 keeps the filter's state)
+    Sp3 start;
+    start.a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, s0.a), __builtin_bit_cast(int, e.a), 0x138, 0xF, 0xF, false));
+    start.b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, s0.b), __builtin_bit_cast(int, e.b), 0x138, 0xF, 0xF, false));
+    start.c = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, s0.c), __builtin_bit_cast(int, e.c), 0x138, 0xF, 0xF, false));
+#pragma unroll 1
+    for(uint32_t i = begin; i < end; ++i) buf[i] = SplitStep<true>(start, buf[i], apCoeff, lpCoeff, hf, 1.0f);
+    const int lastLane = int((n - 1u) / seg);
+    st.lpZ1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.a), lastLane));
+    st.lpZ2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.b), lastLane));
+    st.apZ1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, start.c), lastLane));
+}
+
 // ---- dual-ear FIR, packed over the ears -------------------------------------------------------
 // acc[r] = (L,R) of output frame R*lane + r.  xw points at the x' entry of the lane's first
 // frame; co16[b] = taps 8b..8b+7 as (Coeffs[j][0], Coeffs[j][1]) pairs, one s_load_dwordx16
@@ -322,6 +380,7 @@ __device__ __forceinline__ float DppRowShr(float v, int d)
     }
     return __builtin_bit_cast(float, r);
 }
+__device__ __forceinline__ float DppRowShrF(float v, int d) { return DppRowShr(v, d); }
 // the in-row part alone: E_l = sum over the lanes k <= l OF THE SAME ROW of 16 -- four independent scans per wavefront
 // (the EAX reverb runs one of its four lines per row); q0/q1 return M^((lane & 15) + 1) for a caller that chains rows
 __device__ __forceinline__ S2 ScanLinear2Row(S2 e, S2 m0, S2 m1, uint32_t lane, S2 &q0, S2 &q1)

@@ -244,6 +244,11 @@ void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const fl
     SplitterState *splitters, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n, float *temp,
     hipEvent_t evDone = nullptr);
 
+// the same as ONE launch (pipelined FAST HRTF contexts): see post_wave.hip
+void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
+    const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
+    float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone = nullptr);
+
 // ---- launchers (output_kernels.hip): BFormatDec, ApplyDither, Write<T> behind the buses ----
 // gainsHf / gainsLf: [dry line][32] (column = output line); gainsLf null = single-band decoder; bands =
 // scratch for [dry line][hp | lp][1024]
@@ -352,7 +357,9 @@ void LaunchApplyTargets(hipStream_t s, const DeviceLayout &L, const TargetRecord
 hipError_t LaunchVoiceMix(hipStream_t s, bool exact, const DeviceLayout &L, uint32_t samplesToDo, bool carryAccum);
 // besideVoiceKernel: the post-stream shape (4-wave workgroups of <= 32 VGPRs that fit on a CU next to
 // the wavefront voice kernel's two workgroups)
-void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, bool addCarry, bool besideVoiceKernel = false,
+// carry: the carried HrtfAccumData (1152 x 2) added to the voices' partial sums -- the bus's own accumulator region (in place) or
+// the buffer the fused post-process left it in; null: none
+void LaunchBusReduce(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const float *carry, bool besideVoiceKernel = false,
     hipEvent_t evDone = nullptr);
 
 // ---- launchers (voice_wave.hip): the FAST HRTF hot path, one wavefront per voice ----
@@ -377,7 +384,10 @@ uint32_t WaveKernelGroups(const DeviceLayout &L);
 // the measurement variant's extras (OALGPU_CTX_PROFILE, tools/phase_times.py): s_memtime stamps
 // [voice][8] | [wavefront][4], and the stages to skip; production launches pass null
 struct WaveProf { unsigned long long *times; uint32_t ablate; };
+// nextRecs / nextMap: a parameter block every wavefront installs for the voices it mixed, in its epilogue (null: none; only
+// the kernels WaveKernelAppliesRecords names)
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof = nullptr,
-    hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
+    hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const ParamRecord *nextRecs = nullptr, const int32_t *nextMap = nullptr);
+bool WaveKernelAppliesRecords(const DeviceLayout &L);
 
 } // namespace oalgpu

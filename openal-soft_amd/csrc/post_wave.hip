@@ -125,7 +125,120 @@ __global__ void __launch_bounds__(256) PostShiftKernel(float *__restrict__ left,
     }
 }
 
+// The three steps above as ONE launch (the post stream of a pipelined context: every launch there costs ~4 us of dispatch
+// floor plus its wait for a CU slot beside the voice kernel, and the chain of four -- reduction, split, FIR, shift -- was as
+// long as the voice kernel it runs beside).  Workgroups [0, nch): PostSplitKernel's work, one dry channel each; they hand
+// the filtered channel over through device-scope relaxed atomics (write-through stores, L2-coherent loads of exactly those
+// words -- no fence, which at device scope would write back and invalidate a whole L2 under the voice kernel; the idiom of
+// the convolution kernel) and then raise a counter.  Workgroups [nch, nch + 18): PostFirKernel's work, one wavefront per 64
+// output frames, once the counter says that every channel of THIS update has arrived (`epoch` = what the counter reads
+// then; it only ever grows) -- they sleep-poll until then, which is safe because the dispatcher places a grid's
+// workgroups in index order: the ones that are waited for are resident before the ones that wait.  The shift rides on the
+// FIR's result: frame o of HrtfAccumData + the channels' sum goes to RealOut (o < n) and to its place in the carried
+// accumulator (hrtfbase.h:119-132), which is a buffer of its own (`carryOut`; the reduction of the next update adds it to
+// the voices' partial sums), so that no workgroup writes what another still reads.  The splitter states are read from one
+// buffer and filed in the other for the same reason (a workgroup that starts late must not see the new state).
+__device__ __forceinline__ void PostStoreCoherent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float PostLoadCoherent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int kFusedFrames = 64;                            // output frames per FIR workgroup: one per lane, both ears
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) PostFusedKernel(const float *__restrict__ in, uint32_t nch,
+    const SplitterState *__restrict__ spIn, SplitterState *__restrict__ spOut, const float *__restrict__ hfscales,
+    const float *__restrict__ chanCoeffs, uint32_t taps, const float *__restrict__ accIn, float *__restrict__ carryOut,
+    float *__restrict__ left, float *__restrict__ right, uint32_t n, float *__restrict__ xf, uint32_t *__restrict__ arrived, uint32_t epoch,
+    Tri3 runPower)
+{
+    __shared__ float xs[kLine + 64];                                   // split: the channel; FIR: [kPostGroup][128 + 64] windows
+    const uint32_t lane = threadIdx.x;
+    if(blockIdx.x < nch)
+    {   // ---- BandSplitter::processHfScale of dry channel c (PostSplitKernel)
+        const uint32_t c = blockIdx.x;
+#pragma unroll 8
+        for(uint32_t k = lane; k < uint32_t(kLine); k += 64) xs[k] = (k < n) ? in[size_t{c} * kLine + k] : 0.0f;
+        WaveSync();
+        SplitterState st = spIn[c];
+        SplitterScanHfDpp(st, xs, n, hfscales[c], lane, runPower);
+        if(lane == 0) spOut[c] = st;
+        WaveSync();
+#pragma unroll 8
+        for(uint32_t k = lane; k < uint32_t(kLine); k += 64) PostStoreCoherent(xf + size_t{c} * kLine + k, (k < n) ? xs[k] : 0.0f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the channel is where the others will read it ...
+        if(lane == 0) __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before it counts as arrived
+        return;
+    }
+    // ---- the decoder FIR over 64 output frames -- lane = frame, both ears in the lane, the channel's (left, right) tap pairs
+    // through the scalar cache as SGPR operands: ONE LDS read per tap and two multiply-adds, where lanes that split ears and
+    // taps read coefficient AND sample from LDS for every multiply-add (the LDS pipe is what the voice kernel beside this one
+    // keeps busy) -- and the shift (PostFirKernel + PostShiftKernel)
+    const uint32_t blk = blockIdx.x - nch;
+    const uint32_t o = blk * uint32_t(kFusedFrames) + lane;
+    const int32_t base = int32_t(blk) * kFusedFrames - kHrirLen;
+    const f2 accOld = reinterpret_cast<const f2*>(accIn)[o];           // (requested before the wait)
+    while(int32_t(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) __builtin_amdgcn_s_sleep(8);
+    constexpr int kWin = kHrirLen + kFusedFrames;
+    float (*xw4)[kWin] = reinterpret_cast<float (*)[kWin]>(xs);
+    static_assert(sizeof(xs) >= sizeof(float) * kPostGroup * kWin, "the FIR windows fit into the split's line buffer");
+    float accL = 0.0f, accR = 0.0f;
+    for(uint32_t c0 = 0; c0 < nch; c0 += kPostGroup)
+    {
+        const uint32_t gc = (nch - c0 < uint32_t(kPostGroup)) ? nch - c0 : uint32_t(kPostGroup);
+        WaveSync();
+        for(uint32_t c = 0; c < gc; ++c)
+        {
+#pragma unroll
+            for(int j3 = 0; j3 < kWin / 64; ++j3)
+            {
+                const uint32_t j = lane + 64u * uint32_t(j3);
+                const int32_t fr = base + int32_t(j);
+                xw4[c][j] = (fr >= 0 && fr < kLine) ? PostLoadCoherent(xf + size_t{c0 + c} * kLine + uint32_t(fr)) : 0.0f;
+            }
+        }
+        WaveSync();
+        for(uint32_t c = 0; c < gc; ++c)
+        {
+            const float *xw = &xw4[c][kHrirLen + lane];                  // x_c[o - t] = xw[-t]
+            cf16 *co = (cf16*)(uintptr_t)(chanCoeffs + size_t{c0 + c} * kHrirLen * 2);    // eight (left, right) tap pairs per load
+#pragma unroll 1
+            for(uint32_t t8 = 0; t8 < taps / 8u; ++t8)
+            {
+                const f16 cc = co[t8];
+                const float *xq = xw - 8 * int32_t(t8);
+#pragma unroll
+                for(int j = 0; j < 8; ++j)
+                {
+                    const float x = xq[-j];
+                    accL = __builtin_fmaf(cc[2 * j], x, accL);
+                    accR = __builtin_fmaf(cc[2 * j + 1], x, accR);
+                }
+            }
+        }
+    }
+    {   // PostShiftKernel's arithmetic: s = accumulator + channels' sum
+        const f2 s = f2{accOld.x + accL, accOld.y + accR};
+        if(o < n) { left[o] = left[o] + s.x; right[o] = right[o] + s.y; }
+        // hrtfbase.h:127-132: frames [n, n + 128) move to the front, the following n frames are cleared, anything beyond stays
+        f2 *carry2 = reinterpret_cast<f2*>(carryOut);
+        if(o >= n && o < n + uint32_t(kHrirLen)) carry2[o - n] = s;
+        if(o >= uint32_t(kHrirLen)) carry2[o] = (o < uint32_t(kHrirLen) + n) ? f2{0.0f, 0.0f} : s;
+    }
+}
+
 } // namespace
+
+// the whole FAST post-process in one launch; spIn / spOut: the two splitter-state buffers of the context (the caller swaps them),
+// carryOut: the carried accumulator the next reduction adds (1152 x 2); xf: nch x 1024 floats of scratch; arrived / epoch: the
+// context's channel counter and the value it reaches when this update's channels are all there (nch more than before);
+// runPower: the splitter's transition over a run of ((n + 63) / 64) | 1 samples as the scan wants it (SplitterRunPowers, api.hip)
+void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
+    const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
+    float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone)
+{
+    const uint32_t taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
+    const Tri3 P{runPower[0], runPower[1], runPower[2], runPower[3]};
+    static_assert(kPostFrames % kFusedFrames == 0, "whole workgroups");
+    hipExtLaunchKernelGGL(PostFusedKernel, dim3(nch + kPostFrames / kFusedFrames), dim3(64), 0, s, nullptr, evDone, 0u, in, nch, spIn, spOut, hfscales,
+        chanCoeffs, taps, accIn, carryOut, left, right, n, xf, arrived, epoch, P);
+}
 
 // temp: nch x 1024 filtered channels, then 1152 x 2 channel sums
 // evDone: an event bound to the completion of the last of the three dispatches (null: none)

@@ -179,16 +179,27 @@ __device__ __forceinline__ void WgMixRows(uint32_t *lds, const DeviceLayout &L, 
         __syncthreads();
         const uint32_t nLive = __builtin_amdgcn_readfirstlane(*count);
         const float *rows = L.streams + size_t{v0 + c0} * spv * kLine + 4u * t;
+        // the rows come back from L2 / the fabric (~2 K cycles a round trip): the next batch's loads are in flight while
+        // one batch is multiplied
+        uint32_t rrN[kRowBatch];
+        float4 sN[kRowBatch];
+        auto loadBatch = [&](uint32_t b)
+        {
+#pragma unroll
+            for(uint32_t k = 0; k < kRowBatch; ++k)
+            {
+                rrN[k] = __builtin_amdgcn_readfirstlane(list[(b + k < nLive) ? b + k : (nLive ? nLive - 1u : 0u)]);
+                sN[k] = *reinterpret_cast<const float4*>(rows + size_t{rrN[k]} * kLine);
+            }
+        };
+        if(nLive) loadBatch(0u);
         for(uint32_t b = 0; b < nLive; b += kRowBatch)
         {
             uint32_t rr[kRowBatch];
             float4 s[kRowBatch];
 #pragma unroll
-            for(uint32_t k = 0; k < kRowBatch; ++k)
-            {
-                rr[k] = __builtin_amdgcn_readfirstlane(list[(b + k < nLive) ? b + k : nLive - 1u]);
-                s[k] = *reinterpret_cast<const float4*>(rows + size_t{rr[k]} * kLine);
-            }
+            for(uint32_t k = 0; k < kRowBatch; ++k) { rr[k] = rrN[k]; s[k] = sN[k]; }
+            if(b + kRowBatch < nLive) loadBatch(b + kRowBatch);
 #pragma unroll
             for(uint32_t k = 0; k < kRowBatch; ++k)
             {
@@ -270,15 +281,61 @@ struct WaveArgsHrtf {
     AmbiScaleState *ambi;
     uint32_t *startDelay, *queueDone;
     float *partHrtf;
-    explicit WaveArgsHrtf(const DeviceLayout &L) : numVoices{L.numVoices}, waveVoices{L.waveVoices}, irStride{L.irStride}, pad{0},
+    const float *hrirs;                         // the store's HRIRs: what a parameter record's blend indices point into
+    explicit WaveArgsHrtf(const DeviceLayout &L) : numVoices{L.numVoices}, waveVoices{L.waveVoices}, irStride{L.irStride}, pad{L.irSize},
         tables{L.tables}, buffers{L.buffers}, ctl{L.ctl}, prev{L.prev}, dfilt{L.dfilt}, hrtfOld{L.hrtfOld}, hrtfTgt{L.hrtfTgt},
-        hist{L.hist}, ambi{L.ambi}, startDelay{L.startDelay}, queueDone{L.queueDone}, partHrtf{L.partHrtf} { }
+        hist{L.hist}, ambi{L.ambi}, startDelay{L.startDelay}, queueDone{L.queueDone}, partHrtf{L.partHrtf}, hrirs{L.hrirs} { }
 };
+
+// The next update's parameter block, installed by the wavefront that has just mixed the voice (the kernel's epilogue) instead
+// of by a kernel of its own between two voice kernels: ApplyRecordWave (kernels.hpp) for the kernels that carry the whole
+// DeviceLayout, the same operations on the lean argument block for the HRTF kernels without sends (`pad` holds IrSize there).
+struct NextBlock { const ParamRecord *recs; const int32_t *map; };
+__device__ __forceinline__ void ApplyRecordLean(const WaveArgsHrtf &L, const ParamRecord &r, uint32_t lane)
+{
+    const uint32_t v = r.voice;
+    VoiceCtl &ctl = L.ctl[v];
+    if(lane == 0)
+    {
+        ctl.step = r.step;
+        ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
+        ctl.rsFilterOffset = r.rsFilterOffset;
+        const uint32_t keep = ctl.flags & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue
+            | (r.keepHrtf ? uint32_t(kFlagHrtfDirty) : 0u));
+        ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue))
+            | kFlagHasHrtf | (r.keepHrtf ? 0u : uint32_t(kFlagHrtfDirty));
+        for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = -1;
+        if(!r.keepHrtf)
+        {
+            ctl.hrtfTgtDelay[0] = r.hrtfDelay[0]; ctl.hrtfTgtDelay[1] = r.hrtfDelay[1];
+            ctl.hrtfTgtGain = r.hrtfGain;
+        }
+    }
+    if(lane == 1) BiquadSetTarget(L.dfilt[size_t{v} * 2 + 0].f, r.dirLp);
+    if(lane == 2) BiquadSetTarget(L.dfilt[size_t{v} * 2 + 1].f, r.dirHp);
+    if(!r.keepHrtf)
+    {   // ApplyHrtfTargetWave (kernels.hpp), on the lean block
+        const uint32_t i0 = r.hrtfIdx[0], i1 = r.hrtfIdx[1], i2 = r.hrtfIdx[2], i3 = r.hrtfIdx[3];
+        const float w0 = r.hrtfW[0], w1 = r.hrtfW[1], w2 = r.hrtfW[2], w3 = r.hrtfW[3], pass = r.hrtfPass;
+        const uint32_t live = ((L.pad + 1u) & ~1u) * 2u;
+        for(uint32_t e = lane; e < L.irStride * 2; e += 64)
+        {
+            float x = (e < 2) ? pass : 0.0f;
+            x = L.hrirs[size_t{i0} * (kHrirLen * 2) + e] * w0 + x;
+            x = L.hrirs[size_t{i1} * (kHrirLen * 2) + e] * w1 + x;
+            x = L.hrirs[size_t{i2} * (kHrirLen * 2) + e] * w2 + x;
+            x = L.hrirs[size_t{i3} * (kHrirLen * 2) + e] * w3 + x;
+            L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = (e < live) ? x : 0.0f;
+        }
+    }
+}
+__device__ __forceinline__ void ApplyNextRecord(const WaveArgsHrtf &L, const ParamRecord &r, uint32_t lane) { ApplyRecordLean(L, r, lane); }
+__device__ __forceinline__ void ApplyNextRecord(const DeviceLayout &L, const ParamRecord &r, uint32_t lane) { ApplyRecordWave(L, r, lane); }
 
 // ACCL > 0: the context's mix lines (dry lines and / or the slots' wet lines, <= ACCL of them) accumulate in the
 // wavefront's registers (MixRowAcc) instead of leaving stream rows; such kernels run the register-lean resampler.
 template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool PROF = false, class LT = DeviceLayout, int ACCL = 0>
-__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MIN_WG) VoiceWaveKernel(LT L, uint32_t samplesToDo, WaveProf prof)
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MIN_WG) VoiceWaveKernel(LT L, uint32_t samplesToDo, WaveProf prof, NextBlock next)
 {
     static_assert(std::is_same<LT, DeviceLayout>::value || (NL == 0 && !SENDS), "the lean argument block is the HRTF variants'");
     static_assert(ACCL == 0 || NL > 0 || SENDS, "line accumulators belong to kernels that mix onto lines");
@@ -513,6 +570,36 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             // filter's old coefficients (w.cold) and the source window were parked by the last pass
             const float fstv = fstC;
             const SrcPlan plan = planN;
+            // What the mix onto the lines starts from -- Gains.Target / Gains.Current of the dry lines (line = lane), the first
+            // send's filter pair and gains (wet line = lane) and the sends' slots -- is requested HERE, in front of the
+            // resampler: each was a dependent round trip to L2 of its own in the middle of the voice (1.5 K cycles a piece).
+            float dryTgP = 0.0f, dryCuP = 0.0f, sfP = 0.0f, stP = 0.0f, scP = 0.0f;
+            int32_t sendSlots[6] = {-1, -1, -1, -1, -1, -1};
+            auto sendPrefetch = [&](uint32_t si)
+            {
+                if constexpr (SENDS)
+                {
+                    if(si < L.numSends)
+                    {
+                        const size_t vs = size_t{v} * L.numSends + si;
+                        sfP = (lane < 32u) ? reinterpret_cast<const float*>(&L.sfilt[vs * 2])[lane] : 0.0f;
+                        if(lane < L.wetChannels) { stP = L.sendTgt[vs * L.wetChannels + lane]; scP = L.sendCur[vs * L.wetChannels + lane]; }
+                    }
+                }
+            };
+            if constexpr (NL > 0)
+            {
+                if(lane < L.numDry) { dryTgP = L.gainTgt[size_t{v} * L.numDry + lane]; dryCuP = L.gainCur[size_t{v} * L.numDry + lane]; }
+            }
+            if constexpr (SENDS)
+            {   // VoiceCtl::sendSlot, bytes 48..71 of the voice's control line: through the scalar cache
+                static_assert(offsetof(VoiceCtl, sendSlot) == 48, "VoiceCtl::sendSlot follows the head");
+                cu4 *src = (cu4*)(uintptr_t)(L.ctl + v);
+                const u4 a = src[3], b = src[4];
+                sendSlots[0] = int32_t(a.x); sendSlots[1] = int32_t(a.y); sendSlots[2] = int32_t(a.z); sendSlots[3] = int32_t(a.w);
+                sendSlots[4] = int32_t(b.x); sendSlots[5] = int32_t(b.y);
+                sendPrefetch(0);
+            }
             LoadResampledWave<(ACCL > 0), PROF>(sm, w, L, v, lane, head, playing, N - outPos, N - outPos, bufferItem, looping, plan, outPos, prof);
             asm volatile("" : "+v"(lane));      // addresses used from here on are rebuilt, not carried across the resampler
             if constexpr (NL > 0) requestNext();
@@ -547,8 +634,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                         float tg = 0.0f, cu = 0.0f;
                         if(lane < nd)
                         {
-                            tg = playing ? L.gainTgt[size_t{v} * ndAll + lane] : 0.0f;    // SilentCoeffs when Stopping
-                            cu = counter ? L.gainCur[size_t{v} * ndAll + lane] : tg;      // voice.cpp:1094-1112
+                            tg = playing ? dryTgP : 0.0f;    // SilentCoeffs when Stopping
+                            cu = counter ? dryCuP : tg;      // voice.cpp:1094-1112
                         }
                         const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
                         if(lane < nd) { L.gainCur[size_t{v} * ndAll + lane] = g.newCur; row0.add(g); }
@@ -559,7 +646,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                 {
                     for(uint32_t si = 0; si < numSends; ++si)
                     {
-                        const int32_t slot = L.ctl[v].sendSlot[si];
+                        int32_t slot = sendSlots[0];
+#pragma unroll
+                        for(int k = 1; k < 6; ++k) slot = (si == uint32_t(k)) ? sendSlots[k] : slot;
+                        const float sfC = sfP, stC = stP, scC = scP;     // this send's state, requested one send (or the resampler) ago
+                        sendPrefetch(si + 1u);
                         uint32_t *blkS = ACCL ? nullptr : blkV + size_t{2u + si} * LineBlockDwords(ls);
                         if(slot < 0) { if(ACCL == 0 && lane == 0) blkS[3u * ls] = 0u; continue; }
                         const bool sendFilter = (head.flags >> (kFlagSendFilterShift + si)) & 1u;
@@ -568,17 +659,20 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                         const bool mine = lane >= base && lane < base + wetCh;
                         float tg = 0.0f, cu = 0.0f;
                         float *curp = L.sendCur + (size_t{v} * numSends + si) * wetCh + (lane - base);
-                        if(mine)
-                        {
-                            tg = playing ? L.sendTgt[(size_t{v} * numSends + si) * wetCh + (lane - base)] : 0.0f;
-                            cu = counter ? *curp : tg;
+                        {   // the wet lines' gains came in with wet line = lane: to the lanes of the slot's lines
+                            const float tgS = __shfl(stC, int(lane - base)), cuS = __shfl(scC, int(lane - base));
+                            if(mine)
+                            {
+                                tg = playing ? tgS : 0.0f;
+                                cu = counter ? cuS : tg;
+                            }
                         }
                         const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
                         if(mine) *curp = g.newCur;
                         // filter state of this send
                         BiquadSlot *slots = &L.sfilt[(size_t{v} * numSends + si) * 2];
                         WaveSync();
-                        if(lane < 32u) w.fst[lane] = reinterpret_cast<const float*>(slots)[lane];
+                        if(lane < 32u) w.fst[lane] = sfC;
                         WaveSync();
                         if(sendFilter)
                         {   // its own filtered copy, built in the (currently unused) resampler scratch
@@ -642,8 +736,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                     float tg = 0.0f, cu = 0.0f;
                     if(lane < nd)
                     {
-                        tg = playing ? L.gainTgt[size_t{v} * L.numDry + lane] : 0.0f;
-                        cu = counter ? L.gainCur[size_t{v} * L.numDry + lane] : tg;
+                        tg = playing ? dryTgP : 0.0f;
+                        cu = counter ? dryCuP : tg;
                     }
                     const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
                     RowLineGain r;
@@ -671,8 +765,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                         float tg = 0.0f, cu = 0.0f;
                         if(mine)
                         {
-                            tg = playing ? L.gainTgt[size_t{v} * ndAll + lane] : 0.0f;
-                            cu = counter ? L.gainCur[size_t{v} * ndAll + lane] : tg;
+                            tg = playing ? dryTgP : 0.0f;
+                            cu = counter ? dryCuP : tg;
                         }
                         const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
                         RowLineGain r;
@@ -1243,6 +1337,19 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     }
     waveStamp(3);
     if constexpr (SENDS) { if constexpr (ACCL > 0) dumpLines(); else mixRows(); }
+    // ---- the next update's parameter block: every wavefront installs the records of the voices it has just mixed (HRTF kernels).
+    // The voices' state was written back by this very wavefront, in program order, so its loads see it; the kernel boundary makes
+    // the result visible to the next launch, as it did for the parameter kernel this replaces.
+    if(next.map)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for(uint32_t j = 0; j < vCount; ++j)
+        {
+            const uint32_t v = vBegin + 2u * j;
+            const int32_t ri = __builtin_amdgcn_readfirstlane(next.map[v]);
+            if(ri >= 0) ApplyNextRecord(L, next.recs[ri], lane0);
+        }
+    }
 }
 
 } // namespace
@@ -1287,53 +1394,58 @@ uint32_t WaveKernelGroups(const DeviceLayout &L)
 // prof: null in production; the measurement variants exist for the HRTF kernels without sends only
 // evStart / evStop (both or neither): HIP events bound to the DISPATCH (hipExtLaunchKernel) -- the kernel's own start and end,
 // what rocprofv3's kernel trace reports, without the command-processor time an event recorded around the launch includes
-hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop)
+// the kernels whose wavefronts install a parameter block behind their voices: the HRTF ones (NL == 0)
+bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.hrtf != 0; }
+
+hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
+    const ParamRecord *nextRecs, const int32_t *nextMap)
 {
+    const NextBlock next{nextRecs, L.hrtf ? nextMap : nullptr};
     const uint32_t groups = WaveKernelGroups(L);
     const bool sends = L.numSends != 0;
     const dim3 grid(groups), block(kWThreads);
     const WaveProf none{nullptr, 0u};
     if(prof && L.hrtf && !sends && L.irStride <= 64)
     {
-        if(L.firMfma) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof);
-        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof);
+        if(L.firMfma) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof, next);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, true, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, *prof, next);
     }
     else if(L.accLines && !L.hrtf)
     {   // (the measurement variant of these: the same kernel with PROF)
-        if(prof) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, true, DeviceLayout, 6>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
-        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, false, DeviceLayout, 6>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
+        if(prof) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, true, DeviceLayout, 6>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof, next);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, false, DeviceLayout, 6>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none, next);
     }
     else if(L.accLines && L.hrtf)
     {
-        if(prof) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, true, DeviceLayout, 4>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
-        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, false, DeviceLayout, 4>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
+        if(prof) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, true, DeviceLayout, 4>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof, next);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, false, DeviceLayout, 4>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none, next);
     }
     else if(prof && !L.hrtf)
     {
-        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true, false, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
-        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true, false, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof, next);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false, false, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof, next);
     }
     else if(prof && sends && L.irStride <= 64 && L.firMfma)
-        hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof);
+        hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, *prof, next);
     else if(!L.hrtf)
     {
-        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
-        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none, next);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 1, false>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none, next);
     }
     else if(L.irStride <= 64 && L.firMfma)
     {
-        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
-        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none, next);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none, next);
     }
     else if(L.irStride <= 64)
     {
-        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
-        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none, next);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none, next);
     }
     else
     {
-        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none);
-        else hipExtLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none);
+        if(sends) hipExtLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, true>), grid, block, 0, s, evStart, evStop, 0u, L, samplesToDo, none, next);
+        else hipExtLaunchKernelGGL((VoiceWaveKernel<18, 128, 0, false, false, false, WaveArgsHrtf>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, none, next);
     }
     return hipGetLastError();
 }

@@ -1,37 +1,35 @@
-"""Where an update's period goes beyond the voice kernel: periods of back-to-back updates with and
-without the parameter block, the post-process and the overlapped (two-stream) path."""
-import os, sys, time
-import numpy as np
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd")); sys.path.insert(0, ROOT)
-import torch, oalgpu
+"""Measurement aid: period of the config-3 step loop (parameter block + oalgpu_mix_update) with and without the HRTF post-process
+on the post stream -- whether the post chain (reduction + post-process, beside the next update's voice kernel) or the main
+chain bounds the step.  python tools/step_period.py [xflags]"""
+import os, sys, time, gc
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import oalgpu
 from oalgpu import synth
 import bench
-api = oalgpu.Api(oalgpu.MATH_FAST, device=0)
-mhr = synth.synth_mhr_bytes(); api._mhr = mhr
 V = 4096
+xf = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=xf)
+mhr = open(os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr"), "rb").read(); api._mhr = mhr
 sc, script = bench.build_scene(oalgpu, synth, api, 3, V, 0, mhr, 0)
 allv = list(range(V)); moving = [v for v in allv if script.is_moving(v)]
 sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
-blocks = [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(40)]
-N = 400
-def run(name, fn):
-    for k in range(20): fn(k)
-    sc.sync()
-    t0 = time.perf_counter()
-    for k in range(N): fn(k)
-    t1 = time.perf_counter(); sc.sync(); t2 = time.perf_counter()
-    print("%-46s host %.1f us  period %.1f us" % (name, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6))
-run("apply + mix(post)", lambda k: (sc.apply_block(blocks[k % 40]), sc.mix(1024, post_process=True)))
-run("mix(post)", lambda k: sc.mix(1024, post_process=True))
-run("mix(no post: voices + reduce)", lambda k: sc.mix(1024, post_process=False))
-run("serial entry points: mix_voices only", lambda k: sc.mix_voices(1024))
-run("serial: mix_voices + post_process", lambda k: (sc.mix_voices(1024), sc.post_process(1024)))
-run("apply only", lambda k: sc.apply_block(blocks[k % 40]))
-run("mix(no post: voices + reduce) again", lambda k: sc.mix(1024, post_process=False))
-run("mix(post) again", lambda k: sc.mix(1024, post_process=True))
-run("apply + mix(post) again", lambda k: (sc.apply_block(blocks[k % 40]), sc.mix(1024, post_process=True)))
-sc.set_timing(True)
-run("serial mix_voices only, 3 event records per step", lambda k: sc.mix_voices(1024))
-sc.set_timing(False)
-run("serial mix_voices only", lambda k: sc.mix_voices(1024))
+blocks = [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(48)]
+gc.collect(); gc.disable()
+def run(n, post, params=True):
+    for k in range(n):
+        if params: sc.apply_block(blocks[k % len(blocks)])
+        sc.mix(1024, post_process=post)
+        if k % 25 == 24 and n <= 2000 and False: sc.sync()
+def period(post, params=True, n=1000):
+    run(1500, post, params); sc.sync()
+    out = []
+    for _ in range(3):
+        t0 = time.perf_counter(); run(n, post, params); sc.sync()
+        out.append((time.perf_counter() - t0) / n * 1e6)
+    return " ".join("%.2f" % x for x in out)
+print("xflags", xf)
+print("params + mix, post-process on :", period(True))
+print("params + mix, post-process off:", period(False))
+print("mix only,     post-process on :", period(True, False))
+print("mix only,     post-process off:", period(False, False))
