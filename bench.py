@@ -215,7 +215,8 @@ def mfma_block(kernel, voices, kernel_ms, moving):
     """What the matrix pipe executes per launch of the matrix-pipe HRTF voice kernel: per voice 2 ears x 5 tiles x 3
     K-chunks x 3 split-half products of v_mfma_f32_16x16x32_f16 (16 x 16 x 32 x 2 flop each), one more tile for a voice
     whose filter was replaced; against the dense f16 peak (MI355X_MICROARCH.md: 2.5 PFLOP/s)."""
-    if not kernel.endswith("true>") or "VoiceWaveKernel<17, 64, 0" not in kernel:
+    targs = [a.strip() for a in kernel[kernel.find("<") + 1:kernel.rfind(">")].split(",")] if "<" in kernel else []
+    if "VoiceWaveKernel<17, 64, 0" not in kernel or len(targs) < 5 or targs[4] != "true":     # (the fifth argument: MF)
         return None
     per = 16 * 16 * 32 * 2
     n = voices * 90 + moving * 18
@@ -223,12 +224,49 @@ def mfma_block(kernel, voices, kernel_ms, moving):
     return {"instructions_per_launch": n, "executed_tflops": tf, "dense_f16_peak": 2500.0, "frac_of_dense_f16_peak": tf / 2500.0}
 
 
+LDS_BYTES_PER_CLK_PER_CU = 256       # MI355X_MICROARCH.md, LDS: 64 dwords wide per clock (ds_read_b64 / b128 reach it)
+NUM_CUS = 256
+PEAK_CLOCK_HZ = 2.4e9                # MI355X peak engine clock
+
+
+def lds_block(config_id, voices, kernel, kernel_ms):
+    """The LDS side of the voice kernel, which is what its time follows: instructions, bytes and array-busy cycles
+    per launch from the committed SQ counter passes of the same command (profiles/voice_kernel_sq_counters.json, written by
+    tools/r4_evidence.sh), against the pipe's peak -- 256 B per clock and CU."""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "voice_kernel_sq_counters.json")))["configs"][str(config_id)]
+    except (OSError, ValueError, KeyError):
+        return None
+    if ent.get("voices") != voices or ent.get("kernel") != kernel:
+        return None
+    insts = ent["SQ_INSTS_LDS"]
+    nbytes = insts * 64 * 8                 # a 64-lane ds_read_b64 / ds_write_b64 moves 512 B: the kernel's LDS traffic is 8-byte accesses
+    peak = LDS_BYTES_PER_CLK_PER_CU * NUM_CUS * PEAK_CLOCK_HZ / 1e12
+    tbs = nbytes / (kernel_ms * 1e-3) / 1e12
+    cyc = kernel_ms * 1e-3 * PEAK_CLOCK_HZ
+    return {"instructions_per_launch": insts, "bytes_per_launch": nbytes, "achieved": tbs, "peak": peak, "unit": "TB/s", "frac": tbs / peak,
+            "array_busy_frac": ent["SQ_LDS_IDX_ACTIVE"] / NUM_CUS / cyc, "bank_conflict_cycles": ent.get("SQ_LDS_BANK_CONFLICT"),
+            "wave_cycles_waiting_on_lds_frac": ent["SQ_WAIT_INST_LDS"] / ent["SQ_WAVE_CYCLES"],
+            "valu_instructions_per_launch": ent.get("SQ_INSTS_VALU"),
+            "note": "SQ_INSTS_LDS x 512 B; array_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles at 2.4 GHz); two wavefronts per SIMD "
+                    "issue 8-byte LDS reads at half the pipe's rate (MI355X_MICROARCH.md, LDS), so the pipe's busy share, not its byte rate, is the bound"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
+    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5),
+                    help="BASELINE config (default: 3 = configs[2], the headline, on one GPU; 5 = configs[4], HRTF voices + the "
+                         "65536-tap convolution slot sharded over the GPUs, for --gpus N > 1)")
+    ap.add_argument("--transport", default="rccl", choices=("rccl", "host"),
+                    help="N > 1: how the ranks' bus blocks reach rank 0 -- the library's ncclReduce over xGMI, or its host-staged "
+                         "transport (several processes on ONE GPU: a rehearsal of the N > 1 code path, not a scaling measurement)")
+    ap.add_argument("--rank0-extra-us", type=float, default=None,
+                    help="N > 1: what only rank 0 does per update (reduction of the ranks' blocks, effect slots, post-process), in us of "
+                         "GPU time; its voice share shrinks by that much (default: per config, from profiles/)")
+    ap.add_argument("--equal-shards", action="store_true", help="N > 1: deal every rank the same number of voices (A/B against the weighted deal)")
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU (default 4096; 8192 for config 4)")
     ap.add_argument("--math", default="fast", choices=("fast", "exact"))
     ap.add_argument("--vpg", type=int, default=0, help="voices per workgroup (0 = auto)")
@@ -251,10 +289,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    if args.config is None:
+        args.config = 3 if world == 1 else 5
+    host_transport = world > 1 and args.transport == "host"
+    if host_transport:
+        local_rank = 0                       # every rank on the one GPU
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_transport:                   # (RCCL refuses two ranks on one device: the control plane goes over gloo)
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import oalgpu
     from oalgpu import synth
 
@@ -279,8 +325,30 @@ def main():
     post = hrtf or args.config in (2, 4)     # effect slots / the speaker decode run with the post-process
     # config 2 is a 7.1 device: 5 ambisonic dry lines decoded to the 8 real output lines by the reference's
     # X71 decoder (BFormatDec, dual band) in the post-process; the host takes interleaved s16 PCM away
+    # N > 1: the scene is world x V voices, dealt by cost class; rank 0 -- which alone sums the ranks' bus blocks,
+    # runs the effect slots and the post-process, all on its post stream beside its own voice kernel -- gets fewer voices by what
+    # that work takes (weighted_shards' rank0_extra), so that it is not the rank the others wait for.
+    voice_map = None
+    shard_sizes = [V] * world
+    if world > 1 and not args.equal_shards:
+        from oalgpu.shard import voice_cost, weighted_shards
+        probe = synth.SceneScript(args.config, V * world)
+        nsends_of = (lambda v: v % 5) if args.config == 4 else (lambda v: 1 if args.config == 5 else 0)
+        costs = [voice_cost(hrtf, 24, nsends_of(v), probe.filter_active(v)) for v in range(V * world)]
+        # GPU time per update of what only rank 0 does, and of one voice (profiles/r4: post chain alone on the GPU -- reduction
+        # ~5, the collective ~20 (unmeasured over xGMI: RCCL's own latency figure), convolution ~21 / four reverbs ~86, HRTF
+        # post-process ~15 -- and the voice kernel's time per voice)
+        extra_us = args.rank0_extra_us if args.rank0_extra_us is not None else {3: 40.0, 5: 61.0, 4: 111.0, 2: 34.0}[args.config]
+        voice_us = {3: 36.5, 5: 46.3, 2: 34.4, 4: 117.0 / 2}[args.config] / 4096.0
+        rank0_extra = extra_us / voice_us * (sum(costs) / len(costs))
+        shards = weighted_shards(costs, world, rank0_extra=min(rank0_extra, 0.98 * sum(costs) / world * world / max(world - 1, 1)))
+        shard_sizes = [len(sh) for sh in shards]
+        voice_map = shards[rank]
+        V = max(len(voice_map), 8)           # (a context holds at least one workgroup of voices)
+        if len(voice_map) < V:               # rank 0 with (almost) nothing to mix: pad with voices of its own that stay silent
+            voice_map = voice_map + [voice_map[-1] if voice_map else 0] * (V - len(voice_map))
     sc, script = build_scene(oalgpu, synth, api, args.config, V, rank * V, mhr, args.vpg,
-                             num_real=8 if args.config == 2 else None)
+                             num_real=8 if args.config == 2 else None, voice_map=voice_map)
     if args.config == 2:
         dec_hf, dec_lf = synth.x71_decoder()
         sc.set_bformat_decoder(dec_hf, dec_lf)
@@ -307,11 +375,14 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(oalgpu.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0)
-        sc.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        if host_transport:
+            sc.comm_init_host("/oalgpu_bench_%s" % os.environ.get("MASTER_PORT", "0"), rank, world)
+        else:
+            idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(oalgpu.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            sc.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
     B = args.run
     if B and (args.steps % B or args.warmup % B):
@@ -352,6 +423,30 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
+    tdev = "cpu" if host_transport else f"cuda:{local_rank}"
+
+    def timed_block(first_step):
+        """K steps bracketed as the contract says; returns (seconds, max over ranks; this rank's own seconds until ITS streams
+        were idle, before the closing barrier)."""
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(first_step + k)
+        sc.sync()
+        own = time.perf_counter() - t0
+        fence()
+        e = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([e], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e = float(tt.item())
+        return e, own
+
+    # the K-step block behind ONLY the W warm-up steps the command line names (clocks still ramping, the runtime's queues cold):
+    # reported beside the pre-rolled block as config.cold_block_ms_per_step, so that what the pre-roll is worth is in the record
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    cold_elapsed, _ = timed_block(args.warmup)
     for k in range(preroll):
         step(k)
         if k % 25 == 24:
@@ -359,15 +454,13 @@ def main():
     for k in range(args.warmup):
         step(k)
     fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, own_elapsed = timed_block(args.warmup)
+    rank_ms = [own_elapsed / args.steps * 1e3]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.zeros(world, dtype=torch.float64, device=tdev)
+        tt[rank] = own_elapsed / args.steps * 1e3
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        rank_ms = [float(x) for x in tt.cpu()]
 
     # ---- spread: the same K-step block a few more times (each bracketed like the contract's one)
     extra = []
@@ -378,7 +471,7 @@ def main():
         fence()
         e = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([e], dtype=torch.float64, device=f"cuda:{local_rank}")
+            tt = torch.tensor([e], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             e = float(tt.item())
         extra.append(e / args.steps * 1e3)
@@ -473,7 +566,7 @@ def main():
     event_floor_ms = sc.event_floor_ms(200) if sc.voice_kernel_name().startswith("VoiceWaveKernel") else None
 
     if rank == 0:
-        nvoices_total = V * world
+        nvoices_total = sum(shard_sizes)
         bytes_per_launch = BYTES_PER_VOICE_UPDATE[args.config] * V
         flops_per_launch = FLOPS_PER_VOICE_UPDATE[args.config] * V
         hbm_achieved = bytes_per_launch / (vk_ms * 1e-3) / 1e9
@@ -504,7 +597,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "hbm_roofline_frac": hbm_achieved / HBM_PEAK_GBS,     # the second half of the metric string
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {V} mono f32 voices per GPU "
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {nvoices_total // world} mono f32 voices per GPU "
                                    f"(44.1k->48k, bsinc24"
                                    + ((", HRTF Default HRTF.mhr (irSize 64), " if use_real else
                                        ", HRTF synthetic .mhr with Default-HRTF geometry irSize 64, ")
@@ -513,7 +606,9 @@ def main():
                                    + {4: ", v%5 sends into 4 reverb slots", 5: ", one send into a 65536-tap convolution slot"}.get(args.config, "")
                                    + "), 25% filtered, every 4th voice moving",
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
-                       "preroll_steps": preroll, "math_mode": args.math, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
+                       "preroll_steps": preroll, "cold_block_ms_per_step": cold_elapsed / args.steps * 1e3, "math_mode": args.math,
+                       "voices_per_rank": shard_sizes, "rank_ms_per_step": rank_ms,
+                       "transport": (args.transport if world > 1 else None), "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
                        "e2e_ms_per_update": e2e_ms, "e2e_ms_per_update_p90": e2e_p90_ms if e2e_ms is not None else None,
                        "e2e_throughput": e2e_tput,
                        "e2e_note": "one update alone through the C-ABI from host memory: oalgpu_voice_set_params of the "
@@ -529,9 +624,13 @@ def main():
             # precision (three v_mfma_f32_16x16x32_f16 products per fp32 product, Toeplitz tiles: DESIGN.md 3.1);
             # what the pipe EXECUTES for it is under `mfma`.  `hbm_frac` is the "fraction of HBM roofline"
             # BASELINE's metric string names.  kernel_ms: HIP events bound to the dispatch (hipExtLaunchKernel).
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            # `bound`: what the counters name.  Neither HBM (hbm_frac) nor the matrix pipe (mfma) is near its limit; the kernel's
+            # time follows its LDS instruction stream at two wavefronts per SIMD (`lds`): that is the binding unit.  `achieved` /
+            # `peak` / `frac` stay the algorithmic fp32 figures of rounds 1-3, for continuity.
+            "roofline": {"bound": "lds", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": sc.voice_kernel_name(), "kernel_ms": vk_ms, "event_floor_ms": event_floor_ms,
+                         "lds": lds_block(args.config, V, sc.voice_kernel_name(), vk_ms),
                          "mfma": mfma_block(sc.voice_kernel_name(), V, vk_ms, len(moving)),
                          "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,
                          "hbm_achieved": hbm_achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s",

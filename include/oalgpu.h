@@ -184,9 +184,11 @@ typedef struct oalgpu_context_desc {
 #define OALGPU_CTX_STREAM_ROWS 8u  /* FAST dry-line / send contexts with <= 8 mix lines: leave stream rows in HBM and mix them in the
                                    * voice kernel's tail (the path of contexts with more lines) instead of accumulating the
                                    * lines in the wavefronts' registers: for A/B runs and tests of the row path */
-#define OALGPU_CTX_EAGER    16u   /* oalgpu_mix_update launches at once.  By default a pipelined HRTF context submits an update with the
-                                   * NEXT library call on the context: when that is oalgpu_param_block_apply, the update's voice kernel
-                                   * installs the block itself and no parameter kernel stands between two voice kernels */
+#define OALGPU_CTX_APPLY_IN_VOICE_KERNEL 16u /* pipelined HRTF contexts: oalgpu_mix_update is submitted with the NEXT library call on the
+                                   * context, and when that call is oalgpu_param_block_apply the update's own voice kernel installs the
+                                   * block (every wavefront the records of the voices it mixed) instead of a parameter kernel between
+                                   * two voice kernels.  Measured slower than the parameter kernel on three of five boxes (DESIGN.md
+                                   * 3.10): an opt-in variant, for A/B runs */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 

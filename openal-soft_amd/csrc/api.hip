@@ -114,7 +114,7 @@ struct oalgpu_context {
     struct { bool active{false}; uint32_t samples{0}; int post{0}; } pendingMix;
     // the pipelined host boundary (oalgpu_voice_move_async / oalgpu_read_output_async): pinned ring slots
     static constexpr uint32_t kIoSlots = 4;
-    MoveRecord *panHost[kIoSlots]{};
+    oalgpu_voice_move *panHost[kIoSlots]{};
     size_t panCap{0};
     hipEvent_t panApplied[kIoSlots]{};
     uint32_t panNext{0};
@@ -1704,7 +1704,7 @@ int oalgpu_voice_move_async(oalgpu_context *c, const oalgpu_voice_move *pans, si
         for(uint32_t k = 0; k < oalgpu_context::kIoSlots; ++k)
         {
             if(c->panHost[k]) { HIP_TRY(hipHostFree(c->panHost[k])); c->panHost[k] = nullptr; }
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->panHost[k]), c->L.numVoices * sizeof(MoveRecord), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->panHost[k]), c->L.numVoices * sizeof(oalgpu_voice_move), hipHostMallocDefault));
             if(!c->panApplied[k]) HIP_TRY(hipEventCreateWithFlags(&c->panApplied[k], hipEventDisableTiming));
         }
         c->panCap = c->L.numVoices;
@@ -1712,25 +1712,14 @@ int oalgpu_voice_move_async(oalgpu_context *c, const oalgpu_voice_move *pans, si
     }
     const uint32_t slot = c->panNext % oalgpu_context::kIoSlots;
     if(c->panNext >= oalgpu_context::kIoSlots) HIP_TRY(hipEventSynchronize(c->panApplied[slot]));   // its last use, four batches ago
-    MoveRecord *recs = c->panHost[slot];
-    const HrtfStoreDev store = HostStoreView(c->hrtfHost);
     for(size_t i = 0; i < count; ++i)
-    {
-        const oalgpu_voice_move &p = pans[i];
-        if(p.voice >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: bad voice index");
-        MoveRecord &r = recs[i];
-        const HrirBlend b = HrtfBlendFor(store, p.hrtf_ev, p.hrtf_az, p.hrtf_dist, p.hrtf_spread);
-        r.voice = p.voice;
-        for(int k = 0; k < 4; ++k) { r.hrtfIdx[k] = b.idx[k]; r.hrtfW[k] = b.w[k]; }
-        r.hrtfPass = b.passthru;
-        r.hrtfDelay[0] = b.delay[0]; r.hrtfDelay[1] = b.delay[1];
-        r.hrtfGain = p.hrtf_gain;
-    }
-    // The kernel reads the records straight out of the pinned slot (64 bytes per moved voice over PCIe, behind the
-    // update that is mixing): ONE runtime call.  With a copy on a stream of its own in front of it the call was five
-    // (copy, record, wait, launch, record) and the calling thread, which is what bounds this boundary, spent 13.5 us
-    // in them instead of 4.  The slot is free again when the event bound to the dispatch has fired.
-    LaunchApplyMoves(c->stream, c->L, recs, uint32_t(count), c->panApplied[slot]);
+        if(pans[i].voice >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: bad voice index");
+    // The records go into the pinned slot as they are and the kernel reads them straight out of it (24 bytes per moved voice over
+    // PCIe, behind the update that is mixing): one copy and ONE runtime call on the calling thread, which is what bounds this
+    // boundary -- getCoeffs' index half, which the thread used to evaluate per record, runs in the kernel.  The slot is free again
+    // when the event bound to the dispatch has fired.
+    std::memcpy(c->panHost[slot], pans, count * sizeof(oalgpu_voice_move));
+    LaunchApplyMoves(c->stream, c->L, c->hrtfDev, c->panHost[slot], uint32_t(count), c->panApplied[slot]);
     HIP_TRY(hipGetLastError());
     ++c->panNext;
     return OALGPU_OK;
@@ -2257,7 +2246,7 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(int rc = UseCtx(c)) return rc;                // (submits the update deferred before this one)
-    if(c->useWave && c->ownStream && !c->serialOnly && !c->timing && !(c->desc.flags & OALGPU_CTX_EAGER) && WaveKernelAppliesRecords(c->L))
+    if(c->useWave && c->ownStream && !c->serialOnly && !c->timing && (c->desc.flags & OALGPU_CTX_APPLY_IN_VOICE_KERNEL) && WaveKernelAppliesRecords(c->L))
     {   // submitted with the next library call on this context (see pendingMix); whatever goes wrong then is that call's error
         c->pendingMix.active = true; c->pendingMix.samples = samples_to_do; c->pendingMix.post = post_process;
         return OALGPU_OK;

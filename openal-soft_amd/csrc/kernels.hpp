@@ -103,19 +103,6 @@ struct ParamRecord {
     uint32_t keepHrtf;              // the HRTF target stays as it is (handed over by oalgpu_voice_set_hrtf_targets)
 };
 
-// What is left of a ParamRecord when only a voice's DIRECTION moved (the common case of an update: CalcPanningAndFilters,
-// alc/alu.cpp:1512-1657, with unchanged filter targets): the HRIR blend and the gain.  ApplyMovesKernel.
-struct MoveRecord {
-    uint32_t voice;
-    uint32_t hrtfIdx[4];
-    float hrtfW[4];
-    float hrtfPass;
-    uint32_t hrtfDelay[2];
-    float hrtfGain;
-    uint32_t pad[3];
-};
-static_assert(sizeof(MoveRecord) == 64, "MoveRecord");
-
 struct DeviceLayout {
     // configuration
     uint32_t numVoices, numDry, numReal, numSends, numSlots, wetChannels;
@@ -349,7 +336,8 @@ void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
 // ---- launchers (voice_kernel.hip) ----
 void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);
 void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count);
-void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count, hipEvent_t evDone = nullptr);
+// moves: `count` oalgpu_voice_move records (24 bytes each: voice, the getCoeffs arguments, the gain), device or pinned host memory
+void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev &st, const void *moves, uint32_t count, hipEvent_t evDone = nullptr);
 // Hrtf.Target handed over as the reference's parameter stage left it: coeffs = [count][128][2] (HrirArray)
 struct TargetRecord { uint32_t voice; uint32_t delay[2]; float gain; };
 void LaunchApplyTargets(hipStream_t s, const DeviceLayout &L, const TargetRecord *recs, const float *coeffs, uint32_t count);

@@ -160,25 +160,32 @@ void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *
     if(count) hipLaunchKernelGGL(ApplyParamsKernel, dim3(count), dim3(64), 0, s, L, recs);
 }
 
-// A moved voice of an HRTF context: new target filter, delays and gain; the filter is marked as replaced.
-__global__ void __launch_bounds__(64) ApplyMovesKernel(DeviceLayout L, const MoveRecord *__restrict__ recs)
+// A moved voice of an HRTF context: new target filter, delays and gain; the filter is marked as replaced.  The record is the
+// host's 24 bytes as they are (oalgpu_voice_move, read straight out of a pinned ring slot): BOTH halves of HrtfStore::getCoeffs
+// (core/hrtf.cpp:192-260) run here -- the index half (HrtfBlendFor: the same float operations as on the host, every lane the
+// same values) and the weighted sum of the four HRIRs.  The calling thread, which is what bounds the pipelined boundary,
+// used to evaluate the index half for every moved voice (11 us per 1024 records).
+struct RawMove { uint32_t voice; float ev, az, dist, spread, gain; };
+static_assert(sizeof(RawMove) == sizeof(oalgpu_voice_move), "RawMove mirrors oalgpu_voice_move");
+__global__ void __launch_bounds__(64) ApplyMovesKernel(DeviceLayout L, HrtfStoreDev st, const RawMove *__restrict__ moves)
 {
-    const MoveRecord &r = recs[blockIdx.x];
-    const uint32_t v = r.voice, lane = threadIdx.x;
+    const RawMove m = moves[blockIdx.x];
+    const uint32_t v = m.voice, lane = threadIdx.x;
+    const HrirBlend b = HrtfBlendFor(st, m.ev, m.az, m.dist, m.spread);
     if(lane == 0)
     {
         VoiceCtl &ctl = L.ctl[v];
         ctl.flags |= kFlagHasHrtf | kFlagHrtfDirty;
-        ctl.hrtfTgtDelay[0] = r.hrtfDelay[0]; ctl.hrtfTgtDelay[1] = r.hrtfDelay[1];
-        ctl.hrtfTgtGain = r.hrtfGain;
+        ctl.hrtfTgtDelay[0] = b.delay[0]; ctl.hrtfTgtDelay[1] = b.delay[1];
+        ctl.hrtfTgtGain = m.gain;
     }
-    ApplyHrtfTargetWave(L, v, r.hrtfIdx, r.hrtfW, r.hrtfPass, lane);
+    ApplyHrtfTargetWave(L, v, b.idx, b.w, b.passthru, lane);
 }
 
-// evDone: an event bound to the dispatch's completion (null: none); recs may be pinned host memory
-void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const MoveRecord *recs, uint32_t count, hipEvent_t evDone)
+// evDone: an event bound to the dispatch's completion (null: none); moves may be pinned host memory
+void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev &st, const void *moves, uint32_t count, hipEvent_t evDone)
 {
-    if(count) hipExtLaunchKernelGGL(ApplyMovesKernel, dim3(count), dim3(64), 0, s, nullptr, evDone, 0u, L, recs);
+    if(count) hipExtLaunchKernelGGL(ApplyMovesKernel, dim3(count), dim3(64), 0, s, nullptr, evDone, 0u, L, st, static_cast<const RawMove*>(moves));
 }
 
 // A voice's HRTF target as the reference's own parameter stage computed it (Hrtf.Target after CalcHrtfPanning,

@@ -95,7 +95,7 @@ def close_to(got, want, what, terms=(1, 1)):
     return scale
 
 
-def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_at=None, sample_fmt="f32"):
+def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_at=None, sample_fmt="f32", ctx_flags=0):
     """check_at: the updates (0-based) after which buses and voice states are compared (None: every one).  Between
     checkpoints nothing of the product is read: its two-stream pipeline runs on unsynchronised, as in the bench."""
     import oalgpu
@@ -103,7 +103,7 @@ def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_a
     import bench
     assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
     L = _oracle()
-    api = oalgpu.Api(oalgpu.MATH_FAST)
+    api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=ctx_flags)
     with open(mhr_path, "rb") as f:
         mhr = f.read()
     api._mhr = mhr
@@ -211,3 +211,12 @@ def test_config2_parity_after_updates_1_2_8_50(synth_mhr, sample_fmt):
 def test_config3_parity_after_updates_1_2_8_50(sample_fmt):
     assert os.path.exists(REAL_MHR), "tests/golden/default_hrtf.mhr is a committed fixture"
     run_config(3, 4096, REAL_MHR, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt)
+
+
+@pytest.mark.parametrize("config", [2, 5])
+def test_stream_row_path_of_the_few_line_contexts(synth_mhr, config):
+    """Configs 2 and 5 mix their lines in the wavefronts' registers by default; OALGPU_CTX_STREAM_ROWS puts them on the path of
+    the contexts with more than 6 (4) lines -- stream rows mixed in the voice kernel's tail -- which must agree with the
+    reference just the same."""
+    import oalgpu
+    run_config(config, 4096, synth_mhr, ctx_flags=oalgpu.CTX_STREAM_ROWS)

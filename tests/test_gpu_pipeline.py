@@ -26,16 +26,22 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def test_pipelined_update_equals_serial_update(synth_mhr):
+@pytest.mark.parametrize("variant", ["default", "apply-in-voice-kernel"])
+def test_pipelined_update_equals_serial_update(synth_mhr, variant):
+    """variant "apply-in-voice-kernel" (OALGPU_CTX_APPLY_IN_VOICE_KERNEL): every update is submitted one library call late and
+    the parameter block that follows it is installed by the update's own wavefronts, behind the voices they mixed -- the same
+    operations as ApplyParamsKernel, so still the serial scene's bits."""
     import oalgpu
     from oalgpu import synth
     import bench
     assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
     api = oalgpu.Api(oalgpu.MATH_FAST)
+    papi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_APPLY_IN_VOICE_KERNEL) if variant != "default" else api
     mhr = synth.synth_mhr_bytes()
     api._mhr = mhr
+    papi._mhr = mhr
 
-    def build():
+    def build(api=api):
         sc, script = bench.build_scene(oalgpu, synth, api, 3, V, 0, mhr, 0)
         allv = list(range(V))
         moving = [v for v in allv if script.is_moving(v)]
@@ -43,7 +49,7 @@ def test_pipelined_update_equals_serial_update(synth_mhr):
         blocks = [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(UPDATES)]
         return sc, blocks
 
-    piped, pblocks = build()
+    piped, pblocks = build(papi)
     serial, sblocks = build()
     assert piped.voice_kernel_name() in ("VoiceBlockKernel",) or "VoiceWaveKernel" in piped.voice_kernel_name()
     got, want = {}, {}
