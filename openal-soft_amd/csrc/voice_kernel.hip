@@ -974,7 +974,10 @@ constexpr int kReduceSegs = 16;
 template<int kReduceWaves>
 __global__ void __launch_bounds__(kReduceWaves * 64) __attribute__((amdgpu_num_vgpr(48))) BusReduceKernel(DeviceLayout L, const float *__restrict__ carry)
 {
-    __shared__ float slice[kReduceSegs][64];
+    // (the post-stream shape hands its runs over four at a time: 1 KB, ONE allocation granule of LDS -- beside two voice
+    // workgroups of the dry-line kernels a CU has four granules to spare, and a launch of more reduction workgroups than
+    // CUs (config 4: 336) must not keep a voice workgroup of the next update waiting for LDS)
+    __shared__ float slice[kReduceWaves == 4 ? 4 : kReduceSegs][64];
     const uint32_t wave0 = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t idx = blockIdx.x * 64u + lane;
     const uint32_t dryLines = L.numDry + L.numReal;
@@ -1054,8 +1057,18 @@ __global__ void __launch_bounds__(kReduceWaves * 64) __attribute__((amdgpu_num_v
             for(int q = 0; q < 4; ++q)
                 for(; gA[q] < gE[q]; ++gA[q]) { sum[q] = sum[q] + *reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + oo[q]); oo[q] += sb; }
         }
+        // segments in order 0..15 (segment = wavefront + 4 q), exactly as the 16-wavefront shape sums them
+        float t = (carry && idx >= lineFloats && idx < total) ? carry[idx - lineFloats] : 0.0f;
 #pragma unroll
-        for(int q = 0; q < 4; ++q) slice[wave0 + 4u * uint32_t(q)][lane] = sum[q];
+        for(int q = 0; q < 4; ++q)
+        {
+            slice[wave0][lane] = sum[q];
+            __syncthreads();
+            if(wave0 == 0) { t = t + slice[0][lane]; t = t + slice[1][lane]; t = t + slice[2][lane]; t = t + slice[3][lane]; }
+            __syncthreads();
+        }
+        if(wave0 == 0 && idx < total && (idx < lineFloats || L.hrtf)) L.bus[idx] = t;
+        return;
     }
     else
 #pragma unroll 1
