@@ -122,6 +122,17 @@ struct oalgpu_context {
     hipEvent_t outDone[kIoSlots]{};
     uint32_t outNext{0};
     size_t outFloats{0};
+    // Where the box lets the host store into device memory (large BAR), the move slots ARE device memory: the installing kernel
+    // reads its records out of HBM instead of over PCIe (3 us less in front of the voice kernel, tools/ubench_largebar.hip).
+    bool panInBar{false};
+    // Once oalgpu_read_output_async has been used on an HRTF context, the post-process kernel stores the two output lines into
+    // the next ring slot itself and raises the slot's sequence number (pinned, 64 bytes apart) behind them: reading the output
+    // back costs the host no runtime call.  outRingWritten: the update submitted last did so, for slot outNext % kIoSlots.
+    bool outRing{false}, outRingWritten{false};
+    bool outViaRing[kIoSlots]{};
+    uint32_t outSeq{0}, outSlotSeq[kIoSlots]{};    // every launch that writes a slot raises ITS number
+    uint32_t *outFlags{nullptr};
+    DevBuf<uint32_t> outArrived;
     float *partHrtfBuf[2]{nullptr, nullptr};
     float *partLinesBuf[2]{nullptr, nullptr};
     bool timing{false}, timed{false};
@@ -219,10 +230,11 @@ struct oalgpu_context {
         for(void *p : bufferData) if(p) (void)hipFree(p);
         for(uint32_t k = 0; k < kIoSlots; ++k)
         {
-            if(panHost[k]) (void)hipHostFree(panHost[k]);
+            if(panHost[k]) (void)(panInBar ? hipFree(panHost[k]) : hipHostFree(panHost[k]));
             if(outHost[k]) (void)hipHostFree(outHost[k]);
             for(hipEvent_t e : {panApplied[k], outDone[k]}) if(e) (void)hipEventDestroy(e);
         }
+        if(outFlags) (void)hipHostFree(outFlags);
         if(evStart) (void)hipEventDestroy(evStart);
         if(evVoice) (void)hipEventDestroy(evVoice);
         if(evEnd) (void)hipEventDestroy(evEnd);
@@ -1689,6 +1701,25 @@ void oalgpu_param_block_destroy(oalgpu_param_block *b)
     delete b;
 }
 
+// Large-BAR boxes: fine-grained device memory is host-addressable.  Checked once per context by storing a pattern from the
+// host and reading it back with the device's copy engine, so that a platform that only claims the property falls back to
+// pinned host memory.
+static bool HostStoresReachDevice(oalgpu_context *c)
+{
+    hipDeviceProp_t prop{};
+    if(hipGetDeviceProperties(&prop, c->desc.device) != hipSuccess || !prop.isLargeBar) return false;
+    uint32_t *probe = nullptr;
+    if(hipExtMallocWithFlags(reinterpret_cast<void**>(&probe), 256, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return false; }
+    bool ok = true;
+    for(uint32_t i = 0; i < 64; ++i) probe[i] = 0x5eed0000u + i;
+    __builtin_ia32_sfence();
+    uint32_t back[64] = {};
+    if(hipMemcpy(back, probe, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+    for(uint32_t i = 0; ok && i < 64; ++i) ok = back[i] == 0x5eed0000u + i;
+    (void)hipFree(probe);
+    return ok;
+}
+
 int oalgpu_voice_move_async(oalgpu_context *c, const oalgpu_voice_move *pans, size_t count)
 {
     if(!c || !pans) return Fail(OALGPU_ERR_INVALID, "null argument");
@@ -1703,8 +1734,13 @@ int oalgpu_voice_move_async(oalgpu_context *c, const oalgpu_voice_move *pans, si
         if(int rc = oalgpu_sync(c)) return rc;
         for(uint32_t k = 0; k < oalgpu_context::kIoSlots; ++k)
         {
-            if(c->panHost[k]) { HIP_TRY(hipHostFree(c->panHost[k])); c->panHost[k] = nullptr; }
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->panHost[k]), c->L.numVoices * sizeof(oalgpu_voice_move), hipHostMallocDefault));
+            if(c->panHost[k]) { HIP_TRY(c->panInBar ? hipFree(c->panHost[k]) : hipHostFree(c->panHost[k])); c->panHost[k] = nullptr; }
+        }
+        c->panInBar = HostStoresReachDevice(c);
+        for(uint32_t k = 0; k < oalgpu_context::kIoSlots; ++k)
+        {
+            if(c->panInBar) HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->panHost[k]), c->L.numVoices * sizeof(oalgpu_voice_move), hipDeviceMallocFinegrained));
+            else HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->panHost[k]), c->L.numVoices * sizeof(oalgpu_voice_move), hipHostMallocDefault));
             if(!c->panApplied[k]) HIP_TRY(hipEventCreateWithFlags(&c->panApplied[k], hipEventDisableTiming));
         }
         c->panCap = c->L.numVoices;
@@ -1714,11 +1750,12 @@ int oalgpu_voice_move_async(oalgpu_context *c, const oalgpu_voice_move *pans, si
     if(c->panNext >= oalgpu_context::kIoSlots) HIP_TRY(hipEventSynchronize(c->panApplied[slot]));   // its last use, four batches ago
     for(size_t i = 0; i < count; ++i)
         if(pans[i].voice >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: bad voice index");
-    // The records go into the pinned slot as they are and the kernel reads them straight out of it (24 bytes per moved voice over
-    // PCIe, behind the update that is mixing): one copy and ONE runtime call on the calling thread, which is what bounds this
+    // The records go into the slot as they are and the kernel reads them straight out of it (24 bytes per moved voice: device
+    // memory the host stores into through the BAR, or pinned host memory read over PCIe, behind the update that is mixing): one copy and ONE runtime call on the calling thread, which is what bounds this
     // boundary -- getCoeffs' index half, which the thread used to evaluate per record, runs in the kernel.  The slot is free again
     // when the event bound to the dispatch has fired.
     std::memcpy(c->panHost[slot], pans, count * sizeof(oalgpu_voice_move));
+    if(c->panInBar) __builtin_ia32_sfence();        // (write-combined stores through the BAR: out of the core before the doorbell)
     LaunchApplyMoves(c->stream, c->L, c->hrtfDev, c->panHost[slot], uint32_t(count), c->panApplied[slot]);
     HIP_TRY(hipGetLastError());
     ++c->panNext;
@@ -1744,8 +1781,25 @@ int oalgpu_read_output_async(oalgpu_context *c, uint32_t *ticket)
             if(!c->outDone[k]) HIP_TRY(hipEventCreateWithFlags(&c->outDone[k], hipEventDisableTiming));
         }
         c->outFloats = floats;
+        if(!c->outFlags)
+        {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->outFlags), oalgpu_context::kIoSlots * 64, hipHostMallocDefault));
+            std::memset(c->outFlags, 0, oalgpu_context::kIoSlots * 64);
+            HIP_TRY(c->outArrived.alloc(1)); HIP_TRY(c->outArrived.zero());
+        }
+        // from the next update on the post-process kernel fills the slots itself (the fused FAST post-process of an HRTF
+        // context with its two output lines; everything else keeps the copy below)
+        c->outRing = c->L.hrtf && c->L.numReal == 2 && c->useWave && floats == size_t{2} * kLine;
     }
     const uint32_t slot = c->outNext % oalgpu_context::kIoSlots;
+    if(c->outRingWritten)
+    {   // the update submitted last is already writing this slot
+        c->outRingWritten = false;
+        c->outViaRing[slot] = true;
+        *ticket = c->outNext++;
+        return OALGPU_OK;
+    }
+    c->outViaRing[slot] = false;
     // behind whatever produced the lines: the post stream of a pipelined context, else the main one
     hipStream_t s = (c->useWave && c->ownStream && !c->serialOnly && c->postStream) ? c->postStream : c->stream;
     const float *src = c->L.numReal ? c->L.bus + size_t{c->L.numDry} * kLine : c->L.bus;
@@ -1762,7 +1816,23 @@ int oalgpu_output_wait(oalgpu_context *c, uint32_t ticket, float *out, size_t ou
     if(out_floats < c->outFloats) return Fail(OALGPU_ERR_INVALID, "oalgpu_output_wait: the buffer is smaller than the output lines");
     if(int rc = UseCtx(c)) return rc;
     const uint32_t slot = ticket % oalgpu_context::kIoSlots;
-    HIP_TRY(hipEventSynchronize(c->outDone[slot]));
+    if(c->outViaRing[slot])
+    {   // the kernel raises the slot's sequence number behind its lines
+        const uint32_t *flag = c->outFlags + size_t{slot} * 16;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(10);
+        uint32_t spins = 0;
+        const uint32_t want = c->outSlotSeq[slot];
+        while(__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want)
+        {
+            __builtin_ia32_pause();
+            if((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() > deadline)
+            {
+                HIP_TRY(hipStreamSynchronize(c->postStream ? c->postStream : c->stream));
+                if(__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) return Fail(OALGPU_ERR_HIP, "oalgpu_output_wait: the output slot was never written");
+            }
+        }
+    }
+    else HIP_TRY(hipEventSynchronize(c->outDone[slot]));
     std::memcpy(out, c->outHost[slot], c->outFloats * sizeof(float));
     return OALGPU_OK;
 }
@@ -1969,8 +2039,13 @@ static int PostDirectHrtfFused(oalgpu_context *c, hipStream_t s, uint32_t sample
     c->postEpoch += L.numDry;               // what the channel counter reads when this update's channels have all arrived
     const uint32_t seg = ((samples_to_do + 63u) / 64u) | 1u;
     if(c->runPowerSeg != seg) { SplitterRunPowers(c->dSplitCoeff, seg, c->runPower); c->runPowerSeg = seg; }
+    const uint32_t slot = c->outNext % oalgpu_context::kIoSlots;
+    const bool ring = c->outRing && c->outFlags;
     LaunchPostDirectHrtfFused(s, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->carryBuf.p, spIn, spOut,
-        c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, c->postEpoch, c->runPower, evDone);
+        c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, c->postEpoch, c->runPower, evDone,
+        ring ? c->outHost[slot] : nullptr, ring ? c->outFlags + size_t{slot} * 16 : nullptr, c->outSeq + 1u, c->outArrived.p);
+    if(ring) c->outSlotSeq[slot] = ++c->outSeq;
+    c->outRingWritten = ring;
     HIP_TRY(hipGetLastError());
     c->dSplitCur ^= 1u;
     c->carryInBuf = true;
@@ -2187,6 +2262,7 @@ int oalgpu_mix_voices(oalgpu_context *c, uint32_t samples_to_do)
     if(int rc = FlushInits(c)) return rc;
     if(int rc = JoinPost(c)) return rc;
     if(!c->cbVoices.empty()) { if(int rc = ServiceCallbacks(c, samples_to_do)) return rc; }
+    c->outRingWritten = false;
     if(c->useWave)    // (timing: the two events are bound to the dispatch itself -- the kernel's own start and end)
         HIP_TRY(LaunchVoiceWave(c->stream, c->L, samples_to_do, c->profArg(), c->timing ? c->evStart : nullptr, c->timing ? c->evVoice : nullptr));
     else
@@ -2302,6 +2378,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     if(int rc = UseCtx(c)) return rc;
     if(int rc = FlushInits(c)) return rc;
     if(!c->cbVoices.empty()) { if(int rc = ServiceCallbacks(c, samples_to_do)) return rc; }
+    c->outRingWritten = false;
     const uint32_t p = c->parity;
     DeviceLayout L = c->L;
     L.partHrtf = c->partHrtfBuf[p];

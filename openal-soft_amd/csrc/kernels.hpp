@@ -234,7 +234,8 @@ void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const fl
 // the same as ONE launch (pipelined FAST HRTF contexts): see post_wave.hip
 void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
     const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
-    float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone = nullptr);
+    float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone = nullptr,
+    float *hostOut = nullptr, uint32_t *hostFlag = nullptr, uint32_t hostSeq = 0, uint32_t *outArrived = nullptr);
 
 // ---- launchers (output_kernels.hip): BFormatDec, ApplyDither, Write<T> behind the buses ----
 // gainsHf / gainsLf: [dry line][32] (column = output line); gainsLf null = single-band decoder; bands =

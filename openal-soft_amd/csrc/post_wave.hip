@@ -146,7 +146,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
     const SplitterState *__restrict__ spIn, SplitterState *__restrict__ spOut, const float *__restrict__ hfscales,
     const float *__restrict__ chanCoeffs, uint32_t taps, const float *__restrict__ accIn, float *__restrict__ carryOut,
     float *__restrict__ left, float *__restrict__ right, uint32_t n, float *__restrict__ xf, uint32_t *__restrict__ arrived, uint32_t epoch,
-    Tri3 runPower)
+    Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived)
 {
     __shared__ float xs[kLine + 64];                                   // split: the channel; FIR: [kPostGroup][128 + 64] windows
     const uint32_t lane = threadIdx.x;
@@ -215,11 +215,32 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
     }
     {   // PostShiftKernel's arithmetic: s = accumulator + channels' sum
         const f2 s = f2{accOld.x + accL, accOld.y + accR};
-        if(o < n) { left[o] = left[o] + s.x; right[o] = right[o] + s.y; }
+        if(o < uint32_t(kLine))
+        {
+            float l = left[o], r = right[o];
+            if(o < n) { l = l + s.x; r = r + s.y; left[o] = l; right[o] = r; }
+            // the pipelined host boundary (oalgpu_read_output_async): the two output lines also go straight into the host's
+            // pinned ring slot -- no copy launch behind this kernel, no runtime call on the host
+            if(hostOut) { hostOut[o] = l; hostOut[uint32_t(kLine) + o] = r; }
+        }
         // hrtfbase.h:127-132: frames [n, n + 128) move to the front, the following n frames are cleared, anything beyond stays
         f2 *carry2 = reinterpret_cast<f2*>(carryOut);
         if(o >= n && o < n + uint32_t(kHrirLen)) carry2[o - n] = s;
         if(o >= uint32_t(kHrirLen)) carry2[o] = (o < uint32_t(kHrirLen) + n) ? f2{0.0f, 0.0f} : s;
+    }
+    if(hostOut)
+    {   // the slot's sequence number goes out behind the last FIR workgroup's lines (system scope: the reader is the host)
+        __threadfence_system();
+        if(lane == 0)
+        {
+            const uint32_t nfir = gridDim.x - nch;
+            const uint32_t t = __hip_atomic_fetch_add(outArrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if((t + 1u) % nfir == 0u)
+            {
+                __threadfence_system();
+                __hip_atomic_store(hostFlag, hostSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -228,16 +249,19 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
 // the whole FAST post-process in one launch; spIn / spOut: the two splitter-state buffers of the context (the caller swaps them),
 // carryOut: the carried accumulator the next reduction adds (1152 x 2); xf: nch x 1024 floats of scratch; arrived / epoch: the
 // context's channel counter and the value it reaches when this update's channels are all there (nch more than before);
-// runPower: the splitter's transition over a run of ((n + 63) / 64) | 1 samples as the scan wants it (SplitterRunPowers, api.hip)
+// runPower: the splitter's transition over a run of ((n + 63) / 64) | 1 samples as the scan wants it (SplitterRunPowers, api.hip);
+// hostOut (null: none): 2 x 1024 floats of pinned host memory that receive the two output lines, hostFlag: where hostSeq is
+// stored when they are all there, outArrived: the context's counter of FIR workgroups
 void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
     const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
-    float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone)
+    float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone,
+    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived)
 {
     const uint32_t taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
     const Tri3 P{runPower[0], runPower[1], runPower[2], runPower[3]};
     static_assert(kPostFrames % kFusedFrames == 0, "whole workgroups");
     hipExtLaunchKernelGGL(PostFusedKernel, dim3(nch + kPostFrames / kFusedFrames), dim3(64), 0, s, nullptr, evDone, 0u, in, nch, spIn, spOut, hfscales,
-        chanCoeffs, taps, accIn, carryOut, left, right, n, xf, arrived, epoch, P);
+        chanCoeffs, taps, accIn, carryOut, left, right, n, xf, arrived, epoch, P, hostOut, hostFlag, hostSeq, outArrived);
 }
 
 // temp: nch x 1024 filtered channels, then 1152 x 2 channel sums
