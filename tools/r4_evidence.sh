@@ -16,6 +16,7 @@ for c in 3 2 4 5; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c$c -o p -- python bench.py --config $c --steps 100 --warmup 5 --repeats 0 --no-cpu-baseline < /dev/null > $O/prof_c$c.log 2>&1
   cp $(find $O/prof_c$c -name "p_kernel_stats.csv" | head -1) $O/config${c}_kernel_stats.csv
   if [ $c = 3 ]; then python tools/step_timeline.py $(find $O/prof_c$c -name "p_kernel_trace.csv" | head -1) 4 0.2 > $O/step_timeline.txt 2>&1; fi
+  if [ $c = 4 ] || [ $c = 5 ]; then python tools/step_timeline.py $(find $O/prof_c$c -name "p_kernel_trace.csv" | head -1) 4 0.2 > $O/step_timeline_config$c.txt 2>&1; fi
   head -6 $O/config${c}_kernel_stats.csv | cut -c1-150
   timeout 300 python bench.py --config $c --steps 300 --warmup 20 --no-cpu-baseline < /dev/null > $O/bench_config$c.json 2>/dev/null
   for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -102,4 +103,8 @@ timeout 300 python tools/phase_times.py > $O/voice_kernel_phase_times.txt 2>&1; 
 for c in 2 4 5; do timeout 300 python tools/phase_times_lines.py $c > $O/phase_times_config$c.txt 2>&1; done
 timeout 300 python tools/step_period.py 0 > $O/step_period.txt 2>&1; timeout 300 python tools/step_period.py 16 >> $O/step_period.txt 2>&1; cat $O/step_period.txt
 timeout 120 python tools/post_period.py > $O/post_period.txt 2>&1; cat $O/post_period.txt
+# configs 2, 4, 5: the two-stream pipeline against one stream (OALGPU_CTX_SERIAL = 4)
+: > $O/step_period_configs_final.txt
+for a in "0 2" "4 2" "0 4" "4 4" "0 5" "4 5"; do timeout 200 python tools/step_period.py $a >> $O/step_period_configs_final.txt 2>&1; done
+cat $O/step_period_configs_final.txt
 du -sh $O; find $O -name "*.csv" -size +2M -delete; rm -rf $O/prof_c* $O/pmc_c*
