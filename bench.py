@@ -499,10 +499,11 @@ def main():
         e2e_p90_ms = each[(len(each) * 9) // 10]
 
     # ---- end-to-end THROUGHPUT through the pipelined boundary: per update the moving voices' 24-byte move records go
-    # in from host memory (oalgpu_voice_move_async: the index half of getCoeffs on the host into a pinned ring slot,
-    # the installing kernel -- in front of the next voice kernel -- reads it over PCIe),
-    # the update runs with its post-process, the stereo output comes back (oalgpu_read_output_async into a pinned ring
-    # slot, collected two updates late).  Nothing waits for anything but the output of two updates ago.
+    # in from host memory as they are (oalgpu_voice_move_async: one copy into a ring slot -- device memory behind the BAR
+    # where the box has a large one, pinned host memory otherwise -- and the installing kernel, in front of the next voice
+    # kernel, evaluates getCoeffs' index half itself), the update runs with its post-process, the stereo output comes back
+    # (the post-process kernel stores it into the host's pinned ring slot; collected two updates late).  Nothing waits for
+    # anything but the output of two updates ago.
     e2e_tput = None
     if world == 1 and moving and hrtf and not B:
         def moves_of(update):
@@ -541,8 +542,9 @@ def main():
                                     "host_submit_share": native[1] / native[0],
                                     "note": "the same loop written in C++ (oalgpu_debug_pipelined_run): no python / ctypes per call"},
                     "updates": n_tp, "moved_voices_per_update": len(moving),
-                    "note": "median of 3 runs; per update: oalgpu_voice_move_async (host HRIR-blend indices + "
-                            "ApplyMovesKernel reading the pinned slot) + oalgpu_mix_update + post-process + oalgpu_read_output_async, output collected "
+                    "note": "median of 3 runs; per update: oalgpu_voice_move_async (raw 24-byte records into a ring slot, "
+                            "ApplyMovesKernel evaluates the HRIR-blend indices) + oalgpu_mix_update + post-process + "
+                            "oalgpu_read_output_async (the post-process kernel fills the host's slot), output collected "
                             "two updates late (oalgpu_output_wait); host_submit_share = the calling thread's time inside those "
                             "three calls / wall time (python + ctypes included)"}
 
