@@ -537,10 +537,15 @@ def main():
         dt, busy = each[1]
         sc.pipelined_run(mv, 50, UPDATE_SAMPLES, post)
         native = sorted(sc.pipelined_run(mv, n_tp, UPDATE_SAMPLES, post) for _ in range(3))[1]
+        submit_s = sorted(sc.submit_cost(mv, 200, UPDATE_SAMPLES, post) for _ in range(3))[1]
         e2e_tput = {"e2e_voices_per_s": V * n_tp / dt, "ms_per_update": dt / n_tp * 1e3, "host_submit_share": busy / dt,
                     "native_loop": {"e2e_voices_per_s": V * n_tp / native[0], "ms_per_update": native[0] / n_tp * 1e3,
                                     "host_submit_share": native[1] / native[0],
-                                    "note": "the same loop written in C++ (oalgpu_debug_pipelined_run): no python / ctypes per call"},
+                                    "note": "the same loop written in C++ (oalgpu_debug_pipelined_run): no python / ctypes per call",
+                                    "submit_us_unqueued": submit_s * 1e6, "host_share_unqueued": submit_s / (native[0] / n_tp),
+                                    "note_unqueued": "the three submitting calls timed with every update's output waited for before the next "
+                                                     "is submitted (oalgpu_debug_submit_cost): host_submit_share above also counts the time a call "
+                                                     "spends blocked inside the runtime behind the queue the GPU is draining"},
                     "updates": n_tp, "moved_voices_per_update": len(moving),
                     "note": "median of 3 runs; per update: oalgpu_voice_move_async (raw 24-byte records into a ring slot, "
                             "ApplyMovesKernel evaluates the HRIR-blend indices) + oalgpu_mix_update + post-process + "

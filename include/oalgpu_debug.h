@@ -22,6 +22,11 @@ extern "C" {
 int oalgpu_debug_pipelined_run(oalgpu_context *ctx, const oalgpu_voice_move *moves, size_t count, uint32_t move_sets,
     uint32_t updates, uint32_t samples_to_do, int post_process, float *out, size_t out_floats, double *wall_s, double *busy_s);
 
+/* Measurement aid: the same three submitting calls with every update's output waited for (untimed) before the next is
+ * submitted -- what they cost the calling thread when no call waits behind a full queue.  submit_s: seconds per update. */
+int oalgpu_debug_submit_cost(oalgpu_context *ctx, const oalgpu_voice_move *moves, size_t count, uint32_t move_sets,
+    uint32_t updates, uint32_t samples_to_do, int post_process, float *out, size_t out_floats, double *submit_s);
+
 
 /* The floor of that clock: an EMPTY kernel (one wavefront that returns) dispatched on the context's stream and timed
  * the same way as the voice kernel -- HIP events bound to the dispatch (hipExtLaunchKernel); the median of `reps`

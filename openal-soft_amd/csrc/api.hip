@@ -131,6 +131,11 @@ struct oalgpu_context {
     bool outRing{false}, outRingWritten{false};
     bool outViaRing[kIoSlots]{};
     uint32_t outSeq{0}, outSlotSeq[kIoSlots]{};    // every launch that writes a slot raises ITS number
+    // What the host already knows to be finished saves it runtime calls: an output that has been waited for proves its update's
+    // whole chain done (moves installed, voices mixed, reduced, post-processed), so the checks in front of a slot's or a
+    // partial-bus buffer's reuse need not ask the runtime.  Updates are numbered from 1 as they are submitted.
+    uint64_t updatesSubmitted{0}, updatesKnownDone{0};
+    uint64_t reduceUpdate[2]{0, 0}, panUpdate[kIoSlots]{}, outUpdate[kIoSlots]{};
     uint32_t *outFlags{nullptr};
     DevBuf<uint32_t> outArrived;
     float *partHrtfBuf[2]{nullptr, nullptr};
@@ -1741,13 +1746,16 @@ int oalgpu_voice_move_async(oalgpu_context *c, const oalgpu_voice_move *pans, si
         {
             if(c->panInBar) HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->panHost[k]), c->L.numVoices * sizeof(oalgpu_voice_move), hipDeviceMallocFinegrained));
             else HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->panHost[k]), c->L.numVoices * sizeof(oalgpu_voice_move), hipHostMallocDefault));
-            if(!c->panApplied[k]) HIP_TRY(hipEventCreateWithFlags(&c->panApplied[k], hipEventDisableTiming));
+            // (the host only asks whether the kernel is through with the slot: no data comes back behind this event, so no system-scope fence)
+            if(!c->panApplied[k]) HIP_TRY(hipEventCreateWithFlags(&c->panApplied[k], hipEventDisableTiming | hipEventDisableSystemFence));
         }
         c->panCap = c->L.numVoices;
         c->panNext = 0;
     }
     const uint32_t slot = c->panNext % oalgpu_context::kIoSlots;
-    if(c->panNext >= oalgpu_context::kIoSlots) HIP_TRY(hipEventSynchronize(c->panApplied[slot]));   // its last use, four batches ago
+    if(c->panNext >= oalgpu_context::kIoSlots && c->panUpdate[slot] > c->updatesKnownDone)
+        HIP_TRY(hipEventSynchronize(c->panApplied[slot]));   // its last use, four batches ago
+    c->panUpdate[slot] = c->updatesSubmitted + 1u;           // installed in front of the next update's voices
     for(size_t i = 0; i < count; ++i)
         if(pans[i].voice >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_move_async: bad voice index");
     // The records go into the slot as they are and the kernel reads them straight out of it (24 bytes per moved voice: device
@@ -1796,10 +1804,12 @@ int oalgpu_read_output_async(oalgpu_context *c, uint32_t *ticket)
     {   // the update submitted last is already writing this slot
         c->outRingWritten = false;
         c->outViaRing[slot] = true;
+        c->outUpdate[slot] = c->updatesSubmitted;
         *ticket = c->outNext++;
         return OALGPU_OK;
     }
     c->outViaRing[slot] = false;
+    c->outUpdate[slot] = c->updatesSubmitted;
     // behind whatever produced the lines: the post stream of a pipelined context, else the main one
     hipStream_t s = (c->useWave && c->ownStream && !c->serialOnly && c->postStream) ? c->postStream : c->stream;
     const float *src = c->L.numReal ? c->L.bus + size_t{c->L.numDry} * kLine : c->L.bus;
@@ -1833,6 +1843,7 @@ int oalgpu_output_wait(oalgpu_context *c, uint32_t ticket, float *out, size_t ou
         }
     }
     else HIP_TRY(hipEventSynchronize(c->outDone[slot]));
+    if(c->outUpdate[slot] > c->updatesKnownDone) c->updatesKnownDone = c->outUpdate[slot];
     std::memcpy(out, c->outHost[slot], c->outFloats * sizeof(float));
     return OALGPU_OK;
 }
@@ -1867,6 +1878,29 @@ int oalgpu_debug_pipelined_run(oalgpu_context *c, const oalgpu_voice_move *moves
     const double wall = std::chrono::duration<double>(clk::now() - t0).count();
     if(wall_s) *wall_s = wall;
     if(busy_s) *busy_s = wall - waited;
+    return OALGPU_OK;
+}
+
+/* What the three calls of one pipelined update cost the calling thread when nothing is queued behind them: every update's
+ * output is waited for (untimed) before the next one is submitted, so that no call blocks behind a full queue. */
+int oalgpu_debug_submit_cost(oalgpu_context *c, const oalgpu_voice_move *moves, size_t count, uint32_t move_sets,
+    uint32_t updates, uint32_t samples_to_do, int post_process, float *out, size_t out_floats, double *submit_s)
+{
+    if(!c || !moves || !out || !submit_s || count == 0 || move_sets == 0 || updates == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_submit_cost: bad arguments");
+    if(int rc = oalgpu_sync(c)) return rc;
+    using clk = std::chrono::steady_clock;
+    double spent = 0.0;
+    for(uint32_t u = 0; u < updates; ++u)
+    {
+        uint32_t ticket = 0;
+        const auto t0 = clk::now();
+        if(int rc = oalgpu_voice_move_async(c, moves + size_t{u % move_sets} * count, count)) return rc;
+        if(int rc = oalgpu_mix_update(c, samples_to_do, post_process)) return rc;
+        if(int rc = oalgpu_read_output_async(c, &ticket)) return rc;
+        spent += std::chrono::duration<double>(clk::now() - t0).count();
+        if(int rc = oalgpu_output_wait(c, ticket, out, out_floats)) return rc;
+    }
+    *submit_s = spent / updates;
     return OALGPU_OK;
 }
 
@@ -2386,11 +2420,13 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     // main stream: this update's voices; its partial-bus buffer was last read by the reduction
     // of two updates ago
     // (almost always long done: then no barrier packet goes into the main queue in front of the voice kernel)
+    if(c->reduceUpdate[p] > c->updatesKnownDone)
     {
         const hipError_t q = hipEventQuery(c->evReduceDone[p]);
         if(q == hipErrorNotReady) HIP_TRY(hipStreamWaitEvent(c->stream, c->evReduceDone[p], 0));
         else HIP_TRY(q);
     }
+    c->reduceUpdate[p] = ++c->updatesSubmitted;
     // (timing: the two events are bound to the dispatch itself -- the kernel's own start and end)
     // The event the post stream waits for is bound to the voice kernel's dispatch (hipExtLaunchKernel's stop event: one
     // runtime call less per update than a record behind the launch).  Timing runs use that slot for their own event.
@@ -2446,6 +2482,7 @@ int oalgpu_sync(oalgpu_context *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if(c->postStream) HIP_TRY(hipStreamSynchronize(c->postStream));
     c->postPending = false;
+    c->updatesKnownDone = c->updatesSubmitted;
     return OALGPU_OK;
 }
 

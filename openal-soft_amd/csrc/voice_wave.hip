@@ -948,6 +948,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         // NL == 0: before the FIR, whose ~1100 packed FMAs cover the latency (matrix-pipe FIR: before the build
         // of its inputs, above).  NL > 0 (no FIR in this kernel): right after the resampler, ahead of the
         // filters and the stream-row stores.
+        if constexpr (PROF) { if(first) waveStamp(7); }
 #ifndef OALGPU_EXP_LATE_REQUEST
         if constexpr (NL > 0 || MF) { if(!active) requestNext(); }
 #endif

@@ -499,6 +499,18 @@ class Scene:
               "oalgpu_debug_pipelined_run")
         return wall.value, busy.value
 
+    def submit_cost(self, move_sets, updates, samples=BUFFER_LINE, post_process=True):
+        """oalgpu_debug_submit_cost: seconds per update the three submitting calls cost the calling thread when nothing is queued."""
+        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(m, MOVE_DTYPE) for m in move_sets]))
+        n = self.desc.num_real_channels or self.desc.num_dry_channels
+        out = np.empty((n, BUFFER_LINE), np.float32)
+        spent = C.c_double()
+        lib.oalgpu_debug_submit_cost.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                                 f32p, C.c_size_t, C.POINTER(C.c_double)]
+        check(lib.oalgpu_debug_submit_cost(self.h, flat.ctypes.data_as(C.c_void_p), len(move_sets[0]), len(move_sets), updates, samples,
+                                           1 if post_process else 0, _fp(out), out.size, C.byref(spent)), "oalgpu_debug_submit_cost")
+        return spent.value
+
     def read_output_async(self):
         lib.oalgpu_read_output_async.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         t = C.c_uint32()

@@ -69,6 +69,7 @@ for nm, x in (("pass 0 (first head/buffer/window + table staging)", d0), ("voice
     print("%-52s mean=%.0f p50=%.0f p99=%.0f max=%.0f" % (nm, x.mean(), np.median(x), np.percentile(x, 99), x.max()))
 print("pass 0 in detail (cycles after entry): control line in registers %.0f, request issued %.0f, staging barrier passed %.0f, first voice parked %.0f"
       % ((wt[:, 4] - wt[:, 0]).mean(), (wt[:, 5] - wt[:, 0]).mean(), (wt[:, 6] - wt[:, 0]).mean(), d0.mean()))
+print("  the first request begins at %.0f (accumulators cleared, the pass loop entered)" % (wt[:, 7] - wt[:, 0]).mean())
 h2 = nw.value // 2
 print("wave lifetime, first-half workgroups: mean=%.0f max=%.0f; second half: mean=%.0f max=%.0f" % (tot[:h2].mean(), tot[:h2].max(), tot[h2:].mean(), tot[h2:].max()))
 
