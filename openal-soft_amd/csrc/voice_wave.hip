@@ -1010,8 +1010,15 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                 {
                     const uint32_t p = idx >> 5, pi = idx & 31u;
                     const float *row = filter + pi * 2u * m;
+#ifdef OALGPU_EXP_ROWS128
+                    if constexpr (ACCL == 0)
+                        reinterpret_cast<f4*>(sm.tabF)[idx] = f4{row[2u * p], row[2u * p + 1u], row[m + 2u * p], row[m + 2u * p + 1u]};
+                    else
+#endif
+                    {
                     sm.tabF[idx] = f2{row[2u * p], row[2u * p + 1u]};
                     sm.tabP[idx] = f2{row[m + 2u * p], row[m + 2u * p + 1u]};
+                    }
                 }
             }
             // zero padding of the old-filter coefficient array (never overwritten)

@@ -111,7 +111,7 @@ struct WgLds {
     // of them (LDS is allocated in granules of 1280 bytes: 2 x 62 + 4 granules = 160 KB).
     static constexpr int kPairs = MF ? 12 : kTabPairs;
     WaveLds<R, TAPS, MF> w[kWWaves];
-    f2 tabF[kPairs * 32];                               // [tap pair][phase] = fil[2p], fil[2p+1]
+    alignas(16) f2 tabF[kPairs * 32];                   // [tap pair][phase] = fil[2p], fil[2p+1]
     f2 tabP[kPairs * 32];                               //                    = phd[2p], phd[2p+1]
     uint32_t tabKey, tabM, tabL;
     uint32_t pad;
@@ -270,12 +270,26 @@ __device__ __forceinline__ void ResampleRunStaged(const f2 *tabF, const f2 *tabP
         const uint32_t pi = (tt >> 11) & 31u;
         const f2 *tf = tabF + pi, *tp = tabP + pi;
         const float *s = rdb + (tt >> kFracBits);
+#ifdef OALGPU_EXP_ROWS128
+        {   // experiment: [tap pair][phase] = (fil[2p], fil[2p+1], phd[2p], phd[2p+1]) as ONE 16-byte read
+            const f4 *tq = reinterpret_cast<const f4*>(tabF) + pi;
+            (void)tf; (void)tp;
+#pragma unroll
+            for(int q = 0; q < NP; ++q)
+            {
+                const f4 v = tq[(g * NP + q) * 32];
+                F[q] = f2{v.x, v.y};
+                P[q] = f2{v.z, v.w};
+            }
+        }
+#else
 #pragma unroll
         for(int q = 0; q < NP; ++q)
         {
             F[q] = tf[(g * NP + q) * 32];
             P[q] = tp[(g * NP + q) * 32];
         }
+#endif
         if constexpr (DUAL)
         {   // the pair (s[2j], s[2j+1]) as ONE aligned 8-byte read: out of rd when it starts at an even index, else out of rd2
             const uint32_t pos = tt >> kFracBits;
