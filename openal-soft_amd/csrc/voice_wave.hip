@@ -34,6 +34,9 @@
 
 #pragma clang fp contract(off)
 
+#if defined(OALGPU_EXP_ROWS128) && !defined(OALGPU_EXP_LATE_ROWS)
+#define OALGPU_EXP_LATE_ROWS 1              // (the 16-byte row layout is staged by the prologue's own loop)
+#endif
 #ifndef OALGPU_WAVE_MIN_WG
 #define OALGPU_WAVE_MIN_WG 2              // workgroups per CU the kernels are built for (experiments: 1 shows the unconstrained budget)
 #endif
@@ -949,6 +952,28 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         // of its inputs, above).  NL > 0 (no FIR in this kernel): right after the resampler, ahead of the
         // filters and the stream-row stores.
         if constexpr (PROF) { if(first) waveStamp(7); }
+        // pass 0: the resampler rows the workgroup stages (see the prologue below) are requested BEFORE the first voice's
+        // window, as LDS-DMA gathers (global_load_lds_dword: lane l of the load for tap pair p fetches fil / phd element
+        // 2 p + (l & 1) of phase row l >> 1 straight into tabF / tabP [p][l >> 1] -- no registers hold them, no ds_write, and
+        // their round trip lies behind the issue of the window's loads instead of in front of the staging barrier)
+        constexpr uint32_t kMaxM = 2u * uint32_t(WgLds<R, TAPS, MF>::kPairs);
+        const int kK = headK.rsKind;
+        const uint32_t mK = kK == 2 ? 4u : headK.rsM, lK = kK == 2 ? 1u : headK.rsL;
+        const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24 || mK == 48) && mK <= kMaxM))
+            && (headK.playState == OALGPU_VOICE_PLAYING || headK.playState == OALGPU_VOICE_STOPPING);
+#ifndef OALGPU_EXP_LATE_ROWS
+        if(first && eligK)
+        {
+            typedef const __attribute__((address_space(1))) void *gvoidp;
+            typedef __attribute__((address_space(3))) void *lvoidp;
+            const float *src = L.tables + headK.rsFilterOffset + size_t{lane >> 1} * (2u * mK) + (lane & 1u);
+            for(uint32_t pp = wave; pp < mK / 2u; pp += kWWaves)
+            {
+                __builtin_amdgcn_global_load_lds((gvoidp)(src + 2u * pp), (lvoidp)&sm.tabF[32u * pp], 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gvoidp)(src + mK + 2u * pp), (lvoidp)&sm.tabP[32u * pp], 4, 0, 0);
+            }
+        }
+#endif
 #ifndef OALGPU_EXP_LATE_REQUEST
         if constexpr (NL > 0 || MF) { if(!active) requestNext(); }
 #endif
@@ -961,11 +986,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             // itself (no barrier, no second round trip at kernel start); if that voice does not
             // qualify, wavefront 0 looks for one that does.
             const uint32_t gBegin = group * kWWaves * vpw;
-            const int kK = headK.rsKind;
-            const uint32_t mK = kK == 2 ? 4u : headK.rsM, lK = kK == 2 ? 1u : headK.rsL;
-            constexpr uint32_t kMaxM = 2u * uint32_t(WgLds<R, TAPS, MF>::kPairs);
-            const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24 || mK == 48) && mK <= kMaxM))
-                && (headK.playState == OALGPU_VOICE_PLAYING || headK.playState == OALGPU_VOICE_STOPPING);
             uint32_t key = headK.rsFilterOffset * 8u + uint32_t(kK), m = mK;
             if(eligK)
             {   // (the values to store are made here, behind an opaque move: as loop invariants the compiler kept them
@@ -1003,6 +1023,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             __syncthreads();
             key = sm.tabKey; m = sm.tabM;
             }
+#ifndef OALGPU_EXP_LATE_ROWS
+            if(eligK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the rows requested above are in LDS (and so is this wavefront's window in its registers)
+            else
+#endif
             if(key != 0xffffffffu)
             {
                 const float *filter = L.tables + (key >> 3);
