@@ -353,6 +353,15 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     const uint32_t irStride = L.irStride;
     WL &w = sm.w[wave];
     const uint32_t N = samplesToDo;
+#ifndef OALGPU_EXP_LAZY_ARGS
+    // The argument block's pointers are needed in SGPRs all at once here, so that their kernarg loads are issued together and
+    // waited for ONCE: left to itself the compiler loads each pointer where it spills it to a VGPR lane -- one scalar load and
+    // one s_waitcnt after the other, a dozen dependent round trips in front of every wavefront's first useful instruction.
+    if constexpr (std::is_same<LT, WaveArgsHrtf>::value)
+        asm volatile("; argument block resident" :: "s"(L.tables), "s"(L.buffers), "s"(L.ctl), "s"(L.prev), "s"(L.dfilt), "s"(L.hrtfOld),
+            "s"(L.hrtfTgt), "s"(L.hist), "s"(L.ambi), "s"(L.startDelay), "s"(L.queueDone), "s"(L.partHrtf), "s"(L.hrirs),
+            "s"(next.recs), "s"(next.map), "s"(L.numVoices), "s"(L.waveVoices), "s"(L.irStride), "s"(L.pad), "s"(samplesToDo), "s"(gridDim.x));
+#endif
 
     // The workgroup owns kWWaves*vpw consecutive voices; a wavefront takes every SECOND one of its
     // half of them (wave 0: v, v+2, ..; wave 1: v+1, v+3, ..).  Voices that cost more -- an active
@@ -396,17 +405,31 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     BufferItem bufN{};
     bool loopingN = false;
     float fstC = 0.0f;                      // SENDS: the direct filter's state words, carried to the next pass
+    // the voice whose resampler rows the workgroup stages (see the prologue below): every wavefront
+    // reads its head itself, so that the choice needs no barrier.  (Requested first: both control lines are then in
+    // flight together -- scalar loads return out of order, so the first wait for any of them waits for all.)
+    // (Unconditional loads of a clamped index: behind a branch each request would be waited for where the branch joins.)
+    const uint32_t keyVoice = group * kWWaves * vpw;
+    const uint32_t lastVoice = L.numVoices - 1u;
+#ifdef OALGPU_EXP_COND_HEAD
     if(vCount)
     {
         headN = LoadHeadScalar(L.ctl + voiceAt(0)); bufN = LoadCtlBufferScalar(L.ctl + voiceAt(0));
         if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + voiceAt(0));
     }
+#else
+    {
+        const uint32_t v0 = vCount ? voiceAt(0) : lastVoice;        // (a wavefront without voices never uses what it reads here)
+        headN = LoadHeadScalar(L.ctl + v0); bufN = LoadCtlBufferScalar(L.ctl + v0);
+        if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + v0);
+    }
+#endif
+    asm volatile("" ::: "memory");          // (the first voice's request is issued above this line ...)
+    const VoiceHead headK = LoadHeadScalar(L.ctl + (keyVoice < L.numVoices ? keyVoice : lastVoice));
+    asm volatile("" ::: "memory");          // (... the key voice's above this one: both are in flight at the first wait for either)
+    const int psK = headK.playState, kK = headK.rsKind;
+    const uint32_t mK = kK == 2 ? 4u : headK.rsM, lK = kK == 2 ? 1u : headK.rsL, offK = headK.rsFilterOffset;
     if constexpr (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); waveStamp(4); }
-    // the voice whose resampler rows the workgroup stages (see the prologue below): every wavefront
-    // reads its head itself, so that the choice needs no barrier
-    const uint32_t keyVoice = group * kWWaves * vpw;
-    VoiceHead headK{};
-    if(keyVoice < L.numVoices) headK = LoadHeadScalar(L.ctl + keyVoice);
 
     f2 acc[MF ? 1 : R];
 #pragma unroll
@@ -957,16 +980,14 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         // 2 p + (l & 1) of phase row l >> 1 straight into tabF / tabP [p][l >> 1] -- no registers hold them, no ds_write, and
         // their round trip lies behind the issue of the window's loads instead of in front of the staging barrier)
         constexpr uint32_t kMaxM = 2u * uint32_t(WgLds<R, TAPS, MF>::kPairs);
-        const int kK = headK.rsKind;
-        const uint32_t mK = kK == 2 ? 4u : headK.rsM, lK = kK == 2 ? 1u : headK.rsL;
         const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24 || mK == 48) && mK <= kMaxM))
-            && (headK.playState == OALGPU_VOICE_PLAYING || headK.playState == OALGPU_VOICE_STOPPING);
+            && (psK == OALGPU_VOICE_PLAYING || psK == OALGPU_VOICE_STOPPING);
 #ifndef OALGPU_EXP_LATE_ROWS
         if(first && eligK)
         {
             typedef const __attribute__((address_space(1))) void *gvoidp;
             typedef __attribute__((address_space(3))) void *lvoidp;
-            const float *src = L.tables + headK.rsFilterOffset + size_t{lane >> 1} * (2u * mK) + (lane & 1u);
+            const float *src = L.tables + offK + size_t{lane >> 1} * (2u * mK) + (lane & 1u);
             for(uint32_t pp = wave; pp < mK / 2u; pp += kWWaves)
             {
                 __builtin_amdgcn_global_load_lds((gvoidp)(src + 2u * pp), (lvoidp)&sm.tabF[32u * pp], 4, 0, 0);
@@ -986,7 +1007,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             // itself (no barrier, no second round trip at kernel start); if that voice does not
             // qualify, wavefront 0 looks for one that does.
             const uint32_t gBegin = group * kWWaves * vpw;
-            uint32_t key = headK.rsFilterOffset * 8u + uint32_t(kK), m = mK;
+            uint32_t key = offK * 8u + uint32_t(kK), m = mK;
             if(eligK)
             {   // (the values to store are made here, behind an opaque move: as loop invariants the compiler kept them
                 // in VGPRs across every pass for the one store of pass 0)
