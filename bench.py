@@ -591,12 +591,13 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            # config 3 is BASELINE.json's headline: its metric string verbatim (the "fraction of HBM
-            # roofline" half of it is roofline.hbm_frac; `value` is the voices/s half)
+            # BASELINE.json's metric string verbatim for the two HRTF-stereo configs -- configs[2], the headline, and
+            # configs[4], the same voices with a send into the convolution slot, which `--gpus N` runs (config.workload says
+            # which): the "fraction of HBM roofline" half is roofline.hbm_frac, `value` the voices/s half
             "metric": {3: "mixed voices/sec @48kHz 1024-sample update, HRTF stereo; fraction of HBM roofline",
                        2: "mixed voices/sec @48kHz 1024-sample update, bsinc24 -> 7.1 dry bus",
                        4: "mixed voices/sec @48kHz 1024-sample update, 7.1 dry bus + 4 EAX reverb slots",
-                       5: "mixed voices/sec @48kHz 1024-sample update, HRTF stereo + convolution slot"}[args.config],
+                       5: "mixed voices/sec @48kHz 1024-sample update, HRTF stereo; fraction of HBM roofline"}[args.config],
             "value": nvoices_total * args.steps / elapsed,
             "unit": "voices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
