@@ -150,6 +150,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
 {
     __shared__ float xs[kLine + 64];                                   // split: the channel; FIR: [kPostGroup][128 + 64] windows
     const uint32_t lane = threadIdx.x;
+#ifdef OALGPU_EXP_POST_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     if(blockIdx.x < nch)
     {   // ---- BandSplitter::processHfScale of dry channel c (PostSplitKernel)
         const uint32_t c = blockIdx.x;
