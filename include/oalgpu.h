@@ -189,6 +189,9 @@ typedef struct oalgpu_context_desc {
                                    * block (every wavefront the records of the voices it mixed) instead of a parameter kernel between
                                    * two voice kernels.  Measured slower than the parameter kernel on three of five boxes (DESIGN.md
                                    * 3.10): an opt-in variant, for A/B runs */
+#define OALGPU_CTX_FUSED_REDUCE 32u /* pipelined HRTF contexts without effect slots and without a collective: the bus reduction and the
+                                   * post-process as ONE launch.  One launch less for the host, and measured 1.2-1.9 us per update
+                                   * slower than the two launches: an opt-in variant, for A/B runs */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 

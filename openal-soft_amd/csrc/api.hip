@@ -134,6 +134,15 @@ struct oalgpu_context {
     // What the host already knows to be finished saves it runtime calls: an output that has been waited for proves its update's
     // whole chain done (moves installed, voices mixed, reduced, post-processed), so the checks in front of a slot's or a
     // partial-bus buffer's reuse need not ask the runtime.  Updates are numbered from 1 as they are submitted.
+    // oalgpu_mix_update of a pipelined HRTF context without effect slots and without a collective: reduction and post-process
+    // are ONE launch (LaunchReducePostFused).  fuseReduce: this update's reduction was held back for it (oalgpu_mix_voices_overlapped
+    // -> oalgpu_post_process_overlapped); reducedEpoch: what the launch's counter of reduction workgroups reads when they are through.
+    bool fuseReduce{false}, reduceHeld{false};
+    DeviceLayout heldL{};
+    uint32_t heldParity{0};
+    DevBuf<uint32_t> reducedCount;
+    uint32_t reducedEpoch{0};
+    hipEvent_t lastPostEvent{nullptr};      // what JoinPost waits for: evPostDone, or the fused launch's own event
     uint64_t updatesSubmitted{0}, updatesKnownDone{0};
     uint64_t reduceUpdate[2]{0, 0}, panUpdate[kIoSlots]{}, outUpdate[kIoSlots]{};
     uint32_t *outFlags{nullptr};
@@ -2075,6 +2084,17 @@ static int PostDirectHrtfFused(oalgpu_context *c, hipStream_t s, uint32_t sample
     if(c->runPowerSeg != seg) { SplitterRunPowers(c->dSplitCoeff, seg, c->runPower); c->runPowerSeg = seg; }
     const uint32_t slot = c->outNext % oalgpu_context::kIoSlots;
     const bool ring = c->outRing && c->outFlags;
+    if(c->reduceHeld)
+    {   // the update's reduction rides in the same launch (its partial buses: heldL's)
+        c->reduceHeld = false;
+        if(!c->reducedCount.p) { HIP_TRY(c->reducedCount.alloc(1)); HIP_TRY(c->reducedCount.zero()); }
+        c->reducedEpoch += ReducePostReduceGroups(c->heldL);
+        LaunchReducePostFused(s, c->heldL, CarrySource(c, c->carryAccum && L.hrtf), left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L),
+            c->carryBuf.p, spIn, spOut, c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, c->postEpoch,
+            c->runPower, evDone, ring ? c->outHost[slot] : nullptr, ring ? c->outFlags + size_t{slot} * 16 : nullptr, c->outSeq + 1u,
+            c->outArrived.p, c->reducedCount.p, c->reducedEpoch);
+    }
+    else
     LaunchPostDirectHrtfFused(s, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->carryBuf.p, spIn, spOut,
         c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, c->postEpoch, c->runPower, evDone,
         ring ? c->outHost[slot] : nullptr, ring ? c->outFlags + size_t{slot} * 16 : nullptr, c->outSeq + 1u, c->outArrived.p);
@@ -2090,7 +2110,7 @@ static int PostDirectHrtfFused(oalgpu_context *c, hipStream_t s, uint32_t sample
 static int JoinPost(oalgpu_context *c)
 {
     if(!c->postPending) return OALGPU_OK;
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->evPostDone, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->lastPostEvent ? c->lastPostEvent : c->evPostDone, 0));
     c->postPending = false;
     return OALGPU_OK;
 }
@@ -2384,7 +2404,11 @@ static int RunMixUpdate(oalgpu_context *c, uint32_t samples_to_do, int post_proc
         if(post_process && c->commRank == 0) return oalgpu_post_process(c, samples_to_do);
         return OALGPU_OK;
     }
-    if(int rc = oalgpu_mix_voices_overlapped(c, samples_to_do)) return rc;
+    c->fuseReduce = post_process && !c->comm && c->L.hrtf && c->L.numSlots == 0 && c->L.numReal >= 2 && !c->timing
+        && (c->desc.flags & OALGPU_CTX_FUSED_REDUCE);
+    const int rcv = oalgpu_mix_voices_overlapped(c, samples_to_do);
+    c->fuseReduce = false;
+    if(rcv) { c->reduceHeld = false; return rcv; }
     // sharded contexts: the effects and the post-process run where the reduced buses are, on rank 0
     return oalgpu_post_process_overlapped(c, samples_to_do, post_process && c->commRank == 0);
 }
@@ -2438,6 +2462,12 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     HIP_TRY(hipStreamWaitEvent(c->postStream, c->evVoiceDone[p], 0));
     // (4-wavefront workgroups: they find room on a CU as soon as ONE of the next update's voice workgroups
     // has left it; the 16-wavefront form waits for a whole CU -- measured 62 against 53 us per config-2 step)
+    if(c->fuseReduce)
+    {   // (oalgpu_mix_update: the reduction is launched together with the post-process that follows at once)
+        c->reduceHeld = true; c->heldL = L; c->heldParity = p;
+        c->parity = p ^ 1u;
+        return OALGPU_OK;
+    }
     LaunchBusReduce(c->postStream, L, samples_to_do, CarrySource(c, c->carryAccum && L.hrtf), true, c->evReduceDone[p]);
     HIP_TRY(hipGetLastError());
     if(int rc = CommReduceBus(c, c->postStream)) return rc;      // beside the next update's voice kernel
@@ -2460,9 +2490,13 @@ int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, in
     if(post_process && L.hrtf)
     {
         // (the update's last launch on this stream, unless timing asks for an event of its own behind it: evPostDone rides on it)
-        if(int rc = PostDirectHrtfFused(c, c->postStream, samples_to_do, c->timing ? nullptr : c->evPostDone)) return rc;
-        postDoneBound = !c->timing;
+        // (with the reduction in the same launch the event is the one the voice kernel of two updates on waits for as well)
+        hipEvent_t ev = c->reduceHeld ? c->evReduceDone[c->heldParity] : (c->timing ? nullptr : c->evPostDone);
+        c->lastPostEvent = ev ? ev : c->evPostDone;
+        if(int rc = PostDirectHrtfFused(c, c->postStream, samples_to_do, ev)) return rc;
+        postDoneBound = ev != nullptr;
     }
+    else c->lastPostEvent = c->evPostDone;
     if(post_process && !L.hrtf && c->decOn)
     {   // DeviceBase::Process(AmbiDecPostProcess), alc/alu.cpp:282-287: dry lines -> speaker feeds
         LaunchBFormatDecode(c->postStream, c->exact, L.bus + size_t{L.numDry} * kLine, L.bus, c->decSplit.p, c->decBands.p,

@@ -232,6 +232,12 @@ void LaunchPostDirectHrtfFast(hipStream_t s, float *left, float *right, const fl
     hipEvent_t evDone = nullptr);
 
 // the same as ONE launch (pipelined FAST HRTF contexts): see post_wave.hip
+// workgroups of the reduction inside LaunchReducePostFused: 64 bus columns each (BusFloats(L) / 64, rounded up)
+inline uint32_t ReducePostReduceGroups(const DeviceLayout &L) { return uint32_t((BusFloats(L) + 63u) / 64u); }
+void LaunchReducePostFused(hipStream_t s, const DeviceLayout &L, const float *carry, float *left, float *right, const float *in, uint32_t nch,
+    const float *accIn, float *carryOut, const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs,
+    uint32_t irsize, uint32_t n, float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone,
+    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived, uint32_t *reduced, uint32_t reducedEpoch);
 void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
     const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
     float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone = nullptr,

@@ -17,6 +17,7 @@
 // EXACT mode keeps the term-by-term kernel in percall_kernels.hip.
 #include <hip/hip_ext.h>
 #include "dev_wave.hpp"
+#include "dev_reduce.hpp"
 
 #pragma clang fp contract(off)
 
@@ -142,22 +143,35 @@ __device__ __forceinline__ void PostStoreCoherent(float *p, float v) { __hip_ato
 __device__ __forceinline__ float PostLoadCoherent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 constexpr int kFusedFrames = 64;                            // output frames per FIR workgroup: one per lane, both ears
-__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) PostFusedKernel(const float *__restrict__ in, uint32_t nch,
+// One wavefront's share of the fused post-process: wg < nch = the split of dry channel wg, else FIR block wg - nch of nfirWgs.
+// FUSED: the bus block was reduced by workgroups of the SAME launch (ReducePostFusedKernel): `reduced` reaches `reducedEpoch`
+// when they are all through, and what they wrote is read with L2-coherent loads.
+template<bool FUSED>
+__device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t tid, uint32_t nfirWgs, const float *__restrict__ in, uint32_t nch,
     const SplitterState *__restrict__ spIn, SplitterState *__restrict__ spOut, const float *__restrict__ hfscales,
     const float *__restrict__ chanCoeffs, uint32_t taps, const float *__restrict__ accIn, float *__restrict__ carryOut,
     float *__restrict__ left, float *__restrict__ right, uint32_t n, float *__restrict__ xf, uint32_t *__restrict__ arrived, uint32_t epoch,
-    Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived)
+    Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived,
+    const uint32_t *__restrict__ reduced, uint32_t reducedEpoch)
 {
-    __shared__ float xs[kLine + 64];                                   // split: the channel; FIR: [kPostGroup][128 + 64] windows
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = tid;
 #ifdef OALGPU_EXP_POST_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    if(blockIdx.x < nch)
+    if(wg < nch)
     {   // ---- BandSplitter::processHfScale of dry channel c (PostSplitKernel)
-        const uint32_t c = blockIdx.x;
+        const uint32_t c = wg;
+        if constexpr (FUSED)
+        {   // the dry lines are this launch's own reduction workgroups' sums
+            while(int32_t(__hip_atomic_load(reduced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - reducedEpoch) < 0) __builtin_amdgcn_s_sleep(4);
 #pragma unroll 8
-        for(uint32_t k = lane; k < uint32_t(kLine); k += 64) xs[k] = (k < n) ? in[size_t{c} * kLine + k] : 0.0f;
+            for(uint32_t k = lane; k < uint32_t(kLine); k += 64) xs[k] = (k < n) ? PostLoadCoherent(in + size_t{c} * kLine + k) : 0.0f;
+        }
+        else
+        {
+#pragma unroll 8
+            for(uint32_t k = lane; k < uint32_t(kLine); k += 64) xs[k] = (k < n) ? in[size_t{c} * kLine + k] : 0.0f;
+        }
         WaveSync();
         SplitterState st = spIn[c];
         SplitterScanHfDpp(st, xs, n, hfscales[c], lane, runPower);
@@ -173,14 +187,17 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
     // through the scalar cache as SGPR operands: ONE LDS read per tap and two multiply-adds, where lanes that split ears and
     // taps read coefficient AND sample from LDS for every multiply-add (the LDS pipe is what the voice kernel beside this one
     // keeps busy) -- and the shift (PostFirKernel + PostShiftKernel)
-    const uint32_t blk = blockIdx.x - nch;
+    const uint32_t blk = wg - nch;
     const uint32_t o = blk * uint32_t(kFusedFrames) + lane;
     const int32_t base = int32_t(blk) * kFusedFrames - kHrirLen;
-    const f2 accOld = reinterpret_cast<const f2*>(accIn)[o];           // (requested before the wait)
+    f2 accOld = {0.0f, 0.0f};
+    if constexpr (!FUSED) accOld = reinterpret_cast<const f2*>(accIn)[o];           // (requested before the wait)
     while(int32_t(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) __builtin_amdgcn_s_sleep(8);
+    if constexpr (FUSED)      // (the channels have arrived, so the reduction they waited for is through: its accumulator columns)
+        accOld = f2{PostLoadCoherent(accIn + 2u * o), PostLoadCoherent(accIn + 2u * o + 1u)};
     constexpr int kWin = kHrirLen + kFusedFrames;
     float (*xw4)[kWin] = reinterpret_cast<float (*)[kWin]>(xs);
-    static_assert(sizeof(xs) >= sizeof(float) * kPostGroup * kWin, "the FIR windows fit into the split's line buffer");
+    static_assert(sizeof(float) * (kLine + 64) >= sizeof(float) * kPostGroup * kWin, "the FIR windows fit into the split's line buffer");
     float accL = 0.0f, accR = 0.0f;
     for(uint32_t c0 = 0; c0 < nch; c0 += kPostGroup)
     {
@@ -220,7 +237,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
         const f2 s = f2{accOld.x + accL, accOld.y + accR};
         if(o < uint32_t(kLine))
         {
-            float l = left[o], r = right[o];
+            float l, r;
+            if constexpr (FUSED) { l = PostLoadCoherent(left + o); r = PostLoadCoherent(right + o); }
+            else { l = left[o]; r = right[o]; }
             if(o < n) { l = l + s.x; r = r + s.y; left[o] = l; right[o] = r; }
             // the pipelined host boundary (oalgpu_read_output_async): the two output lines also go straight into the host's
             // pinned ring slot -- no copy launch behind this kernel, no runtime call on the host
@@ -236,7 +255,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
         __threadfence_system();
         if(lane == 0)
         {
-            const uint32_t nfir = gridDim.x - nch;
+            const uint32_t nfir = nfirWgs;
             const uint32_t t = __hip_atomic_fetch_add(outArrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             if((t + 1u) % nfir == 0u)
             {
@@ -245,6 +264,53 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
             }
         }
     }
+}
+
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) PostFusedKernel(const float *__restrict__ in, uint32_t nch,
+    const SplitterState *__restrict__ spIn, SplitterState *__restrict__ spOut, const float *__restrict__ hfscales,
+    const float *__restrict__ chanCoeffs, uint32_t taps, const float *__restrict__ accIn, float *__restrict__ carryOut,
+    float *__restrict__ left, float *__restrict__ right, uint32_t n, float *__restrict__ xf, uint32_t *__restrict__ arrived, uint32_t epoch,
+    Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived)
+{
+    __shared__ float xs[kLine + 64];                                   // split: the channel; FIR: [kPostGroup][128 + 64] windows
+    PostFusedBlock<false>(xs, blockIdx.x, threadIdx.x, gridDim.x - nch, in, nch, spIn, spOut, hfscales, chanCoeffs, taps, accIn, carryOut, left, right, n,
+        xf, arrived, epoch, runPower, hostOut, hostFlag, hostSeq, outArrived, nullptr, 0u);
+}
+
+// Reduction AND post-process of a context without effect slots and without a collective as ONE launch: workgroups
+// [0, nReduce) are BusReduceKernel<4>'s (four wavefronts, 64 bus columns each; they store their sums written-through and
+// count themselves in), the rest are PostFusedKernel's workgroups with three idle wavefronts that leave at once -- the
+// splits wait for the reduction's counter, the FIR blocks for the splits'.  One dispatch gap and one launch less on the post
+// stream than the two kernels; the same sums in the same order, so the same bits.
+// (four partial sums of each run per step instead of BusReduceKernel<4>'s eight: beside the post-process's registers that is
+// what keeps the launch within the 48 registers two voice wavefronts leave of a SIMD)
+#ifndef OALGPU_FUSED_KF
+#define OALGPU_FUSED_KF 4
+#endif
+struct ReducePostArgs {
+    const float *carry; uint32_t nReduce;
+    const float *in; uint32_t nch;
+    const SplitterState *spIn; SplitterState *spOut; const float *hfscales, *chanCoeffs; uint32_t taps;
+    const float *accIn; float *carryOut, *left, *right; uint32_t n; float *xf; uint32_t *arrived; uint32_t epoch; Tri3 runPower;
+    float *hostOut; uint32_t *hostFlag; uint32_t hostSeq; uint32_t *outArrived;
+    uint32_t *reduced; uint32_t reducedEpoch;
+};
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) ReducePostFusedKernel(DeviceLayout L, ReducePostArgs A)
+{
+    __shared__ float xs[kLine + 64];
+    if(blockIdx.x < A.nReduce)
+    {
+        BusReduceBlock<4, true, OALGPU_FUSED_KF>(L, A.carry, reinterpret_cast<float (*)[64]>(xs), blockIdx.x, threadIdx.x);
+        if(threadIdx.x < 64)
+        {   // the sums are where the others will read them before this workgroup counts as through
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if(threadIdx.x == 0) __hip_atomic_fetch_add(A.reduced, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if(threadIdx.x >= 64) return;
+    PostFusedBlock<true>(xs, blockIdx.x - A.nReduce, threadIdx.x, gridDim.x - A.nReduce - A.nch, A.in, A.nch, A.spIn, A.spOut, A.hfscales, A.chanCoeffs, A.taps,
+        A.accIn, A.carryOut, A.left, A.right, A.n, A.xf, A.arrived, A.epoch, A.runPower, A.hostOut, A.hostFlag, A.hostSeq, A.outArrived, A.reduced, A.reducedEpoch);
 }
 
 } // namespace
@@ -265,6 +331,23 @@ void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const f
     static_assert(kPostFrames % kFusedFrames == 0, "whole workgroups");
     hipExtLaunchKernelGGL(PostFusedKernel, dim3(nch + kPostFrames / kFusedFrames), dim3(64), 0, s, nullptr, evDone, 0u, in, nch, spIn, spOut, hfscales,
         chanCoeffs, taps, accIn, carryOut, left, right, n, xf, arrived, epoch, P, hostOut, hostFlag, hostSeq, outArrived);
+}
+
+// The reduction of update k and its HRTF post-process in one launch (see ReducePostFusedKernel); reduced / reducedEpoch: the
+// context's counter of reduction workgroups and what it reads when this update's are all through
+void LaunchReducePostFused(hipStream_t s, const DeviceLayout &L, const float *carry, float *left, float *right, const float *in, uint32_t nch,
+    const float *accIn, float *carryOut, const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs,
+    uint32_t irsize, uint32_t n, float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone,
+    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived, uint32_t *reduced, uint32_t reducedEpoch)
+{
+    ReducePostArgs A{};
+    A.carry = carry; A.nReduce = ReducePostReduceGroups(L);
+    A.in = in; A.nch = nch; A.spIn = spIn; A.spOut = spOut; A.hfscales = hfscales; A.chanCoeffs = chanCoeffs;
+    A.taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
+    A.accIn = accIn; A.carryOut = carryOut; A.left = left; A.right = right; A.n = n; A.xf = xf; A.arrived = arrived; A.epoch = epoch;
+    A.runPower = Tri3{runPower[0], runPower[1], runPower[2], runPower[3]};
+    A.hostOut = hostOut; A.hostFlag = hostFlag; A.hostSeq = hostSeq; A.outArrived = outArrived; A.reduced = reduced; A.reducedEpoch = reducedEpoch;
+    hipExtLaunchKernelGGL(ReducePostFusedKernel, dim3(A.nReduce + nch + kPostFrames / kFusedFrames), dim3(256), 0, s, nullptr, evDone, 0u, L, A);
 }
 
 // temp: nch x 1024 filtered channels, then 1152 x 2 channel sums

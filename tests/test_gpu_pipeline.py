@@ -26,17 +26,19 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("variant", ["default", "apply-in-voice-kernel"])
+@pytest.mark.parametrize("variant", ["default", "apply-in-voice-kernel", "fused-reduce"])
 def test_pipelined_update_equals_serial_update(synth_mhr, variant):
     """variant "apply-in-voice-kernel" (OALGPU_CTX_APPLY_IN_VOICE_KERNEL): every update is submitted one library call late and
     the parameter block that follows it is installed by the update's own wavefronts, behind the voices they mixed -- the same
-    operations as ApplyParamsKernel, so still the serial scene's bits."""
+    operations as ApplyParamsKernel, so still the serial scene's bits.  "fused-reduce" (OALGPU_CTX_FUSED_REDUCE): the reduction and
+    the post-process of an update as one launch -- the same sums in the same order."""
     import oalgpu
     from oalgpu import synth
     import bench
     assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
     api = oalgpu.Api(oalgpu.MATH_FAST)
-    papi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_APPLY_IN_VOICE_KERNEL) if variant != "default" else api
+    flags = {"default": 0, "apply-in-voice-kernel": oalgpu.CTX_APPLY_IN_VOICE_KERNEL, "fused-reduce": oalgpu.CTX_FUSED_REDUCE}[variant]
+    papi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=flags) if flags else api
     mhr = synth.synth_mhr_bytes()
     api._mhr = mhr
     papi._mhr = mhr
