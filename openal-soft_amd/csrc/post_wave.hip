@@ -218,6 +218,9 @@ __device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t 
         {
             const float *xw = &xw4[c][kHrirLen + lane];                  // x_c[o - t] = xw[-t]
             cf16 *co = (cf16*)(uintptr_t)(chanCoeffs + size_t{c0 + c} * kHrirLen * 2);    // eight (left, right) tap pairs per load
+            // (OALGPU_EXP_POST_PIPE: the next eight tap pairs requested while these are multiplied -- the kernel 1.5-2 us shorter
+            // beside the voice kernel, 33 registers instead of 25, and the STEP 1.2-1.9 us longer: profiles/r4/post_fir_pipe_ab.txt)
+#ifndef OALGPU_EXP_POST_PIPE
 #pragma unroll 1
             for(uint32_t t8 = 0; t8 < taps / 8u; ++t8)
             {
@@ -231,6 +234,31 @@ __device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t 
                     accR = __builtin_fmaf(cc[2 * j + 1], x, accR);
                 }
             }
+#else
+            const uint32_t nt8 = taps / 8u;                              // taps is a multiple of 16: an even number of steps
+            f16 ca = co[0];
+#pragma unroll 1
+            for(uint32_t t8 = 0; t8 < nt8; t8 += 2)
+            {
+                const f16 cb = co[t8 + 1u];
+                const float *xq = xw - 8 * int32_t(t8);
+#pragma unroll
+                for(int j = 0; j < 8; ++j)
+                {
+                    const float x = xq[-j];
+                    accL = __builtin_fmaf(ca[2 * j], x, accL);
+                    accR = __builtin_fmaf(ca[2 * j + 1], x, accR);
+                }
+                ca = co[(t8 + 2u < nt8) ? t8 + 2u : 0u];
+#pragma unroll
+                for(int j = 0; j < 8; ++j)
+                {
+                    const float x = xq[-8 - j];
+                    accL = __builtin_fmaf(cb[2 * j], x, accL);
+                    accR = __builtin_fmaf(cb[2 * j + 1], x, accR);
+                }
+            }
+#endif
         }
     }
     {   // PostShiftKernel's arithmetic: s = accumulator + channels' sum
