@@ -77,6 +77,19 @@ __device__ __forceinline__ void StoreRowBlock(uint32_t *blk, uint32_t ls, uint32
     if(lane < 8u) blk[3u * ls + lane] = lane == 0u ? (live ? mask : 0u) : (lane == 1u ? maxFade : 0u);
 }
 
+// A workgroup's partial bus is written once and read once, by the reduction, from whatever XCD its workgroup lands on:
+// stored non-temporally it does not wait, dirty, in this XCD's L2 for the write-back at the kernel's end (0.45 us off the
+// launch, 0.5-0.85 off the step: profiles/r4/nt_partials_ab.txt).
+template<class T>
+__device__ __forceinline__ void StorePartial(T *p, T v)
+{
+#ifdef OALGPU_EXP_CACHED_PARTIALS
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // ---- MixSamples straight out of LDS into the wavefront's own line accumulators (contexts with <= 8 mix lines) ----
 // The resampled / filtered samples of a voice are in LDS when DoFilters ends; with few enough lines the wavefront keeps
 // N lines x 64R frames of accumulator in registers (lane l owns frames [R l, R l + R) of every line, like the HRTF
@@ -249,7 +262,7 @@ __device__ __forceinline__ void WgMixRows(uint32_t *lds, const DeviceLayout &L, 
         float4 o;
         o.x = (4u * t < N) ? acc[c][0] : 0.0f; o.y = (4u * t + 1u < N) ? acc[c][1] : 0.0f;
         o.z = (4u * t + 2u < N) ? acc[c][2] : 0.0f; o.w = (4u * t + 3u < N) ? acc[c][3] : 0.0f;
-        *reinterpret_cast<float4*>(pl + size_t(c) * kLine) = o;
+        StorePartial(reinterpret_cast<f4*>(pl + size_t(c) * kLine), f4{o.x, o.y, o.z, o.w});
     }
 }
 
@@ -1328,8 +1341,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                 f2 sum = areaOf(0)[k];
 #pragma unroll
                 for(int ww = 1; ww < kWWaves; ++ww) { const f2 o = areaOf(ww)[k]; sum.x += o.x; sum.y += o.y; }
-                pl[size_t(c) * kLine + k] = (k < N) ? sum.x : 0.0f;
-                if(uint32_t(c) + 1u < nlines) pl[size_t(c + 1) * kLine + k] = (k < N) ? sum.y : 0.0f;
+                StorePartial(&pl[size_t(c) * kLine + k], (k < N) ? sum.x : 0.0f);
+                if(uint32_t(c) + 1u < nlines) StorePartial(&pl[size_t(c + 1) * kLine + k], (k < N) ? sum.y : 0.0f);
             }
         }
         waveStamp(3);
@@ -1385,7 +1398,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
 #pragma unroll
                 for(int ww = 1; ww < kWWaves; ++ww) { const f2 o = dumpOf(ww)[dumpAt(k)]; s.x += o.x; s.y += o.y; }
             }
-            ph[k] = s;
+            StorePartial(&ph[k], s);
         }
     }
     waveStamp(3);
