@@ -970,6 +970,12 @@ hipError_t LaunchVoiceMixT(hipStream_t s, const DeviceLayout &L, uint32_t sample
 // (a 16-wave workgroup does: it holds back one voice workgroup of every CU it lands on, and that
 // launch, which fills the machine exactly once, ends that much later).
 // (kReduceWaves = 16, one run per wavefront, when nothing else is running: oalgpu_mix_voices.)
+// (the partial buses are read once: streamed past L2, like the stores that wrote them -- profiles/r4/nt_partials_ab.txt)
+#ifdef OALGPU_EXP_CACHED_PARTIALS
+#define OALGPU_PARTIAL_LOAD(p) (*(p))
+#else
+#define OALGPU_PARTIAL_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 constexpr int kReduceSegs = 16;
 template<int kReduceWaves>
 __global__ void __launch_bounds__(kReduceWaves * 64) __attribute__((amdgpu_num_vgpr(48))) BusReduceKernel(DeviceLayout L, const float *__restrict__ carry)
@@ -1044,7 +1050,7 @@ __global__ void __launch_bounds__(kReduceWaves * 64) __attribute__((amdgpu_num_v
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
 #pragma unroll
-                    for(int k = 0; k < 8; ++k) v[q][k] = *reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + (oo[q] + uint32_t(k) * sb));
+                    for(int k = 0; k < 8; ++k) v[q][k] = OALGPU_PARTIAL_LOAD(reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + (oo[q] + uint32_t(k) * sb)));
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
                 {

@@ -826,7 +826,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             {
             // ---- DoHrtfMix, voice.cpp:827-902
             WaveSync();
+#ifdef OALGPU_EXP_CACHED_PARTIALS
             if(playing) L.hist[size_t{v} * kHist + lane] = w.in[N + lane];
+#else
+            if(playing) __builtin_nontemporal_store(w.in[N + lane], &L.hist[size_t{v} * kHist + lane]);    // (read next by the next launch)
+#endif
 
             const float targetGain = tail.tgtGain * (playing ? 1.0f : 0.0f);
             const float oldGain = counter ? tail.oldGain : tail.tgtGain;   // voice.cpp:1100
