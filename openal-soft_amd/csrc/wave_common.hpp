@@ -127,15 +127,20 @@ struct WgLds {
 // the FIR that runs while the window is in flight would then wait for the window), and they
 // deliver the raw element: the int16 -> float conversion happens when the window is stored to
 // LDS (GatherDecode), so that no load has to be waited for here.
+#ifdef OALGPU_EXP_NT_WINDOW
+#define OALGPU_WINDOW_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define OALGPU_WINDOW_LOAD(p) (*(p))
+#endif
 template<int FMT>
 __device__ __forceinline__ float LoadRawGlobal(const void *data, size_t idx)
 {
     if constexpr (FMT == OALGPU_FMT_FLOAT)
-        return reinterpret_cast<const __attribute__((address_space(1))) float*>(
-            (const __attribute__((address_space(1))) void*)data)[idx];
+        return OALGPU_WINDOW_LOAD(reinterpret_cast<const __attribute__((address_space(1))) float*>(
+            (const __attribute__((address_space(1))) void*)data) + idx);
     else
-        return __builtin_bit_cast(float, int32_t(reinterpret_cast<const __attribute__((address_space(1))) int16_t*>(
-            (const __attribute__((address_space(1))) void*)data)[idx]));
+        return __builtin_bit_cast(float, int32_t(OALGPU_WINDOW_LOAD(reinterpret_cast<const __attribute__((address_space(1))) int16_t*>(
+            (const __attribute__((address_space(1))) void*)data) + idx)));
 }
 
 __device__ __forceinline__ float GatherDecode(float raw, bool isShort)
@@ -185,7 +190,7 @@ __device__ __forceinline__ void GatherLinearT(float (&pre)[NPRE], const BufferIt
             reinterpret_cast<const __attribute__((address_space(1))) float*>((const __attribute__((address_space(1))) void*)b.data) + dataPos;
         const __attribute__((address_space(1))) float *pl = p + lane;
 #pragma unroll
-        for(int i = 0; i < NPRE; ++i) pre[i] = pl[NT * i];
+        for(int i = 0; i < NPRE; ++i) pre[i] = OALGPU_WINDOW_LOAD(pl + NT * i);
     }
     else
     {
