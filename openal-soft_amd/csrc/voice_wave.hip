@@ -1402,7 +1402,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
 #pragma unroll
                 for(int ww = 1; ww < kWWaves; ++ww) { const f2 o = dumpOf(ww)[dumpAt(k)]; s.x += o.x; s.y += o.y; }
             }
+#ifdef OALGPU_EXP_CACHED_ACCUM
+            ph[k] = s;
+#else
             StorePartial(&ph[k], s);
+#endif
         }
     }
     waveStamp(3);
