@@ -100,3 +100,15 @@ def test_no_cpu_fallback_without_device():
         api.resample(oalgpu.RS_LINEAR, 60211, np.zeros(2048, np.float32), 0, 64)
     with pytest.raises(oalgpu.OalgpuError, match="no HIP device"):
         oalgpu.Scene(api, num_dry=3)
+
+
+def test_context_flags_of_the_python_driver_match_the_header():
+    """The ctypes driver repeats the OALGPU_CTX_* bits of include/oalgpu.h; a renumbered flag must not go unnoticed."""
+    import re
+    import oalgpu
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "oalgpu.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+OALGPU_CTX_(\w+)\s+(\d+)u", hdr)}
+    assert len(defs) >= 6 and len(set(defs.values())) == len(defs)           # distinct bits
+    for name, bit in defs.items():
+        assert bit and bit & (bit - 1) == 0, (name, bit)                      # single bits
+        assert getattr(oalgpu, "CTX_" + name) == bit, name
