@@ -298,6 +298,10 @@ def main():
                          "packed fp32 VALU FMAs (OALGPU_CTX_FIR_VALU), for A/B runs")
     ap.add_argument("--preroll", type=int, default=None, help="untimed steps in front of the W warm-up steps, W included (default 2000)")
     ap.add_argument("--xflags", type=int, default=0, help="experiment bits or-ed into oalgpu_context_desc::flags")
+    ap.add_argument("--resident", default="auto", choices=("auto", "on", "off"),
+                    help="OALGPU_CTX_RESIDENT: one launch of the HRTF voice kernel stays on the machine over the updates of a block; every "
+                         "step still is one oalgpu_param_block_apply + one oalgpu_mix_update with its own output (auto: on where the "
+                         "library has the mode -- HRTF contexts without sends on one GPU, i.e. the headline config)")
     ap.add_argument("--run", type=int, default=0, metavar="B",
                     help="submit the steps B at a time through oalgpu_mix_update_run (one library call per B updates "
                          "instead of two per update); B must divide --steps and --warmup; 0 = one update per call")
@@ -329,8 +333,10 @@ def main():
     # torch's lazy CUDA initialisation (hundreds of ms) happens HERE, not inside the first fence: there it left the GPU idle
     # right before the timed block, whose 20 steps then ran on ramping clocks (63 against 48.7 us per step at K = 20)
     torch.cuda.synchronize()
+    want_resident = args.resident == "on" or (args.resident == "auto" and args.config == 3 and world == 1 and args.math == "fast"
+                                              and args.fir == "mfma")
     api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank,
-                     ctx_flags=(oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0) | args.xflags)
+                     ctx_flags=(oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0) | (oalgpu.CTX_RESIDENT if want_resident else 0) | args.xflags)
     real_mhr = os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr")
     use_real = args.mhr == "default" and os.path.exists(real_mhr)
     if use_real:
@@ -477,6 +483,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     fence()
+    res0 = sc.resident_stats() if want_resident else None
     elapsed, own_elapsed = timed_block(args.warmup)
     rank_ms = [own_elapsed / args.steps * 1e3]
     if dist is not None:
@@ -498,6 +505,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             e = float(tt.item())
         extra.append(e / args.steps * 1e3)
+    res1 = sc.resident_stats() if want_resident else None
 
     # ---- end-to-end latency of ONE update through the boundary as a host uses it: the moving voices'
     # oalgpu_voice_params records go in from host memory (biquad design + H2D inside
@@ -591,6 +599,23 @@ def main():
     sc.sync()
     sc.set_timing(False)
     vk_ms = float(np.mean(vk))
+    # The resident launch (OALGPU_CTX_RESIDENT): the voice kernel of the timed blocks is ONE launch per block; its own duration
+    # (HIP events bound to the dispatch, collected by the library when the launch has ended) over the updates it covered is
+    # the kernel's time per update -- cold start and any wait for the host's doorbells included.  The launched kernel's time of
+    # the pass above stays in the line as kernel_ms_launched.
+    resident = None
+    vk_launched_ms = vk_ms
+    if want_resident and res0 and res1 and res1["timed_updates"] > res0["timed_updates"] and not res1["failed"]:
+        upd = res1["timed_updates"] - res0["timed_updates"]
+        lau = res1["timed_launches"] - res0["timed_launches"]
+        kms = res1["timed_kernel_ms"] - res0["timed_kernel_ms"]
+        vk_ms = kms / upd
+        resident = {"launches": lau, "updates": upd, "launch_ms_mean": kms / max(lau, 1), "updates_per_launch": upd / max(lau, 1),
+                    "kernel_ms_per_update": vk_ms, "door_in_device_memory": bool(res1["door_in_device_memory"]),
+                    "parks_total": res1["parks"], "launches_total": res1["launches"],
+                    "note": "the timed blocks (the contract's one and the repeats): one launch of the voice kernel per K-step block, ended "
+                            "by the block's closing oalgpu_sync; launch_ms_mean is what rocprofv3's kernel trace shows per call of "
+                            "VoiceWaveKernel<..., true> for those blocks"}
     # the same clock around an EMPTY kernel: what the dispatch-bound events include besides a kernel's own run time
     # (rocprofv3's kernel trace reports the voice kernel about this much shorter, profiles/README.md)
     event_floor_ms = sc.event_floor_ms(200) if sc.voice_kernel_name().startswith("VoiceWaveKernel") else None
@@ -660,7 +685,8 @@ def main():
             # `peak` / `frac` stay the algorithmic fp32 figures of rounds 1-3, for continuity.
             "roofline": {"bound": "lds", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": sc.voice_kernel_name(), "kernel_ms": vk_ms, "event_floor_ms": event_floor_ms,
+                         "kernel": sc.voice_kernel_name() + (" [resident launch]" if resident else ""), "kernel_ms": vk_ms,
+                         "kernel_ms_launched": vk_launched_ms, "resident": resident, "event_floor_ms": event_floor_ms,
                          "lds": lds_block(args.config, V, sc.voice_kernel_name(), vk_ms),
                          "mfma": mfma_block(sc.voice_kernel_name(), V, vk_ms, len(moving)),
                          "flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch,

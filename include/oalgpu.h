@@ -192,6 +192,19 @@ typedef struct oalgpu_context_desc {
 #define OALGPU_CTX_FUSED_REDUCE 32u /* pipelined HRTF contexts without effect slots and without a collective: the bus reduction and the
                                    * post-process as ONE launch.  One launch less for the host, and measured 1.2-1.9 us per update
                                    * slower than the two launches: an opt-in variant, for A/B runs */
+#define OALGPU_CTX_RESIDENT 64u   /* pipelined FAST HRTF contexts without sends, effect slots or a collective (IrSize <= 64): ONE launch of the
+                                   * voice kernel stays on the machine over many updates.  Every oalgpu_mix_update (with its post-process) still
+                                   * submits one update and produces its own output: the call writes the update's doorbell slot -- the length and
+                                   * the parameter block of the oalgpu_param_block_apply in front of it, which the kernel's wavefronts install for
+                                   * their own voices -- and launches the update's reduction and post-process, which wait for device counters
+                                   * instead of for a kernel's end.  A workgroup starts update u + 1 when IT is through with u.  The kernel stays
+                                   * through oalgpu_param_block_apply, oalgpu_mix_update, oalgpu_read_output_async and oalgpu_output_wait; any
+                                   * other entry point of the library (on any context of the device) first tells it to leave -- it finishes the
+                                   * updates that have been rung and ends, and the next oalgpu_mix_update launches a new one -- so results are
+                                   * those of a launch per update, bit for bit (tests/test_gpu_pipeline.py).  A host that stops calling for long
+                                   * should call oalgpu_sync: the kernel holds the device's compute units while it waits, and gives up (the
+                                   * context then reports an error and launches per update) after 2 s without a doorbell inside a wait.
+                                   * Contexts the mode does not cover ignore the flag. */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 
@@ -410,6 +423,18 @@ int oalgpu_voice_set_state(oalgpu_context *ctx, uint32_t voice, int play_state);
  * Asynchronous on the context's stream; oalgpu_sync() or a read-back waits. */
 int oalgpu_mix_update(oalgpu_context *ctx, uint32_t samples_to_do, int post_process);
 int oalgpu_sync(oalgpu_context *ctx);
+/* OALGPU_CTX_RESIDENT: what the mode has done so far.  timed_*: launches that have ended -- their own durations (HIP events
+ * bound to the dispatch) and the updates they covered; timed_kernel_ms / timed_updates is the voice kernel's time per update. */
+typedef struct oalgpu_resident_info {
+    int32_t  enabled, failed, running, door_in_device_memory;
+    uint32_t launches, updates, parks, timed_launches;
+    uint64_t timed_updates;
+    double   timed_kernel_ms;
+    uint32_t max_updates_per_launch, pad;
+} oalgpu_resident_info;
+int oalgpu_resident_stats(oalgpu_context *ctx, oalgpu_resident_info *out);
+/* a launch ends by itself after this many updates (default 4096); the next update starts a new one */
+int oalgpu_resident_set_max_updates(oalgpu_context *ctx, uint32_t max_updates);
 /* Run the context on a caller-owned HIP stream (hipStream_t), e.g. the stream an RCCL
  * collective is ordered on; NULL returns to a private stream. */
 int oalgpu_set_stream(oalgpu_context *ctx, void *hip_stream);

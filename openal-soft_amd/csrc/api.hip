@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,13 @@ int Fail(int code, const std::string &msg)
     return code;
 }
 
+// resident voice kernels (OALGPU_CTX_RESIDENT) running on `device` are told to leave: see ResidentState below
+void ParkResidentContexts(int device);
+
+// Every entry point that may allocate, copy synchronously or wait for the device comes through here.  A resident voice kernel
+// ends only when its host says so, and anything that synchronises the device (hipFree, a blocking hipMemcpy, the null stream)
+// would wait for it for ever: so whoever selects the device first parks the resident kernels on it (they finish the updates
+// that have been rung and leave; the next oalgpu_mix_update of such a context launches a new one).
 int UseDevice(int device)
 {
     int count = 0;
@@ -53,6 +61,7 @@ int UseDevice(int device)
         return Fail(OALGPU_ERR_NO_DEVICE, "no HIP device available (the product has no CPU path)");
     if(device < 0 || device >= count) return Fail(OALGPU_ERR_INVALID, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device));
+    ParkResidentContexts(device);
     return OALGPU_OK;
 }
 
@@ -131,6 +140,7 @@ struct oalgpu_context {
     bool outRing{false}, outRingWritten{false};
     bool outViaRing[kIoSlots]{};
     uint32_t outSeq{0}, outSlotSeq[kIoSlots]{};    // every launch that writes a slot raises ITS number
+    uint32_t outArrivedTotal{0};                   // what outArrived (the FIR workgroups of every slot-writing launch: it only grows) reads by now
     // What the host already knows to be finished saves it runtime calls: an output that has been waited for proves its update's
     // whole chain done (moves installed, voices mixed, reduced, post-processed), so the checks in front of a slot's or a
     // partial-bus buffer's reuse need not ask the runtime.  Updates are numbered from 1 as they are submitted.
@@ -239,6 +249,47 @@ struct oalgpu_context {
     std::vector<CbVoice> cbVoices;
     std::vector<int32_t> cbOfVoice;                // [voice] index into cbVoices, -1 = not a callback source
 
+    // ---- the resident voice kernel (OALGPU_CTX_RESIDENT; protocol and device side: kernels.hpp ResidentDoor, voice_wave.hip) ----
+    // One launch of the HRTF voice kernel stays on the machine while the host only calls oalgpu_param_block_apply,
+    // oalgpu_mix_update, oalgpu_read_output_async and oalgpu_output_wait.  Per update the host writes a doorbell slot and
+    // launches the update's reduction (reduce stream) and post-process (post stream), which wait for device counters.  Any
+    // other entry point parks the kernel first (UseDevice): it finishes what has been rung and ends, and whatever the entry
+    // point puts on the main stream runs behind it in stream order.
+    struct ResidentState {
+        bool enabled{false};                       // the context was created with OALGPU_CTX_RESIDENT and its layout has a resident kernel
+        bool ready{false}, failed{false};          // buffers and streams exist; the mode gave up (the context then launches per update)
+        bool running{false};                       // a launch is on the main stream that has not been told to leave
+        std::mutex lock;                           // submit / park (another context's entry point parks this one's kernel)
+        hipStream_t reduceStream{nullptr};
+        ResidentDoor *door{nullptr};               // the host's view (the device reads the same address)
+        bool doorInBar{false};
+        DevBuf<uint32_t> counters;                 // [kRcCount][16]
+        uint32_t *hostFlags{nullptr};              // pinned [kRhCount][16]
+        DevBuf<float> part;                        // kResidentSets sets of partial buses
+        size_t setFloats{0};
+        uint32_t next{0};                          // the next update's index (counts this context's resident updates)
+        uint32_t endSeq{0};                        // where the running launch ends by itself
+        uint32_t launches{0}, startedTotal{0};
+        uint32_t launchBase{0};                    // the running launch's first update
+        // A host that keeps calling entry points the kernel has to leave for (parameters set the launched way before every
+        // update, say) would pay a launch AND the wait for its workgroups per update: after three launches in a row that
+        // covered fewer than two updates the context launches per update for a while, then tries again.
+        uint32_t shortRuns{0}, cooldown{0};
+        uint32_t maxUpdates{4096};
+        uint32_t setUses[kResidentSets]{};         // updates that went into each partial set so far
+        uint32_t posts{0};                         // post-processes launched in this mode
+        uint32_t firGroups{0}, redGroups{0}, groupsPerCu{0};
+        oalgpu_param_block *pendingBlock{nullptr}; // oalgpu_param_block_apply: rides in the next update's doorbell slot
+        hipEvent_t copyPending{nullptr};           // a copy out of the bus block queued on the post stream: the next reduction waits for it
+        // the launches' own times (events bound to the dispatch), collected when the launch is known to have ended
+        static constexpr uint32_t kEv = 4;
+        hipEvent_t evStart[kEv]{}, evStop[kEv]{};
+        uint32_t evFirst[kEv]{}, evLast[kEv]{};    // the updates the launch of that event pair covered: [first, last)
+        bool evOpen[kEv]{};
+        double kernelMs{0.0};
+        uint64_t kernelUpdates{0}, kernelLaunches{0}, parks{0};
+    } res;
+
     ~oalgpu_context()
     {
         for(void *p : bufferData) if(p) (void)hipFree(p);
@@ -249,6 +300,11 @@ struct oalgpu_context {
             for(hipEvent_t e : {panApplied[k], outDone[k]}) if(e) (void)hipEventDestroy(e);
         }
         if(outFlags) (void)hipHostFree(outFlags);
+        if(res.door) (void)(res.doorInBar ? hipFree(res.door) : hipHostFree(res.door));
+        if(res.hostFlags) (void)hipHostFree(res.hostFlags);
+        for(uint32_t k = 0; k < ResidentState::kEv; ++k)
+            for(hipEvent_t e : {res.evStart[k], res.evStop[k]}) if(e) (void)hipEventDestroy(e);
+        if(res.reduceStream) (void)hipStreamDestroy(res.reduceStream);
         if(evStart) (void)hipEventDestroy(evStart);
         if(evVoice) (void)hipEventDestroy(evVoice);
         if(evEnd) (void)hipEventDestroy(evEnd);
@@ -259,13 +315,71 @@ struct oalgpu_context {
     }
 };
 
+struct oalgpu_param_block {
+    DevBuf<ParamRecord> recs;
+    uint32_t count{0};
+    int device{0};
+    uint32_t hrtfGeneration{0};                             // of the store the records' HRIR indices and weights were taken from
+    DevBuf<int32_t> voiceToRec;                             // [voice of the context] -> index of its record in the block, or -1: how a
+                                                            // voice kernel's wavefront finds the records of the voices it mixed
+    uint32_t mapVoices{0};
+    std::vector<std::pair<uint32_t, uint32_t>> cbSteps;     // (voice, mStep) of the callback voices in the block
+    oalgpu_context *heldBy{nullptr};                        // a resident context that keeps the block for its next update (res.pendingBlock)
+};
+
 static int FlushPendingMix(oalgpu_context *c, struct oalgpu_param_block *next = nullptr);
-// every entry point that enqueues work on a context or reads its state goes through here: the device, and the deferred update
+static bool ResidentWanted(const oalgpu_context *c, int post_process);
+static int FlushResidentBlock(oalgpu_context *c);
+// every entry point that enqueues work on a context or reads its state goes through here: the device (which parks a resident
+// voice kernel: whatever follows on the main stream then runs behind its end), a parameter block that was waiting for a
+// resident update, and the deferred update
 static int UseCtx(oalgpu_context *c)
 {
     if(int rc = UseDevice(c->desc.device)) return rc;
+    if(int rc = FlushResidentBlock(c)) return rc;
     return FlushPendingMix(c);
 }
+// the entry points a resident voice kernel stays through (they touch neither the main stream nor anything that synchronises the device)
+static int UseCtxResident(oalgpu_context *c)
+{
+    if(!c->res.running && !c->res.pendingBlock) return UseCtx(c);
+    HIP_TRY(hipSetDevice(c->desc.device));
+    return OALGPU_OK;
+}
+
+// ---- resident voice kernels: who is running, and how they are told to leave ----
+namespace {
+std::mutex gResLock;                        // submit / park of every context's resident state
+std::vector<oalgpu_context*> gResRunning;
+std::atomic<int> gResCount{0};
+
+// (gResLock held) the running launch finishes the updates that have been rung and ends; nothing waits here
+void ResidentParkLocked(oalgpu_context *c)
+{
+    auto &R = c->res;
+    if(!R.running) return;
+    __atomic_store_n(&R.door->exitSeq, R.next, __ATOMIC_RELEASE);
+    __builtin_ia32_sfence();                // (write-combined stores through the BAR leave the core)
+    R.running = false;
+    ++R.parks;
+    R.shortRuns = (R.next - R.launchBase < 2u) ? R.shortRuns + 1u : 0u;
+    if(R.shortRuns >= 3u) { R.shortRuns = 0u; R.cooldown = 256u; }
+    const uint32_t e = (R.launches - 1u) % oalgpu_context::ResidentState::kEv;
+    R.evLast[e] = R.next;
+    gResRunning.erase(std::remove(gResRunning.begin(), gResRunning.end(), c), gResRunning.end());
+    gResCount.store(int(gResRunning.size()), std::memory_order_relaxed);
+}
+} // namespace
+
+namespace oalgpu {
+void ParkResidentContexts(int device)
+{
+    if(gResCount.load(std::memory_order_relaxed) == 0) return;
+    std::lock_guard<std::mutex> g(gResLock);
+    std::vector<oalgpu_context*> run = gResRunning;
+    for(oalgpu_context *c : run) if(c->desc.device == device) ResidentParkLocked(c);
+}
+} // namespace oalgpu
 
 namespace {
 
@@ -995,6 +1109,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     // (FirMfmaH, dev_wave.hpp) unless the host asks for packed fp32 VALU FMAs
     L.firMfma = (desc->flags & OALGPU_CTX_FIR_VALU) ? 0u : 1u;
     c->serialOnly = (desc->flags & OALGPU_CTX_SERIAL) != 0;
+    c->res.enabled = (desc->flags & OALGPU_CTX_RESIDENT) != 0 && !(desc->flags & (OALGPU_CTX_PROFILE | OALGPU_CTX_SERIAL));
     c->useWave = WaveKernelApplies(c->exact, L);
     if(c->useWave)
     {
@@ -1078,9 +1193,11 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
 void oalgpu_context_destroy(oalgpu_context *ctx)
 {
     if(!ctx) return;
-    (void)hipSetDevice(ctx->desc.device);
+    (void)UseDevice(ctx->desc.device);          // (a resident voice kernel is told to leave)
+    if(ctx->res.pendingBlock) { ctx->res.pendingBlock->heldBy = nullptr; ctx->res.pendingBlock = nullptr; }
     (void)FlushPendingMix(ctx);
     (void)hipStreamSynchronize(ctx->stream);
+    if(ctx->res.reduceStream) (void)hipStreamSynchronize(ctx->res.reduceStream);
     if(ctx->postStream) (void)hipStreamSynchronize(ctx->postStream);
     delete ctx->comm;
     for(auto &cb : ctx->cbVoices)
@@ -1641,16 +1758,6 @@ int oalgpu_voice_set_hrtf_targets(oalgpu_context *c, const uint32_t *voices, con
     return OALGPU_OK;
 }
 
-struct oalgpu_param_block {
-    DevBuf<ParamRecord> recs;
-    uint32_t count{0};
-    int device{0};
-    uint32_t hrtfGeneration{0};                             // of the store the records' HRIR indices and weights were taken from
-    DevBuf<int32_t> voiceToRec;                             // [voice of the context] -> index of its record in the block, or -1: how a
-                                                            // voice kernel's wavefront finds the records of the voices it mixed
-    uint32_t mapVoices{0};
-    std::vector<std::pair<uint32_t, uint32_t>> cbSteps;     // (voice, mStep) of the callback voices in the block
-};
 
 int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params,
     size_t count, oalgpu_param_block **out)
@@ -1691,6 +1798,13 @@ int oalgpu_param_block_apply(oalgpu_context *c, oalgpu_param_block *b)
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(c->L.hrtf && b->hrtfGeneration != c->hrtfGeneration)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_param_block_apply: the block was built against another HRTF data set (its HRIR indices are that store's); create it again");
+    if(!c->res.cooldown && ResidentWanted(c, 1) && !c->res.pendingBlock && b->mapVoices == c->L.numVoices && b->cbSteps.empty())
+    {   // a resident context: the block rides in the next update's doorbell slot and the voice kernel's wavefronts install it
+        // (another entry point in between applies it the launched way: FlushResidentBlock)
+        c->res.pendingBlock = b;
+        b->heldBy = c;
+        return OALGPU_OK;
+    }
     if(c->pendingMix.active && b->mapVoices == c->L.numVoices && WaveKernelAppliesRecords(c->L) && c->initPending.empty())
     {   // the update submitted last has not been launched yet: its voice kernel installs this block (see pendingMix)
         if(int rc = UseDevice(c->desc.device)) return rc;
@@ -1711,26 +1825,56 @@ int oalgpu_param_block_apply(oalgpu_context *c, oalgpu_param_block *b)
 void oalgpu_param_block_destroy(oalgpu_param_block *b)
 {
     if(!b) return;
-    (void)hipSetDevice(b->device);
+    (void)UseDevice(b->device);                 // (resident voice kernels leave: freeing device memory waits for the device)
+    // a context that still holds the block for its next resident update applies it now, while it exists
+    if(b->heldBy && b->heldBy->res.pendingBlock == b) (void)FlushResidentBlock(b->heldBy);
     delete b;
 }
 
-// Large-BAR boxes: fine-grained device memory is host-addressable.  Checked once per context by storing a pattern from the
-// host and reading it back with the device's copy engine, so that a platform that only claims the property falls back to
-// pinned host memory.
+// Large-BAR boxes: fine-grained device memory is host-addressable, so a slot the host fills per update can BE device memory
+// (the kernel's first read is an HBM read, not a PCIe round trip).  Checked once per context, and without trusting the
+// property alone: (1) the pointer is probed through the kernel's own user-copy path (write(2) out of it, read(2) into it, on a
+// pipe: an address the CPU cannot touch comes back as EFAULT, not as SIGSEGV); (2) the host stores a pattern, a KERNEL reads it
+// (plain loads, as ApplyMovesKernel reads its records), the host stores a second pattern over it, a second launch reads that:
+// a slot whose lines an earlier launch left in L2 must show the new stores, or the context keeps pinned host memory.
+// (BAR stores do not pass through an L2; the kernels read such slots either at their start, behind the launch's own
+// invalidate, or -- the resident kernel's doorbell -- with system-scope loads.)
+namespace {
+__global__ void ProbeReadKernel(const uint32_t *src, uint32_t *dst, uint32_t n)
+{
+    const uint32_t i = threadIdx.x;
+    if(i < n) dst[i] = src[i] + __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+bool HostCanTouch(void *p, size_t bytes)
+{
+    int fd[2];
+    if(pipe(fd) != 0) return false;
+    bool ok = write(fd[1], p, bytes) == ssize_t(bytes);        // the kernel reads the range on our behalf
+    if(ok) ok = read(fd[0], p, bytes) == ssize_t(bytes);       // ... and writes the same bytes back into it
+    close(fd[0]); close(fd[1]);
+    return ok;
+}
+}
 static bool HostStoresReachDevice(oalgpu_context *c)
 {
     hipDeviceProp_t prop{};
     if(hipGetDeviceProperties(&prop, c->desc.device) != hipSuccess || !prop.isLargeBar) return false;
-    uint32_t *probe = nullptr;
+    uint32_t *probe = nullptr, *seen = nullptr;
     if(hipExtMallocWithFlags(reinterpret_cast<void**>(&probe), 256, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return false; }
-    bool ok = true;
-    for(uint32_t i = 0; i < 64; ++i) probe[i] = 0x5eed0000u + i;
-    __builtin_ia32_sfence();
-    uint32_t back[64] = {};
-    if(hipMemcpy(back, probe, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); ok = false; }
-    for(uint32_t i = 0; ok && i < 64; ++i) ok = back[i] == 0x5eed0000u + i;
-    (void)hipFree(probe);
+    if(hipMalloc(reinterpret_cast<void**>(&seen), 256) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(probe); return false; }
+    bool ok = HostCanTouch(probe, 256);
+    for(uint32_t round = 0; ok && round < 2; ++round)
+    {
+        const uint32_t pat = round ? 0xc0de0000u : 0x5eed0000u;
+        for(uint32_t i = 0; i < 64; ++i) probe[i] = pat + i;
+        __builtin_ia32_sfence();
+        uint32_t back[64] = {};
+        hipLaunchKernelGGL(ProbeReadKernel, dim3(1), dim3(64), 0, c->stream, probe, seen, 64u);
+        if(hipGetLastError() != hipSuccess || hipMemcpyAsync(back, seen, sizeof(back), hipMemcpyDeviceToHost, c->stream) != hipSuccess
+            || hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        for(uint32_t i = 0; ok && i < 64; ++i) ok = back[i] == 2u * (pat + i);
+    }
+    (void)hipFree(probe); (void)hipFree(seen);
     return ok;
 }
 
@@ -1787,8 +1931,9 @@ static size_t OutputLineFloats(const oalgpu_context *c)
 int oalgpu_read_output_async(oalgpu_context *c, uint32_t *ticket)
 {
     if(!c || !ticket) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(int rc = UseCtx(c)) return rc;
     const size_t floats = OutputLineFloats(c);
+    // (a resident voice kernel stays where it is unless the ring's buffers have yet to be allocated)
+    if(int rc = (c->outFloats != floats) ? UseCtx(c) : UseCtxResident(c)) return rc;
     if(c->outFloats != floats)
     {
         for(uint32_t k = 0; k < oalgpu_context::kIoSlots; ++k)
@@ -1824,6 +1969,8 @@ int oalgpu_read_output_async(oalgpu_context *c, uint32_t *ticket)
     const float *src = c->L.numReal ? c->L.bus + size_t{c->L.numDry} * kLine : c->L.bus;
     HIP_TRY(hipMemcpyAsync(c->outHost[slot], src, floats * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(c->outDone[slot], s));
+    // (a resident context's next reduction runs on a stream of its own and rewrites these lines: it has to wait for the copy)
+    if(c->res.running) c->res.copyPending = c->outDone[slot];
     *ticket = c->outNext++;
     return OALGPU_OK;
 }
@@ -1831,9 +1978,14 @@ int oalgpu_read_output_async(oalgpu_context *c, uint32_t *ticket)
 int oalgpu_output_wait(oalgpu_context *c, uint32_t ticket, float *out, size_t out_floats)
 {
     if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(ticket >= c->outNext || c->outNext - ticket > oalgpu_context::kIoSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_output_wait: the ticket's slot was reused (four may be outstanding)");
+    // Four ring slots.  Where the post-process kernel fills the slots itself (outRing), the update submitted AFTER the newest
+    // ticket is already writing the slot of the ticket four back -- at submit time, not when its own ticket is drawn -- so only
+    // three tickets may be outstanding there; a slot filled by a copy is overwritten only by oalgpu_read_output_async itself.
+    const uint32_t live = c->outRing ? oalgpu_context::kIoSlots - 1u : oalgpu_context::kIoSlots;
+    if(ticket >= c->outNext || c->outNext - ticket > live)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_output_wait: the ticket's slot was reused (three tickets may be outstanding)");
     if(out_floats < c->outFloats) return Fail(OALGPU_ERR_INVALID, "oalgpu_output_wait: the buffer is smaller than the output lines");
-    if(int rc = UseCtx(c)) return rc;
+    if(int rc = UseCtxResident(c)) return rc;
     const uint32_t slot = ticket % oalgpu_context::kIoSlots;
     if(c->outViaRing[slot])
     {   // the kernel raises the slot's sequence number behind its lines
@@ -2073,34 +2225,58 @@ static void SplitterRunPowers(float coeff, uint32_t seg, float out[4])
 }
 
 // MixDirectHrtf of a FAST wavefront-kernel context in one launch (post_wave.hip): reads the bus block's accumulator, leaves the
-// shifted accumulator in carryBuf and the new splitter states in the other state buffer
-static int PostDirectHrtfFused(oalgpu_context *c, hipStream_t s, uint32_t samples_to_do, hipEvent_t evDone)
+// shifted accumulator in carryBuf and the new splitter states in the other state buffer.
+// resident: the update's reduction is BusReduceResidentKernel on the reduce stream (ResidentSubmit): the launch waits for ITS
+// counter and counts itself in for the next one.
+// The counters the kernels wait for only ever grow and the host keeps what they will read (postEpoch, reducedEpoch, outSeq, the
+// resident targets): those mirrors move only once the launch has been accepted -- a failed launch must not leave every later
+// one waiting for a count that never comes.
+static int PostDirectHrtfFused(oalgpu_context *c, hipStream_t s, uint32_t samples_to_do, hipEvent_t evDone, bool resident = false)
 {
     const DeviceLayout &L = c->L;
     float *left = L.bus + size_t{L.numDry} * kLine;
     SplitterState *spIn = c->dSplitCur ? c->dSplit2.p : c->dSplit.p, *spOut = c->dSplitCur ? c->dSplit.p : c->dSplit2.p;
-    c->postEpoch += L.numDry;               // what the channel counter reads when this update's channels have all arrived
+    const uint32_t postEpoch = c->postEpoch + L.numDry;    // what the channel counter reads when this update's channels have all arrived
     const uint32_t seg = ((samples_to_do + 63u) / 64u) | 1u;
     if(c->runPowerSeg != seg) { SplitterRunPowers(c->dSplitCoeff, seg, c->runPower); c->runPowerSeg = seg; }
     const uint32_t slot = c->outNext % oalgpu_context::kIoSlots;
     const bool ring = c->outRing && c->outFlags;
-    if(c->reduceHeld)
+    const uint32_t outTarget = c->outArrivedTotal + PostResidentFirGroups();
+    auto &R = c->res;
+    if(resident)
+    {
+        c->reduceHeld = false;
+        LaunchPostResident(s, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->carryBuf.p, spIn, spOut, c->dHfScale.p, c->dCoeffs.p,
+            c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, postEpoch, c->runPower, evDone, ring ? c->outHost[slot] : nullptr,
+            ring ? c->outFlags + size_t{slot} * 16 : nullptr, c->outSeq + 1u, R.counters.p, R.hostFlags, (R.posts + 1u) * R.redGroups,
+            (R.posts + 1u) * R.firGroups, R.posts + 1u);
+        HIP_TRY(hipGetLastError());
+        ++R.posts;
+    }
+    else if(c->reduceHeld)
     {   // the update's reduction rides in the same launch (its partial buses: heldL's)
         c->reduceHeld = false;
         if(!c->reducedCount.p) { HIP_TRY(c->reducedCount.alloc(1)); HIP_TRY(c->reducedCount.zero()); }
-        c->reducedEpoch += ReducePostReduceGroups(c->heldL);
+        const uint32_t reducedEpoch = c->reducedEpoch + ReducePostReduceGroups(c->heldL);
         LaunchReducePostFused(s, c->heldL, CarrySource(c, c->carryAccum && L.hrtf), left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L),
-            c->carryBuf.p, spIn, spOut, c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, c->postEpoch,
+            c->carryBuf.p, spIn, spOut, c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, postEpoch,
             c->runPower, evDone, ring ? c->outHost[slot] : nullptr, ring ? c->outFlags + size_t{slot} * 16 : nullptr, c->outSeq + 1u,
-            c->outArrived.p, c->reducedCount.p, c->reducedEpoch);
+            c->outArrived.p, outTarget, c->reducedCount.p, reducedEpoch);
+        HIP_TRY(hipGetLastError());
+        c->reducedEpoch = reducedEpoch;
+        if(ring) c->outArrivedTotal = outTarget;
     }
     else
-    LaunchPostDirectHrtfFused(s, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->carryBuf.p, spIn, spOut,
-        c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, c->postEpoch, c->runPower, evDone,
-        ring ? c->outHost[slot] : nullptr, ring ? c->outFlags + size_t{slot} * 16 : nullptr, c->outSeq + 1u, c->outArrived.p);
+    {
+        LaunchPostDirectHrtfFused(s, left, left + kLine, L.bus, L.numDry, L.bus + BusAccumOffset(L), c->carryBuf.p, spIn, spOut,
+            c->dHfScale.p, c->dCoeffs.p, c->dIrSize, samples_to_do, c->dTemp.p, c->postArrived.p, postEpoch, c->runPower, evDone,
+            ring ? c->outHost[slot] : nullptr, ring ? c->outFlags + size_t{slot} * 16 : nullptr, c->outSeq + 1u, c->outArrived.p, outTarget);
+        HIP_TRY(hipGetLastError());
+        if(ring) c->outArrivedTotal = outTarget;
+    }
+    c->postEpoch = postEpoch;
     if(ring) c->outSlotSeq[slot] = ++c->outSeq;
     c->outRingWritten = ring;
-    HIP_TRY(hipGetLastError());
     c->dSplitCur ^= 1u;
     c->carryInBuf = true;
     return OALGPU_OK;
@@ -2115,6 +2291,206 @@ static int JoinPost(oalgpu_context *c)
     return OALGPU_OK;
 }
 
+
+// ---- the resident voice kernel: host side (device side and protocol: kernels.hpp ResidentDoor, voice_wave.hip, post_wave.hip) ----
+static bool ResidentWanted(const oalgpu_context *c, int post_process)
+{
+    const auto &R = c->res;
+    return R.enabled && !R.failed && WaveKernelHasResident(c->L) && post_process && c->hrtfLoaded && c->directSet && !c->timing && c->cbVoices.empty()
+        && c->initPending.empty() && c->carryAccum && !c->comm && !c->pendingMix.active && c->useWave && c->ownStream && !c->serialOnly
+        && c->L.numReal >= 2 && c->L.numSlots == 0;
+}
+
+// a parameter block that was waiting for a resident update is applied the launched way (the caller has parked the kernel)
+static int FlushResidentBlock(oalgpu_context *c)
+{
+    oalgpu_param_block *b = c->res.pendingBlock;
+    if(!b) return OALGPU_OK;
+    c->res.pendingBlock = nullptr;
+    b->heldBy = nullptr;
+    if(int rc = FlushInits(c)) return rc;
+    LaunchApplyParams(c->stream, c->L, b->recs.p, b->count);
+    HIP_TRY(hipGetLastError());
+    return OALGPU_OK;
+}
+
+static int ResidentGiveUp(oalgpu_context *c, const std::string &why)
+{
+    c->res.failed = true;
+    return Fail(OALGPU_ERR_HIP, "resident voice kernel: " + why + " (the context launches per update from now on)");
+}
+
+// streams, the door, counters, partial sets: once per context, with nothing resident on the device
+static int ResidentInit(oalgpu_context *c)
+{
+    auto &R = c->res;
+    if(int rc = UseDevice(c->desc.device)) return rc;
+    hipDeviceProp_t prop{};
+    HIP_TRY(hipGetDeviceProperties(&prop, c->desc.device));
+    // every workgroup of the launch has to be on the machine at once: nothing ever leaves to make room
+    R.groupsPerCu = uint32_t(std::max(0, WaveResidentGroupsPerCu()));
+    if(uint64_t{R.groupsPerCu} * uint32_t(prop.multiProcessorCount) < c->L.numGroups)
+        return ResidentGiveUp(c, "the device does not hold all of the launch's workgroups at once");
+    // the reduce stream between the main stream's priority class (highest) and the post stream's (lowest): a class has its own
+    // hardware queues, and a queue the resident kernel sits in never moves
+    int prioLeast = 0, prioGreatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
+    if(prioLeast - prioGreatest < 2) return ResidentGiveUp(c, "fewer than three stream priority classes");
+    HIP_TRY(hipStreamCreateWithPriority(&R.reduceStream, hipStreamDefault, (prioLeast + prioGreatest) / 2));
+    R.doorInBar = HostStoresReachDevice(c);
+    if(R.doorInBar) HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&R.door), sizeof(ResidentDoor), hipDeviceMallocFinegrained));
+    else HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&R.door), sizeof(ResidentDoor), hipHostMallocDefault));
+    std::memset(R.door, 0, sizeof(ResidentDoor));
+    R.door->exitSeq = 0x40000000u;
+    __builtin_ia32_sfence();
+    HIP_TRY(R.counters.alloc(size_t{kRcCount} * 16)); HIP_TRY(R.counters.zero());
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&R.hostFlags), size_t{kRhCount} * 16 * sizeof(uint32_t), hipHostMallocDefault));
+    std::memset(R.hostFlags, 0, size_t{kRhCount} * 16 * sizeof(uint32_t));
+    R.setFloats = size_t{c->L.numGroups} * (kLine + kHrirLen) * 2;
+    HIP_TRY(R.part.alloc(R.setFloats * kResidentSets));
+    for(uint32_t k = 0; k < oalgpu_context::ResidentState::kEv; ++k) { HIP_TRY(hipEventCreate(&R.evStart[k])); HIP_TRY(hipEventCreate(&R.evStop[k])); }
+    R.firGroups = PostResidentFirGroups();
+    R.redGroups = uint32_t((BusFloats(c->L) + 63u) / 64u);
+    R.ready = true;
+    return OALGPU_OK;
+}
+
+// the launches whose events have fired hand over their times
+static void ResidentCollectTimes(oalgpu_context *c, bool all)
+{
+    auto &R = c->res;
+    for(uint32_t k = 0; k < oalgpu_context::ResidentState::kEv; ++k)
+    {
+        if(!R.evOpen[k] || (R.running && k == (R.launches - 1u) % oalgpu_context::ResidentState::kEv)) continue;
+        if(!all && hipEventQuery(R.evStop[k]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        float ms = 0.0f;
+        if(hipEventElapsedTime(&ms, R.evStart[k], R.evStop[k]) == hipSuccess)
+        {
+            R.kernelMs += double(ms); R.kernelUpdates += R.evLast[k] - R.evFirst[k]; ++R.kernelLaunches;
+        }
+        else (void)hipGetLastError();
+        R.evOpen[k] = false;
+    }
+}
+
+static int ResidentCheckError(oalgpu_context *c)
+{
+    auto &R = c->res;
+    if(!R.hostFlags) return OALGPU_OK;
+    const uint32_t e = __atomic_load_n(R.hostFlags + 16u * kRhError, __ATOMIC_ACQUIRE);
+    if(!e) return OALGPU_OK;
+    __atomic_store_n(R.hostFlags + 16u * kRhError, 0u, __ATOMIC_RELEASE);
+    static const char *what[4] = {"", "the voice kernel waited 2 s for the host or for its reduction", "a reduction waited 2 s for the voice kernel",
+        "a reduction waited 2 s for the post-process"};
+    return ResidentGiveUp(c, e < 4 ? what[e] : "a wait timed out");
+}
+
+// One update of a resident context: the doorbell, its reduction (reduce stream) and its post-process (post stream).
+// Returns 1 when the update has to go the launched way after all (the caller falls through), 0 when submitted, < 0 on errors.
+static int ResidentSubmit(oalgpu_context *c, uint32_t samples_to_do)
+{
+    auto &R = c->res;
+    if(!R.ready) { if(int rc = ResidentInit(c)) return R.failed ? 1 : rc; }
+    HIP_TRY(hipSetDevice(c->desc.device));
+    using clk = std::chrono::steady_clock;
+    std::unique_lock<std::mutex> g(gResLock);
+    const DeviceLayout &L = c->L;
+    if(!R.running)
+    {
+        // the reduce stream joins whatever the post stream still runs (the bus block and the carried accumulator are theirs too)
+        if(c->postPending) HIP_TRY(hipStreamWaitEvent(R.reduceStream, c->lastPostEvent ? c->lastPostEvent : c->evPostDone, 0));
+        const uint32_t k = R.launches % oalgpu_context::ResidentState::kEv;
+        if(R.evOpen[k]) { HIP_TRY(hipEventSynchronize(R.evStop[k])); ResidentCollectTimes(c, false); }
+        ResidentArgs a{};
+        a.door = R.door; a.counters = R.counters.p; a.hostFlags = R.hostFlags; a.partBase = R.part.p; a.setStride = uint32_t(R.setFloats);
+        a.base = R.next; a.endSeq = R.next + R.maxUpdates; a.redPerUpdate = R.redGroups;
+        a.startedTarget = R.startedTotal + L.numGroups; a.launchId = R.launches + 1u;
+        __atomic_store_n(&R.door->exitSeq, R.next + 0x40000000u, __ATOMIC_RELEASE);
+        __atomic_store_n(&R.door->seq, R.next, __ATOMIC_RELEASE);
+        __builtin_ia32_sfence();
+        HIP_TRY(LaunchVoiceWaveResident(c->stream, L, a, R.evStart[k], R.evStop[k]));
+        R.evOpen[k] = true; R.evFirst[k] = R.next; R.evLast[k] = R.next;
+        ++R.launches; R.startedTotal = a.startedTarget; R.endSeq = a.endSeq; R.launchBase = R.next;
+        // Nothing that waits for this kernel may get onto the machine in front of it: a reduction that polls for workgroups which
+        // find no room beside it would wait for ever.  The last workgroup to start says so (a pinned word).
+        const auto deadline = clk::now() + std::chrono::seconds(5);
+        uint32_t spins = 0;
+        while(__atomic_load_n(R.hostFlags + 16u * kRhResident, __ATOMIC_ACQUIRE) != a.launchId)
+        {
+            __builtin_ia32_pause();
+            if((++spins & 0x3ffu) == 0 && clk::now() > deadline)
+            {   // (it may still start: tell it to leave at once, then wait for the stream)
+                __atomic_store_n(&R.door->exitSeq, R.next, __ATOMIC_RELEASE);
+                __builtin_ia32_sfence();
+                g.unlock();
+                (void)hipStreamSynchronize(c->stream);
+                R.evLast[k] = R.next;
+                (void)ResidentGiveUp(c, "its workgroups did not all start within 5 s");
+                return 1;
+            }
+        }
+        R.running = true;
+        gResRunning.push_back(c);
+        gResCount.store(int(gResRunning.size()), std::memory_order_relaxed);
+    }
+    {   // the host stays at most kResidentDepth updates ahead of the post-process (doorbell slots, queue depth)
+        const auto deadline = clk::now() + std::chrono::seconds(5);
+        uint32_t spins = 0;
+        while(int32_t(R.posts - __atomic_load_n(R.hostFlags + 16u * kRhProgress, __ATOMIC_ACQUIRE)) >= int32_t(kResidentDepth))
+        {
+            __builtin_ia32_pause();
+            if((++spins & 0x3ffu) == 0 && clk::now() > deadline)
+            {
+                ResidentParkLocked(c);
+                g.unlock();
+                (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(R.reduceStream); (void)hipStreamSynchronize(c->postStream);
+                if(int rc = ResidentCheckError(c)) return rc;
+                return ResidentGiveUp(c, "the post-process made no progress for 5 s");
+            }
+        }
+    }
+    if(__atomic_load_n(R.hostFlags + 16u * kRhError, __ATOMIC_RELAXED))
+    {
+        ResidentParkLocked(c);
+        g.unlock();
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(R.reduceStream); (void)hipStreamSynchronize(c->postStream);
+        return ResidentCheckError(c);
+    }
+    c->outRingWritten = false;
+    // ---- the doorbell: the slot first, then the sequence number
+    oalgpu_param_block *b = R.pendingBlock;
+    R.pendingBlock = nullptr;
+    if(b) b->heldBy = nullptr;
+    ResidentSlot &sl = R.door->slot[R.next % kResidentSlots];
+    sl.recs = b ? reinterpret_cast<unsigned long long>(b->recs.p) : 0ull;
+    sl.map = b ? reinterpret_cast<unsigned long long>(b->voiceToRec.p) : 0ull;
+    sl.samples = samples_to_do;
+    __builtin_ia32_sfence();
+    __atomic_store_n(&R.door->seq, R.next + 1u, __ATOMIC_RELEASE);
+    __builtin_ia32_sfence();
+    // ---- the update's reduction and post-process: launches of their own that wait for device counters
+    const uint32_t set = R.next % kResidentSets;
+    if(R.copyPending) { HIP_TRY(hipStreamWaitEvent(R.reduceStream, R.copyPending, 0)); R.copyPending = nullptr; }
+    DeviceLayout Lr = L;
+    Lr.partHrtf = R.part.p + size_t{set} * R.setFloats;
+    LaunchBusReduceResident(R.reduceStream, Lr, CarrySource(c, true), R.counters.p, R.hostFlags, set, (R.setUses[set] + 1u) * L.numGroups,
+        R.posts * R.firGroups);
+    HIP_TRY(hipGetLastError());
+    ++R.setUses[set];
+    c->lastPostEvent = c->evPostDone;
+    if(int rc = PostDirectHrtfFused(c, c->postStream, samples_to_do, c->evPostDone, true)) return rc;
+    c->postPending = true;
+    ++R.next;
+    ++c->updatesSubmitted;
+    R.evLast[(R.launches - 1u) % oalgpu_context::ResidentState::kEv] = R.next;
+    if(R.next == R.endSeq)
+    {   // the launch's own bound: it leaves by itself behind this update; the next one starts a new launch
+        R.running = false;
+        gResRunning.erase(std::remove(gResRunning.begin(), gResRunning.end(), c), gResRunning.end());
+        gResCount.store(int(gResRunning.size()), std::memory_order_relaxed);
+    }
+    return OALGPU_OK;
+}
 
 // ---- callback sources: what Voice::mix does for VoiceFlag::IsCallback, mirrored on the host ---------------------
 namespace {
@@ -2375,8 +2751,15 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
 {
     if(!c || samples_to_do == 0 || samples_to_do > kLine) return Fail(OALGPU_ERR_INVALID, "samples_to_do must be 1..1024");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
+    if(c->res.cooldown) --c->res.cooldown;
+    else if(ResidentWanted(c, post_process))
+    {   // the resident voice kernel: a doorbell, the update's reduction and its post-process
+        const int rc = ResidentSubmit(c, samples_to_do);
+        if(rc <= 0) return rc;                       // (1: the mode is not available after all -- on to the launched path)
+    }
     if(int rc = UseCtx(c)) return rc;                // (submits the update deferred before this one)
-    if(c->useWave && c->ownStream && !c->serialOnly && !c->timing && (c->desc.flags & OALGPU_CTX_APPLY_IN_VOICE_KERNEL) && WaveKernelAppliesRecords(c->L))
+    if(c->useWave && c->ownStream && !c->serialOnly && !c->timing && (c->desc.flags & OALGPU_CTX_APPLY_IN_VOICE_KERNEL) && WaveKernelAppliesRecords(c->L)
+        && !(c->res.enabled && !c->res.failed))
     {   // submitted with the next library call on this context (see pendingMix); whatever goes wrong then is that call's error
         c->pendingMix.active = true; c->pendingMix.samples = samples_to_do; c->pendingMix.post = post_process;
         return OALGPU_OK;
@@ -2512,11 +2895,13 @@ int oalgpu_post_process_overlapped(oalgpu_context *c, uint32_t samples_to_do, in
 int oalgpu_sync(oalgpu_context *c)
 {
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
-    if(int rc = UseCtx(c)) return rc;
+    if(int rc = UseCtx(c)) return rc;           // (a resident voice kernel finishes what has been rung and ends)
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if(c->res.reduceStream) HIP_TRY(hipStreamSynchronize(c->res.reduceStream));
     if(c->postStream) HIP_TRY(hipStreamSynchronize(c->postStream));
     c->postPending = false;
     c->updatesKnownDone = c->updatesSubmitted;
+    if(c->res.ready) { ResidentCollectTimes(c, true); if(int rc = ResidentCheckError(c)) return rc; }
     return OALGPU_OK;
 }
 
@@ -2802,6 +3187,27 @@ const char *oalgpu_voice_kernel_name(oalgpu_context *c)
 
 /* Multi-GPU: whether this context's voice kernel continues the carried HRTF accumulator tail
  * (exactly one rank must, the one that runs the post-process on the reduced buses). */
+int oalgpu_resident_stats(oalgpu_context *c, oalgpu_resident_info *out)
+{
+    if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(gResLock);
+    const auto &R = c->res;
+    out->enabled = R.enabled ? 1 : 0; out->failed = R.failed ? 1 : 0; out->running = R.running ? 1 : 0;
+    out->door_in_device_memory = R.doorInBar ? 1 : 0;
+    out->launches = R.launches; out->updates = R.next; out->parks = uint32_t(R.parks);
+    out->timed_launches = uint32_t(R.kernelLaunches); out->timed_updates = R.kernelUpdates; out->timed_kernel_ms = R.kernelMs;
+    out->max_updates_per_launch = R.maxUpdates;
+    return OALGPU_OK;
+}
+
+int oalgpu_resident_set_max_updates(oalgpu_context *c, uint32_t max_updates)
+{
+    if(!c || max_updates == 0 || max_updates > 0x10000000u) return Fail(OALGPU_ERR_INVALID, "oalgpu_resident_set_max_updates: 1 .. 2^28");
+    if(int rc = UseCtx(c)) return rc;
+    c->res.maxUpdates = max_updates;
+    return OALGPU_OK;
+}
+
 int oalgpu_set_carry_accum(oalgpu_context *c, int enable)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }

@@ -17,11 +17,25 @@ __device__ __forceinline__ void ReduceStore(float *p, float v)
     else *p = v;
 }
 
+// COHLOAD: the partial sums (and the carry) were written by launches that are still RUNNING (the resident voice kernel, the
+// post-process of the update before): read them with L2-coherent loads (device-scope relaxed atomics), whatever an L2 holds of
+// those lines from the last time they were read is not to be trusted
+template<bool COHLOAD, class P>
+__device__ __forceinline__ float ReduceLoad(P p)
+{
+    if constexpr (COHLOAD) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+struct ReduceNoHook { __device__ __forceinline__ void operator()() const { } };
+
 // slice: kReduceWaves == 4 ? [4][64] : [kReduceSegs][64] floats of LDS; block: which 64 columns; tid: thread of the workgroup
 // (kReduceWaves x 64 of them, all of which must call this -- it synchronises the workgroup)
 // KF: partial sums of each of a wavefront's four runs requested per step (the post-stream shape: 4 x KF loads in flight)
-template<int kReduceWaves, bool COHERENT, int KF = 8>
-__device__ __forceinline__ void BusReduceBlock(const DeviceLayout &L, const float *__restrict__ carry, float (*slice)[64], uint32_t block, uint32_t tid)
+// mid (the four-wavefront shape): called by every thread between the runs' sums and the carry's load -- the partial buses have
+// been read, the bus block has not been touched
+template<int kReduceWaves, bool COHERENT, int KF = 8, bool COHLOAD = false, class MID = ReduceNoHook>
+__device__ __forceinline__ void BusReduceBlock(const DeviceLayout &L, const float *__restrict__ carry, float (*slice)[64], uint32_t block, uint32_t tid,
+    MID mid = MID{})
 {
     // (the post-stream shape hands its runs over four at a time: 1 KB, ONE allocation granule of LDS -- beside two voice
     // workgroups of the dry-line kernels a CU has four granules to spare, and a launch of more reduction workgroups than
@@ -92,7 +106,7 @@ __device__ __forceinline__ void BusReduceBlock(const DeviceLayout &L, const floa
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
 #pragma unroll
-                    for(int k = 0; k < KF; ++k) v[q][k] = *reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + (oo[q] + uint32_t(k) * sb));
+                    for(int k = 0; k < KF; ++k) v[q][k] = ReduceLoad<COHLOAD>(reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + (oo[q] + uint32_t(k) * sb)));
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
                 {
@@ -103,10 +117,11 @@ __device__ __forceinline__ void BusReduceBlock(const DeviceLayout &L, const floa
             }
 #pragma unroll
             for(int q = 0; q < 4; ++q)
-                for(; gA[q] < gE[q]; ++gA[q]) { sum[q] = sum[q] + *reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + oo[q]); oo[q] += sb; }
+                for(; gA[q] < gE[q]; ++gA[q]) { sum[q] = sum[q] + ReduceLoad<COHLOAD>(reinterpret_cast<gfloatp>(reinterpret_cast<gcharp>(base) + oo[q])); oo[q] += sb; }
         }
+        mid();
         // segments in order 0..15 (segment = wavefront + 4 q), exactly as the 16-wavefront shape sums them
-        float t = (carry && idx >= lineFloats && idx < total) ? carry[idx - lineFloats] : 0.0f;
+        float t = (carry && idx >= lineFloats && idx < total) ? ReduceLoad<COHLOAD>(carry + (idx - lineFloats)) : 0.0f;
 #pragma unroll
         for(int q = 0; q < 4; ++q)
         {

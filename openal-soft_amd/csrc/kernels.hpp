@@ -215,6 +215,50 @@ __device__ __forceinline__ void ApplyRecordWave(const DeviceLayout &L, const Par
 
 struct VoiceInitRecord { uint32_t voice; int32_t buffer, looping, position; uint32_t positionFrac; int32_t queue; };
 
+// ---------------------------------------------------------------------------------------------
+// The resident voice kernel (OALGPU_CTX_RESIDENT, voice_wave.hip): ONE launch of the HRTF voice kernel stays on its
+// voices over many updates.  Every update is still submitted by its own oalgpu_mix_update: the host writes the update's
+// slot (its parameter block and its length) and then rings the doorbell -- plain stores into memory the kernel polls
+// with system-scope loads (fine-grained device memory behind the BAR, or pinned host memory).  A workgroup starts update
+// u as soon as IT is through with u - 1: it installs the block's records of its own voices (ApplyRecordLean), mixes,
+// stores its partial bus written-through into set u % kResidentSets and counts itself in on that set's arrival counter,
+// which the update's reduction (BusReduceResidentKernel, its own launch on the context's reduce stream) polls.
+// Counters only ever grow; every wait is a signed difference against a target the host passes.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kResidentSets = 4;           // partial-bus sets: a workgroup may be this many updates ahead of the reduction
+constexpr uint32_t kResidentSlots = 16;         // doorbell slots (the host stays <= kResidentDepth updates ahead of the post-process)
+constexpr uint32_t kResidentDepth = 8;
+constexpr unsigned long long kResidentWatchdogTicks = 200000000ull;    // s_memrealtime ticks (100 MHz): 2 s without progress = give up
+
+struct ResidentSlot { unsigned long long recs, map; uint32_t samples, pad[3]; };        // 32 bytes
+struct alignas(64) ResidentDoor {
+    uint32_t seq;                               // updates rung so far: update u may run once int32(seq - u) > 0
+    uint32_t exitSeq;                           // the kernel leaves once its next update is >= this (host: park)
+    uint32_t pad[14];
+    ResidentSlot slot[kResidentSlots];          // slot[u % kResidentSlots]: written before seq
+};
+// device counters of a resident context, one uint32 each, 64 bytes apart (index x 16)
+enum ResidentCounter : uint32_t {
+    kRcArrive0 = 0,                             // .. kRcArrive0 + kResidentSets - 1: voice workgroups that stored their partial into the set
+    kRcRedRead = 4,                             // reduction workgroups that are through READING their partial set
+    kRcRedDone = 5,                             // reduction workgroups whose sums are in the bus block
+    kRcPostDone = 6,                            // post-process FIR workgroups that are through (stores included)
+    kRcStarted = 7,                             // voice workgroups of all resident launches that have started
+    kRcCount = 8
+};
+// pinned host words the kernels write (system scope), 64 bytes apart (index x 16)
+enum ResidentHostFlag : uint32_t { kRhResident = 0, kRhError = 1, kRhProgress = 2, kRhCount = 3 };
+struct ResidentArgs {
+    const ResidentDoor *door;
+    uint32_t *counters;                         // [kRcCount * 16]
+    uint32_t *hostFlags;                        // [kRhCount * 16], pinned host memory
+    float *partBase;                            // kResidentSets sets of [group][1152][2]
+    uint32_t setStride;                         // floats between two sets
+    uint32_t base, endSeq;                      // this launch's first update, and the update in front of which it leaves by itself
+    uint32_t redPerUpdate;                      // reduction workgroups per update
+    uint32_t startedTarget, launchId;           // kRcStarted reaches startedTarget when every workgroup of THIS launch has started
+};
+
 // ---- launchers (percall_kernels.hip) ----
 void LaunchResample(hipStream_t s, bool exact, const ResampleSpec &spec, const float *src, uint32_t frac,
     uint32_t increment, float *dst, uint32_t n);
@@ -241,11 +285,20 @@ inline uint32_t ReducePostReduceGroups(const DeviceLayout &L) { return uint32_t(
 void LaunchReducePostFused(hipStream_t s, const DeviceLayout &L, const float *carry, float *left, float *right, const float *in, uint32_t nch,
     const float *accIn, float *carryOut, const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs,
     uint32_t irsize, uint32_t n, float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone,
-    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived, uint32_t *reduced, uint32_t reducedEpoch);
+    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived, uint32_t outTarget, uint32_t *reduced, uint32_t reducedEpoch);
 void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
     const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
     float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone = nullptr,
-    float *hostOut = nullptr, uint32_t *hostFlag = nullptr, uint32_t hostSeq = 0, uint32_t *outArrived = nullptr);
+    float *hostOut = nullptr, uint32_t *hostFlag = nullptr, uint32_t hostSeq = 0, uint32_t *outArrived = nullptr, uint32_t outTarget = 0);
+// resident contexts (OALGPU_CTX_RESIDENT): the reduction and the post-process of one update as launches that wait for device
+// counters instead of for the voice kernel's end (post_wave.hip)
+void LaunchBusReduceResident(hipStream_t s, const DeviceLayout &L, const float *carry, uint32_t *counters, uint32_t *hostFlags, uint32_t set,
+    uint32_t arriveTarget, uint32_t postDoneTarget);
+uint32_t PostResidentFirGroups();
+void LaunchPostResident(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
+    const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
+    float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone, float *hostOut, uint32_t *hostFlag, uint32_t hostSeq,
+    uint32_t *counters, uint32_t *hostFlags, uint32_t redDoneTarget, uint32_t postDoneTarget, uint32_t progressValue);
 
 // ---- launchers (output_kernels.hip): BFormatDec, ApplyDither, Write<T> behind the buses ----
 // gainsHf / gainsLf: [dry line][32] (column = output line); gainsLf null = single-band decoder; bands =
@@ -388,5 +441,9 @@ struct WaveProf { unsigned long long *times; uint32_t ablate; };
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof = nullptr,
     hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const ParamRecord *nextRecs = nullptr, const int32_t *nextMap = nullptr);
 bool WaveKernelAppliesRecords(const DeviceLayout &L);
+// the resident launch of the HRTF hot path (OALGPU_CTX_RESIDENT): see ResidentDoor above
+bool WaveKernelHasResident(const DeviceLayout &L);
+hipError_t LaunchVoiceWaveResident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop);
+int WaveResidentGroupsPerCu();
 
 } // namespace oalgpu

@@ -143,17 +143,44 @@ __device__ __forceinline__ void PostStoreCoherent(float *p, float v) { __hip_ato
 __device__ __forceinline__ float PostLoadCoherent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 constexpr int kFusedFrames = 64;                            // output frames per FIR workgroup: one per lane, both ears
-// One wavefront's share of the fused post-process: wg < nch = the split of dry channel wg, else FIR block wg - nch of nfirWgs.
-// FUSED: the bus block was reduced by workgroups of the SAME launch (ReducePostFusedKernel): `reduced` reaches `reducedEpoch`
-// when they are all through, and what they wrote is read with L2-coherent loads.
-template<bool FUSED>
-__device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t tid, uint32_t nfirWgs, const float *__restrict__ in, uint32_t nch,
+
+// Every wait inside these kernels is bounded: a counter that never arrives (a launch that failed on the host's side, a voice
+// kernel that gave up) becomes an error word the host reads, not a hung GPU.  `ready` is asked until it says yes or 2 s have
+// passed (s_memrealtime: 100 MHz).
+template<class F>
+__device__ __forceinline__ bool PostWait(F ready, int nap)
+{
+    if(ready()) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for(uint32_t spins = 0;; ++spins)
+    {
+        if(nap <= 4) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
+        if(ready()) return true;
+        if((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > kResidentWatchdogTicks) return false;
+    }
+}
+__device__ __forceinline__ bool PostWaitCounter(const uint32_t *counter, uint32_t target, int nap)
+{
+    return PostWait([&]() { return int32_t(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0; }, nap);
+}
+// One wavefront's share of the fused post-process: wg < nch = the split of dry channel wg, else FIR block wg - nch; outTarget: what `outArrived` reads when this launch's FIR workgroups are all through.
+// MODE 1 (FUSED): the bus block was reduced by workgroups of the SAME launch (ReducePostFusedKernel): `reduced` reaches
+// `reducedEpoch` when they are all through, and what they wrote is read with L2-coherent loads.
+// MODE 2 (resident contexts): the reduction is a launch of its own on another stream (BusReduceResidentKernel) that may still be
+// running, and the NEXT update's reduction is waiting for this launch's FIR workgroups (`postDone`) before it touches the bus
+// block and reads the carried accumulator: besides MODE 1's loads, everything another launch reads or overwrites while this one
+// still runs -- the output lines, the carried accumulator -- is stored written-through, and a FIR workgroup counts itself in
+// behind its stores.  The last one tells the host how far the post-process has come (`progress`, pinned).
+struct PostResident { uint32_t *postDone; uint32_t postDoneTarget; uint32_t *progress; uint32_t progressValue; uint32_t *error; };
+template<int MODE>
+__device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t tid, uint32_t outTarget, const float *__restrict__ in, uint32_t nch,
     const SplitterState *__restrict__ spIn, SplitterState *__restrict__ spOut, const float *__restrict__ hfscales,
     const float *__restrict__ chanCoeffs, uint32_t taps, const float *__restrict__ accIn, float *__restrict__ carryOut,
     float *__restrict__ left, float *__restrict__ right, uint32_t n, float *__restrict__ xf, uint32_t *__restrict__ arrived, uint32_t epoch,
     Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived,
-    const uint32_t *__restrict__ reduced, uint32_t reducedEpoch)
+    const uint32_t *__restrict__ reduced, uint32_t reducedEpoch, PostResident PR = PostResident{nullptr, 0u, nullptr, 0u, nullptr})
 {
+    constexpr bool FUSED = MODE != 0, RESID = MODE == 2;
     const uint32_t lane = tid;
 #ifdef OALGPU_EXP_POST_PRIO
     __builtin_amdgcn_s_setprio(3);
@@ -163,7 +190,7 @@ __device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t 
         const uint32_t c = wg;
         if constexpr (FUSED)
         {   // the dry lines are this launch's own reduction workgroups' sums
-            while(int32_t(__hip_atomic_load(reduced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - reducedEpoch) < 0) __builtin_amdgcn_s_sleep(4);
+            if(!PostWaitCounter(reduced, reducedEpoch, 4) && PR.error && lane == 0) __hip_atomic_store(PR.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll 8
             for(uint32_t k = lane; k < uint32_t(kLine); k += 64) xs[k] = (k < n) ? PostLoadCoherent(in + size_t{c} * kLine + k) : 0.0f;
         }
@@ -192,7 +219,7 @@ __device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t 
     const int32_t base = int32_t(blk) * kFusedFrames - kHrirLen;
     f2 accOld = {0.0f, 0.0f};
     if constexpr (!FUSED) accOld = reinterpret_cast<const f2*>(accIn)[o];           // (requested before the wait)
-    while(int32_t(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) __builtin_amdgcn_s_sleep(8);
+    if(!PostWaitCounter(arrived, epoch, 8) && PR.error && lane == 0) __hip_atomic_store(PR.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if constexpr (FUSED)      // (the channels have arrived, so the reduction they waited for is through: its accumulator columns)
         accOld = f2{PostLoadCoherent(accIn + 2u * o), PostLoadCoherent(accIn + 2u * o + 1u)};
     constexpr int kWin = kHrirLen + kFusedFrames;
@@ -268,24 +295,53 @@ __device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t 
             float l, r;
             if constexpr (FUSED) { l = PostLoadCoherent(left + o); r = PostLoadCoherent(right + o); }
             else { l = left[o]; r = right[o]; }
-            if(o < n) { l = l + s.x; r = r + s.y; left[o] = l; right[o] = r; }
+            if(o < n)
+            {
+                l = l + s.x; r = r + s.y;
+                if constexpr (RESID) { PostStoreCoherent(left + o, l); PostStoreCoherent(right + o, r); }
+                else { left[o] = l; right[o] = r; }
+            }
             // the pipelined host boundary (oalgpu_read_output_async): the two output lines also go straight into the host's
             // pinned ring slot -- no copy launch behind this kernel, no runtime call on the host
             if(hostOut) { hostOut[o] = l; hostOut[uint32_t(kLine) + o] = r; }
         }
         // hrtfbase.h:127-132: frames [n, n + 128) move to the front, the following n frames are cleared, anything beyond stays
         f2 *carry2 = reinterpret_cast<f2*>(carryOut);
-        if(o >= n && o < n + uint32_t(kHrirLen)) carry2[o - n] = s;
-        if(o >= uint32_t(kHrirLen)) carry2[o] = (o < uint32_t(kHrirLen) + n) ? f2{0.0f, 0.0f} : s;
+        auto storeCarry = [&](uint32_t at, f2 v)
+        {
+            if constexpr (RESID) { PostStoreCoherent(carryOut + 2u * at, v.x); PostStoreCoherent(carryOut + 2u * at + 1u, v.y); }
+            else carry2[at] = v;
+        };
+        if(o >= n && o < n + uint32_t(kHrirLen)) storeCarry(o - n, s);
+        if(o >= uint32_t(kHrirLen)) storeCarry(o, (o < uint32_t(kHrirLen) + n) ? f2{0.0f, 0.0f} : s);
     }
-    if(hostOut)
+    if constexpr (RESID)
+    {   // behind this workgroup's stores (acknowledged: they are written through): it counts as through; the last one of the
+        // launch hands the ring slot's sequence number (behind everybody's lines) and the progress word to the host
+        if(hostOut) __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if(lane == 0)
+        {
+            const uint32_t t = __hip_atomic_fetch_add(PR.postDone, 1u, hostOut ? __ATOMIC_ACQ_REL : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(t + 1u == PR.postDoneTarget)
+            {
+                if(hostOut)
+                {
+                    __threadfence_system();
+                    __hip_atomic_store(hostFlag, hostSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __hip_atomic_store(PR.progress, PR.progressValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    else if(hostOut)
     {   // the slot's sequence number goes out behind the last FIR workgroup's lines (system scope: the reader is the host)
+        // (outArrived only ever grows; `outTarget` is what it reads when this launch's FIR workgroups are all through)
         __threadfence_system();
         if(lane == 0)
         {
-            const uint32_t nfir = nfirWgs;
             const uint32_t t = __hip_atomic_fetch_add(outArrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if((t + 1u) % nfir == 0u)
+            if(t + 1u == outTarget)
             {
                 __threadfence_system();
                 __hip_atomic_store(hostFlag, hostSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -298,10 +354,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
     const SplitterState *__restrict__ spIn, SplitterState *__restrict__ spOut, const float *__restrict__ hfscales,
     const float *__restrict__ chanCoeffs, uint32_t taps, const float *__restrict__ accIn, float *__restrict__ carryOut,
     float *__restrict__ left, float *__restrict__ right, uint32_t n, float *__restrict__ xf, uint32_t *__restrict__ arrived, uint32_t epoch,
-    Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived)
+    Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived, uint32_t outTarget)
 {
     __shared__ float xs[kLine + 64];                                   // split: the channel; FIR: [kPostGroup][128 + 64] windows
-    PostFusedBlock<false>(xs, blockIdx.x, threadIdx.x, gridDim.x - nch, in, nch, spIn, spOut, hfscales, chanCoeffs, taps, accIn, carryOut, left, right, n,
+    PostFusedBlock<0>(xs, blockIdx.x, threadIdx.x, outTarget, in, nch, spIn, spOut, hfscales, chanCoeffs, taps, accIn, carryOut, left, right, n,
         xf, arrived, epoch, runPower, hostOut, hostFlag, hostSeq, outArrived, nullptr, 0u);
 }
 
@@ -320,7 +376,7 @@ struct ReducePostArgs {
     const float *in; uint32_t nch;
     const SplitterState *spIn; SplitterState *spOut; const float *hfscales, *chanCoeffs; uint32_t taps;
     const float *accIn; float *carryOut, *left, *right; uint32_t n; float *xf; uint32_t *arrived; uint32_t epoch; Tri3 runPower;
-    float *hostOut; uint32_t *hostFlag; uint32_t hostSeq; uint32_t *outArrived;
+    float *hostOut; uint32_t *hostFlag; uint32_t hostSeq; uint32_t *outArrived; uint32_t outTarget;
     uint32_t *reduced; uint32_t reducedEpoch;
 };
 __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) ReducePostFusedKernel(DeviceLayout L, ReducePostArgs A)
@@ -337,28 +393,110 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(256) __attribute__((amdgp
         return;
     }
     if(threadIdx.x >= 64) return;
-    PostFusedBlock<true>(xs, blockIdx.x - A.nReduce, threadIdx.x, gridDim.x - A.nReduce - A.nch, A.in, A.nch, A.spIn, A.spOut, A.hfscales, A.chanCoeffs, A.taps,
+    PostFusedBlock<1>(xs, blockIdx.x - A.nReduce, threadIdx.x, A.outTarget, A.in, A.nch, A.spIn, A.spOut, A.hfscales, A.chanCoeffs, A.taps,
         A.accIn, A.carryOut, A.left, A.right, A.n, A.xf, A.arrived, A.epoch, A.runPower, A.hostOut, A.hostFlag, A.hostSeq, A.outArrived, A.reduced, A.reducedEpoch);
 }
 
+// ---- resident contexts (OALGPU_CTX_RESIDENT; the protocol: kernels.hpp ResidentDoor) ----
+// The reduction of update u of a resident context: BusReduceKernel<4>'s sums in the same order, launched when the update is
+// SUBMITTED, on the context's reduce stream.  It waits for the voice workgroups' arrival on the update's partial set (the voice
+// kernel is one launch that never ends in between), reads the set with L2-coherent loads, tells the voice kernel that the set
+// may be written again (kRcRedRead) and only then waits for the post-process of update u - 1 (its FIR workgroups have read the
+// bus block and written the carried accumulator: kRcPostDone) -- so that only the carry's add and the stores, not the 4.7 MB of
+// partial sums, lie between two post-processes.  Its sums are stored written-through; it counts itself in on kRcRedDone.
+struct ResidentReduceArgs {
+    uint32_t *counters, *hostFlags;
+    uint32_t set, arriveTarget, postDoneTarget;
+};
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) BusReduceResidentKernel(DeviceLayout L, const float *__restrict__ carry,
+    ResidentReduceArgs A)
+{
+    __shared__ float slice[4][64];
+    const uint32_t tid = threadIdx.x;
+    if(tid == 0)
+    {
+        if(!PostWaitCounter(A.counters + 16u * (kRcArrive0 + A.set), A.arriveTarget, 4))
+            __hip_atomic_store(A.hostFlags + 16u * kRhError, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    auto mid = [&]()
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every partial sum this thread asked for has arrived
+        __syncthreads();
+        if(tid == 0)
+        {
+            __hip_atomic_fetch_add(A.counters + 16u * kRcRedRead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(!PostWaitCounter(A.counters + 16u * kRcPostDone, A.postDoneTarget, 4))
+                __hip_atomic_store(A.hostFlags + 16u * kRhError, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+    };
+    BusReduceBlock<4, true, 8, true>(L, carry, slice, blockIdx.x, tid, mid);
+    if(tid < 64)
+    {   // the sums are where the post-process will read them before this workgroup counts as through
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(tid == 0) __hip_atomic_fetch_add(A.counters + 16u * kRcRedDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) PostResidentKernel(const float *__restrict__ in, uint32_t nch,
+    const SplitterState *__restrict__ spIn, SplitterState *__restrict__ spOut, const float *__restrict__ hfscales,
+    const float *__restrict__ chanCoeffs, uint32_t taps, const float *__restrict__ accIn, float *__restrict__ carryOut,
+    float *__restrict__ left, float *__restrict__ right, uint32_t n, float *__restrict__ xf, uint32_t *__restrict__ arrived, uint32_t epoch,
+    Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, const uint32_t *__restrict__ reduced,
+    uint32_t reducedEpoch, PostResident PR)
+{
+    __shared__ float xs[kLine + 64];
+    PostFusedBlock<2>(xs, blockIdx.x, threadIdx.x, 0u, in, nch, spIn, spOut, hfscales, chanCoeffs, taps, accIn, carryOut, left, right, n,
+        xf, arrived, epoch, runPower, hostOut, hostFlag, hostSeq, nullptr, reduced, reducedEpoch, PR);
+}
+
 } // namespace
+
+// update u's reduction of a resident context (see BusReduceResidentKernel): L.partHrtf = the update's partial set; counters /
+// hostFlags: the context's (kernels.hpp ResidentCounter / ResidentHostFlag); arriveTarget: what the set's arrival counter reads
+// when every voice workgroup has stored update u's partial; postDoneTarget: what kRcPostDone reads when the post-process of
+// update u - 1 is through
+void LaunchBusReduceResident(hipStream_t s, const DeviceLayout &L, const float *carry, uint32_t *counters, uint32_t *hostFlags, uint32_t set,
+    uint32_t arriveTarget, uint32_t postDoneTarget)
+{
+    const uint32_t total = uint32_t(BusFloats(L));
+    hipLaunchKernelGGL(BusReduceResidentKernel, dim3((total + 63u) / 64u), dim3(256), 0, s, L, carry, ResidentReduceArgs{counters, hostFlags, set, arriveTarget, postDoneTarget});
+}
+
+// update u's HRTF post-process of a resident context (PostFusedBlock<2>); redDoneTarget: what kRcRedDone reads when update u's
+// reduction is through; postDoneTarget: what kRcPostDone reads when this launch's FIR workgroups are; progressValue: what the
+// last of them stores into the host's progress word
+uint32_t PostResidentFirGroups() { return uint32_t(kPostFrames / kFusedFrames); }
+void LaunchPostResident(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
+    const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
+    float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone, float *hostOut, uint32_t *hostFlag, uint32_t hostSeq,
+    uint32_t *counters, uint32_t *hostFlags, uint32_t redDoneTarget, uint32_t postDoneTarget, uint32_t progressValue)
+{
+    const uint32_t taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
+    const Tri3 P{runPower[0], runPower[1], runPower[2], runPower[3]};
+    const PostResident PR{counters + 16u * kRcPostDone, postDoneTarget, hostFlags + 16u * kRhProgress, progressValue, hostFlags + 16u * kRhError};
+    hipExtLaunchKernelGGL(PostResidentKernel, dim3(nch + kPostFrames / kFusedFrames), dim3(64), 0, s, nullptr, evDone, 0u, in, nch, spIn, spOut, hfscales,
+        chanCoeffs, taps, accIn, carryOut, left, right, n, xf, arrived, epoch, P, hostOut, hostFlag, hostSeq, counters + 16u * kRcRedDone, redDoneTarget, PR);
+}
 
 // the whole FAST post-process in one launch; spIn / spOut: the two splitter-state buffers of the context (the caller swaps them),
 // carryOut: the carried accumulator the next reduction adds (1152 x 2); xf: nch x 1024 floats of scratch; arrived / epoch: the
 // context's channel counter and the value it reaches when this update's channels are all there (nch more than before);
 // runPower: the splitter's transition over a run of ((n + 63) / 64) | 1 samples as the scan wants it (SplitterRunPowers, api.hip);
 // hostOut (null: none): 2 x 1024 floats of pinned host memory that receive the two output lines, hostFlag: where hostSeq is
-// stored when they are all there, outArrived: the context's counter of FIR workgroups
+// stored when they are all there, outArrived / outTarget: the context's counter of FIR workgroups (it only ever grows) and what
+// it reads when this launch's are all through
 void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const float *in, uint32_t nch, const float *accIn, float *carryOut,
     const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs, uint32_t irsize, uint32_t n,
     float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone,
-    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived)
+    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived, uint32_t outTarget)
 {
     const uint32_t taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
     const Tri3 P{runPower[0], runPower[1], runPower[2], runPower[3]};
     static_assert(kPostFrames % kFusedFrames == 0, "whole workgroups");
     hipExtLaunchKernelGGL(PostFusedKernel, dim3(nch + kPostFrames / kFusedFrames), dim3(64), 0, s, nullptr, evDone, 0u, in, nch, spIn, spOut, hfscales,
-        chanCoeffs, taps, accIn, carryOut, left, right, n, xf, arrived, epoch, P, hostOut, hostFlag, hostSeq, outArrived);
+        chanCoeffs, taps, accIn, carryOut, left, right, n, xf, arrived, epoch, P, hostOut, hostFlag, hostSeq, outArrived, outTarget);
 }
 
 // The reduction of update k and its HRTF post-process in one launch (see ReducePostFusedKernel); reduced / reducedEpoch: the
@@ -366,7 +504,7 @@ void LaunchPostDirectHrtfFused(hipStream_t s, float *left, float *right, const f
 void LaunchReducePostFused(hipStream_t s, const DeviceLayout &L, const float *carry, float *left, float *right, const float *in, uint32_t nch,
     const float *accIn, float *carryOut, const SplitterState *spIn, SplitterState *spOut, const float *hfscales, const float *chanCoeffs,
     uint32_t irsize, uint32_t n, float *xf, uint32_t *arrived, uint32_t epoch, const float runPower[4], hipEvent_t evDone,
-    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived, uint32_t *reduced, uint32_t reducedEpoch)
+    float *hostOut, uint32_t *hostFlag, uint32_t hostSeq, uint32_t *outArrived, uint32_t outTarget, uint32_t *reduced, uint32_t reducedEpoch)
 {
     ReducePostArgs A{};
     A.carry = carry; A.nReduce = ReducePostReduceGroups(L);
@@ -374,7 +512,7 @@ void LaunchReducePostFused(hipStream_t s, const DeviceLayout &L, const float *ca
     A.taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
     A.accIn = accIn; A.carryOut = carryOut; A.left = left; A.right = right; A.n = n; A.xf = xf; A.arrived = arrived; A.epoch = epoch;
     A.runPower = Tri3{runPower[0], runPower[1], runPower[2], runPower[3]};
-    A.hostOut = hostOut; A.hostFlag = hostFlag; A.hostSeq = hostSeq; A.outArrived = outArrived; A.reduced = reduced; A.reducedEpoch = reducedEpoch;
+    A.hostOut = hostOut; A.hostFlag = hostFlag; A.hostSeq = hostSeq; A.outArrived = outArrived; A.outTarget = outTarget; A.reduced = reduced; A.reducedEpoch = reducedEpoch;
     hipExtLaunchKernelGGL(ReducePostFusedKernel, dim3(A.nReduce + nch + kPostFrames / kFusedFrames), dim3(256), 0, s, nullptr, evDone, 0u, L, A);
 }
 

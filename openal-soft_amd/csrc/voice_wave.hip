@@ -306,7 +306,34 @@ struct WaveArgsHrtf {
 // The next update's parameter block, installed by the wavefront that has just mixed the voice (the kernel's epilogue) instead
 // of by a kernel of its own between two voice kernels: ApplyRecordWave (kernels.hpp) for the kernels that carry the whole
 // DeviceLayout, the same operations on the lean argument block for the HRTF kernels without sends (`pad` holds IrSize there).
-struct NextBlock { const ParamRecord *recs; const int32_t *map; };
+struct NextBlock { const ParamRecord *recs; const int32_t *map; ResidentArgs res; };   // (res: the resident launch's, RES)
+
+// ---- the resident launch (RES, OALGPU_CTX_RESIDENT; the protocol: kernels.hpp ResidentDoor) ----
+// What the host writes is read with system-scope loads (they go to memory: nothing a cache holds of the door can be trusted
+// inside one launch); what other launches read while this one runs -- the partial buses -- is stored written-through
+// (device-scope relaxed atomics: sc1 stores), the idiom of post_wave.hip.
+[[maybe_unused]] __device__ __forceinline__ uint32_t ResLoadSys(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+[[maybe_unused]] __device__ __forceinline__ unsigned long long ResLoadSys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+[[maybe_unused]] __device__ __forceinline__ uint32_t ResLoadDev(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+[[maybe_unused]] __device__ __forceinline__ void StorePartialCoherent(f2 *p, f2 v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One poll loop for every wait of the resident launch: `ready` is asked until it says yes or the watchdog's time is up
+// (false: the caller flags the error and leaves -- a wait never hangs the GPU).  Short naps first, longer ones once the
+// wait has lasted.
+template<class F>
+__device__ __forceinline__ bool ResWait(F ready)
+{
+    if(ready()) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for(uint32_t spins = 0;; ++spins)
+    {
+        if(spins < 32u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(24);
+        if(ready()) return true;
+        if((spins & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t0 > kResidentWatchdogTicks) return false;
+    }
+}
 __device__ __forceinline__ void ApplyRecordLean(const WaveArgsHrtf &L, const ParamRecord &r, uint32_t lane)
 {
     const uint32_t v = r.voice;
@@ -350,9 +377,13 @@ __device__ __forceinline__ void ApplyNextRecord(const DeviceLayout &L, const Par
 
 // ACCL > 0: the context's mix lines (dry lines and / or the slots' wet lines, <= ACCL of them) accumulate in the
 // wavefront's registers (MixRowAcc) instead of leaving stream rows; such kernels run the register-lean resampler.
-template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool PROF = false, class LT = DeviceLayout, int ACCL = 0>
+// RES: the resident launch -- the kernel's body is one UPDATE of a loop that ends when the host says so (see NextBlock above);
+// everything a launch does per update it does per turn of that loop, in the same order with the same operations: the bits are
+// those of one launch per update (tests/test_gpu_pipeline.py).
+template<int R, int TAPS, int NL, bool SENDS, bool MF = false, bool PROF = false, class LT = DeviceLayout, int ACCL = 0, bool RES = false>
 __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MIN_WG) VoiceWaveKernel(LT L, uint32_t samplesToDo, WaveProf prof, NextBlock next)
 {
+    static_assert(!RES || (MF && NL == 0 && !SENDS && !PROF && ACCL == 0 && std::is_same<LT, WaveArgsHrtf>::value), "the resident launch is the HRTF hot path's");
     static_assert(std::is_same<LT, DeviceLayout>::value || (NL == 0 && !SENDS), "the lean argument block is the HRTF variants'");
     static_assert(ACCL == 0 || NL > 0 || SENDS, "line accumulators belong to kernels that mix onto lines");
     static_assert(!MF || (R == 17 && TAPS == 64 && NL == 0), "the matrix-pipe FIR is the 64-tap HRTF form");
@@ -365,7 +396,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     const uint32_t vpw = L.waveVoices;
     const uint32_t irStride = L.irStride;
     WL &w = sm.w[wave];
-    const uint32_t N = samplesToDo;
+    uint32_t N = samplesToDo;                   // (RES: every update brings its own length)
 #ifndef OALGPU_EXP_LAZY_ARGS
     // The argument block's pointers are needed in SGPRs all at once here, so that their kernarg loads are issued together and
     // waited for ONCE: left to itself the compiler loads each pointer where it spills it to a VGPR lane -- one scalar load and
@@ -408,6 +439,93 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     const bool rev = group >= (gridDim.x + 1u) / 2u;
     auto voiceAt = [&](uint32_t j) { return vBegin + 2u * (rev ? vCount - 1u - j : j); };
 
+    // ---- RES: this launch's turn of the update loop (one pass through the kernel's body otherwise) ----
+    uint32_t upd = 0u, updBase = 0u;
+    if constexpr (RES)
+    {
+        const ResidentArgs &RA = next.res;
+        upd = updBase = RA.base;
+        if(t == 0)
+        {   // the host launches nothing that waits for this kernel before every workgroup of it has a CU (see ResidentSubmit)
+            const uint32_t old = __hip_atomic_fetch_add(RA.counters + 16u * kRcStarted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(old + 1u == RA.startedTarget)
+                __hip_atomic_store(RA.hostFlags + 16u * kRhResident, RA.launchId, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    for(;;)
+    {
+    // RES: thread and lane index are re-derived per update behind an opaque move, like the lane index per pass below: what the
+    // body computes from them (the dump's and the partial's addresses) then is a few VALU per update, not a set of loop
+    // invariants kept in registers across the resampler and the FIR, whose peaks decide the kernel's register count.
+    uint32_t tU = t, laneU = lane0;
+    if constexpr (RES) asm volatile("" : "+v"(tU), "+v"(laneU));
+    const uint32_t t = tU, lane0 = laneU;
+    bool stageRows = true;                      // pass 0 stages the workgroup's resampler rows (RES: only when they are not there yet)
+    if constexpr (RES)
+    {
+        const ResidentArgs &RA = next.res;
+        // Thread 0 waits for the update: the doorbell (or the word to leave), and -- kResidentSets updates on -- for the reduction
+        // that still reads the partial set this update's sums go into.  The others wait at the barrier; what thread 0 learned
+        // goes round through LDS.  The decision to leave is the host's alone (exitSeq, or the launch's own bound endSeq), so
+        // that every workgroup takes it for the same update; the watchdog only turns a host that went away into an error.
+        if(t == 0)
+        {
+            uint32_t go = 0u, fault = 0u;
+            unsigned long long recs = 0ull, map = 0ull;
+            uint32_t smp = 0u;
+            if(upd != RA.endSeq)
+            {
+                const ResidentDoor *door = RA.door;
+                uint32_t leave = 0u;
+                const bool ok = ResWait([&]() {
+                    if(int32_t(ResLoadSys(&door->seq) - upd) > 0) return true;
+                    leave = int32_t(ResLoadSys(&door->exitSeq) - upd) <= 0 ? 1u : 0u;
+                    return leave != 0u;
+                });
+                fault = ok ? 0u : 1u;
+                go = (ok && !leave) ? 1u : 0u;
+                if(go && int32_t(upd - kResidentSets) >= 0)
+                {
+                    const uint32_t want = (upd - kResidentSets + 1u) * RA.redPerUpdate;
+                    const uint32_t *rr = RA.counters + 16u * kRcRedRead;
+                    if(!ResWait([&]() { return int32_t(ResLoadDev(rr) - want) >= 0; })) { fault = 1u; go = 0u; }
+                }
+                if(go)
+                {
+                    const ResidentSlot *sl = &door->slot[upd % kResidentSlots];
+                    recs = ResLoadSys(&sl->recs); map = ResLoadSys(&sl->map); smp = ResLoadSys(&sl->samples);
+                }
+            }
+            if(fault) __hip_atomic_store(RA.hostFlags + 16u * kRhError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sm.res[0] = go; sm.res[1] = smp;
+            sm.res[2] = uint32_t(recs); sm.res[3] = uint32_t(recs >> 32); sm.res[4] = uint32_t(map); sm.res[5] = uint32_t(map >> 32);
+        }
+        __syncthreads();
+        if(__builtin_amdgcn_readfirstlane(sm.res[0]) == 0u) break;
+        N = __builtin_amdgcn_readfirstlane(sm.res[1]);
+        const unsigned long long recsU = (uint64_t{uint32_t(__builtin_amdgcn_readfirstlane(sm.res[3]))} << 32) | uint32_t(__builtin_amdgcn_readfirstlane(sm.res[2]));
+        const unsigned long long mapU = (uint64_t{uint32_t(__builtin_amdgcn_readfirstlane(sm.res[5]))} << 32) | uint32_t(__builtin_amdgcn_readfirstlane(sm.res[4]));
+        // the update's parameter block: every wavefront installs the records of its own voices, as ApplyParamsKernel would in
+        // front of a launch (the voices' state of the update before was written back by this very wavefront, in program order)
+        if(mapU)
+        {
+            const int32_t *map = reinterpret_cast<const int32_t*>(mapU);
+            const ParamRecord *recs = reinterpret_cast<const ParamRecord*>(recsU);
+            for(uint32_t j = 0; j < vCount; ++j)
+            {
+                const uint32_t v = vBegin + 2u * j;
+                const int32_t ri = __builtin_amdgcn_readfirstlane(map[v]);
+                if(ri >= 0) ApplyRecordLean(L, recs[ri], lane0);
+            }
+        }
+        // What the update reads through the scalar cache -- the voices' control lines -- was written with vector stores, by this
+        // wavefront and (the key voice's head) by wavefront 0: the stores are in L2 before the barrier, the scalar cache forgets
+        // behind it.  (Nothing crosses workgroups: no fence of wider scope, which would write back and invalidate a whole L2.)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_s_dcache_inv();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     // Voices are processed in passes; pass 0 only requests the first voice's source window and
     // stages the workgroup's resampler rows.  The request for the NEXT voice's window sits at one
     // point of the pass -- after this voice's FIR inputs are built, before its FIR runs -- so the
@@ -999,8 +1117,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         constexpr uint32_t kMaxM = 2u * uint32_t(WgLds<R, TAPS, MF>::kPairs);
         const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24 || mK == 48) && mK <= kMaxM))
             && (psK == OALGPU_VOICE_PLAYING || psK == OALGPU_VOICE_STOPPING);
+        // RES: the rows staged by an earlier update of this launch are still there unless the key voice's resampler changed
+        // (every wavefront reads the same head behind the update's barrier and the same LDS words: a uniform decision)
+        if constexpr (RES) { if(first && upd != updBase) stageRows = !(eligK && sm.tabKey == offK * 8u + uint32_t(kK) && sm.tabM == mK); }
 #ifndef OALGPU_EXP_LATE_ROWS
-        if(first && eligK)
+        if(first && eligK && stageRows)
         {
             typedef const __attribute__((address_space(1))) void *gvoidp;
             typedef __attribute__((address_space(3))) void *lvoidp;
@@ -1018,7 +1139,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         else requestNext();
         if constexpr (PROF) { if(first) waveStamp(5); }
 
-        if(first)
+        if(first && stageRows)
         {   // ---- workgroup prologue: pick and stage the resampler rows most voices will use
             // Normally those of the workgroup's first voice, whose head every wavefront has read
             // itself (no barrier, no second round trip at kernel start); if that voice does not
@@ -1393,6 +1514,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         }
         __syncthreads();
         f2 *ph = reinterpret_cast<f2*>(L.partHrtf) + size_t{group} * (kLine + kHrirLen);
+        if constexpr (RES)      // the update's set of partial buses
+            ph = reinterpret_cast<f2*>(next.res.partBase + size_t{upd % kResidentSets} * next.res.setStride) + size_t{group} * (kLine + kHrirLen);
         for(uint32_t k = t; k < uint32_t(kLine + kHrirLen); k += kWThreads)
         {
             f2 s = {0.0f, 0.0f};
@@ -1405,7 +1528,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
 #ifdef OALGPU_EXP_CACHED_ACCUM
             ph[k] = s;
 #else
-            StorePartial(&ph[k], s);
+            if constexpr (RES) StorePartialCoherent(&ph[k], s);       // (read by the reduction's launch while this one runs on)
+            else StorePartial(&ph[k], s);
 #endif
         }
     }
@@ -1414,7 +1538,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     // ---- the next update's parameter block: every wavefront installs the records of the voices it has just mixed (HRTF kernels).
     // The voices' state was written back by this very wavefront, in program order, so its loads see it; the kernel boundary makes
     // the result visible to the next launch, as it did for the parameter kernel this replaces.
-    if(next.map)
+    if(!RES && next.map)
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         for(uint32_t j = 0; j < vCount; ++j)
@@ -1423,6 +1547,16 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             const int32_t ri = __builtin_amdgcn_readfirstlane(next.map[v]);
             if(ri >= 0) ApplyNextRecord(L, next.recs[ri], lane0);
         }
+    }
+    if constexpr (!RES) break;
+    else
+    {   // the workgroup's partial is where the reduction will read it (written through, every thread's stores acknowledged)
+        // before the workgroup counts as arrived for this update; then on to the next one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if(t == 0) __hip_atomic_fetch_add(next.res.counters + 16u * (kRcArrive0 + upd % kResidentSets), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++upd;
+    }
     }
 }
 
@@ -1474,7 +1608,7 @@ bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.hrtf != 0; }
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap)
 {
-    const NextBlock next{nextRecs, L.hrtf ? nextMap : nullptr};
+    const NextBlock next{nextRecs, L.hrtf ? nextMap : nullptr, ResidentArgs{}};
     const uint32_t groups = WaveKernelGroups(L);
     const bool sends = L.numSends != 0;
     const dim3 grid(groups), block(kWThreads);
@@ -1523,6 +1657,7 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     }
     return hipGetLastError();
 }
+
 #endif
 
 } // namespace oalgpu

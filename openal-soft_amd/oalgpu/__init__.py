@@ -77,6 +77,7 @@ class ContextDesc(C.Structure):
 
 # oalgpu_context_desc::flags
 CTX_FIR_VALU, CTX_PROFILE, CTX_SERIAL, CTX_STREAM_ROWS, CTX_APPLY_IN_VOICE_KERNEL, CTX_FUSED_REDUCE = 1, 2, 4, 8, 16, 32
+CTX_RESIDENT = 64
 
 
 class VoiceDesc(C.Structure):
@@ -649,6 +650,22 @@ class Scene:
 
     def sync(self):
         check(lib.oalgpu_sync(self.h), "oalgpu_sync")
+
+    def resident_stats(self):
+        """OALGPU_CTX_RESIDENT: dict of oalgpu_resident_info (launches, updates, parks, the ended launches' own time)"""
+        class Info(C.Structure):
+            _fields_ = [("enabled", C.c_int32), ("failed", C.c_int32), ("running", C.c_int32), ("door_in_device_memory", C.c_int32),
+                        ("launches", C.c_uint32), ("updates", C.c_uint32), ("parks", C.c_uint32), ("timed_launches", C.c_uint32),
+                        ("timed_updates", C.c_uint64), ("timed_kernel_ms", C.c_double),
+                        ("max_updates_per_launch", C.c_uint32), ("pad", C.c_uint32)]
+        info = Info()
+        lib.oalgpu_resident_stats.argtypes = [C.c_void_p, C.POINTER(Info)]
+        check(lib.oalgpu_resident_stats(self.h, C.byref(info)), "oalgpu_resident_stats")
+        return {k: getattr(info, k) for k, _ in Info._fields_ if k != "pad"}
+
+    def resident_set_max_updates(self, n):
+        lib.oalgpu_resident_set_max_updates.argtypes = [C.c_void_p, C.c_uint32]
+        check(lib.oalgpu_resident_set_max_updates(self.h, n), "oalgpu_resident_set_max_updates")
 
     def dry(self):
         n = self.desc.num_dry_channels + self.desc.num_real_channels

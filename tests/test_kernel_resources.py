@@ -86,6 +86,38 @@ def test_reduction_fits_beside_the_hrtf_voice_kernel(voice_wave, voice_kernel, t
         assert 2 * granule(voice["group_segment_fixed_size"], 1280) + granule(reduce4["group_segment_fixed_size"], 1280) <= 160 * 1024
 
 
+def test_resident_voice_kernel_leaves_room_for_what_waits_for_it(voice_wave, tmp_path):
+    """OALGPU_CTX_RESIDENT: the voice kernel never leaves the machine, and the reduction and the post-process of every update
+    WAIT for it (device counters) -- they must be able to start on a SIMD that holds one wavefront of each of a CU's two
+    resident voice workgroups, or nothing ever moves again.  The resident kernel is its own translation unit with the
+    Makefile's flags for it (machine LICM off: 217 registers instead of 249)."""
+    hip, per_file = makefile_flags()
+    assert "-disable-machine-licm" in per_file["voice_wave_res"]
+    out = tmp_path / "voice_wave_res.s"
+    subprocess.run([HIPCC, *hip, *per_file["voice_wave_res"], "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", str(out),
+                    os.path.join(CSRC, "voice_wave_res.hip")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    meta = {}
+    for block in re.split(r"\n  - ", text[text.index("amdhsa.kernels:"):])[1:]:
+        fields = dict(re.findall(r"\.(\w+):\s+(\S+)", block))
+        if "name" in fields:
+            meta[fields["name"]] = {k: int(v) for k, v in fields.items() if v.isdigit()}
+    assert len(meta) == 1, sorted(meta)
+    voice = next(iter(meta.values()))
+    assert voice["vgpr_spill_count"] == 0 and voice["private_segment_fixed_size"] == 0, voice
+    post = kernel_metadata(tmp_path, "post_wave.hip", ["-mllvm", "-amdgpu-load-store-vectorizer=0"])
+    red = next(m for n, m in post.items() if "BusReduceResidentKernel" in n)
+    pst = next(m for n, m in post.items() if "PostResidentKernel" in n)
+    for other in (red, pst):
+        assert other["vgpr_spill_count"] == 0, other
+        assert 2 * granule(voice["vgpr_count"]) + granule(other["vgpr_count"]) <= 512, (voice, other)
+    lds = 2 * granule(voice["group_segment_fixed_size"], 1280) + granule(red["group_segment_fixed_size"], 1280) + granule(pst["group_segment_fixed_size"], 1280)
+    assert lds <= 160 * 1024, lds
+    # the launched product kernel's LDS footprint, which the resident one shares
+    launched = next(m for n, m in voice_wave.items() if "VoiceWaveKernelILi17ELi64ELi0ELb0ELb1ELb0E" in n)
+    assert launched["group_segment_fixed_size"] == voice["group_segment_fixed_size"]
+
+
 def test_no_packed_fp32_op_takes_src0_low_and_src1_high():
     """gfx950: v_pk_{fma,mul,add}_f32 with op_sel = [0,1,..] (low lane = src0.lo x src1.HI) reads src1.hi as zero in
     a few percent of its executions while another wavefront of the SIMD executes MFMAs (tools/ubench_pk_opsel.hip,
