@@ -302,6 +302,7 @@ def main():
                     help="OALGPU_CTX_RESIDENT: one launch of the HRTF voice kernel stays on the machine over the updates of a block; every "
                          "step still is one oalgpu_param_block_apply + one oalgpu_mix_update with its own output (auto: on where the "
                          "library has the mode -- HRTF contexts without sends on one GPU, i.e. the headline config)")
+    ap.add_argument("--static", action="store_true", help="experiment: no parameter block per step (no voice moves)")
     ap.add_argument("--run", type=int, default=0, metavar="B",
                     help="submit the steps B at a time through oalgpu_mix_update_run (one library call per B updates "
                          "instead of two per update); B must divide --steps and --warmup; 0 = one update per call")
@@ -333,10 +334,18 @@ def main():
     # torch's lazy CUDA initialisation (hundreds of ms) happens HERE, not inside the first fence: there it left the GPU idle
     # right before the timed block, whose 20 steps then ran on ramping clocks (63 against 48.7 us per step at K = 20)
     torch.cuda.synchronize()
-    want_resident = args.resident == "on" or (args.resident == "auto" and args.config == 3 and world == 1 and args.math == "fast"
-                                              and args.fir == "mfma")
+    # How the headline context runs its voice kernel (both are product modes, chosen by context flags):
+    # resident -- ONE launch stays on its voices over the block, every step still one oalgpu_param_block_apply + one
+    # oalgpu_mix_update with its own output -- pays for itself over a few dozen updates between two synchronisations (a launch's
+    # first updates run at the launched pace and the block ends with the pipeline's drain: tools/resident_block_cost.py), so it is
+    # what a K-step block of K >= 48 uses; shorter blocks launch per update, with the parameter block installed by the voice
+    # kernel's own wavefronts (OALGPU_CTX_APPLY_IN_VOICE_KERNEL).  The library makes the same choice by itself for a host that
+    # keeps its resident launches short (oalgpu_resident_set_short_run).
+    hot = args.config == 3 and world == 1 and args.math == "fast" and args.fir == "mfma"
+    want_resident = args.resident == "on" or (args.resident == "auto" and hot and args.steps >= 48)
+    mode_flags = (oalgpu.CTX_RESIDENT if want_resident else 0) | (oalgpu.CTX_APPLY_IN_VOICE_KERNEL if hot and args.resident != "off" else 0)
     api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank,
-                     ctx_flags=(oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0) | (oalgpu.CTX_RESIDENT if want_resident else 0) | args.xflags)
+                     ctx_flags=(oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0) | mode_flags | args.xflags)
     real_mhr = os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr")
     use_real = args.mhr == "default" and os.path.exists(real_mhr)
     if use_real:
@@ -418,7 +427,8 @@ def main():
             if k % B == 0:
                 sc.mix_run([blocks[(k + j) % nblocks] for j in range(B)], UPDATE_SAMPLES, post)
             return
-        sc.apply_block(blocks[k % nblocks])
+        if not args.static:
+            sc.apply_block(blocks[k % nblocks])
         sc.mix(UPDATE_SAMPLES, post_process=post)
 
     def fence():
@@ -476,14 +486,14 @@ def main():
         step(k)
     fence()
     cold_elapsed, _ = timed_block(args.warmup)
+    sync_every = max(25, args.steps) if want_resident else 25      # (a resident launch lives from one synchronisation to the next)
     for k in range(preroll):
         step(k)
-        if k % 25 == 24:
+        if k % sync_every == sync_every - 1:
             fence()
     for k in range(args.warmup):
         step(k)
     fence()
-    res0 = sc.resident_stats() if want_resident else None
     elapsed, own_elapsed = timed_block(args.warmup)
     rank_ms = [own_elapsed / args.steps * 1e3]
     if dist is not None:
@@ -505,7 +515,18 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             e = float(tt.item())
         extra.append(e / args.steps * 1e3)
-    res1 = sc.resident_stats() if want_resident else None
+    # the resident launch's own time (HIP events bound to its dispatch: they cost the launch call ~15 us of host time, so they
+    # are switched on only here, behind the timed blocks): the same K-step block a few more times
+    res0 = res1 = None
+    if want_resident:
+        sc.resident_set_timing(True)
+        res0 = sc.resident_stats()
+        for r in range(max(1, min(args.repeats, 3))):
+            for k in range(args.steps):
+                step(args.warmup + (r + 7) * args.steps + k)
+            fence()
+        res1 = sc.resident_stats()
+        sc.resident_set_timing(False)
 
     # ---- end-to-end latency of ONE update through the boundary as a host uses it: the moving voices'
     # oalgpu_voice_params records go in from host memory (biquad design + H2D inside
@@ -613,9 +634,10 @@ def main():
         resident = {"launches": lau, "updates": upd, "launch_ms_mean": kms / max(lau, 1), "updates_per_launch": upd / max(lau, 1),
                     "kernel_ms_per_update": vk_ms, "door_in_device_memory": bool(res1["door_in_device_memory"]),
                     "parks_total": res1["parks"], "launches_total": res1["launches"],
-                    "note": "the timed blocks (the contract's one and the repeats): one launch of the voice kernel per K-step block, ended "
-                            "by the block's closing oalgpu_sync; launch_ms_mean is what rocprofv3's kernel trace shows per call of "
-                            "VoiceWaveKernel<..., true> for those blocks"}
+                    "waits_us_per_update": {k[:-3]: (res1[k] - res0[k]) / upd for k in res1 if k.endswith("_us")},
+                    "note": "K-step blocks like the timed ones, run behind them with the launches' events on: one launch of the voice kernel "
+                            "per block, ended by the block's closing oalgpu_sync; launch_ms_mean is what rocprofv3's kernel trace shows "
+                            "per call of VoiceWaveKernel<..., true> for such blocks"}
     # the same clock around an EMPTY kernel: what the dispatch-bound events include besides a kernel's own run time
     # (rocprofv3's kernel trace reports the voice kernel about this much shorter, profiles/README.md)
     event_floor_ms = sc.event_floor_ms(200) if sc.voice_kernel_name().startswith("VoiceWaveKernel") else None
@@ -662,6 +684,9 @@ def main():
                                    + {4: ", v%5 sends into 4 reverb slots", 5: ", one send into a 65536-tap convolution slot"}.get(args.config, "")
                                    + "), 25% filtered, every 4th voice moving",
                        "voices_total": nvoices_total, "update_samples": UPDATE_SAMPLES,
+                       "voice_kernel_mode": ("resident launch (OALGPU_CTX_RESIDENT): one launch per K-step block" if want_resident else
+                                             ("launch per update, parameter block installed by the voice kernel (OALGPU_CTX_APPLY_IN_VOICE_KERNEL)"
+                                              if mode_flags & oalgpu.CTX_APPLY_IN_VOICE_KERNEL else "launch per update")),
                        "preroll_steps": preroll, "cold_block_ms_per_step": cold_elapsed / args.steps * 1e3, "math_mode": args.math,
                        "voices_per_rank": shard_sizes, "rank_ms_per_step": rank_ms,
                        "transport": (args.transport if world > 1 else None), "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,

@@ -431,8 +431,22 @@ typedef struct oalgpu_resident_info {
     uint64_t timed_updates;
     double   timed_kernel_ms;
     uint32_t max_updates_per_launch, pad;
+    /* where the time BETWEEN the kernels' work went, in microseconds summed over the updates so far (the counters are read when
+     * the context is idle: oalgpu_sync first): wait_door / wait_reduction: a voice workgroup (mean over the workgroups) waiting for
+     * the doorbell / for the reduction that still reads its partial set; wait_arrival / wait_post: the reduction waiting for the
+     * voice workgroups / for the post-process of the update before; wait_reduced / wait_split: the post-process waiting for the
+     * reduction / its FIR workgroups for the band splits */
+    double   wait_door_us, wait_reduction_us, wait_arrival_us, wait_post_us, wait_reduced_us, wait_split_us;
+    double   install_us, busy_us, top_us;   /* a voice workgroup (mean): installing the update's parameter block; mixing its voices up to the
+                                            * arrival; from there to the next update known (the door's loads and the two waits) */
 } oalgpu_resident_info;
 int oalgpu_resident_stats(oalgpu_context *ctx, oalgpu_resident_info *out);
+/* A launch pays for itself over a few dozen updates; a host that keeps ending it early (a synchronisation every 20 updates,
+ * another entry point before every update) is better off with a launch per update.  After three launches in a row that were
+ * parked before `updates` updates (default 32) the context launches per update for the next 192, then tries again; 0 = never. */
+int oalgpu_resident_set_short_run(oalgpu_context *ctx, uint32_t updates);
+/* the launches carry HIP events bound to their dispatch (timed_* above): ~15 us more of host time per launch, off by default */
+int oalgpu_resident_set_timing(oalgpu_context *ctx, int enable);
 /* a launch ends by itself after this many updates (default 4096); the next update starts a new one */
 int oalgpu_resident_set_max_updates(oalgpu_context *ctx, uint32_t max_updates);
 /* Run the context on a caller-owned HIP stream (hipStream_t), e.g. the stream an RCCL

@@ -224,6 +224,7 @@ struct oalgpu_context {
     uint32_t postEpoch{0};                  // ... and the value it has reached after the last launch
     const ParamRecord *nextRecs{nullptr};   // the block the voice kernel being launched installs in its epilogue (RunMixUpdate)
     const int32_t *nextMap{nullptr};
+    const float *nextRows{nullptr};
     bool carryInBuf{false};                 // the carried accumulator is in carryBuf (else: in the bus block's accumulator region)
     DevBuf<float> dHfScale, dCoeffs, dTemp;
     uint32_t dIrSize{0};
@@ -271,10 +272,14 @@ struct oalgpu_context {
         uint32_t endSeq{0};                        // where the running launch ends by itself
         uint32_t launches{0}, startedTotal{0};
         uint32_t launchBase{0};                    // the running launch's first update
-        // A host that keeps calling entry points the kernel has to leave for (parameters set the launched way before every
-        // update, say) would pay a launch AND the wait for its workgroups per update: after three launches in a row that
-        // covered fewer than two updates the context launches per update for a while, then tries again.
+        // A launch pays for itself over a few dozen updates (its first updates run at the launched path's pace, and the block
+        // ends with the pipeline's drain: 45.5 against 44.5 us per update for blocks of 20, 38.8 against 42.9 for blocks of 50,
+        // tools/resident_block_cost.py).  A host that keeps it short -- a synchronisation every 20 updates, parameters set the
+        // launched way before every update -- is better off with a launch per update: after three launches in a row that covered
+        // fewer than 32 updates the context launches per update for a while, then tries again.
         uint32_t shortRuns{0}, cooldown{0};
+        uint32_t shortRun{32};                     // launches that cover fewer updates count as short (0: never fall back)
+        uint32_t awaitStarted{0};                  // the launch id whose "every workgroup has started" word the host has yet to see
         uint32_t maxUpdates{4096};
         uint32_t setUses[kResidentSets]{};         // updates that went into each partial set so far
         uint32_t posts{0};                         // post-processes launched in this mode
@@ -286,6 +291,7 @@ struct oalgpu_context {
         hipEvent_t evStart[kEv]{}, evStop[kEv]{};
         uint32_t evFirst[kEv]{}, evLast[kEv]{};    // the updates the launch of that event pair covered: [first, last)
         bool evOpen[kEv]{};
+        bool timeLaunches{false};                  // oalgpu_set_timing: the launches carry their events
         double kernelMs{0.0};
         uint64_t kernelUpdates{0}, kernelLaunches{0}, parks{0};
     } res;
@@ -323,6 +329,7 @@ struct oalgpu_param_block {
     DevBuf<int32_t> voiceToRec;                             // [voice of the context] -> index of its record in the block, or -1: how a
                                                             // voice kernel's wavefront finds the records of the voices it mixed
     uint32_t mapVoices{0};
+    DevBuf<float> rows;                                     // [record][irStride][2]: the records' blended target HRIRs (resident contexts)
     std::vector<std::pair<uint32_t, uint32_t>> cbSteps;     // (voice, mStep) of the callback voices in the block
     oalgpu_context *heldBy{nullptr};                        // a resident context that keeps the block for its next update (res.pendingBlock)
 };
@@ -358,12 +365,12 @@ void ResidentParkLocked(oalgpu_context *c)
 {
     auto &R = c->res;
     if(!R.running) return;
-    __atomic_store_n(&R.door->exitSeq, R.next, __ATOMIC_RELEASE);
+    __atomic_store_n(&R.door->exitSeq[R.launches & 3u], R.next, __ATOMIC_RELEASE);     // (R.launches: the running launch's id)
     __builtin_ia32_sfence();                // (write-combined stores through the BAR leave the core)
     R.running = false;
     ++R.parks;
-    R.shortRuns = (R.next - R.launchBase < 2u) ? R.shortRuns + 1u : 0u;
-    if(R.shortRuns >= 3u) { R.shortRuns = 0u; R.cooldown = 256u; }
+    R.shortRuns = (R.next - R.launchBase < R.shortRun) ? R.shortRuns + 1u : 0u;
+    if(R.shortRuns >= 3u) { R.shortRuns = 0u; R.cooldown = 192u; }
     const uint32_t e = (R.launches - 1u) % oalgpu_context::ResidentState::kEv;
     R.evLast[e] = R.next;
     gResRunning.erase(std::remove(gResRunning.begin(), gResRunning.end(), c), gResRunning.end());
@@ -1784,6 +1791,14 @@ int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const o
             HIP_TRY(b->voiceToRec.alloc(map.size()));
             HIP_TRY(b->voiceToRec.upload(map.data(), map.size()));
             b->mapVoices = uint32_t(map.size());
+            if((c->res.enabled || (c->desc.flags & OALGPU_CTX_APPLY_IN_VOICE_KERNEL)) && c->L.hrtf && c->L.hrirs)
+            {   // a resident context's voice kernel installs the block itself: the HRIR blend of every record now, once
+                HIP_TRY(b->rows.alloc(count * size_t{c->L.irStride} * 2));
+                HIP_TRY(b->rows.zero());
+                LaunchBlendRows(c->stream, c->L, b->recs.p, uint32_t(count), b->rows.p);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
         }
     }
     for(size_t i = 0; i < count; ++i)
@@ -1798,7 +1813,7 @@ int oalgpu_param_block_apply(oalgpu_context *c, oalgpu_param_block *b)
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     if(c->L.hrtf && b->hrtfGeneration != c->hrtfGeneration)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_param_block_apply: the block was built against another HRTF data set (its HRIR indices are that store's); create it again");
-    if(!c->res.cooldown && ResidentWanted(c, 1) && !c->res.pendingBlock && b->mapVoices == c->L.numVoices && b->cbSteps.empty())
+    if(!c->res.cooldown && ResidentWanted(c, 1) && !c->res.pendingBlock && b->mapVoices == c->L.numVoices && b->cbSteps.empty() && b->rows.p)
     {   // a resident context: the block rides in the next update's doorbell slot and the voice kernel's wavefronts install it
         // (another entry point in between applies it the launched way: FlushResidentBlock)
         c->res.pendingBlock = b;
@@ -2341,7 +2356,7 @@ static int ResidentInit(oalgpu_context *c)
     if(R.doorInBar) HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&R.door), sizeof(ResidentDoor), hipDeviceMallocFinegrained));
     else HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&R.door), sizeof(ResidentDoor), hipHostMallocDefault));
     std::memset(R.door, 0, sizeof(ResidentDoor));
-    R.door->exitSeq = 0x40000000u;
+    for(uint32_t &e : R.door->exitSeq) e = 0x40000000u;
     __builtin_ia32_sfence();
     HIP_TRY(R.counters.alloc(size_t{kRcCount} * 16)); HIP_TRY(R.counters.zero());
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&R.hostFlags), size_t{kRhCount} * 16 * sizeof(uint32_t), hipHostMallocDefault));
@@ -2382,7 +2397,31 @@ static int ResidentCheckError(oalgpu_context *c)
     __atomic_store_n(R.hostFlags + 16u * kRhError, 0u, __ATOMIC_RELEASE);
     static const char *what[4] = {"", "the voice kernel waited 2 s for the host or for its reduction", "a reduction waited 2 s for the voice kernel",
         "a reduction waited 2 s for the post-process"};
-    return ResidentGiveUp(c, e < 4 ? what[e] : "a wait timed out");
+    // where everything stood: the counters the kernels wait for, beside what the host expects them to reach
+    std::string state;
+    {
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(R.reduceStream); (void)hipStreamSynchronize(c->postStream);
+        uint32_t w[kRcCount * 16] = {};
+        uint32_t pa = 0;
+        if(hipMemcpy(w, R.counters.p, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess
+            && hipMemcpy(&pa, c->postArrived.p, sizeof(pa), hipMemcpyDeviceToHost) == hipSuccess)
+        {
+            char buf[512];
+            std::snprintf(buf, sizeof(buf), " [updates %u, launches %u, groups %u; arrive %u %u %u %u (uses %u %u %u %u), redRead %u redDone %u (per update %u), "
+                "postDone %u (posts %u x %u), postArrived %u (epoch %u), started %u (expected %u), progress %u]", R.next, R.launches, c->L.numGroups,
+                w[0], w[16], w[32], w[48], R.setUses[0], R.setUses[1], R.setUses[2], R.setUses[3], w[16 * kRcRedRead], w[16 * kRcRedDone], R.redGroups,
+                w[16 * kRcPostDone], R.posts, R.firGroups, pa, c->postEpoch, w[16 * kRcStarted], R.startedTotal,
+                __atomic_load_n(R.hostFlags + 16u * kRhProgress, __ATOMIC_ACQUIRE));
+            state = buf;
+            const uint32_t *fi = R.hostFlags + 16u * kRhFault;
+            std::snprintf(buf, sizeof(buf), " [the voice workgroup that gave up: update %u, doorbell %u, exit word %u, reduction counter %u of %u, workgroup %u, launch %u, "
+                "%u ticks; host: seq %u exit %u %u %u %u]", fi[0], fi[1], fi[2], fi[3], fi[4], fi[5], fi[6], fi[7], R.door->seq, R.door->exitSeq[0], R.door->exitSeq[1],
+                R.door->exitSeq[2], R.door->exitSeq[3]);
+            if(e == 1) state += buf;
+        }
+        else (void)hipGetLastError();
+    }
+    return ResidentGiveUp(c, std::string(e < 4 ? what[e] : "a wait timed out") + state);
 }
 
 // One update of a resident context: the doorbell, its reduction (reduce stream) and its post-process (post stream).
@@ -2395,43 +2434,24 @@ static int ResidentSubmit(oalgpu_context *c, uint32_t samples_to_do)
     using clk = std::chrono::steady_clock;
     std::unique_lock<std::mutex> g(gResLock);
     const DeviceLayout &L = c->L;
-    if(!R.running)
+    // a new launch: prepared here, started BEHIND the update's doorbell (the kernel finds its first update rung when it comes up)
+    const bool launchNow = !R.running;
+    ResidentArgs a{};
+    uint32_t evk = 0;
+    bool timed = false;
+    if(launchNow)
     {
         // the reduce stream joins whatever the post stream still runs (the bus block and the carried accumulator are theirs too)
         if(c->postPending) HIP_TRY(hipStreamWaitEvent(R.reduceStream, c->lastPostEvent ? c->lastPostEvent : c->evPostDone, 0));
-        const uint32_t k = R.launches % oalgpu_context::ResidentState::kEv;
+        const uint32_t k = evk = R.launches % oalgpu_context::ResidentState::kEv;
         if(R.evOpen[k]) { HIP_TRY(hipEventSynchronize(R.evStop[k])); ResidentCollectTimes(c, false); }
-        ResidentArgs a{};
+        timed = R.timeLaunches;           // (events bound to the dispatch cost the launch call ~15 us of host time)
         a.door = R.door; a.counters = R.counters.p; a.hostFlags = R.hostFlags; a.partBase = R.part.p; a.setStride = uint32_t(R.setFloats);
         a.base = R.next; a.endSeq = R.next + R.maxUpdates; a.redPerUpdate = R.redGroups;
         a.startedTarget = R.startedTotal + L.numGroups; a.launchId = R.launches + 1u;
-        __atomic_store_n(&R.door->exitSeq, R.next + 0x40000000u, __ATOMIC_RELEASE);
+        __atomic_store_n(&R.door->exitSeq[a.launchId & 3u], R.next + 0x40000000u, __ATOMIC_RELEASE);
         __atomic_store_n(&R.door->seq, R.next, __ATOMIC_RELEASE);
         __builtin_ia32_sfence();
-        HIP_TRY(LaunchVoiceWaveResident(c->stream, L, a, R.evStart[k], R.evStop[k]));
-        R.evOpen[k] = true; R.evFirst[k] = R.next; R.evLast[k] = R.next;
-        ++R.launches; R.startedTotal = a.startedTarget; R.endSeq = a.endSeq; R.launchBase = R.next;
-        // Nothing that waits for this kernel may get onto the machine in front of it: a reduction that polls for workgroups which
-        // find no room beside it would wait for ever.  The last workgroup to start says so (a pinned word).
-        const auto deadline = clk::now() + std::chrono::seconds(5);
-        uint32_t spins = 0;
-        while(__atomic_load_n(R.hostFlags + 16u * kRhResident, __ATOMIC_ACQUIRE) != a.launchId)
-        {
-            __builtin_ia32_pause();
-            if((++spins & 0x3ffu) == 0 && clk::now() > deadline)
-            {   // (it may still start: tell it to leave at once, then wait for the stream)
-                __atomic_store_n(&R.door->exitSeq, R.next, __ATOMIC_RELEASE);
-                __builtin_ia32_sfence();
-                g.unlock();
-                (void)hipStreamSynchronize(c->stream);
-                R.evLast[k] = R.next;
-                (void)ResidentGiveUp(c, "its workgroups did not all start within 5 s");
-                return 1;
-            }
-        }
-        R.running = true;
-        gResRunning.push_back(c);
-        gResCount.store(int(gResRunning.size()), std::memory_order_relaxed);
     }
     {   // the host stays at most kResidentDepth updates ahead of the post-process (doorbell slots, queue depth)
         const auto deadline = clk::now() + std::chrono::seconds(5);
@@ -2464,12 +2484,47 @@ static int ResidentSubmit(oalgpu_context *c, uint32_t samples_to_do)
     ResidentSlot &sl = R.door->slot[R.next % kResidentSlots];
     sl.recs = b ? reinterpret_cast<unsigned long long>(b->recs.p) : 0ull;
     sl.map = b ? reinterpret_cast<unsigned long long>(b->voiceToRec.p) : 0ull;
+    sl.rows = b ? reinterpret_cast<unsigned long long>(b->rows.p) : 0ull;
     sl.samples = samples_to_do;
     __builtin_ia32_sfence();
     __atomic_store_n(&R.door->seq, R.next + 1u, __ATOMIC_RELEASE);
     __builtin_ia32_sfence();
+    if(launchNow)
+    {
+        const uint32_t k = evk;
+        HIP_TRY(LaunchVoiceWaveResident(c->stream, L, a, timed ? R.evStart[k] : nullptr, timed ? R.evStop[k] : nullptr));
+        R.evOpen[k] = timed; R.evFirst[k] = R.next; R.evLast[k] = R.next;
+        ++R.launches; R.startedTotal = a.startedTarget; R.endSeq = a.endSeq; R.launchBase = R.next;
+        // Nothing that waits for this kernel may get onto the machine in front of it: a reduction that polls for workgroups which
+        // find no room beside it would wait for ever.  The last workgroup to start says so (a pinned word): the doorbell is rung at
+        // once -- the workgroups that are there start on the update -- and the host looks for the word only in front of the first
+        // reduction it launches (awaitStarted), which nobody needs before the voices of the update are through.
+        R.awaitStarted = a.launchId;
+        R.running = true;
+        gResRunning.push_back(c);
+        gResCount.store(int(gResRunning.size()), std::memory_order_relaxed);
+    }
     // ---- the update's reduction and post-process: launches of their own that wait for device counters
     const uint32_t set = R.next % kResidentSets;
+    if(R.awaitStarted)
+    {
+        const uint32_t id = R.awaitStarted;
+        R.awaitStarted = 0u;
+        const auto deadline = clk::now() + std::chrono::seconds(5);
+        uint32_t spins = 0;
+        while(__atomic_load_n(R.hostFlags + 16u * kRhResident, __ATOMIC_ACQUIRE) != id)
+        {
+            __builtin_ia32_pause();
+            if((++spins & 0x3ffu) == 0 && clk::now() > deadline)
+            {   // (it may still start, and the update has been rung: it is told to leave behind that update; the update is lost)
+                ++R.next;
+                ResidentParkLocked(c);
+                g.unlock();
+                (void)hipStreamSynchronize(c->stream);
+                return ResidentGiveUp(c, "its workgroups did not all start within 5 s");
+            }
+        }
+    }
     if(R.copyPending) { HIP_TRY(hipStreamWaitEvent(R.reduceStream, R.copyPending, 0)); R.copyPending = nullptr; }
     DeviceLayout Lr = L;
     Lr.partHrtf = R.part.p + size_t{set} * R.setFloats;
@@ -2759,7 +2814,7 @@ int oalgpu_mix_update(oalgpu_context *c, uint32_t samples_to_do, int post_proces
     }
     if(int rc = UseCtx(c)) return rc;                // (submits the update deferred before this one)
     if(c->useWave && c->ownStream && !c->serialOnly && !c->timing && (c->desc.flags & OALGPU_CTX_APPLY_IN_VOICE_KERNEL) && WaveKernelAppliesRecords(c->L)
-        && !(c->res.enabled && !c->res.failed))
+        && !(c->res.enabled && !c->res.failed && !c->res.cooldown))
     {   // submitted with the next library call on this context (see pendingMix); whatever goes wrong then is that call's error
         c->pendingMix.active = true; c->pendingMix.samples = samples_to_do; c->pendingMix.post = post_process;
         return OALGPU_OK;
@@ -2779,7 +2834,8 @@ static int RunMixUpdate(oalgpu_context *c, uint32_t samples_to_do, int post_proc
 {
     c->nextRecs = next ? next->recs.p : nullptr;
     c->nextMap = next ? next->voiceToRec.p : nullptr;
-    struct Clear { oalgpu_context *c; ~Clear() { c->nextRecs = nullptr; c->nextMap = nullptr; } } clear{c};
+    c->nextRows = next ? next->rows.p : nullptr;
+    struct Clear { oalgpu_context *c; ~Clear() { c->nextRecs = nullptr; c->nextMap = nullptr; c->nextRows = nullptr; } } clear{c};
     if(!(c->useWave && c->ownStream) || c->serialOnly)
     {   // one stream: the workgroup-per-voice-group kernel reads the carried accumulator itself,
         // and a caller-owned stream (RCCL ordering) is never forked
@@ -2838,7 +2894,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     // The event the post stream waits for is bound to the voice kernel's dispatch (hipExtLaunchKernel's stop event: one
     // runtime call less per update than a record behind the launch).  Timing runs use that slot for their own event.
     HIP_TRY(LaunchVoiceWave(c->stream, L, samples_to_do, c->profArg(), c->timing ? c->evStart : nullptr, c->timing ? c->evVoice : c->evVoiceDone[p],
-        c->nextRecs, c->nextMap));
+        c->nextRecs, c->nextMap, c->nextRows));
     if(c->timing) HIP_TRY(hipEventRecord(c->evVoiceDone[p], c->stream));
     // post stream: the reduction (adds the carried HRTF accumulator tail); whatever follows on that stream -- a collective, the effects, the post-process -- runs beside
     // the next update's parameter and voice kernels
@@ -3190,13 +3246,43 @@ const char *oalgpu_voice_kernel_name(oalgpu_context *c)
 int oalgpu_resident_stats(oalgpu_context *c, oalgpu_resident_info *out)
 {
     if(!c || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
+    auto &R = c->res;
+    uint32_t w[kRcCount * 16] = {};
+    if(R.ready && !R.running)
+    {   // the wait counters: a copy on the null stream, with nothing resident on the device
+        if(int rc = UseDevice(c->desc.device)) return rc;
+        HIP_TRY(hipMemcpy(w, R.counters.p, sizeof(w), hipMemcpyDeviceToHost));
+    }
     std::lock_guard<std::mutex> g(gResLock);
-    const auto &R = c->res;
     out->enabled = R.enabled ? 1 : 0; out->failed = R.failed ? 1 : 0; out->running = R.running ? 1 : 0;
     out->door_in_device_memory = R.doorInBar ? 1 : 0;
     out->launches = R.launches; out->updates = R.next; out->parks = uint32_t(R.parks);
     out->timed_launches = uint32_t(R.kernelLaunches); out->timed_updates = R.kernelUpdates; out->timed_kernel_ms = R.kernelMs;
-    out->max_updates_per_launch = R.maxUpdates;
+    out->max_updates_per_launch = R.maxUpdates; out->pad = 0;
+    // (the voice kernel's words: every 128th workgroup keeps them)
+    const double tick = 0.01, groups = double(std::max<uint32_t>((c->L.numGroups + 127u) / 128u, 1u));
+    out->wait_door_us = w[16 * kRcWaitDoor] * tick / groups; out->wait_reduction_us = w[16 * kRcWaitRed] * tick / groups;
+    out->wait_arrival_us = w[16 * kRcWaitArrive] * tick; out->wait_post_us = w[16 * kRcWaitPost] * tick;
+    out->wait_reduced_us = w[16 * kRcWaitRedDone] * tick; out->wait_split_us = w[16 * kRcWaitSplit] * tick;
+    out->install_us = w[16 * kRcInstall] * tick / groups; out->busy_us = w[16 * kRcBusy] * tick / groups;
+    out->top_us = w[16 * kRcTop] * tick / groups;
+    return OALGPU_OK;
+}
+
+int oalgpu_resident_set_short_run(oalgpu_context *c, uint32_t updates)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseCtx(c)) return rc;
+    c->res.shortRun = updates;
+    c->res.shortRuns = 0; c->res.cooldown = 0;
+    return OALGPU_OK;
+}
+
+int oalgpu_resident_set_timing(oalgpu_context *c, int enable)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseCtx(c)) return rc;           // (the running launch ends: the next one carries the events, or no longer does)
+    c->res.timeLaunches = enable != 0;
     return OALGPU_OK;
 }
 

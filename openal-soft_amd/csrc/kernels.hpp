@@ -230,11 +230,14 @@ constexpr uint32_t kResidentSlots = 16;         // doorbell slots (the host stay
 constexpr uint32_t kResidentDepth = 8;
 constexpr unsigned long long kResidentWatchdogTicks = 200000000ull;    // s_memrealtime ticks (100 MHz): 2 s without progress = give up
 
-struct ResidentSlot { unsigned long long recs, map; uint32_t samples, pad[3]; };        // 32 bytes
+// recs / map: the update's parameter block (0: none); rows: its records' blended target HRIRs, [record][irStride][2]
+struct ResidentSlot { unsigned long long recs, map, rows; uint32_t samples, pad; };      // 32 bytes
 struct alignas(64) ResidentDoor {
     uint32_t seq;                               // updates rung so far: update u may run once int32(seq - u) > 0
-    uint32_t exitSeq;                           // the kernel leaves once its next update is >= this (host: park)
-    uint32_t pad[14];
+    uint32_t exitSeq[4];                        // [launch id % 4]: that launch leaves once its next update is >= this (host: park).
+                                                // Per launch: the next launch is queued -- and the door is ringing for it -- while
+                                                // the one that was parked is still finishing what had been rung for IT
+    uint32_t pad[11];
     ResidentSlot slot[kResidentSlots];          // slot[u % kResidentSlots]: written before seq
 };
 // device counters of a resident context, one uint32 each, 64 bytes apart (index x 16)
@@ -244,10 +247,23 @@ enum ResidentCounter : uint32_t {
     kRcRedDone = 5,                             // reduction workgroups whose sums are in the bus block
     kRcPostDone = 6,                            // post-process FIR workgroups that are through (stores included)
     kRcStarted = 7,                             // voice workgroups of all resident launches that have started
-    kRcCount = 8
+    // where the time between updates goes (s_memrealtime ticks, 10 ns, summed; oalgpu_resident_stats):
+    kRcWaitDoor = 8,                            // voice workgroups (all of them): waiting for the doorbell
+    kRcWaitRed = 9,                             // voice workgroups: waiting for the reduction that still reads their partial set
+    kRcWaitArrive = 10,                         // the reduction's first workgroup: waiting for the voice workgroups' arrival
+    kRcWaitPost = 11,                           // the reduction's first workgroup: waiting for the post-process of the update before
+    kRcWaitRedDone = 12,                        // the post-process's first split workgroup: waiting for the reduction
+    kRcWaitSplit = 13,                          // the post-process's first FIR workgroup: waiting for the splits
+    kRcInstall = 14,                            // voice workgroups: from the doorbell seen to the parameter block installed (both barriers)
+    kRcBusy = 15,                               // voice workgroups: from there to the arrival on the partial set
+    kRcTop = 16,                                // voice workgroups: from the arrival to the next update seen (the door's loads and both waits above)
+    kRcCount = 17
 };
 // pinned host words the kernels write (system scope), 64 bytes apart (index x 16)
-enum ResidentHostFlag : uint32_t { kRhResident = 0, kRhError = 1, kRhProgress = 2, kRhCount = 3 };
+enum ResidentHostFlag : uint32_t { kRhResident = 0, kRhError = 1, kRhProgress = 2,
+    kRhFault = 3,           // what a voice workgroup that gave up was looking at: [+0] update, [+1] doorbell, [+2] exit word, [+3] reduction counter,
+                            // [+4] the count it wanted, [+5] workgroup, [+6] launch id, [+7] ticks waited
+    kRhCount = 4 };
 struct ResidentArgs {
     const ResidentDoor *door;
     uint32_t *counters;                         // [kRcCount * 16]
@@ -400,6 +416,9 @@ void LaunchConvolution(hipStream_t s, const ConvLayoutHost &h);
 // ---- launchers (voice_kernel.hip) ----
 void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecord *recs, uint32_t count);
 void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count);
+// rows[record][irStride][2] = the records' target HRIRs as ApplyHrtfTargetWave leaves them in hrtfTgt (HRTF contexts; records with
+// keepHrtf are skipped): evaluated once per parameter block, for the resident voice kernel's install
+void LaunchBlendRows(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count, float *rows);
 // moves: `count` oalgpu_voice_move records (24 bytes each: voice, the getCoeffs arguments, the gain), device or pinned host memory
 void LaunchApplyMoves(hipStream_t s, const DeviceLayout &L, const HrtfStoreDev &st, const void *moves, uint32_t count, hipEvent_t evDone = nullptr);
 // Hrtf.Target handed over as the reference's parameter stage left it: coeffs = [count][128][2] (HrirArray)
@@ -439,7 +458,8 @@ struct WaveProf { unsigned long long *times; uint32_t ablate; };
 // nextRecs / nextMap: a parameter block every wavefront installs for the voices it mixed, in its epilogue (null: none; only
 // the kernels WaveKernelAppliesRecords names)
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof = nullptr,
-    hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const ParamRecord *nextRecs = nullptr, const int32_t *nextMap = nullptr);
+    hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const ParamRecord *nextRecs = nullptr, const int32_t *nextMap = nullptr,
+    const float *nextRows = nullptr);
 bool WaveKernelAppliesRecords(const DeviceLayout &L);
 // the resident launch of the HRTF hot path (OALGPU_CTX_RESIDENT): see ResidentDoor above
 bool WaveKernelHasResident(const DeviceLayout &L);

@@ -147,21 +147,25 @@ constexpr int kFusedFrames = 64;                            // output frames per
 // Every wait inside these kernels is bounded: a counter that never arrives (a launch that failed on the host's side, a voice
 // kernel that gave up) becomes an error word the host reads, not a hung GPU.  `ready` is asked until it says yes or 2 s have
 // passed (s_memrealtime: 100 MHz).
+// waited (resident contexts' measurement words, kernels.hpp kRcWait*): the wait's length in ticks is added there (null: nowhere)
 template<class F>
-__device__ __forceinline__ bool PostWait(F ready, int nap)
+__device__ __forceinline__ bool PostWait(F ready, int nap, uint32_t *waited = nullptr)
 {
     if(ready()) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = false;
     for(uint32_t spins = 0;; ++spins)
     {
         if(nap <= 4) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(8);
-        if(ready()) return true;
-        if((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > kResidentWatchdogTicks) return false;
+        if(ready()) { ok = true; break; }
+        if((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > kResidentWatchdogTicks) break;
     }
+    if(waited) __hip_atomic_fetch_add(waited, uint32_t(__builtin_amdgcn_s_memrealtime() - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
 }
-__device__ __forceinline__ bool PostWaitCounter(const uint32_t *counter, uint32_t target, int nap)
+__device__ __forceinline__ bool PostWaitCounter(const uint32_t *counter, uint32_t target, int nap, uint32_t *waited = nullptr)
 {
-    return PostWait([&]() { return int32_t(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0; }, nap);
+    return PostWait([&]() { return int32_t(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0; }, nap, waited);
 }
 // One wavefront's share of the fused post-process: wg < nch = the split of dry channel wg, else FIR block wg - nch; outTarget: what `outArrived` reads when this launch's FIR workgroups are all through.
 // MODE 1 (FUSED): the bus block was reduced by workgroups of the SAME launch (ReducePostFusedKernel): `reduced` reaches
@@ -171,26 +175,23 @@ __device__ __forceinline__ bool PostWaitCounter(const uint32_t *counter, uint32_
 // block and reads the carried accumulator: besides MODE 1's loads, everything another launch reads or overwrites while this one
 // still runs -- the output lines, the carried accumulator -- is stored written-through, and a FIR workgroup counts itself in
 // behind its stores.  The last one tells the host how far the post-process has come (`progress`, pinned).
-struct PostResident { uint32_t *postDone; uint32_t postDoneTarget; uint32_t *progress; uint32_t progressValue; uint32_t *error; };
+struct PostResident { uint32_t *postDone; uint32_t postDoneTarget; uint32_t *progress; uint32_t progressValue; uint32_t *error; uint32_t *counters; };
 template<int MODE>
 __device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t tid, uint32_t outTarget, const float *__restrict__ in, uint32_t nch,
     const SplitterState *__restrict__ spIn, SplitterState *__restrict__ spOut, const float *__restrict__ hfscales,
     const float *__restrict__ chanCoeffs, uint32_t taps, const float *__restrict__ accIn, float *__restrict__ carryOut,
     float *__restrict__ left, float *__restrict__ right, uint32_t n, float *__restrict__ xf, uint32_t *__restrict__ arrived, uint32_t epoch,
     Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived,
-    const uint32_t *__restrict__ reduced, uint32_t reducedEpoch, PostResident PR = PostResident{nullptr, 0u, nullptr, 0u, nullptr})
+    const uint32_t *__restrict__ reduced, uint32_t reducedEpoch, PostResident PR = PostResident{nullptr, 0u, nullptr, 0u, nullptr, nullptr})
 {
     constexpr bool FUSED = MODE != 0, RESID = MODE == 2;
     const uint32_t lane = tid;
-#ifdef OALGPU_EXP_POST_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     if(wg < nch)
     {   // ---- BandSplitter::processHfScale of dry channel c (PostSplitKernel)
         const uint32_t c = wg;
         if constexpr (FUSED)
         {   // the dry lines are this launch's own reduction workgroups' sums
-            if(!PostWaitCounter(reduced, reducedEpoch, 4) && PR.error && lane == 0) __hip_atomic_store(PR.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if(!PostWaitCounter(reduced, reducedEpoch, 4, (RESID && wg == 0 && lane == 0) ? PR.counters + 16u * kRcWaitRedDone : nullptr) && PR.error && lane == 0) __hip_atomic_store(PR.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll 8
             for(uint32_t k = lane; k < uint32_t(kLine); k += 64) xs[k] = (k < n) ? PostLoadCoherent(in + size_t{c} * kLine + k) : 0.0f;
         }
@@ -210,26 +211,50 @@ __device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t 
         if(lane == 0) __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... before it counts as arrived
         return;
     }
-    // ---- the decoder FIR over 64 output frames -- lane = frame, both ears in the lane, the channel's (left, right) tap pairs
-    // through the scalar cache as SGPR operands: ONE LDS read per tap and two multiply-adds, where lanes that split ears and
-    // taps read coefficient AND sample from LDS for every multiply-add (the LDS pipe is what the voice kernel beside this one
-    // keeps busy) -- and the shift (PostFirKernel + PostShiftKernel)
+    // ---- the decoder FIR over 64 output frames -- lane = frame, both ears in the lane; the channels' windows AND their (left,
+    // right) tap pairs come out of LDS: a window read per lane and a broadcast read of the pair per tap, two multiply-adds.  The
+    // taps do not depend on the update, so the first two channels' are staged BEFORE the wait for the splits (until round 5 they
+    // came through the scalar cache eight pairs at a time, each load waited for where it was used: 44 dependent scalar loads were
+    // most of what lay between the splits' arrival and the workgroup's end -- and that interval is on the post chain's critical
+    // path, which bounds the step).  Two channels at a time: windows and tap pairs of two fit the 4352 bytes the split's line
+    // buffer has anyway -- with a second array for four channels' taps (8448 bytes, seven LDS granules) the kernel no longer
+    // started beside a resident voice kernel and its reduction (round 5: the post-process of an update then was what everything
+    // else waited for).  Then the shift (PostFirKernel + PostShiftKernel).
     const uint32_t blk = wg - nch;
     const uint32_t o = blk * uint32_t(kFusedFrames) + lane;
     const int32_t base = int32_t(blk) * kFusedFrames - kHrirLen;
+    constexpr int kCoefDw = kHrirLen * 2;                        // one channel's staged tap pairs
+    constexpr int kWin = kHrirLen + kFusedFrames;
+    constexpr int kPair = 2;                                     // channels per pass
+    static_assert(sizeof(float) * (kLine + 64) >= sizeof(float) * kPair * (kWin + kCoefDw), "two windows and two channels' taps fit into the split's line buffer");
+    float (*xw4)[kWin] = reinterpret_cast<float (*)[kWin]>(xs);
+    float *cst = xs + kPair * kWin;
+    auto stageCoeffs = [&](uint32_t c0, uint32_t gc)
+    {   // (the channels' tap pairs lie 128 pairs apart in memory as in LDS: four loads in flight off one base per channel -- left
+        // to the compiler's unrolling the copy alone took the kernel from 26 to 48 registers)
+        typedef const __attribute__((address_space(1))) float *gfloatp;
+        gfloatp src = reinterpret_cast<gfloatp>((const __attribute__((address_space(1))) void*)(chanCoeffs + size_t{c0} * kCoefDw)) + lane;
+        float *dst = cst + lane;
+#pragma unroll 1
+        for(uint32_t q = 0; q < gc; ++q)
+        {
+            const float a = src[0], b = src[64], c2 = src[128], d = src[192];
+            dst[0] = a; dst[64] = b; dst[128] = c2; dst[192] = d;
+            src += kCoefDw; dst += kCoefDw;
+        }
+    };
+    stageCoeffs(0u, nch < uint32_t(kPair) ? nch : uint32_t(kPair));
     f2 accOld = {0.0f, 0.0f};
     if constexpr (!FUSED) accOld = reinterpret_cast<const f2*>(accIn)[o];           // (requested before the wait)
-    if(!PostWaitCounter(arrived, epoch, 8) && PR.error && lane == 0) __hip_atomic_store(PR.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if(!PostWaitCounter(arrived, epoch, 8, (RESID && wg == nch && lane == 0) ? PR.counters + 16u * kRcWaitSplit : nullptr) && PR.error && lane == 0) __hip_atomic_store(PR.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if constexpr (FUSED)      // (the channels have arrived, so the reduction they waited for is through: its accumulator columns)
         accOld = f2{PostLoadCoherent(accIn + 2u * o), PostLoadCoherent(accIn + 2u * o + 1u)};
-    constexpr int kWin = kHrirLen + kFusedFrames;
-    float (*xw4)[kWin] = reinterpret_cast<float (*)[kWin]>(xs);
-    static_assert(sizeof(float) * (kLine + 64) >= sizeof(float) * kPostGroup * kWin, "the FIR windows fit into the split's line buffer");
     float accL = 0.0f, accR = 0.0f;
-    for(uint32_t c0 = 0; c0 < nch; c0 += kPostGroup)
+    for(uint32_t c0 = 0; c0 < nch; c0 += kPair)
     {
-        const uint32_t gc = (nch - c0 < uint32_t(kPostGroup)) ? nch - c0 : uint32_t(kPostGroup);
+        const uint32_t gc = (nch - c0 < uint32_t(kPair)) ? nch - c0 : uint32_t(kPair);
         WaveSync();
+        if(c0) stageCoeffs(c0, gc);
         for(uint32_t c = 0; c < gc; ++c)
         {
 #pragma unroll
@@ -244,48 +269,20 @@ __device__ __forceinline__ void PostFusedBlock(float *xs, uint32_t wg, uint32_t 
         for(uint32_t c = 0; c < gc; ++c)
         {
             const float *xw = &xw4[c][kHrirLen + lane];                  // x_c[o - t] = xw[-t]
-            cf16 *co = (cf16*)(uintptr_t)(chanCoeffs + size_t{c0 + c} * kHrirLen * 2);    // eight (left, right) tap pairs per load
-            // (OALGPU_EXP_POST_PIPE: the next eight tap pairs requested while these are multiplied -- the kernel 1.5-2 us shorter
-            // beside the voice kernel, 33 registers instead of 25, and the STEP 1.2-1.9 us longer: profiles/r4/post_fir_pipe_ab.txt)
-#ifndef OALGPU_EXP_POST_PIPE
+            const f2 *cw = reinterpret_cast<const f2*>(cst + c * uint32_t(kCoefDw));
 #pragma unroll 1
-            for(uint32_t t8 = 0; t8 < taps / 8u; ++t8)
-            {
-                const f16 cc = co[t8];
-                const float *xq = xw - 8 * int32_t(t8);
+            for(uint32_t t4 = 0; t4 < taps; t4 += 4)
+            {   // (four taps in flight: the kernel stays within the 32 registers that fit beside the voice kernels' wavefronts)
+                float x[4]; f2 cc[4];
 #pragma unroll
-                for(int j = 0; j < 8; ++j)
+                for(int j = 0; j < 4; ++j) { x[j] = xw[-int32_t(t4) - j]; cc[j] = cw[t4 + uint32_t(j)]; }
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
                 {
-                    const float x = xq[-j];
-                    accL = __builtin_fmaf(cc[2 * j], x, accL);
-                    accR = __builtin_fmaf(cc[2 * j + 1], x, accR);
+                    accL = __builtin_fmaf(cc[j].x, x[j], accL);
+                    accR = __builtin_fmaf(cc[j].y, x[j], accR);
                 }
             }
-#else
-            const uint32_t nt8 = taps / 8u;                              // taps is a multiple of 16: an even number of steps
-            f16 ca = co[0];
-#pragma unroll 1
-            for(uint32_t t8 = 0; t8 < nt8; t8 += 2)
-            {
-                const f16 cb = co[t8 + 1u];
-                const float *xq = xw - 8 * int32_t(t8);
-#pragma unroll
-                for(int j = 0; j < 8; ++j)
-                {
-                    const float x = xq[-j];
-                    accL = __builtin_fmaf(ca[2 * j], x, accL);
-                    accR = __builtin_fmaf(ca[2 * j + 1], x, accR);
-                }
-                ca = co[(t8 + 2u < nt8) ? t8 + 2u : 0u];
-#pragma unroll
-                for(int j = 0; j < 8; ++j)
-                {
-                    const float x = xq[-8 - j];
-                    accL = __builtin_fmaf(cb[2 * j], x, accL);
-                    accR = __builtin_fmaf(cb[2 * j + 1], x, accR);
-                }
-            }
-#endif
         }
     }
     {   // PostShiftKernel's arithmetic: s = accumulator + channels' sum
@@ -415,7 +412,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) BusR
     const uint32_t tid = threadIdx.x;
     if(tid == 0)
     {
-        if(!PostWaitCounter(A.counters + 16u * (kRcArrive0 + A.set), A.arriveTarget, 4))
+        if(!PostWaitCounter(A.counters + 16u * (kRcArrive0 + A.set), A.arriveTarget, 4, blockIdx.x == 0 ? A.counters + 16u * kRcWaitArrive : nullptr))
             __hip_atomic_store(A.hostFlags + 16u * kRhError, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
@@ -426,7 +423,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) BusR
         if(tid == 0)
         {
             __hip_atomic_fetch_add(A.counters + 16u * kRcRedRead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if(!PostWaitCounter(A.counters + 16u * kRcPostDone, A.postDoneTarget, 4))
+            if(!PostWaitCounter(A.counters + 16u * kRcPostDone, A.postDoneTarget, 4, blockIdx.x == 0 ? A.counters + 16u * kRcWaitPost : nullptr))
                 __hip_atomic_store(A.hostFlags + 16u * kRhError, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __syncthreads();
@@ -475,7 +472,7 @@ void LaunchPostResident(hipStream_t s, float *left, float *right, const float *i
 {
     const uint32_t taps = irsize <= 16u ? 16u : ((irsize + 15u) & ~15u);
     const Tri3 P{runPower[0], runPower[1], runPower[2], runPower[3]};
-    const PostResident PR{counters + 16u * kRcPostDone, postDoneTarget, hostFlags + 16u * kRhProgress, progressValue, hostFlags + 16u * kRhError};
+    const PostResident PR{counters + 16u * kRcPostDone, postDoneTarget, hostFlags + 16u * kRhProgress, progressValue, hostFlags + 16u * kRhError, counters};
     hipExtLaunchKernelGGL(PostResidentKernel, dim3(nch + kPostFrames / kFusedFrames), dim3(64), 0, s, nullptr, evDone, 0u, in, nch, spIn, spOut, hfscales,
         chanCoeffs, taps, accIn, carryOut, left, right, n, xf, arrived, epoch, P, hostOut, hostFlag, hostSeq, counters + 16u * kRcRedDone, redDoneTarget, PR);
 }

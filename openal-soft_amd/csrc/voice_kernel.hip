@@ -155,6 +155,30 @@ void LaunchInitVoices(hipStream_t s, const DeviceLayout &L, const VoiceInitRecor
     if(count) hipLaunchKernelGGL(InitVoicesKernel, dim3(count), dim3(64), 0, s, L, recs);
 }
 
+// the weighted sum of ApplyHrtfTargetWave (kernels.hpp) into a row of the parameter block instead of the voice's filter
+__global__ void __launch_bounds__(64) BlendRowsKernel(DeviceLayout L, const ParamRecord *__restrict__ recs, float *__restrict__ rows)
+{
+    const ParamRecord &r = recs[blockIdx.x];
+    if(r.keepHrtf) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i0 = r.hrtfIdx[0], i1 = r.hrtfIdx[1], i2 = r.hrtfIdx[2], i3 = r.hrtfIdx[3];
+    const float w0 = r.hrtfW[0], w1 = r.hrtfW[1], w2 = r.hrtfW[2], w3 = r.hrtfW[3];
+    const uint32_t live = ((L.irSize + 1u) & ~1u) * 2u;
+    for(uint32_t e = lane; e < L.irStride * 2; e += 64)
+    {
+        float x = (e < 2) ? r.hrtfPass : 0.0f;
+        x = L.hrirs[size_t{i0} * (kHrirLen * 2) + e] * w0 + x;
+        x = L.hrirs[size_t{i1} * (kHrirLen * 2) + e] * w1 + x;
+        x = L.hrirs[size_t{i2} * (kHrirLen * 2) + e] * w2 + x;
+        x = L.hrirs[size_t{i3} * (kHrirLen * 2) + e] * w3 + x;
+        rows[size_t{blockIdx.x} * L.irStride * 2 + e] = (e < live) ? x : 0.0f;
+    }
+}
+void LaunchBlendRows(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count, float *rows)
+{
+    if(count) hipLaunchKernelGGL(BlendRowsKernel, dim3(count), dim3(64), 0, s, L, recs, rows);
+}
+
 void LaunchApplyParams(hipStream_t s, const DeviceLayout &L, const ParamRecord *recs, uint32_t count)
 {
     if(count) hipLaunchKernelGGL(ApplyParamsKernel, dim3(count), dim3(64), 0, s, L, recs);

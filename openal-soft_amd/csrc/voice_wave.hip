@@ -306,7 +306,8 @@ struct WaveArgsHrtf {
 // The next update's parameter block, installed by the wavefront that has just mixed the voice (the kernel's epilogue) instead
 // of by a kernel of its own between two voice kernels: ApplyRecordWave (kernels.hpp) for the kernels that carry the whole
 // DeviceLayout, the same operations on the lean argument block for the HRTF kernels without sends (`pad` holds IrSize there).
-struct NextBlock { const ParamRecord *recs; const int32_t *map; ResidentArgs res; };   // (res: the resident launch's, RES)
+struct NextBlock { const ParamRecord *recs; const int32_t *map; const float *rows; ResidentArgs res; };   // (rows: the records' blended target HRIRs,
+                                                                                                          // null: blend at install; res: the resident launch's, RES)
 
 // ---- the resident launch (RES, OALGPU_CTX_RESIDENT; the protocol: kernels.hpp ResidentDoor) ----
 // What the host writes is read with system-scope loads (they go to memory: nothing a cache holds of the door can be trusted
@@ -322,17 +323,21 @@ struct NextBlock { const ParamRecord *recs; const int32_t *map; ResidentArgs res
 // One poll loop for every wait of the resident launch: `ready` is asked until it says yes or the watchdog's time is up
 // (false: the caller flags the error and leaves -- a wait never hangs the GPU).  Short naps first, longer ones once the
 // wait has lasted.
+// waited: what the wait lasted, in s_memrealtime ticks, is added to this counter (null: nowhere)
 template<class F>
-__device__ __forceinline__ bool ResWait(F ready)
+__device__ __forceinline__ bool ResWait(F ready, uint32_t *waited = nullptr)
 {
     if(ready()) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = false;
     for(uint32_t spins = 0;; ++spins)
     {
         if(spins < 32u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(24);
-        if(ready()) return true;
-        if((spins & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t0 > kResidentWatchdogTicks) return false;
+        if(ready()) { ok = true; break; }
+        if((spins & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t0 > kResidentWatchdogTicks) break;
     }
+    if(waited) __hip_atomic_fetch_add(waited, uint32_t(__builtin_amdgcn_s_memrealtime() - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
 }
 __device__ __forceinline__ void ApplyRecordLean(const WaveArgsHrtf &L, const ParamRecord &r, uint32_t lane)
 {
@@ -374,6 +379,101 @@ __device__ __forceinline__ void ApplyRecordLean(const WaveArgsHrtf &L, const Par
 }
 __device__ __forceinline__ void ApplyNextRecord(const WaveArgsHrtf &L, const ParamRecord &r, uint32_t lane) { ApplyRecordLean(L, r, lane); }
 __device__ __forceinline__ void ApplyNextRecord(const DeviceLayout &L, const ParamRecord &r, uint32_t lane) { ApplyRecordWave(L, r, lane); }
+
+// ---- RES: ApplyRecordLean for TWO voices at once, as three rounds of loads instead of a dozen dependent ones ----
+// The resident kernel installs an update's records in front of the update, on every workgroup's critical path: record by record
+// (map entry -> record -> four HRIRs -> control line -> filter slots, each waiting for the one before, per voice) that was as long
+// as mixing a voice.  Here a wavefront reads both map entries first; then everything both installs READ -- the records' scalars,
+// the voices' control flags, the filter slots' targets and the records' blended target HRIRs, which the block carries
+// precomputed (BlendRowsKernel: the same weighted sum as ApplyHrtfTargetWave, evaluated once when the block is created) --;
+// then it stores.  Same values as ApplyRecordLean, so the same bits as ApplyParamsKernel.
+struct RecScalars {
+    uint32_t step; int32_t rsKind; uint32_t rsM, rsL; float rsSf; uint32_t rsFilterOffset, flags, keepHrtf, delay0, delay1; float gain;
+    float lp[5], hp[5];
+};
+__device__ __forceinline__ RecScalars LoadRecScalars(const ParamRecord &r)
+{
+    RecScalars o;
+    o.step = r.step; o.rsKind = r.rsKind; o.rsM = r.rsM; o.rsL = r.rsL; o.rsSf = r.rsSf; o.rsFilterOffset = r.rsFilterOffset;
+    o.flags = r.flags; o.keepHrtf = r.keepHrtf; o.delay0 = r.hrtfDelay[0]; o.delay1 = r.hrtfDelay[1]; o.gain = r.hrtfGain;
+#pragma unroll
+    for(int k = 0; k < 5; ++k) { o.lp[k] = r.dirLp[k]; o.hp[k] = r.dirHp[k]; }
+    return o;
+}
+__device__ __forceinline__ void InstallPair(const WaveArgsHrtf &L, const int32_t *__restrict__ map, const ParamRecord *__restrict__ recs,
+    const float *__restrict__ rows, uint32_t vA, uint32_t vB, bool hasB, uint32_t lane)
+{
+    // ---- round 1: which records
+    const int32_t mA = map[vA], mB = map[hasB ? vB : vA];
+    const int32_t riA = __builtin_amdgcn_readfirstlane(mA), riBr = __builtin_amdgcn_readfirstlane(mB);
+    const int32_t riB = hasB ? riBr : -1;
+    if(riA < 0 && riB < 0) return;
+    const bool doA = riA >= 0, doB = riB >= 0;
+    const uint32_t irStride = L.irStride;
+    // ---- round 2: everything the installs read
+    RecScalars sA{}, sB{};
+    f2 rowA = {0.0f, 0.0f}, rowB = {0.0f, 0.0f};
+    uint32_t flA = 0u, flB = 0u;
+    if(doA)
+    {
+        sA = LoadRecScalars(recs[riA]);
+        if(lane < irStride) rowA = reinterpret_cast<const f2*>(rows + size_t{uint32_t(riA)} * irStride * 2u)[lane];
+        if(lane == 0) flA = L.ctl[vA].flags;
+    }
+    if(doB)
+    {
+        sB = LoadRecScalars(recs[riB]);
+        if(lane < irStride) rowB = reinterpret_cast<const f2*>(rows + size_t{uint32_t(riB)} * irStride * 2u)[lane];
+        if(lane == 0) flB = L.ctl[vB].flags;
+    }
+    // the direct filter pairs: lanes 1, 2 = voice A's (low-pass, high-pass), lanes 3, 4 = voice B's
+    const bool fLane = lane >= 1u && lane <= 4u;
+    const bool fB = lane >= 3u, fHp = ((lane - 1u) & 1u) != 0u;
+    const bool fOn = fLane && (fB ? doB : doA);
+    BiquadState *fp = &L.dfilt[size_t{fB ? vB : vA} * 2u + (fHp ? 1u : 0u)].f;
+    float tb0 = 0.0f, tb1 = 0.0f, tb2 = 0.0f, ta1 = 0.0f, ta2 = 0.0f;
+    int32_t fcounter = 0;
+    if(fOn) { tb0 = fp->tb0; tb1 = fp->tb1; tb2 = fp->tb2; ta1 = fp->ta1; ta2 = fp->ta2; fcounter = fp->counter; }
+    // ---- the stores
+    auto installCtl = [&](uint32_t v, const RecScalars &r, uint32_t flagsOld, f2 row)
+    {
+        VoiceCtl &ctl = L.ctl[v];
+        if(lane == 0)
+        {
+            ctl.step = r.step;
+            ctl.rsKind = r.rsKind; ctl.rsM = r.rsM; ctl.rsL = r.rsL; ctl.rsSf = r.rsSf;
+            ctl.rsFilterOffset = r.rsFilterOffset;
+            const uint32_t keep = flagsOld & (kFlagFading | kFlagHasHrtf | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue
+                | (r.keepHrtf ? uint32_t(kFlagHrtfDirty) : 0u));
+            ctl.flags = keep | (r.flags & ~(kFlagFading | kFlagHasHrtf | kFlagHrtfDirty | kFlagAmbiScale | kFlagNfc | kFlagDelayed | kFlagQueue))
+                | kFlagHasHrtf | (r.keepHrtf ? 0u : uint32_t(kFlagHrtfDirty));
+            for(int i = 0; i < 6; ++i) ctl.sendSlot[i] = -1;
+            if(!r.keepHrtf)
+            {
+                ctl.hrtfTgtDelay[0] = r.delay0; ctl.hrtfTgtDelay[1] = r.delay1;
+                ctl.hrtfTgtGain = r.gain;
+            }
+        }
+        if(!r.keepHrtf && lane < irStride) reinterpret_cast<f2*>(L.hrtfTgt + size_t{v} * irStride * 2u)[lane] = row;
+    };
+    if(doA) installCtl(vA, sA, flA, rowA);
+    if(doB) installCtl(vB, sB, flB, rowB);
+    if(fOn)
+    {   // BiquadSetTarget (dev_mix.hpp) on the values read above
+        float c[5];
+#pragma unroll
+        for(int k = 0; k < 5; ++k) c[k] = fB ? (fHp ? sB.hp[k] : sB.lp[k]) : (fHp ? sA.hp[k] : sA.lp[k]);
+        bool changed = !(fabsf(c[0] - tb0) <= 0.015625f);
+        changed |= !(fabsf(c[1] - tb1) <= 0.015625f);
+        changed |= !(fabsf(c[2] - tb2) <= 0.015625f);
+        changed |= !(fabsf(c[3] - ta1) <= 0.015625f);
+        changed |= !(fabsf(c[4] - ta2) <= 0.015625f);
+        fp->tb0 = c[0]; fp->tb1 = c[1]; fp->tb2 = c[2]; fp->ta1 = c[3]; fp->ta2 = c[4];
+        const bool snap = changed ? !(fcounter >= 0) : (fcounter <= 0);
+        if(changed && fcounter >= 0) fp->counter = 256;
+        if(snap) { fp->counter = 0; fp->b0 = c[0]; fp->b1 = c[1]; fp->b2 = c[2]; fp->a1 = c[3]; fp->a2 = c[4]; }
+    }
+}
 
 // ACCL > 0: the context's mix lines (dry lines and / or the slots' wet lines, <= ACCL of them) accumulate in the
 // wavefront's registers (MixRowAcc) instead of leaving stream rows; such kernels run the register-lean resampler.
@@ -470,37 +570,56 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         // that every workgroup takes it for the same update; the watchdog only turns a host that went away into an error.
         if(t == 0)
         {
+            const unsigned long long tTop = __builtin_amdgcn_s_memrealtime();
             uint32_t go = 0u, fault = 0u;
-            unsigned long long recs = 0ull, map = 0ull;
+            unsigned long long recs = 0ull, map = 0ull, rowsP = 0ull;
             uint32_t smp = 0u;
             if(upd != RA.endSeq)
             {
                 const ResidentDoor *door = RA.door;
-                uint32_t leave = 0u;
-                const bool ok = ResWait([&]() {
-                    if(int32_t(ResLoadSys(&door->seq) - upd) > 0) return true;
-                    leave = int32_t(ResLoadSys(&door->exitSeq) - upd) <= 0 ? 1u : 0u;
-                    return leave != 0u;
-                });
-                fault = ok ? 0u : 1u;
-                go = (ok && !leave) ? 1u : 0u;
-                if(go && int32_t(upd - kResidentSets) >= 0)
+                const uint32_t *exitp = &door->exitSeq[RA.launchId & 3u];
+                const uint32_t *rr = RA.counters + 16u * kRcRedRead;
+                const bool needRed = int32_t(upd - kResidentSets) >= 0;
+                const uint32_t want = (upd - kResidentSets + 1u) * RA.redPerUpdate;
+                // one round of loads per look: the word to leave, the doorbell and the reduction's counter are in flight together
+                unsigned long long t0 = 0ull;
+                uint32_t waitedFor = 0u;                     // 1: the doorbell, 2: the reduction
+                for(uint32_t spins = 0;; ++spins)
                 {
-                    const uint32_t want = (upd - kResidentSets + 1u) * RA.redPerUpdate;
-                    const uint32_t *rr = RA.counters + 16u * kRcRedRead;
-                    if(!ResWait([&]() { return int32_t(ResLoadDev(rr) - want) >= 0; })) { fault = 1u; go = 0u; }
+                    const uint32_t ex = ResLoadSys(exitp), sq = ResLoadSys(&door->seq), rd = needRed ? ResLoadDev(rr) : want;
+                    // (the word to leave first: a parked launch ends in front of the update the NEXT launch is being rung for)
+                    if(int32_t(ex - upd) <= 0) break;
+                    const bool rung = int32_t(sq - upd) > 0, redOk = int32_t(rd - want) >= 0;
+                    if(rung && redOk) { go = 1u; break; }
+                    if(spins == 0u) { t0 = __builtin_amdgcn_s_memrealtime(); waitedFor = rung ? 2u : 1u; }
+                    else if((spins & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t0 > kResidentWatchdogTicks)
+                    {
+                        fault = 1u;
+                        uint32_t *fi = RA.hostFlags + 16u * kRhFault;
+                        fi[0] = upd; fi[1] = sq; fi[2] = ex; fi[3] = rd; fi[4] = want; fi[5] = group; fi[6] = RA.launchId;
+                        fi[7] = uint32_t(__builtin_amdgcn_s_memrealtime() - t0);
+                        break;
+                    }
+                    if(spins < 32u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(24);
                 }
+                if(waitedFor && (group & 127u) == 0u)
+                    __hip_atomic_fetch_add(RA.counters + 16u * (waitedFor == 1u ? kRcWaitDoor : kRcWaitRed), uint32_t(__builtin_amdgcn_s_memrealtime() - t0),
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if(go)
                 {
                     const ResidentSlot *sl = &door->slot[upd % kResidentSlots];
-                    recs = ResLoadSys(&sl->recs); map = ResLoadSys(&sl->map); smp = ResLoadSys(&sl->samples);
+                    recs = ResLoadSys(&sl->recs); map = ResLoadSys(&sl->map); rowsP = ResLoadSys(&sl->rows); smp = ResLoadSys(&sl->samples);
                 }
             }
             if(fault) __hip_atomic_store(RA.hostFlags + 16u * kRhError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if((group & 127u) == 0u)       // (every 128th workgroup keeps the books: 32-bit sums of ticks over all of them wrap within seconds)
+                __hip_atomic_fetch_add(RA.counters + 16u * kRcTop, uint32_t(__builtin_amdgcn_s_memrealtime() - tTop), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sm.res[0] = go; sm.res[1] = smp;
             sm.res[2] = uint32_t(recs); sm.res[3] = uint32_t(recs >> 32); sm.res[4] = uint32_t(map); sm.res[5] = uint32_t(map >> 32);
+            sm.res[8] = uint32_t(rowsP); sm.res[9] = uint32_t(rowsP >> 32);
         }
         __syncthreads();
+        const unsigned long long tSeen = __builtin_amdgcn_s_memrealtime();
         if(__builtin_amdgcn_readfirstlane(sm.res[0]) == 0u) break;
         N = __builtin_amdgcn_readfirstlane(sm.res[1]);
         const unsigned long long recsU = (uint64_t{uint32_t(__builtin_amdgcn_readfirstlane(sm.res[3]))} << 32) | uint32_t(__builtin_amdgcn_readfirstlane(sm.res[2]));
@@ -511,12 +630,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         {
             const int32_t *map = reinterpret_cast<const int32_t*>(mapU);
             const ParamRecord *recs = reinterpret_cast<const ParamRecord*>(recsU);
-            for(uint32_t j = 0; j < vCount; ++j)
-            {
-                const uint32_t v = vBegin + 2u * j;
-                const int32_t ri = __builtin_amdgcn_readfirstlane(map[v]);
-                if(ri >= 0) ApplyRecordLean(L, recs[ri], lane0);
-            }
+            const unsigned long long rowsU = (uint64_t{uint32_t(__builtin_amdgcn_readfirstlane(sm.res[9]))} << 32) | uint32_t(__builtin_amdgcn_readfirstlane(sm.res[8]));
+            const float *rows = reinterpret_cast<const float*>(rowsU);
+            for(uint32_t j = 0; j < vCount; j += 2u)
+                InstallPair(L, map, recs, rows, vBegin + 2u * j, vBegin + 2u * j + 2u, j + 1u < vCount, lane0);
         }
         // What the update reads through the scalar cache -- the voices' control lines -- was written with vector stores, by this
         // wavefront and (the key voice's head) by wavefront 0: the stores are in L2 before the barrier, the scalar cache forgets
@@ -525,6 +642,13 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if(t == 0)
+        {
+            const unsigned long long tIn = __builtin_amdgcn_s_memrealtime();
+            if((group & 127u) == 0u)
+                __hip_atomic_fetch_add(RA.counters + 16u * kRcInstall, uint32_t(tIn - tSeen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm.res[6] = uint32_t(tIn);
+        }
     }
     // Voices are processed in passes; pass 0 only requests the first voice's source window and
     // stages the workgroup's resampler rows.  The request for the NEXT voice's window sits at one
@@ -1541,6 +1665,17 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     if(!RES && next.map)
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        bool done = false;
+        if constexpr (std::is_same<LT, WaveArgsHrtf>::value)
+        {   // the block carries its records' blended HRIRs: two voices per round of loads (InstallPair)
+            if(next.rows)
+            {
+                for(uint32_t j = 0; j < vCount; j += 2u)
+                    InstallPair(L, next.map, next.recs, next.rows, vBegin + 2u * j, vBegin + 2u * j + 2u, j + 1u < vCount, lane0);
+                done = true;
+            }
+        }
+        if(!done)
         for(uint32_t j = 0; j < vCount; ++j)
         {
             const uint32_t v = vBegin + 2u * j;
@@ -1554,7 +1689,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         // before the workgroup counts as arrived for this update; then on to the next one
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if(t == 0) __hip_atomic_fetch_add(next.res.counters + 16u * (kRcArrive0 + upd % kResidentSets), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(t == 0)
+        {
+            __hip_atomic_fetch_add(next.res.counters + 16u * (kRcArrive0 + upd % kResidentSets), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if((group & 127u) == 0u)
+                __hip_atomic_fetch_add(next.res.counters + 16u * kRcBusy, uint32_t(__builtin_amdgcn_s_memrealtime()) - sm.res[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         ++upd;
     }
     }
@@ -1606,9 +1746,9 @@ uint32_t WaveKernelGroups(const DeviceLayout &L)
 bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.hrtf != 0; }
 
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
-    const ParamRecord *nextRecs, const int32_t *nextMap)
+    const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)
 {
-    const NextBlock next{nextRecs, L.hrtf ? nextMap : nullptr, ResidentArgs{}};
+    const NextBlock next{nextRecs, L.hrtf ? nextMap : nullptr, L.hrtf ? nextRows : nullptr, ResidentArgs{}};
     const uint32_t groups = WaveKernelGroups(L);
     const bool sends = L.numSends != 0;
     const dim3 grid(groups), block(kWThreads);

@@ -17,7 +17,7 @@ bool WaveKernelHasResident(const DeviceLayout &L)
 
 hipError_t LaunchVoiceWaveResident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop)
 {
-    const NextBlock next{nullptr, nullptr, args};
+    const NextBlock next{nullptr, nullptr, nullptr, args};
     const WaveProf none{nullptr, 0u};
     hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, false, WaveArgsHrtf, 0, true>), dim3(WaveKernelGroups(L)), dim3(kWThreads), 0, s,
         evStart, evStop, 0u, WaveArgsHrtf{L}, 0u, none, next);

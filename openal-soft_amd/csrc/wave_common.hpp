@@ -115,7 +115,7 @@ struct WgLds {
     f2 tabP[kPairs * 32];                               //                    = phd[2p], phd[2p+1]
     uint32_t tabKey, tabM, tabL;
     uint32_t pad;
-    uint32_t res[8];                                    // RES (voice_wave.hip): what thread 0 learned about the update -- go, samples, records, map
+    uint32_t res[12];                                   // RES (voice_wave.hip): what thread 0 learned about the update -- go, samples, records, map, rows
 };
 
 // ---- source window ----------------------------------------------------------------------------

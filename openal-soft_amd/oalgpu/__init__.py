@@ -657,11 +657,22 @@ class Scene:
             _fields_ = [("enabled", C.c_int32), ("failed", C.c_int32), ("running", C.c_int32), ("door_in_device_memory", C.c_int32),
                         ("launches", C.c_uint32), ("updates", C.c_uint32), ("parks", C.c_uint32), ("timed_launches", C.c_uint32),
                         ("timed_updates", C.c_uint64), ("timed_kernel_ms", C.c_double),
-                        ("max_updates_per_launch", C.c_uint32), ("pad", C.c_uint32)]
+                        ("max_updates_per_launch", C.c_uint32), ("pad", C.c_uint32),
+                        ("wait_door_us", C.c_double), ("wait_reduction_us", C.c_double), ("wait_arrival_us", C.c_double),
+                        ("wait_post_us", C.c_double), ("wait_reduced_us", C.c_double), ("wait_split_us", C.c_double),
+                        ("install_us", C.c_double), ("busy_us", C.c_double), ("top_us", C.c_double)]
         info = Info()
         lib.oalgpu_resident_stats.argtypes = [C.c_void_p, C.POINTER(Info)]
         check(lib.oalgpu_resident_stats(self.h, C.byref(info)), "oalgpu_resident_stats")
         return {k: getattr(info, k) for k, _ in Info._fields_ if k != "pad"}
+
+    def resident_set_short_run(self, updates):
+        lib.oalgpu_resident_set_short_run.argtypes = [C.c_void_p, C.c_uint32]
+        check(lib.oalgpu_resident_set_short_run(self.h, updates), "oalgpu_resident_set_short_run")
+
+    def resident_set_timing(self, on):
+        lib.oalgpu_resident_set_timing.argtypes = [C.c_void_p, C.c_int]
+        check(lib.oalgpu_resident_set_timing(self.h, 1 if on else 0), "oalgpu_resident_set_timing")
 
     def resident_set_max_updates(self, n):
         lib.oalgpu_resident_set_max_updates.argtypes = [C.c_void_p, C.c_uint32]

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 V = 4096
 UPDATES = 56
-CHECK = (0, 1, 2, 7, 8, 9, 23, 40, 55)
+CHECK = (0, 1, 2, 7, 9, 10, 23, 40, 55)
 SIZES = {5: 600, 17: 257, 30: 1000}          # updates shorter than a full line
 pytestmark = pytest.mark.gpu
 
@@ -51,6 +51,8 @@ def test_resident_updates_equal_launched_updates(synth_mhr):
     # ---- the resident scene first, alone: another context's entry points would park its kernel every time
     res, rblocks = _build(oalgpu, synth, bench, rapi, mhr, UPDATES)
     res.resident_set_max_updates(9)                     # launches end by themselves every nine updates
+    res.resident_set_timing(True)
+    res.resident_set_short_run(0)                       # (the reads below keep the launches short: no falling back)
     got = {}
     for k in range(UPDATES):
         res.apply_block(rblocks[k])
@@ -101,6 +103,7 @@ def test_resident_outputs_through_the_ring(synth_mhr):
         sc, blocks = _build(oalgpu, synth, bench, api, mhr, updates)
         got, tickets = [], []
         if mode == "resident":
+            sc.resident_set_short_run(0)
             for k in range(updates):
                 sc.apply_block(blocks[k])
                 sc.mix(1024, post_process=True)
@@ -164,7 +167,7 @@ def test_other_entry_points_park_the_resident_kernel(synth_mhr):
         got.append(sc.hrtf_accum().copy())
         if mode == "resident":
             info = sc.resident_stats()
-            # (launches that keep covering fewer than two updates send the context to the launched path for a while)
+            # (launches that keep being parked early send the context to the launched path for a while)
             assert info["failed"] == 0 and 3 <= info["updates"] <= updates and info["parks"] >= 3, info
         outs[mode] = got
         sc.close(); other.close()
