@@ -263,6 +263,15 @@ int oalgpu_hrtf_build_direct_host(const void *mhr, size_t size, uint32_t device_
  * (>= 0) or a negative error. */
 int oalgpu_buffer_register(oalgpu_context *ctx, const void *data, int fmt_type,
     uint32_t frame_step, uint32_t sample_len, uint32_t loop_start, uint32_t loop_end);
+/* alDeleteBuffers / a buffer's storage replaced (core/buffer_storage.h:47-77: the storage is freed and reused; VoiceBufferItems
+ * are reused too, core/voice.h:84-98): the host gives the handle up.  The HBM copy is freed, and the handle handed out again by a
+ * later registration, once nothing refers to it: no voice slot that was initialised on it -- a slot lets go when it is
+ * initialised again or set to OALGPU_VOICE_STOPPED --, no queue link of a live buffer (oalgpu_buffer_queue_link), no channel
+ * view (oalgpu_buffer_channel_view).  Until then the voices that play it keep playing it; the handle can no longer be named
+ * in oalgpu_voice_init / oalgpu_buffer_queue_link / oalgpu_buffer_channel_view.  max_buffers bounds the LIVE handles. */
+int oalgpu_buffer_release(oalgpu_context *ctx, int buffer);
+/* (tests) whether the handle is live, whether its release is waiting for references to go, and how many hold it */
+int oalgpu_buffer_info(oalgpu_context *ctx, int buffer, int32_t *live, int32_t *release_pending, uint32_t *references);
 
 /* One channel of an interleaved multi-channel buffer as a buffer of its own (same frames and
  * loop points, no copy): multi-channel sources -- B-Format in particular -- are mixed as one
@@ -358,6 +367,10 @@ int oalgpu_buffer_queue_link(oalgpu_context *ctx, int buffer, int next_buffer);
 int oalgpu_voice_init_queue(oalgpu_context *ctx, uint32_t voice, int first_buffer, int looping, int32_t position,
     uint32_t position_frac);
 int oalgpu_voice_queue_state(oalgpu_context *ctx, uint32_t voice, int32_t *current_buffer, uint32_t *buffers_done);
+/* alSourceUnqueueBuffers: the first `count` buffers of the voice's queue -- processed ones: checked against the buffers_done the
+ * host has read back (oalgpu_voice_queue_state, oalgpu_voices_readback) -- leave the queue; the voice's hold moves to the buffer
+ * behind them, so that a released buffer among them is freed while the source plays on. */
+int oalgpu_voice_queue_unqueue(oalgpu_context *ctx, uint32_t voice, uint32_t count);
 
 /* ---- callback sources (AL_SOFT_callback_buffer) ----------------------------------------------------------------
  * BufferStorage::mCallback / VoiceBufferItem::mCallback (core/buffer_storage.h:48, core/voice.h:85): the source's
@@ -553,6 +566,8 @@ typedef struct oalgpu_voice_brief {
     uint32_t position_frac;
     int32_t  has_buffer;
     int32_t  fading;
+    int32_t  current_buffer;      /* the handle of mCurrentBuffer (-1: none): where a streaming source's queue has got to */
+    uint32_t buffers_done;        /* streaming sources: buffers played through since the voice was initialised */
 } oalgpu_voice_brief;
 int oalgpu_voices_readback(oalgpu_context *ctx, const uint32_t *voices, size_t count, oalgpu_voice_brief *out);
 

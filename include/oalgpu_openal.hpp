@@ -25,10 +25,14 @@
  *      owns the HRTF accumulator's tail.  The state the rest of the reference looks at (positions, play state, the
  *      end of a source) is read back.
  *
- * Scope: mono, static (VoiceFlag::IsStatic) sources of every PCM sample type and of both ADPCM types, on a device in
- * RenderMode::Normal (ambisonic dry lines) or RenderMode::Hrtf, with up to MaxSendCount auxiliary sends into the
- * context's active effect slots.  Anything else (multi-channel or streaming sources, direct channels, delayed
- * starts) makes mix() report an error and the caller runs the reference's own loop for that update.
+ * Scope: static sources (VoiceFlag::IsStatic) of any channel count -- a channel of interleaved frames is one device voice,
+ * Voice::mix's per-ChannelData loop (voice.cpp:1058-1091) -- and mono streaming sources (buffer queues that grow while
+ * they play, voice.cpp:563-594, :1182-1218), of every PCM sample type and both ADPCM types, with delayed starts
+ * (voice.cpp:1023-1046), on a device in RenderMode::Normal (ambisonic dry lines) or RenderMode::Hrtf, with up to MaxSendCount
+ * auxiliary sends into the context's active effect slots.  Buffers are registered when a voice first starts on them and given
+ * up when their storage changes (oalgpu_buffer_release).  What is left -- callback, B-Format, UHJ and near-field-compensated
+ * sources, direct channels -- makes mix() report an error BEFORE anything on the device changed, and the caller runs the
+ * reference's own loop for that update; the device context then starts every voice over from its Voice.
  *
  * BiquadInterpFilter keeps its target coefficients private; the shelf gains are recovered from them
  * (ShelfGainAt), so the including translation unit must see them -- upstream that is one friend declaration in
@@ -38,7 +42,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <chrono>
 #include <map>
+#include <unordered_set>
 #include <span>
 #include <string>
 #include <utility>
@@ -116,38 +122,83 @@ public:
 
     /* Voice::mix's place in the voice loop: returns true when this call completed the update's batch and the
      * batch was mixed (false: more voices to come, or an error -- then error() != 0 and the caller runs the CPU
-     * loop over batch() for that update). */
-    bool mix(Voice *voice, Voice::State vstate, ContextBase *context, DeviceBase &dev, unsigned samplesToDo)
+     * loop over batch() for that update).  deviceTime: Voice::mix's own argument (a delayed start,
+     * voice.cpp:1023-1046, is measured against it). */
+    bool mix(Voice *voice, Voice::State vstate, ContextBase *context, DeviceBase &dev, std::chrono::nanoseconds deviceTime,
+        unsigned samplesToDo)
     {
+        auto const voices = context->getVoicesSpanAcquired();
         if(mSeen == 0)
         {
             mExpected = 0;
-            for(Voice *v : context->getVoicesSpanAcquired())
+            for(Voice *v : voices)
             {
                 auto const st = v->mPlayState.load(std::memory_order_acquire);
                 if(st != Voice::Stopped && st != Voice::Pending) ++mExpected;
             }
-            mBatch.clear();
+            mBatch.clear(); mBatchIndex.clear();
+            mCursor = 0;
         }
+        /* the voice loop walks the context's voices in order (alu.cpp:2201-2206): so does the cursor, and a voice's place in
+         * that array is where its entry lives (voices are pooled; the array only grows, core/context.h:159-160) */
+        while(mCursor < voices.size() && voices[mCursor] != voice) ++mCursor;
+        if(mCursor == voices.size()) { mSeen = 0; failText(OALGPU_ERR_INVALID, "oalgpu_openal: a voice outside the context's voice array"); return false; }
         mBatch.emplace_back(voice, vstate);
+        mBatchIndex.push_back(uint32_t(mCursor++));
         if(++mSeen != mExpected) return false;
         mSeen = 0;
-        return flush(context, dev, samplesToDo) == 0;
+        const int rc = flush(context, dev, deviceTime, samplesToDo);
+        mChanged.clear();
+        if(rc != 0) mResync = true;         /* the caller mixes this update on the CPU: what the device context holds is stale then */
+        return rc == 0;
     }
     bool batchComplete() const { return mSeen == 0; }
     void reset() { mSeen = 0; }                     /* a new update begins (DeviceBase::renderSamples) */
     const std::vector<std::pair<Voice*, Voice::State>> &batch() const { return mBatch; }
-    size_t liveVoices() const { return mVoices.size(); }
+    size_t liveVoices() const { size_t n{0}; for(auto const &e : mEntries) n += e.live ? 1u : 0u; return n; }
+    size_t liveBuffers() const { return mBuffers.size(); }
+
+    /* ---- two optional hooks for the maintainer's side of the seam ----
+     * CalcSourceParams (alc/alu.cpp:2012-2031) knows which voices it recomputed: with one call at its end the update hands
+     * over exactly those voices' parameters instead of comparing every voice's (a voice's Hrtf.Target alone is 1 KB).
+     * Without the hook (trackChanges(false), the default) every voice is compared. */
+    void trackChanges(bool on) { mTrack = on; }
+    void noteParamsChanged(const Voice *voice) { mChanged.insert(voice); }
+    /* alDeleteBuffers / alBufferData on a buffer the mixer has seen (the storage is freed and the item reused,
+     * core/buffer_storage.h:47-77, core/voice.h:84-98): its HBM copy is given up; without the hook a changed item is noticed
+     * the next time a voice starts on it (the key below) */
+    void forgetBuffer(const VoiceBufferItem *item)
+    {
+        auto it = mBuffers.find(item);
+        if(it == mBuffers.end() || !mGpu) return;
+        releaseEntry(it->second);
+        mBuffers.erase(it);
+    }
 
 private:
-    struct Entry {
+    /* what a registered copy was made of: an item whose storage was replaced no longer matches */
+    struct BufferKey {
+        const void *data{nullptr}; size_t kind{0}; unsigned frameStep{0}, sampleLen{0}, loopStart{0}, loopEnd{0}, blockAlign{0};
+        bool operator==(const BufferKey &o) const
+        { return data == o.data && kind == o.kind && frameStep == o.frameStep && sampleLen == o.sampleLen && loopStart == o.loopStart
+            && loopEnd == o.loopEnd && blockAlign == o.blockAlign; }
+    };
+    struct BufferEntry { BufferKey key; int handle{-1}; std::vector<int> views; };
+    struct Chan {
         uint32_t index{0};
-        int lastState{int(Voice::Playing)};
-        unsigned sourceId{0};
         bool haveParams{false};
         oalgpu_voice_params params{};
         bool haveTarget{false};
         HrtfFilter target{};                        /* the Hrtf.Target the device context was last given */
+    };
+    struct Entry {
+        bool live{false};
+        int lastState{int(Voice::Playing)};
+        unsigned sourceId{0};
+        std::vector<Chan> chans;                    /* one device voice per mixed channel (Voice::mix's ChannelData loop) */
+        bool queue{false};                          /* a streaming source: the items it has been linked through, in order */
+        std::vector<std::pair<const VoiceBufferItem*, int>> chain;
+        uint32_t doneSeen{0};
     };
 
     int fail(int rc, const char *what)
@@ -205,23 +256,55 @@ private:
         return 0;
     }
 
-    /* al::Buffer storage behind a VoiceBufferItem, registered once (InitVoice, al/source.cpp:639-670) */
-    int bufferHandle(const Voice *voice, const VoiceBufferItem *item)
+    void releaseEntry(BufferEntry &be)
     {
-        auto hb = mBufferHandle.find(item);
-        if(hb != mBufferHandle.end()) return hb->second;
+        for(int v : be.views) if(v >= 0) (void)oalgpu_buffer_release(mGpu, v);
+        if(be.handle >= 0) (void)oalgpu_buffer_release(mGpu, be.handle);
+        be.views.clear(); be.handle = -1;
+    }
+
+    /* al::Buffer storage behind a VoiceBufferItem (InitVoice, al/source.cpp:639-670): registered when a voice first starts on
+     * it; an item whose storage, length, format or loop points changed since -- a buffer deleted and another allocated at the
+     * same address, alBufferData on it -- gives its old copy up (the library frees it when the last voice playing it lets go)
+     * and is registered anew */
+    BufferEntry *bufferEntry(const Voice *voice, const VoiceBufferItem *item)
+    {
+        BufferKey key;
+        key.kind = item->mSamples.index();
+        key.data = std::visit([](auto const &s) -> const void* { return s.data(); }, item->mSamples);
+        key.frameStep = voice->mFrameStep; key.sampleLen = item->mSampleLen; key.loopStart = item->mLoopStart; key.loopEnd = item->mLoopEnd;
+        key.blockAlign = item->mBlockAlign;
+        auto hb = mBuffers.find(item);
+        if(hb != mBuffers.end())
+        {
+            if(hb->second.key == key) return &hb->second;
+            releaseEntry(hb->second);
+            mBuffers.erase(hb);
+        }
         /* SampleVariant (core/buffer_storage.h:35-43) and oalgpu_fmt_type list the PCM types in the same order */
-        const size_t kind = item->mSamples.index();
-        const void *data = std::visit([](auto const &s) -> const void* { return s.data(); }, item->mSamples);
         int h;
-        if(kind <= size_t(OALGPU_FMT_ALAW))
-            h = oalgpu_buffer_register(mGpu, data, int(kind), voice->mFrameStep, item->mSampleLen, item->mLoopStart, item->mLoopEnd);
+        if(key.kind <= size_t(OALGPU_FMT_ALAW))
+            h = oalgpu_buffer_register(mGpu, key.data, int(key.kind), key.frameStep, key.sampleLen, key.loopStart, key.loopEnd);
         else
-            h = oalgpu_buffer_register_adpcm(mGpu, data, kind == 7 ? OALGPU_ADPCM_IMA4 : OALGPU_ADPCM_MS, voice->mFrameStep,
-                item->mBlockAlign, item->mSampleLen, item->mLoopStart, item->mLoopEnd);
-        if(h < 0) return fail(h, "oalgpu_buffer_register");
-        mBufferHandle.emplace(item, h);
-        return h;
+            h = oalgpu_buffer_register_adpcm(mGpu, key.data, key.kind == 7 ? OALGPU_ADPCM_IMA4 : OALGPU_ADPCM_MS, key.frameStep,
+                key.blockAlign, key.sampleLen, key.loopStart, key.loopEnd);
+        if(h < 0) { fail(h, "oalgpu_buffer_register"); return nullptr; }
+        BufferEntry be; be.key = key; be.handle = h;
+        return &mBuffers.emplace(item, std::move(be)).first->second;
+    }
+    /* the buffer a channel's device voice reads: the item's copy itself (mono data, or a mono source whose samples feed both of
+     * its channels: mDuplicateMono, voice.cpp:1058-1059), or one channel of interleaved frames */
+    int channelBuffer(BufferEntry &be, unsigned channel, bool wholeBuffer)
+    {
+        if(wholeBuffer) return be.handle;
+        if(be.views.size() <= channel) be.views.resize(channel + 1u, -1);
+        if(be.views[channel] < 0)
+        {
+            const int v = oalgpu_buffer_channel_view(mGpu, be.handle, channel);
+            if(v < 0) return fail(v, "oalgpu_buffer_channel_view");
+            be.views[channel] = v;
+        }
+        return be.views[channel];
     }
 
     int slotOf(std::span<EffectSlotBase*const> auxslots, std::span<FloatBufferLine> target) const
@@ -252,33 +335,97 @@ private:
         }
     }
 
-    int flush(ContextBase *context, DeviceBase &dev, unsigned samplesToDo)
+    void dropEntry(Entry &e)
+    {
+        for(Chan &ch : e.chans)
+        {   /* the device voice lets go of its buffer (a released one is freed then) and the slot goes back */
+            (void)oalgpu_voice_set_state(mGpu, ch.index, OALGPU_VOICE_STOPPED);
+            mFreeIndex.push_back(ch.index);
+        }
+        e = Entry{};
+    }
+
+    /* a streaming source's queue (VoiceBufferItem::mNext): items the voice has not been linked through yet are registered
+     * and linked behind the last one (alSourceQueueBuffers appends while the source plays) */
+    int extendChain(const Voice *voice, Entry &e)
+    {
+        const VoiceBufferItem *last = e.chain.back().first;
+        while(const VoiceBufferItem *next = last->mNext.load(std::memory_order_acquire))
+        {
+            BufferEntry *be = bufferEntry(voice, next);
+            if(!be) return mError;
+            if(int rc = oalgpu_buffer_queue_link(mGpu, e.chain.back().second, be->handle)) return fail(rc, "oalgpu_buffer_queue_link");
+            e.chain.emplace_back(next, be->handle);
+            last = next;
+        }
+        return 0;
+    }
+
+    int flush(ContextBase *context, DeviceBase &dev, std::chrono::nanoseconds deviceTime, unsigned samplesToDo)
     {
         if(!mGpu) { if(int rc = createContext(context, dev)) return rc; }
         auto const auxspan = std::span{*context->mActiveAuxSlots.load(std::memory_order_acquire)};
         auto const auxslots = auxspan.first(auxspan.size() >> 1);
         if(dev.NumAuxSends && auxslots.size() > mNumSlots)
             return failText(OALGPU_ERR_CAPACITY, "oalgpu_openal: more active effect slots than the device context was created for");
+        if(mResync)
+        {   /* an update went to the CPU loop: the voices moved on there; every entry starts over from its Voice */
+            for(Entry &e : mEntries) if(e.live) dropEntry(e);
+            mResync = false;
+        }
+        if(mEntries.size() < context->getVoicesSpanAcquired().size()) mEntries.resize(context->getVoicesSpanAcquired().size());
+
+        /* ---- pass 1: what the library cannot mix sends the whole update to the CPU loop BEFORE anything on the device changed */
+        for(auto &[voice, vstate] : mBatch)
+        {
+            if(voice->mFlags.test(VoiceFlag::IsCallback) || voice->mFlags.test(VoiceFlag::IsAmbisonic) || voice->mFlags.test(VoiceFlag::HasNfc)
+                || voice->mDecoder)
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: callback, B-Format, UHJ and near-field-compensated sources are not batched");
+            const bool hrtfVoice = voice->mFlags.test(VoiceFlag::HasHrtf);
+            if(hrtfVoice != mHrtf || (!mHrtf && voice->mDirect.Buffer.data() != dev.Dry.Buffer.data()))
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: direct-channel voices are not batched");
+            if(!voice->mFlags.test(VoiceFlag::IsStatic))
+            {
+                if(voice->mFmtChannels != FmtMono || voice->mDuplicateMono)
+                    return failText(OALGPU_ERR_INVALID, "oalgpu_openal: streaming sources are batched as mono sources only");
+            }
+        }
 
         std::vector<uint32_t> ids, tgtIds, tgtDelays;
         std::vector<oalgpu_voice_params> params;
         std::vector<float> tgtCoeffs, tgtGains;
-        std::vector<std::pair<Voice*, Entry*>> mixed;
-        for(auto &[voice, vstate] : mBatch)
+        mMixed.clear();
+        for(size_t bi{0}; bi < mBatch.size(); ++bi)
         {
-            /* (a mono voice mixes mChans[0] alone unless panning duplicates it, voice.cpp:1058-1059) */
-            if(voice->mFmtChannels != FmtMono || voice->mDuplicateMono || !voice->mFlags.test(VoiceFlag::IsStatic)
-                || voice->mFlags.test(VoiceFlag::IsAmbisonic) || voice->mFlags.test(VoiceFlag::HasNfc))
-                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: mono static sources only");
-            auto it = mVoices.find(voice);
-            if(it != mVoices.end() && it->second.sourceId != voice->mSourceID.load(std::memory_order_relaxed)
-                && voice->mSourceID.load(std::memory_order_relaxed) != 0u)
-            {   /* the Voice object now plays another source (voices are pooled, core/context.h:159-160) */
-                mFreeIndex.push_back(it->second.index);
-                mVoices.erase(it);
-                it = mVoices.end();
+            Voice *voice = mBatch[bi].first;
+            const Voice::State vstate = mBatch[bi].second;
+            Entry &e = mEntries[mBatchIndex[bi]];
+            const unsigned sourceId = voice->mSourceID.load(std::memory_order_relaxed);
+            if(e.live && e.sourceId != sourceId && sourceId != 0u)
+                dropEntry(e);                       /* the Voice object now plays another source (voices are pooled) */
+            /* ---- a delayed start (voice.cpp:1023-1046): untouched until the update it starts in */
+            unsigned outPos = 0u;
+            if(voice->mStartTime > deviceTime)
+            {
+                if(vstate == Voice::Stopping)
+                {
+                    voice->mPlayState.store(Voice::Stopped, std::memory_order_release);
+                    if(e.live) dropEntry(e);
+                    continue;
+                }
+                auto const diff = voice->mStartTime - deviceTime;
+                if(diff >= std::chrono::seconds{1}) continue;
+                outPos = static_cast<unsigned>(std::chrono::round<std::chrono::seconds>(diff * dev.mSampleRate).count());
+                if(outPos >= samplesToDo) continue;
             }
-            if(it == mVoices.end())
+            if(voice->mStep < 1u)
+            {   /* voice.cpp:1002-1010 */
+                if(vstate == Voice::Stopping) { voice->mPlayState.store(Voice::Stopped, std::memory_order_release); if(e.live) dropEntry(e); }
+                continue;
+            }
+            const size_t nch = (voice->mFmtChannels == FmtMono && !voice->mDuplicateMono) ? 1u : voice->mChans.size();
+            bool started = false;
+            if(!e.live)
             {   /* a voice that starts playing: InitVoice (al/source.cpp:639-670) */
                 auto *item = voice->mCurrentBuffer.load(std::memory_order_relaxed);
                 if(!item)
@@ -286,77 +433,106 @@ private:
                     if(vstate == Voice::Stopping) voice->mPlayState.store(Voice::Stopped, std::memory_order_release);
                     continue;
                 }
-                const int h = bufferHandle(voice, item);
-                if(h < 0) return h;
-                if(mFreeIndex.empty()) return failText(OALGPU_ERR_CAPACITY, "oalgpu_openal: more playing voices than max_voices");
-                Entry e;
-                e.index = mFreeIndex.back(); mFreeIndex.pop_back();
-                e.sourceId = voice->mSourceID.load(std::memory_order_relaxed);
-                oalgpu_voice_desc vd{h, voice->mLoopBuffer.load(std::memory_order_relaxed) != nullptr,
-                    voice->mPosition.load(std::memory_order_relaxed), voice->mPositionFrac.load(std::memory_order_relaxed),
-                    voice->mFrequency};
-                if(int rc = oalgpu_voice_init(mGpu, e.index, &vd)) return fail(rc, "oalgpu_voice_init");
-                it = mVoices.emplace(voice, e).first;
+                BufferEntry *be = bufferEntry(voice, item);
+                if(!be) return mError;
+                if(mFreeIndex.size() < nch) return failText(OALGPU_ERR_CAPACITY, "oalgpu_openal: more playing voices than max_voices");
+                e.live = true; e.sourceId = sourceId; e.lastState = int(Voice::Playing);
+                e.queue = !voice->mFlags.test(VoiceFlag::IsStatic);
+                auto *loop = voice->mLoopBuffer.load(std::memory_order_relaxed);
+                if(e.queue)
+                {
+                    if(loop && loop != item)
+                        return failText(OALGPU_ERR_INVALID, "oalgpu_openal: a looping queue entered behind its first buffer is not batched");
+                    e.chain.assign(1, {item, be->handle});
+                    if(int rc = extendChain(voice, e)) return rc;
+                }
+                for(size_t c{0}; c < nch; ++c)
+                {
+                    Chan ch;
+                    ch.index = mFreeIndex.back(); mFreeIndex.pop_back();
+                    const int h = channelBuffer(*be, unsigned(c), voice->mFmtChannels == FmtMono);
+                    if(h < 0) return h;
+                    int rc;
+                    if(e.queue)
+                        rc = oalgpu_voice_init_queue(mGpu, ch.index, h, loop != nullptr, voice->mPosition.load(std::memory_order_relaxed),
+                            voice->mPositionFrac.load(std::memory_order_relaxed));
+                    else
+                    {
+                        oalgpu_voice_desc vd{h, loop != nullptr, voice->mPosition.load(std::memory_order_relaxed),
+                            voice->mPositionFrac.load(std::memory_order_relaxed), voice->mFrequency};
+                        rc = oalgpu_voice_init(mGpu, ch.index, &vd);
+                    }
+                    if(rc) return fail(rc, "oalgpu_voice_init");
+                    e.chans.push_back(ch);
+                }
+                e.doneSeen = 0;
+                started = true;
             }
-            Entry &e = it->second;
-            mixed.emplace_back(voice, &e);
+            else if(e.queue) { if(int rc = extendChain(voice, e)) return rc; }
+            mMixed.emplace_back(voice, &e);
             if(e.lastState != int(vstate))
             {   /* ProcessVoiceChanges' play-state changes (alu.cpp:2057-2151) */
-                if(int rc = oalgpu_voice_set_state(mGpu, e.index, int(vstate))) return fail(rc, "oalgpu_voice_set_state");
+                for(Chan &ch : e.chans)
+                    if(int rc = oalgpu_voice_set_state(mGpu, ch.index, int(vstate))) return fail(rc, "oalgpu_voice_set_state");
                 e.lastState = int(vstate);
             }
-            /* what CalcVoiceParams left in the Voice (alu.cpp:1512-1710, :2012-2031) */
-            oalgpu_voice_params p{};
-            p.step = voice->mStep;
-            p.resampler = int(voice->mProps.mResampler);
-            auto &chan = voice->mChans[0];
+            if(outPos)
+                for(Chan &ch : e.chans)
+                    if(int rc = oalgpu_voice_set_start_delay(mGpu, ch.index, outPos)) return fail(rc, "oalgpu_voice_set_start_delay");
+            /* what CalcVoiceParams left in the Voice (alu.cpp:1512-1710, :2012-2031); with the maintainer's hook only for the
+             * voices it ran for */
+            if(mTrack && !started && !mChanged.count(voice)) continue;
             const float inv_rate = 1.0f / float(dev.mSampleRate);
-            p.direct_filter.active = voice->mDirect.FilterActive ? 1 : 0;
-            p.direct_filter.hf_norm = voice->mProps.Direct.HFReference * inv_rate;
-            p.direct_filter.lf_norm = voice->mProps.Direct.LFReference * inv_rate;
-            p.direct_filter.gain_hf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.LowPass, -1.0f) : 1.0f;
-            p.direct_filter.gain_lf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.HighPass, 1.0f) : 1.0f;
-            const bool hrtfVoice = voice->mFlags.test(VoiceFlag::HasHrtf);
-            if(hrtfVoice != mHrtf || (!mHrtf && voice->mDirect.Buffer.data() != dev.Dry.Buffer.data()))
-                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: direct-channel voices are not batched");
-            if(mHrtf) p.hrtf_dist = OALGPU_HRTF_KEEP_TARGET;       /* Hrtf.Target itself is handed over below */
-            else for(size_t c{0}; c < dev.Dry.Buffer.size(); ++c) p.dry_gains[c] = chan.mDryParams.Gains.Target[c];
-            for(unsigned s{0}; s < unsigned(OALGPU_MAX_SENDS); ++s)
+            for(size_t c{0}; c < nch; ++c)
             {
-                p.send_slot[s] = -1;
-                p.send_filter[s] = oalgpu_filter_params{0, 1.0f, 5000.0f*inv_rate, 1.0f, 250.0f*inv_rate};
-                if(s >= dev.NumAuxSends || voice->mSend[s].Buffer.empty()) continue;
-                /* mSend[s].Buffer = the slot's Wet.Buffer (alu.cpp:1676-1683, :1729-1736) */
-                p.send_slot[s] = slotOf(auxslots, voice->mSend[s].Buffer);
-                if(p.send_slot[s] < 0) return failText(OALGPU_ERR_INVALID, "oalgpu_openal: a send targets a buffer that is no active slot's");
-                auto &wet = chan.mWetParams[s];
-                const bool on = voice->mSend[s].FilterActive;
-                p.send_filter[s].active = on ? 1 : 0;
-                p.send_filter[s].hf_norm = voice->mProps.Send[s].HFReference * inv_rate;
-                p.send_filter[s].lf_norm = voice->mProps.Send[s].LFReference * inv_rate;
-                p.send_filter[s].gain_hf = on ? ShelfGainAt(wet.LowPass, -1.0f) : 1.0f;
-                p.send_filter[s].gain_lf = on ? ShelfGainAt(wet.HighPass, 1.0f) : 1.0f;
-                for(uint32_t c{0}; c < mWetChannels; ++c) p.send_gains[s][c] = wet.Gains.Target[c];
-            }
-            /* only what changed goes over: CalcVoiceParams ran for the voices with pending properties, and
-             * BiquadInterpFilter::setParams with unchanged targets is a no-op (biquad.cpp:131-149) */
-            if(!e.haveParams || std::memcmp(&e.params, &p, sizeof(p)) != 0)
-            {
-                e.params = p; e.haveParams = true;
-                ids.push_back(e.index);
-                params.push_back(p);
-            }
-            if(mHrtf)
-            {
-                auto const &tg = chan.mDryParams.Hrtf.Target;
-                if(!e.haveTarget || tg.Gain != e.target.Gain || tg.Delay[0] != e.target.Delay[0] || tg.Delay[1] != e.target.Delay[1]
-                    || std::memcmp(&tg.Coeffs, &e.target.Coeffs, sizeof(tg.Coeffs)) != 0)
+                Chan &ch = e.chans[c];
+                auto &chan = voice->mChans[c];
+                oalgpu_voice_params p{};
+                p.step = voice->mStep;
+                p.resampler = int(voice->mProps.mResampler);
+                p.direct_filter.active = voice->mDirect.FilterActive ? 1 : 0;
+                p.direct_filter.hf_norm = voice->mProps.Direct.HFReference * inv_rate;
+                p.direct_filter.lf_norm = voice->mProps.Direct.LFReference * inv_rate;
+                p.direct_filter.gain_hf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.LowPass, -1.0f) : 1.0f;
+                p.direct_filter.gain_lf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.HighPass, 1.0f) : 1.0f;
+                if(mHrtf) p.hrtf_dist = OALGPU_HRTF_KEEP_TARGET;       /* Hrtf.Target itself is handed over below */
+                else for(size_t l{0}; l < dev.Dry.Buffer.size(); ++l) p.dry_gains[l] = chan.mDryParams.Gains.Target[l];
+                for(unsigned s{0}; s < unsigned(OALGPU_MAX_SENDS); ++s)
                 {
-                    e.target = tg; e.haveTarget = true;
-                    tgtIds.push_back(e.index);
-                    tgtDelays.push_back(tg.Delay[0]); tgtDelays.push_back(tg.Delay[1]);
-                    tgtGains.push_back(tg.Gain);
-                    tgtCoeffs.insert(tgtCoeffs.end(), &tg.Coeffs[0][0], &tg.Coeffs[0][0] + HrirLength*2);
+                    p.send_slot[s] = -1;
+                    p.send_filter[s] = oalgpu_filter_params{0, 1.0f, 5000.0f*inv_rate, 1.0f, 250.0f*inv_rate};
+                    if(s >= dev.NumAuxSends || voice->mSend[s].Buffer.empty()) continue;
+                    /* mSend[s].Buffer = the slot's Wet.Buffer (alu.cpp:1676-1683, :1729-1736) */
+                    p.send_slot[s] = slotOf(auxslots, voice->mSend[s].Buffer);
+                    if(p.send_slot[s] < 0) return failText(OALGPU_ERR_INVALID, "oalgpu_openal: a send targets a buffer that is no active slot's");
+                    auto &wet = chan.mWetParams[s];
+                    const bool on = voice->mSend[s].FilterActive;
+                    p.send_filter[s].active = on ? 1 : 0;
+                    p.send_filter[s].hf_norm = voice->mProps.Send[s].HFReference * inv_rate;
+                    p.send_filter[s].lf_norm = voice->mProps.Send[s].LFReference * inv_rate;
+                    p.send_filter[s].gain_hf = on ? ShelfGainAt(wet.LowPass, -1.0f) : 1.0f;
+                    p.send_filter[s].gain_lf = on ? ShelfGainAt(wet.HighPass, 1.0f) : 1.0f;
+                    for(uint32_t l{0}; l < mWetChannels; ++l) p.send_gains[s][l] = wet.Gains.Target[l];
+                }
+                /* only what changed goes over: BiquadInterpFilter::setParams with unchanged targets is a no-op (biquad.cpp:131-149) */
+                if(!ch.haveParams || std::memcmp(&ch.params, &p, sizeof(p)) != 0)
+                {
+                    ch.params = p; ch.haveParams = true;
+                    ids.push_back(ch.index);
+                    params.push_back(p);
+                }
+                if(mHrtf)
+                {
+                    auto const &tg = chan.mDryParams.Hrtf.Target;
+                    if(!ch.haveTarget || tg.Gain != ch.target.Gain || tg.Delay[0] != ch.target.Delay[0] || tg.Delay[1] != ch.target.Delay[1]
+                        || std::memcmp(&tg.Coeffs, &ch.target.Coeffs, sizeof(tg.Coeffs)) != 0)
+                    {
+                        ch.target = tg; ch.haveTarget = true;
+                        tgtIds.push_back(ch.index);
+                        tgtDelays.push_back(tg.Delay[0]); tgtDelays.push_back(tg.Delay[1]);
+                        tgtGains.push_back(tg.Gain);
+                        tgtCoeffs.insert(tgtCoeffs.end(), &tg.Coeffs[0][0], &tg.Coeffs[0][0] + HrirLength*2);
+                    }
                 }
             }
         }
@@ -401,27 +577,48 @@ private:
         }
 
         /* the state the reference mutates in place stays authoritative on the device; what the rest of the
-         * reference looks at (GetSourceOffset, the play state, the end of a source) is read back */
+         * reference looks at (GetSourceOffset, the play state, the end of a source, a queue's progress) is read back from the
+         * voice's first channel */
         std::vector<uint32_t> rb;
-        for(auto &ve : mixed) rb.push_back(ve.second->index);
+        for(auto &ve : mMixed) rb.push_back(ve.second->chans[0].index);
         mBrief.resize(rb.size());
         if(!rb.empty())
             if(int rc = oalgpu_voices_readback(mGpu, rb.data(), rb.size(), mBrief.data())) return fail(rc, "oalgpu_voices_readback");
-        for(size_t k{0}; k < mixed.size(); ++k)
+        for(size_t k{0}; k < mMixed.size(); ++k)
         {
-            Voice *voice = mixed[k].first;
-            Entry &e = *mixed[k].second;
+            Voice *voice = mMixed[k].first;
+            Entry &e = *mMixed[k].second;
             const oalgpu_voice_brief &st = mBrief[k];
             if(st.fading) voice->mFlags.set(VoiceFlag::IsFading);
             if(e.lastState == int(Voice::Stopping))
             {   /* voice.cpp:1119-1123: faded out; the Voice object returns to the pool */
                 voice->mPlayState.store(Voice::Stopped, std::memory_order_release);
-                mFreeIndex.push_back(e.index);
-                mVoices.erase(voice);
+                dropEntry(e);
                 continue;
             }
             voice->mPosition.store(st.position, std::memory_order_relaxed);
             voice->mPositionFrac.store(st.position_frac, std::memory_order_relaxed);
+            if(e.queue)
+            {   /* voice.cpp:1182-1218: where the queue has got to, and the buffers it left behind */
+                const unsigned sourceID = voice->mSourceID.load(std::memory_order_relaxed);
+                if(st.has_buffer)
+                    for(auto const &link : e.chain)
+                        if(link.second == st.current_buffer)
+                        { voice->mCurrentBuffer.store(const_cast<VoiceBufferItem*>(link.first), std::memory_order_release); break; }
+                const uint32_t done = st.buffers_done - e.doneSeen;
+                e.doneSeen = st.buffers_done;
+                if(done > 0 && context->mEnabledEvts.load(std::memory_order_acquire).test(AsyncEnableBits::BufferCompleted))
+                {
+                    auto *ring = context->mAsyncEvents.get();
+                    if(auto const evt_vec = ring->getWriteVector(); !evt_vec[0].empty())
+                    {
+                        auto &evt = InitAsyncEvent<AsyncBufferCompleteEvent>(evt_vec[0].front());
+                        evt.mId = sourceID;
+                        evt.mCount = done;
+                        ring->writeAdvance(1);
+                    }
+                }
+            }
             if(!st.has_buffer)
             {
                 endOfSource(voice, context);
@@ -436,11 +633,16 @@ private:
     oalgpu_context *mGpu{nullptr};
     bool mHrtf{false};
     uint32_t mNumSlots{0}, mWetChannels{4};
-    std::map<const VoiceBufferItem*, int> mBufferHandle;
-    std::map<const Voice*, Entry> mVoices;
+    std::map<const VoiceBufferItem*, BufferEntry> mBuffers;
+    std::vector<Entry> mEntries;                    /* [place in the context's voice array] */
     std::vector<uint32_t> mFreeIndex;
     unsigned mExpected{0}, mSeen{0};
+    size_t mCursor{0};
     std::vector<std::pair<Voice*, Voice::State>> mBatch;
+    std::vector<uint32_t> mBatchIndex;
+    std::vector<std::pair<Voice*, Entry*>> mMixed;
+    bool mTrack{false}, mResync{false};
+    std::unordered_set<const Voice*> mChanged;
     std::vector<float> mLines;
     std::vector<oalgpu_voice_brief> mBrief;
     int mError{0};

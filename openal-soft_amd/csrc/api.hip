@@ -178,7 +178,15 @@ struct oalgpu_context {
     DevBuf<uint32_t> queueDone;            // [voice] buffers a streaming voice has played through
     std::vector<void*> bufferData;
     std::vector<uint32_t> bufferLoopLen;   // loop_end - loop_start of every registered buffer (0: cannot loop)
-    uint32_t numBuffers{0};
+    uint32_t numBuffers{0};                // handles handed out so far (released ones are reused: freeBuffers)
+    // The lifetime of a buffer handle (oalgpu_buffer_release): a handle is freed -- its HBM copy, and the handle for reuse -- when
+    // the host has released it AND nothing refers to it any more: no voice slot that was initialised on it (voiceHead: cleared when
+    // the slot is initialised again or set to Stopped), no live buffer whose queue link points at it, no channel view of it.
+    struct BufHost { bool live{false}, released{false}; int32_t parent{-1}, next{-1}; uint32_t refs{0}; };
+    std::vector<BufHost> bufHost;
+    std::vector<uint32_t> freeBuffers;
+    std::vector<int32_t> voiceHead;        // [voice] the buffer the slot was initialised on (a queue: its first), -1: none
+    std::vector<uint32_t> queueDoneKnown, queueUnqueued;   // [voice] AsyncBufferComplete counts the host has read back / given up (oalgpu_voice_queue_unqueue)
     DevBuf<VoiceCtl> ctl;
     DevBuf<float> prev, hrtfOld, hrtfTgt, hist, gainCur, gainTgt, sendCur, sendTgt;
     DevBuf<BiquadSlot> dfilt, sfilt;
@@ -193,6 +201,7 @@ struct oalgpu_context {
     DevBuf<AmbiMapEntry> dryMap, wetMaps;   // MixParams::AmbiMap of the dry bus / of every slot's wet bus
     DevBuf<PanRecord> panRecs;
     std::vector<VoiceCtl> ctlHost;          // oalgpu_voices_readback: staging
+    std::vector<uint32_t> doneHost;
     DevBuf<TargetRecord> tgtRecs;           // oalgpu_voice_set_hrtf_targets: staging
     DevBuf<float> tgtCoeffs;
     bool serialOnly{false};                // OALGPU_CTX_SERIAL: no two-stream pipeline
@@ -1133,6 +1142,10 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.buffers = c->buffers.p;
     c->bufferData.assign(std::max<uint32_t>(desc->max_buffers, 1u), nullptr);
     c->bufferLoopLen.assign(std::max<uint32_t>(desc->max_buffers, 1u), 0u);
+    c->bufHost.assign(std::max<uint32_t>(desc->max_buffers, 1u), oalgpu_context::BufHost{});
+    c->voiceHead.assign(std::max<uint32_t>(desc->max_voices, 1u), -1);
+    c->queueDoneKnown.assign(std::max<uint32_t>(desc->max_voices, 1u), 0u);
+    c->queueUnqueued.assign(std::max<uint32_t>(desc->max_voices, 1u), 0u);
     c->cbOfVoice.assign(std::max<uint32_t>(desc->max_voices, 1u), -1);
 
     const size_t nv = desc->max_voices;
@@ -1465,6 +1478,70 @@ int oalgpu_hrtf_build_direct_host(const void *mhr, size_t size, uint32_t device_
     return OALGPU_OK;
 }
 
+// ---- buffer handles: allocation, references, release ----
+static bool BufferLive(const oalgpu_context *c, int h) { return h >= 0 && uint32_t(h) < c->numBuffers && c->bufHost[size_t(h)].live; }
+static int AllocBufferHandle(oalgpu_context *c, uint32_t *out)
+{
+    if(!c->freeBuffers.empty()) { *out = c->freeBuffers.back(); c->freeBuffers.pop_back(); }
+    else if(c->numBuffers < c->desc.max_buffers) *out = c->numBuffers++;
+    else return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    c->bufHost[*out] = oalgpu_context::BufHost{};
+    c->bufHost[*out].live = true;
+    return OALGPU_OK;
+}
+static void BufferUnref(oalgpu_context *c, int h);
+// (the caller has made sure nothing on the device still reads the buffer: hipFree waits for the device besides)
+static void BufferFreeNow(oalgpu_context *c, int h)
+{
+    auto &b = c->bufHost[size_t(h)];
+    if(c->bufferData[size_t(h)]) { (void)hipFree(c->bufferData[size_t(h)]); c->bufferData[size_t(h)] = nullptr; }
+    const int32_t parent = b.parent, next = b.next;
+    b = oalgpu_context::BufHost{};
+    c->bufferLoopLen[size_t(h)] = 0;
+    c->freeBuffers.push_back(uint32_t(h));
+    if(parent >= 0) BufferUnref(c, parent);
+    if(next >= 0) BufferUnref(c, next);
+}
+static void BufferUnref(oalgpu_context *c, int h)
+{
+    if(h < 0) return;
+    auto &b = c->bufHost[size_t(h)];
+    if(b.refs) --b.refs;
+    if(b.refs == 0 && b.released && b.live) BufferFreeNow(c, h);
+}
+static void SetVoiceHead(oalgpu_context *c, uint32_t voice, int h)
+{
+    const int old = c->voiceHead[voice];
+    c->voiceHead[voice] = h;
+    if(h >= 0) ++c->bufHost[size_t(h)].refs;
+    if(old >= 0) BufferUnref(c, old);
+}
+
+int oalgpu_buffer_release(oalgpu_context *c, int buffer)
+{
+    if(!c || !BufferLive(c, buffer)) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_release: not a registered buffer");
+    if(c->bufHost[size_t(buffer)].released) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_release: released before");
+    if(int rc = UseCtx(c)) return rc;
+    for(const auto &cb : c->cbVoices)
+        if(cb.buffer == buffer && !cb.retired) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_release: a callback source's storage is the library's own");
+    // initialisations that wait for the next update name their buffers: they are on the device before anything is freed
+    if(int rc = FlushInits(c)) return rc;
+    auto &b = c->bufHost[size_t(buffer)];
+    b.released = true;
+    if(b.refs == 0) BufferFreeNow(c, buffer);
+    return OALGPU_OK;
+}
+
+int oalgpu_buffer_info(oalgpu_context *c, int buffer, int32_t *live, int32_t *release_pending, uint32_t *references)
+{
+    if(!c || buffer < 0 || uint32_t(buffer) >= c->bufHost.size()) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_info: bad handle");
+    const auto &b = c->bufHost[size_t(buffer)];
+    if(live) *live = b.live ? 1 : 0;
+    if(release_pending) *release_pending = (b.live && b.released) ? 1 : 0;
+    if(references) *references = b.refs;
+    return OALGPU_OK;
+}
+
 int oalgpu_buffer_register(oalgpu_context *c, const void *data, int fmt_type, uint32_t frame_step,
     uint32_t sample_len, uint32_t loop_start, uint32_t loop_end)
 {
@@ -1472,14 +1549,15 @@ int oalgpu_buffer_register(oalgpu_context *c, const void *data, int fmt_type, ui
     if(!c || !data || fmt_type < 0 || fmt_type > OALGPU_FMT_ALAW || frame_step == 0 || sample_len == 0
         || loop_end > sample_len || loop_start >= (loop_end ? loop_end : 1u))
         return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_register: bad arguments");
-    if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    if(c->freeBuffers.empty() && c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
     if(int rc = UseCtx(c)) return rc;
     const size_t nbytes = size_t{sample_len} * frame_step * bytesPer[fmt_type];
     void *dev = nullptr;
     HIP_TRY(hipMalloc(&dev, nbytes + 16));
     const hipError_t e = hipMemcpy(dev, data, nbytes, hipMemcpyHostToDevice);
     if(e != hipSuccess) { (void)hipFree(dev); return Fail(OALGPU_ERR_HIP, hipGetErrorString(e)); }
-    const uint32_t h = c->numBuffers++;
+    uint32_t h = 0;
+    if(int rc = AllocBufferHandle(c, &h)) { (void)hipFree(dev); return rc; }
     c->bufferData[h] = dev;
     c->bufferLoopLen[h] = loop_end > loop_start ? loop_end - loop_start : 0u;
     BufferItem item{dev, fmt_type, frame_step, sample_len, loop_start, loop_end, 0};
@@ -1490,7 +1568,7 @@ int oalgpu_buffer_register(oalgpu_context *c, const void *data, int fmt_type, ui
 int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc *d)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }
-    if(!c || !d || voice >= c->L.numVoices || d->buffer < 0 || uint32_t(d->buffer) >= c->numBuffers
+    if(!c || !d || voice >= c->L.numVoices || !BufferLive(c, d->buffer) || c->bufHost[size_t(d->buffer)].released
         || d->position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: bad arguments");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
@@ -1498,6 +1576,13 @@ int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: a looping voice needs a buffer registered with loop_end > loop_start");
     RetireCallbackVoice(c, voice);
     c->initPending.push_back(VoiceInitRecord{voice, d->buffer, d->looping ? 1 : 0, d->position, d->position_frac, 0});
+    if(c->voiceHead[voice] >= 0 && c->bufHost[size_t(c->voiceHead[voice])].released)
+    {   // the slot's old buffer may be freed by this: the device must be through with it (and the initialisation on it first)
+        if(int rc = UseCtx(c)) return rc;
+        if(int rc = FlushInits(c)) return rc;
+    }
+    SetVoiceHead(c, voice, d->buffer);
+    c->queueDoneKnown[voice] = c->queueUnqueued[voice] = 0;
     return OALGPU_OK;
 }
 
@@ -1508,10 +1593,16 @@ int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc
  * ends, and Voice::mix leaves finished buffers behind (voice.cpp:1182-1194). */
 int oalgpu_buffer_queue_link(oalgpu_context *c, int buffer, int next_buffer)
 {
-    if(!c || buffer < 0 || uint32_t(buffer) >= c->numBuffers || next_buffer >= int(c->numBuffers))
+    if(!c || !BufferLive(c, buffer) || (next_buffer >= 0 && (!BufferLive(c, next_buffer) || c->bufHost[size_t(next_buffer)].released)))
         return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_queue_link: bad buffer");
     if(int rc = UseCtx(c)) return rc;
     if(int rc = oalgpu_sync(c)) return rc;
+    {   // the link holds its target
+        const int32_t old = c->bufHost[size_t(buffer)].next;
+        c->bufHost[size_t(buffer)].next = next_buffer < 0 ? -1 : next_buffer;
+        if(next_buffer >= 0) ++c->bufHost[size_t(next_buffer)].refs;
+        if(old >= 0) BufferUnref(c, old);
+    }
     const int32_t next = next_buffer < 0 ? 0 : next_buffer + 1;
     HIP_TRY(hipMemcpy(reinterpret_cast<char*>(c->buffers.p + buffer) + offsetof(BufferItem, next), &next, sizeof(next),
         hipMemcpyHostToDevice));
@@ -1522,11 +1613,18 @@ int oalgpu_voice_init_queue(oalgpu_context *c, uint32_t voice, int first_buffer,
     uint32_t position_frac)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }
-    if(!c || voice >= c->L.numVoices || first_buffer < 0 || uint32_t(first_buffer) >= c->numBuffers || position_frac >= kFracOne)
+    if(!c || voice >= c->L.numVoices || !BufferLive(c, first_buffer) || c->bufHost[size_t(first_buffer)].released || position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_queue: bad arguments");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
     RetireCallbackVoice(c, voice);
     c->initPending.push_back(VoiceInitRecord{voice, first_buffer, looping ? 1 : 0, position, position_frac, 1});
+    if(c->voiceHead[voice] >= 0 && c->bufHost[size_t(c->voiceHead[voice])].released)
+    {
+        if(int rc = UseCtx(c)) return rc;
+        if(int rc = FlushInits(c)) return rc;
+    }
+    SetVoiceHead(c, voice, first_buffer);
+    c->queueDoneKnown[voice] = c->queueUnqueued[voice] = 0;
     return OALGPU_OK;
 }
 
@@ -1541,6 +1639,26 @@ int oalgpu_voice_queue_state(oalgpu_context *c, uint32_t voice, int32_t *current
     if(int rc = oalgpu_sync(c)) return rc;
     HIP_TRY(hipMemcpy(current_buffer, &c->ctl.p[voice].curBuffer, sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(buffers_done, c->queueDone.p + voice, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    c->queueDoneKnown[voice] = *buffers_done;
+    return OALGPU_OK;
+}
+
+/* alSourceUnqueueBuffers: the first `count` buffers of the voice's queue -- processed ones: the library checks the count against
+ * what the host has READ BACK of the voice (oalgpu_voice_queue_state, oalgpu_voices_readback) -- leave the queue: the voice's hold
+ * moves on to the buffer behind them, so that a released buffer among them can be freed while the source plays on. */
+int oalgpu_voice_queue_unqueue(oalgpu_context *c, uint32_t voice, uint32_t count)
+{
+    if(!c || voice >= c->L.numVoices) return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_queue_unqueue: bad arguments");
+    if(count == 0) return OALGPU_OK;
+    if(c->queueUnqueued[voice] + count > c->queueDoneKnown[voice])
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_queue_unqueue: more buffers than the voice is known to have played through (read its state back first)");
+    if(int rc = UseCtx(c)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    if(int rc = oalgpu_sync(c)) return rc;
+    int head = c->voiceHead[voice];
+    for(uint32_t i = 0; i < count && head >= 0; ++i) head = c->bufHost[size_t(head)].next;
+    c->queueUnqueued[voice] += count;
+    SetVoiceHead(c, voice, head);
     return OALGPU_OK;
 }
 
@@ -1554,7 +1672,7 @@ int oalgpu_buffer_register_adpcm(oalgpu_context *c, const void *data, int adpcm_
         || sample_len == 0 || loop_end > sample_len || loop_start >= (loop_end ? loop_end : 1u)
         || samples_per_block < (adpcm_type == OALGPU_ADPCM_MS ? 3u : 2u) || samples_per_block > 65536u)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_register_adpcm: bad arguments");
-    if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    if(c->freeBuffers.empty() && c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
     if(int rc = UseCtx(c)) return rc;
     const uint32_t numBlocks = (sample_len + samples_per_block - 1u) / samples_per_block;
     const size_t blockBytes = adpcm_type == OALGPU_ADPCM_MS ? size_t{(samples_per_block - 2u) / 2u + 7u} * channels
@@ -1571,7 +1689,8 @@ int oalgpu_buffer_register_adpcm(oalgpu_context *c, const void *data, int adpcm_
     if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(comp);
     if(e != hipSuccess) { (void)hipFree(pcm); return Fail(OALGPU_ERR_HIP, hipGetErrorString(e)); }
-    const uint32_t h = c->numBuffers++;
+    uint32_t h = 0;
+    if(int rc = AllocBufferHandle(c, &h)) { (void)hipFree(pcm); return rc; }
     c->bufferData[h] = pcm;
     c->bufferLoopLen[h] = loop_end > loop_start ? loop_end - loop_start : 0u;
     BufferItem item{pcm, OALGPU_FMT_SHORT, channels, sample_len, loop_start, loop_end, 0};
@@ -1657,18 +1776,23 @@ int oalgpu_voice_set_nfc(oalgpu_context *c, uint32_t voice, float w0)
 
 int oalgpu_buffer_channel_view(oalgpu_context *c, int buffer, uint32_t channel)
 {
-    if(!c || buffer < 0 || uint32_t(buffer) >= c->numBuffers) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_channel_view: bad buffer");
-    if(c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    if(!c || !BufferLive(c, buffer) || c->bufHost[size_t(buffer)].released) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_channel_view: bad buffer");
+    if(c->freeBuffers.empty() && c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
     if(int rc = UseCtx(c)) return rc;
     static const size_t bytesPer[7] = {1, 2, 4, 4, 8, 1, 1};
     BufferItem item{};
     HIP_TRY(hipMemcpy(&item, c->buffers.p + buffer, sizeof(item), hipMemcpyDeviceToHost));
     if(channel >= item.frameStep) return Fail(OALGPU_ERR_INVALID, "oalgpu_buffer_channel_view: channel >= frame_step");
     item.data = static_cast<const char*>(item.data) + size_t{channel} * bytesPer[item.fmt];
-    HIP_TRY(hipMemcpy(c->buffers.p + c->numBuffers, &item, sizeof(item), hipMemcpyHostToDevice));
-    c->bufferData[c->numBuffers] = nullptr;               // the storage belongs to `buffer`
-    c->bufferLoopLen[c->numBuffers] = c->bufferLoopLen[size_t(buffer)];
-    return int(c->numBuffers++);
+    uint32_t h = 0;
+    if(int rc = AllocBufferHandle(c, &h)) return rc;
+    item.next = 0;
+    HIP_TRY(hipMemcpy(c->buffers.p + h, &item, sizeof(item), hipMemcpyHostToDevice));
+    c->bufferData[h] = nullptr;                            // the storage belongs to `buffer`: the view holds it
+    c->bufferLoopLen[h] = c->bufferLoopLen[size_t(buffer)];
+    c->bufHost[h].parent = buffer;
+    ++c->bufHost[size_t(buffer)].refs;
+    return int(h);
 }
 
 static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oalgpu_voice_params *params,
@@ -2164,6 +2288,7 @@ int oalgpu_voice_set_state(oalgpu_context *c, uint32_t voice, int play_state)
     HIP_TRY(hipMemcpyAsync(&c->ctl.p[voice].playState, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if(c->cbOfVoice[voice] >= 0) c->cbVoices[size_t(c->cbOfVoice[voice])].state = play_state;
+    if(play_state == OALGPU_VOICE_STOPPED) SetVoiceHead(c, voice, -1);      // (a released buffer the slot was the last to hold is freed: hipFree waits for the device)
     return OALGPU_OK;
 }
 
@@ -2664,7 +2789,7 @@ int oalgpu_voice_init_callback(oalgpu_context *c, uint32_t voice, int fmt_type, 
     int32_t reuse = -1;
     for(size_t j = 0; j < c->cbVoices.size(); ++j)
         if(c->cbVoices[j].retired) { reuse = int32_t(j); break; }
-    if(reuse < 0 && c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
+    if(reuse < 0 && c->freeBuffers.empty() && c->numBuffers >= c->desc.max_buffers) return Fail(OALGPU_ERR_CAPACITY, "buffer table full");
     oalgpu_context::CbVoice fresh;
     oalgpu_context::CbVoice &cb = reuse >= 0 ? c->cbVoices[size_t(reuse)] : fresh;
     if(reuse >= 0)
@@ -2704,12 +2829,12 @@ int oalgpu_voice_init_callback(oalgpu_context *c, uint32_t voice, int fmt_type, 
     }
     HIP_TRY(hipMemset(dev, 0, nbytes + 16));
     for(int k = 0; k < 2; ++k) HIP_TRY(hipEventRecord(cb.copied[k], c->stream));
-    const uint32_t h = reuse >= 0 ? uint32_t(cb.buffer) : c->numBuffers;
+    uint32_t h = reuse >= 0 ? uint32_t(cb.buffer) : 0u;
+    if(reuse < 0) { if(int rc = AllocBufferHandle(c, &h)) return rc; }       // (the storage is the library's own: never released by the host)
     // one frame long until the first update hands the voice its window (a static buffer has at least one)
     BufferItem item{dev, fmt_type, 1u, 1u, 0u, 0u, 0};
     HIP_TRY(hipMemcpy(c->buffers.p + h, &item, sizeof(item), hipMemcpyHostToDevice));
     undo.armed = false;
-    if(reuse < 0) ++c->numBuffers;
     c->bufferData[h] = dev;
     c->bufferLoopLen[h] = 0u;
     cb.voice = voice; cb.fn = fn; cb.user = userptr; cb.buffer = int32_t(h);
@@ -3126,7 +3251,20 @@ int oalgpu_voices_readback(oalgpu_context *c, const uint32_t *voices, size_t cou
     {
         const VoiceCtl &ctl = c->ctlHost[voices[i] - lo];
         out[i] = oalgpu_voice_brief{ctl.playState, ctl.position, ctl.positionFrac, ctl.curBuffer >= 0 ? 1 : 0,
-            (ctl.flags & kFlagFading) ? 1 : 0};
+            (ctl.flags & kFlagFading) ? 1 : 0, ctl.curBuffer, 0u};
+    }
+    // streaming sources: the buffers they have played through (AsyncBufferCompleteEvent counts, voice.cpp:1207-1218)
+    bool anyQueue = false;
+    for(size_t i = 0; i < count; ++i) anyQueue = anyQueue || (c->ctlHost[voices[i] - lo].flags & kFlagQueue);
+    if(anyQueue)
+    {
+        c->doneHost.resize(size_t{hi - lo} + 1u);
+        HIP_TRY(hipMemcpy(c->doneHost.data(), c->queueDone.p + lo, c->doneHost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for(size_t i = 0; i < count; ++i)
+        {
+            out[i].buffers_done = c->doneHost[voices[i] - lo];
+            c->queueDoneKnown[voices[i]] = out[i].buffers_done;
+        }
     }
     return OALGPU_OK;
 }

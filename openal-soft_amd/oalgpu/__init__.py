@@ -344,6 +344,27 @@ class Scene:
                                                 frame_step, n, loop_start, loop_end),
                      "oalgpu_buffer_register")
 
+    def release_buffer(self, buffer):
+        """oalgpu_buffer_release: the handle is given up; freed (and reusable) once no voice slot, queue link or view holds it"""
+        lib.oalgpu_buffer_release.argtypes = [C.c_void_p, C.c_int]
+        check(lib.oalgpu_buffer_release(self.h, buffer), "oalgpu_buffer_release")
+
+    def buffer_info(self, buffer):
+        """(live, release pending, references) of a buffer handle"""
+        lib.oalgpu_buffer_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+        live, pend, refs = C.c_int32(0), C.c_int32(0), C.c_uint32(0)
+        check(lib.oalgpu_buffer_info(self.h, buffer, C.byref(live), C.byref(pend), C.byref(refs)), "oalgpu_buffer_info")
+        return bool(live.value), bool(pend.value), refs.value
+
+    def init_voice(self, voice, buffer, looping, position=0, frac=0, frequency=44100):
+        """oalgpu_voice_init on a given voice slot (add_voice takes the next free one)"""
+        d = VoiceDesc(buffer, 1 if looping else 0, position, frac, frequency)
+        check(lib.oalgpu_voice_init(self.h, voice, C.byref(d)), "oalgpu_voice_init")
+
+    def unqueue(self, voice, count):
+        lib.oalgpu_voice_queue_unqueue.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        check(lib.oalgpu_voice_queue_unqueue(self.h, voice, count), "oalgpu_voice_queue_unqueue")
+
     def add_voice(self, buffer, looping, position=0, frac=0, frequency=44100):
         d = VoiceDesc(buffer, 1 if looping else 0, position, frac, frequency)
         v = self.nvoices

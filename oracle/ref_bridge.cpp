@@ -95,7 +95,7 @@ enum Mode { ModeCpu = 0, ModeAdapters = 1, ModeBatch = 2 };
 struct Dev final : DeviceBase { Dev() : DeviceBase{DeviceType::Loopback} { } };
 struct Ctx final : ContextBase { explicit Ctx(DeviceBase *d) : ContextBase{d} { } };
 struct Item final : VoiceBufferItem { };
-struct BufferData { std::vector<float> samples; std::vector<int16_t> samples16; Item item; };
+struct BufferData { std::vector<float> samples; std::vector<int16_t> samples16; Item item; unsigned channels{1}; };
 struct SlotData { EffectSlotBase slot; };
 
 bool gInit = false;
@@ -123,6 +123,7 @@ struct oalbridge {
     std::unique_ptr<oalgpu_openal::BatchMixer> batch;
     int error{0};
     std::string errorText;
+    bool trackChanges{false};               /* the batch mixer is told which voices CalcSourceParams recomputes (its optional hook) */
     /* test aid for the output stage (ApplyDither / Write<T>, alu.cpp:2309-2408, are file-local): lines added
      * to DeviceBase::RealOut by the voice loop's first voice, so that the reference's own output stage
      * converts a known signal */
@@ -165,7 +166,7 @@ void Voice::mix(State const vstate, ContextBase *const context, std::chrono::nan
         return;
     }
     /* BATCH: oalgpu_openal::BatchMixer collects the update's voices and mixes them with the last one */
-    if(!b->batch->mix(this, vstate, context, *b->dev, samplesToDo) && b->batch->error() && b->batch->batchComplete())
+    if(!b->batch->mix(this, vstate, context, *b->dev, deviceTime, samplesToDo) && b->batch->error() && b->batch->batchComplete())
     {   /* "on error the caller runs the CPU loop for that update"  */
         if(!b->error) { b->error = b->batch->error(); b->errorText = b->batch->errorText(); }
         for(auto &[voice, st] : b->batch->batch())
@@ -484,6 +485,129 @@ int oalbridge_restart_source(oalbridge *b, int source, int buffer, int looping, 
     return 0;
 }
 
+/* ---- the voice kinds beyond mono static sources ------------------------------------------------------------------ */
+int oalbridge_add_source(oalbridge *b, int buffer, int looping, int position, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf);
+/* interleaved multi-channel data (FmtStereo: two channels, mFrameStep = 2) */
+int oalbridge_add_buffer_interleaved(oalbridge *b, const float *data, uint32_t frames, uint32_t channels, uint32_t loop_start, uint32_t loop_end)
+{
+    auto &buf = b->buffers.emplace_back();
+    buf.samples.assign(data, data + size_t{frames} * channels);
+    buf.samples.resize(size_t{frames} * channels + 8);
+    buf.item.mSamples = std::span<f32>{reinterpret_cast<f32*>(buf.samples.data()), size_t{frames} * channels};
+    buf.item.mBlockAlign = 1;
+    buf.item.mSampleLen = frames;
+    buf.item.mLoopStart = loop_start;
+    buf.item.mLoopEnd = loop_end;
+    buf.channels = channels;
+    return int(b->buffers.size() - 1);
+}
+
+/* a playing STEREO static source (InitVoice with a two-channel buffer: Voice::prepare sizes mChans, CalcPanningAndFilters pans
+ * the channels apart, alu.cpp:1100-1260) */
+int oalbridge_add_source_stereo(oalbridge *b, int buffer, int looping, int position, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf)
+{
+    auto &ctx = *b->ctx;
+    auto &buf = b->buffers.at(size_t(buffer));
+    if(buf.channels != 2) return -1;
+    const size_t n = ctx.mActiveVoiceCount.load(std::memory_order_relaxed);
+    if(n >= ctx.mVoices.load(std::memory_order_relaxed)->size()) ctx.allocVoices(64);
+    Voice *v = (*ctx.mVoices.load(std::memory_order_relaxed))[n];
+    v->mLoopBuffer.store(looping ? &buf.item : nullptr, std::memory_order_relaxed);
+    v->mFmtChannels = FmtStereo;
+    v->mFrequency = 44100;
+    v->mFrameStep = 2;
+    v->mBytesPerBlock = 8u;
+    v->mSamplesPerBlock = 1;
+    v->mAmbiOrder = 0;
+    v->mFlags.reset();
+    v->mFlags.set(VoiceFlag::IsStatic);
+    v->mNumCallbackBlocks = 0;
+    v->mCallbackBlockOffset = 0;
+    v->prepare(b->dev.get());
+    v->mPosition.store(position, std::memory_order_relaxed);
+    v->mPositionFrac.store(0u, std::memory_order_relaxed);
+    v->mCurrentBuffer.store(&buf.item, std::memory_order_relaxed);
+    v->mStartTime = {};
+    v->mSourceID.store(unsigned(n + 1), std::memory_order_relaxed);
+    auto *props = NewProps(b);
+    FillProps(b, *props, gain, x, y, z, resampler, pitch, gain_hf);
+    v->mUpdate.store(props, std::memory_order_release);
+    v->mPlayState.store(Voice::Playing, std::memory_order_release);
+    ctx.mActiveVoiceCount.store(n + 1, std::memory_order_release);
+    b->sources.push_back(v);
+    return int(n);
+}
+
+/* a playing STREAMING source on a queue of mono buffers (alSourceQueueBuffers + alSourcePlay: the items linked through
+ * mNext, the voice not VoiceFlag::IsStatic, mLoopBuffer = the queue's head when looping, al/source.cpp:639-670) */
+int oalbridge_add_source_queue(oalbridge *b, const int *buffers, uint32_t count, int looping, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf)
+{
+    if(count == 0) return -1;
+    for(uint32_t i{0}; i < count; ++i)
+        b->buffers.at(size_t(buffers[i])).item.mNext.store(i + 1 < count ? &b->buffers.at(size_t(buffers[i + 1])).item : nullptr, std::memory_order_relaxed);
+    const int src = oalbridge_add_source(b, buffers[0], 0, 0, gain, x, y, z, resampler, pitch, gain_hf);
+    Voice *v = b->sources.at(size_t(src));
+    v->mFlags.reset(VoiceFlag::IsStatic);
+    v->mLoopBuffer.store(looping ? &b->buffers.at(size_t(buffers[0])).item : nullptr, std::memory_order_relaxed);
+    return src;
+}
+
+/* alSourceQueueBuffers on a playing source: one more item behind the queue's last */
+int oalbridge_queue_buffer(oalbridge *b, int last_buffer, int buffer)
+{
+    b->buffers.at(size_t(buffer)).item.mNext.store(nullptr, std::memory_order_relaxed);
+    b->buffers.at(size_t(last_buffer)).item.mNext.store(&b->buffers.at(size_t(buffer)).item, std::memory_order_release);
+    return 0;
+}
+
+/* which buffer of the bridge the source's mCurrentBuffer is (-1: none) */
+int oalbridge_source_buffer(oalbridge *b, int source)
+{
+    auto *cur = b->sources.at(size_t(source))->mCurrentBuffer.load(std::memory_order_relaxed);
+    for(size_t i{0}; i < b->buffers.size(); ++i) if(&b->buffers[i].item == cur) return int(i);
+    return -1;
+}
+
+/* Voice::mStartTime: the source starts `delay_samples` output samples from now (alSourcePlayAtTimeSOFT; DeviceBase::getClockTime,
+ * core/device.h:375-384, is what ProcessContexts hands to Voice::mix, alc/alu.cpp:2182) */
+int oalbridge_set_start_delay(oalbridge *b, int source, uint32_t delay_samples)
+{
+    auto &dev = *b->dev;
+    using namespace std::chrono;
+    auto const now = dev.getClockTime();
+    b->sources.at(size_t(source))->mStartTime = now + nanoseconds{seconds{delay_samples}} / dev.mSampleRate;
+    return 0;
+}
+
+/* alBufferData on an existing buffer: new samples in the SAME storage (same item, same address, same length) -- what a buffer
+ * deleted and another allocated in its place looks like to the mixer; with forget the batch mixer is told (its forgetBuffer hook,
+ * which a maintainer calls from alDeleteBuffers / alBufferData) */
+int oalbridge_replace_buffer(oalbridge *b, int buffer, const float *data, uint32_t frames, int forget)
+{
+    auto &buf = b->buffers.at(size_t(buffer));
+    if(buf.samples.size() < size_t{frames} + 4) return -1;         /* (the storage stays where it is) */
+    std::copy(data, data + frames, buf.samples.begin());
+    buf.item.mSamples = std::span<f32>{reinterpret_cast<f32*>(buf.samples.data()), frames};
+    buf.item.mSampleLen = frames;
+    buf.item.mLoopStart = 0; buf.item.mLoopEnd = frames;
+    if(forget) b->batch->forgetBuffer(&buf.item);
+    return 0;
+}
+
+int oalbridge_batch_live_buffers(oalbridge *b) { return int(b->batch->liveBuffers()); }
+
+/* the batch mixer's CalcSourceParams hook: from now on it hands over the parameters of exactly the voices whose properties
+ * the bridge changed (= the voices CalcSourceParams recomputes, alu.cpp:2012-2031) instead of comparing every voice's */
+int oalbridge_track_changes(oalbridge *b, int on)
+{
+    b->trackChanges = on != 0;
+    b->batch->trackChanges(on != 0);
+    return 0;
+}
+
 /* voices the batched mixer currently keeps a device-side slot for (stopped voices give theirs back) */
 int oalbridge_batch_live_voices(oalbridge *b) { return int(b->batch->liveVoices()); }
 
@@ -500,6 +624,7 @@ int oalbridge_update_source_ex(oalbridge *b, int source, float gain, float x, fl
     FillProps(b, *props, gain, x, y, z, resampler, pitch, gain_hf, send_slot, send_gain, send_gain_hf);
     if(auto *old = v->mUpdate.exchange(props, std::memory_order_acq_rel))
         AtomicReplaceHead(b->ctx->mFreeVoiceProps, old);
+    if(b->trackChanges) b->batch->noteParamsChanged(v);
     return 0;
 }
 

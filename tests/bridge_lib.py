@@ -53,6 +53,15 @@ def lib():
         L.oalbridge_source_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
         L.oalbridge_render_lines.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_int, C.c_float, C.POINTER(C.c_uint32),
                                              C.c_void_p, C.c_uint32, C.c_uint32]
+        L.oalbridge_add_buffer_interleaved.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oalbridge_add_source_stereo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float]
+        L.oalbridge_add_source_queue.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float]
+        L.oalbridge_queue_buffer.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oalbridge_source_buffer.argtypes = [C.c_void_p, C.c_int]
+        L.oalbridge_set_start_delay.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        L.oalbridge_replace_buffer.argtypes = [C.c_void_p, C.c_int, f32p, C.c_uint32, C.c_int]
+        L.oalbridge_batch_live_buffers.argtypes = [C.c_void_p]
+        L.oalbridge_track_changes.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -98,6 +107,43 @@ class Bridge:
         if self.h:
             lib().oalbridge_destroy(self.h)
             self.h = None
+
+    # ---- the voice kinds beyond mono static sources, and buffer lifetime
+    def add_buffer_interleaved(self, data, channels, loop_start=0, loop_end=None):
+        data = np.ascontiguousarray(data, np.float32)
+        frames = data.size // channels
+        return lib().oalbridge_add_buffer_interleaved(self.h, data.ctypes.data_as(f32p), frames, channels, loop_start,
+                                                      frames if loop_end is None else loop_end)
+
+    def add_source_stereo(self, buffer, looping, position, gain, pos, resampler=RS_LINEAR, pitch=1.0, gain_hf=1.0):
+        src = lib().oalbridge_add_source_stereo(self.h, buffer, 1 if looping else 0, position, gain, *pos, resampler, pitch, gain_hf)
+        assert src >= 0
+        return src
+
+    def add_source_queue(self, buffers, looping, gain, pos, resampler=RS_LINEAR, pitch=1.0, gain_hf=1.0):
+        arr = (C.c_int * len(buffers))(*buffers)
+        src = lib().oalbridge_add_source_queue(self.h, arr, len(buffers), 1 if looping else 0, gain, *pos, resampler, pitch, gain_hf)
+        assert src >= 0
+        return src
+
+    def queue_buffer(self, last_buffer, buffer):
+        lib().oalbridge_queue_buffer(self.h, last_buffer, buffer)
+
+    def source_buffer(self, source):
+        return lib().oalbridge_source_buffer(self.h, source)
+
+    def set_start_delay(self, source, samples):
+        lib().oalbridge_set_start_delay(self.h, source, samples)
+
+    def replace_buffer(self, buffer, data, forget):
+        data = np.ascontiguousarray(data, np.float32)
+        assert lib().oalbridge_replace_buffer(self.h, buffer, data.ctypes.data_as(f32p), data.size, 1 if forget else 0) == 0
+
+    def batch_live_buffers(self):
+        return lib().oalbridge_batch_live_buffers(self.h)
+
+    def track_changes(self, on=True):
+        lib().oalbridge_track_changes(self.h, 1 if on else 0)
 
     def add_buffer(self, data, loop_start=0, loop_end=None):
         data = np.ascontiguousarray(data, np.float32)

@@ -170,3 +170,129 @@ def test_hrtf_batched_update_behind_the_reference_voice_loop(math_mode, i16):
     stopped = set(range(1, 256, 9))
     ended = {v for v in range(256) if v % 16 == 5}          # ran out of buffer in the third update, Stopped after the fourth
     assert live[0] == 256 and live[1] == 256 - len(stopped) and live[-1] == 256 - len(ended - stopped), live
+
+
+# ---- the voice kinds the library has, behind the binding it ships: multi-channel static sources, streaming sources on growing
+# queues, delayed starts; buffers whose storage is replaced (VERDICT r4 "missing" 2 and 3) ------------------------------------
+def render_kinds(mode, kind, math_mode=1, hrtf=False, track=False):
+    """five updates of a small scene with one source of the kind under test among ordinary mono sources, through the
+    reference's renderSamples; returns (output, per-source state incl. which buffer it plays)"""
+    rng = np.random.default_rng(0xC0FFEE)
+    b = bl.Bridge(mode, math_mode, hrtf=hrtf, num_sends=0)
+    if track:
+        b.track_changes(True)
+    mono = [b.add_buffer(rng.uniform(-1, 1, 20000).astype(np.float32)) for _ in range(3)]
+    srcs = [b.add_source(mono[v % 3], True, 997 * v, 0.2, (float(v - 2), 0.0, -2.0), resampler=bl.RS_BSINC24 if hrtf else bl.RS_LINEAR,
+                         gain_hf=0.5 if v == 1 else 1.0) for v in range(5)]
+    special, extra = None, {}
+    if kind == "stereo":
+        st = rng.uniform(-1, 1, (9000, 2)).astype(np.float32)
+        special = b.add_source_stereo(b.add_buffer_interleaved(st, 2), False, 100, 0.3, (0.5, 0.0, -1.0), resampler=bl.RS_LINEAR)
+    elif kind == "queue":
+        parts = [b.add_buffer(rng.uniform(-1, 1, n).astype(np.float32)) for n in (1500, 700, 2600, 900)]
+        extra["parts"] = parts
+        extra["late"] = b.add_buffer(rng.uniform(-1, 1, 3000).astype(np.float32))
+        special = b.add_source_queue(parts, False, 0.3, (-0.5, 0.2, -1.5), resampler=bl.RS_LINEAR)
+    elif kind == "delay":
+        special = b.add_source(mono[0], True, 4321, 0.3, (1.0, 0.5, -1.0), resampler=bl.RS_LINEAR)
+        b.set_start_delay(special, 1024 + 300)             # starts 300 samples into the SECOND update
+    out, cur = [], []
+    for k in range(5):
+        if k:
+            for v in srcs[::2]:
+                b.update_source(v, 0.2 + 0.01 * k, (float(v - 2) * (1.0 - 0.1 * k), 0.1 * k, -2.0),
+                                resampler=bl.RS_BSINC24 if hrtf else bl.RS_LINEAR, gain_hf=0.5 if v == 1 else 1.0)
+        if kind == "queue" and k == 2:
+            b.queue_buffer(extra["parts"][-1], extra["late"])      # alSourceQueueBuffers while the source plays
+        out.append(b.render(1024))
+        cur.append(b.source_buffer(special) if special is not None else -1)
+    states = [b.source_state(v) + b.source_flags(v) for v in srcs + ([special] if special is not None else [])]
+    b.close()
+    return np.concatenate(out), states, cur
+
+
+@pytest.mark.gpu
+@needs_bridge
+@pytest.mark.parametrize("hrtf", [False, True], ids=["stereo-device", "hrtf-device"])
+@pytest.mark.parametrize("kind", ["stereo", "queue", "delay"])
+def test_voice_kinds_behind_the_reference_voice_loop(kind, hrtf):
+    """a scene that contains ONE such source used to send every update back to the CPU loop"""
+    import oalgpu
+    want, sw, cw = render_kinds(bl.MODE_CPU, kind, hrtf=hrtf)
+    got, sg, cg = render_kinds(bl.MODE_BATCH, kind, math_mode=oalgpu.MATH_FAST, hrtf=hrtf)
+    assert sg == sw, [(i, a, b) for i, (a, b) in enumerate(zip(sg, sw)) if a != b][:4]
+    assert cg == cw, (cg, cw)                                # a streaming source's current buffer follows the queue
+    err = float(np.abs(got.astype(np.float64) - want).max())
+    bound = 2e-5 * float(np.abs(want).max()) + 1e-7
+    assert err <= bound, (kind, err, bound)
+    if kind == "delay":                                      # silent before its start: the first update has only the other sources
+        assert np.abs(want[1024 + 300 - 8:1024 + 300 + 200]).max() > 0
+
+
+@pytest.mark.gpu
+@needs_bridge
+def test_changed_voices_only_with_the_parameter_hook():
+    """BatchMixer::trackChanges: told which voices CalcSourceParams recomputed, the update hands over those voices' parameters
+    only -- the result is the one with every voice compared"""
+    import oalgpu
+    want, sw, _ = render_kinds(bl.MODE_CPU, "none", hrtf=True)
+    a, sa, _ = render_kinds(bl.MODE_BATCH, "none", math_mode=oalgpu.MATH_FAST, hrtf=True)
+    t, st, _ = render_kinds(bl.MODE_BATCH, "none", math_mode=oalgpu.MATH_FAST, hrtf=True, track=True)
+    assert sa == sw and st == sw
+    assert np.array_equal(a.view(np.uint32), t.view(np.uint32))
+    assert float(np.abs(a.astype(np.float64) - want).max()) <= 2e-5 * float(np.abs(want).max()) + 1e-7
+
+
+@pytest.mark.gpu
+@needs_bridge
+@pytest.mark.parametrize("case", ["same-length+forget", "other-length"])
+def test_a_buffer_freed_and_reallocated_at_the_same_address_plays_the_new_samples(case):
+    """core/buffer_storage.h:47-77: buffer storage is freed and reused.  A source plays buffer A to its end; A's storage then holds
+    other samples (the same VoiceBufferItem, the same address); a new source on it must play THOSE.  With the same length nothing
+    about the item tells -- the maintainer's forgetBuffer hook (alDeleteBuffers / alBufferData) does; another length is noticed by
+    the mixer itself."""
+    import oalgpu
+    rng = np.random.default_rng(5)
+    first = rng.uniform(-1, 1, 3000).astype(np.float32)
+    second = rng.uniform(-1, 1, 3000 if case.startswith("same") else 2500).astype(np.float32)
+
+    def run(mode):
+        b = bl.Bridge(mode, oalgpu.MATH_FAST, hrtf=False, num_sends=0)
+        keep = b.add_source(b.add_buffer(rng.uniform(-1, 1, 30000).astype(np.float32) * 0 + 0.01), True, 0, 0.1, (0.0, 0.0, -1.0))
+        buf = b.add_buffer(first)
+        s1 = b.add_source(buf, False, 0, 0.5, (1.0, 0.0, -1.0))
+        out = [b.render(1024) for _ in range(5)]            # s1 runs out of buffer, fades, stops
+        assert b.source_state(s1)[0] == 0
+        b.replace_buffer(buf, second, forget=case.startswith("same"))
+        b.restart_source(s1, buf, False, 0, 0.5, (1.0, 0.0, -1.0), bl.RS_LINEAR, 1.0, 1.0, -1, 1.0, 1.0)
+        out += [b.render(1024) for _ in range(2)]
+        live = b.batch_live_buffers() if mode == bl.MODE_BATCH else 0
+        b.close()
+        return np.concatenate(out), live
+
+    want, _ = run(bl.MODE_CPU)
+    got, live = run(bl.MODE_BATCH)
+    assert float(np.abs(got.astype(np.float64) - want).max()) <= 2e-5 * float(np.abs(want).max()) + 1e-7
+    assert np.abs(want[5 * 1024:]).max() > 0.05             # the second run sounded
+    assert live == 2                                        # the replaced copy was given up, not kept beside the new one
+
+
+@pytest.mark.gpu
+@needs_bridge
+def test_hrtf_batched_update_at_the_headline_size():
+    """BASELINE configs[2]'s size through the binding that is shipped: 4096 HRTF sources behind the reference's own
+    renderSamples / ProcessContexts / CalcVoiceParams in BATCH mode (with the parameter hook, as tools/bridge_period.py times
+    it) against the reference's own Voice::mix: four updates, every 4th source moving, a quarter filtered, a send into the
+    reference's ReverbState; integer state exact."""
+    import oalgpu
+    kw = dict(nsources=4096, todo=(1024, 1024, 1024, 1024))
+    want, sw, _ = render_hrtf(bl.MODE_CPU, **kw)
+    got, sg, live = render_hrtf(bl.MODE_BATCH, math_mode=oalgpu.MATH_FAST, **kw)
+    assert sg == sw, [(i, a, b) for i, (a, b) in enumerate(zip(sg, sw)) if a != b][:4]
+    err = float(np.abs(got.astype(np.float64) - want).max())
+    # 4e-5 of the maximum: twice the 256-source bound -- both sides sum sixteen times as many voices in fp32 (the reference
+    # serially into HrtfAccumData, the GPU per workgroup and then across workgroups), whose rounding noise grows with the root
+    # of the count; measured 2.05e-5.  (tests/test_gpu_error_bound.py bounds the product against an f64 mix at this size.)
+    bound = 4e-5 * float(np.abs(want).max()) + 1e-7
+    assert err <= bound, (err, bound)
+    assert live[0] == 4096
