@@ -23,6 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "measure"))      # oalmeasure: measurement loops over the public C-ABI
 
 UPDATE_SAMPLES = 1024
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, MI355X_MICROARCH.md
@@ -252,6 +253,16 @@ def lds_block(config_id, voices, kernel, kernel_ms):
                     "issue 8-byte LDS reads at half the pipe's rate (MI355X_MICROARCH.md, LDS), so the pipe's busy share, not its byte rate, is the bound"}
 
 
+def _file_source(name):
+    """profiles/<name>@sha256:<first 16 hex digits>: which committed counter file a figure of the line was read from"""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return f"profiles/{name}@sha256:{hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]}"
+    except OSError:
+        return None
+
+
 def _warm_code_pages():
     """On a fresh box the HIP runtime's and the library's code is paged in from disk as it is first executed; a path that runs
     for the first time inside a 1 ms timed block (a stream-wait the warm-up never needed, say) would put a disk read into it.
@@ -269,6 +280,56 @@ def _warm_code_pages():
                     pass
     except OSError:
         pass
+
+
+def join_ranks(oalgpu, sc, dist, torch, rank, world, local_rank, host_transport, tag):
+    """the library's own exchange (oalgpu_comm_init / oalgpu_comm_init_host); torch.distributed only carries the 128-byte id"""
+    if host_transport:
+        sc.comm_init_host("/oalgpu_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag), rank, world)
+    else:
+        idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(oalgpu.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        sc.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+
+
+def calibrate_shards(oalgpu, synth, api, args, V, rank, world, mhr, hrtf, post, dist, torch, local_rank, host_transport):
+    """N > 1, before the voices are dealt: an equal-share scene (V voices per rank) through the library's sharded path -- every
+    rank's own time per update (until ITS streams are idle) over 60 untimed updates behind 30 warm-up ones.  Rank 0 alone runs the
+    effect slots and the post-process and receives the other ranks' bus blocks; its excess over the mean of the others is what
+    the deal takes off its share (rank0_extra_us), the others' time per voice the conversion (us_per_voice)."""
+    sc, script = build_scene(oalgpu, synth, api, args.config, V, rank * V, mhr, args.vpg, num_real=8 if args.config == 2 else None)
+    if args.config == 2:
+        dec_hf, dec_lf = synth.x71_decoder()
+        sc.set_bformat_decoder(dec_hf, dec_lf)
+    allv = list(range(V))
+    moving = [v for v in allv if script.is_moving(v)]
+    sc.set_params_batch(allv, param_array(oalgpu, script, allv, 0))
+    blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(8)] if moving else []
+    join_ranks(oalgpu, sc, dist, torch, rank, world, local_rank, host_transport, "cal")
+
+    def run(n):
+        for k in range(n):
+            if blocks:
+                sc.apply_block(blocks[k % len(blocks)])
+            sc.mix(UPDATE_SAMPLES, post_process=post)
+        sc.sync()
+    run(30)
+    dist.barrier()
+    t0 = time.perf_counter()
+    run(60)
+    own_us = (time.perf_counter() - t0) / 60 * 1e6
+    tdev = "cpu" if host_transport else f"cuda:{local_rank}"
+    tt = torch.zeros(world, dtype=torch.float64, device=tdev)
+    tt[rank] = own_us
+    dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+    per_rank = [float(x) for x in tt.cpu()]
+    others = sum(per_rank[1:]) / max(world - 1, 1)
+    sc.close()
+    dist.barrier()
+    return {"rank_us_per_update": per_rank, "rank0_extra_us": max(0.0, per_rank[0] - others), "us_per_voice": others / V,
+            "note": "60 updates of an equal-share scene through the library's sharded path on this machine, every rank's own clock"}
 
 
 def main():
@@ -308,7 +369,20 @@ def main():
                          "instead of two per update); B must divide --steps and --warmup; 0 = one update per call")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher (WORLD_SIZE unset) would measure ONE GPU and call it N: it starts itself again as
+    # the driver would -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- and every rank then checks
+    # that the world it finds is the one that was asked for.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: the line would claim GPUs it did not run on "
+                         f"(start it as python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}, or plain "
+                         f"`python bench.py --gpus {args.gpus}`, which does that itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -327,6 +401,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import oalgpu
     from oalgpu import synth
+    import oalmeasure
 
     if oalgpu.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
@@ -363,17 +438,21 @@ def main():
     # runs the effect slots and the post-process, all on its post stream beside its own voice kernel -- gets fewer voices by what
     # that work takes (weighted_shards' rank0_extra), so that it is not the rank the others wait for.
     voice_map = None
+    calibration = None
     shard_sizes = [V] * world
     if world > 1 and not args.equal_shards:
         from oalgpu.shard import voice_cost, weighted_shards
         probe = synth.SceneScript(args.config, V * world)
         nsends_of = (lambda v: v % 5) if args.config == 4 else (lambda v: 1 if args.config == 5 else 0)
         costs = [voice_cost(hrtf, 24, nsends_of(v), probe.filter_active(v)) for v in range(V * world)]
-        # GPU time per update of what only rank 0 does, and of one voice (profiles/r4: post chain alone on the GPU -- reduction
-        # ~5, the collective ~20 (unmeasured over xGMI: RCCL's own latency figure), convolution ~21 / four reverbs ~86, HRTF
-        # post-process ~15 -- and the voice kernel's time per voice)
-        extra_us = args.rank0_extra_us if args.rank0_extra_us is not None else {3: 40.0, 5: 61.0, 4: 111.0, 2: 34.0}[args.config]
-        voice_us = {3: 36.5, 5: 46.3, 2: 34.4, 4: 117.0 / 2}[args.config] / 4096.0
+        # What only rank 0 does per update (it receives the ranks' blocks, runs the effect slots and the post-process) and what a
+        # voice costs are MEASURED on this very machine before the deal: every rank runs 60 untimed updates of an equal-share
+        # scene through the library's N > 1 path and reports its own time per update; rank 0's excess over the others is its
+        # extra, the others' time over their voices the price of a voice (calibrate_shards below).  --rank0-extra-us overrides.
+        calibration = calibrate_shards(oalgpu, synth, api, args, V, rank, world, mhr, hrtf, post, dist, torch, local_rank, host_transport)
+        extra_us, voice_us = calibration["rank0_extra_us"], calibration["us_per_voice"]
+        if args.rank0_extra_us is not None:
+            extra_us = args.rank0_extra_us
         rank0_extra = extra_us / voice_us * (sum(costs) / len(costs))
         shards = weighted_shards(costs, world, rank0_extra=min(rank0_extra, 0.98 * sum(costs) / world * world / max(world - 1, 1)))
         shard_sizes = [len(sh) for sh in shards]
@@ -409,15 +488,12 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        if host_transport:
-            sc.comm_init_host("/oalgpu_bench_%s" % os.environ.get("MASTER_PORT", "0"), rank, world)
-        else:
-            idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(oalgpu.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, src=0)
-            sc.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        join_ranks(oalgpu, sc, dist, torch, rank, world, local_rank, host_transport, "run")
+        comm_seen = sc.comm_info()
+        if comm_seen[1] != world or (comm_seen[2] not in (-1, world)):
+            raise SystemExit(f"bench.py: the library's exchange sees {comm_seen} but the job has {world} ranks")
 
+    comm_seen = locals().get("comm_seen")
     B = args.run
     if B and (args.steps % B or args.warmup % B):
         raise SystemExit("--run B: B must divide --steps and --warmup")
@@ -587,16 +663,16 @@ def main():
         n_tp = 400
         each = sorted(run(n_tp) for _ in range(3))
         dt, busy = each[1]
-        sc.pipelined_run(mv, 50, UPDATE_SAMPLES, post)
-        native = sorted(sc.pipelined_run(mv, n_tp, UPDATE_SAMPLES, post) for _ in range(3))[1]
-        submit_s = sorted(sc.submit_cost(mv, 200, UPDATE_SAMPLES, post) for _ in range(3))[1]
+        oalmeasure.pipelined_run(sc, mv, 50, UPDATE_SAMPLES, post)
+        native = sorted(oalmeasure.pipelined_run(sc, mv, n_tp, UPDATE_SAMPLES, post) for _ in range(3))[1]
+        submit_s = sorted(oalmeasure.submit_cost(sc, mv, 200, UPDATE_SAMPLES, post) for _ in range(3))[1]
         e2e_tput = {"e2e_voices_per_s": V * n_tp / dt, "ms_per_update": dt / n_tp * 1e3, "host_submit_share": busy / dt,
                     "native_loop": {"e2e_voices_per_s": V * n_tp / native[0], "ms_per_update": native[0] / n_tp * 1e3,
                                     "host_submit_share": native[1] / native[0],
-                                    "note": "the same loop written in C++ (oalgpu_debug_pipelined_run): no python / ctypes per call",
+                                    "note": "the same loop written in C++ (tools/measure: oalmeasure_pipelined_run): no python / ctypes per call",
                                     "submit_us_unqueued": submit_s * 1e6, "host_share_unqueued": submit_s / (native[0] / n_tp),
                                     "note_unqueued": "the three submitting calls timed with every update's output waited for before the next "
-                                                     "is submitted (oalgpu_debug_submit_cost): host_submit_share above also counts the time a call "
+                                                     "is submitted (oalmeasure_submit_cost): host_submit_share above also counts the time a call "
                                                      "spends blocked inside the runtime behind the queue the GPU is draining"},
                     "updates": n_tp, "moved_voices_per_update": len(moving),
                     "note": "median of 3 runs; per update: oalgpu_voice_move_async (raw 24-byte records into a ring slot, "
@@ -640,7 +716,7 @@ def main():
                             "per call of VoiceWaveKernel<..., true> for such blocks"}
     # the same clock around an EMPTY kernel: what the dispatch-bound events include besides a kernel's own run time
     # (rocprofv3's kernel trace reports the voice kernel about this much shorter, profiles/README.md)
-    event_floor_ms = sc.event_floor_ms(200) if sc.voice_kernel_name().startswith("VoiceWaveKernel") else None
+    event_floor_ms = oalmeasure.event_floor_ms(sc, 200) if sc.voice_kernel_name().startswith("VoiceWaveKernel") else None
 
     if rank == 0:
         nvoices_total = sum(shard_sizes)
@@ -652,12 +728,14 @@ def main():
         # (profiles/voice_kernel_traffic.json: FETCH_SIZE / WRITE_SIZE collected and corrected
         # as MI355X_MICROARCH.md prescribes); None when the profile was taken on another config
         traffic = None
+        traffic_source = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "voice_kernel_traffic.json")))
             ent = tj.get("configs", {}).get(str(args.config), tj)
             if ent.get("config", args.config) == args.config and ent.get("voices") == V \
                     and ent.get("kernel", sc.voice_kernel_name()) == sc.voice_kernel_name():
                 traffic = ent["hbm_bytes_per_launch"]
+                traffic_source = _file_source("voice_kernel_traffic.json")
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -689,7 +767,10 @@ def main():
                                               if mode_flags & oalgpu.CTX_APPLY_IN_VOICE_KERNEL else "launch per update")),
                        "preroll_steps": preroll, "cold_block_ms_per_step": cold_elapsed / args.steps * 1e3, "math_mode": args.math,
                        "voices_per_rank": shard_sizes, "rank_ms_per_step": rank_ms,
-                       "transport": (args.transport if world > 1 else None), "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
+                       "transport": (args.transport if world > 1 else None),
+                       "rccl_ranks": (comm_seen[2] if comm_seen and comm_seen[3] == "rccl" else None),
+                       "comm": ({"rank": comm_seen[0], "world": comm_seen[1], "transport_ranks": comm_seen[2], "kind": comm_seen[3]} if comm_seen else None),
+                       "calibration": calibration, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
                        "e2e_ms_per_update": e2e_ms, "e2e_ms_per_update_p90": e2e_p90_ms if e2e_ms is not None else None,
                        "e2e_throughput": e2e_tput,
                        "e2e_note": "one update alone through the C-ABI from host memory: oalgpu_voice_set_params of the "
@@ -710,6 +791,9 @@ def main():
             # `peak` / `frac` stay the algorithmic fp32 figures of rounds 1-3, for continuity.
             "roofline": {"bound": "lds", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
+                         # (traffic, lds and mfma.instructions are NOT measured in this run: they are the committed rocprofv3 PMC passes
+                         # of the same command on the builder's box, per launch of the launched kernel -- the files and their hashes)
+                         "traffic_source": traffic_source, "counters_source": _file_source("voice_kernel_sq_counters.json"),
                          "kernel": sc.voice_kernel_name() + (" [resident launch]" if resident else ""), "kernel_ms": vk_ms,
                          "kernel_ms_launched": vk_launched_ms, "resident": resident, "event_floor_ms": event_floor_ms,
                          "lds": lds_block(args.config, V, sc.voice_kernel_name(), vk_ms),

@@ -28,6 +28,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built -fvisibility=hidden: these declarations are its whole export list */
+#endif
 
 #define OALGPU_BUFFER_LINE_SIZE 1024      /* BufferLineSize, core/bufferline.h:11 */
 #define OALGPU_MAX_RESAMPLER_PADDING 48   /* core/resampler_limits.h:8 */
@@ -180,7 +183,7 @@ typedef struct oalgpu_context_desc {
 #define OALGPU_CTX_FIR_VALU 1u    /* FAST HRTF voices (IrSize <= 64): the dual-ear FIR as packed fp32 VALU FMAs
                                    * instead of the matrix pipe in split half precision */
 #define OALGPU_CTX_PROFILE  2u    /* the voice kernel's measurement variant: per-phase cycle stamps and stage ablation,
-                                   * read and set through include/oalgpu_debug.h */
+                                   * read and set through the measurement build only (tools/measure/oalgpu_measure.h) */
 #define OALGPU_CTX_STREAM_ROWS 8u  /* FAST dry-line / send contexts with <= 8 mix lines: leave stream rows in HBM and mix them in the
                                    * voice kernel's tail (the path of contexts with more lines) instead of accumulating the
                                    * lines in the wavefronts' registers: for A/B runs and tests of the row path */
@@ -538,6 +541,9 @@ int oalgpu_comm_init(oalgpu_context *ctx, const void *unique_id, size_t size, in
  * with the host.  For ranks RCCL cannot connect: several processes sharing ONE GPU.  Everything else of a sharded
  * update (which rank runs effects and post-process, which carries the accumulator) is the same code as with RCCL. */
 int oalgpu_comm_init_host(oalgpu_context *ctx, const char *name, int rank, int world);
+/* the exchange as the library sees it: this rank, the world it was given, the ranks the transport itself counts (RCCL:
+ * ncclCommCount of the library's communicator) and the transport's name ("rccl", "host", "none") */
+int oalgpu_comm_info(oalgpu_context *ctx, int *rank, int *world, int *transport_ranks, char *kind, size_t kind_size);
 int oalgpu_comm_destroy(oalgpu_context *ctx);
 
 /* Mixing state of one voice after the last update (the fields Voice::mix mutates). */
@@ -825,6 +831,9 @@ int  oalgpu_reverb_skip(oalgpu_reverb *rev, uint32_t n);
  * 0..3 in, dry lines out.  NULL detaches. */
 int  oalgpu_slot_set_reverb(oalgpu_context *ctx, uint32_t slot, oalgpu_reverb *rev);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,9 @@
 // thread (resampler state, biquad design), and kernel launches on the context's stream.
 // No CPU fallback exists anywhere in this file: without a HIP device every entry point fails.
 #include "../../include/oalgpu.h"
-#include "../../include/oalgpu_debug.h"
+#ifdef OALGPU_MEASUREMENT
+#include "../../tools/measure/oalgpu_measure.h"
+#endif
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -441,6 +443,7 @@ struct RcclApi {
     ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*getErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*commCount)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
     std::string why;
 };
@@ -468,6 +471,7 @@ RcclApi &Rccl()
         a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(h, "ncclCommDestroy"));
         a.reduce = reinterpret_cast<decltype(a.reduce)>(dlsym(h, "ncclReduce"));
         a.getErrorString = reinterpret_cast<decltype(a.getErrorString)>(dlsym(h, "ncclGetErrorString"));
+        a.commCount = reinterpret_cast<decltype(a.commCount)>(dlsym(h, "ncclCommCount"));
         a.ok = a.getUniqueId && a.commInitRank && a.commDestroy && a.reduce;
         if(!a.ok) a.why = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclReduce";
         return a;
@@ -492,6 +496,8 @@ int FailRccl(const char *what, ncclResult_t r)
 struct BusTransport {
     virtual ~BusTransport() = default;
     virtual int reduceToRoot(oalgpu_context *c, hipStream_t s) = 0;
+    virtual int ranks() const = 0;              // ranks the transport itself counts (RCCL: ncclCommCount)
+    virtual const char *kind() const = 0;
 };
 
 namespace {
@@ -505,6 +511,12 @@ struct RcclTransport final : BusTransport {
         if(r != ncclSuccess) return FailRccl("ncclReduce", r);
         return OALGPU_OK;
     }
+    int ranks() const override
+    {
+        int n = 0;
+        return (Rccl().commCount && Rccl().commCount(comm, &n) == ncclSuccess) ? n : -1;
+    }
+    const char *kind() const override { return "rccl"; }
 };
 
 __global__ void AddBusKernel(float *__restrict__ bus, const float *__restrict__ add, uint32_t n)
@@ -541,6 +553,8 @@ struct HostTransport final : BusTransport {
     uint64_t submitted{0};                         // updates enqueued by the host (selects the staging slot)
 
     float *slot(int r, uint64_t q) const { return ring + (size_t(r) * kSlots + size_t(q % kSlots)) * floats; }
+    int ranks() const override { return hdr ? int(hdr->world) : world; }
+    const char *kind() const override { return "host"; }
 
     static bool WaitFor(const std::function<bool()> &ok, std::atomic<uint32_t> &failed)
     {
@@ -742,6 +756,18 @@ int oalgpu_comm_init_host(oalgpu_context *c, const char *name, int rank, int wor
     }
     c->comm = t.release(); c->commRank = rank; c->commWorld = world;
     c->carryAccum = rank == 0;
+    return OALGPU_OK;
+}
+
+/* what the context's exchange looks like from the inside: this rank, the world it was given, and the ranks the transport itself
+ * counts (RCCL: ncclCommCount of the communicator the library created; -1: the library's RCCL has no such call) */
+int oalgpu_comm_info(oalgpu_context *c, int *rank, int *world, int *transport_ranks, char *kind, size_t kind_size)
+{
+    if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(rank) *rank = c->commRank;
+    if(world) *world = c->commWorld;
+    if(transport_ranks) *transport_ranks = c->comm ? c->comm->ranks() : 1;
+    if(kind && kind_size) { std::snprintf(kind, kind_size, "%s", c->comm ? c->comm->kind() : "none"); }
     return OALGPU_OK;
 }
 
@@ -2148,62 +2174,6 @@ int oalgpu_output_wait(oalgpu_context *c, uint32_t ticket, float *out, size_t ou
     return OALGPU_OK;
 }
 
-int oalgpu_debug_pipelined_run(oalgpu_context *c, const oalgpu_voice_move *moves, size_t count, uint32_t move_sets,
-    uint32_t updates, uint32_t samples_to_do, int post_process, float *out, size_t out_floats, double *wall_s, double *busy_s)
-{
-    if(!c || !moves || !out || count == 0 || move_sets == 0 || updates < 3) return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_pipelined_run: bad arguments");
-    if(int rc = oalgpu_sync(c)) return rc;
-    using clk = std::chrono::steady_clock;
-    std::vector<uint32_t> tickets(updates);
-    double waited = 0.0;
-    const auto t0 = clk::now();
-    for(uint32_t u = 0; u < updates; ++u)
-    {
-        if(int rc = oalgpu_voice_move_async(c, moves + size_t{u % move_sets} * count, count)) return rc;
-        if(int rc = oalgpu_mix_update(c, samples_to_do, post_process)) return rc;
-        if(int rc = oalgpu_read_output_async(c, &tickets[u])) return rc;
-        if(u >= 2)
-        {
-            const auto w0 = clk::now();
-            if(int rc = oalgpu_output_wait(c, tickets[u - 2], out, out_floats)) return rc;
-            waited += std::chrono::duration<double>(clk::now() - w0).count();
-        }
-    }
-    for(uint32_t u = updates - 2; u < updates; ++u)
-    {
-        const auto w0 = clk::now();
-        if(int rc = oalgpu_output_wait(c, tickets[u], out, out_floats)) return rc;
-        waited += std::chrono::duration<double>(clk::now() - w0).count();
-    }
-    const double wall = std::chrono::duration<double>(clk::now() - t0).count();
-    if(wall_s) *wall_s = wall;
-    if(busy_s) *busy_s = wall - waited;
-    return OALGPU_OK;
-}
-
-/* What the three calls of one pipelined update cost the calling thread when nothing is queued behind them: every update's
- * output is waited for (untimed) before the next one is submitted, so that no call blocks behind a full queue. */
-int oalgpu_debug_submit_cost(oalgpu_context *c, const oalgpu_voice_move *moves, size_t count, uint32_t move_sets,
-    uint32_t updates, uint32_t samples_to_do, int post_process, float *out, size_t out_floats, double *submit_s)
-{
-    if(!c || !moves || !out || !submit_s || count == 0 || move_sets == 0 || updates == 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_submit_cost: bad arguments");
-    if(int rc = oalgpu_sync(c)) return rc;
-    using clk = std::chrono::steady_clock;
-    double spent = 0.0;
-    for(uint32_t u = 0; u < updates; ++u)
-    {
-        uint32_t ticket = 0;
-        const auto t0 = clk::now();
-        if(int rc = oalgpu_voice_move_async(c, moves + size_t{u % move_sets} * count, count)) return rc;
-        if(int rc = oalgpu_mix_update(c, samples_to_do, post_process)) return rc;
-        if(int rc = oalgpu_read_output_async(c, &ticket)) return rc;
-        spent += std::chrono::duration<double>(clk::now() - t0).count();
-        if(int rc = oalgpu_output_wait(c, ticket, out, out_floats)) return rc;
-    }
-    *submit_s = spent / updates;
-    return OALGPU_OK;
-}
-
 int oalgpu_set_stream(oalgpu_context *c, void *hip_stream)
 {
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
@@ -3287,26 +3257,7 @@ int oalgpu_last_update_ms(oalgpu_context *c, float *total_ms, float *voice_kerne
     return OALGPU_OK;
 }
 
-__global__ void EmptyKernel() {}
-
-int oalgpu_debug_event_floor_ms(oalgpu_context *c, uint32_t reps, float *ms)
-{
-    if(!c || !ms || reps == 0 || reps > 4096) return Fail(OALGPU_ERR_INVALID, "oalgpu_debug_event_floor_ms: bad arguments");
-    if(int rc = UseCtx(c)) return rc;
-    if(int rc = oalgpu_sync(c)) return rc;
-    std::vector<float> each(reps);
-    for(uint32_t r = 0; r < reps; ++r)
-    {
-        hipExtLaunchKernelGGL(EmptyKernel, dim3(1), dim3(64), 0, c->stream, c->evStart, c->evVoice, 0u);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventSynchronize(c->evVoice));
-        HIP_TRY(hipEventElapsedTime(&each[r], c->evStart, c->evVoice));
-    }
-    std::sort(each.begin(), each.end());
-    *ms = each[reps / 2];
-    return OALGPU_OK;
-}
-
+#ifdef OALGPU_MEASUREMENT      // (liboalgpu_measure.so, `make measure`: tools/measure/oalgpu_measure.h)
 /* Measurement aid, OALGPU_CTX_PROFILE contexts: which stages the voice kernel's measurement variant skips
  * (1 FIR, 2 resampler, 8 direct filter, 16 FIR input build); 0 = none. */
 int oalgpu_debug_set_ablate(oalgpu_context *c, uint32_t mask)
@@ -3337,6 +3288,8 @@ int oalgpu_debug_wave_times(oalgpu_context *c, unsigned long long *out, uint32_t
     *waves = WaveKernelGroups(c->L) * 4u;
     return OALGPU_OK;
 }
+
+#endif // OALGPU_MEASUREMENT
 
 int oalgpu_slot_set_convolution(oalgpu_context *c, uint32_t slot, oalgpu_convolution *conv)
 {

@@ -168,11 +168,7 @@ __device__ __forceinline__ void ApplyHrtfTargetWave(const DeviceLayout &L, uint3
         x = L.hrirs[size_t{i1} * (kHrirLen * 2) + e] * w1 + x;
         x = L.hrirs[size_t{i2} * (kHrirLen * 2) + e] * w2 + x;
         x = L.hrirs[size_t{i3} * (kHrirLen * 2) + e] * w3 + x;
-#ifdef OALGPU_EXP_CACHED_PARTIALS
-        L.hrtfTgt[size_t{v} * L.irStride * 2 + e] = (e < live) ? x : 0.0f;
-#else
         __builtin_nontemporal_store((e < live) ? x : 0.0f, &L.hrtfTgt[size_t{v} * L.irStride * 2 + e]);    // (read by the next launch)
-#endif
     }
 }
 

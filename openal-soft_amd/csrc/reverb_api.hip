@@ -3,6 +3,9 @@
 // per-block launch.
 #include "api_util.hpp"
 #include "reverb_dev.hpp"
+#ifdef OALGPU_MEASUREMENT
+#include "../../tools/measure/oalgpu_measure.h"
+#endif
 
 #include <cstdlib>
 #include <cstring>
@@ -257,8 +260,6 @@ int oalgpu_reverb_process_device(oalgpu_reverb *r, const float *wet_in_dev, floa
     return OALGPU_OK;
 }
 
-/* measurement aid: cycle-counter stamps of the launches from here on, [4 roles][8 sub-blocks][8]
- * (tools/reverb_phase_times.py; a device instance only) */
 int oalgpu_reverb_set_math_mode(oalgpu_reverb *r, int math_mode)
 {
     if(!r || (math_mode != OALGPU_MATH_EXACT && math_mode != OALGPU_MATH_FAST)) return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_set_math_mode: bad arguments");
@@ -266,6 +267,9 @@ int oalgpu_reverb_set_math_mode(oalgpu_reverb *r, int math_mode)
     return OALGPU_OK;
 }
 
+#ifdef OALGPU_MEASUREMENT      // (liboalgpu_measure.so, `make measure`: tools/measure/oalgpu_measure.h)
+/* measurement aid: cycle-counter stamps of the launches from here on, [4 roles][8 sub-blocks][8]
+ * (tools/reverb_phase_times.py; a device instance only) */
 int oalgpu_reverb_debug_enable_phase_times(oalgpu_reverb *r)
 {
     if(!r || r->device < 0) return Fail(OALGPU_ERR_INVALID, "oalgpu_reverb_debug_enable_phase_times: needs a device instance");
@@ -283,6 +287,7 @@ int oalgpu_reverb_debug_phase_times(oalgpu_reverb *r, unsigned long long *out)
     HIP_TRY(r->stamps.download(out, 4 * 8 * 8));
     return OALGPU_OK;
 }
+#endif // OALGPU_MEASUREMENT
 
 int oalgpu_reverb_skip(oalgpu_reverb *r, uint32_t n)
 {

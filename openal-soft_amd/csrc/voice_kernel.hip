@@ -995,11 +995,7 @@ hipError_t LaunchVoiceMixT(hipStream_t s, const DeviceLayout &L, uint32_t sample
 // launch, which fills the machine exactly once, ends that much later).
 // (kReduceWaves = 16, one run per wavefront, when nothing else is running: oalgpu_mix_voices.)
 // (the partial buses are read once: streamed past L2, like the stores that wrote them -- profiles/r4/nt_partials_ab.txt)
-#ifdef OALGPU_EXP_CACHED_PARTIALS
-#define OALGPU_PARTIAL_LOAD(p) (*(p))
-#else
 #define OALGPU_PARTIAL_LOAD(p) __builtin_nontemporal_load(p)
-#endif
 constexpr int kReduceSegs = 16;
 template<int kReduceWaves>
 __global__ void __launch_bounds__(kReduceWaves * 64) __attribute__((amdgpu_num_vgpr(48))) BusReduceKernel(DeviceLayout L, const float *__restrict__ carry)

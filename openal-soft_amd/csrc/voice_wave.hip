@@ -34,9 +34,6 @@
 
 #pragma clang fp contract(off)
 
-#if defined(OALGPU_EXP_ROWS128) && !defined(OALGPU_EXP_LATE_ROWS)
-#define OALGPU_EXP_LATE_ROWS 1              // (the 16-byte row layout is staged by the prologue's own loop)
-#endif
 #ifndef OALGPU_WAVE_MIN_WG
 #define OALGPU_WAVE_MIN_WG 2              // workgroups per CU the kernels are built for (experiments: 1 shows the unconstrained budget)
 #endif
@@ -83,11 +80,7 @@ __device__ __forceinline__ void StoreRowBlock(uint32_t *blk, uint32_t ls, uint32
 template<class T>
 __device__ __forceinline__ void StorePartial(T *p, T v)
 {
-#ifdef OALGPU_EXP_CACHED_PARTIALS
-    *p = v;
-#else
     __builtin_nontemporal_store(v, p);
-#endif
 }
 
 // ---- MixSamples straight out of LDS into the wavefront's own line accumulators (contexts with <= 8 mix lines) ----
@@ -497,7 +490,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     const uint32_t irStride = L.irStride;
     WL &w = sm.w[wave];
     uint32_t N = samplesToDo;                   // (RES: every update brings its own length)
-#ifndef OALGPU_EXP_LAZY_ARGS
     // The argument block's pointers are needed in SGPRs all at once here, so that their kernarg loads are issued together and
     // waited for ONCE: left to itself the compiler loads each pointer where it spills it to a VGPR lane -- one scalar load and
     // one s_waitcnt after the other, a dozen dependent round trips in front of every wavefront's first useful instruction.
@@ -505,7 +497,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         asm volatile("; argument block resident" :: "s"(L.tables), "s"(L.buffers), "s"(L.ctl), "s"(L.prev), "s"(L.dfilt), "s"(L.hrtfOld),
             "s"(L.hrtfTgt), "s"(L.hist), "s"(L.ambi), "s"(L.startDelay), "s"(L.queueDone), "s"(L.partHrtf), "s"(L.hrirs),
             "s"(next.recs), "s"(next.map), "s"(L.numVoices), "s"(L.waveVoices), "s"(L.irStride), "s"(L.pad), "s"(samplesToDo), "s"(gridDim.x));
-#endif
 
     // The workgroup owns kWWaves*vpw consecutive voices; a wavefront takes every SECOND one of its
     // half of them (wave 0: v, v+2, ..; wave 1: v+1, v+3, ..).  Voices that cost more -- an active
@@ -524,11 +515,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                 prof.times[size_t{L.numVoices} * 8 + size_t{group * kWWaves + wave} * 8 + slot] = __builtin_readcyclecounter();
         }
     };
-#ifdef OALGPU_EXP_ABLATE
-    const uint32_t ablate = OALGPU_EXP_ABLATE;
-#else
     const uint32_t ablate = PROF ? prof.ablate : 0u;
-#endif
     waveStamp(0);
     // Two workgroups share a CU, and the launch fills the machine exactly once: workgroup g and
     // g + gridDim/2 land on the same CU (the dispatcher deals the first half one per CU, then the
@@ -666,19 +653,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     // (Unconditional loads of a clamped index: behind a branch each request would be waited for where the branch joins.)
     const uint32_t keyVoice = group * kWWaves * vpw;
     const uint32_t lastVoice = L.numVoices - 1u;
-#ifdef OALGPU_EXP_COND_HEAD
-    if(vCount)
-    {
-        headN = LoadHeadScalar(L.ctl + voiceAt(0)); bufN = LoadCtlBufferScalar(L.ctl + voiceAt(0));
-        if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + voiceAt(0));
-    }
-#else
     {
         const uint32_t v0 = vCount ? voiceAt(0) : lastVoice;        // (a wavefront without voices never uses what it reads here)
         headN = LoadHeadScalar(L.ctl + v0); bufN = LoadCtlBufferScalar(L.ctl + v0);
         if constexpr (NL == 0) tailN = LoadTailScalar(L.ctl + v0);
     }
-#endif
     asm volatile("" ::: "memory");          // (the first voice's request is issued above this line ...)
     const VoiceHead headK = LoadHeadScalar(L.ctl + (keyVoice < L.numVoices ? keyVoice : lastVoice));
     asm volatile("" ::: "memory");          // (... the key voice's above this one: both are in flight at the first wait for either)
@@ -755,10 +734,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                         || !(headN.position >= 0 && uint32_t(headN.position) >= bufN.loopEnd));
                     planN.prefetch = planN.prefetch && GatherCovers(planN.bsrc, bufN, loopingN, uint32_t(headN.position));
                 }
-                if(headN.flags & (kFlagDelayed | kFlagQueue)) planN.prefetch = false;
-#ifdef OALGPU_EXP_NOPREFETCH
-                planN.prefetch = false;
-#endif   // a delayed start's window depends on where in
+                if(headN.flags & (kFlagDelayed | kFlagQueue)) planN.prefetch = false;   // a delayed start's window depends on where in
                                                                                    // the update it starts; a queue's spans several buffers
                 // (the window first: each gather variant starts by waiting for older loads into its
                 // registers -- the variants share them -- and must not find a fresh one in front of it)
@@ -1061,18 +1037,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             stamp(2);
             // (matrix-pipe FIR: the next voice's request leaves now -- the FIR is too short to cover it, the
             // build of its inputs in front of it makes up for that)
-#ifndef OALGPU_EXP_LATE_REQUEST
             if constexpr (MF) requestNext();
-#endif
             if constexpr (NL == 0)
             {
             // ---- DoHrtfMix, voice.cpp:827-902
             WaveSync();
-#ifdef OALGPU_EXP_CACHED_PARTIALS
-            if(playing) L.hist[size_t{v} * kHist + lane] = w.in[N + lane];
-#else
             if(playing) __builtin_nontemporal_store(w.in[N + lane], &L.hist[size_t{v} * kHist + lane]);    // (read next by the next launch)
-#endif
 
             const float targetGain = tail.tgtGain * (playing ? 1.0f : 0.0f);
             const float oldGain = counter ? tail.oldGain : tail.tgtGain;   // voice.cpp:1100
@@ -1244,7 +1214,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         // RES: the rows staged by an earlier update of this launch are still there unless the key voice's resampler changed
         // (every wavefront reads the same head behind the update's barrier and the same LDS words: a uniform decision)
         if constexpr (RES) { if(first && upd != updBase) stageRows = !(eligK && sm.tabKey == offK * 8u + uint32_t(kK) && sm.tabM == mK); }
-#ifndef OALGPU_EXP_LATE_ROWS
         if(first && eligK && stageRows)
         {
             typedef const __attribute__((address_space(1))) void *gvoidp;
@@ -1256,10 +1225,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                 __builtin_amdgcn_global_load_lds((gvoidp)(src + mK + 2u * pp), (lvoidp)&sm.tabP[32u * pp], 4, 0, 0);
             }
         }
-#endif
-#ifndef OALGPU_EXP_LATE_REQUEST
         if constexpr (NL > 0 || MF) { if(!active) requestNext(); }
-#endif
         else requestNext();
         if constexpr (PROF) { if(first) waveStamp(5); }
 
@@ -1306,10 +1272,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             __syncthreads();
             key = sm.tabKey; m = sm.tabM;
             }
-#ifndef OALGPU_EXP_LATE_ROWS
             if(eligK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the rows requested above are in LDS (and so is this wavefront's window in its registers)
             else
-#endif
             if(key != 0xffffffffu)
             {
                 const float *filter = L.tables + (key >> 3);
@@ -1317,11 +1281,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
                 {
                     const uint32_t p = idx >> 5, pi = idx & 31u;
                     const float *row = filter + pi * 2u * m;
-#ifdef OALGPU_EXP_ROWS128
-                    if constexpr (ACCL == 0)
-                        reinterpret_cast<f4*>(sm.tabF)[idx] = f4{row[2u * p], row[2u * p + 1u], row[m + 2u * p], row[m + 2u * p + 1u]};
-                    else
-#endif
                     {
                     sm.tabF[idx] = f2{row[2u * p], row[2u * p + 1u]};
                     sm.tabP[idx] = f2{row[m + 2u * p], row[m + 2u * p + 1u]};
@@ -1349,11 +1308,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             else if constexpr (MF)
             {
                 FirMfmaH<5, false, (ACCL == 0)>(accM, w.xh, w.hr, invX * invH, lane);
-#ifdef OALGPU_EXP_NOOLDPASS
-                if(false)
-#else
                 if(oldPass)
-#endif
                 {   // the replaced filter's fade-out (MixHrtfBlend, hrtfbase.h:54-70): 64 inputs x IrSize taps land in
                     // frames 0..126 -- the first eight columns of tile 0.  Its inputs go over the main inputs' first
                     // 104 dwords (frames -64..143; the main FIR has read them), as halves like those: frame = lane.
@@ -1398,9 +1353,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
             }
         }
 
-#ifdef OALGPU_EXP_LATE_REQUEST
-        requestNext();
-#endif
         // ---------------- the next voice's state is parked in LDS ----------------
         // After the FIR every LDS word the next pass starts from is free (rd shares x2; in[0..63],
         // fst and cold were last read above), and what was requested before the FIR has landed.
@@ -1649,12 +1601,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
 #pragma unroll
                 for(int ww = 1; ww < kWWaves; ++ww) { const f2 o = dumpOf(ww)[dumpAt(k)]; s.x += o.x; s.y += o.y; }
             }
-#ifdef OALGPU_EXP_CACHED_ACCUM
-            ph[k] = s;
-#else
             if constexpr (RES) StorePartialCoherent(&ph[k], s);       // (read by the reduction's launch while this one runs on)
             else StorePartial(&ph[k], s);
-#endif
         }
     }
     waveStamp(3);

@@ -15,9 +15,6 @@ constexpr int kWThreads = kWWaves * 64;
 constexpr int kTabPairs = 24;                 // staged resampler rows: up to 48 taps (matrix-pipe kernels: 12, see WgLds)
 
 constexpr int kPre = 17;                      // prefetched source samples per lane (17*64 = 1088)
-#ifndef OALGPU_EXP_NORESAMPLE
-#define OALGPU_EXP_NORESAMPLE false
-#endif
 
 // ---- scalar-cache views of the per-voice control block and the buffer table -------------------
 // VoiceCtl (kernels.hpp) in two pieces: the head (bytes 0..47: everything needed to locate and
@@ -128,11 +125,7 @@ struct WgLds {
 // the FIR that runs while the window is in flight would then wait for the window), and they
 // deliver the raw element: the int16 -> float conversion happens when the window is stored to
 // LDS (GatherDecode), so that no load has to be waited for here.
-#ifdef OALGPU_EXP_NT_WINDOW
-#define OALGPU_WINDOW_LOAD(p) __builtin_nontemporal_load(p)
-#else
 #define OALGPU_WINDOW_LOAD(p) (*(p))
-#endif
 template<int FMT>
 __device__ __forceinline__ float LoadRawGlobal(const void *data, size_t idx)
 {
@@ -276,26 +269,12 @@ __device__ __forceinline__ void ResampleRunStaged(const f2 *tabF, const f2 *tabP
         const uint32_t pi = (tt >> 11) & 31u;
         const f2 *tf = tabF + pi, *tp = tabP + pi;
         const float *s = rdb + (tt >> kFracBits);
-#ifdef OALGPU_EXP_ROWS128
-        {   // experiment: [tap pair][phase] = (fil[2p], fil[2p+1], phd[2p], phd[2p+1]) as ONE 16-byte read
-            const f4 *tq = reinterpret_cast<const f4*>(tabF) + pi;
-            (void)tf; (void)tp;
-#pragma unroll
-            for(int q = 0; q < NP; ++q)
-            {
-                const f4 v = tq[(g * NP + q) * 32];
-                F[q] = f2{v.x, v.y};
-                P[q] = f2{v.z, v.w};
-            }
-        }
-#else
 #pragma unroll
         for(int q = 0; q < NP; ++q)
         {
             F[q] = tf[(g * NP + q) * 32];
             P[q] = tp[(g * NP + q) * 32];
         }
-#endif
         if constexpr (DUAL)
         {   // the pair (s[2j], s[2j+1]) as ONE aligned 8-byte read: out of rd when it starts at an even index, else out of rd2
             const uint32_t pos = tt >> kFracBits;
@@ -676,15 +655,11 @@ __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const LT &L,
         if constexpr (PROF) { if(prof.times && lane == 0 && loaded == 0) prof.times[size_t{v} * 8 + 7] = __builtin_readcyclecounter(); }
 
         // voice.cpp:764-769
-        if((increment == kFracOne && fracPos == 0) || (PROF && (prof.ablate & 2u)) || OALGPU_EXP_NORESAMPLE)
+        if((increment == kFracOne && fracPos == 0) || (PROF && (prof.ablate & 2u)))
         {
             for(uint32_t k = lane; k < bdst; k += 64) mixing[loaded + k] = srcBuffer[k];
         }
-#if defined(OALGPU_EXP_NOSTAGED)
-        else if(false)
-#else
         else if(staged)
-#endif
         {
             // (the first chunk of a prefetched window is in rd AND rd2)
             const bool dual = plan.prefetch && loaded == 0;
@@ -697,11 +672,7 @@ __device__ __forceinline__ void LoadResampledWave(SM &sm, WV &w, const LT &L,
                     reinterpret_cast<float*>(&w.pad[0]), lane, dual ? w.rd2 + (kMaxEdge - sL) : nullptr, uint32_t(kMaxEdge) - sL);
             }
         }
-#if defined(OALGPU_EXP_NOGENERIC)
-        else if(false)
-#else
         else
-#endif
         {
             const TabLayout lay = ReferenceTabLayout(rsM);
             for(uint32_t k = lane; k < bdst; k += 64)

@@ -114,11 +114,11 @@ def _fp(a):
     return a.ctypes.data_as(f32p)
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
-        raise OalgpuError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+def _load(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise OalgpuError(f"{path} is missing: build it with __graft_entry__.build() "
                           "(hipcc --offload-arch=gfx950); there is no fallback path")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.oalgpu_version.restype = C.c_char_p
     L.oalgpu_last_error.restype = C.c_char_p
     L.oalgpu_bsinc_table_get.argtypes = [C.c_int, C.POINTER(BsincTable)]
@@ -175,7 +175,6 @@ def _load():
     L.oalgpu_voice_readback.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(VoiceState)]
     L.oalgpu_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.oalgpu_last_update_ms.argtypes = [C.c_void_p, f32p, f32p]
-    L.oalgpu_debug_event_floor_ms.argtypes = [C.c_void_p, C.c_uint32, f32p]
     return L
 
 
@@ -507,32 +506,6 @@ class Scene:
         lib.oalgpu_voice_move_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         check(lib.oalgpu_voice_move_async(self.h, moves.ctypes.data_as(C.c_void_p), len(moves)), "oalgpu_voice_move_async")
 
-    def pipelined_run(self, move_sets, updates, samples=BUFFER_LINE, post_process=True):
-        """oalgpu_debug_pipelined_run: the section-3c loop in C++; move_sets: list of equally long MOVE_DTYPE arrays.
-        Returns (wall seconds, seconds of the calling thread outside oalgpu_output_wait)."""
-        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(m, MOVE_DTYPE) for m in move_sets]))
-        n = self.desc.num_real_channels or self.desc.num_dry_channels
-        out = np.empty((n, BUFFER_LINE), np.float32)
-        wall, busy = C.c_double(), C.c_double()
-        lib.oalgpu_debug_pipelined_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
-                                                   f32p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        check(lib.oalgpu_debug_pipelined_run(self.h, flat.ctypes.data_as(C.c_void_p), len(move_sets[0]), len(move_sets), updates, samples,
-                                             1 if post_process else 0, _fp(out), out.size, C.byref(wall), C.byref(busy)),
-              "oalgpu_debug_pipelined_run")
-        return wall.value, busy.value
-
-    def submit_cost(self, move_sets, updates, samples=BUFFER_LINE, post_process=True):
-        """oalgpu_debug_submit_cost: seconds per update the three submitting calls cost the calling thread when nothing is queued."""
-        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(m, MOVE_DTYPE) for m in move_sets]))
-        n = self.desc.num_real_channels or self.desc.num_dry_channels
-        out = np.empty((n, BUFFER_LINE), np.float32)
-        spent = C.c_double()
-        lib.oalgpu_debug_submit_cost.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
-                                                 f32p, C.c_size_t, C.POINTER(C.c_double)]
-        check(lib.oalgpu_debug_submit_cost(self.h, flat.ctypes.data_as(C.c_void_p), len(move_sets[0]), len(move_sets), updates, samples,
-                                           1 if post_process else 0, _fp(out), out.size, C.byref(spent)), "oalgpu_debug_submit_cost")
-        return spent.value
-
     def read_output_async(self):
         lib.oalgpu_read_output_async.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         t = C.c_uint32()
@@ -595,6 +568,14 @@ class Scene:
         """the host-staged transport (shared-memory ring `name`): ranks RCCL cannot connect, e.g. on one GPU"""
         lib.oalgpu_comm_init_host.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
         check(lib.oalgpu_comm_init_host(self.h, name.encode(), rank, world), "oalgpu_comm_init_host")
+
+    def comm_info(self):
+        """(rank, world, ranks the transport counts, transport name)"""
+        lib.oalgpu_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        r, w, t = C.c_int(0), C.c_int(0), C.c_int(0)
+        kind = C.create_string_buffer(16)
+        check(lib.oalgpu_comm_info(self.h, C.byref(r), C.byref(w), C.byref(t), kind, 16), "oalgpu_comm_info")
+        return r.value, w.value, t.value, kind.value.decode()
 
     def comm_destroy(self):
         lib.oalgpu_comm_destroy.argtypes = [C.c_void_p]
@@ -737,12 +718,6 @@ class Scene:
         a, b = C.c_float(), C.c_float()
         check(lib.oalgpu_last_update_ms(self.h, C.byref(a), C.byref(b)), "oalgpu_last_update_ms")
         return a.value, b.value
-
-    def event_floor_ms(self, reps=200):
-        """what the dispatch-bound HIP events report for an EMPTY kernel (median of `reps`)"""
-        a = C.c_float()
-        check(lib.oalgpu_debug_event_floor_ms(self.h, reps, C.byref(a)), "oalgpu_debug_event_floor_ms")
-        return a.value
 
 
 def comm_unique_id():

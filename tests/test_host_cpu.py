@@ -17,19 +17,48 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def test_library_exports_every_declared_symbol():
+def _exported(path):
+    import subprocess
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-nm") else "nm"
+    out = subprocess.run([nm, "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def _declared(path):
+    hdr = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    return set(re.findall(r"\b(oalgpu_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_library_exports_exactly_the_declared_symbols():
+    """liboalgpu.so's dynamic symbol table IS include/oalgpu.h: every declared entry point exported, nothing else (no measurement
+    aid, no C++ symbol, no kernel stub)"""
     import glob
-    names = set()
-    for path in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):      # oalgpu.h (the boundary), oalgpu_debug.h (measurement aids)
-        hdr = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
-        found = set(re.findall(r"\b(oalgpu_[a-z0-9_]+)\s*\(", hdr))
-        # the boundary header declares no measurement aid
-        assert os.path.basename(path) != "oalgpu.h" or not [n for n in found if n.startswith("oalgpu_debug_")]
-        names |= found
-    names = sorted(names)
-    assert len(names) >= 110 and "oalgpu_debug_phase_times" in names
-    missing = [n for n in names if not hasattr(oalgpu.lib, n)]
-    assert not missing, missing
+    headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    assert [os.path.basename(h) for h in headers] == ["oalgpu.h"]                 # (the measurement header lives in tools/measure/)
+    declared = _declared(headers[0])
+    assert len(declared) >= 110 and not [n for n in declared if "_debug_" in n]
+    exported = _exported(oalgpu.LIB_PATH)
+    assert not [n for n in exported if not n.startswith("oalgpu_")], [n for n in exported if not n.startswith("oalgpu_")][:10]
+    assert not [n for n in exported if "_debug_" in n]
+    assert sorted(declared) == exported, (sorted(declared - set(exported)), sorted(set(exported) - declared))
+    assert not [n for n in declared if not hasattr(oalgpu.lib, n)]
+
+
+def test_measurement_build_is_the_product_plus_the_declared_aids():
+    """`make measure`: liboalgpu_measure.so = the same exports + the oalgpu_*debug_* readers tools/measure/oalgpu_measure.h declares;
+    liboalmeasure.so exports oalmeasure_* and needs nothing of liboalgpu.so beyond its public symbols"""
+    measure = os.path.join(oalgpu.PKG_DIR, "liboalgpu_measure.so")
+    aids = os.path.join(ROOT, "tools", "measure", "liboalmeasure.so")
+    if not (os.path.exists(measure) and os.path.exists(aids)):
+        pytest.skip("make measure was not run")
+    mh = _declared(os.path.join(ROOT, "tools", "measure", "oalgpu_measure.h"))
+    extra = sorted(set(_exported(measure)) - set(_exported(oalgpu.LIB_PATH)))
+    assert extra == sorted(mh) and len(extra) == 5 and all("_debug_" in n for n in extra), extra
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", aids], check=True, capture_output=True, text=True).stdout
+    wanted = {line.split()[-1] for line in out.splitlines() if "oalgpu_" in line}
+    assert wanted and wanted <= set(_exported(oalgpu.LIB_PATH)), wanted
+    assert [n for n in _exported(aids) if n.startswith("oalmeasure_")] == ["oalmeasure_event_floor_ms", "oalmeasure_pipelined_run", "oalmeasure_submit_cost"]
 
 
 def test_tables_match_reference_golden():

@@ -2,9 +2,11 @@
 (contexts created with OALGPU_CTX_PROFILE | OALGPU_CTX_SERIAL; add 1 = OALGPU_CTX_FIR_VALU as argv[1])."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools", "measure"))
 import numpy as np
 import oalgpu
+import oalmeasure
+oalmeasure.use_measurement_build()      # liboalgpu_measure.so: the product's sources + the oalgpu_debug_* readers
 from oalgpu import synth
 import bench
 V = 4096
@@ -18,7 +20,6 @@ for k in range(6):
     sc.mix(1024, post_process=True)
 sc.sync()
 out = np.zeros((V, 8), np.uint64)
-oalgpu.lib.oalgpu_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p]
 rc = oalgpu.lib.oalgpu_debug_phase_times(sc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0, rc
 t = out.astype(np.int64)
 names = ["src in LDS", "resample", "biquad", "hist+x' build", "request next", "FIR(+old pass)", "write-back"]
@@ -61,7 +62,6 @@ print("workgroups of the first half: mean of max=%.0f max=%.0f; second half: mea
 
 # per-wavefront stamps: entry, first voice requested+parked (pass 0), voices done, partial stored
 wt = np.zeros((V, 8), np.uint64); nw = C.c_uint32(0)
-oalgpu.lib.oalgpu_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
 rc = oalgpu.lib.oalgpu_debug_wave_times(sc.h, wt.ctypes.data_as(C.c_void_p), C.byref(nw)); assert rc == 0, rc
 wt = wt[:nw.value].astype(np.int64)
 d0 = wt[:, 1] - wt[:, 0]; d1 = wt[:, 2] - wt[:, 1]; d2 = wt[:, 3] - wt[:, 2]; tot = wt[:, 3] - wt[:, 0]

@@ -2,9 +2,11 @@
 send contexts (BASELINE configs 2, 4, 5): python tools/phase_times_lines.py CONFIG [VOICES]."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "openal-soft_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools", "measure"))
 import numpy as np
 import oalgpu
+import oalmeasure
+oalmeasure.use_measurement_build()      # liboalgpu_measure.so: the product's sources + the oalgpu_debug_* readers
 from oalgpu import synth
 import bench
 config = int(sys.argv[1]) if len(sys.argv) > 1 else 2
@@ -20,7 +22,6 @@ for k in range(6):
 sc.sync()
 print("kernel:", sc.voice_kernel_name())
 out = np.zeros((V, 8), np.uint64)
-oalgpu.lib.oalgpu_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p]
 rc = oalgpu.lib.oalgpu_debug_phase_times(sc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0, rc
 t = out.astype(np.int64)
 names = ["src in LDS", "resample", "filters+rows", "hist+x' build", "request next", "FIR/park", "write-back"]
@@ -35,7 +36,6 @@ if config == 4:
         vs = [v for v in allv if v % 5 == ns]
         print(f"  {ns} sends:", " ".join(f"{n}={d[vs, i].mean():.0f}" for i, n in enumerate(names)), "sum=%.0f" % d[vs].sum(axis=1).mean())
 wt = np.zeros((V, 8), np.uint64); nw = C.c_uint32(0)
-oalgpu.lib.oalgpu_debug_wave_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
 rc = oalgpu.lib.oalgpu_debug_wave_times(sc.h, wt.ctypes.data_as(C.c_void_p), C.byref(nw)); assert rc == 0, rc
 wt = wt[:nw.value].astype(np.int64)
 d0 = wt[:, 1] - wt[:, 0]; d1 = wt[:, 2] - wt[:, 1]; d2 = wt[:, 3] - wt[:, 2]; tot = wt[:, 3] - wt[:, 0]

@@ -8,13 +8,15 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "openal-soft_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "measure"))
 import oalgpu  # noqa: E402
+import oalmeasure  # noqa: E402
+oalmeasure.use_measurement_build()
 
 rng = np.random.default_rng(0)
 g = oalgpu.Reverb(4)
 if len(sys.argv) > 1 and sys.argv[1] == "fast":
     g.set_math_mode(oalgpu.MATH_FAST)
-oalgpu.lib.oalgpu_reverb_debug_enable_phase_times.argtypes = [C.c_void_p]
 assert oalgpu.lib.oalgpu_reverb_debug_enable_phase_times(g.h) == 0
 g.update(oalgpu.ReverbProps.make(modulation_depth=0.5))
 x = (rng.standard_normal((4, 1024)) * 0.1).astype(np.float32)
@@ -22,7 +24,6 @@ o = np.zeros((4, 1024), np.float32)
 for k in range(20):
     g.process(x, o)
 buf = (C.c_ulonglong * 256)()
-oalgpu.lib.oalgpu_reverb_debug_phase_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert oalgpu.lib.oalgpu_reverb_debug_phase_times(g.h, buf) == 0
 t = np.array(buf, np.int64).reshape(4, 8, 8)
 k0 = t[0, 7, 0]
