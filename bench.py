@@ -778,7 +778,8 @@ def main():
                                    "oalgpu_read_dry (D2H, sync); no overlap -- a latency, not the throughput `value` is",
                        "repeat_ms_per_step": {"n": len(extra), "median": float(np.median(extra)) if extra else None,
                                               "min": min(extra) if extra else None, "max": max(extra) if extra else None},
-                       "parallelism": f"voice-shard x{world}" + (" + ncclReduce of the bus block to rank 0, issued by the library" if world > 1 else "")},
+                       "parallelism": f"voice-shard x{world}" + ((" + the bus block summed to rank 0 through host-staged shared memory (a rehearsal of the code path on one device, not RCCL)"
+                                                                       if host_transport else " + ncclReduce of the bus block to rank 0, issued by the library") if world > 1 else "")},
             # 68 flop/B: the path sits above the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 20 flop/B), so the binding
             # roofline is arithmetic.  `achieved` prices the ALGORITHMIC fp32 flops of the path against
             # the fp32 peak, 157.3 TFLOP/s -- the same figure for v_pk_fma_f32 and for fp32 MFMA on gfx950 -- as
