@@ -95,9 +95,12 @@ def close_to(got, want, what, terms=(1, 1)):
     return scale
 
 
-def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_at=None, sample_fmt="f32", ctx_flags=0):
+def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_at=None, sample_fmt="f32", ctx_flags=0, via_blocks=False):
     """check_at: the updates (0-based) after which buses and voice states are compared (None: every one).  Between
-    checkpoints nothing of the product is read: its two-stream pipeline runs on unsynchronised, as in the bench."""
+    checkpoints nothing of the product is read: its two-stream pipeline runs on unsynchronised, as in the bench.
+    via_blocks: the product takes every update's parameters as a parameter block resident in HBM and runs the updates up to
+    the next checkpoint in ONE oalgpu_mix_update_run call -- bench.py's timed loop, the path on which the
+    OALGPU_CTX_APPLY_IN_VOICE_KERNEL / _FUSED_REDUCE / _RESIDENT contexts differ from the plain one."""
     import oalgpu
     from oalgpu import synth
     import bench
@@ -123,14 +126,25 @@ def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_a
     allv = list(range(nvoices))
     moving = [v for v in allv if gscript.is_moving(v)]
     sounded = False
+    blocks, first_pending = [], 0
+    if via_blocks:
+        assert len(set(todo)) == 1, "oalgpu_mix_update_run: one length for the run"
+        blocks = [gsc.param_block(allv if k == 0 else moving, bench.param_array(oalgpu, gscript, allv if k == 0 else moving, k))
+                  for k in range(len(todo))]
+        if ctx_flags & oalgpu.CTX_RESIDENT:
+            gsc.resident_set_short_run(0)           # (the checkpoints keep the launches short: no falling back to launches per update)
     for k in range(len(todo)):
         n = todo[k]
         voices = allv if k == 0 else moving
-        gsc.set_params_batch(voices, bench.param_array(oalgpu, gscript, voices, k))
         for v in voices:
             osc.set_params(v, oscript.fill(ol.VoiceParams(), v, k))
         # ---- the product: one pipelined update, effects and post-process included
-        gsc.mix(n, post_process=True)
+        if not via_blocks:
+            gsc.set_params_batch(voices, bench.param_array(oalgpu, gscript, voices, k))
+            gsc.mix(n, post_process=True)
+        elif check_at is None or k in check_at or k == len(todo) - 1:
+            gsc.mix_run(blocks[first_pending:k + 1], n, post_process=True)
+            first_pending = k + 1
         # ---- the reference: voice loop, then the slots' effects into the dry lines, then the post-process
         osc.mix(n, post_process=False)
         wets = [osc.wet(s) for s in range(nslots)]
@@ -168,6 +182,9 @@ def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_a
             hg, ho = np.array(g.hrtf_history[:]), np.array(o.hrtf_history[:])
             assert np.abs(hg - ho).max() <= 2e-5 * max(1.0, np.abs(ho).max()) + 1e-7, v
             assert tuple(g.hrtf_old_delay) == tuple(o.hrtf_old_delay), v
+    if via_blocks and ctx_flags & oalgpu.CTX_RESIDENT:
+        info = gsc.resident_stats()
+        assert info["enabled"] == 1 and info["failed"] == 0 and info["updates"] == len(todo), info
     for e in oeffects:
         e.close()
     gsc.close()
@@ -211,6 +228,29 @@ def test_config2_parity_after_updates_1_2_8_50(synth_mhr, sample_fmt):
 def test_config3_parity_after_updates_1_2_8_50(sample_fmt):
     assert os.path.exists(REAL_MHR), "tests/golden/default_hrtf.mhr is a committed fixture"
     run_config(3, 4096, REAL_MHR, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt)
+
+
+@pytest.mark.parametrize("sample_fmt", ["f32", "i16"])
+def test_config4_parity_after_updates_1_2_8_50(synth_mhr, sample_fmt):
+    run_config(4, 8192, synth_mhr, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt)
+
+
+@pytest.mark.parametrize("sample_fmt", ["f32", "i16"])
+def test_config5_parity_after_updates_1_2_8_50_on_the_default_data_set(sample_fmt):
+    assert os.path.exists(REAL_MHR), "tests/golden/default_hrtf.mhr is a committed fixture"
+    run_config(5, 4096, REAL_MHR, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt)
+
+
+@pytest.mark.parametrize("mode", ["plain", "apply_in_voice_kernel", "fused_reduce", "resident"])
+def test_config3_block_driven_contexts_against_the_reference(mode):
+    """bench.py's timed loop -- parameter blocks resident in HBM, runs of updates in one oalgpu_mix_update_run -- held against
+    the compiled reference directly at full size, fifty updates, for the plain context and each opt-in variant of the update
+    pipeline (the voice kernel installing the next block itself; the reduction fused into the post-process launch; ONE launch
+    of the voice kernel that stays on the device across the run's updates)."""
+    import oalgpu
+    flags = {"plain": 0, "apply_in_voice_kernel": oalgpu.CTX_APPLY_IN_VOICE_KERNEL, "fused_reduce": oalgpu.CTX_FUSED_REDUCE,
+             "resident": oalgpu.CTX_RESIDENT}[mode]
+    run_config(3, 4096, REAL_MHR, todo=(1024,) * 50, check_at=SCHEDULE, ctx_flags=flags, via_blocks=True)
 
 
 @pytest.mark.parametrize("config", [2, 5])

@@ -9,7 +9,12 @@ its own maximum) added up in float64, and both the full-size reference run and t
     |gpu - truth| <= |reference - truth| + 1e-7 max|truth|      (maximum and RMS, every update)
 
 i.e. the GPU is at least as close to the exact mix as the reference is -- whatever separates the two in the
-full-size parity test is the reference's own noise.  Both data sets (synthetic, Default HRTF.mhr)."""
+full-size parity test is the reference's own noise.  Both data sets (synthetic, Default HRTF.mhr).
+
+The same for BASELINE configs[1] (4096 voices into 5 dry lines, no HRTF): there the product keeps every line's sum in
+the wavefront's registers (MixRowAcc, csrc/voice_wave.hip) and the reference adds one voice after the other into the
+shared line (Mix_, core/mixer/mixer_c.cpp:150-186) -- one rounding per voice and sample instead of 64, so the
+reference's own noise is smaller and the product's has to be as well."""
 import os
 import sys
 
@@ -26,6 +31,7 @@ pytestmark = pytest.mark.gpu
 V = 4096
 CHUNK = 16
 UPDATES = 3
+LINE_MARGIN = 1e-7            # (of max|truth|; what the product may be worse by than the reference)
 
 
 def _chunk_truth(L, synth, bufs, v0, todo):
@@ -99,5 +105,67 @@ def test_gpu_is_as_close_to_the_exact_mix_as_the_reference(synth_mhr, data_set):
     gt, rt = gsc.hrtf_accum().astype(np.float64), osc.hrtf_accum().astype(np.float64)
     scale = float(np.abs(truth_tail).max())
     assert np.abs(gt - truth_tail).max() <= np.abs(rt - truth_tail).max() + 1e-7 * max(scale, 1e-3)
+    gsc.close()
+    osc.close()
+
+
+def _chunk_truth_lines(L, synth, bufs, v0, todo):
+    """voices [v0, v0 + CHUNK) of the config-2 scene alone on the reference: the five dry lines per update"""
+    sc = ol.Scene(L, sample_rate=48000, num_dry=5, num_real=0, num_sends=0, num_slots=0, wet_channels=4, hrtf=False)
+    script = synth.SceneScript(2, CHUNK, v0)
+    handles = {}
+    for i in range(CHUNK):
+        b = script.buffer_of(i, len(bufs))
+        if b not in handles:
+            handles[b] = sc.add_buffer(bufs[b], ol.FMT_FLOAT)
+        sc.add_voice(handles[b], True, position=script.start_position(i))
+    outs = []
+    for k, n in enumerate(todo):
+        for i in range(CHUNK):
+            if k == 0 or script.is_moving(i):
+                sc.set_params(i, script.fill(ol.VoiceParams(), i, k))
+        sc.mix(n, post_process=False)
+        outs.append(sc.dry()[:5, :n].astype(np.float64))
+    sc.close()
+    return outs
+
+
+def test_line_accumulators_are_as_close_to_the_exact_mix_as_the_reference(synth_mhr):
+    import oalgpu
+    from oalgpu import synth
+    import bench
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    L = _oracle()
+    todo = (1024, 1000, 1024)
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    with open(synth_mhr, "rb") as f:
+        api._mhr = f.read()
+    gsc, gscript = bench.build_scene(oalgpu, synth, api, 2, V, 0, api._mhr, 0)
+    assert "DeviceLayout, 6" in gsc.voice_kernel_name(), gsc.voice_kernel_name()      # (the six-line register accumulators)
+    osc, oscript, _ = build_reference_scene(L, synth, 2, V, synth_mhr)
+    truth = [np.zeros((5, n)) for n in todo]
+    bufs = synth.scene_buffers(2, V)
+    for v0 in range(0, V, CHUNK):
+        outs = _chunk_truth_lines(L, synth, bufs, v0, todo)
+        for k in range(len(todo)):
+            truth[k] += outs[k]
+    allv = list(range(V))
+    moving = [v for v in allv if gscript.is_moving(v)]
+    for k, n in enumerate(todo):
+        voices = allv if k == 0 else moving
+        gsc.set_params_batch(voices, bench.param_array(oalgpu, gscript, voices, k))
+        for v in voices:
+            osc.set_params(v, oscript.fill(ol.VoiceParams(), v, k))
+        gsc.mix(n, post_process=False)
+        osc.mix(n, post_process=False)
+        g = gsc.dry()[:5, :n].astype(np.float64)
+        r = osc.dry()[:5, :n].astype(np.float64)
+        scale = float(np.abs(truth[k]).max())
+        eg, er = np.abs(g - truth[k]), np.abs(r - truth[k])
+        print(f"config 2 update {k}: |gpu - truth| max {eg.max() / scale:.2e} rms {np.sqrt((eg ** 2).mean()) / scale:.2e}; "
+              f"|reference - truth| max {er.max() / scale:.2e} rms {np.sqrt((er ** 2).mean()) / scale:.2e} (of max|truth| {scale:.3e})")
+        assert scale > 0.1, "the scene must sound"
+        assert eg.max() <= er.max() + LINE_MARGIN * scale, (k, eg.max() / scale, er.max() / scale)
+        assert np.sqrt((eg ** 2).mean()) <= np.sqrt((er ** 2).mean()) + LINE_MARGIN * scale, k
     gsc.close()
     osc.close()
