@@ -184,7 +184,8 @@ typedef struct oalgpu_context_desc {
                                    * instead of the matrix pipe in split half precision */
 #define OALGPU_CTX_PROFILE  2u    /* the voice kernel's measurement variant: per-phase cycle stamps and stage ablation,
                                    * read and set through the measurement build only (tools/measure/oalgpu_measure.h) */
-#define OALGPU_CTX_STREAM_ROWS 8u  /* FAST dry-line / send contexts with <= 8 mix lines: leave stream rows in HBM and mix them in the
+#define OALGPU_CTX_STREAM_ROWS 8u  /* FAST contexts that would keep their lines in the wavefronts' registers (dry-line contexts without sends
+                                   * and <= 6 lines; HRTF contexts with one first-order send): leave stream rows in HBM and mix them in the
                                    * voice kernel's tail (the path of contexts with more lines) instead of accumulating the
                                    * lines in the wavefronts' registers: for A/B runs and tests of the row path */
 #define OALGPU_CTX_APPLY_IN_VOICE_KERNEL 16u /* pipelined HRTF contexts: oalgpu_mix_update is submitted with the NEXT library call on the
@@ -322,9 +323,11 @@ typedef struct oalgpu_voice_params {
     int32_t  resampler;                              /* props.mResampler */
     oalgpu_filter_params direct_filter;              /* alc/alu.cpp:1619-1637 */
     float    dry_gains[OALGPU_MAX_OUTPUT_CHANNELS];  /* mDryParams.Gains.Target */
-    float    hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread; /* getCoeffs arguments, alu.cpp:1214; hrtf_dist =
-                                                      * OALGPU_HRTF_KEEP_TARGET: the voice's HRTF target, delays and gain
-                                                      * stay as they are (see oalgpu_voice_set_hrtf_targets) */
+    float    hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread; /* getCoeffs arguments, alu.cpp:1214.  A distance is never negative
+                                                      * in the reference (a vector norm, alu.cpp:1761, scaled: :1214); NEGATIVE values of hrtf_dist
+                                                      * are reserved: OALGPU_HRTF_KEEP_TARGET (-1) = the voice's HRTF target,
+                                                      * delays and gain stay as they are (see oalgpu_voice_set_hrtf_targets),
+                                                      * any other negative value is rejected with OALGPU_ERR_INVALID */
     float    hrtf_gain;                              /* Hrtf.Target.Gain */
     int32_t  send_slot[OALGPU_MAX_SENDS];            /* -1: mSend[i].Buffer empty */
     oalgpu_filter_params send_filter[OALGPU_MAX_SENDS];
@@ -579,19 +582,24 @@ int oalgpu_voices_readback(oalgpu_context *ctx, const uint32_t *voices, size_t c
 
 /* ---- the pipelined host boundary: an update's moved voices in, its output lines out, nothing waits ---------------------
  * What CalcPanningAndFilters (alc/alu.cpp:1512-1657) hands over for a voice whose direction moved while its filter
- * targets stayed: the HRTF direction and gain.  oalgpu_voice_move_async evaluates the index half of
- * HrtfStore::getCoeffs (core/hrtf.cpp:192-245) on the host into a pinned ring slot and queues the kernel that installs
- * the records in front of the next oalgpu_mix_update -- it reads them straight out of the pinned slot, 64 bytes per moved
- * voice over PCIe: one runtime call --; it returns without waiting for any of that.  HRTF contexts only. */
+ * targets stayed: the HRTF direction and gain.  oalgpu_voice_move_async copies the raw 24-byte records into a ring slot --
+ * device memory mapped into the host's address space where the box has a large BAR (probed once per context with a kernel
+ * that reads what the host stored), pinned host memory otherwise -- and queues the kernel that installs them in front of the
+ * next oalgpu_mix_update: it reads the records out of the slot and evaluates BOTH halves of HrtfStore::getCoeffs
+ * (core/hrtf.cpp:192-260: the indices and blend weights, then the weighted sum of the four responses) on the device.
+ * One runtime call; it returns without waiting for any of that.  HRTF contexts only. */
 typedef struct oalgpu_voice_move {
     uint32_t voice;
     float hrtf_ev, hrtf_az, hrtf_dist, hrtf_spread;   /* as in oalgpu_voice_params */
     float hrtf_gain;
 } oalgpu_voice_move;
 int oalgpu_voice_move_async(oalgpu_context *ctx, const oalgpu_voice_move *moves, size_t count);
-/* Queues the copy of the update's output lines -- the real lines of an HRTF / decoded context (left, right, ...), else
- * the dry lines; [line][1024] floats -- into a pinned ring slot behind the update's post-process and returns a ticket;
- * oalgpu_output_wait blocks until that copy has landed and hands the lines over.  Four tickets may be outstanding. */
+/* The update's output lines -- the real lines of an HRTF / decoded context (left, right, ...), else the dry lines;
+ * [line][1024] floats -- two updates late without a copy in between: HRTF contexts with a post-process have the
+ * post-process kernel store the lines into a pinned ring slot itself and raise the slot's sequence number (no copy launch,
+ * no runtime call on the host: oalgpu_output_wait polls that word); other contexts queue a device-to-host copy behind the
+ * update.  Returns a ticket; oalgpu_output_wait blocks until the lines have landed and hands them over.  Three tickets may be
+ * outstanding (a fourth call fails with OALGPU_ERR_CAPACITY: the slot it would take is still uncollected). */
 int oalgpu_read_output_async(oalgpu_context *ctx, uint32_t *ticket);
 int oalgpu_output_wait(oalgpu_context *ctx, uint32_t ticket, float *out, size_t out_floats);
 

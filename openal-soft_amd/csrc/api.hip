@@ -1857,7 +1857,10 @@ static int BuildParamRecords(oalgpu_context *c, const uint32_t *voices, const oa
         }
         r.hrtfDir[0] = p.hrtf_ev; r.hrtfDir[1] = p.hrtf_az; r.hrtfDir[2] = p.hrtf_dist; r.hrtfDir[3] = p.hrtf_spread;
         r.hrtfGain = p.hrtf_gain;
-        r.keepHrtf = (c->L.hrtf && p.hrtf_dist < 0.0f) ? 1u : 0u;       // OALGPU_HRTF_KEEP_TARGET
+        // negative distances are reserved (the reference never passes one: a vector norm, alu.cpp:1761): -1 keeps the target
+        if(c->L.hrtf && p.hrtf_dist < 0.0f && p.hrtf_dist != OALGPU_HRTF_KEEP_TARGET)
+            return Fail(OALGPU_ERR_INVALID, "voice parameters: hrtf_dist < 0 is reserved (OALGPU_HRTF_KEEP_TARGET = -1)");
+        r.keepHrtf = (c->L.hrtf && p.hrtf_dist == OALGPU_HRTF_KEEP_TARGET) ? 1u : 0u;
         if(c->L.hrtf && c->hrtfLoaded && !r.keepHrtf)
         {   // the index half of HrtfStore::getCoeffs (core/hrtf.cpp:192-245) on the host's copy of the store
             const HrirBlend b = HrtfBlendFor(hostStore, p.hrtf_ev, p.hrtf_az, p.hrtf_dist, p.hrtf_spread);

@@ -118,3 +118,23 @@ def test_async_boundary_against_the_reference(synth_mhr):
             (o.play_state, o.position, o.position_frac, o.has_buffer, o.fading), v
     sc.close()
     osc.close()
+
+
+def test_negative_hrtf_distances_are_reserved(synth_mhr):
+    """include/oalgpu.h: hrtf_dist = OALGPU_HRTF_KEEP_TARGET (-1) keeps the voice's target; any other negative distance is
+    rejected (the reference passes a vector norm, alc/alu.cpp:1761, :1214)"""
+    import oalgpu
+    from oalgpu import synth
+    import bench
+    mhr = open(synth_mhr, "rb").read()
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    api._mhr = mhr
+    sc, script = bench.build_scene(oalgpu, synth, api, 3, 8, 0, mhr, 0)
+    arr = bench.param_array(oalgpu, script, [0, 1], 0)
+    sc.set_params_batch([0, 1], arr)
+    arr[1].hrtf_dist = -1.0
+    sc.set_params_batch([0, 1], arr)
+    arr[1].hrtf_dist = -2.0
+    with pytest.raises(oalgpu.OalgpuError):
+        sc.set_params_batch([0, 1], arr)
+    sc.close()
