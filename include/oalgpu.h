@@ -209,6 +209,13 @@ typedef struct oalgpu_context_desc {
                                    * should call oalgpu_sync: the kernel holds the device's compute units while it waits, and gives up (the
                                    * context then reports an error and launches per update) after 2 s without a doorbell inside a wait.
                                    * Contexts the mode does not cover ignore the flag. */
+#define OALGPU_CTX_SLICE_LINES 128u /* FAST dry-line contexts whose lines do not fit the wavefronts' registers (sends, or 7 .. 24 mix lines; no
+                                   * near-field control): instead of leaving a 4 KB stream row per mixed signal in HBM and mixing the rows in
+                                   * the voice kernel's tail, cut the update into four 256-frame slices, one per wavefront of a workgroup, each
+                                   * of which walks all of the workgroup's voices and keeps its 24 lines x 4 frames per lane in registers: no
+                                   * row ever leaves the CU (csrc/voice_slice.hip).  Measured on BASELINE configs[3]: the voice kernel's
+                                   * HBM traffic falls to a third and its time nearly doubles -- the per-voice work is done four times and the
+                                   * kernel is instruction-bound: an opt-in variant, for A/B runs.  Other contexts ignore it. */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 

@@ -1201,17 +1201,25 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.hrirs = nullptr;
     for(uint32_t &n : L.chansPerOrder) n = 0;
     L.accLines = 0;
-    if(c->useWave && !(desc->flags & OALGPU_CTX_STREAM_ROWS)) L.accLines = WaveKernelAccLines(L);
+    L.sliceLines = 0;
+    if(c->useWave && !(desc->flags & OALGPU_CTX_STREAM_ROWS))
+    {
+        L.accLines = WaveKernelAccLines(L);
+        // dry lines AND sends, or more lines than the wavefront-per-voice kernel holds in registers: stream rows, or -- opt-in,
+        // OALGPU_CTX_SLICE_LINES -- a wavefront per 256-frame slice (voice_slice.hip: a third of the traffic, twice the time); the
+        // measurement variants (OALGPU_CTX_PROFILE) exist for the stream-row kernel only
+        if(!L.accLines && (desc->flags & OALGPU_CTX_SLICE_LINES) && !(desc->flags & OALGPU_CTX_PROFILE)) L.sliceLines = SliceKernelLines(L);
+    }
     if(c->useWave && (!L.hrtf || L.numSends))
     {   // one partial bus per workgroup, from the wavefronts' line accumulators (accLines) or from stream rows mixed by the
         // voice kernel's tail
         L.lineStride = L.mixLines <= 8 ? 8u : (L.mixLines <= 16 ? 16u : 32u);
         L.streamsPerVoice = 2u + L.numSends;
     }
-    if(c->useWave && (!L.hrtf || L.numSends) && !L.accLines) { if(int rc = AllocStreamRows(c.get())) return rc; }
+    if(c->useWave && (!L.hrtf || L.numSends) && !L.accLines && !L.sliceLines) { if(int rc = AllocStreamRows(c.get())) return rc; }
     HIP_TRY(c->partLines.alloc(size_t{L.numLineGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
     // the two-stream pipeline of oalgpu_mix_update alternates between two sets of partial buses
-    HIP_TRY(c->partLines2.alloc(c->useWave && (L.streams || L.accLines) ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
+    HIP_TRY(c->partLines2.alloc(c->useWave && (L.streams || L.accLines || L.sliceLines) ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
     c->partLinesBuf[0] = c->partLines.p; c->partLinesBuf[1] = c->partLines2.p;
     HIP_TRY(c->partHrtf.alloc(L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0)); L.partHrtf = c->partHrtf.p;
     HIP_TRY(c->partHrtf2.alloc(c->useWave && L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
@@ -1772,6 +1780,7 @@ int oalgpu_context_set_nfc(oalgpu_context *c, float w1, const uint32_t channels_
     if(c->useWave)
     {   // the wavefront kernel: every order adds one stream row per voice (near-field contexts mix through stream rows)
         L.accLines = 0;
+        L.sliceLines = 0;
         const uint32_t spv = 2u + L.numSends + orders;
         HIP_TRY(c->streams.alloc(nv * spv * kLine)); HIP_TRY(c->streams.zero());
         HIP_TRY(c->lineGains.alloc(nv * spv * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
@@ -2977,7 +2986,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     const uint32_t p = c->parity;
     DeviceLayout L = c->L;
     L.partHrtf = c->partHrtfBuf[p];
-    if(L.streams || L.accLines) L.partLines = c->partLinesBuf[p];
+    if(L.streams || L.accLines || L.sliceLines) L.partLines = c->partLinesBuf[p];
     // main stream: this update's voices; its partial-bus buffer was last read by the reduction
     // of two updates ago
     // (almost always long done: then no barrier packet goes into the main queue in front of the voice kernel)

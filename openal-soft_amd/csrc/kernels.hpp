@@ -112,6 +112,7 @@ struct DeviceLayout {
     uint32_t firMfma;                       // voice_wave.hip: the HRTF FIR (IrSize <= 64) on the matrix pipe in split half
                                             // precision (default) instead of packed VALU FMAs (OALGPU_CTX_FIR_VALU)
     uint32_t mixLines;                      // lines accumulated by the voice kernel
+    uint32_t sliceLines;                    // voice_slice.hip: the context's voices are mixed a wavefront per 256-frame slice (0 = no)
     uint32_t accLines;                      // voice_wave.hip: the mix lines accumulate in the wavefronts' registers (<= 8 lines;
                                             // the kernel's ACCL: 4, 6 or 8) instead of leaving stream rows; 0 = stream rows
     // tables + buffers
@@ -457,6 +458,10 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, const ParamRecord *nextRecs = nullptr, const int32_t *nextMap = nullptr,
     const float *nextRows = nullptr);
 bool WaveKernelAppliesRecords(const DeviceLayout &L);
+// ---- launcher (voice_slice.hip): dry-line / send contexts with up to 24 mix lines, a wavefront per 256-frame slice ----
+uint32_t SliceKernelLines(const DeviceLayout &L);        // the accumulator lines the slice kernel would run this layout with (0: not its)
+const char *SliceKernelName();
+hipError_t LaunchVoiceSlice(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
 // the resident launch of the HRTF hot path (OALGPU_CTX_RESIDENT): see ResidentDoor above
 bool WaveKernelHasResident(const DeviceLayout &L);
 hipError_t LaunchVoiceWaveResident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop);

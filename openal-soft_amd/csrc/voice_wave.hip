@@ -1673,6 +1673,7 @@ uint32_t WaveKernelAccLines(const DeviceLayout &L)
 
 const char *WaveKernelName(const DeviceLayout &L)
 {
+    if(L.sliceLines) return SliceKernelName();
     const bool sends = L.numSends != 0;
     if(L.accLines)
         return !L.hrtf ? "VoiceWaveKernel<17, 64, 1, false, false, false, DeviceLayout, 6>" : "VoiceWaveKernel<17, 64, 0, true, true, false, DeviceLayout, 4>";
@@ -1696,6 +1697,7 @@ bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.hrtf != 0; }
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)
 {
+    if(L.sliceLines) return LaunchVoiceSlice(s, L, samplesToDo, evStart, evStop);       // (voice_slice.hip)
     const NextBlock next{nextRecs, L.hrtf ? nextMap : nullptr, L.hrtf ? nextRows : nullptr, ResidentArgs{}};
     const uint32_t groups = WaveKernelGroups(L);
     const bool sends = L.numSends != 0;

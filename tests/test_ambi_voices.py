@@ -43,7 +43,7 @@ def test_prescale_is_live():
 
 # ------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "fast, a wavefront per slice"])
 @pytest.mark.parametrize("kw", [dict(), dict(sends=0, nambi=2, nmono=0), dict(todo=(333, 1024, 64, 1000), seed=5)],
                          ids=["default", "ambi_only", "ragged"])
 def test_gpu_matches_oracle(mode, kw):
@@ -52,7 +52,7 @@ def test_gpu_matches_oracle(mode, kw):
     which = "ref" if ol.available("ref") else "port"
     L = ol.load(which)
     L.L.oal_set_simd(1)
-    api = oalgpu.Api(oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST)
+    api = oalgpu.Api(oalgpu.MATH_EXACT if mode == "exact" else oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_SLICE_LINES if "slice" in mode else 0)
     a = ambi_cases.run(api, **kw).astype(np.float64)
     b = ambi_cases.run(L, **kw).astype(np.float64)
     # sums over several voices: the multi-voice tolerance of tests/test_gpu_parity.py

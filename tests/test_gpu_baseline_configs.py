@@ -95,7 +95,8 @@ def close_to(got, want, what, terms=(1, 1)):
     return scale
 
 
-def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_at=None, sample_fmt="f32", ctx_flags=0, via_blocks=False):
+def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_at=None, sample_fmt="f32", ctx_flags=0, via_blocks=False,
+               expect_kernel=None):
     """check_at: the updates (0-based) after which buses and voice states are compared (None: every one).  Between
     checkpoints nothing of the product is read: its two-stream pipeline runs on unsynchronised, as in the bench.
     via_blocks: the product takes every update's parameters as a parameter block resident in HBM and runs the updates up to
@@ -114,6 +115,8 @@ def run_config(config, nvoices, mhr_path, todo=(1024, 1024, 1024, 1024), check_a
     nslots = {4: 4, 5: 1}.get(config, 0)
 
     gsc, gscript = bench.build_scene(oalgpu, synth, api, config, nvoices, 0, mhr, 0, sample_fmt=sample_fmt)
+    if expect_kernel is not None:
+        assert expect_kernel in gsc.voice_kernel_name(), gsc.voice_kernel_name()
     conv_ir = None
     if config == 5:
         # the reference pans a mono response to the front (ConvolutionProps orientation, convolution.cpp:511-620)
@@ -205,7 +208,23 @@ def test_config3_4096_hrtf_voices(synth_mhr, data_set):
 
 
 def test_config4_8192_voices_four_reverb_slots(synth_mhr):
-    run_config(4, 8192, synth_mhr)
+    run_config(4, 8192, synth_mhr, expect_kernel="VoiceWaveKernel")
+
+
+def test_config4_a_wavefront_per_slice(synth_mhr):
+    """OALGPU_CTX_SLICE_LINES: the 21 mix lines in the registers of four wavefronts that own a 256-frame slice each
+    (csrc/voice_slice.hip) -- nothing of a voice's rows leaves the CU -- against the reference at full size."""
+    import oalgpu
+    run_config(4, 8192, synth_mhr, ctx_flags=oalgpu.CTX_SLICE_LINES, expect_kernel="VoiceSliceKernel")
+
+
+@pytest.mark.parametrize("path", ["stream rows", "a wavefront per slice"])
+def test_config4_odd_update_lengths_and_a_ragged_last_workgroup(synth_mhr, path):
+    """Updates that end inside a 256-frame slice, inside the gain ramp (40 < 64 frames) or inside the first slice, and a
+    voice count that leaves the last workgroup partly empty."""
+    import oalgpu
+    run_config(4, 2039, synth_mhr, todo=(1024, 1000, 300, 40, 257, 1024), ctx_flags=oalgpu.CTX_SLICE_LINES if "slice" in path else 0,
+               expect_kernel="VoiceSliceKernel" if "slice" in path else "VoiceWaveKernel")
 
 
 def test_config5_4096_hrtf_voices_and_a_65536_tap_convolution(synth_mhr):
@@ -235,6 +254,12 @@ def test_config4_parity_after_updates_1_2_8_50(synth_mhr, sample_fmt):
     run_config(4, 8192, synth_mhr, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt)
 
 
+def test_config4_a_wavefront_per_slice_after_updates_1_2_8_50(synth_mhr):
+    import oalgpu
+    run_config(4, 8192, synth_mhr, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt="i16", ctx_flags=oalgpu.CTX_SLICE_LINES,
+               expect_kernel="VoiceSliceKernel")
+
+
 @pytest.mark.parametrize("sample_fmt", ["f32", "i16"])
 def test_config5_parity_after_updates_1_2_8_50_on_the_default_data_set(sample_fmt):
     assert os.path.exists(REAL_MHR), "tests/golden/default_hrtf.mhr is a committed fixture"
@@ -259,4 +284,4 @@ def test_stream_row_path_of_the_few_line_contexts(synth_mhr, config):
     the contexts with more than 6 (4) lines -- stream rows mixed in the voice kernel's tail -- which must agree with the
     reference just the same."""
     import oalgpu
-    run_config(config, 4096, synth_mhr, ctx_flags=oalgpu.CTX_STREAM_ROWS)
+    run_config(config, 4096, synth_mhr, ctx_flags=oalgpu.CTX_STREAM_ROWS, expect_kernel="VoiceWaveKernel")

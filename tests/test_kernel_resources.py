@@ -74,6 +74,18 @@ def test_wavefront_voice_kernels_do_not_spill(voice_wave):
         assert 2 * m["group_segment_fixed_size"] <= 160 * 1024, (name, m)   # two workgroups per CU
 
 
+def test_slice_voice_kernel_keeps_its_lines_in_registers(tmp_path):
+    """OALGPU_CTX_SLICE_LINES (csrc/voice_slice.hip): 24 lines x 4 frames per lane beside the resampler, no scratch, two
+    workgroups per CU."""
+    _, per_file = makefile_flags()
+    assert "-disable-machine-licm" in per_file["voice_slice"]
+    meta = kernel_metadata(tmp_path, "voice_slice.hip", per_file["voice_slice"])
+    (name, m), = [(n, m) for n, m in meta.items() if "VoiceSliceKernel" in n]
+    assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
+    assert m["vgpr_count"] + m.get("agpr_count", 0) <= 256, (name, m)
+    assert 2 * granule(m["group_segment_fixed_size"], 1280) <= 160 * 1024, (name, m)
+
+
 def test_reduction_fits_beside_the_hrtf_voice_kernel(voice_wave, voice_kernel, tmp_path):
     reduce4 = next(m for n, m in voice_kernel.items() if "BusReduceKernelILi4E" in n)
     assert reduce4["vgpr_spill_count"] == 0
