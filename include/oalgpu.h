@@ -610,6 +610,28 @@ int oalgpu_voice_move_async(oalgpu_context *ctx, const oalgpu_voice_move *moves,
 int oalgpu_read_output_async(oalgpu_context *ctx, uint32_t *ticket);
 int oalgpu_output_wait(oalgpu_context *ctx, uint32_t ticket, float *out, size_t out_floats);
 
+/* What the rest of the reference has to hear about the voices, without reading them all back every update: the voices whose
+ * play state (a source that runs out of buffer sets itself Stopping, core/voice.cpp:1201-1232), current buffer or count of
+ * buffers played through (a streaming source, voice.cpp:1182-1218) changed since the last report -- each with its position at
+ * that moment.  oalgpu_voice_events_async queues one small kernel behind the update submitted last (it writes the changes
+ * into a slot of pinned host memory) and returns a ticket; oalgpu_voice_events_wait hands the report over, normally updates
+ * later, when it has long landed.  Four tickets may be outstanding.  A report holds 1024 changes: beyond that
+ * oalgpu_voice_events_wait fails with OALGPU_ERR_CAPACITY (count is still set) and the host reads the voices back
+ * (oalgpu_voices_readback); what the report missed is not reported again.  A voice the host has just started (Playing, on a
+ * buffer, not Playing in the report before) is no news and is not reported. */
+typedef struct oalgpu_voice_event {
+    uint32_t voice;
+    int32_t  play_state;
+    int32_t  has_buffer;
+    int32_t  current_buffer;
+    uint32_t buffers_done;
+    int32_t  position;
+    uint32_t position_frac;
+    int32_t  fading;
+} oalgpu_voice_event;
+int oalgpu_voice_events_async(oalgpu_context *ctx, uint32_t *ticket);
+int oalgpu_voice_events_wait(oalgpu_context *ctx, uint32_t ticket, oalgpu_voice_event *out, size_t capacity, size_t *count);
+
 /* Timing of the last oalgpu_mix_update/mix_voices launch sequence, measured with HIP events on
  * the context's stream: total milliseconds, and the share of the voice kernel. */
 int oalgpu_last_update_ms(oalgpu_context *ctx, float *total_ms, float *voice_kernel_ms);

@@ -143,8 +143,22 @@ public:
          * that array is where its entry lives (voices are pooled; the array only grows, core/context.h:159-160) */
         while(mCursor < voices.size() && voices[mCursor] != voice) ++mCursor;
         if(mCursor == voices.size()) { mSeen = 0; failText(OALGPU_ERR_INVALID, "oalgpu_openal: a voice outside the context's voice array"); return false; }
-        mBatch.emplace_back(voice, vstate);
-        mBatchIndex.push_back(uint32_t(mCursor++));
+        /* pipelined, with the parameter hook: a voice that just plays on -- known to the device context, no change of state, of
+         * parameters or of its queue -- needs no word; only the others are walked when the batch is complete */
+        const size_t place = mCursor++;
+        bool quiet = false;
+        if(mDepth && mTrack && !mResync && place < mEntries.size())
+        {
+            const Entry &e = mEntries[place];
+            quiet = e.live && !e.queue && vstate == Voice::Playing && e.lastState == int(Voice::Playing)
+                && e.sourceId == voice->mSourceID.load(std::memory_order_relaxed) && !(voice->mStartTime > deviceTime)
+                && voice->mStep >= 1u && (mChanged.empty() || !mChanged.count(voice));
+        }
+        if(!quiet)
+        {
+            mBatch.emplace_back(voice, vstate);
+            mBatchIndex.push_back(uint32_t(place));
+        }
         if(++mSeen != mExpected) return false;
         mSeen = 0;
         const int rc = flush(context, dev, deviceTime, samplesToDo);
@@ -157,6 +171,32 @@ public:
     const std::vector<std::pair<Voice*, Voice::State>> &batch() const { return mBatch; }
     size_t liveVoices() const { size_t n{0}; for(auto const &e : mEntries) n += e.live ? 1u : 0u; return n; }
     size_t liveBuffers() const { return mBuffers.size(); }
+
+    /* ---- the pipelined mode: nothing of an update is waited for in the update itself ----
+     * The synchronous form above reads the update's buses and every voice's state back before ProcessContexts goes on -- five
+     * blocking calls per update.  setPipelined(depth), before the first update, moves what is left of the update behind the
+     * boundary as well: the device's HRTF post-process (MixDirectHrtf over the dry lines and the accumulator, alu.cpp:289-298)
+     * runs on the GPU behind the voices, with the decoder the device was set up with (HrtfPostProcess::mHrtfState, handed over
+     * as it is; the device keeps std::monostate in mPostProcess while the mode lasts), and an update's two output lines are
+     * added to DeviceBase::RealOut `depth` updates later (oalgpu_read_output_async / oalgpu_output_wait: by then they have
+     * long landed in pinned memory).  Voice state comes back the same way, as a report of what CHANGED
+     * (oalgpu_voice_events_async): a source that ran out of buffer is heard of `depth` updates late -- Voice::mStartTime-style
+     * latency the application sees as `depth` x update size more output latency -- and Voice::mPosition is refreshed with such
+     * a report only (GetSourceOffset: oalgpu_voices_readback).  Scope: RenderMode::Hrtf without auxiliary sends (effect slots
+     * would have to move behind the boundary too: oalgpu_slot_set_*), a constant update size.  drain() collects what is
+     * outstanding (before the device stops, or before leaving the mode). */
+    void setPipelined(unsigned depth) { mDepth = std::min(depth, 2u); }
+    bool pipelined() const { return mDepth != 0u; }
+    int drain(ContextBase *context, DeviceBase &dev)
+    {
+        while(!mPending.empty()) { if(int rc = collect(context, dev)) return rc; }
+        return 0;
+    }
+    size_t pendingUpdates() const { return mPending.size(); }
+    /* where flush() spent its time so far, seconds: [0] the walk over the update's voices (what to tell the device context),
+     * [1] the submission (oalgpu_mix_update and the two requests behind it), [2] collecting the update `depth` back */
+    const double *times() const { return mTimes; }
+    int collectOne(ContextBase *context, DeviceBase &dev) { return mPending.empty() ? 0 : collect(context, dev); }
 
     /* ---- two optional hooks for the maintainer's side of the seam ----
      * CalcSourceParams (alc/alu.cpp:2012-2031) knows which voices it recomputed: with one call at its end the update hands
@@ -249,8 +289,30 @@ private:
             if(int rc = oalgpu_hrtf_load_store(mGpu, store->mSampleRate, dev.mIrSize, dist.data(), evc.data(), uint32_t(dist.size()),
                 azc.data(), iro.data(), uint32_t(azc.size()), &store->mCoeffs[0][0][0], delays.data(), uint32_t(store->mCoeffs.size())))
                 return fail(rc, "oalgpu_hrtf_load_store");
-            /* DeviceBase::HrtfAccumData and its tail stay the reference's: MixDirectHrtf runs there (alu.cpp:289-298) */
-            if(int rc = oalgpu_set_carry_accum(mGpu, 0)) return fail(rc, "oalgpu_set_carry_accum");
+            if(!mDepth)
+            {   /* DeviceBase::HrtfAccumData and its tail stay the reference's: MixDirectHrtf runs there (alu.cpp:289-298) */
+                if(int rc = oalgpu_set_carry_accum(mGpu, 0)) return fail(rc, "oalgpu_set_carry_accum");
+            }
+        }
+        if(mDepth)
+        {   /* the post-process moves behind the boundary with the decoder InitHrtfPanning built (alc/panning.cpp:1100-1134) */
+            auto *pp = std::get_if<HrtfPostProcess>(&dev.mPostProcess);
+            if(!mHrtf || dev.NumAuxSends || !pp || !pp->mHrtfState)
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: the pipelined mode covers RenderMode::Hrtf devices without auxiliary sends");
+            DirectHrtfState &st = *pp->mHrtfState;
+            std::vector<float> coeffs(st.mChannels.size() * HrirLength * 2), hf(st.mChannels.size());
+            for(size_t c{0}; c < st.mChannels.size(); ++c)
+            {
+                std::memcpy(&coeffs[c * HrirLength * 2], &st.mChannels[c].mCoeffs[0][0], sizeof(float) * HrirLength * 2);
+                hf[c] = st.mChannels[c].mHfScale;
+            }
+            if(int rc = oalgpu_set_direct_hrtf(mGpu, coeffs.data(), hf.data(), dev.mXOverFreq / float(dev.mSampleRate), st.mIrSize))
+                return fail(rc, "oalgpu_set_direct_hrtf");
+            if(int rc = oalgpu_set_carry_accum(mGpu, 1)) return fail(rc, "oalgpu_set_carry_accum");
+            mSavedPost = std::move(*pp);
+            dev.mPostProcess.emplace<std::monostate>();
+            mEntryOfIndex.assign(mMaxVoices, -1);
+            mIndexBorn.assign(mMaxVoices, 0u);
         }
         for(uint32_t i = 0; i < mMaxVoices; ++i) mFreeIndex.push_back(mMaxVoices - 1u - i);
         return 0;
@@ -340,6 +402,7 @@ private:
         for(Chan &ch : e.chans)
         {   /* the device voice lets go of its buffer (a released one is freed then) and the slot goes back */
             (void)oalgpu_voice_set_state(mGpu, ch.index, OALGPU_VOICE_STOPPED);
+            if(!mEntryOfIndex.empty()) mEntryOfIndex[ch.index] = -1;
             mFreeIndex.push_back(ch.index);
         }
         e = Entry{};
@@ -391,6 +454,8 @@ private:
             }
         }
 
+        ++mUpdateNo;
+        auto const tWalk = std::chrono::steady_clock::now();
         std::vector<uint32_t> ids, tgtIds, tgtDelays;
         std::vector<oalgpu_voice_params> params;
         std::vector<float> tgtCoeffs, tgtGains;
@@ -450,6 +515,7 @@ private:
                 {
                     Chan ch;
                     ch.index = mFreeIndex.back(); mFreeIndex.pop_back();
+                    if(!mEntryOfIndex.empty() && c == 0) { mEntryOfIndex[ch.index] = int32_t(mBatchIndex[bi]); mIndexBorn[ch.index] = mUpdateNo; }
                     const int h = channelBuffer(*be, unsigned(c), voice->mFmtChannels == FmtMono);
                     if(h < 0) return h;
                     int rc;
@@ -536,11 +602,15 @@ private:
                 }
             }
         }
+        mTimes[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tWalk).count();
         if(!ids.empty())
             if(int rc = oalgpu_voice_set_params(mGpu, ids.data(), params.data(), ids.size())) return fail(rc, "oalgpu_voice_set_params");
         if(!tgtIds.empty())
             if(int rc = oalgpu_voice_set_hrtf_targets(mGpu, tgtIds.data(), tgtCoeffs.data(), tgtDelays.data(), tgtGains.data(), tgtIds.size()))
                 return fail(rc, "oalgpu_voice_set_hrtf_targets");
+
+        /* (pipelined mode: the update is submitted with its post-process and nothing is read back here, see submitPipelined) */
+        if(mDepth) return submitPipelined(context, dev, samplesToDo);
 
         /* the voice loop: one batched update; its buses join the reference's mixing buffers */
         if(int rc = oalgpu_mix_update(mGpu, samplesToDo, 0)) return fail(rc, "oalgpu_mix_update");
@@ -628,8 +698,125 @@ private:
         return 0;
     }
 
+    /* ---- the pipelined mode: the update is submitted; what an earlier one produced is collected ---- */
+    struct Pending { uint32_t outTicket, evTicket; unsigned samples; uint64_t update; };
+    int submitPipelined(ContextBase *context, DeviceBase &dev, unsigned samplesToDo)
+    {
+        auto const t0 = std::chrono::steady_clock::now();
+        if(int rc = oalgpu_mix_update(mGpu, samplesToDo, 1)) return fail(rc, "oalgpu_mix_update");
+        /* a voice the reference told to stop fades out in this very update (voice.cpp:1119-1123): its Voice returns to the pool
+         * now, its device slot behind the update (the calls below are queued behind it) */
+        for(auto &ve : mMixed)
+            if(ve.second->live && ve.second->lastState == int(Voice::Stopping))
+            {
+                ve.first->mPlayState.store(Voice::Stopped, std::memory_order_release);
+                dropEntry(*ve.second);
+            }
+        Pending p{0u, 0u, samplesToDo, mUpdateNo};
+        if(int rc = oalgpu_read_output_async(mGpu, &p.outTicket)) return fail(rc, "oalgpu_read_output_async");
+        if(int rc = oalgpu_voice_events_async(mGpu, &p.evTicket)) return fail(rc, "oalgpu_voice_events_async");
+        mPending.push_back(p);
+        auto const t1 = std::chrono::steady_clock::now();
+        /* the update `depth` back: its output lines and what it changed about the voices have long landed in pinned memory */
+        while(mPending.size() > mDepth) { if(int rc = collect(context, dev)) return rc; }
+        mTimes[1] += std::chrono::duration<double>(t1 - t0).count();
+        mTimes[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        return 0;
+    }
+    int collect(ContextBase *context, DeviceBase &dev)
+    {
+        const Pending p = mPending.front();
+        mPending.erase(mPending.begin());
+        /* the update's output lines: HrtfPostProcess's result (alu.cpp:289-298), `depth` updates late */
+        const size_t nreal = dev.RealOut.Buffer.size();
+        mLines.resize(nreal * BufferLineSize);
+        if(int rc = oalgpu_output_wait(mGpu, p.outTicket, mLines.data(), mLines.size())) return fail(rc, "oalgpu_output_wait");
+        for(size_t c{0}; c < nreal; ++c)
+            for(size_t i{0}; i < p.samples; ++i)
+                dev.RealOut.Buffer[c][i] += mLines[c*BufferLineSize + i];
+        /* what changed about the voices in that update */
+        mEvents.resize(1024);
+        size_t count{0};
+        const int rc = oalgpu_voice_events_wait(mGpu, p.evTicket, mEvents.data(), mEvents.size(), &count);
+        if(rc == OALGPU_ERR_CAPACITY) return resyncStates(context);
+        if(rc) return fail(rc, "oalgpu_voice_events_wait");
+        auto const voices = context->getVoicesSpanAcquired();
+        for(size_t k{0}; k < count; ++k)
+        {
+            const oalgpu_voice_event &ev = mEvents[k];
+            if(ev.voice >= mEntryOfIndex.size() || mEntryOfIndex[ev.voice] < 0 || mIndexBorn[ev.voice] > p.update) continue;
+            const size_t place = size_t(mEntryOfIndex[ev.voice]);
+            if(place >= mEntries.size() || place >= voices.size()) continue;
+            Entry &e = mEntries[place];
+            if(!e.live || e.chans.empty() || e.chans[0].index != ev.voice) continue;
+            applyState(voices[place], e, context, ev.fading != 0, ev.position, ev.position_frac, ev.has_buffer != 0, ev.current_buffer, ev.buffers_done);
+        }
+        return 0;
+    }
+    /* more changes than a report holds (hundreds of sources ending in one update): every live voice is read back */
+    int resyncStates(ContextBase *context)
+    {
+        auto const voices = context->getVoicesSpanAcquired();
+        std::vector<uint32_t> rb; std::vector<size_t> places;
+        for(size_t i{0}; i < mEntries.size() && i < voices.size(); ++i)
+            if(mEntries[i].live && !mEntries[i].chans.empty()) { rb.push_back(mEntries[i].chans[0].index); places.push_back(i); }
+        mBrief.resize(rb.size());
+        if(!rb.empty())
+            if(int rc = oalgpu_voices_readback(mGpu, rb.data(), rb.size(), mBrief.data())) return fail(rc, "oalgpu_voices_readback");
+        for(size_t k{0}; k < rb.size(); ++k)
+        {
+            const oalgpu_voice_brief &st = mBrief[k];
+            applyState(voices[places[k]], mEntries[places[k]], context, st.fading != 0, st.position, st.position_frac, st.has_buffer != 0,
+                st.current_buffer, st.buffers_done);
+        }
+        return 0;
+    }
+    /* the state Voice::mix leaves in the Voice after an update (voice.cpp:1116-1232), from what the device context reports */
+    void applyState(Voice *voice, Entry &e, ContextBase *context, bool fading, int32_t position, uint32_t positionFrac, bool hasBuffer,
+        int32_t currentBuffer, uint32_t buffersDone)
+    {
+        if(fading) voice->mFlags.set(VoiceFlag::IsFading);
+        if(e.lastState == int(Voice::Stopping)) return;          /* (on its way out: the Voice is not touched any more) */
+        voice->mPosition.store(position, std::memory_order_relaxed);
+        voice->mPositionFrac.store(positionFrac, std::memory_order_relaxed);
+        if(e.queue)
+        {   /* voice.cpp:1182-1218: where the queue has got to, and the buffers it left behind */
+            const unsigned sourceID = voice->mSourceID.load(std::memory_order_relaxed);
+            if(hasBuffer)
+                for(auto const &link : e.chain)
+                    if(link.second == currentBuffer)
+                    { voice->mCurrentBuffer.store(const_cast<VoiceBufferItem*>(link.first), std::memory_order_release); break; }
+            const uint32_t done = buffersDone - e.doneSeen;
+            e.doneSeen = buffersDone;
+            if(done > 0 && context->mEnabledEvts.load(std::memory_order_acquire).test(AsyncEnableBits::BufferCompleted))
+            {
+                auto *ring = context->mAsyncEvents.get();
+                if(auto const evt_vec = ring->getWriteVector(); !evt_vec[0].empty())
+                {
+                    auto &evt = InitAsyncEvent<AsyncBufferCompleteEvent>(evt_vec[0].front());
+                    evt.mId = sourceID;
+                    evt.mCount = done;
+                    ring->writeAdvance(1);
+                }
+            }
+        }
+        if(!hasBuffer)
+        {
+            endOfSource(voice, context);
+            e.lastState = int(Voice::Stopping);     /* (the device context set it itself) */
+        }
+    }
+
     int mMathMode, mDevice;
     unsigned mMaxVoices;
+    unsigned mDepth{0};
+    double mTimes[3]{0.0, 0.0, 0.0};
+    uint64_t mUpdateNo{0};
+    std::vector<Pending> mPending;
+    std::vector<int32_t> mEntryOfIndex;             /* [device voice] -> place of its entry (pipelined mode) */
+    std::vector<uint64_t> mIndexBorn;               /* [device voice] the update it was initialised in */
+    std::vector<oalgpu_voice_event> mEvents;
+    HrtfPostProcess mSavedPost;
     oalgpu_context *mGpu{nullptr};
     bool mHrtf{false};
     uint32_t mNumSlots{0}, mWetChannels{4};

@@ -139,6 +139,12 @@ struct oalgpu_context {
     // Once oalgpu_read_output_async has been used on an HRTF context, the post-process kernel stores the two output lines into
     // the next ring slot itself and raises the slot's sequence number (pinned, 64 bytes apart) behind them: reading the output
     // back costs the host no runtime call.  outRingWritten: the update submitted last did so, for slot outNext % kIoSlots.
+    // oalgpu_voice_events_async: what changed about the voices since the last report, into pinned ring slots
+    static constexpr uint32_t kEvCap = 1024;
+    uint32_t *evHost[kIoSlots]{};
+    hipEvent_t evDone[kIoSlots]{};
+    uint32_t evNext{0};
+    DevBuf<uint32_t> evSnapshot, evCounters;
     bool outRing{false}, outRingWritten{false};
     bool outViaRing[kIoSlots]{};
     uint32_t outSeq{0}, outSlotSeq[kIoSlots]{};    // every launch that writes a slot raises ITS number
@@ -314,6 +320,8 @@ struct oalgpu_context {
         {
             if(panHost[k]) (void)(panInBar ? hipFree(panHost[k]) : hipHostFree(panHost[k]));
             if(outHost[k]) (void)hipHostFree(outHost[k]);
+            if(evHost[k]) (void)hipHostFree(evHost[k]);
+            if(evDone[k]) (void)hipEventDestroy(evDone[k]);
             for(hipEvent_t e : {panApplied[k], outDone[k]}) if(e) (void)hipEventDestroy(e);
         }
         if(outFlags) (void)hipHostFree(outFlags);
@@ -2183,6 +2191,57 @@ int oalgpu_output_wait(oalgpu_context *c, uint32_t ticket, float *out, size_t ou
     else HIP_TRY(hipEventSynchronize(c->outDone[slot]));
     if(c->outUpdate[slot] > c->updatesKnownDone) c->updatesKnownDone = c->outUpdate[slot];
     std::memcpy(out, c->outHost[slot], c->outFloats * sizeof(float));
+    return OALGPU_OK;
+}
+
+/* What changed about the voices since the last report (the first one reports every voice that is not Stopped): see oalgpu.h */
+int oalgpu_voice_events_async(oalgpu_context *c, uint32_t *ticket)
+{
+    if(!c || !ticket) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(int rc = UseCtx(c)) return rc;
+    if(int rc = FlushInits(c)) return rc;
+    constexpr uint32_t slots = oalgpu_context::kIoSlots;
+    if(!c->evHost[0])
+    {
+        for(uint32_t k = 0; k < slots; ++k)
+        {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->evHost[k]), (4u + size_t{oalgpu_context::kEvCap} * 8u) * sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&c->evDone[k], hipEventDisableTiming));
+        }
+        HIP_TRY(c->evSnapshot.alloc(size_t{c->L.numVoices} * 3)); HIP_TRY(c->evSnapshot.zero());       // (0 = Stopped, buffer 0: what a slot never used looks like but for the buffer)
+        HIP_TRY(c->evCounters.alloc(2)); HIP_TRY(c->evCounters.zero());
+        std::vector<uint32_t> init(size_t{c->L.numVoices} * 3, 0u);
+        for(uint32_t v = 0; v < c->L.numVoices; ++v) { init[size_t{v} * 3 + 0] = uint32_t(OALGPU_VOICE_STOPPED); init[size_t{v} * 3 + 1] = 0xffffffffu; }
+        HIP_TRY(hipMemcpyAsync(c->evSnapshot.p, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    const uint32_t slot = c->evNext % slots;
+    // (four slots: the ticket four back must have been collected -- its event is long done -- or is given up)
+    LaunchVoiceEvents(c->stream, c->L, c->evSnapshot.p, c->evHost[slot], oalgpu_context::kEvCap, c->evCounters.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->evDone[slot], c->stream));
+    *ticket = c->evNext++;
+    return OALGPU_OK;
+}
+
+int oalgpu_voice_events_wait(oalgpu_context *c, uint32_t ticket, oalgpu_voice_event *out, size_t capacity, size_t *count)
+{
+    if(!c || !count || (!out && capacity)) return Fail(OALGPU_ERR_INVALID, "null argument");
+    if(ticket >= c->evNext || c->evNext - ticket > oalgpu_context::kIoSlots)
+        return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_events_wait: the ticket's slot was reused (four tickets may be outstanding)");
+    if(int rc = UseCtxResident(c)) return rc;
+    const uint32_t slot = ticket % oalgpu_context::kIoSlots;
+    HIP_TRY(hipEventSynchronize(c->evDone[slot]));
+    const uint32_t *h = c->evHost[slot];
+    const uint32_t n = h[0];
+    *count = n;
+    if(n > oalgpu_context::kEvCap || n > capacity)
+        return Fail(OALGPU_ERR_CAPACITY, "oalgpu_voice_events_wait: " + std::to_string(n) + " changes, more than the report holds (read the voices back: oalgpu_voices_readback)");
+    for(uint32_t i = 0; i < n; ++i)
+    {
+        const uint32_t *e = h + 4u + size_t{i} * 8u;
+        out[i] = oalgpu_voice_event{e[0], int32_t(e[1]), int32_t(e[2]) >= 0 ? 1 : 0, int32_t(e[2]), e[3], int32_t(e[4]), e[5], int32_t(e[6])};
+    }
     return OALGPU_OK;
 }
 

@@ -440,6 +440,8 @@ struct PanRecord { uint32_t voice; float dir[3]; float spread; float dryGain; fl
 void LaunchPanGains(hipStream_t s, const DeviceLayout &L, const PanRecord *recs, uint32_t count, const AmbiMapEntry *dryMap,
     const AmbiMapEntry *wetMaps);
 void LaunchSetStartDelay(hipStream_t s, const DeviceLayout &L, uint32_t voice, uint32_t samples);
+// oalgpu_voice_events_async: hostSlot = [count, 0, 0, 0 | capacity x 8 dwords] of pinned host memory; counters: two device words, zero
+void LaunchVoiceEvents(hipStream_t s, const DeviceLayout &L, uint32_t *snapshot, uint32_t *hostSlot, uint32_t capacity, uint32_t *counters);
 void LaunchSetVoiceWindow(hipStream_t s, const DeviceLayout &L, uint32_t voice, int32_t buffer, uint32_t sampleLen, int32_t position);
 
 // ---- launcher (adpcm_kernels.hip): IMA4 / MS ADPCM blocks -> interleaved 16-bit PCM, one thread per block and channel ----

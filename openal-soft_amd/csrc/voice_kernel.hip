@@ -81,6 +81,52 @@ __global__ void SetVoiceWindowKernel(DeviceLayout L, uint32_t v, int32_t buffer,
 void LaunchSetVoiceWindow(hipStream_t s, const DeviceLayout &L, uint32_t voice, int32_t buffer, uint32_t sampleLen, int32_t position)
 { hipLaunchKernelGGL(SetVoiceWindowKernel, dim3(1), dim3(1), 0, s, L, voice, buffer, sampleLen, position); }
 
+// oalgpu_voice_events_async: what changed about the voices since the last report -- the play state (a source that ran out of
+// buffer sets itself Stopping, core/voice.cpp:1201-1232), the buffer a streaming source has got to and the buffers it left
+// behind (voice.cpp:1182-1218) -- appended to a slot of pinned host memory by the threads that find a difference; the
+// workgroup that finishes last writes the count in front of them.  snapshot: [voice][3] what the last report saw.
+__global__ void __launch_bounds__(256) VoiceEventsKernel(DeviceLayout L, uint32_t *snapshot, uint32_t *hostSlot, uint32_t capacity, uint32_t *counters)
+{
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if(v < L.numVoices)
+    {
+        const VoiceCtl &c = L.ctl[v];
+        const uint32_t st = uint32_t(c.playState), cb = uint32_t(c.curBuffer), qd = L.queueDone[v];
+        uint32_t *snap = snapshot + size_t{v} * 3;
+        if(snap[0] != st || snap[1] != cb || snap[2] != qd)
+        {
+            // (a voice the host has just started -- Playing, on a buffer, not Playing in the report before -- is no news to the host)
+            const bool started = st == uint32_t(OALGPU_VOICE_PLAYING) && int32_t(cb) >= 0 && snap[0] != uint32_t(OALGPU_VOICE_PLAYING);
+            snap[0] = st; snap[1] = cb; snap[2] = qd;
+            const uint32_t idx = started ? 0xffffffffu : atomicAdd(&counters[0], 1u);
+            if(idx < capacity)
+            {
+                uint32_t *e = hostSlot + 4u + size_t{idx} * 8u;
+                e[0] = v; e[1] = st; e[2] = cb; e[3] = qd; e[4] = uint32_t(c.position); e[5] = c.positionFrac;
+                e[6] = (c.flags & kFlagFading) ? 1u : 0u; e[7] = 0u;
+            }
+        }
+    }
+    __syncthreads();
+    if(threadIdx.x == 0)
+    {
+        __threadfence_system();
+        const uint32_t done = atomicAdd(&counters[1], 1u);
+        if(done + 1u == gridDim.x)
+        {
+            const uint32_t n = atomicExch(&counters[0], 0u);
+            counters[1] = 0u;
+            hostSlot[0] = n;
+            __threadfence_system();
+        }
+    }
+}
+
+void LaunchVoiceEvents(hipStream_t s, const DeviceLayout &L, uint32_t *snapshot, uint32_t *hostSlot, uint32_t capacity, uint32_t *counters)
+{
+    hipLaunchKernelGGL(VoiceEventsKernel, dim3((L.numVoices + 255u) / 256u), dim3(256), 0, s, L, snapshot, hostSlot, capacity, counters);
+}
+
 void LaunchSetStartDelay(hipStream_t s, const DeviceLayout &L, uint32_t voice, uint32_t samples)
 { hipLaunchKernelGGL(SetStartDelayKernel, dim3(1), dim3(1), 0, s, L, voice, samples); }
 

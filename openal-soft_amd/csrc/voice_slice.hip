@@ -143,24 +143,31 @@ struct VoicePlan {
     uint32_t outPos;                          // a delayed start's first output frame (voice.cpp:1023-1046)
     int32_t bufferItem;
     uint32_t bsrcFull;                        // the update's first chunk as the reference sizes it (the hold rule reads it)
+    bool multi;                               // the reference loads the update's window in more than one chunk
 };
 
 // ---- the update's source window, element by element -----------------------------------------------------------------
-// W(A), A >= 0: element A of mResampleData as LoadResampledSamples builds it for this update (voice.cpp:662-753) if the
-// update were loaded in one piece: A < 24 -> mPrevSamples[A]; then the source from the voice's position on -- zeros in
-// front of a negative position (:679-697), the buffer with its loop (LoadBufferStatic, :500-544), the queue (LoadBufferQueue,
-// :563-594), the last sample held past the end; a voice without a buffer holds the sample nearest zero of what mPrevSamples
-// has ahead of the position (:704-719).  dst[i] = W(A0 + i), i < cnt, by one wavefront.
+// W(A), A >= 0: element A of mResampleData (relative to the update's start) as LoadResampledSamples builds it
+// (voice.cpp:662-753): A < 24 -> mPrevSamples[A]; then the source from the voice's position on -- zeros in front of a
+// negative position (:679-697), the buffer with its loop (LoadBufferStatic, :500-544), the queue (LoadBufferQueue, :563-594),
+// the last sample held past the end; a voice without a buffer holds the sample nearest zero of what mPrevSamples has ahead of
+// the position (:704-719).
+// The reference loads the window in chunks of at most kResampleDataSize samples (CalculateBufferSize, :600-640: pitches above
+// ~1.27 at 1024 frames), and what a chunk puts past the END of a source depends on the chunk: LoadBufferStatic / LoadBufferQueue
+// hold the last sample they loaded IN THAT CALL -- a chunk that begins at or past the end holds 0.  So the outputs of chunk c
+// see: A < S_c + 24 what chunk c - 1 left there (the 24 samples carried over, :807-810), from there on what chunk c's own load
+// put there.  anchor = S_c, the chunk's source offset from the update's start; anchorPrev = S_(c-1) (unused for chunk 0, where
+// A < 24 is mPrevSamples).  dst[i] = W(A0 + i) as chunk c's outputs see it, i < cnt, by one wavefront.
 template<class LT>
 __device__ __forceinline__ void FillWindow(float *dst, uint32_t A0, uint32_t cnt, const LT &L, uint32_t v, const VoiceHead &h,
-    const BufferItem &buf, const VoicePlan &p, SliceWaveLds &w, uint32_t lane)
+    const BufferItem &buf, const VoicePlan &p, SliceWaveLds &w, uint32_t lane, uint32_t anchor = 0u, uint32_t anchorPrev = 0u)
 {
     const float *prev = L.prev + size_t{v} * kMaxPad;
     const uint32_t nPrev = A0 < uint32_t(kMaxEdge) ? ((uint32_t(kMaxEdge) - A0 < cnt) ? uint32_t(kMaxEdge) - A0 : cnt) : 0u;
     for(uint32_t i = lane; i < nPrev; i += 64u) dst[i] = prev[A0 + i];
     if(nPrev == cnt) return;
     if(p.bufferItem < 0)
-    {   // voice.cpp:704-719
+    {   // voice.cpp:704-719 (decided by the update's first chunk: later ones find the held sample everywhere they look)
         const uint32_t avail = p.bsrcFull < uint32_t(kMaxEdge) ? p.bsrcFull : uint32_t(kMaxEdge);
         if(lane < uint32_t(kMaxEdge)) w.misc[lane] = prev[kMaxEdge + lane];
         WaveSync();
@@ -182,47 +189,72 @@ __device__ __forceinline__ void FillWindow(float *dst, uint32_t A0, uint32_t cnt
         WaveSync();
         return;
     }
-    const uint32_t e0 = A0 + nPrev - uint32_t(kMaxEdge);              // source samples from the voice's position
-    const uint32_t m = cnt - nPrev;
-    float *d = dst + nPrev;
-    const int64_t p0 = int64_t{h.position} + int64_t{e0};
-    uint32_t z = 0;
-    if(p0 < 0) { const uint64_t need = uint64_t(-p0); z = need < m ? uint32_t(need) : m; }
-    for(uint32_t i = lane; i < z; i += 64u) d[i] = 0.0f;
-    if(z == m) return;
-    const uint64_t upos64 = uint64_t(p0 + int64_t{z});
-    const uint32_t upos = upos64 > 0xffffffffull ? 0xffffffffu : uint32_t(upos64);
-    d += z;
-    const uint32_t n = m - z;
-    if(p.queue)
-    {   // LoadBufferQueue: crawl from the voice's current item; past the queue's end its last sample is held
-        int32_t item = p.bufferItem;
-        uint32_t dataPos = upos, done = 0;
-        float last = 0.0f;
-        for(uint32_t guard = 0; item >= 0 && done < n && guard < 4096u; ++guard)
-        {
-            const BufferItem b = L.buffers[item];
-            const int32_t nextItem = b.next > 0 ? b.next - 1 : h.loopBuffer;
-            if(b.sampleLen) last = LoadSampleAny(b.fmt, b.data, size_t{b.sampleLen - 1u} * b.frameStep);
-            if(dataPos >= b.sampleLen) { dataPos -= b.sampleLen; item = nextItem; continue; }
-            const uint32_t rem = (n - done < b.sampleLen - dataPos) ? n - done : b.sampleLen - dataPos;
-            for(uint32_t k = lane; k < rem; k += 64u) d[done + k] = LoadSampleAny(b.fmt, b.data, size_t{dataPos + k} * b.frameStep);
-            done += rem;
-            dataPos = 0;
-            item = nextItem;
-        }
-        for(uint32_t k = done + lane; k < n; k += 64u) d[k] = last;
-        return;
-    }
-    if(p.looping) { FillFromBuffer<64>(d, n, buf, true, upos, lane); return; }
-    // LoadBufferStatic without a loop: past the end the buffer's last sample (nothing at all if the UPDATE began past it)
-    if(!p.anyFull) { for(uint32_t k = lane; k < n; k += 64u) d[k] = 0.0f; return; }
-    const uint32_t lastIdx = buf.sampleLen - 1u;
-    for(uint32_t k = lane; k < n; k += 64u)
+    // [nPrev, cnt): first what the chunk before left (A < anchor + 24), then the chunk's own load
+    uint32_t i0 = nPrev;
+    for(int part = 0; part < 2 && i0 < cnt; ++part)
     {
-        const uint64_t idx64 = uint64_t{upos} + k;
-        const uint32_t idx = idx64 < lastIdx ? uint32_t(idx64) : lastIdx;
-        d[k] = LoadSampleAny(buf.fmt, buf.data, size_t{idx} * buf.frameStep);
+        uint32_t i1 = cnt, from = anchor;
+        if(part == 0)
+        {
+            const uint64_t edge = uint64_t{anchor} + uint32_t(kMaxEdge);
+            if(anchor == 0u || uint64_t{A0} + i0 >= edge) continue;
+            i1 = (edge - A0 < cnt) ? uint32_t(edge - A0) : cnt;
+            from = anchorPrev;
+        }
+        const uint32_t e0 = A0 + i0 - uint32_t(kMaxEdge);              // source samples from the voice's position
+        const uint32_t m = i1 - i0;
+        float *d = dst + i0;
+        i0 = i1;
+        const int64_t p0 = int64_t{h.position} + int64_t{e0};
+        uint32_t z = 0;
+        if(p0 < 0) { const uint64_t need = uint64_t(-p0); z = need < m ? uint32_t(need) : m; }
+        for(uint32_t i = lane; i < z; i += 64u) d[i] = 0.0f;
+        if(z == m) continue;
+        const uint64_t upos64 = uint64_t(p0 + int64_t{z});
+        const uint32_t upos = upos64 > 0xffffffffull ? 0xffffffffu : uint32_t(upos64);
+        d += z;
+        const uint32_t n = m - z;
+        // where the load that put these samples there began (a negative position: at the buffer's start, voice.cpp:679-697)
+        const int64_t c0 = int64_t{h.position} + int64_t{from};
+        const uint64_t callPos = c0 > 0 ? uint64_t(c0) : 0ull;
+        if(p.queue)
+        {   // LoadBufferQueue: crawl from the voice's current item; past the queue's end the last sample THAT call loaded is held
+            int32_t item = p.bufferItem;
+            uint64_t total = 0;                         // samples of the items visited (a queue that ends: of the whole rest of it)
+            float last = 0.0f;
+            uint32_t dataPos = upos, done = 0;
+            for(uint32_t guard = 0; item >= 0 && done < n && guard < 4096u; ++guard)
+            {
+                const BufferItem b = L.buffers[item];
+                total += b.sampleLen;
+                if(b.sampleLen) last = LoadSampleAny(b.fmt, b.data, size_t{b.sampleLen - 1u} * b.frameStep);
+                if(dataPos >= b.sampleLen) dataPos -= b.sampleLen;
+                else
+                {
+                    const uint32_t rem = (n - done < b.sampleLen - dataPos) ? n - done : b.sampleLen - dataPos;
+                    for(uint32_t k = lane; k < rem; k += 64u) d[done + k] = LoadSampleAny(b.fmt, b.data, size_t{dataPos + k} * b.frameStep);
+                    done += rem;
+                    dataPos = 0;
+                }
+                item = b.next > 0 ? b.next - 1 : h.loopBuffer;
+            }
+            if(done < n)
+            {   // the queue ended: the call held its last sample if it had loaded any, i.e. if it began in front of the end
+                const float hold = callPos < total ? last : 0.0f;
+                for(uint32_t k = done + lane; k < n; k += 64u) d[k] = hold;
+            }
+            continue;
+        }
+        if(p.looping) { FillFromBuffer<64>(d, n, buf, true, upos, lane); continue; }
+        // LoadBufferStatic without a loop: past the end the buffer's last sample, if the call began in front of the end
+        const bool any = uint64_t{buf.sampleLen} > callPos;
+        const uint32_t lastIdx = buf.sampleLen - 1u;
+        const float hold = any ? LoadSampleAny(buf.fmt, buf.data, size_t{lastIdx} * buf.frameStep) : 0.0f;
+        for(uint32_t k = lane; k < n; k += 64u)
+        {
+            const uint64_t idx64 = uint64_t{upos} + k;
+            d[k] = idx64 < buf.sampleLen ? LoadSampleAny(buf.fmt, buf.data, size_t(idx64) * buf.frameStep) : hold;
+        }
     }
 }
 
@@ -261,6 +293,7 @@ __device__ __forceinline__ VoicePlan PlanVoice(const LT &L, uint32_t v, const Vo
     uint32_t bdst = 0;
     p.bsrcFull = 0;
     if(p.active) CalcBufferSize(h.positionFrac, h.step, N - p.outPos, bdst, p.bsrcFull);
+    p.multi = p.active && bdst < N - p.outPos;
     return p;
 }
 
@@ -278,7 +311,7 @@ __device__ __forceinline__ SlicePlan PlanSlice(const VoiceHead &h, const BufferI
     SliceBufferSize(s.frac, h.step, s.cnt, s.bdst, s.bsrc);
     // the plain shape: a static float / int16 buffer, the whole slice in one piece, at most one loop wrap inside the window
     s.pref = false;
-    if(p.bufferItem >= 0 && !p.queue && h.position >= 0 && s.bdst == s.cnt && (buf.fmt == OALGPU_FMT_FLOAT || buf.fmt == OALGPU_FMT_SHORT))
+    if(p.bufferItem >= 0 && !p.queue && !p.multi && h.position >= 0 && s.bdst == s.cnt && (buf.fmt == OALGPU_FMT_FLOAT || buf.fmt == OALGPU_FMT_SHORT))
     {
         s.nPrev = s.srcOff < uint32_t(kMaxEdge) ? uint32_t(kMaxEdge) - s.srcOff : 0u;
         const uint32_t total = uint32_t(kMaxEdge) + s.bsrc;
@@ -665,39 +698,59 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
             const bool staged = (kind == 2 || kind == 3) && sm.tabKey == tableKey;
             const uint32_t sM = kind == 2 ? 4u : head.rsM, sL = kind == 2 ? 1u : head.rsL;
             const float *filter = L.tables + head.rsFilterOffset;
-            uint32_t srcOff = sp.srcOff, frac = sp.frac;
+            // The reference's chunks of the voice's update (CalculateBufferSize with ITS capacity: one chunk up to a pitch of ~1.27),
+            // cut to the slice; each cut in pieces the slice's window holds.  What lies past a source's end depends on the chunk
+            // that loaded it (FillWindow).
+            const uint32_t Nv = N - vp.outPos;
+            const uint32_t l0 = f0 + dstOff - vp.outPos, l1 = l0 + cnt;      // the slice's voice samples
+            uint32_t D = 0u, S = 0u, Sprev = 0u, fc = head.positionFrac;
             bool firstPiece = true;
-            for(uint32_t loaded = 0; loaded < cnt;)
+            while(D < l1)
             {
-                uint32_t bdst, bsrc;
-                if(firstPiece) { bdst = sp.bdst; bsrc = sp.bsrc; }
-                else SliceBufferSize(frac, increment, cnt - loaded, bdst, bsrc);
-                const bool dual = firstPiece && sp.pref;
-                if(!dual)
+                uint32_t cd = Nv - D, cs = 0u;
+                if(vp.multi) CalcBufferSize(fc, increment, Nv - D, cd, cs);
+                const uint32_t a = D > l0 ? D : l0, e = (D + cd < l1) ? D + cd : l1;
+                if(a < e)
                 {
-                    WaveSync();
-                    FillWindow(w.rd, srcOff, uint32_t(kMaxEdge) + bsrc, L, v, head, buf, vp, w, lane);
+                    const uint64_t ta = uint64_t{fc} + uint64_t{a - D} * increment;
+                    uint32_t srcOff = S + uint32_t(ta >> kFracBits), frac = uint32_t(ta) & kFracMask;
+                    for(uint32_t loaded = a; loaded < e;)
+                    {
+                        uint32_t bdst, bsrc;
+                        SliceBufferSize(frac, increment, e - loaded, bdst, bsrc);
+                        const bool dual = firstPiece && sp.pref;
+                        if(!dual)
+                        {
+                            WaveSync();
+                            FillWindow(w.rd, srcOff, uint32_t(kMaxEdge) + bsrc, L, v, head, buf, vp, w, lane, S, Sprev);
+                        }
+                        WaveSync();
+                        float *out = row + dstOff + (loaded - l0);
+                        if(increment == kFracOne && frac == 0u)
+                        {
+                            for(uint32_t k = lane; k < bdst; k += 64u) out[k] = w.rd[kMaxEdge + k];
+                        }
+                        else if(staged)
+                            ResampleRunRingM(sm, w.rd + (kMaxEdge - sL), sM, frac, increment, bdst, out, reinterpret_cast<float*>(&w.pad[0]), lane,
+                                dual ? w.rd2 + (kMaxEdge - sL) : nullptr, uint32_t(kMaxEdge) - sL);
+                        else
+                        {
+                            const TabLayout lay = ReferenceTabLayout(head.rsM);
+                            for(uint32_t k = lane; k < bdst; k += 64u)
+                                out[k] = ResampleAt<false, false>(kind, head.rsM, head.rsL, head.rsSf, filter, lay, w.rd, frac, increment, k, bdst);
+                        }
+                        loaded += bdst;
+                        const uint64_t tn = uint64_t{frac} + uint64_t{bdst} * increment;
+                        srcOff += uint32_t(tn >> kFracBits);
+                        frac = uint32_t(tn) & kFracMask;
+                        firstPiece = false;
+                    }
                 }
-                WaveSync();
-                float *out = row + dstOff + loaded;
-                if(increment == kFracOne && frac == 0u)
-                {
-                    for(uint32_t k = lane; k < bdst; k += 64u) out[k] = w.rd[kMaxEdge + k];
-                }
-                else if(staged)
-                    ResampleRunRingM(sm, w.rd + (kMaxEdge - sL), sM, frac, increment, bdst, out, reinterpret_cast<float*>(&w.pad[0]), lane,
-                        dual ? w.rd2 + (kMaxEdge - sL) : nullptr, uint32_t(kMaxEdge) - sL);
-                else
-                {
-                    const TabLayout lay = ReferenceTabLayout(head.rsM);
-                    for(uint32_t k = lane; k < bdst; k += 64u)
-                        out[k] = ResampleAt<false, false>(kind, head.rsM, head.rsL, head.rsSf, filter, lay, w.rd, frac, increment, k, bdst);
-                }
-                loaded += bdst;
-                const uint64_t tn = uint64_t{frac} + uint64_t{bdst} * increment;
-                srcOff += uint32_t(tn >> kFracBits);
-                frac = uint32_t(tn) & kFracMask;
-                firstPiece = false;
+                const uint64_t tc = uint64_t{fc} + uint64_t{cd} * increment;
+                Sprev = S;
+                S += uint32_t(tc >> kFracBits);
+                fc = uint32_t(tc) & kFracMask;
+                D += cd;
             }
         }
         asm volatile("" : "+v"(lane));
@@ -910,9 +963,19 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
         int32_t bufferItem = head.curBuffer;
         if(playing)
         {   // mPrevSamples: the 48 samples around the position the update ends at
-            const uint32_t srcOffEnd = uint32_t((uint64_t{N - outPos} * head.step + head.positionFrac) >> kFracBits);
+            const uint32_t Nv = N - outPos;
+            uint32_t D = 0u, S = 0u, Sprev = 0u, fc = head.positionFrac;
+            while(vq.multi)
+            {   // (the reference takes them out of the window of the update's LAST chunk)
+                uint32_t cd, cs;
+                CalcBufferSize(fc, head.step, Nv - D, cd, cs);
+                if(D + cd >= Nv) break;
+                const uint64_t tc = uint64_t{fc} + uint64_t{cd} * head.step;
+                Sprev = S; S += uint32_t(tc >> kFracBits); fc = uint32_t(tc) & kFracMask; D += cd;
+            }
+            const uint32_t srcOffEnd = S + uint32_t((uint64_t{Nv - D} * head.step + fc) >> kFracBits);
             WaveSync();
-            FillWindow(w.rd, srcOffEnd, uint32_t(kMaxPad), L, v, head, buf, vq, w, lane);
+            FillWindow(w.rd, srcOffEnd, uint32_t(kMaxPad), L, v, head, buf, vq, w, lane, S, Sprev);
             WaveSync();
             if(lane < uint32_t(kMaxPad)) L.prev[size_t{v} * kMaxPad + lane] = w.rd[lane];
             WaveSync();

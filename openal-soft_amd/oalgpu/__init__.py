@@ -76,6 +76,11 @@ class ContextDesc(C.Structure):
 
 
 # oalgpu_context_desc::flags
+class VoiceEvent(C.Structure):
+    _fields_ = [("voice", C.c_uint32), ("play_state", C.c_int32), ("has_buffer", C.c_int32), ("current_buffer", C.c_int32),
+                ("buffers_done", C.c_uint32), ("position", C.c_int32), ("position_frac", C.c_uint32), ("fading", C.c_int32)]
+
+
 CTX_FIR_VALU, CTX_PROFILE, CTX_SERIAL, CTX_STREAM_ROWS, CTX_APPLY_IN_VOICE_KERNEL, CTX_FUSED_REDUCE = 1, 2, 4, 8, 16, 32
 CTX_RESIDENT = 64
 CTX_SLICE_LINES = 128
@@ -520,6 +525,20 @@ class Scene:
         lib.oalgpu_output_wait.argtypes = [C.c_void_p, C.c_uint32, f32p, C.c_size_t]
         check(lib.oalgpu_output_wait(self.h, ticket, _fp(out), out.size), "oalgpu_output_wait")
         return out
+
+    def voice_events_async(self):
+        lib.oalgpu_voice_events_async.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        t = C.c_uint32()
+        check(lib.oalgpu_voice_events_async(self.h, C.byref(t)), "oalgpu_voice_events_async")
+        return t.value
+
+    def voice_events_wait(self, ticket, capacity=1024):
+        """-> list of VoiceEvent (what changed about the voices since the report before)"""
+        arr = (VoiceEvent * capacity)()
+        n = C.c_size_t()
+        lib.oalgpu_voice_events_wait.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        check(lib.oalgpu_voice_events_wait(self.h, ticket, arr, capacity, C.byref(n)), "oalgpu_voice_events_wait")
+        return [arr[i] for i in range(n.value)]
 
     def param_block(self, voices, params_array):
         voices = np.ascontiguousarray(voices, np.uint32)

@@ -608,6 +608,35 @@ int oalbridge_track_changes(oalbridge *b, int on)
     return 0;
 }
 
+/* the batch mixer's pipelined mode (include/oalgpu_openal.hpp: the post-process behind the boundary too, an update's output
+ * `depth` updates late), before the first update; oalbridge_drain collects what is outstanding: `depth` updates' output,
+ * interleaved stereo, `frames` frames each, one update after the other */
+int oalbridge_set_pipelined(oalbridge *b, uint32_t depth)
+{
+    b->batch->setPipelined(depth);
+    return 0;
+}
+
+int oalbridge_batch_times(oalbridge *b, double out[3]) { for(int i = 0; i < 3; ++i) out[i] = b->batch->times()[i]; return 0; }
+
+int oalbridge_drain(oalbridge *b, float *interleaved, uint32_t frames, uint32_t max_updates)
+{
+    auto &dev = *b->dev;
+    uint32_t got = 0;
+    while(got < max_updates && b->batch->pendingUpdates() > 0)
+    {
+        std::ranges::fill(dev.MixBuffer | std::views::join, 0.0f);
+        if(int rc = b->batch->collectOne(b->ctx.get(), dev)) { b->error = rc; b->errorText = b->batch->errorText(); return -1; }
+        for(uint32_t i = 0; i < frames; ++i)
+        {
+            interleaved[(size_t{got} * frames + i) * 2 + 0] = dev.RealOut.Buffer[0][i];
+            interleaved[(size_t{got} * frames + i) * 2 + 1] = dev.RealOut.Buffer[1][i];
+        }
+        ++got;
+    }
+    return int(got);
+}
+
 /* voices the batched mixer currently keeps a device-side slot for (stopped voices give theirs back) */
 int oalbridge_batch_live_voices(oalbridge *b) { return int(b->batch->liveVoices()); }
 

@@ -142,6 +142,27 @@ class Bridge:
     def batch_live_buffers(self):
         return lib().oalbridge_batch_live_buffers(self.h)
 
+    def set_pipelined(self, depth=2):
+        """the batch mixer's pipelined mode (before the first render): outputs `depth` updates late"""
+        lib().oalbridge_set_pipelined.argtypes = [C.c_void_p, C.c_uint32]
+        lib().oalbridge_set_pipelined(self.h, depth)
+
+    def drain(self, frames, max_updates=4):
+        """what is outstanding in the pipelined mode: [updates][frames][2]"""
+        out = np.zeros((max_updates, frames, 2), np.float32)
+        lib().oalbridge_drain.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32]
+        n = lib().oalbridge_drain(self.h, out.ctypes.data_as(f32p), frames, max_updates)
+        if n < 0:
+            raise RuntimeError("oalbridge_drain: " + lib().oalbridge_error(self.h).decode())
+        return out[:n]
+
+    def batch_times(self):
+        """seconds the batch mixer's flush spent so far: (walking the voices, submitting, collecting)"""
+        t = (C.c_double * 3)()
+        lib().oalbridge_batch_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib().oalbridge_batch_times(self.h, t)
+        return tuple(t)
+
     def track_changes(self, on=True):
         lib().oalbridge_track_changes(self.h, 1 if on else 0)
 

@@ -296,3 +296,56 @@ def test_hrtf_batched_update_at_the_headline_size():
     bound = 4e-5 * float(np.abs(want).max()) + 1e-7
     assert err <= bound, (err, bound)
     assert live[0] == 4096
+
+
+# ---- the pipelined mode of the batch mixer (include/oalgpu_openal.hpp) --------------------------------------
+def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=False):
+    """The HRTF device without auxiliary sends: config-3-shaped sources, every 4th moving, one in sixteen running out of buffer in
+    the third update, a ninth told to stop in the second.  pipelined: the batch mixer's pipelined mode with that depth; the
+    outstanding updates are drained at the end.  -> ([updates (+ depth)][1024][2], play states)"""
+    b = bl.Bridge(mode, 1, hrtf=True, num_sends=0)
+    if pipelined:
+        b.set_pipelined(pipelined)
+    if track:
+        b.track_changes(True)
+    srcs = bl.build_config3(b, nsources, slot=-1)
+    out = []
+    for k in range(updates):
+        if k:
+            bl.move_config3(b, srcs, k, slot=-1)
+        if stop and k == 1:
+            for v in srcs[1::9]:
+                b.stop_source(v)
+        out.append(b.render(1024))
+    if pipelined:
+        out.extend(b.drain(1024))
+    states = [b.source_state(v)[0] for v in srcs]
+    live = b.batch_live_voices() if mode == bl.MODE_BATCH else 0
+    b.close()
+    return np.stack(out), states, live
+
+
+@pytest.mark.gpu
+@needs_bridge
+@pytest.mark.parametrize("nsources,track", [(256, False), (4096, True)])
+def test_pipelined_batch_mixer_delivers_the_same_render_two_updates_late(nsources, track):
+    """BatchMixer::setPipelined(2): voices AND the HRTF post-process behind the boundary, an update's two output lines added to
+    RealOut two updates later, voice state heard of through change reports -- against the reference's own render of the same
+    scene (its Voice::mix, its MixDirectHrtf): update u of the pipelined render is update u - 2 of the reference's, the first
+    two are silence, the last two come out of the drain; sources that end or are stopped reach the same play state."""
+    import oalgpu
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    # (the last of the 4096 sources that run out of buffer does so in the seventh update; the pipelined side hears of it two
+    # updates later and the source is Stopped the update after that)
+    U, D = 11, 2
+    want, sw, _ = render_hrtf_direct(bl.MODE_CPU, nsources, U)
+    got, sg, live = render_hrtf_direct(bl.MODE_BATCH, nsources, U, pipelined=D, track=track)
+    assert got.shape[0] == U + D and not got[:D].any()
+    scale = float(np.abs(want).max())
+    assert scale > 0.02
+    tol = (4e-5 if nsources > 1000 else 2e-5) * scale + 1e-7        # (the bounds of the synchronous tests above)
+    for u in range(U):
+        err = float(np.abs(got[u + D].astype(np.float64) - want[u]).max())
+        assert err <= tol, (u, err, tol)
+    assert sg == sw, [(i, a, b) for i, (a, b) in enumerate(zip(sg, sw)) if a != b][:6]
+    assert live == sum(1 for s in sw if s == 1)         # every source that stopped or ended gave its device slot back

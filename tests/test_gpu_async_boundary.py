@@ -138,3 +138,45 @@ def test_negative_hrtf_distances_are_reserved(synth_mhr):
     with pytest.raises(oalgpu.OalgpuError):
         sc.set_params_batch([0, 1], arr)
     sc.close()
+
+
+def test_voice_events_report_what_a_full_readback_would_show(synth_mhr):
+    """oalgpu_voice_events_async / _wait: voices that run out of buffer (Playing -> Stopping -> Stopped) show up in the reports, with
+    the state a full read-back (oalgpu_voices_readback) has at that update; voices that just play on are not reported again."""
+    import oalgpu
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    api._mhr = open(synth_mhr, "rb").read()
+    V = 300
+    sc = api.make_scene(num_dry=4, num_real=2, hrtf=True, max_voices=V, max_buffers=4)
+    rng = np.random.default_rng(5)
+    long_buf = sc.add_buffer(rng.uniform(-1, 1, 48000).astype(np.float32), oalgpu.FMT_FLOAT, loop_start=0, loop_end=48000)
+    short_buf = sc.add_buffer(rng.uniform(-1, 1, 2500).astype(np.float32), oalgpu.FMT_FLOAT)
+    ending = set(range(0, V, 7))                       # these run out during the third update
+    import oracle_lib as ol
+    for v in range(V):
+        sc.add_voice(short_buf if v in ending else long_buf, v not in ending, position=(v * 131) % 400)
+        sc.set_params(v, ol.make_voice_params(60211, ol.RS_BSINC24, hrtf=(0.1 * (v % 9), 0.3 * (v % 11), 2.0, 0.0, 0.2)))
+    tickets, known = [], {}
+    for k in range(6):
+        sc.mix(1024, post_process=True)
+        tickets.append(sc.voice_events_async())
+        if k >= 2:
+            for e in sc.voice_events_wait(tickets[k - 2]):
+                known[e.voice] = (e.play_state, e.has_buffer, e.position, e.position_frac)
+    for t in tickets[-2:]:
+        for e in sc.voice_events_wait(t):
+            known[e.voice] = (e.play_state, e.has_buffer, e.position, e.position_frac)
+    assert set(known) == ending                         # (voices the host started and that play on are no news)
+    for v in range(V):
+        st = sc.voice_state(v)
+        if v in ending:
+            assert st.play_state == oalgpu.VOICE_STOPPED and known[v][0] == oalgpu.VOICE_STOPPED and known[v][1] == 0, (v, known[v])
+        else:
+            assert st.play_state == oalgpu.VOICE_PLAYING
+    # nothing changes any more: an empty report
+    sc.mix(1024, post_process=True)
+    sc.mix(1024, post_process=True)
+    sc.voice_events_wait(sc.voice_events_async())
+    sc.mix(1024, post_process=True)
+    assert sc.voice_events_wait(sc.voice_events_async()) == []
+    sc.close()

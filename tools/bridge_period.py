@@ -29,15 +29,19 @@ def main():
     print(f"{N} HRTF sources behind the reference's renderSamples, 1024-sample updates, one host thread")
     print(f"{'':34s}{'us / update':>12s}{'voices/s':>12s}{'of which outside render: moves':>34s}")
     for scene in ("moving", "static"):
-        for name, mode, track in (("reference Voice::mix (CPU)", bl.MODE_CPU, False), ("batch mixer, every voice compared", bl.MODE_BATCH, False),
-                                  ("batch mixer + parameter hook", bl.MODE_BATCH, True)):
+        for name, mode, track, depth in (("reference Voice::mix (CPU)", bl.MODE_CPU, False, 0), ("batch mixer, every voice compared", bl.MODE_BATCH, False, 0),
+                                         ("batch mixer + parameter hook", bl.MODE_BATCH, True, 0),
+                                         ("batch mixer pipelined (post-process on the GPU, output 2 updates late) + hook", bl.MODE_BATCH, True, 2)):
             b = bl.Bridge(mode, oalgpu.MATH_FAST, hrtf=True, num_sends=0)
+            if depth:
+                b.set_pipelined(depth)
             if track:
                 b.track_changes(True)
             srcs = bl.build_config3(b, N, slot=-1)
-            for k in range(5):                                  # voices started, filters settled, clocks up
+            for k in range(12):                                 # voices started, the sources that run out of buffer gone, clocks up
                 b.render(1024)
             t_render, t_move = [], []
+            bt0 = b.batch_times() if depth else None
             for k in range(args.updates):
                 t0 = time.perf_counter()
                 if scene == "moving":
@@ -46,9 +50,16 @@ def main():
                 b.render(1024)
                 t2 = time.perf_counter()
                 t_move.append(t1 - t0); t_render.append(t2 - t1)
+            parts = ""
+            if depth:
+                bt1 = b.batch_times()
+                w, sub, col = [(a1 - a0) / args.updates * 1e6 for a0, a1 in zip(bt0, bt1)]
+                parts = f"   [mean per update: flush walks the voices {w:.1f} us, submits {sub:.1f}, collects {col:.1f}; the rest is the reference's ProcessContexts and the per-voice seam]"
+            if depth:
+                parts += "\n      render times of the timed updates [us]: " + " ".join(f"{t * 1e6:.0f}" for t in t_render)
             b.close()
             r = float(np.median(t_render))
-            print(f"{scene + ': ' + name:34s}{r * 1e6:12.1f}{N / r / 1e6:11.2f}M{float(np.median(t_move)) * 1e6:34.1f}")
+            print(f"{scene + ': ' + name:34s}{r * 1e6:12.1f}{N / r / 1e6:11.2f}M{float(np.median(t_move)) * 1e6:34.1f}{parts}", flush=True)
 
 
 if __name__ == "__main__":
