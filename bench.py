@@ -731,11 +731,10 @@ def main():
         traffic_source = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "voice_kernel_traffic.json")))
-            ent = tj.get("configs", {}).get(str(args.config), tj)
-            if ent.get("config", args.config) == args.config and ent.get("voices") == V \
-                    and ent.get("kernel", sc.voice_kernel_name()) == sc.voice_kernel_name():
-                traffic = ent["hbm_bytes_per_launch"]
-                traffic_source = _file_source("voice_kernel_traffic.json")
+            for ent in tj.get("configs", {}).values():       # (config 4 has two entries: stream rows, and the opt-in slice kernel)
+                if ent.get("config") == args.config and ent.get("voices") == V and ent.get("kernel") == sc.voice_kernel_name():
+                    traffic = ent["hbm_bytes_per_launch"]
+                    traffic_source = _file_source("voice_kernel_traffic.json")
         except (OSError, ValueError, KeyError):
             pass
         out = {
