@@ -3372,6 +3372,36 @@ int oalgpu_slot_set_convolution(oalgpu_context *c, uint32_t slot, oalgpu_convolu
     return OALGPU_OK;
 }
 
+// An EAX reverb instance is ONE workgroup that needs a compute unit's LDS nearly to itself (128 KB: both pipelines' rows,
+// csrc/reverb_kernels.hip), and it runs on the post stream beside the NEXT update's voice kernel.  A voice kernel whose grid fills
+// the machine exactly (two 78 KB workgroups on every CU) then finds the instances' CUs taken: the workgroups it cannot place wait
+// for a second round, and the launch lasts 1.6 times as long (BASELINE configs[3]: 110 -> 174 us in every other update, the
+// reverbs 85 -> 170 us in the updates between, profiles/r5/evidence/step_timeline_config4.txt).  With reverbs attached the
+// automatic voices-per-workgroup choice therefore leaves the instances their CUs: a few more voices per wavefront, so that the
+// grid fits on the CUs that are left -- one round, and the reverbs run beside it undisturbed.
+static int RebalanceWaveGroups(oalgpu_context *c)
+{
+    if(!c->useWave || c->desc.voices_per_group != 0u) return OALGPU_OK;
+    uint32_t reverbs = 0;
+    for(oalgpu_reverb *r : c->slotReverb) reverbs += r ? 1u : 0u;
+    hipDeviceProp_t prop{};
+    if(hipGetDeviceProperties(&prop, c->desc.device) != hipSuccess || prop.multiProcessorCount <= 0) { (void)hipGetLastError(); return OALGPU_OK; }
+    const uint32_t cus = uint32_t(prop.multiProcessorCount);
+    const uint32_t slots = 2u * (cus > reverbs ? cus - reverbs : 1u);          // two voice workgroups per compute unit
+    DeviceLayout &L = c->L;
+    uint32_t vpw = std::max<uint32_t>(1u, (c->desc.max_voices + 2047u) / 2048u);  // (oalgpu_context_create's rule)
+    const uint32_t full = 2u * cus;
+    auto groupsOf = [&](uint32_t w) { DeviceLayout T = L; T.waveVoices = w; return WaveKernelGroups(T); };
+    // only a grid that was meant to fill the machine in one round is thinned out (smaller scenes leave room anyway)
+    if(reverbs && groupsOf(vpw) <= full) { while(groupsOf(vpw) > slots) ++vpw; }
+    if(vpw == L.waveVoices) return OALGPU_OK;
+    if(int rc = oalgpu_sync(c)) return rc;
+    L.waveVoices = vpw;
+    L.numGroups = std::max<uint32_t>(1u, WaveKernelGroups(L));       // (never more than the context's buffers were sized for)
+    L.numLineGroups = L.numGroups;
+    return OALGPU_OK;
+}
+
 int oalgpu_slot_set_effect(oalgpu_context *c, uint32_t slot, oalgpu_effect *fx)
 {
     if(!c || slot >= c->L.numSlots) return Fail(OALGPU_ERR_INVALID, "oalgpu_slot_set_effect: bad slot");
@@ -3393,7 +3423,7 @@ int oalgpu_slot_set_reverb(oalgpu_context *c, uint32_t slot, oalgpu_reverb *rev)
     if(int rc = oalgpu_sync(c)) return rc;
     if(rev) { if(int rc = oalgpu_reverb_set_math_mode(rev, c->exact ? OALGPU_MATH_EXACT : OALGPU_MATH_FAST)) return rc; }
     c->slotReverb[slot] = rev;
-    return OALGPU_OK;
+    return RebalanceWaveGroups(c);
 }
 
 const char *oalgpu_voice_kernel_name(oalgpu_context *c)
