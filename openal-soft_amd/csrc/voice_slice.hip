@@ -35,9 +35,9 @@ namespace oalgpu {
 namespace {
 
 constexpr int kSl = 256;                      // frames per slice
-constexpr int kSlPre = 10;                    // prefetched window: registers per lane
-constexpr int kSlWin = kSlPre * 64;           // source samples a slice's window holds (pitch <= ~2.4 in one piece)
-constexpr int kSlRd = kMaxEdge + kSlWin + 8;  // 672 floats = 10.5 x 64: rd2 starts half the banks away from rd
+constexpr int kSlPre = 9;                     // prefetched window: registers per lane
+constexpr int kSlWin = kSlPre * 64;           // source samples a slice's window holds (pitch <= ~2.1 in one piece)
+constexpr int kSlRd = kMaxEdge + kSlWin + 8;  // 608 floats = 9.5 x 64: rd2 starts half the banks away from rd
 static_assert(kSlRd % 64 == 32, "rd2 sits half the banks away from rd");
 constexpr int kSlBlock = 16;                  // voices between two workgroup barriers (mailbox slots)
 constexpr int kSlStages = 8;                  // recurrences with a hand-over: direct filter, six sends, ambisonic splitter
@@ -55,8 +55,20 @@ struct alignas(16) SliceWaveLds {
     uint32_t pad[3];
 };
 
+// What a voice's update is, worked out ONCE per workgroup (by one wavefront, in front of the block's voices) for the four
+// wavefronts that mix its slices: the plan, and the gains of all lines resolved (line = lane)
+struct SliceRec {
+    uint32_t w[16];                           // see RecWord
+    float gain[32], cur[32], step[32];        // per line: the gain behind the ramp; the ramp's start and step (slice 0 only)
+    uint32_t fade[32];                        // per line: frames the ramp covers (0: none)
+    int32_t rowId[32];                        // per line: the signal it is mixed from (-1 none, 0 unfiltered row, 1 direct-filtered, 2 + send)
+};
+enum RecWord : int { kRwFlags = 0, kRwOutPos, kRwBufferItem, kRwBsrcFull, kRwSfBits, kRwHaveSend, kRwPending, kRwRestMask, kRwOrder };
+enum RecFlag : uint32_t { kRfActive = 1u, kRfPlaying = 2u, kRfLooping = 4u, kRfQueue = 8u, kRfAnyFull = 16u, kRfMulti = 32u, kRfDirectFilter = 64u };
+
 struct SliceWgLds {
     SliceWaveLds w[kWWaves];
+    SliceRec rec[kSlBlock];
     alignas(16) f2 tabF[kTabPairs * 32];      // [tap pair][phase], as in voice_wave.hip
     f2 tabP[kTabPairs * 32];
     uint32_t tabKey, tabM, tabL, pad;
@@ -360,6 +372,7 @@ __device__ __forceinline__ void GatherSlice(float (&pre)[kSlPre], uint32_t count
         if(k < count)
             r = isShort ? LoadRawGlobal<OALGPU_FMT_SHORT>(b.data, size_t{idx} * fs) : LoadRawGlobal<OALGPU_FMT_FLOAT>(b.data, size_t{idx} * fs);
         pre[i] = r;
+        __builtin_amdgcn_sched_barrier(0);          // (one element's address arithmetic at a time: ten at once cost ten register pairs)
     }
 }
 
@@ -489,6 +502,29 @@ __device__ __forceinline__ uint32_t PairsAtRest(float word, uint32_t lane)
     return ((bad & 0xffffffffull) ? 0u : 1u) | ((bad >> 32) ? 0u : 2u);
 }
 
+// A voice's control line (VoiceCtl, 128 bytes) rides in ONE vector register, lane = dword, requested two voices ahead; its fields
+// come out with v_readlane where they are used.  (As scalar loads two voices ahead the lines were 56 SGPRs live across the whole
+// loop body, and the body's straight-line part was 680 spill moves of 1650 VALU instructions.)
+static_assert(offsetof(VoiceCtl, sendSlot) == 48 && offsetof(VoiceCtl, buf) == 96, "VoiceCtl layout");
+__device__ __forceinline__ uint32_t CtlWord(uint32_t ctlv, int k) { return uint32_t(__builtin_amdgcn_readlane(int(ctlv), k)); }
+__device__ __forceinline__ VoiceHead HeadFrom(uint32_t c)
+{
+    VoiceHead h;
+    h.playState = int32_t(CtlWord(c, 0)); h.position = int32_t(CtlWord(c, 1)); h.positionFrac = CtlWord(c, 2);
+    h.curBuffer = int32_t(CtlWord(c, 3)); h.loopBuffer = int32_t(CtlWord(c, 4)); h.step = CtlWord(c, 5);
+    h.rsKind = int32_t(CtlWord(c, 6)); h.rsM = CtlWord(c, 7); h.rsL = CtlWord(c, 8);
+    h.rsSf = __builtin_bit_cast(float, CtlWord(c, 9)); h.rsFilterOffset = CtlWord(c, 10); h.flags = CtlWord(c, 11);
+    return h;
+}
+__device__ __forceinline__ BufferItem BufFrom(uint32_t c)
+{
+    BufferItem b;
+    b.data = reinterpret_cast<const void*>((uint64_t{CtlWord(c, 25)} << 32) | CtlWord(c, 24));
+    b.fmt = int32_t(CtlWord(c, 26)); b.frameStep = CtlWord(c, 27); b.sampleLen = CtlWord(c, 28);
+    b.loopStart = CtlWord(c, 29); b.loopEnd = CtlWord(c, 30); b.next = int32_t(CtlWord(c, 31));
+    return b;
+}
+
 template<int ACCN>
 __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceKernel(SliceArgs L, uint32_t N)
 {
@@ -566,35 +602,146 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
     const uint32_t laneSlot = laneWet ? (lane0 - numDry) / (wetCh ? wetCh : 1u) : 0u;
     const uint32_t laneCh = laneWet ? (lane0 - numDry) % (wetCh ? wetCh : 1u) : 0u;
 
-    // ---- the voices' control lines run two ahead, a plain slice's window one ahead ----
-    static_assert(offsetof(VoiceCtl, sendSlot) == 48, "VoiceCtl::sendSlot follows the head");
-    VoiceHead hA{}, hB{};
-    BufferItem bA{}, bB{};
-    u4 ssA0{}, ssA1{}, ssB0{}, ssB1{};            // VoiceCtl::sendSlot, bytes 48..71 of the control line
-    auto loadCtl = [&](uint32_t vx, VoiceHead &h, BufferItem &b, u4 &s0, u4 &s1)
+    auto loadCtlV = [&](uint32_t vx, uint32_t lane) -> uint32_t
+    { return lane < 32u ? reinterpret_cast<const uint32_t*>(L.ctl + (vx < L.numVoices ? vx : lastVoice))[lane] : 0u; };
+
+    // ---- a voice's record (SliceRec): its plan; the gains of every line it feeds, resolved as MixSamples will use them
+    // (voice.cpp:934-984, :1094-1112 -- ONE PrepareMixLine per voice, line = lane: a dry line takes the dry gains, a slot's wet
+    // line those of the first send into the slot; further sends into the same slot are left `pending`); Gains.Current as the
+    // update leaves it; which filter pairs are at rest, and the inactive ones that are not cleared (voice.cpp:264-265).
+    // By ONE wavefront per voice, before the four slice wavefronts start on the block.
+    struct ProLoads { uint32_t ctl; float dryTg, dryCu, sTg0, sCu0, sTg1, sCu1, df, sf[3]; };
+    auto proRequest = [&](uint32_t vx, ProLoads &q, uint32_t lane)
     {
-        h = LoadHeadScalar(L.ctl + vx); b = LoadCtlBufferScalar(L.ctl + vx);
-        cu4 *src = (cu4*)(uintptr_t)(L.ctl + vx);
-        s0 = src[3]; s1 = src[4];
+        q.ctl = loadCtlV(vx, lane);
+        const size_t sb = size_t{vx} * sendLanes;
+        q.dryTg = q.dryCu = q.sTg0 = q.sCu0 = q.sTg1 = q.sCu1 = q.df = 0.0f;
+        if(lane < numDry) { q.dryTg = L.gainTgt[size_t{vx} * numDry + lane]; q.dryCu = L.gainCur[size_t{vx} * numDry + lane]; }
+        if(lane < sendLanes) { q.sTg0 = L.sendTgt[sb + lane]; q.sCu0 = L.sendCur[sb + lane]; }
+        if(lane + 64u < sendLanes) { q.sTg1 = L.sendTgt[sb + lane + 64u]; q.sCu1 = L.sendCur[sb + lane + 64u]; }
+        if(lane < 32u) q.df = reinterpret_cast<const float*>(L.dfilt + size_t{vx} * 2)[lane];
+        const float *sf = reinterpret_cast<const float*>(L.sfilt + size_t{vx} * numSends * 2);      // [send][2 x 16 dwords]
+#pragma unroll
+        for(int k = 0; k < 3; ++k) q.sf[k] = (64u * uint32_t(k) + lane < 32u * numSends) ? sf[64u * uint32_t(k) + lane] : 0.0f;
     };
-    if(nv)
+    auto prepare = [&](uint32_t vx, const ProLoads &q, SliceRec &rec, uint32_t lane)
     {
-        loadCtl(v0, hA, bA, ssA0, ssA1);
-        loadCtl((v0 + 1u < L.numVoices) ? v0 + 1u : lastVoice, hB, bB, ssB0, ssB1);
-    }
+        const VoiceHead h = HeadFrom(q.ctl);
+        const BufferItem b = BufFrom(q.ctl);
+        const VoicePlan vp = PlanVoice(L, vx, h, b, N);
+        if(!vp.active) { if(lane < 16u) rec.w[lane] = 0u; return; }
+        const bool playing = vp.playing;
+        const bool directFilter = (h.flags & kFlagDirectFilter) != 0;
+        const uint32_t counter = (h.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
+        const uint32_t sfBits = (h.flags >> kFlagSendFilterShift) & 0x3fu;
+        int32_t sendSlots[6];
+#pragma unroll
+        for(int k = 0; k < 6; ++k) sendSlots[k] = int32_t(CtlWord(q.ctl, 12 + k));
+        uint32_t haveSend = 0u;
+#pragma unroll
+        for(int k = 0; k < 6; ++k) if(uint32_t(k) < numSends && sendSlots[k] >= 0) haveSend |= 1u << k;
+        uint32_t restMask = PairsAtRest(q.df, lane) & 1u;
+#pragma unroll
+        for(int k = 0; k < 3; ++k) if(2u * uint32_t(k) < numSends) restMask |= PairsAtRest(q.sf[k], lane) << (1u + 2u * uint32_t(k));
+        // every slot's first send; the lanes of the slot's lines learn which
+        int32_t mySend = -1;
+        uint32_t taken = 0u, slotsTaken = 0u;
+#pragma unroll
+        for(int k = 0; k < 6; ++k)
+        {
+            if(!((haveSend >> k) & 1u)) continue;
+            const uint32_t slot = uint32_t(sendSlots[k]) & 31u;
+            if((slotsTaken >> slot) & 1u) continue;
+            slotsTaken |= 1u << slot;
+            taken |= 1u << k;
+            if(laneWet && laneSlot == slot) mySend = k;
+        }
+        const bool isDry = lane < numDry;
+        const bool mine = isDry || mySend >= 0;
+        const uint32_t from = uint32_t(mySend) * wetCh + laneCh;        // (the sends' gains came in packed, lane = send x wet channel)
+        float tgS = __shfl(q.sTg0, int(from & 63u)), cuS = __shfl(q.sCu0, int(from & 63u));
+        if(sendLanes > 64u)
+        {
+            const float tB = __shfl(q.sTg1, int(from & 63u)), cB = __shfl(q.sCu1, int(from & 63u));
+            if(from >= 64u) { tgS = tB; cuS = cB; }
+        }
+        const float tg = (mine && playing) ? (isDry ? q.dryTg : tgS) : 0.0f;              // SilentCoeffs when Stopping
+        const float cu = (mine && counter) ? (isDry ? q.dryCu : cuS) : tg;                // voice.cpp:1094-1112
+        const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+        RowGain all;
+        if(mine)
+        {
+            float *curStore = isDry ? L.gainCur + size_t{vx} * numDry + lane : L.sendCur + (size_t{vx} * numSends + uint32_t(mySend)) * wetCh + laneCh;
+            *curStore = g.newCur;
+            all.add(g);
+        }
+        int32_t rowId = -1;
+        if(isDry) rowId = directFilter ? 1 : 0;
+        else if(mySend >= 0) rowId = ((sfBits >> uint32_t(mySend)) & 1u) ? 2 + mySend : 0;
+        // the signals: bits 0..5 the filtered sends, 6 the unfiltered row, 7 the direct-filtered row (in this order: the direct
+        // filter runs in place)
+        uint32_t order = taken & sfBits;
+        if(__ballot(rowId == 0) != 0ull) order |= 1u << 6;
+        if(directFilter) order |= 1u << 7;
+        // an inactive pair that is not at rest is cleared (voice.cpp:264-265): bit 0 the direct pair, 1 + i send i's
+        uint32_t clr = (((haveSend & ~sfBits) << 1) | (directFilter ? 0u : 1u)) & ~restMask;
+        while(clr)
+        {
+            const uint32_t stage = uint32_t(__builtin_ctz(clr));
+            clr &= clr - 1u;
+            float *slots32 = stage ? reinterpret_cast<float*>(&L.sfilt[(size_t{vx} * numSends + (stage - 1u)) * 2]) : reinterpret_cast<float*>(&L.dfilt[size_t{vx} * 2]);
+            WaveSync();
+            if(lane < 32u) w.fst[lane] = slots32[lane];
+            WaveSync();
+            WaveDoFilters(w.fst, reinterpret_cast<BiquadSlot*>(slots32), false, w.in, 0u, lane);
+            WaveSync();
+        }
+        const uint32_t flags = kRfActive | (playing ? kRfPlaying : 0u) | (vp.looping ? kRfLooping : 0u) | (vp.queue ? kRfQueue : 0u)
+            | (vp.anyFull ? kRfAnyFull : 0u) | (vp.multi ? kRfMulti : 0u) | (directFilter ? kRfDirectFilter : 0u);
+        if(lane < 16u)
+        {
+            uint32_t wv = 0u;
+            wv = lane == uint32_t(kRwFlags) ? flags : wv;
+            wv = lane == uint32_t(kRwOutPos) ? vp.outPos : wv;
+            wv = lane == uint32_t(kRwBufferItem) ? uint32_t(vp.bufferItem) : wv;
+            wv = lane == uint32_t(kRwBsrcFull) ? vp.bsrcFull : wv;
+            wv = lane == uint32_t(kRwSfBits) ? sfBits : wv;
+            wv = lane == uint32_t(kRwHaveSend) ? haveSend : wv;
+            wv = lane == uint32_t(kRwPending) ? (haveSend & ~taken) : wv;
+            wv = lane == uint32_t(kRwRestMask) ? restMask : wv;
+            wv = lane == uint32_t(kRwOrder) ? order : wv;
+            rec.w[lane] = wv;
+        }
+        if(lane < 32u) { rec.gain[lane] = all.gain; rec.cur[lane] = all.cur; rec.step[lane] = all.step; rec.fade[lane] = all.fadeLen; rec.rowId[lane] = rowId; }
+    };
+    auto planOf = [&](uint32_t rw) -> VoicePlan
+    {   // (a record's words, lane = word, back into the plan the slice code reads)
+        VoicePlan p{};
+        const uint32_t fl = CtlWord(rw, kRwFlags);
+        p.active = (fl & kRfActive) != 0u; p.playing = (fl & kRfPlaying) != 0u; p.looping = (fl & kRfLooping) != 0u; p.queue = (fl & kRfQueue) != 0u;
+        p.anyFull = (fl & kRfAnyFull) != 0u; p.multi = (fl & kRfMulti) != 0u;
+        p.outPos = CtlWord(rw, kRwOutPos); p.bufferItem = int32_t(CtlWord(rw, kRwBufferItem)); p.bsrcFull = CtlWord(rw, kRwBsrcFull);
+        return p;
+    };
+
     float preN[kSlPre];
     float prevN = 0.0f;
 #pragma unroll
     for(int i = 0; i < kSlPre; ++i) preN[i] = 0.0f;
-    // what the mix starts from, requested one voice ahead with the window: target gains (lane = line / send x wet channel), and for
-    // the wavefront of the voice's FIRST slice the current gains and the filter pairs as memory holds them (lane = word)
-    float dryTgN = 0.0f, dryCuN = 0.0f, sTgN = 0.0f, sCuN = 0.0f, dfN = 0.0f;
+    // requested one voice ahead with the window, by the wavefront of the voice's FIRST slice: the filter pairs as memory holds them
+    float dfN = 0.0f;
     float sfN[3] = {0.0f, 0.0f, 0.0f};            // the sends' pairs, two per register: sends 2 q (lanes 0..31) and 2 q + 1
     VoicePlan vpN{};
     SlicePlan spN{};
-    auto request = [&](uint32_t vn, const VoiceHead &h, const BufferItem &b, uint32_t lane)
+    uint32_t rwN = 0u;                            // the next voice's record words, lane = word
+    auto request = [&](uint32_t vn, uint32_t jbn, uint32_t ctlv, uint32_t lane)
     {
-        vpN = PlanVoice(L, vn, h, b, N);
+        rwN = sm.rec[jbn].w[lane & 15u];
+        vpN = planOf(rwN);
+        spN = SlicePlan{};
+        if(!vpN.active) return;
+        const VoiceHead h = HeadFrom(ctlv);
+        const BufferItem b = BufFrom(ctlv);
         spN = PlanSlice(h, b, vpN, f0, nS);
         if(spN.pref)
         {
@@ -602,43 +749,61 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
             GatherSlice(preN, total - spN.nPrev, b, vpN.looping, spN.upos, lane);
             prevN = (lane < spN.nPrev) ? L.prev[size_t{vn} * kMaxPad + spN.srcOff + lane] : 0.0f;
         }
-        if(spN.cnt)
+        // the filter pairs that run, for the wavefront that starts them
+        const uint32_t running = ((CtlWord(rwN, kRwSfBits) & CtlWord(rwN, kRwHaveSend)) << 1) | ((CtlWord(rwN, kRwFlags) & kRfDirectFilter) ? 1u : 0u);
+        if(spN.cnt && running && wave == vpN.outPos / uint32_t(kSl))
         {
-            const bool firstN = wave == vpN.outPos / uint32_t(kSl);
-            const size_t sb = size_t{vn} * sendLanes;
-            if(lane < numDry) dryTgN = L.gainTgt[size_t{vn} * numDry + lane];
-            if(lane < sendLanes) sTgN = L.sendTgt[sb + lane];
-            if(firstN)
-            {
-                if(lane < numDry) dryCuN = L.gainCur[size_t{vn} * numDry + lane];
-                if(lane < sendLanes) sCuN = L.sendCur[sb + lane];
-                if(lane < 32u) dfN = reinterpret_cast<const float*>(L.dfilt + size_t{vn} * 2)[lane];
-                const float *sf = reinterpret_cast<const float*>(L.sfilt + size_t{vn} * numSends * 2);      // [send][2 x 16 dwords]
+            if(lane < 32u) dfN = reinterpret_cast<const float*>(L.dfilt + size_t{vn} * 2)[lane];
+            const float *sf = reinterpret_cast<const float*>(L.sfilt + size_t{vn} * numSends * 2);      // [send][2 x 16 dwords]
 #pragma unroll
-                for(int q = 0; q < 3; ++q)
-                    if(64u * uint32_t(q) + lane < 32u * numSends) sfN[q] = sf[64u * uint32_t(q) + lane];
-            }
+            for(int q = 0; q < 3; ++q)
+                if(64u * uint32_t(q) + lane < 32u * numSends) sfN[q] = sf[64u * uint32_t(q) + lane];
         }
     };
-    if(nv) request(v0, hA, bA, lane0);
 
-    for(uint32_t j = 0; j < nv; ++j)
+    for(uint32_t b0 = 0; b0 < nv; b0 += uint32_t(kSlBlock))
+    {
+    const uint32_t nb = (nv - b0 < uint32_t(kSlBlock)) ? nv - b0 : uint32_t(kSlBlock);
+    __syncthreads();                              // the block before is through: its records and mailboxes are free
+    // (the lane index behind an opaque move per block: addresses built from it are a few VALU here, not loop invariants in scratch)
+    uint32_t laneB = lane0;
+    asm volatile("" : "+v"(laneB));
+    {   // ---- the block's records: four voices per wavefront, the next one's loads in flight while one is worked out
+        ProLoads qa, qb;
+        if(wave < nb) proRequest(v0 + b0 + wave, qa, laneB);
+#pragma unroll
+        for(int q = 0; q < kSlBlock / kWWaves; ++q)
+        {
+            const uint32_t jbq = wave + uint32_t(kWWaves * q);
+            if(jbq >= nb) break;
+            if(jbq + uint32_t(kWWaves) < nb) proRequest(v0 + b0 + jbq + uint32_t(kWWaves), qb, laneB);
+            prepare(v0 + b0 + jbq, qa, sm.rec[jbq], laneB);
+            qa = qb;
+        }
+    }
+    __syncthreads();
+    uint32_t ctlA = loadCtlV(v0 + b0, laneB), ctlB = loadCtlV(v0 + b0 + 1u, laneB);
+    // (nothing of the block before is carried: the request registers begin again, so that they are not live across the prologue)
+#pragma unroll
+    for(int i = 0; i < kSlPre; ++i) preN[i] = 0.0f;
+    prevN = 0.0f; dfN = 0.0f; sfN[0] = sfN[1] = sfN[2] = 0.0f;
+    request(v0 + b0, 0u, ctlA, laneB);
+
+    for(uint32_t jb = 0; jb < nb; ++jb)
     {
         uint32_t lane = lane0;
         asm volatile("" : "+v"(lane));
-        if(j && (j % uint32_t(kSlBlock)) == 0u) __syncthreads();       // the mailboxes of the block before are free
+        const uint32_t j = b0 + jb;
         const uint32_t v = v0 + j;
-        const uint32_t jb = j % uint32_t(kSlBlock);
         const uint32_t tagBase = (j / uint32_t(kSlBlock)) * 8u;
-        const VoiceHead head = hA;
-        const BufferItem buf = bA;
+        const uint32_t ctlCur = ctlA, rw = rwN;
         const VoicePlan vp = vpN;
         const SlicePlan sp = spN;
 
         // this voice's window leaves the registers; the next voice's is requested
         if(sp.pref)
         {
-            const bool isShort = buf.fmt == OALGPU_FMT_SHORT;
+            const bool isShort = int32_t(CtlWord(ctlCur, 26)) == OALGPU_FMT_SHORT;
             if(lane < sp.nPrev) { w.rd[lane] = prevN; if(lane) w.rd2[lane - 1u] = prevN; }
 #pragma unroll
             for(int i = 0; i < kSlPre; ++i)
@@ -649,45 +814,28 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
                 if(at) w.rd2[at - 1u] = sv;
             }
         }
-        const float dryTg = dryTgN, dryCu = dryCuN, sTg0 = sTgN, sCu0 = sCuN;
-        const u4 ssa = ssA0, ssb = ssA1;
         const uint32_t kFirst = vp.outPos / uint32_t(kSl);
         const bool isFirst = wave == kFirst, isLast = wave == kLast;
-        uint32_t restMask = 0u;                 // isFirst: which of the voice's filter pairs are at rest (bit 0 direct, 1 + i send i)
         if(sp.cnt && isFirst)
-        {
+        {   // (the pairs that run start from these)
             if(lane < 32u) w.st[0][lane] = dfN;
-            restMask = PairsAtRest(dfN, lane) & 1u;
 #pragma unroll
             for(int q = 0; q < 3; ++q)
-                if(2u * uint32_t(q) < numSends)
-                {
-                    if(64u * uint32_t(q) + lane < 32u * numSends) (&w.st[1][0])[64u * uint32_t(q) + lane] = sfN[q];
-                    restMask |= PairsAtRest(sfN[q], lane) << (1u + 2u * uint32_t(q));
-                }
+                if(64u * uint32_t(q) + lane < 32u * numSends) (&w.st[1][0])[64u * uint32_t(q) + lane] = sfN[q];
         }
-        hA = hB; bA = bB; ssA0 = ssB0; ssA1 = ssB1;
-        if(j + 1u < nv)
+        ctlA = ctlB;
+        if(jb + 1u < nb)
         {
-            request(v + 1u, hA, bA, lane);
-            loadCtl((v + 2u < L.numVoices) ? v + 2u : lastVoice, hB, bB, ssB0, ssB1);
+            request(v + 1u, jb + 1u, ctlA, lane);
+            ctlB = loadCtlV(v + 2u, lane);
         }
         if(!vp.active) continue;
         if(wave < kFirst || wave > kLast) continue;
+        const VoiceHead head = HeadFrom(ctlCur);
+        const BufferItem buf = BufFrom(ctlCur);
         const bool playing = vp.playing;
-        const uint32_t counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
         const uint32_t cnt = sp.cnt, dstOff = sp.dstOff;
         float *row = w.in;
-
-        // (more than 64 send x wet-channel gains: the second register's worth is fetched here)
-        float sTg1 = 0.0f, sCu1 = 0.0f;
-        if(sendLanes > 64u && lane + 64u < sendLanes)
-        {
-            const size_t sb = size_t{v} * sendLanes;
-            sTg1 = L.sendTgt[sb + lane + 64u];
-            if(isFirst) sCu1 = L.sendCur[sb + lane + 64u];
-        }
-        const int32_t sendSlots[6] = {int32_t(ssa.x), int32_t(ssa.y), int32_t(ssa.z), int32_t(ssa.w), int32_t(ssb.x), int32_t(ssb.y)};
 
         // ---- LoadResampledSamples for the slice: row[dstOff .. dstOff + cnt)
         if(cnt != uint32_t(kSl)) for(uint32_t k = lane; k < uint32_t(kSl); k += 64u) if(k < dstOff || k >= dstOff + cnt) row[k] = 0.0f;
@@ -771,7 +919,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
                 {
                     const uint32_t f = __hip_atomic_load(&sm.flag[jb][stage], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if(f == want) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(8);                        // (~0.2 us a look: a waiting wavefront's polls are instructions the SIMD's other wavefront could issue)
                     if(spins > (1u << 24)) break;                      // (never: a wavefront waits only for lower slices, and slice 0 for nobody)
                 }
                 // (mailbox and flag are LDS, which serves a wavefront's operations in order: nothing of wider scope to wait for --
@@ -809,73 +957,24 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
             WaveSync();
         }
 
-        // ---- DoFilters and MixSamples (voice.cpp:934-984).  The gains of ALL lines are resolved at once, line = lane: a dry line
-        // takes the voice's dry gains, a slot's wet line the gains of the send that feeds the slot -- ONE PrepareMixLine per voice
-        // and slice instead of one per send (two sends into the same slot: the second waits for another pass).  Every line is
-        // mixed from exactly one of the voice's signals: the unfiltered row (0: dry lines without a direct filter, sends without
-        // a filter), the direct-filtered row (1), a send's own filtered copy (2 + send).  The signals that exist go one after
-        // the other through ONE filter run and ONE mix: a single site of each keeps the 96 accumulator registers in one
+        // ---- DoFilters and MixSamples (voice.cpp:934-984).  Every line is mixed from exactly one of the voice's signals -- the
+        // unfiltered row (0: dry lines without a direct filter, sends without a filter), the direct-filtered row (1), a send's
+        // own filtered copy (2 + send) -- with the gains the voice's record holds (line = lane).  The signals that exist go one
+        // after the other through ONE filter run and ONE mix: a single site of each keeps the 96 accumulator registers in one
         // allocation across the loop.
         const bool ramp = wave == 0u;
-        const bool directFilter = (head.flags & kFlagDirectFilter) != 0;
-        const uint32_t sfBits = (head.flags >> kFlagSendFilterShift) & 0x3fu;
-        uint32_t haveSend = 0u;
-#pragma unroll
-        for(int q = 0; q < 6; ++q) if(uint32_t(q) < numSends && sendSlots[q] >= 0) haveSend |= 1u << q;
-        uint32_t pending = haveSend;
-        bool firstPass = true;
-        do
+        const SliceRec &rec = sm.rec[jb];
+        RowGain all;
+        int32_t rowId = -1;
+        if(lane < 32u)
         {
-            // this pass's sends: every slot's first pending one; the lanes of the slot's lines learn which
-            int32_t mySend = -1;
-            uint32_t taken = 0u, slotsTaken = 0u;
-#pragma unroll
-            for(int q = 0; q < 6; ++q)
-            {
-                if(!((pending >> q) & 1u)) continue;
-                const uint32_t slot = uint32_t(sendSlots[q]) & 31u;
-                if((slotsTaken >> slot) & 1u) continue;
-                slotsTaken |= 1u << slot;
-                taken |= 1u << q;
-                if(laneWet && laneSlot == slot) mySend = q;
-            }
-            pending &= ~taken;
-            const bool isDry = firstPass && lane < numDry;
-            const bool mine = isDry || mySend >= 0;
-            // the sends' gains came in packed, lane = send x wet channel
-            const uint32_t from = uint32_t(mySend) * wetCh + laneCh;
-            float tgS = __shfl(sTg0, int(from & 63u)), cuS = isFirst ? __shfl(sCu0, int(from & 63u)) : 0.0f;
-            if(sendLanes > 64u)
-            {
-                const float tB = __shfl(sTg1, int(from & 63u)), cB = __shfl(sCu1, int(from & 63u));
-                if(from >= 64u) { tgS = tB; cuS = cB; }
-            }
-            const float tg = (mine && playing) ? (isDry ? dryTg : tgS) : 0.0f;              // SilentCoeffs when Stopping
-            const float cu = (mine && isFirst && counter) ? (isDry ? dryCu : cuS) : tg;       // voice.cpp:1094-1112
-            RowGain all;
-            if(isFirst)
-            {   // (the voice's first slice: MixLine's ramp, and the gain the update leaves behind)
-                const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
-                if(mine)
-                {
-                    float *curStore = isDry ? L.gainCur + size_t{v} * numDry + lane : L.sendCur + (size_t{v} * numSends + uint32_t(mySend)) * wetCh + laneCh;
-                    *curStore = g.newCur;
-                    all.add(g);
-                }
-            }
-            else if(mine)
-            {   // (the ramp is over: the target, unless silent)
-                const float c = (__builtin_fabsf(tg) > kGainSilence) ? tg : 0.0f;
-                all.gain = c; all.cur = c;
-            }
-            int32_t rowId = -1;
-            if(isDry) rowId = directFilter ? 1 : 0;
-            else if(mySend >= 0) rowId = ((sfBits >> uint32_t(mySend)) & 1u) ? 2 + mySend : 0;
-            // the signals of this pass: bits 0..5 the filtered sends, 6 the unfiltered row, 7 the direct-filtered row (in this order:
-            // the direct filter runs in place)
-            uint32_t order = taken & sfBits;
-            if(__ballot(rowId == 0) != 0ull) order |= 1u << 6;
-            if(firstPass && directFilter) order |= 1u << 7;
+            all.gain = rec.gain[lane]; rowId = rec.rowId[lane];
+            if(ramp) { all.cur = rec.cur[lane]; all.step = rec.step[lane]; all.fadeLen = rec.fade[lane]; }
+        }
+        uint32_t order = CtlWord(rw, kRwOrder);
+        uint32_t pending = CtlWord(rw, kRwPending);
+        for(;;)
+        {
             while(order)
             {
                 const uint32_t bit = uint32_t(__builtin_ctz(order));
@@ -903,23 +1002,60 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
                 MixSlice<ACCN>(acc, src, rg, ramp, lane);
                 WaveSync();
             }
-            firstPass = false;
-        } while(pending);
-        if(isFirst)
-        {   // an inactive pair that is not at rest is cleared (voice.cpp:264-265): bit 0 the direct pair, 1 + i send i's
-            uint32_t clr = (((haveSend & ~sfBits) << 1) | (directFilter ? 0u : 1u)) & ~restMask;
-            while(clr)
+            if(!pending) break;
+            // ---- (rare) further sends into a slot that already has one: another pass, resolved here -- every slot's first pending send
+            const uint32_t sfBits = CtlWord(rw, kRwSfBits);
+            int32_t mySend = -1;
+            uint32_t taken = 0u, slotsTaken = 0u;
+#pragma unroll
+            for(int q = 0; q < 6; ++q)
             {
-                const uint32_t stage = uint32_t(__builtin_ctz(clr));
-                clr &= clr - 1u;
-                float *slots32 = stage ? reinterpret_cast<float*>(&L.sfilt[(size_t{v} * numSends + (stage - 1u)) * 2]) : reinterpret_cast<float*>(&L.dfilt[size_t{v} * 2]);
-                WaveSync();
-                if(lane < 32u) w.fst[lane] = w.st[stage][lane];
-                WaveSync();
-                WaveDoFilters(w.fst, reinterpret_cast<BiquadSlot*>(slots32), false, row, 0u, lane);
-                WaveSync();
+                if(!((pending >> q) & 1u)) continue;
+                const uint32_t slot = CtlWord(ctlCur, 12 + q) & 31u;
+                if((slotsTaken >> slot) & 1u) continue;
+                slotsTaken |= 1u << slot;
+                taken |= 1u << q;
+                if(laneWet && laneSlot == slot) mySend = q;
+            }
+            pending &= ~taken;
+            const bool mine = mySend >= 0;
+            const size_t gi = (size_t{v} * numSends + uint32_t(mine ? mySend : 0)) * wetCh + laneCh;
+            const float tgS = mine ? L.sendTgt[gi] : 0.0f;
+            const float tg = (mine && playing) ? tgS : 0.0f;
+            const uint32_t counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;
+            all = RowGain{};
+            if(isFirst)
+            {
+                const float cu = (mine && counter) ? L.sendCur[gi] : tg;
+                const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+                if(mine) { L.sendCur[gi] = g.newCur; all.add(g); }
+            }
+            else if(mine)
+            {
+                const float c = (__builtin_fabsf(tg) > kGainSilence) ? tg : 0.0f;
+                all.gain = c; all.cur = c;
+            }
+            rowId = mine ? (((sfBits >> uint32_t(mySend)) & 1u) ? 2 + mySend : 0) : -1;
+            order = taken & sfBits;
+            if(__ballot(rowId == 0) != 0ull) order |= 1u << 6;
+            // (their inactive pairs that are not at rest are cleared by the voice's first slice)
+            if(isFirst)
+            {
+                uint32_t clr = ((taken & ~sfBits) << 1) & ~CtlWord(rw, kRwRestMask);
+                while(clr)
+                {
+                    const uint32_t stage = uint32_t(__builtin_ctz(clr));
+                    clr &= clr - 1u;
+                    float *slots32 = reinterpret_cast<float*>(&L.sfilt[(size_t{v} * numSends + (stage - 1u)) * 2]);
+                    WaveSync();
+                    if(lane < 32u) w.fst[lane] = slots32[lane];
+                    WaveSync();
+                    WaveDoFilters(w.fst, reinterpret_cast<BiquadSlot*>(slots32), false, row, 0u, lane);
+                    WaveSync();
+                }
             }
         }
+    }
     }
 
     // ---- the wavefront's quarter of the workgroup's partial bus (the reduction reads all 1024 frames of every line)
