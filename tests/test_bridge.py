@@ -299,7 +299,7 @@ def test_hrtf_batched_update_at_the_headline_size():
 
 
 # ---- the pipelined mode of the batch mixer (include/oalgpu_openal.hpp) --------------------------------------
-def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=False):
+def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=False, restart=False):
     """The HRTF device without auxiliary sends: config-3-shaped sources, every 4th moving, one in sixteen running out of buffer in
     the third update, a ninth told to stop in the second.  pipelined: the batch mixer's pipelined mode with that depth; the
     outstanding updates are drained at the end.  -> ([updates (+ depth)][1024][2], play states)"""
@@ -316,6 +316,12 @@ def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=Fa
         if stop and k == 1:
             for v in srcs[1::9]:
                 b.stop_source(v)
+        if restart and k == 5:
+            # the voices stopped at update 1 faded out during it and are Stopped: their Voice objects start over as other sources
+            # (on the GPU side: other device slots, or the same ones again -- a late report about the old voice must not reach the new)
+            for j, v in enumerate(srcs[1::9]):
+                b.restart_source(v, (j + 3) % 8, True, 1000 + 37 * j, 0.05, (1.0, 0.5 * (j % 3 - 1), -1.5), bl.RS_BSINC24, 1.0,
+                                 0.5 if j % 2 else 1.0, -1, 0.5, 1.0)
         out.append(b.render(1024))
     if pipelined:
         out.extend(b.drain(1024))
@@ -327,8 +333,8 @@ def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=Fa
 
 @pytest.mark.gpu
 @needs_bridge
-@pytest.mark.parametrize("nsources,track", [(256, False), (4096, True)])
-def test_pipelined_batch_mixer_delivers_the_same_render_two_updates_late(nsources, track):
+@pytest.mark.parametrize("nsources,track,restart", [(256, False, False), (256, True, True), (4096, True, False)])
+def test_pipelined_batch_mixer_delivers_the_same_render_two_updates_late(nsources, track, restart):
     """BatchMixer::setPipelined(2): voices AND the HRTF post-process behind the boundary, an update's two output lines added to
     RealOut two updates later, voice state heard of through change reports -- against the reference's own render of the same
     scene (its Voice::mix, its MixDirectHrtf): update u of the pipelined render is update u - 2 of the reference's, the first
@@ -338,8 +344,8 @@ def test_pipelined_batch_mixer_delivers_the_same_render_two_updates_late(nsource
     # (the last of the 4096 sources that run out of buffer does so in the seventh update; the pipelined side hears of it two
     # updates later and the source is Stopped the update after that)
     U, D = 11, 2
-    want, sw, _ = render_hrtf_direct(bl.MODE_CPU, nsources, U)
-    got, sg, live = render_hrtf_direct(bl.MODE_BATCH, nsources, U, pipelined=D, track=track)
+    want, sw, _ = render_hrtf_direct(bl.MODE_CPU, nsources, U, restart=restart)
+    got, sg, live = render_hrtf_direct(bl.MODE_BATCH, nsources, U, pipelined=D, track=track, restart=restart)
     assert got.shape[0] == U + D and not got[:D].any()
     scale = float(np.abs(want).max())
     assert scale > 0.02
