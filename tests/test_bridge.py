@@ -174,11 +174,13 @@ def test_hrtf_batched_update_behind_the_reference_voice_loop(math_mode, i16):
 
 # ---- the voice kinds the library has, behind the binding it ships: multi-channel static sources, streaming sources on growing
 # queues, delayed starts; buffers whose storage is replaced (VERDICT r4 "missing" 2 and 3) ------------------------------------
-def render_kinds(mode, kind, math_mode=1, hrtf=False, track=False):
+def render_kinds(mode, kind, math_mode=1, hrtf=False, track=False, pipelined=0):
     """five updates of a small scene with one source of the kind under test among ordinary mono sources, through the
     reference's renderSamples; returns (output, per-source state incl. which buffer it plays)"""
     rng = np.random.default_rng(0xC0FFEE)
     b = bl.Bridge(mode, math_mode, hrtf=hrtf, num_sends=0)
+    if pipelined:
+        b.set_pipelined(pipelined)
     if track:
         b.track_changes(True)
     mono = [b.add_buffer(rng.uniform(-1, 1, 20000).astype(np.float32)) for _ in range(3)]
@@ -206,6 +208,8 @@ def render_kinds(mode, kind, math_mode=1, hrtf=False, track=False):
             b.queue_buffer(extra["parts"][-1], extra["late"])      # alSourceQueueBuffers while the source plays
         out.append(b.render(1024))
         cur.append(b.source_buffer(special) if special is not None else -1)
+    if pipelined:
+        out.extend(b.drain(1024))
     states = [b.source_state(v) + b.source_flags(v) for v in srcs + ([special] if special is not None else [])]
     b.close()
     return np.concatenate(out), states, cur
@@ -355,3 +359,18 @@ def test_pipelined_batch_mixer_delivers_the_same_render_two_updates_late(nsource
         assert err <= tol, (u, err, tol)
     assert sg == sw, [(i, a, b) for i, (a, b) in enumerate(zip(sg, sw)) if a != b][:6]
     assert live == sum(1 for s in sw if s == 1)         # every source that stopped or ended gave its device slot back
+
+
+@pytest.mark.gpu
+@needs_bridge
+@pytest.mark.parametrize("kind", ["stereo", "queue", "delay"])
+def test_pipelined_batch_mixer_with_the_other_voice_kinds(kind):
+    """the pipelined mode with a multi-channel source, a streaming source on a growing queue (its progress comes back in the change
+    reports) and a delayed start among the mono sources: the render is the reference's, two updates late"""
+    import oalgpu
+    want, _, _ = render_kinds(bl.MODE_CPU, kind, hrtf=True)
+    got, _, _ = render_kinds(bl.MODE_BATCH, kind, math_mode=oalgpu.MATH_FAST, hrtf=True, track=True, pipelined=2)
+    assert got.shape[0] == want.shape[0] + 2 * 1024 and not got[:2048].any()
+    err = float(np.abs(got[2048:].astype(np.float64) - want).max())
+    bound = 2e-5 * float(np.abs(want).max()) + 1e-7
+    assert err <= bound, (kind, err, bound)
