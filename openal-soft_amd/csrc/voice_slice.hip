@@ -63,7 +63,7 @@ struct SliceRec {
     uint32_t fade[32];                        // per line: frames the ramp covers (0: none)
     int32_t rowId[32];                        // per line: the signal it is mixed from (-1 none, 0 unfiltered row, 1 direct-filtered, 2 + send)
 };
-enum RecWord : int { kRwFlags = 0, kRwOutPos, kRwBufferItem, kRwBsrcFull, kRwSfBits, kRwHaveSend, kRwPending, kRwRestMask, kRwOrder };
+enum RecWord : int { kRwFlags = 0, kRwOutPos, kRwBufferItem, kRwBsrcFull, kRwSfBits, kRwHaveSend, kRwPending, kRwOrder };
 enum RecFlag : uint32_t { kRfActive = 1u, kRfPlaying = 2u, kRfLooping = 4u, kRfQueue = 8u, kRfAnyFull = 16u, kRfMulti = 32u, kRfDirectFilter = 64u };
 
 struct SliceWgLds {
@@ -610,19 +610,15 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
     // line those of the first send into the slot; further sends into the same slot are left `pending`); Gains.Current as the
     // update leaves it; which filter pairs are at rest, and the inactive ones that are not cleared (voice.cpp:264-265).
     // By ONE wavefront per voice, before the four slice wavefronts start on the block.
-    struct ProLoads { uint32_t ctl; float dryTg, dryCu, sTg0, sCu0, sTg1, sCu1, df, sf[3]; };
+    struct ProLoads { uint32_t ctl; float dryTg, dryCu, sTg0, sCu0, sTg1, sCu1; };
     auto proRequest = [&](uint32_t vx, ProLoads &q, uint32_t lane)
     {
         q.ctl = loadCtlV(vx, lane);
         const size_t sb = size_t{vx} * sendLanes;
-        q.dryTg = q.dryCu = q.sTg0 = q.sCu0 = q.sTg1 = q.sCu1 = q.df = 0.0f;
+        q.dryTg = q.dryCu = q.sTg0 = q.sCu0 = q.sTg1 = q.sCu1 = 0.0f;
         if(lane < numDry) { q.dryTg = L.gainTgt[size_t{vx} * numDry + lane]; q.dryCu = L.gainCur[size_t{vx} * numDry + lane]; }
         if(lane < sendLanes) { q.sTg0 = L.sendTgt[sb + lane]; q.sCu0 = L.sendCur[sb + lane]; }
         if(lane + 64u < sendLanes) { q.sTg1 = L.sendTgt[sb + lane + 64u]; q.sCu1 = L.sendCur[sb + lane + 64u]; }
-        if(lane < 32u) q.df = reinterpret_cast<const float*>(L.dfilt + size_t{vx} * 2)[lane];
-        const float *sf = reinterpret_cast<const float*>(L.sfilt + size_t{vx} * numSends * 2);      // [send][2 x 16 dwords]
-#pragma unroll
-        for(int k = 0; k < 3; ++k) q.sf[k] = (64u * uint32_t(k) + lane < 32u * numSends) ? sf[64u * uint32_t(k) + lane] : 0.0f;
     };
     auto prepare = [&](uint32_t vx, const ProLoads &q, SliceRec &rec, uint32_t lane)
     {
@@ -640,9 +636,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
         uint32_t haveSend = 0u;
 #pragma unroll
         for(int k = 0; k < 6; ++k) if(uint32_t(k) < numSends && sendSlots[k] >= 0) haveSend |= 1u << k;
-        uint32_t restMask = PairsAtRest(q.df, lane) & 1u;
-#pragma unroll
-        for(int k = 0; k < 3; ++k) if(2u * uint32_t(k) < numSends) restMask |= PairsAtRest(q.sf[k], lane) << (1u + 2u * uint32_t(k));
         // every slot's first send; the lanes of the slot's lines learn which
         int32_t mySend = -1;
         uint32_t taken = 0u, slotsTaken = 0u;
@@ -683,19 +676,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
         uint32_t order = taken & sfBits;
         if(__ballot(rowId == 0) != 0ull) order |= 1u << 6;
         if(directFilter) order |= 1u << 7;
-        // an inactive pair that is not at rest is cleared (voice.cpp:264-265): bit 0 the direct pair, 1 + i send i's
-        uint32_t clr = (((haveSend & ~sfBits) << 1) | (directFilter ? 0u : 1u)) & ~restMask;
-        while(clr)
-        {
-            const uint32_t stage = uint32_t(__builtin_ctz(clr));
-            clr &= clr - 1u;
-            float *slots32 = stage ? reinterpret_cast<float*>(&L.sfilt[(size_t{vx} * numSends + (stage - 1u)) * 2]) : reinterpret_cast<float*>(&L.dfilt[size_t{vx} * 2]);
-            WaveSync();
-            if(lane < 32u) w.fst[lane] = slots32[lane];
-            WaveSync();
-            WaveDoFilters(w.fst, reinterpret_cast<BiquadSlot*>(slots32), false, w.in, 0u, lane);
-            WaveSync();
-        }
         const uint32_t flags = kRfActive | (playing ? kRfPlaying : 0u) | (vp.looping ? kRfLooping : 0u) | (vp.queue ? kRfQueue : 0u)
             | (vp.anyFull ? kRfAnyFull : 0u) | (vp.multi ? kRfMulti : 0u) | (directFilter ? kRfDirectFilter : 0u);
         if(lane < 16u)
@@ -708,7 +688,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
             wv = lane == uint32_t(kRwSfBits) ? sfBits : wv;
             wv = lane == uint32_t(kRwHaveSend) ? haveSend : wv;
             wv = lane == uint32_t(kRwPending) ? (haveSend & ~taken) : wv;
-            wv = lane == uint32_t(kRwRestMask) ? restMask : wv;
             wv = lane == uint32_t(kRwOrder) ? order : wv;
             rec.w[lane] = wv;
         }
@@ -749,9 +728,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
             GatherSlice(preN, total - spN.nPrev, b, vpN.looping, spN.upos, lane);
             prevN = (lane < spN.nPrev) ? L.prev[size_t{vn} * kMaxPad + spN.srcOff + lane] : 0.0f;
         }
-        // the filter pairs that run, for the wavefront that starts them
-        const uint32_t running = ((CtlWord(rwN, kRwSfBits) & CtlWord(rwN, kRwHaveSend)) << 1) | ((CtlWord(rwN, kRwFlags) & kRfDirectFilter) ? 1u : 0u);
-        if(spN.cnt && running && wave == vpN.outPos / uint32_t(kSl))
+        // the voice's filter pairs as memory holds them, for the wavefront of its first slice: it starts the ones that run and
+        // clears the inactive ones that are not at rest
+        if(spN.cnt && wave == vpN.outPos / uint32_t(kSl))
         {
             if(lane < 32u) dfN = reinterpret_cast<const float*>(L.dfilt + size_t{vn} * 2)[lane];
             const float *sf = reinterpret_cast<const float*>(L.sfilt + size_t{vn} * numSends * 2);      // [send][2 x 16 dwords]
@@ -816,12 +795,18 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
         }
         const uint32_t kFirst = vp.outPos / uint32_t(kSl);
         const bool isFirst = wave == kFirst, isLast = wave == kLast;
+        uint32_t restMask = 0u;                 // isFirst: which of the voice's filter pairs are at rest (bit 0 direct, 1 + i send i)
         if(sp.cnt && isFirst)
-        {   // (the pairs that run start from these)
+        {
             if(lane < 32u) w.st[0][lane] = dfN;
+            restMask = PairsAtRest(dfN, lane) & 1u;
 #pragma unroll
             for(int q = 0; q < 3; ++q)
-                if(64u * uint32_t(q) + lane < 32u * numSends) (&w.st[1][0])[64u * uint32_t(q) + lane] = sfN[q];
+                if(2u * uint32_t(q) < numSends)
+                {
+                    if(64u * uint32_t(q) + lane < 32u * numSends) (&w.st[1][0])[64u * uint32_t(q) + lane] = sfN[q];
+                    restMask |= PairsAtRest(sfN[q], lane) << (1u + 2u * uint32_t(q));
+                }
         }
         ctlA = ctlB;
         if(jb + 1u < nb)
@@ -1038,21 +1023,21 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, 2) VoiceSliceK
             rowId = mine ? (((sfBits >> uint32_t(mySend)) & 1u) ? 2 + mySend : 0) : -1;
             order = taken & sfBits;
             if(__ballot(rowId == 0) != 0ull) order |= 1u << 6;
-            // (their inactive pairs that are not at rest are cleared by the voice's first slice)
-            if(isFirst)
+        }
+        if(isFirst)
+        {   // an inactive pair that is not at rest is cleared (voice.cpp:264-265): bit 0 the direct pair, 1 + i send i's
+            const uint32_t sfBits = CtlWord(rw, kRwSfBits);
+            uint32_t clr = (((CtlWord(rw, kRwHaveSend) & ~sfBits) << 1) | ((CtlWord(rw, kRwFlags) & kRfDirectFilter) ? 0u : 1u)) & ~restMask;
+            while(clr)
             {
-                uint32_t clr = ((taken & ~sfBits) << 1) & ~CtlWord(rw, kRwRestMask);
-                while(clr)
-                {
-                    const uint32_t stage = uint32_t(__builtin_ctz(clr));
-                    clr &= clr - 1u;
-                    float *slots32 = reinterpret_cast<float*>(&L.sfilt[(size_t{v} * numSends + (stage - 1u)) * 2]);
-                    WaveSync();
-                    if(lane < 32u) w.fst[lane] = slots32[lane];
-                    WaveSync();
-                    WaveDoFilters(w.fst, reinterpret_cast<BiquadSlot*>(slots32), false, row, 0u, lane);
-                    WaveSync();
-                }
+                const uint32_t stage = uint32_t(__builtin_ctz(clr));
+                clr &= clr - 1u;
+                float *slots32 = stage ? reinterpret_cast<float*>(&L.sfilt[(size_t{v} * numSends + (stage - 1u)) * 2]) : reinterpret_cast<float*>(&L.dfilt[size_t{v} * 2]);
+                WaveSync();
+                if(lane < 32u) w.fst[lane] = w.st[stage][lane];
+                WaveSync();
+                WaveDoFilters(w.fst, reinterpret_cast<BiquadSlot*>(slots32), false, row, 0u, lane);
+                WaveSync();
             }
         }
     }
