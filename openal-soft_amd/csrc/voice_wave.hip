@@ -1549,7 +1549,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         waveStamp(3);
         }
     };
-    if constexpr (NL > 0) { if constexpr (ACCL > 0) dumpLines(); else mixRows(); return; }
+    if constexpr (NL > 0) { if constexpr (ACCL > 0) dumpLines(); else mixRows(); }
+    else
+    {
     // ---- one partial per workgroup: waves dump their accumulators, then a fixed-order sum
     {
         // [frame] = (L, R), frames < 64R (the matrix-pipe kernels: 17 entries per 16 frames, in the place of xh)
@@ -1607,9 +1609,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
     }
     waveStamp(3);
     if constexpr (SENDS) { if constexpr (ACCL > 0) dumpLines(); else mixRows(); }
-    // ---- the next update's parameter block: every wavefront installs the records of the voices it has just mixed (HRTF kernels).
+    }
+    // ---- the next update's parameter block: every wavefront installs the records of the voices it has just mixed.
     // The voices' state was written back by this very wavefront, in program order, so its loads see it; the kernel boundary makes
-    // the result visible to the next launch, as it did for the parameter kernel this replaces.
+    // the result visible to the next launch, as it did for the parameter kernel this replaces.  (The dry-line kernels too: what
+    // their tail reads -- stream rows and gain blocks -- is none of what a record writes.)
     if(!RES && next.map)
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1691,14 +1695,14 @@ uint32_t WaveKernelGroups(const DeviceLayout &L)
 // prof: null in production; the measurement variants exist for the HRTF kernels without sends only
 // evStart / evStop (both or neither): HIP events bound to the DISPATCH (hipExtLaunchKernel) -- the kernel's own start and end,
 // what rocprofv3's kernel trace reports, without the command-processor time an event recorded around the launch includes
-// the kernels whose wavefronts install a parameter block behind their voices: the HRTF ones (NL == 0)
-bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.hrtf != 0; }
+// the kernels whose wavefronts install a parameter block behind their voices: every VoiceWaveKernel (voice_slice.hip has no such epilogue)
+bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.sliceLines == 0; }      // (every VoiceWaveKernel; not the slice kernel)
 
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)
 {
     if(L.sliceLines) return LaunchVoiceSlice(s, L, samplesToDo, evStart, evStop);       // (voice_slice.hip)
-    const NextBlock next{nextRecs, L.hrtf ? nextMap : nullptr, L.hrtf ? nextRows : nullptr, ResidentArgs{}};
+    const NextBlock next{nextRecs, nextMap, L.hrtf ? nextRows : nullptr, ResidentArgs{}};
     const uint32_t groups = WaveKernelGroups(L);
     const bool sends = L.numSends != 0;
     const dim3 grid(groups), block(kWThreads);

@@ -76,3 +76,50 @@ def test_pipelined_update_equals_serial_update(synth_mhr, variant):
         assert np.array_equal(_bits(a.prev_samples), _bits(b.prev_samples)), v
     piped.close()
     serial.close()
+
+
+@pytest.mark.parametrize("config", [2, 4, 5])
+def test_parameter_block_installed_by_the_dry_line_and_send_kernels(synth_mhr, config):
+    """OALGPU_CTX_APPLY_IN_VOICE_KERNEL on the other voice kernels -- dry lines in registers (config 2), stream rows with sends
+    (config 4), HRTF with a send (config 5): the update's own wavefronts install the next parameter block behind the voices they
+    mixed; bit for bit the scene whose blocks go through ApplyParamsKernel, one update after the other with a host synchronisation."""
+    import oalgpu
+    from oalgpu import synth
+    import bench
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    nv, updates = 2048, 12
+    mhr = synth.synth_mhr_bytes()
+
+    def build(flags):
+        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=flags)
+        api._mhr = mhr
+        sc, script = bench.build_scene(oalgpu, synth, api, config, nv, 0, mhr, 0)
+        allv = list(range(nv))
+        moving = [v for v in allv if script.is_moving(v)]
+        sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
+        blocks = [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(updates)]
+        return sc, blocks
+
+    piped, pblocks = build(oalgpu.CTX_APPLY_IN_VOICE_KERNEL)
+    serial, sblocks = build(0)
+    nslots = {4: 4, 5: 1}.get(config, 0)
+    for k in range(updates):
+        piped.apply_block(pblocks[k])
+        piped.mix(1024, post_process=True)
+        serial.apply_block(sblocks[k])
+        serial.mix_voices(1024)
+        serial.post_process(1024)
+        serial.sync()
+        if k in (0, 1, 5, updates - 1):
+            a, b = piped.dry().copy(), serial.dry().copy()
+            assert np.array_equal(_bits(a), _bits(b)), f"config {config}: bus block differs after update {k}"
+            assert np.abs(b).max() > 1e-4
+            for s in range(nslots):
+                assert np.array_equal(_bits(piped.wet(s)), _bits(serial.wet(s))), f"config {config}: wet bus {s} differs after update {k}"
+    for v in range(0, nv, 61):
+        a, b = piped.voice_state(v), serial.voice_state(v)
+        assert (a.play_state, a.position, a.position_frac) == (b.play_state, b.position, b.position_frac), v
+        assert np.array_equal(_bits(a.prev_samples), _bits(b.prev_samples)), v
+        assert np.array_equal(_bits(a.dry_current), _bits(b.dry_current)), v
+    piped.close()
+    serial.close()
