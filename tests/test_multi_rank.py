@@ -82,8 +82,8 @@ def test_library_comm_single_rank_rccl(synth_mhr):
     RCCL communicator, then oalgpu_mix_update (voice kernel on the main stream; partial-bus reduction,
     ncclReduce of the bus block and the post-process on the post stream) against the oracle, over several
     back-to-back updates without draining in between.  In its own process (librccl.so is loaded there)."""
-    # (the communicator's bring-up inside librccl.so did not return once in ~40 runs on the pool's boxes -- the worker never reached
-    # the library's own code, and the same tree passed three times in a row on the next box: one retry, on another port)
+    # (once in some forty runs on the pool's boxes the worker did not finish within 300 s -- where it hung was not seen; the same
+    # tree ran it three times in a row in seconds on the next box: one retry, on another port, with a shorter limit)
     p = None
     for attempt in range(2):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OAL_TEST_MHR=synth_mhr)
