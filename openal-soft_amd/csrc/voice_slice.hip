@@ -17,14 +17,20 @@
 //   * the resampler is a pure function of the source and the output's position: output frame f of the update reads the source
 //     at position + ((frac + f step) >> 16), so a slice is resampled from its own window of the source (the window of the
 //     update, core/voice.cpp:662-753, is contiguous; a slice's window is a part of it -- FillWindow below restates what every
-//     element of the update's window is, for static, looping, queued, ended and not-yet-started sources);
+//     element of the update's window is, for static, looping, queued, ended and not-yet-started sources, chunk by chunk where
+//     the reference loads the window in chunks: what lies past a source's END depends on the chunk that loaded it);
 //   * the filters (DoFilters, the ambisonic splitter) are recurrences over the frames: their state goes from the wavefront of
 //     slice k to the wavefront of slice k + 1 through an LDS mailbox (the four wavefronts become a pipeline, skewed by one
 //     filter run; three voices in four have no active filter and need no hand-over at all);
 //   * gains ramp over the first <= 64 frames only (MixLine's Counter, voice.cpp:1093): slice 0 alone sees the ramp;
+//   * what does not depend on the slice -- a voice's plan, the gains of all its lines (ONE PrepareMixLine per voice, line =
+//     lane), Gains.Current as the update leaves it -- is worked out once per workgroup, by one wavefront per voice, in front of
+//     every block of 16 voices, and read by the four slice wavefronts from LDS records (SliceRec);
 //   * everything that changes a voice's state for the NEXT update -- position, play state, mPrevSamples, flags -- is written
 //     after a barrier at the end, when no wavefront reads this update's state any more.
-// The four wavefronts do the same amount of work by construction (the same voices, a quarter of the frames each).
+// The four wavefronts do the same amount of work by construction (the same voices, a quarter of the frames each), and the kernel's
+// time is linear in the voices per workgroup.  Opt-in (OALGPU_CTX_SLICE_LINES): a third of the stream-row kernel's HBM traffic
+// and half again its instructions -- both kernels are bound by instruction issue.
 // FAST arithmetic (FMA, own summation order); integer state bit-exact.  Near-field control and HRTF stay with voice_wave.hip.
 #include <hip/hip_ext.h>
 #include "wave_common.hpp"
