@@ -163,7 +163,11 @@ public:
         mSeen = 0;
         const int rc = flush(context, dev, deviceTime, samplesToDo);
         mChanged.clear();
-        if(rc != 0) mResync = true;         /* the caller mixes this update on the CPU: what the device context holds is stale then */
+        if(rc != 0)
+        {
+            mResync = true;                 /* the caller mixes this update on the CPU: what the device context holds is stale then */
+            if(mDepth) leavePipelined(context, dev);   /* ... and the CPU loop needs the device's own post-process back */
+        }
         return rc == 0;
     }
     bool batchComplete() const { return mSeen == 0; }
@@ -191,6 +195,21 @@ public:
     {
         while(!mPending.empty()) { if(int rc = collect(context, dev)) return rc; }
         return 0;
+    }
+    /* back to the synchronous form (also what a failed update does by itself): the voice state of what is outstanding is
+     * applied, its output lines are dropped (drain() before, to have them), the device gets its HrtfPostProcess back and the
+     * accumulator's tail is the reference's again.  One update's tail of the HRTF accumulator stays behind on the GPU: a seam
+     * of IrSize samples, once. */
+    void leavePipelined(ContextBase *context, DeviceBase &dev)
+    {
+        if(!mDepth) return;
+        const int savedError = mError;
+        const std::string savedText = mErrorText;
+        while(!mPending.empty()) { if(collect(context, dev, true)) { mPending.clear(); break; } }     /* (drain() first to keep their output) */
+        mError = savedError; mErrorText = savedText;
+        if(mSavedPost.mHrtfState) dev.mPostProcess.emplace<HrtfPostProcess>(std::move(mSavedPost));
+        if(mGpu) (void)oalgpu_set_carry_accum(mGpu, 0);
+        mDepth = 0;
     }
     size_t pendingUpdates() const { return mPending.size(); }
     /* where flush() spent its time so far, seconds: [0] the walk over the update's voices (what to tell the device context),
@@ -723,7 +742,7 @@ private:
         mTimes[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         return 0;
     }
-    int collect(ContextBase *context, DeviceBase &dev)
+    int collect(ContextBase *context, DeviceBase &dev, bool dropOutput = false)
     {
         const Pending p = mPending.front();
         mPending.erase(mPending.begin());
@@ -731,7 +750,7 @@ private:
         const size_t nreal = dev.RealOut.Buffer.size();
         mLines.resize(nreal * BufferLineSize);
         if(int rc = oalgpu_output_wait(mGpu, p.outTicket, mLines.data(), mLines.size())) return fail(rc, "oalgpu_output_wait");
-        for(size_t c{0}; c < nreal; ++c)
+        for(size_t c{0}; c < nreal && !dropOutput; ++c)
             for(size_t i{0}; i < p.samples; ++i)
                 dev.RealOut.Buffer[c][i] += mLines[c*BufferLineSize + i];
         /* what changed about the voices in that update */

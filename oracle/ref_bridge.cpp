@@ -617,6 +617,13 @@ int oalbridge_set_pipelined(oalbridge *b, uint32_t depth)
     return 0;
 }
 
+/* back to the synchronous form (BatchMixer::leavePipelined; oalbridge_drain first keeps the outstanding output) */
+int oalbridge_leave_pipelined(oalbridge *b)
+{
+    b->batch->leavePipelined(b->ctx.get(), *b->dev);
+    return 0;
+}
+
 int oalbridge_batch_times(oalbridge *b, double out[3]) { for(int i = 0; i < 3; ++i) out[i] = b->batch->times()[i]; return 0; }
 
 int oalbridge_drain(oalbridge *b, float *interleaved, uint32_t frames, uint32_t max_updates)

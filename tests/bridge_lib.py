@@ -156,6 +156,10 @@ class Bridge:
             raise RuntimeError("oalbridge_drain: " + lib().oalbridge_error(self.h).decode())
         return out[:n]
 
+    def leave_pipelined(self):
+        lib().oalbridge_leave_pipelined.argtypes = [C.c_void_p]
+        lib().oalbridge_leave_pipelined(self.h)
+
     def batch_times(self):
         """seconds the batch mixer's flush spent so far: (walking the voices, submitting, collecting)"""
         t = (C.c_double * 3)()

@@ -374,3 +374,33 @@ def test_pipelined_batch_mixer_with_the_other_voice_kinds(kind):
     err = float(np.abs(got[2048:].astype(np.float64) - want).max())
     bound = 2e-5 * float(np.abs(want).max()) + 1e-7
     assert err <= bound, (kind, err, bound)
+
+
+@pytest.mark.gpu
+@needs_bridge
+def test_leaving_the_pipelined_mode_hands_the_post_process_back():
+    """BatchMixer::leavePipelined after a drain: the device has its HrtfPostProcess again and the synchronous form carries on --
+    the render is the reference's but for one seam (the HRTF accumulator's tail of the last pipelined update stays on the GPU)."""
+    import oalgpu
+    U1, U2, n = 5, 4, 256
+    want, _, _ = render_hrtf_direct(bl.MODE_CPU, n, U1 + U2, stop=False)
+    b = bl.Bridge(bl.MODE_BATCH, 1, hrtf=True, num_sends=0)
+    b.set_pipelined(2)
+    srcs = bl.build_config3(b, n, slot=-1)
+    out = []
+    for k in range(U1 + U2):
+        if k:
+            bl.move_config3(b, srcs, k, slot=-1)
+        if k == U1:
+            out.extend(b.drain(1024))
+            b.leave_pipelined()
+        out.append(b.render(1024))
+    b.close()
+    got = np.stack(out)
+    assert got.shape[0] == U1 + U2 + 2 and not got[:2].any()
+    scale = float(np.abs(want).max())
+    for u in range(U1 + U2):
+        a, w = got[u + 2].astype(np.float64), want[u]
+        if u == U1:
+            a, w = a[128:], w[128:]                  # (the seam: HrirLength samples)
+        assert float(np.abs(a - w).max()) <= 2e-5 * scale + 1e-7, u
