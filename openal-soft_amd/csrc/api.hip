@@ -175,6 +175,7 @@ struct oalgpu_context {
     uint32_t hrtfGeneration{0};            // bumped by every oalgpu_hrtf_load_mhr: parameter blocks carry HRIR indices of ONE store
     bool carryAccum{true};
     bool useWave{false};                   // FAST contexts without sends (HRTF, or <= 8 dry lines): voice_wave.hip
+    uint32_t groupsAllocated{0};           // workgroups the partial-bus buffers were sized for (oalgpu_context_create)
     std::vector<oalgpu_convolution*> slotConv;   // per effect slot: attached convolution reverb (not owned)
     std::vector<oalgpu_reverb*> slotReverb;      // per effect slot: attached EAX reverb (not owned)
     std::vector<oalgpu_effect*> slotEffect;      // per effect slot: equalizer / modulator / echo / dedicated (not owned)
@@ -1204,12 +1205,14 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     }
     HIP_TRY(c->queueDone.alloc(nv)); HIP_TRY(c->queueDone.zero()); L.queueDone = c->queueDone.p;
     L.numLineGroups = L.numGroups;
+    c->groupsAllocated = L.numGroups;
     L.streams = nullptr; L.lineGains = nullptr; L.lineStride = 0; L.streamsPerVoice = 0;
     L.nfc = nullptr; L.nfcOrders = 0;
     L.hrirs = nullptr;
     for(uint32_t &n : L.chansPerOrder) n = 0;
     L.accLines = 0;
     L.sliceLines = 0;
+    L.wave16 = 0;                           // (decided when the HRTF data set is known: InstallHrtfData)
     if(c->useWave && !(desc->flags & OALGPU_CTX_STREAM_ROWS))
     {
         L.accLines = WaveKernelAccLines(L);
@@ -1321,6 +1324,17 @@ static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
     {
         L.accLines = 0;
         if(int rc = AllocStreamRows(c)) return rc;
+    }
+    // one voice per wavefront, sixteen per workgroup (voice_wave16.hip): its grid is voices / 16 workgroups -- never more partial
+    // buses than the context's buffers were sized for (the wavefront-per-voice kernel's grid has at least twice as many)
+    if(c->useWave)
+    {
+        const bool want16 = (c->desc.flags & OALGPU_CTX_WAVE16) && Wave16Applies(L);
+        L.wave16 = want16 ? 1u : 0u;
+        const uint32_t groups = std::max<uint32_t>(1u, WaveKernelGroups(L));
+        if(groups > c->groupsAllocated) return Fail(OALGPU_ERR_INVALID, "internal: the voice kernel's grid outgrew the partial buses");
+        L.numGroups = groups; L.numLineGroups = groups;
+        if(L.wave16) c->res.enabled = false;
     }
     return OALGPU_OK;
 }
@@ -3381,7 +3395,7 @@ int oalgpu_slot_set_convolution(oalgpu_context *c, uint32_t slot, oalgpu_convolu
 // grid fits on the CUs that are left -- one round, and the reverbs run beside it undisturbed.
 static int RebalanceWaveGroups(oalgpu_context *c)
 {
-    if(!c->useWave || c->desc.voices_per_group != 0u) return OALGPU_OK;
+    if(!c->useWave || c->desc.voices_per_group != 0u || c->L.wave16) return OALGPU_OK;
     uint32_t reverbs = 0;
     for(oalgpu_reverb *r : c->slotReverb) reverbs += r ? 1u : 0u;
     hipDeviceProp_t prop{};

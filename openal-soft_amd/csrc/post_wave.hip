@@ -354,6 +354,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
     Tri3 runPower, float *__restrict__ hostOut, uint32_t *__restrict__ hostFlag, uint32_t hostSeq, uint32_t *__restrict__ outArrived, uint32_t outTarget)
 {
     __shared__ float xs[kLine + 64];                                   // split: the channel; FIR: [kPostGroup][128 + 64] windows
+    __builtin_amdgcn_s_setprio(3);                                     // (a short chain the step waits for, beside a voice kernel that fills the SIMDs)
     PostFusedBlock<0>(xs, blockIdx.x, threadIdx.x, outTarget, in, nch, spIn, spOut, hfscales, chanCoeffs, taps, accIn, carryOut, left, right, n,
         xf, arrived, epoch, runPower, hostOut, hostFlag, hostSeq, outArrived, nullptr, 0u);
 }

@@ -1050,6 +1050,7 @@ __global__ void __launch_bounds__(kReduceWaves * 64) __attribute__((amdgpu_num_v
     // workgroups of the dry-line kernels a CU has four granules to spare, and a launch of more reduction workgroups than
     // CUs (config 4: 336) must not keep a voice workgroup of the next update waiting for LDS)
     __shared__ float slice[kReduceWaves == 4 ? 4 : kReduceSegs][64];
+    if constexpr (kReduceWaves == 4) __builtin_amdgcn_s_setprio(3);      // (the post-stream shape: a short chain beside a voice kernel that fills the SIMDs)
     const uint32_t wave0 = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t idx = blockIdx.x * 64u + lane;
     const uint32_t dryLines = L.numDry + L.numReal;

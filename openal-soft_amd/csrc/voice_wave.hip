@@ -1677,6 +1677,7 @@ uint32_t WaveKernelAccLines(const DeviceLayout &L)
 
 const char *WaveKernelName(const DeviceLayout &L)
 {
+    if(L.wave16) return Wave16KernelName();
     if(L.sliceLines) return SliceKernelName();
     const bool sends = L.numSends != 0;
     if(L.accLines)
@@ -1689,6 +1690,7 @@ const char *WaveKernelName(const DeviceLayout &L)
 
 uint32_t WaveKernelGroups(const DeviceLayout &L)
 {
+    if(L.wave16) return Wave16Groups(L);
     return (L.numVoices + kWWaves * L.waveVoices - 1u) / (kWWaves * L.waveVoices);
 }
 
@@ -1701,6 +1703,7 @@ bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.sliceLines == 0;
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)
 {
+    if(L.wave16) return LaunchVoiceWave16(s, L, samplesToDo, prof, evStart, evStop, nextRecs, nextMap, L.hrtf ? nextRows : nullptr);   // (voice_wave16.hip)
     if(L.sliceLines) return LaunchVoiceSlice(s, L, samplesToDo, evStart, evStop);       // (voice_slice.hip)
     const NextBlock next{nextRecs, nextMap, L.hrtf ? nextRows : nullptr, ResidentArgs{}};
     const uint32_t groups = WaveKernelGroups(L);

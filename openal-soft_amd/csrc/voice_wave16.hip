@@ -1,0 +1,763 @@
+// The FAST HRTF hot path at FOUR wavefronts per SIMD: one voice per wavefront, sixteen wavefronts per workgroup, one
+// workgroup per compute unit (OALGPU_CTX_WAVE16; BASELINE configs[2]).
+//
+//   "for every Playing|Stopping voice: voice->mix(...)"   alc/alu.cpp:2201-2206
+//      -> Voice::mix                                       core/voice.cpp:988-1233
+//      -> LoadResampledSamples / Resample_*                voice.cpp:642-824, mixer_sse.cpp:199-329
+//      -> DoFilters (dual biquad)                          voice.cpp:255-267
+//      -> DoHrtfMix -> MixHrtf / MixHrtfBlend              voice.cpp:827-902, mixer/hrtfbase.h:17-89
+//
+// Why this shape.  VoiceWaveKernel (voice_wave.hip) keeps two voices per wavefront and two wavefronts per SIMD (217
+// registers: two complete resampler outputs in flight, the accumulator tiles live across both voices, the next voice's
+// window requested over the FIR).  Its counters name no saturated unit: a wavefront issues one instruction per ~10
+// cycles, two of them cannot keep a SIMD's issue ports busy, and the phases in which they could (all eight wavefronts of
+// a CU resampling: the LDS pipe) they spend in step.  Here a wavefront owns ONE voice, so
+//   * nothing is carried from voice to voice: the accumulator tiles live from the FIR to the dump only, no request-ahead
+//     registers, no parking -- the peaks are the ring resampler (two sets of 6 tap pairs) and the FIR's fragments: <= 112
+//     registers, four wavefronts per SIMD, with the 64 registers the post-stream kernels need left over;
+//   * the resampler's outputs stay in registers (16 per lane, output = lane + 64 j) -- there is no LDS copy of the sample
+//     line: the FIR's inputs (x', split half precision, one ear at a time) are built straight from them, so the
+//     wavefront's LDS is the window (parked twice, aligned pair reads) OR one ear's inputs OR the dump: 9.4 KB, sixteen
+//     of them + the workgroup's resampler rows + the post-process's 5 KB on one CU;
+//   * 4096 voices are exactly one wavefront per voice slot of the machine (256 CUs x 16): one round, one partial bus per
+//     CU (256 instead of 512).
+// Voices the register path does not cover (a window that does not fit, queues, delayed starts, other formats and
+// resamplers) take voice_wave.hip's generic loader (LoadResampledWave) into an LDS sample line and join the common path
+// from there.  Arithmetic is FAST mode; all integer state is bit-exact (the same statements as voice_wave.hip).
+#define OALGPU_WAVE_NO_LAUNCHER
+#include "voice_wave.hip"
+
+#pragma clang fp contract(off)
+
+namespace oalgpu {
+namespace {
+
+constexpr int kW16Waves = 16;
+constexpr int kW16Threads = kW16Waves * 64;
+constexpr int kW16Outs = kLine / 64;                    // outputs per lane: output k = lane + 64 j
+
+// ---- the wavefront's LDS: four views of one area of 2352 dwords ----
+constexpr int kW16Rd = 1184;                            // fast path: the window (48 + 17 x 64 + 8 -> 32 mod 64: rd2 half the banks away)
+constexpr int kW16Rd2 = kMaxEdge + kPre * 64 + 8;       // the same window one sample on
+constexpr int kW16Area = kResampleDataSize + kLine;     // generic path: DeviceBase::mResampleData + the sample line
+static_assert(kW16Rd % 64 == 32 && kW16Rd >= kMaxPad + kPre * 64 + 8, "rd2 sits half the banks away from rd");
+static_assert(kW16Rd + kW16Rd2 <= kW16Area, "the twice-parked window fits");
+constexpr int kW16DumpF2 = 64 * 17 + 68;                // FirMfmaH's tiles as frames, 17 entries per 16 frames
+static_assert(kW16DumpF2 * 2 <= kW16Area, "the dump fits");
+struct W16PhaseB {
+    uint32_t xh[2][kXhDw];                              // ONE ear's FIR inputs [hi | lo], two frames per dword (FirMfmaH)
+    uint32_t hr[2][kHrDw];                              // that ear's reversed response [hi | lo]
+    uint32_t hro[2][kHrDw];                             // a replaced filter's old response
+    float in0[2 * kHist];                               // [Hrtf.History | the first 64 samples]: what the delayed inputs' head reads
+};
+static_assert(sizeof(W16PhaseB) <= size_t(kW16Area) * 4, "phase B fits the area (nothing of it is written before the sample line is back in registers)");
+struct alignas(16) W16Lds {
+    union {
+        struct { float rd[kW16Rd]; float rd2[kW16Rd2]; } a;                    // register path: the window, twice
+        struct { float rd[kResampleDataSize]; float smp[kLine]; } g;           // generic loader: window + sample line
+        W16PhaseB b;
+        f2 dump[kW16DumpF2];
+        float raw[kW16Area];
+    };
+    int32_t best;
+    uint32_t pad[3];
+};
+struct W16Wg {
+    W16Lds w[kW16Waves];
+    alignas(16) f2 tabF[12 * 32];                       // [tap pair][phase] = fil[2p], fil[2p+1]   (up to 24 taps)
+    f2 tabP[12 * 32];
+    uint32_t tabKey, tabM, tabL, pad;
+};
+static_assert(sizeof(W16Wg) <= 157440, "123 LDS granules: the post-process (4) and the reduction (1) fit beside it");
+
+// what LoadResampledWave (wave_common.hpp) reaches through its wavefront-LDS argument
+struct W16GenView { float *rd, *in, *rd2; int32_t &best; uint32_t *pad; };
+
+// ---- resampler: ResampleRunRing (wave_common.hpp) with the outputs left in registers ----
+// Outputs lane, lane + 64, ...: outs[j] = output lane + 64 j.  Two register sets of NP tap pairs; while one group is
+// multiplied the next group's 3 NP reads are in flight (four wavefronts per SIMD cover the rest of the latency).
+template<int M, bool DUAL>
+__device__ __forceinline__ void ResampleRingRegs(const f2 *tabF, const f2 *tabP, const float *rdb, uint32_t frac0, uint32_t increment,
+    uint32_t bdst, float (&outs)[kW16Outs], uint32_t lane, const float *rd2b, uint32_t rdbIndex)
+{
+    constexpr int NP = (M / 2 >= 6) ? 6 : M / 2;
+    constexpr int G = (M / 2) / NP;               // 1 (cubic, bsinc12), 2 (bsinc24)
+    f2 F[2][NP], P[2][NP], S[2][NP];
+    const uint32_t tstep = 64u * increment;
+    const uint32_t tlast = frac0 + (bdst - 1u) * increment;
+    auto load = [&](int set, uint32_t tt, int g)
+    {
+        tt = tt < tlast ? tt : tlast;
+        const uint32_t pi = (tt >> 11) & 31u;
+        const f2 *tf = tabF + pi, *tp = tabP + pi;
+        const uint32_t pos = tt >> kFracBits;
+#pragma unroll
+        for(int q = 0; q < NP; ++q)
+        {
+            F[set][q] = tf[(g * NP + q) * 32];
+            P[set][q] = tp[(g * NP + q) * 32];
+        }
+        if constexpr (DUAL)
+        {
+            const bool odd = ((rdbIndex + pos) & 1u) != 0u;
+            const f2 *sp = reinterpret_cast<const f2*>(odd ? rd2b + pos - 1u : rdb + pos);
+#pragma unroll
+            for(int q = 0; q < NP; ++q) S[set][q] = sp[g * NP + q];
+        }
+        else
+        {
+            const float *s = rdb + pos;
+#pragma unroll
+            for(int q = 0; q < NP; ++q) S[set][q] = f2{s[2 * (g * NP + q)], s[2 * (g * NP + q) + 1]};
+        }
+    };
+    const uint32_t tb = frac0 + lane * increment;
+    load(0, tb, 0);
+#pragma unroll
+    for(int j = 0; j < kW16Outs; ++j)
+    {
+        outs[j] = 0.0f;
+        if(uint32_t(64 * j) < bdst)
+        {
+            const uint32_t tt0 = tb + uint32_t(j) * tstep;
+            const uint32_t tt = tt0 < tlast ? tt0 : tlast;
+            const f2 pf = splat(float(tt & 2047u) * (1.0f / 2048.0f));
+            f2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
+#pragma unroll
+            for(int g = 0; g < G; ++g)
+            {
+                const int u = j * G + g, nx = u + 1;
+                if(nx < kW16Outs * G) load(nx & 1, tb + uint32_t(nx / G) * tstep, nx % G);
+#pragma unroll
+                for(int q = 0; q < NP; ++q)
+                {
+                    const f2 c = pkfma(pf, P[u & 1][q], F[u & 1][q]);
+                    if(q & 1) r1 = pkfma(c, S[u & 1][q], r1);
+                    else r0 = pkfma(c, S[u & 1][q], r0);
+                }
+            }
+            outs[j] = (r0.x + r0.y) + (r1.x + r1.y);
+        }
+    }
+}
+
+// ---- the dual-ear FIR on the matrix pipe, ONE ear: FirMfmaH (dev_wave.hpp) without the ear loop ----
+// (fragments are fetched when they are needed: the other three wavefronts of the SIMD cover the LDS latency)
+template<int TILES, bool LOW8>
+__device__ __forceinline__ void FirMfmaEar(f4 (&acc)[5], const uint32_t (&xh)[2][kXhDw], const uint32_t (&hr)[2][kHrDw], float inv, uint32_t lane)
+{
+    const uint32_t i = lane & 15u, g = lane >> 4;
+    const uint32_t u0 = 16u - i + 8u * g, shift = (u0 & 1u) * 2u, ud = u0 >> 1;
+    const f4 vinv = {inv, inv, inv, inv};
+    h8 A[2][3];
+#pragma unroll
+    for(int s = 0; s < 2; ++s)
+#pragma unroll
+        for(int c = 0; c < 3; ++c)
+        {
+            const uint32_t *p = hr[s] + ud + 16 * c;
+            const uint32_t q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+            const u4 q = {__builtin_amdgcn_alignbyte(q1, q0, shift), __builtin_amdgcn_alignbyte(q2, q1, shift),
+                __builtin_amdgcn_alignbyte(q3, q2, shift), __builtin_amdgcn_alignbyte(q4, q3, shift)};
+            A[s][c] = __builtin_bit_cast(h8, q);
+        }
+#pragma unroll
+    for(int T = 0; T < TILES; ++T)
+    {
+        __builtin_amdgcn_sched_barrier(0);                       // (a tile at a time: the scheduler must not hold five tiles' fragments at once)
+        const uint32_t j = (T == 4 && i > 3u) ? 3u : i;          // the ring-out tile has four columns
+        h8 B[2][3];
+#pragma unroll
+        for(int s = 0; s < 2; ++s)
+        {
+            const u4 *p = reinterpret_cast<const u4*>(xh[s]) + 32 * T + 2u * j + g;
+#pragma unroll
+            for(int c = 0; c < 3; ++c) B[s][c] = __builtin_bit_cast(h8, p[4 * c]);
+        }
+        f4 ta = {0.0f, 0.0f, 0.0f, 0.0f}, tb = ta, tc = ta;
+#pragma unroll
+        for(int c = 0; c < 3; ++c)
+        {
+            ta = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1][c], B[0][c], ta, 0, 0, 0);
+            tb = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0][c], B[1][c], tb, 0, 0, 0);
+            tc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0][c], B[0][c], tc, 0, 0, 0);
+        }
+        f4 sum = __builtin_elementwise_fma((ta + tb) + tc, vinv, acc[T]);
+        asm volatile("" : "+v"(sum));                            // (summed HERE: left to itself the compiler sinks the three partial tiles' sum to the dump)
+        if(!LOW8 || i < 8u) acc[T] = sum;
+        __builtin_amdgcn_sched_barrier(0);                       // (nor three partial tiles per tile until the end)
+    }
+}
+
+__device__ __forceinline__ float W16ReadLaneF(float v, int l)
+{ return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+// a response (tap = lane, one ear) as split halves r[80 - lane] in hr[hi | lo] (FirMfmaH's operand A); returns 1 / scale
+__device__ __forceinline__ float W16StageResponse(uint32_t (&hr)[2][kHrDw], float h, uint32_t lane)
+{
+    float sh, inv;
+    HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, __builtin_fabsf(h))), sh, inv);
+    uint32_t hi, lo;
+    SplitHalf2(h * sh, 0.0f, hi, lo);
+    // zero padding: the halves outside u in [17, 80]
+    uint32_t *hz32 = &hr[0][0];
+    for(uint32_t k = lane; k < uint32_t(2 * kHrDw); k += 64) hz32[k] = 0u;
+    uint16_t *hz = reinterpret_cast<uint16_t*>(&hr[0][0]);
+    const uint32_t u = 80u - lane;
+    hz[0 * kHrHalves + u] = uint16_t(hi); hz[1 * kHrHalves + u] = uint16_t(lo);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, inv)));
+}
+
+// The voices of a workgroup's sixteen wavefronts.  Wavefronts w, w + 4, w + 8, w + 12 share a SIMD; voices that cost more --
+// an active filter, a replaced HRIR -- tend to come in regular patterns (every n-th source of a scene), so the slot within
+// a group of four rotates with the group: a period-4 pattern puts one voice of each kind on every SIMD.
+__device__ __forceinline__ uint32_t W16VoiceOf(uint32_t group, uint32_t wave)
+{
+    const uint32_t a = wave >> 2, b = wave & 3u;
+    return group * uint32_t(kW16Waves) + 4u * a + ((a + b) & 3u);
+}
+
+struct Next16 { const ParamRecord *recs; const int32_t *map; const float *rows; };
+
+// PROF: the measurement variant (tools/phase_times16.py): s_memtime stamps per phase; the product variant carries none of it
+template<bool PROF>
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kW16Threads) VoiceWave16Kernel(WaveArgsHrtf L, uint32_t samplesToDo, Next16 next, WaveProf prof)
+{
+    unsigned long long tEntry = 0;
+    if constexpr (PROF) tEntry = __builtin_readcyclecounter();
+    __shared__ W16Wg sm;
+    const uint32_t t = threadIdx.x;
+    uint32_t lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t group = blockIdx.x;
+    const uint32_t irStride = L.irStride;
+    const uint32_t N = samplesToDo;
+    W16Lds &w = sm.w[wave];
+    asm volatile("; argument block resident" :: "s"(L.tables), "s"(L.buffers), "s"(L.ctl), "s"(L.prev), "s"(L.dfilt), "s"(L.hrtfOld),
+        "s"(L.hrtfTgt), "s"(L.hist), "s"(L.ambi), "s"(L.startDelay), "s"(L.queueDone), "s"(L.partHrtf), "s"(L.hrirs),
+        "s"(next.recs), "s"(next.map), "s"(L.numVoices), "s"(L.irStride), "s"(L.pad), "s"(samplesToDo));
+
+    const uint32_t vRaw = W16VoiceOf(group, wave);
+    const bool haveVoice = vRaw < L.numVoices;
+    const uint32_t lastVoice = L.numVoices - 1u;
+    const uint32_t v = haveVoice ? vRaw : lastVoice;                 // (a wavefront without a voice reads a valid line and mixes nothing)
+    const uint32_t keyVoice = group * uint32_t(kW16Waves);           // the voice whose resampler rows the workgroup stages
+    auto stamp = [&](int slot)
+    {
+        if constexpr (PROF) { if(prof.times && haveVoice && (t & 63u) == 0u) prof.times[size_t{v} * 8 + slot] = __builtin_readcyclecounter(); }
+    };
+    if constexpr (PROF) { if(prof.times && haveVoice && (t & 63u) == 0u) prof.times[size_t{v} * 8 + 0] = tEntry; }
+    const VoiceHead head = LoadHeadScalar(L.ctl + v);
+    const BufferItem buf = LoadCtlBufferScalar(L.ctl + v);
+    const VoiceTail tail = LoadTailScalar(L.ctl + v);
+    asm volatile("" ::: "memory");
+    const VoiceHead headK = LoadHeadScalar(L.ctl + (keyVoice < L.numVoices ? keyVoice : lastVoice));
+    asm volatile("" ::: "memory");
+    const int psK = headK.playState, kK = headK.rsKind;
+    const uint32_t mK = kK == 2 ? 4u : headK.rsM, lK = kK == 2 ? 1u : headK.rsL, offK = headK.rsFilterOffset;
+
+    // ---- the workgroup's resampler rows: LDS-DMA gathers, a tap pair per wavefront (voice_wave.hip's pass 0) ----
+    const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24)))
+        && (psK == OALGPU_VOICE_PLAYING || psK == OALGPU_VOICE_STOPPING);
+    if(eligK)
+    {
+        typedef const __attribute__((address_space(1))) void *gvoidp;
+        typedef __attribute__((address_space(3))) void *lvoidp;
+        const float *src = L.tables + offK + size_t{lane >> 1} * (2u * mK) + (lane & 1u);
+        for(uint32_t pp = wave; pp < mK / 2u; pp += uint32_t(kW16Waves))
+        {
+            __builtin_amdgcn_global_load_lds((gvoidp)(src + 2u * pp), (lvoidp)&sm.tabF[32u * pp], 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvoidp)(src + mK + 2u * pp), (lvoidp)&sm.tabP[32u * pp], 4, 0, 0);
+        }
+        if(t == 0) { sm.tabKey = offK * 8u + uint32_t(kK); sm.tabM = mK; sm.tabL = lK; }
+    }
+
+    // ---- what the voice starts from: the source window (register path), mPrevSamples, Hrtf.History, the direct filter
+    // pair, the target response (tap = lane), a replaced filter's old one ----
+    const int vstate = head.playState;
+    const bool mixes = haveVoice && (vstate == OALGPU_VOICE_PLAYING || vstate == OALGPU_VOICE_STOPPING);
+    const bool playing = haveVoice && vstate == OALGPU_VOICE_PLAYING;
+    bool active = mixes && head.step >= 1u;
+    const bool dirty = (head.flags & kFlagHrtfDirty) != 0;
+    SrcPlan plan = PlanSource(head, N);
+    bool looping = false;
+    if(head.curBuffer >= 0)
+    {   // voice.cpp:1015-1019: a position at or past the loop end plays on without looping
+        looping = head.loopBuffer >= 0 && ((head.flags & kFlagQueue) || !(head.position >= 0 && uint32_t(head.position) >= buf.loopEnd));
+        plan.prefetch = plan.prefetch && GatherCovers(plan.bsrc, buf, looping, uint32_t(head.position));
+    }
+    if(head.flags & (kFlagDelayed | kFlagQueue)) plan.prefetch = false;
+    // the register path: a prefetched window resampled from the workgroup's staged rows with two sets of 6 tap pairs
+    const uint32_t sM = head.rsKind == 2 ? 4u : head.rsM, sL = head.rsKind == 2 ? 1u : head.rsL;
+    const bool regPath = active && plan.prefetch && eligK && (head.rsKind == 2 || head.rsKind == 3)
+        && head.rsFilterOffset * 8u + uint32_t(head.rsKind) == offK * 8u + uint32_t(kK) && sM == mK
+        && !(head.step == kFracOne && head.positionFrac == 0u);
+    float pre[kPre];
+#pragma unroll
+    for(int i = 0; i < kPre; ++i) pre[i] = 0.0f;
+    float prevv = 0.0f;
+    if(regPath)
+    {
+        GatherStatic(pre, plan.bsrc, buf, looping, uint32_t(head.position), lane);
+        prevv = (lane < kMaxPad) ? L.prev[size_t{v} * kMaxPad + lane] : 0.0f;
+    }
+
+    // the key voice does not qualify: wavefront 0 looks for one that does (voice_wave.hip's prologue)
+    if(!eligK)
+    {
+        if(wave == 0)
+        {
+            const uint32_t cand = keyVoice + lane;
+            bool eligible = false;
+            uint32_t off = 0, m = 0, l = 0;
+            int kind = 0;
+            if(lane < uint32_t(kW16Waves) && cand < L.numVoices)
+            {
+                const VoiceCtl &c = L.ctl[cand];
+                kind = c.rsKind; off = c.rsFilterOffset; m = c.rsM; l = c.rsL;
+                if(kind == 2) { m = 4; l = 1; }
+                eligible = (kind == 2 || (kind == 3 && (m == 12 || m == 24)))
+                    && (c.playState == OALGPU_VOICE_PLAYING || c.playState == OALGPU_VOICE_STOPPING);
+            }
+            const unsigned long long mask = __ballot(eligible);
+            if(mask)
+            {
+                const int firstLane = __ffsll((long long)mask) - 1;
+                const uint32_t key = uint32_t(__shfl(int(off * 8u + uint32_t(kind)), firstLane));
+                const uint32_t fm = uint32_t(__shfl(int(m), firstLane)), fl = uint32_t(__shfl(int(l), firstLane));
+                if(lane == 0) { sm.tabKey = key; sm.tabM = fm; sm.tabL = fl; }
+            }
+            else if(lane == 0) { sm.tabKey = 0xffffffffu; sm.tabM = 0; sm.tabL = 0; }
+        }
+        __syncthreads();
+        const uint32_t key = sm.tabKey, m = sm.tabM;
+        if(key != 0xffffffffu)
+        {
+            const float *filter = L.tables + (key >> 3);
+            for(uint32_t idx = t; idx < (m / 2u) * 32u; idx += uint32_t(kW16Threads))
+            {
+                const uint32_t p = idx >> 5, pi = idx & 31u;
+                const float *row = filter + pi * 2u * m;
+                sm.tabF[idx] = f2{row[2u * p], row[2u * p + 1u]};
+                sm.tabP[idx] = f2{row[m + 2u * p], row[m + 2u * p + 1u]};
+            }
+        }
+    }
+    // the rows (LDS-DMA) and this wavefront's window are in; the window is parked twice (rd2[i] = rd[i + 1])
+    if(regPath)
+    {
+        const bool isShort = buf.fmt == OALGPU_FMT_SHORT;
+        if(lane < kMaxPad) { w.a.rd[lane] = prevv; if(lane) w.a.rd2[lane - 1u] = prevv; }
+#pragma unroll
+        for(int i = 0; i < kPre; ++i)
+        {
+            const float sv = GatherDecode(pre[i], isShort);
+            w.a.rd[kMaxEdge + lane + 64u * uint32_t(i)] = sv;
+            w.a.rd2[kMaxEdge - 1u + lane + 64u * uint32_t(i)] = sv;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stamp(7);
+    // Instruction arbitration between the four wavefronts of a SIMD goes by priority, then by age: left alone the oldest runs
+    // through its phases first and the youngest runs its last ones alone, at a quarter of the issue rate (measured: the
+    // resampler took 11 K cycles for a workgroup's first wavefront and 38 K for its last).  A wavefront therefore gives
+    // priority away as it advances: whoever is behind is served first.  (Level 3 is left to the post-stream kernels that run beside
+    // this one: the reduction and the post-process of the update before are short chains the step waits for.)
+    __builtin_amdgcn_s_setprio(2);
+
+    // ---- voice.cpp:1002-1046: what does not mix; delayed starts ----
+    uint32_t outPos = 0;
+    if(mixes && !active && !playing && lane == 0) L.ctl[v].playState = OALGPU_VOICE_STOPPED;
+    if(active && (head.flags & kFlagDelayed))
+    {
+        const uint32_t d = L.startDelay[v];
+        if(!playing)
+        {
+            if(lane == 0) { L.ctl[v].playState = OALGPU_VOICE_STOPPED; L.ctl[v].flags = head.flags & ~kFlagDelayed; L.startDelay[v] = 0u; }
+            active = false;
+        }
+        else if(d >= N) { if(lane == 0) L.startDelay[v] = d - N; active = false; }
+        else
+        {
+            outPos = d;
+            if(lane == 0) L.startDelay[v] = 0u;
+            for(uint32_t k = lane; k < outPos; k += 64) w.g.smp[k] = 0.0f;
+        }
+    }
+
+    f4 accM[2][5];
+#pragma unroll
+    for(int e = 0; e < 2; ++e)
+#pragma unroll
+        for(int b = 0; b < 5; ++b) accM[e][b] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    uint32_t counter = 0, fademix = 0, todo = 0;
+    float endGain = 0.0f, gainAfterBlend = 0.0f;
+    float fstv = 0.0f, histv = 0.0f;
+    f2 hT = {0.0f, 0.0f};
+    int32_t bufferItem = head.curBuffer;
+    if(active)
+    {
+        float outs[kW16Outs];
+        // ---------------- LoadResampledSamples ----------------
+        if(regPath)
+        {
+            WaveSync();
+            const float *rdb = w.a.rd + (kMaxEdge - sL), *rd2b = w.a.rd2 + (kMaxEdge - sL);
+            const uint32_t rdbIndex = uint32_t(kMaxEdge) - sL;
+            if(sM == 24u) ResampleRingRegs<24, true>(sm.tabF, sm.tabP, rdb, head.positionFrac, head.step, N, outs, lane, rd2b, rdbIndex);
+            else if(sM == 12u) ResampleRingRegs<12, true>(sm.tabF, sm.tabP, rdb, head.positionFrac, head.step, N, outs, lane, rd2b, rdbIndex);
+            else ResampleRingRegs<4, false>(sm.tabF, sm.tabP, rdb, head.positionFrac, head.step, N, outs, lane, nullptr, 0u);
+            asm volatile("" : "+v"(lane));
+            // voice.cpp:772-785: history for the next update, taken at the end-of-mix position
+            if(playing)
+            {
+                const uint32_t srcOffset = uint32_t((uint64_t{N} * head.step + head.positionFrac) >> kFracBits);
+                if(lane < kMaxPad) L.prev[size_t{v} * kMaxPad + lane] = w.a.rd[srcOffset + lane];
+            }
+        }
+        else
+        {
+            W16GenView gv{w.g.rd, w.g.smp - kHist, nullptr, w.best, w.pad};
+            LoadResampledWave<true, false>(sm, gv, L, v, lane, head, playing, N - outPos, N - outPos, bufferItem, looping,
+                SrcPlan{false, plan.bdst, plan.bsrc}, outPos);
+            asm volatile("" : "+v"(lane));
+            WaveSync();
+#pragma unroll
+            for(int j = 0; j < kW16Outs; ++j) outs[j] = w.g.smp[lane + 64u * uint32_t(j)];
+        }
+        if(N < uint32_t(kLine))
+        {   // (a short block: outputs from N on are whatever the clamped reads produced)
+#pragma unroll
+            for(int j = 0; j < kW16Outs; ++j) if(lane + 64u * uint32_t(j) >= N) outs[j] = 0.0f;
+        }
+        stamp(1);
+        __builtin_amdgcn_s_setprio(1);
+        // the direct filter pair, Hrtf.History and the target response (tap = lane): requested now, behind the resampler --
+        // held across it they would be four registers at the kernel's register peak; the SIMD's other wavefronts cover the trip
+        fstv = (lane < 32u) ? reinterpret_cast<const float*>(L.dfilt + size_t{v} * 2)[lane] : 0.0f;
+        histv = L.hist[size_t{v} * kHist + lane];
+        hT = (lane < irStride) ? reinterpret_cast<const f2*>(L.hrtfTgt + size_t{v} * irStride * 2)[lane] : f2{0.0f, 0.0f};
+        WaveSync();                                 // (the window is dead from here on: its area is the sample line's / phase B's)
+
+        auto toLine = [&]()
+        {
+#pragma unroll
+            for(int j = 0; j < kW16Outs; ++j) w.g.smp[lane + 64u * uint32_t(j)] = outs[j];
+            WaveSync();
+        };
+        auto fromLine = [&]()
+        {
+            WaveSync();
+#pragma unroll
+            for(int j = 0; j < kW16Outs; ++j) outs[j] = w.g.smp[lane + 64u * uint32_t(j)];
+            WaveSync();
+        };
+        if(head.flags & kFlagAmbiScale)
+        {   // VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
+            const AmbiScaleState a = L.ambi[v];
+            SplitterState sp{a.coeff, a.lpZ1, a.lpZ2, a.apZ1};
+            toLine();
+            SplitterScan<false>(sp, w.g.smp + outPos, N - outPos, a.hfScale, a.lfScale, lane);
+            fromLine();
+            if(lane == 0) { L.ambi[v].lpZ1 = sp.lpZ1; L.ambi[v].lpZ2 = sp.lpZ2; L.ambi[v].apZ1 = sp.apZ1; }
+        }
+        counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
+
+        // ---------------- DoFilters, direct path (voice.cpp:255-267) ----------------
+        {
+            const bool directFilter = (head.flags & kFlagDirectFilter) != 0;
+            BiquadState f0, f1;
+            {
+                float a[13], b[13];
+#pragma unroll
+                for(int k = 0; k < 13; ++k) { a[k] = W16ReadLaneF(fstv, k); b[k] = W16ReadLaneF(fstv, 16 + k); }
+                f0 = BiquadState{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], __builtin_bit_cast(int32_t, a[12])};
+                f1 = BiquadState{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11], __builtin_bit_cast(int32_t, b[12])};
+            }
+            BiquadSlot *slots = &L.dfilt[size_t{v} * 2];
+            if(directFilter)
+            {
+                toLine();
+                if(f0.counter <= 0 && f1.counter <= 0)
+                {
+                    BiquadDualWaveScan(f0, f1, w.g.smp + outPos, N - outPos, lane);
+                    if(lane == 0) { slots[0].f.z1 = f0.z1; slots[0].f.z2 = f0.z2; slots[1].f.z1 = f1.z1; slots[1].f.z2 = f1.z2; }
+                }
+                else
+                {
+                    if(lane == 0) BiquadDualInterp(f0, f1, w.g.smp + outPos, w.g.smp + outPos, N - outPos);
+                    if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
+                }
+                fromLine();
+            }
+            else
+            {   // an inactive pair is cleared (voice.cpp:264-265); the store is skipped when it already is clear
+                const bool clean0 = f0.z1 == 0.0f && f0.z2 == 0.0f && f0.counter == 0 && f0.b0 == f0.tb0 && f0.b1 == f0.tb1
+                    && f0.b2 == f0.tb2 && f0.a1 == f0.ta1 && f0.a2 == f0.ta2;
+                const bool clean1 = f1.z1 == 0.0f && f1.z2 == 0.0f && f1.counter == 0 && f1.b0 == f1.tb0 && f1.b1 == f1.tb1
+                    && f1.b2 == f1.tb2 && f1.a1 == f1.ta1 && f1.a2 == f1.ta2;
+                if(!(clean0 && clean1) && lane == 0)
+                {
+                    BiquadClear(f0); BiquadClear(f1);
+                    slots[0].f = f0; slots[1].f = f1;
+                }
+            }
+        }
+
+        stamp(2);
+        __builtin_amdgcn_s_setprio(0);
+        // ---------------- DoHrtfMix, voice.cpp:827-902 ----------------
+        // Hrtf.History for the next update: in[N .. N + 63] of [history | samples]
+        {
+            const uint32_t q = N + lane;                        // index into [history(64) | samples]
+            float hv;
+            if(N == uint32_t(kLine)) hv = outs[kW16Outs - 1];   // samples 960 + lane
+            else
+            {
+                const uint32_t k = q - uint32_t(kHist);         // sample index where q >= 64
+                const uint32_t j0 = (N - uint32_t(kHist)) >> 6; // (N >= 64 here when used; uniform)
+                float lo = 0.0f, hi2 = 0.0f;
+#pragma unroll
+                for(int j = 0; j < kW16Outs; ++j) { if(uint32_t(j) == j0) lo = outs[j]; if(uint32_t(j) == j0 + 1u) hi2 = outs[j]; }
+                const float sLo = __shfl(lo, int(k & 63u)), sHi = __shfl(hi2, int(k & 63u));
+                const float smpv = (N >= uint32_t(kHist)) ? (((k >> 6) == j0) ? sLo : sHi) : __shfl(outs[0], int(k & 63u));
+                const float old = __shfl(histv, int(q & 63u));
+                hv = (q >= uint32_t(kHist)) ? smpv : old;
+            }
+            if(playing) __builtin_nontemporal_store(hv, &L.hist[size_t{v} * kHist + lane]);
+        }
+        w.b.in0[lane] = histv;
+        w.b.in0[kHist + lane] = outs[0];
+
+        const float targetGain = tail.tgtGain * (playing ? 1.0f : 0.0f);
+        const float oldGain = counter ? tail.oldGain : tail.tgtGain;   // voice.cpp:1100
+        float blendGain = targetGain;
+        if(counter)
+        {
+            fademix = N < counter ? N : counter;
+            if(counter > fademix)
+                blendGain = lerpf(oldGain, targetGain, float(fademix) / float(counter));
+        }
+        const float newStep = fademix ? blendGain / float(fademix) : 0.0f;
+        gainAfterBlend = fademix ? blendGain : oldGain;
+        todo = N - fademix;
+        endGain = targetGain;
+        if(todo && counter > N)
+            endGain = lerpf(gainAfterBlend, targetGain, float(todo) / float(counter - fademix));
+        const float mainStep = todo ? (endGain - gainAfterBlend) / float(todo) : 0.0f;
+        const bool oldOn = fademix && oldGain > kGainSilence;
+        const bool newOn = fademix && newStep * float(fademix) > kGainSilence;
+        const float oldStep = fademix ? oldGain / float(fademix) : 0.0f;
+        const bool merged = !dirty;
+        const bool oldPass = !merged && oldOn;
+        // (a replaced filter's old response, tap = lane: requested here, used behind the first ear's main FIR)
+        const f2 hO = (oldPass && lane < irStride) ? reinterpret_cast<const f2*>(L.hrtfOld + size_t{v} * irStride * 2)[lane] : f2{0.0f, 0.0f};
+        const float gbase = gainAfterBlend - mainStep * float(fademix);
+        // g(i): the gain of input frame i (MixHrtfBlend's two ramps summed while Old == Target, hrtfbase.h:54-88)
+        auto gainAt = [&](uint32_t i, bool mayFade)
+        {
+            float g = __builtin_fmaf(mainStep, float(i), gbase);
+            if(mayFade && i < fademix)
+            {
+                float gf = newOn ? newStep * float(i) : 0.0f;
+                if(merged && oldOn) gf += oldStep * float(fademix - i);
+                g = gf;
+            }
+            return g;
+        };
+        WaveSync();
+
+#pragma unroll
+        for(int e = 0; e < 2; ++e)
+        {
+            const uint32_t d = tail.tgtDelay[e];
+            // x'[i] = in[64 - d + i] * g(i), i < N: frames i >= d are sample i - d (this lane: i = lane + 64 j + d), frames below d
+            // come out of the history (lane = frame).  First the products' largest magnitude, then the power-of-two scale that
+            // puts it into [2^14, 2^15), the split and the stores (half index 64 + i).
+            const float headIn = (lane < d) ? w.b.in0[kHist - d + lane] : 0.0f;
+            const float headP = (lane < d && lane < N) ? headIn * gainAt(lane, true) : 0.0f;
+            float mxf = __builtin_fabsf(headP);
+#pragma unroll
+            for(int j = 0; j < kW16Outs; ++j)
+            {
+                const uint32_t i = lane + 64u * uint32_t(j) + d;
+                const float p = (i < N) ? outs[j] * gainAt(i, j == 0) : 0.0f;
+                mxf = __builtin_fmaxf(__builtin_fabsf(p), mxf);
+            }
+            float sx, invX;
+            HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, mxf)), sx, invX);
+            invX = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invX)));
+            sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
+            // zero pads: frames -64 .. -1 and N .. 1103 (whole dwords: N is even or the odd half is rewritten below)
+            if(lane < 32u) { w.b.xh[0][lane] = 0u; w.b.xh[1][lane] = 0u; }
+            for(uint32_t dw = 32u + (N >> 1) + lane; dw < uint32_t(kXhDw); dw += 64u) { w.b.xh[0][dw] = 0u; w.b.xh[1][dw] = 0u; }
+            uint16_t *xz = reinterpret_cast<uint16_t*>(&w.b.xh[0][0]);
+            if(lane < d)
+            {
+                uint32_t hi, lo;
+                SplitHalf2(headP * sx, 0.0f, hi, lo);
+                xz[0 * kXhHalves + 64u + lane] = uint16_t(hi); xz[1 * kXhHalves + 64u + lane] = uint16_t(lo);
+            }
+#pragma unroll
+            for(int j = 0; j < kW16Outs; j += 2)
+            {
+                const uint32_t i0 = lane + 64u * uint32_t(j) + d, i1 = i0 + 64u;
+                const float p0 = (i0 < N) ? outs[j] * gainAt(i0, j == 0) : 0.0f;
+                const float p1 = (i1 < N) ? outs[j + 1] * gainAt(i1, false) : 0.0f;
+                uint32_t hi, lo;
+                SplitHalf2(p0 * sx, p1 * sx, hi, lo);
+                // (frames up to 1023 + 63 < 1104: inside the array for any delay)
+                xz[0 * kXhHalves + 64u + i0] = uint16_t(hi); xz[1 * kXhHalves + 64u + i0] = uint16_t(lo);
+                xz[0 * kXhHalves + 64u + i1] = uint16_t(hi >> 16); xz[1 * kXhHalves + 64u + i1] = uint16_t(lo >> 16);
+            }
+            const float invH = W16StageResponse(w.b.hr, e == 0 ? hT.x : hT.y, lane);
+            WaveSync();
+            FirMfmaEar<5, false>(accM[e], w.b.xh, w.b.hr, invX * invH, lane);
+            if(oldPass)
+            {   // the replaced filter's fade-out (MixHrtfBlend, hrtfbase.h:54-70): 64 inputs x IrSize taps land in frames 0..126 --
+                // the first eight columns of tile 0.  Its inputs go over the main inputs' frames -64..143, frame = lane.
+                const uint32_t od = tail.oldDelay[e];
+                float xo = 0.0f;
+                if(lane < fademix) xo = w.b.in0[kHist - od + lane] * (oldStep * float(fademix - lane));
+                float sxo, invXo;
+                HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, __builtin_fabsf(xo))), sxo, invXo);
+                invXo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invXo)));
+                uint32_t hi, lo;
+                SplitHalf2(xo * sxo, 0.0f, hi, lo);
+                WaveSync();
+                xz[0 * kXhHalves + 64u + lane] = uint16_t(hi); xz[1 * kXhHalves + 64u + lane] = uint16_t(lo);
+                if(lane < 40u) { w.b.xh[0][64u + lane] = 0u; w.b.xh[1][64u + lane] = 0u; }
+                const float invHO = W16StageResponse(w.b.hro, e == 0 ? hO.x : hO.y, lane);
+                WaveSync();
+                FirMfmaEar<1, true>(accM[e], w.b.xh, w.b.hro, invXo * invHO, lane);
+            }
+            WaveSync();
+            stamp(3 + e);
+        }
+    }
+
+    // ---------------- state write-back (voice.cpp:1094-1232) ----------------
+    if(active)
+    {
+        if(dirty && (counter == 0 || fademix))
+        {   // Old <- Target
+            if(lane < irStride) reinterpret_cast<f2*>(L.hrtfOld + size_t{v} * irStride * 2)[lane] = hT;
+        }
+        if(lane == 0)
+        {
+            VoiceCtl &c = L.ctl[v];
+            if(counter == 0 || fademix) { c.hrtfOldDelay[0] = tail.tgtDelay[0]; c.hrtfOldDelay[1] = tail.tgtDelay[1]; }
+            c.hrtfOldGain = todo ? endGain : gainAfterBlend;
+            uint32_t flags = (head.flags | kFlagFading) & ~kFlagDelayed;
+            if(counter == 0 || fademix) flags &= ~kFlagHrtfDirty;
+            c.flags = flags;
+            if(!playing) c.playState = OALGPU_VOICE_STOPPED;
+            else
+            {
+                int32_t bufPosInt = head.position;
+                uint32_t bufPosFrac = head.positionFrac + head.step * (N - outPos);
+                const uint32_t samplesDone = bufPosFrac >> kFracBits;
+                bufPosInt = AddSat(bufPosInt, int32_t(samplesDone));
+                bufPosFrac &= kFracMask;
+                if(bufferItem >= 0 && bufPosInt > 0 && (head.flags & kFlagQueue))
+                {   // a streaming source: buffers the position ran past are done (voice.cpp:1182-1194)
+                    uint32_t buffersDone = 0;
+                    const int32_t before = bufferItem;
+                    AdvanceQueue(L.buffers, bufferItem, head.loopBuffer, bufPosInt, buffersDone);
+                    if(buffersDone) L.queueDone[v] += buffersDone;
+                    if(bufferItem >= 0 && bufferItem != before) c.buf = L.buffers[bufferItem];
+                }
+                else if(bufferItem >= 0 && bufPosInt > 0)
+                {
+                    if(looping)
+                    {
+                        uint32_t pos = uint32_t(bufPosInt);
+                        if(pos >= buf.loopEnd)
+                        {
+                            pos = ((pos - buf.loopStart) % (buf.loopEnd - buf.loopStart)) + buf.loopStart;
+                            bufPosInt = int32_t(pos);
+                        }
+                    }
+                    else if(uint32_t(bufPosInt) >= buf.sampleLen)
+                        bufferItem = -1;
+                }
+                c.position = bufPosInt;
+                c.positionFrac = bufPosFrac;
+                c.curBuffer = bufferItem;
+                if(bufferItem < 0)
+                {
+                    c.loopBuffer = -1;
+                    c.playState = OALGPU_VOICE_STOPPING;
+                }
+            }
+        }
+    }
+
+    stamp(5);
+    // ---------------- one partial bus per workgroup: the wavefronts dump their tiles, then a fixed-order sum ----------------
+    {
+        WaveSync();
+        f2 *dump = w.dump;
+        const uint32_t jc = lane & 15u, q4 = lane >> 4;
+#pragma unroll
+        for(int T = 0; T < 4; ++T)
+#pragma unroll
+            for(int r = 0; r < 4; ++r)
+                dump[17u * (16u * uint32_t(T) + jc) + 4u * q4 + uint32_t(r)] = f2{accM[0][T][r], accM[1][T][r]};
+        if(jc < 4u)
+        {
+#pragma unroll
+            for(int r = 0; r < 4; ++r) dump[17u * (64u + jc) + 4u * q4 + uint32_t(r)] = f2{accM[0][4][r], accM[1][4][r]};
+        }
+        __syncthreads();
+        f2 *ph = reinterpret_cast<f2*>(L.partHrtf) + size_t{group} * (kLine + kHrirLen);
+        for(uint32_t k = t; k < uint32_t(kLine + kHrirLen); k += uint32_t(kW16Threads))
+        {
+            f2 s = {0.0f, 0.0f};
+            if(k < 64u * 17u)
+            {
+                const uint32_t at = k + (k >> 4);
+                s = sm.w[0].dump[at];
+#pragma unroll
+                for(int ww = 1; ww < kW16Waves; ++ww) { const f2 o = sm.w[ww].dump[at]; s.x += o.x; s.y += o.y; }
+            }
+            StorePartial(&ph[k], s);
+        }
+    }
+    stamp(6);
+
+    // ---- the next update's parameter block: every wavefront installs the record of the voice it has just mixed ----
+    if(next.map && haveVoice)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if(next.rows && irStride <= 64u) InstallPair(L, next.map, next.recs, next.rows, v, v, false, lane);
+        else
+        {
+            const int32_t ri = __builtin_amdgcn_readfirstlane(next.map[v]);
+            if(ri >= 0) ApplyNextRecord(L, next.recs[ri], lane);
+        }
+    }
+}
+
+} // namespace
+
+bool Wave16Applies(const DeviceLayout &L)
+{
+    return L.hrtf && L.numSends == 0 && L.firMfma && L.irStride >= 8 && L.irStride <= 64 && L.accLines == 0 && L.sliceLines == 0;
+}
+uint32_t Wave16Groups(const DeviceLayout &L) { return (L.numVoices + uint32_t(kW16Waves) - 1u) / uint32_t(kW16Waves); }
+const char *Wave16KernelName() { return "VoiceWave16Kernel"; }
+
+hipError_t LaunchVoiceWave16(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
+    const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)
+{
+    const Next16 next{nextRecs, nextMap, nextRows};
+    const WaveProf none{nullptr, 0u};
+    if(prof) hipExtLaunchKernelGGL(VoiceWave16Kernel<true>, dim3(Wave16Groups(L)), dim3(kW16Threads), 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, next, *prof);
+    else hipExtLaunchKernelGGL(VoiceWave16Kernel<false>, dim3(Wave16Groups(L)), dim3(kW16Threads), 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, next, none);
+    return hipGetLastError();
+}
+
+} // namespace oalgpu

@@ -12,7 +12,7 @@ namespace oalgpu {
 // Which layouts have a resident launch, and the launch itself (evStart / evStop: HIP events bound to the dispatch, or null).
 bool WaveKernelHasResident(const DeviceLayout &L)
 {
-    return L.hrtf && L.numSends == 0 && L.firMfma && L.irStride >= 8 && L.irStride <= 64 && L.accLines == 0;
+    return L.hrtf && L.numSends == 0 && L.firMfma && L.irStride >= 8 && L.irStride <= 64 && L.accLines == 0 && L.wave16 == 0;
 }
 
 hipError_t LaunchVoiceWaveResident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop)

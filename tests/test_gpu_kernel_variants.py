@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 VARIANTS = {
     "wave+mfma-f16x2": (0, "VoiceWaveKernel<17, 64, 0, false, true>"),
     "wave+valu": (1, "VoiceWaveKernel<17, 64, 0, false>"),
+    "wave16": (256, "VoiceWave16Kernel"),          # OALGPU_CTX_WAVE16: one voice per wavefront, sixteen wavefronts per workgroup
 }
 CASES = [
     dict(fmt=ol.FMT_FLOAT, resampler=ol.RS_BSINC24, steps=[60211], n_updates=4, nvoices=24),

@@ -5,7 +5,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows), key=lambda e: e[0])
-voice = [i for i, e in enumerate(ev) if "VoiceWaveKernel" in e[2]]
+voice = [i for i, e in enumerate(ev) if ("VoiceWaveKernel" in e[2] or "VoiceWave16Kernel" in e[2])]
 frac = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5     # where in the run (by voice-kernel count) the window lies
 mid = voice[int(len(voice) * frac)]
 t0 = ev[mid][0]
