@@ -216,10 +216,11 @@ typedef struct oalgpu_context_desc {
                                    * row ever leaves the CU (csrc/voice_slice.hip).  Measured on BASELINE configs[3]: the voice kernel's
                                    * HBM traffic falls to a third and its time nearly doubles -- the per-voice work is done four times and the
                                    * kernel is instruction-bound: an opt-in variant, for A/B runs.  Other contexts ignore it. */
-#define OALGPU_CTX_WAVE16  256u   /* FAST HRTF contexts without sends (IrSize <= 64): one voice per wavefront, sixteen wavefronts per workgroup, one
-                                   * workgroup per compute unit -- four wavefronts per SIMD instead of two, the resampler's outputs in registers,
-                                   * one ear's FIR inputs at a time (csrc/voice_wave16.hip).  Other contexts ignore the flag; it
-                                   * takes precedence over OALGPU_CTX_RESIDENT. */
+#define OALGPU_CTX_WAVE_PAIRS 256u /* FAST HRTF contexts without sends (IrSize <= 64) mix one voice per wavefront at four wavefronts per SIMD --
+                                   * 16, 8 or 4 wavefronts per workgroup by the scene's size; the resampler's outputs in registers, one ear's FIR
+                                   * inputs at a time (csrc/voice_wave16.hip).  This flag selects the form of rounds 1-5 instead:
+                                   * two voices per wavefront, two wavefronts per SIMD (csrc/voice_wave.hip) -- for A/B runs; OALGPU_CTX_RESIDENT,
+                                   * which exists for that form only, implies it.  Other contexts ignore the flag. */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 

@@ -1329,8 +1329,14 @@ static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
     // buses than the context's buffers were sized for (the wavefront-per-voice kernel's grid has at least twice as many)
     if(c->useWave)
     {
-        const bool want16 = (c->desc.flags & OALGPU_CTX_WAVE16) && Wave16Applies(L);
-        L.wave16 = want16 ? 1u : 0u;
+        const bool want16 = !(c->desc.flags & (OALGPU_CTX_WAVE_PAIRS | OALGPU_CTX_RESIDENT)) && Wave16Applies(L);
+        uint32_t cus = 256u;
+        {
+            hipDeviceProp_t prop{};
+            if(hipGetDeviceProperties(&prop, c->desc.device) == hipSuccess && prop.multiProcessorCount > 0) cus = uint32_t(prop.multiProcessorCount);
+            else (void)hipGetLastError();
+        }
+        L.wave16 = want16 ? Wave16WavesFor(L.numVoices, cus) : 0u;
         const uint32_t groups = std::max<uint32_t>(1u, WaveKernelGroups(L));
         if(groups > c->groupsAllocated) return Fail(OALGPU_ERR_INVALID, "internal: the voice kernel's grid outgrew the partial buses");
         L.numGroups = groups; L.numLineGroups = groups;

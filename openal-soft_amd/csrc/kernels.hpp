@@ -115,8 +115,9 @@ struct DeviceLayout {
     uint32_t sliceLines;                    // voice_slice.hip: the context's voices are mixed a wavefront per 256-frame slice (0 = no)
     uint32_t accLines;                      // voice_wave.hip: the mix lines accumulate in the wavefronts' registers (<= 8 lines;
                                             // the kernel's ACCL: 4, 6 or 8) instead of leaving stream rows; 0 = stream rows
-    uint32_t wave16;                        // voice_wave16.hip: one voice per wavefront, sixteen wavefronts per workgroup (HRTF contexts
-                                            // without sends, IrSize <= 64; OALGPU_CTX_WAVE16); numGroups = voices / 16 then
+    uint32_t wave16;                        // voice_wave16.hip: one voice per wavefront, this many (4, 8 or 16) wavefronts per workgroup (HRTF
+                                            // contexts without sends, IrSize <= 64; 0 = voice_wave.hip's two voices per wavefront,
+                                            // OALGPU_CTX_WAVE_PAIRS); numGroups = voices / wave16 then
     // tables + buffers
     const float *tables;                    // [bsinc12 | bsinc24 | bsinc48 | spline | gaussian]
     const BufferItem *buffers;
@@ -470,8 +471,9 @@ hipError_t LaunchVoiceSlice(hipStream_t s, const DeviceLayout &L, uint32_t sampl
 bool WaveKernelHasResident(const DeviceLayout &L);
 // ---- launcher (voice_wave16.hip): the HRTF hot path at four wavefronts per SIMD, one voice per wavefront ----
 bool Wave16Applies(const DeviceLayout &L);
+uint32_t Wave16WavesFor(uint32_t voices, uint32_t cus);
 uint32_t Wave16Groups(const DeviceLayout &L);
-const char *Wave16KernelName();
+const char *Wave16KernelName(const DeviceLayout &L);
 hipError_t LaunchVoiceWave16(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows);
 hipError_t LaunchVoiceWaveResident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop);

@@ -1677,7 +1677,7 @@ uint32_t WaveKernelAccLines(const DeviceLayout &L)
 
 const char *WaveKernelName(const DeviceLayout &L)
 {
-    if(L.wave16) return Wave16KernelName();
+    if(L.wave16) return Wave16KernelName(L);
     if(L.sliceLines) return SliceKernelName();
     const bool sends = L.numSends != 0;
     if(L.accLines)

@@ -32,8 +32,6 @@
 namespace oalgpu {
 namespace {
 
-constexpr int kW16Waves = 16;
-constexpr int kW16Threads = kW16Waves * 64;
 constexpr int kW16Outs = kLine / 64;                    // outputs per lane: output k = lane + 64 j
 
 // ---- the wavefront's LDS: four views of one area of 2352 dwords ----
@@ -62,13 +60,14 @@ struct alignas(16) W16Lds {
     int32_t best;
     uint32_t pad[3];
 };
+template<int WAVES>
 struct W16Wg {
-    W16Lds w[kW16Waves];
+    W16Lds w[WAVES];
     alignas(16) f2 tabF[12 * 32];                       // [tap pair][phase] = fil[2p], fil[2p+1]   (up to 24 taps)
     f2 tabP[12 * 32];
     uint32_t tabKey, tabM, tabL, pad;
 };
-static_assert(sizeof(W16Wg) <= 157440, "123 LDS granules: the post-process (4) and the reduction (1) fit beside it");
+static_assert(sizeof(W16Wg<16>) <= 157440, "123 LDS granules: the post-process (4) and the reduction (1) fit beside it");
 
 // what LoadResampledWave (wave_common.hpp) reaches through its wavefront-LDS argument
 struct W16GenView { float *rd, *in, *rd2; int32_t &best; uint32_t *pad; };
@@ -211,21 +210,24 @@ __device__ __forceinline__ float W16StageResponse(uint32_t (&hr)[2][kHrDw], floa
 // The voices of a workgroup's sixteen wavefronts.  Wavefronts w, w + 4, w + 8, w + 12 share a SIMD; voices that cost more --
 // an active filter, a replaced HRIR -- tend to come in regular patterns (every n-th source of a scene), so the slot within
 // a group of four rotates with the group: a period-4 pattern puts one voice of each kind on every SIMD.
-__device__ __forceinline__ uint32_t W16VoiceOf(uint32_t group, uint32_t wave)
+__device__ __forceinline__ uint32_t W16VoiceOf(uint32_t group, uint32_t wave, uint32_t waves)
 {
     const uint32_t a = wave >> 2, b = wave & 3u;
-    return group * uint32_t(kW16Waves) + 4u * a + ((a + b) & 3u);
+    return group * waves + 4u * a + ((a + b) & 3u);
 }
 
 struct Next16 { const ParamRecord *recs; const int32_t *map; const float *rows; };
 
 // PROF: the measurement variant (tools/phase_times16.py): s_memtime stamps per phase; the product variant carries none of it
-template<bool PROF>
-__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kW16Threads) VoiceWave16Kernel(WaveArgsHrtf L, uint32_t samplesToDo, Next16 next, WaveProf prof)
+// WAVES: wavefronts (= voices) per workgroup -- 16 where the scene fills the machine that way (one workgroup per compute unit),
+// 8 or 4 for smaller scenes, so that every compute unit gets its share of them
+template<bool PROF, int WAVES>
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Kernel(WaveArgsHrtf L, uint32_t samplesToDo, Next16 next, WaveProf prof)
 {
     unsigned long long tEntry = 0;
     if constexpr (PROF) tEntry = __builtin_readcyclecounter();
-    __shared__ W16Wg sm;
+    constexpr uint32_t kW16Waves = uint32_t(WAVES), kW16Threads = uint32_t(WAVES) * 64u;
+    __shared__ W16Wg<WAVES> sm;
     const uint32_t t = threadIdx.x;
     uint32_t lane = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -237,7 +239,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kW16Threads) VoiceWave16K
         "s"(L.hrtfTgt), "s"(L.hist), "s"(L.ambi), "s"(L.startDelay), "s"(L.queueDone), "s"(L.partHrtf), "s"(L.hrirs),
         "s"(next.recs), "s"(next.map), "s"(L.numVoices), "s"(L.irStride), "s"(L.pad), "s"(samplesToDo));
 
-    const uint32_t vRaw = W16VoiceOf(group, wave);
+    const uint32_t vRaw = W16VoiceOf(group, wave, kW16Waves);
     const bool haveVoice = vRaw < L.numVoices;
     const uint32_t lastVoice = L.numVoices - 1u;
     const uint32_t v = haveVoice ? vRaw : lastVoice;                 // (a wavefront without a voice reads a valid line and mixes nothing)
@@ -721,7 +723,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kW16Threads) VoiceWave16K
                 const uint32_t at = k + (k >> 4);
                 s = sm.w[0].dump[at];
 #pragma unroll
-                for(int ww = 1; ww < kW16Waves; ++ww) { const f2 o = sm.w[ww].dump[at]; s.x += o.x; s.y += o.y; }
+                for(int ww = 1; ww < WAVES; ++ww) { const f2 o = sm.w[ww].dump[at]; s.x += o.x; s.y += o.y; }
             }
             StorePartial(&ph[k], s);
         }
@@ -747,16 +749,35 @@ bool Wave16Applies(const DeviceLayout &L)
 {
     return L.hrtf && L.numSends == 0 && L.firMfma && L.irStride >= 8 && L.irStride <= 64 && L.accLines == 0 && L.sliceLines == 0;
 }
-uint32_t Wave16Groups(const DeviceLayout &L) { return (L.numVoices + uint32_t(kW16Waves) - 1u) / uint32_t(kW16Waves); }
-const char *Wave16KernelName() { return "VoiceWave16Kernel"; }
+// wavefronts per workgroup for a scene of `voices` on a device of `cus` compute units: the smallest of 4 / 8 / 16 whose grid fits the
+// machine in one round (16 beyond that: the rounds follow each other out of phase)
+uint32_t Wave16WavesFor(uint32_t voices, uint32_t cus)
+{
+    for(uint32_t w : {4u, 8u}) if((voices + w - 1u) / w <= cus) return w;
+    return 16u;
+}
+uint32_t Wave16Groups(const DeviceLayout &L) { return (L.numVoices + L.wave16 - 1u) / L.wave16; }
+const char *Wave16KernelName(const DeviceLayout &L)
+{
+    return L.wave16 == 16u ? "VoiceWave16Kernel<16>" : (L.wave16 == 8u ? "VoiceWave16Kernel<8>" : "VoiceWave16Kernel<4>");
+}
 
 hipError_t LaunchVoiceWave16(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)
 {
     const Next16 next{nextRecs, nextMap, nextRows};
     const WaveProf none{nullptr, 0u};
-    if(prof) hipExtLaunchKernelGGL(VoiceWave16Kernel<true>, dim3(Wave16Groups(L)), dim3(kW16Threads), 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, next, *prof);
-    else hipExtLaunchKernelGGL(VoiceWave16Kernel<false>, dim3(Wave16Groups(L)), dim3(kW16Threads), 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, next, none);
+    const dim3 grid(Wave16Groups(L)), block(L.wave16 * 64u);
+#define OALGPU_W16_LAUNCH(P, W, PA) hipExtLaunchKernelGGL((VoiceWave16Kernel<P, W>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, next, PA)
+    if(prof)
+    {
+        if(L.wave16 == 16u) OALGPU_W16_LAUNCH(true, 16, *prof); else if(L.wave16 == 8u) OALGPU_W16_LAUNCH(true, 8, *prof); else OALGPU_W16_LAUNCH(true, 4, *prof);
+    }
+    else
+    {
+        if(L.wave16 == 16u) OALGPU_W16_LAUNCH(false, 16, none); else if(L.wave16 == 8u) OALGPU_W16_LAUNCH(false, 8, none); else OALGPU_W16_LAUNCH(false, 4, none);
+    }
+#undef OALGPU_W16_LAUNCH
     return hipGetLastError();
 }
 

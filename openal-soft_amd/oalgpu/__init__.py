@@ -84,7 +84,7 @@ class VoiceEvent(C.Structure):
 CTX_FIR_VALU, CTX_PROFILE, CTX_SERIAL, CTX_STREAM_ROWS, CTX_APPLY_IN_VOICE_KERNEL, CTX_FUSED_REDUCE = 1, 2, 4, 8, 16, 32
 CTX_RESIDENT = 64
 CTX_SLICE_LINES = 128
-CTX_WAVE16 = 256
+CTX_WAVE_PAIRS = 256
 
 
 class VoiceDesc(C.Structure):

@@ -73,7 +73,7 @@ def test_widest_bus(libs):
         return sc
 
     gsc, osc = build(api, max_voices=10), build(L)
-    assert "VoiceWaveKernel" in gsc.voice_kernel_name()
+    assert "VoiceWave" in gsc.voice_kernel_name()
     for k in range(3):
         gsc.mix(1000, post_process=False); osc.mix(1000, post_process=False)
         close(gsc.dry()[:, :1000], osc.dry()[:, :1000], f"dry, update {k}")

@@ -10,9 +10,9 @@ from scenes import run_scene
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {
-    "wave+mfma-f16x2": (0, "VoiceWaveKernel<17, 64, 0, false, true>"),
+    "wave16": (0, "VoiceWave16Kernel<4>"),          # the default: one voice per wavefront, four wavefronts per SIMD (voice_wave16.hip)
+    "wave+mfma-f16x2": (256, "VoiceWaveKernel<17, 64, 0, false, true>"),     # OALGPU_CTX_WAVE_PAIRS: two voices per wavefront
     "wave+valu": (1, "VoiceWaveKernel<17, 64, 0, false>"),
-    "wave16": (256, "VoiceWave16Kernel"),          # OALGPU_CTX_WAVE16: one voice per wavefront, sixteen wavefronts per workgroup
 }
 CASES = [
     dict(fmt=ol.FMT_FLOAT, resampler=ol.RS_BSINC24, steps=[60211], n_updates=4, nvoices=24),

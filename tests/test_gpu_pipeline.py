@@ -53,7 +53,7 @@ def test_pipelined_update_equals_serial_update(synth_mhr, variant):
 
     piped, pblocks = build(papi)
     serial, sblocks = build()
-    assert piped.voice_kernel_name() in ("VoiceBlockKernel",) or "VoiceWaveKernel" in piped.voice_kernel_name()
+    assert piped.voice_kernel_name() in ("VoiceBlockKernel",) or "VoiceWave" in piped.voice_kernel_name()
     got, want = {}, {}
     for k in range(UPDATES):
         piped.apply_block(pblocks[k])

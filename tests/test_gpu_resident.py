@@ -44,7 +44,7 @@ def test_resident_updates_equal_launched_updates(synth_mhr):
     assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
     mhr = synth.synth_mhr_bytes()
     rapi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT)
-    sapi = oalgpu.Api(oalgpu.MATH_FAST)
+    sapi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_WAVE_PAIRS)     # (the launched form of the SAME kernel: the resident launch exists for the two-voices-per-wavefront form)
     rapi._mhr = mhr
     sapi._mhr = mhr
 
@@ -98,7 +98,7 @@ def test_resident_outputs_through_the_ring(synth_mhr):
     updates = 24
     outs = {}
     for mode in ("resident", "launched"):
-        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT if mode == "resident" else 0)
+        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT if mode == "resident" else oalgpu.CTX_WAVE_PAIRS)
         api._mhr = mhr
         sc, blocks = _build(oalgpu, synth, bench, api, mhr, updates)
         got, tickets = [], []
@@ -140,7 +140,7 @@ def test_other_entry_points_park_the_resident_kernel(synth_mhr):
     updates = 12
     outs = {}
     for mode in ("resident", "launched"):
-        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT if mode == "resident" else 0)
+        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT if mode == "resident" else oalgpu.CTX_WAVE_PAIRS)
         api._mhr = mhr
         sc, script = bench.build_scene(oalgpu, synth, api, 3, 512, 0, mhr, 0)
         other, _ = bench.build_scene(oalgpu, synth, api, 3, 64, 0, mhr, 0)

@@ -10,7 +10,7 @@ oalmeasure.use_measurement_build()      # liboalgpu_measure.so: the product's so
 from oalgpu import synth
 import bench
 V = 4096
-api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_PROFILE | oalgpu.CTX_SERIAL | (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
+api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_WAVE_PAIRS | oalgpu.CTX_PROFILE | oalgpu.CTX_SERIAL | (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
 mhr = synth.synth_mhr_bytes(); api._mhr = mhr
 sc, script = bench.build_scene(oalgpu, synth, api, 3, V, 0, mhr, 0)
 allv = list(range(V)); moving = [v for v in allv if script.is_moving(v)]

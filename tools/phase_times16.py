@@ -12,7 +12,7 @@ oalmeasure.use_measurement_build()      # liboalgpu_measure.so: the product's so
 from oalgpu import synth
 import bench
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_WAVE16 | oalgpu.CTX_PROFILE | oalgpu.CTX_SERIAL)
+api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_PROFILE | oalgpu.CTX_SERIAL)
 mhr = synth.synth_mhr_bytes(); api._mhr = mhr
 sc, script = bench.build_scene(oalgpu, synth, api, 3, V, 0, mhr, 0)
 allv = list(range(V)); moving = [v for v in allv if script.is_moving(v)]
