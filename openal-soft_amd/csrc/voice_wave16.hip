@@ -60,12 +60,14 @@ struct alignas(16) W16Lds {
     int32_t best;
     uint32_t pad[3];
 };
+// (the rows FIRST: a DS instruction's immediate offset has 16 bits, and with the rows behind 150 KB of wavefront areas every one
+// of the resampler's 24 row reads per output needed a VALU operation of its own to build its address)
 template<int WAVES>
 struct W16Wg {
-    W16Lds w[WAVES];
     alignas(16) f2 tabF[12 * 32];                       // [tap pair][phase] = fil[2p], fil[2p+1]   (up to 24 taps)
     f2 tabP[12 * 32];
     uint32_t tabKey, tabM, tabL, pad;
+    W16Lds w[WAVES];
 };
 static_assert(sizeof(W16Wg<16>) <= 157440, "123 LDS granules: the post-process (4) and the reduction (1) fit beside it");
 
@@ -249,6 +251,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
         if constexpr (PROF) { if(prof.times && haveVoice && (t & 63u) == 0u) prof.times[size_t{v} * 8 + slot] = __builtin_readcyclecounter(); }
     };
     if constexpr (PROF) { if(prof.times && haveVoice && (t & 63u) == 0u) prof.times[size_t{v} * 8 + 0] = tEntry; }
+    // (eight more stamps per voice behind the first block: the inside of the first ear's pass)
+    auto stamp2 = [&](int slot)
+    {
+        if constexpr (PROF) { if(prof.times && haveVoice && (t & 63u) == 0u) prof.times[size_t{L.numVoices} * 8 + size_t{v} * 8 + slot] = __builtin_readcyclecounter(); }
+    };
     const VoiceHead head = LoadHeadScalar(L.ctl + v);
     const BufferItem buf = LoadCtlBufferScalar(L.ctl + v);
     const VoiceTail tail = LoadTailScalar(L.ctl + v);
@@ -570,6 +577,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
             return g;
         };
         WaveSync();
+        stamp2(0);
 
 #pragma unroll
         for(int e = 0; e < 2; ++e)
@@ -614,9 +622,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
                 xz[0 * kXhHalves + 64u + i0] = uint16_t(hi); xz[1 * kXhHalves + 64u + i0] = uint16_t(lo);
                 xz[0 * kXhHalves + 64u + i1] = uint16_t(hi >> 16); xz[1 * kXhHalves + 64u + i1] = uint16_t(lo >> 16);
             }
+            if(e == 0) stamp2(1);
             const float invH = W16StageResponse(w.b.hr, e == 0 ? hT.x : hT.y, lane);
             WaveSync();
+            if(e == 0) stamp2(2);
             FirMfmaEar<5, false>(accM[e], w.b.xh, w.b.hr, invX * invH, lane);
+            if(e == 0) stamp2(3);
             if(oldPass)
             {   // the replaced filter's fade-out (MixHrtfBlend, hrtfbase.h:54-70): 64 inputs x IrSize taps land in frames 0..126 --
                 // the first eight columns of tile 0.  Its inputs go over the main inputs' frames -64..143, frame = lane.
@@ -697,6 +708,20 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
         }
     }
 
+    // ---- the next update's parameter block: every wavefront installs the record of the voice it has just mixed.  Here, in front
+    // of the dump's barrier: the install is a chain of dependent round trips (map entry -> record -> stores), and all but the
+    // workgroup's last wavefront spend it waiting for that one anyway.  The voice's state was written back by this very wavefront,
+    // in program order.
+    if(next.map && haveVoice)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if(next.rows && irStride <= 64u) InstallPair(L, next.map, next.recs, next.rows, v, v, false, lane);
+        else
+        {
+            const int32_t ri = __builtin_amdgcn_readfirstlane(next.map[v]);
+            if(ri >= 0) ApplyNextRecord(L, next.recs[ri], lane);
+        }
+    }
     stamp(5);
     // ---------------- one partial bus per workgroup: the wavefronts dump their tiles, then a fixed-order sum ----------------
     {
@@ -730,17 +755,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
     }
     stamp(6);
 
-    // ---- the next update's parameter block: every wavefront installs the record of the voice it has just mixed ----
-    if(next.map && haveVoice)
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if(next.rows && irStride <= 64u) InstallPair(L, next.map, next.recs, next.rows, v, v, false, lane);
-        else
-        {
-            const int32_t ri = __builtin_amdgcn_readfirstlane(next.map[v]);
-            if(ri >= 0) ApplyNextRecord(L, next.recs[ri], lane);
-        }
-    }
 }
 
 } // namespace

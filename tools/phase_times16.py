@@ -24,6 +24,9 @@ sc.sync()
 out = np.zeros((V, 8), np.uint64)
 rc = oalgpu.lib.oalgpu_debug_phase_times(sc.h, out.ctypes.data_as(C.c_void_p)); assert rc == 0, rc
 t = out.astype(np.int64)
+out2 = np.zeros((V, 8), np.uint64); nw = C.c_uint32(0)
+rc = oalgpu.lib.oalgpu_debug_wave_times(sc.h, out2.ctypes.data_as(C.c_void_p), C.byref(nw)); assert rc == 0, rc
+t_in = out2.astype(np.int64)
 names = ["entry->barrier", "resample", "filters", "ear0 x'+FIR", "ear1 x'+FIR", "write-back", "dump+partial"]
 t2 = np.stack([t[:, 0], t[:, 7], t[:, 1], t[:, 2], t[:, 3], t[:, 4], t[:, 5], t[:, 6]], axis=1)
 d = np.diff(t2, axis=1)
@@ -46,3 +49,25 @@ for i, n in enumerate(names):
     print("  %-14s per workgroup: mean=%.0f max=%.0f min=%.0f" % (n, x.mean(), x.max(axis=1).mean(), x.min(axis=1).mean()))
 late = np.argmax(arrive, axis=1)
 print("which slot arrives last (wave index within the workgroup, histogram):", np.bincount(late, minlength=16).tolist())
+dl = d.reshape(-1, 16, 7)[np.arange(late.size), late]
+print("the workgroup's LAST wavefront, phase by phase:", " ".join(f"{n}={dl[:, i].mean():.0f}" for i, n in enumerate(names)))
+first = np.argmin(arrive, axis=1)
+df = d.reshape(-1, 16, 7)[np.arange(first.size), first]
+print("the workgroup's FIRST wavefront, phase by phase:", " ".join(f"{n}={df[:, i].mean():.0f}" for i, n in enumerate(names)))
+g = 37
+base = t[vv[g], 0].min()
+print("workgroup", g, ": wave, voice, stamps relative to the first entry [entry barrier resampled filtered ear0 ear1 written dumped]")
+order = [0, 7, 1, 2, 3, 4, 5, 6]
+inv = {}
+for w in range(16):
+    a, b = w >> 2, w & 3
+    inv[w] = g * 16 + 4 * a + ((a + b) & 3)
+for w in range(16):
+    v = inv[w]
+    print("  w%2d v%%4=%d " % (w, v % 4), " ".join("%6d" % (t[v, k] - base) for k in order))
+
+# the inside of the first ear's pass (stamps 8..11 of the voice): setup (history, gains) | x' build | response staged | FIR
+sub = np.stack([t[:, 2], t_in[:, 0], t_in[:, 1], t_in[:, 2], t_in[:, 3], t[:, 3]], axis=1)
+ds = np.diff(sub, axis=1)
+for kn, vs in kinds.items():
+    print("  ear 0 of", kn, ": setup=%.0f x'build=%.0f response=%.0f FIR=%.0f old pass/rest=%.0f" % tuple(ds[vs].mean(axis=0)))
