@@ -579,49 +579,70 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
         WaveSync();
         stamp2(0);
 
+        // The inputs' scale -- the power of two that puts their largest magnitude into [2^14, 2^15) -- comes from a bound, once for both
+        // ears: the largest sample (or history value) times the largest gain of the block.  (The products' own maximum was a
+        // second pass over them per ear, for a bit or two of headroom the split does not need: a value's halves keep 22
+        // significant bits wherever it lies below the block's maximum.)
+        float sx, invX;
+        {
+            float mxo = __builtin_fabsf(histv);
+#pragma unroll
+            for(int j = 0; j < kW16Outs; ++j) mxo = __builtin_fmaxf(__builtin_fabsf(outs[j]), mxo);
+            const float mxw = __builtin_bit_cast(float, WaveMaxBits(__builtin_bit_cast(uint32_t, mxo)));
+            const float gmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(blendGain) + __builtin_fabsf(oldGain), __builtin_fabsf(gainAfterBlend)),
+                __builtin_fabsf(endGain));
+            HalfScale(__builtin_bit_cast(uint32_t, mxw * gmax), sx, invX);
+            invX = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invX)));
+            sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
+        }
+        const float step64 = mainStep * 64.0f * sx;
+        // x'[i] = in[64 - d + i] * g(i), i < N: frames i >= d are sample i - d (this lane: i = lane + 64 j + d), frames below d come
+        // out of the history (lane = frame); split into halves and stored at half index 64 + i.  FULL: a whole line -- only the last
+        // 64 samples can land at or beyond frame N.
+        auto buildEar = [&](uint32_t d, auto fullTag)
+        {
+            constexpr bool FULL = decltype(fullTag)::value;
+            // zero pads: frames -64 .. -1 and N .. 1103 (whole dwords: N is even or the odd half is rewritten below)
+            if(lane < 32u) { w.b.xh[0][lane] = 0u; w.b.xh[1][lane] = 0u; }
+            for(uint32_t dw = 32u + (N >> 1) + lane; dw < uint32_t(kXhDw); dw += 64u) { w.b.xh[0][dw] = 0u; w.b.xh[1][dw] = 0u; }
+            WaveSync();                                         // (the halves below go through a pointer of another type)
+            uint16_t *xz = reinterpret_cast<uint16_t*>(&w.b.xh[0][0]) + 64u + lane + d;       // frame lane + d
+            if(lane < d)
+            {
+                const float headP = (lane < N) ? w.b.in0[kHist - d + lane] * gainAt(lane, true) : 0.0f;
+                uint32_t hi, lo;
+                SplitHalf2(headP * sx, 0.0f, hi, lo);
+                uint16_t *xh0 = reinterpret_cast<uint16_t*>(&w.b.xh[0][0]) + 64u + lane;
+                xh0[0] = uint16_t(hi); xh0[kXhHalves] = uint16_t(lo);
+            }
+            const uint32_t i00 = lane + d;
+            const float g0s = gainAt(i00, true) * sx;                                  // frame lane + d: the only row inside the fade
+            const float gls = __builtin_fmaf(mainStep, float(i00), gbase) * sx;        // the main ramp at that frame, scaled
+#pragma unroll
+            for(int j = 0; j < kW16Outs; j += 2)
+            {
+                const float ga = (j == 0) ? g0s : __builtin_fmaf(step64, float(j), gls);
+                const float gb = __builtin_fmaf(step64, float(j + 1), gls);
+                float p0 = outs[j] * ga, p1 = outs[j + 1] * gb;
+                if(!FULL || j + 2 == kW16Outs)
+                {
+                    if(i00 + 64u * uint32_t(j) >= N) p0 = 0.0f;
+                    if(i00 + 64u * uint32_t(j + 1) >= N) p1 = 0.0f;
+                }
+                uint32_t hi, lo;
+                SplitHalf2(p0, p1, hi, lo);
+                // (frames up to 1023 + 63 < 1104: inside the array for any delay)
+                xz[64 * j] = uint16_t(hi); xz[kXhHalves + 64 * j] = uint16_t(lo);
+                xz[64 * (j + 1)] = uint16_t(hi >> 16); xz[kXhHalves + 64 * (j + 1)] = uint16_t(lo >> 16);
+            }
+        };
+
 #pragma unroll
         for(int e = 0; e < 2; ++e)
         {
             const uint32_t d = tail.tgtDelay[e];
-            // x'[i] = in[64 - d + i] * g(i), i < N: frames i >= d are sample i - d (this lane: i = lane + 64 j + d), frames below d
-            // come out of the history (lane = frame).  First the products' largest magnitude, then the power-of-two scale that
-            // puts it into [2^14, 2^15), the split and the stores (half index 64 + i).
-            const float headIn = (lane < d) ? w.b.in0[kHist - d + lane] : 0.0f;
-            const float headP = (lane < d && lane < N) ? headIn * gainAt(lane, true) : 0.0f;
-            float mxf = __builtin_fabsf(headP);
-#pragma unroll
-            for(int j = 0; j < kW16Outs; ++j)
-            {
-                const uint32_t i = lane + 64u * uint32_t(j) + d;
-                const float p = (i < N) ? outs[j] * gainAt(i, j == 0) : 0.0f;
-                mxf = __builtin_fmaxf(__builtin_fabsf(p), mxf);
-            }
-            float sx, invX;
-            HalfScale(WaveMaxBits(__builtin_bit_cast(uint32_t, mxf)), sx, invX);
-            invX = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invX)));
-            sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
-            // zero pads: frames -64 .. -1 and N .. 1103 (whole dwords: N is even or the odd half is rewritten below)
-            if(lane < 32u) { w.b.xh[0][lane] = 0u; w.b.xh[1][lane] = 0u; }
-            for(uint32_t dw = 32u + (N >> 1) + lane; dw < uint32_t(kXhDw); dw += 64u) { w.b.xh[0][dw] = 0u; w.b.xh[1][dw] = 0u; }
+            if(N == uint32_t(kLine)) buildEar(d, std::true_type{}); else buildEar(d, std::false_type{});
             uint16_t *xz = reinterpret_cast<uint16_t*>(&w.b.xh[0][0]);
-            if(lane < d)
-            {
-                uint32_t hi, lo;
-                SplitHalf2(headP * sx, 0.0f, hi, lo);
-                xz[0 * kXhHalves + 64u + lane] = uint16_t(hi); xz[1 * kXhHalves + 64u + lane] = uint16_t(lo);
-            }
-#pragma unroll
-            for(int j = 0; j < kW16Outs; j += 2)
-            {
-                const uint32_t i0 = lane + 64u * uint32_t(j) + d, i1 = i0 + 64u;
-                const float p0 = (i0 < N) ? outs[j] * gainAt(i0, j == 0) : 0.0f;
-                const float p1 = (i1 < N) ? outs[j + 1] * gainAt(i1, false) : 0.0f;
-                uint32_t hi, lo;
-                SplitHalf2(p0 * sx, p1 * sx, hi, lo);
-                // (frames up to 1023 + 63 < 1104: inside the array for any delay)
-                xz[0 * kXhHalves + 64u + i0] = uint16_t(hi); xz[1 * kXhHalves + 64u + i0] = uint16_t(lo);
-                xz[0 * kXhHalves + 64u + i1] = uint16_t(hi >> 16); xz[1 * kXhHalves + 64u + i1] = uint16_t(lo >> 16);
-            }
             if(e == 0) stamp2(1);
             const float invH = W16StageResponse(w.b.hr, e == 0 ? hT.x : hT.y, lane);
             WaveSync();
