@@ -610,8 +610,9 @@ int oalgpu_voice_move_async(oalgpu_context *ctx, const oalgpu_voice_move *moves,
  * [line][1024] floats -- two updates late without a copy in between: HRTF contexts with a post-process have the
  * post-process kernel store the lines into a pinned ring slot itself and raise the slot's sequence number (no copy launch,
  * no runtime call on the host: oalgpu_output_wait polls that word); other contexts queue a device-to-host copy behind the
- * update.  Returns a ticket; oalgpu_output_wait blocks until the lines have landed and hands them over.  Three tickets may be
- * outstanding (a fourth call fails with OALGPU_ERR_CAPACITY: the slot it would take is still uncollected). */
+ * update.  Returns a ticket; oalgpu_output_wait blocks until the lines have landed and hands them over.  The ring has four slots:
+ * a ticket stays valid until four more have been handed out -- the call never fails for want of a slot, it reuses the oldest, and
+ * oalgpu_output_wait on a ticket whose slot has been reused returns OALGPU_ERR_INVALID. */
 int oalgpu_read_output_async(oalgpu_context *ctx, uint32_t *ticket);
 int oalgpu_output_wait(oalgpu_context *ctx, uint32_t ticket, float *out, size_t out_floats);
 

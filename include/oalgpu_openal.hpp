@@ -427,6 +427,18 @@ private:
         e = Entry{};
     }
 
+    /* Buffers a streaming source has played through leave its queue on the device context as well (oalgpu_voice_queue_unqueue:
+     * the voice's hold moves on, a buffer the application has released among them is freed) and the front of the chain: without
+     * this a long-running stream kept every buffer it had ever queued alive, until the buffer table was full. */
+    void leaveBehind(Entry &e, uint32_t done)
+    {
+        if(!e.queue || done == 0 || e.chain.size() < 2) return;
+        const uint32_t n = done < e.chain.size() - 1 ? done : uint32_t(e.chain.size() - 1);
+        for(const Chan &ch : e.chans)
+            if(oalgpu_voice_queue_unqueue(mGpu, ch.index, n) != 0) return;      /* (what the device context does not know as played stays) */
+        e.chain.erase(e.chain.begin(), e.chain.begin() + n);
+    }
+
     /* a streaming source's queue (VoiceBufferItem::mNext): items the voice has not been linked through yet are registered
      * and linked behind the last one (alSourceQueueBuffers appends while the source plays) */
     int extendChain(const Voice *voice, Entry &e)
@@ -696,6 +708,7 @@ private:
                         { voice->mCurrentBuffer.store(const_cast<VoiceBufferItem*>(link.first), std::memory_order_release); break; }
                 const uint32_t done = st.buffers_done - e.doneSeen;
                 e.doneSeen = st.buffers_done;
+                leaveBehind(e, done);
                 if(done > 0 && context->mEnabledEvts.load(std::memory_order_acquire).test(AsyncEnableBits::BufferCompleted))
                 {
                     auto *ring = context->mAsyncEvents.get();
@@ -805,8 +818,11 @@ private:
                 for(auto const &link : e.chain)
                     if(link.second == currentBuffer)
                     { voice->mCurrentBuffer.store(const_cast<VoiceBufferItem*>(link.first), std::memory_order_release); break; }
-            const uint32_t done = buffersDone - e.doneSeen;
-            e.doneSeen = buffersDone;
+            /* (a report that is older than what a resynchronisation has read in between: nothing new in it) */
+            const int32_t ahead = int32_t(buffersDone - e.doneSeen);
+            const uint32_t done = ahead > 0 ? uint32_t(ahead) : 0u;
+            if(ahead > 0) e.doneSeen = buffersDone;
+            leaveBehind(e, done);
             if(done > 0 && context->mEnabledEvts.load(std::memory_order_acquire).test(AsyncEnableBits::BufferCompleted))
             {
                 auto *ring = context->mAsyncEvents.get();

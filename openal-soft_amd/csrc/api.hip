@@ -911,7 +911,7 @@ int oalgpu_converter_create(int device, int src_type, int dst_type, uint32_t cha
 void oalgpu_converter_destroy(oalgpu_converter *c)
 {
     if(!c) return;
-    (void)hipSetDevice(c->device);
+    (void)UseDevice(c->device);          // (a resident voice kernel on the device is told to leave first: it would sit out the synchronisation until its watchdog)
     (void)hipDeviceSynchronize();
     delete c;
 }
@@ -1630,6 +1630,8 @@ int oalgpu_buffer_register(oalgpu_context *c, const void *data, int fmt_type, ui
 int oalgpu_voice_init(oalgpu_context *c, uint32_t voice, const oalgpu_voice_desc *d)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }
+    // (a parameter block that waits for a resident update was applied BEFORE this call: it goes in first, as on the launched path)
+    if(c && c->res.pendingBlock) { if(int rc = UseCtx(c)) return rc; }
     if(!c || !d || voice >= c->L.numVoices || !BufferLive(c, d->buffer) || c->bufHost[size_t(d->buffer)].released
         || d->position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init: bad arguments");
@@ -1675,6 +1677,8 @@ int oalgpu_voice_init_queue(oalgpu_context *c, uint32_t voice, int first_buffer,
     uint32_t position_frac)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }
+    // (a parameter block that waits for a resident update was applied BEFORE this call: it goes in first, as on the launched path)
+    if(c && c->res.pendingBlock) { if(int rc = UseCtx(c)) return rc; }
     if(!c || voice >= c->L.numVoices || !BufferLive(c, first_buffer) || c->bufHost[size_t(first_buffer)].released || position_frac >= kFracOne)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_voice_init_queue: bad arguments");
     if(c->L.hrtf && !c->hrtfLoaded) return Fail(OALGPU_ERR_NO_HRTF, "HRTF context without a data set");
@@ -1981,7 +1985,8 @@ int oalgpu_param_block_create(oalgpu_context *c, const uint32_t *voices, const o
             HIP_TRY(b->voiceToRec.alloc(map.size()));
             HIP_TRY(b->voiceToRec.upload(map.data(), map.size()));
             b->mapVoices = uint32_t(map.size());
-            if((c->res.enabled || (c->desc.flags & OALGPU_CTX_APPLY_IN_VOICE_KERNEL)) && c->L.hrtf && c->L.hrirs)
+            // (rows of up to 64 taps: InstallPair moves one tap pair per lane; longer responses are blended at install, ApplyRecordLean)
+            if((c->res.enabled || (c->desc.flags & OALGPU_CTX_APPLY_IN_VOICE_KERNEL)) && c->L.hrtf && c->L.hrirs && c->L.irStride <= 64u)
             {   // a resident context's voice kernel installs the block itself: the HRIR blend of every record now, once
                 HIP_TRY(b->rows.alloc(count * size_t{c->L.irStride} * 2));
                 HIP_TRY(b->rows.zero());
@@ -2261,6 +2266,7 @@ int oalgpu_voice_events_wait(oalgpu_context *c, uint32_t ticket, oalgpu_voice_ev
     {
         const uint32_t *e = h + 4u + size_t{i} * 8u;
         out[i] = oalgpu_voice_event{e[0], int32_t(e[1]), int32_t(e[2]) >= 0 ? 1 : 0, int32_t(e[2]), e[3], int32_t(e[4]), e[5], int32_t(e[6])};
+        if(e[0] < c->L.numVoices) c->queueDoneKnown[e[0]] = e[3];      // (what oalgpu_voice_queue_unqueue checks against)
     }
     return OALGPU_OK;
 }
@@ -3191,6 +3197,8 @@ int oalgpu_set_bformat_decoder(oalgpu_context *c, uint32_t num_out, const float 
 int oalgpu_set_output(oalgpu_context *c, int sample_type, float dither_depth, uint32_t dither_seed)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }
+    // (a parameter block that waits for a resident update was applied BEFORE this call: it goes in first, as on the launched path)
+    if(c && c->res.pendingBlock) { if(int rc = UseCtx(c)) return rc; }
     if(!c || sample_type < OALGPU_OUT_I8 || sample_type > OALGPU_OUT_F32 || dither_depth < 0.0f)
         return Fail(OALGPU_ERR_INVALID, "oalgpu_set_output: bad arguments");
     c->outType = sample_type; c->ditherDepth = dither_depth; c->ditherSeed = dither_seed;
@@ -3246,6 +3254,8 @@ int oalgpu_read_hrtf_accum(oalgpu_context *c, float *out)
 int oalgpu_bus_device_ptr(oalgpu_context *c, void **ptr, size_t *nfloats, void **hip_stream)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }
+    // (a parameter block that waits for a resident update was applied BEFORE this call: it goes in first, as on the launched path)
+    if(c && c->res.pendingBlock) { if(int rc = UseCtx(c)) return rc; }
     if(!c || !ptr || !nfloats) return Fail(OALGPU_ERR_INVALID, "null argument");
     *ptr = c->L.bus;
     *nfloats = BusFloats(c->L);
@@ -3333,6 +3343,8 @@ int oalgpu_voices_readback(oalgpu_context *c, const uint32_t *voices, size_t cou
 int oalgpu_set_timing(oalgpu_context *c, int enable)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }
+    // (a parameter block that waits for a resident update was applied BEFORE this call: it goes in first, as on the launched path)
+    if(c && c->res.pendingBlock) { if(int rc = UseCtx(c)) return rc; }
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
     c->timing = enable != 0;
     c->timed = false;
@@ -3509,6 +3521,8 @@ int oalgpu_resident_set_max_updates(oalgpu_context *c, uint32_t max_updates)
 int oalgpu_set_carry_accum(oalgpu_context *c, int enable)
 {
     if(c) { if(int rc = FlushPendingMix(c)) return rc; }
+    // (a parameter block that waits for a resident update was applied BEFORE this call: it goes in first, as on the launched path)
+    if(c && c->res.pendingBlock) { if(int rc = UseCtx(c)) return rc; }
     if(!c) return Fail(OALGPU_ERR_INVALID, "null argument");
     c->carryAccum = enable != 0;
     return OALGPU_OK;

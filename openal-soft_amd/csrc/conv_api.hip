@@ -186,7 +186,7 @@ int oalgpu_convolution_create_ex(int device, uint32_t num_out_lines, const float
 void oalgpu_convolution_destroy(oalgpu_convolution *c)
 {
     if(!c) return;
-    (void)hipSetDevice(c->device);
+    (void)UseDevice(c->device);          // (a resident voice kernel on the device is told to leave first: it would sit out the synchronisation until its watchdog)
     (void)hipDeviceSynchronize();
     delete c;
 }

@@ -393,7 +393,7 @@ int oalgpu_effect_create(int device, int math_mode, int kind, uint32_t sample_ra
 void oalgpu_effect_destroy(oalgpu_effect *e)
 {
     if(!e) return;
-    (void)hipSetDevice(e->device);
+    (void)UseDevice(e->device);          // (a resident voice kernel on the device is told to leave first: it would sit out the synchronisation until its watchdog)
     (void)hipDeviceSynchronize();
     delete e;
 }

@@ -128,7 +128,7 @@ void oalgpu_reverb_destroy(oalgpu_reverb *r)
     if(!r) return;
     if(r->device >= 0)
     {
-        (void)hipSetDevice(r->device);
+        (void)UseDevice(r->device);       // (a resident voice kernel on the device is told to leave first)
         (void)hipDeviceSynchronize();
     }
     delete r;

@@ -97,8 +97,11 @@ __global__ void __launch_bounds__(256) VoiceEventsKernel(DeviceLayout L, uint32_
         {
             // (a voice the host has just started -- Playing, on a buffer, not Playing in the report before -- is no news to the host)
             const bool started = st == uint32_t(OALGPU_VOICE_PLAYING) && int32_t(cb) >= 0 && snap[0] != uint32_t(OALGPU_VOICE_PLAYING);
+            // (nor is a voice that was Stopped in the last report and still is: the first report's snapshot differs from every slot
+            // nobody ever initialised -- a context with more than the report's capacity of unused slots overflowed it)
+            const bool idle = st == uint32_t(OALGPU_VOICE_STOPPED) && snap[0] == uint32_t(OALGPU_VOICE_STOPPED);
             snap[0] = st; snap[1] = cb; snap[2] = qd;
-            const uint32_t idx = started ? 0xffffffffu : atomicAdd(&counters[0], 1u);
+            const uint32_t idx = (started || idle) ? 0xffffffffu : atomicAdd(&counters[0], 1u);
             if(idx < capacity)
             {
                 uint32_t *e = hostSlot + 4u + size_t{idx} * 8u;

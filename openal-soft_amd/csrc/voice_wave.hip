@@ -1620,7 +1620,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kWThreads, OALGPU_WAVE_MI
         bool done = false;
         if constexpr (std::is_same<LT, WaveArgsHrtf>::value)
         {   // the block carries its records' blended HRIRs: two voices per round of loads (InstallPair)
-            if(next.rows)
+            if(next.rows && L.irStride <= 64u)       // (InstallPair moves ONE tap pair per lane: responses of up to 64 taps)
             {
                 for(uint32_t j = 0; j < vCount; j += 2u)
                     InstallPair(L, next.map, next.recs, next.rows, vBegin + 2u * j, vBegin + 2u * j + 2u, j + 1u < vCount, lane0);

@@ -180,3 +180,22 @@ def test_voice_events_report_what_a_full_readback_would_show(synth_mhr):
     sc.mix(1024, post_process=True)
     assert sc.voice_events_wait(sc.voice_events_async()) == []
     sc.close()
+
+
+def test_the_first_voice_events_report_leaves_unused_slots_out(synth_mhr):
+    """a context created for many more voices than it plays (BatchMixer: max_voices slots, a handful of sources): the first report
+    used to list every slot nobody ever initialised -- Stopped against a snapshot seeded with another buffer index -- and with
+    more than 1024 of them oalgpu_voice_events_wait failed with OALGPU_ERR_CAPACITY."""
+    import oalgpu
+    import oracle_lib as ol
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    api._mhr = open(synth_mhr, "rb").read()
+    sc = api.make_scene(num_dry=4, num_real=2, hrtf=True, max_voices=3000, max_buffers=2)
+    rng = np.random.default_rng(6)
+    buf = sc.add_buffer(rng.uniform(-1, 1, 48000).astype(np.float32), oalgpu.FMT_FLOAT, loop_start=0, loop_end=48000)
+    for v in range(5):
+        sc.add_voice(buf, True, position=100 * v)
+        sc.set_params(v, ol.make_voice_params(60211, ol.RS_BSINC24, hrtf=(0.1, 0.3 * v, 2.0, 0.0, 0.2)))
+    sc.mix(1024, post_process=True)
+    assert sc.voice_events_wait(sc.voice_events_async()) == []       # (started by the host, playing on: no news; 2995 slots never used)
+    sc.close()

@@ -123,3 +123,42 @@ def test_parameter_block_installed_by_the_dry_line_and_send_kernels(synth_mhr, c
         assert np.array_equal(_bits(a.dry_current), _bits(b.dry_current)), v
     piped.close()
     serial.close()
+
+
+def test_parameter_block_installed_by_the_128_tap_kernel():
+    """OALGPU_CTX_APPLY_IN_VOICE_KERNEL on a data set of more than 64 taps (VoiceWaveKernel<18, 128, ...>): the epilogue's fast
+    install moves one tap pair per lane, so such responses are blended at install (ApplyRecordLean) -- with the pre-blended rows
+    only the first 64 taps of a moved voice's target were replaced.  Bit for bit the scene whose blocks go through
+    ApplyParamsKernel."""
+    import oalgpu
+    from oalgpu import synth
+    import bench
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    nv, updates = 256, 6
+    mhr = synth.synth_mhr_bytes(ir_size=128)
+
+    def build(flags):
+        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=flags)
+        api._mhr = mhr
+        sc, script = bench.build_scene(oalgpu, synth, api, 3, nv, 0, mhr, 0)
+        allv = list(range(nv))
+        moving = [v for v in allv if script.is_moving(v)]
+        sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
+        blocks = [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(updates)]
+        return sc, blocks
+
+    piped, pblocks = build(oalgpu.CTX_APPLY_IN_VOICE_KERNEL)
+    serial, sblocks = build(0)
+    assert "128" in piped.voice_kernel_name(), piped.voice_kernel_name()
+    for k in range(updates):
+        piped.apply_block(pblocks[k])
+        piped.mix(1024, post_process=True)
+        serial.apply_block(sblocks[k])
+        serial.mix_voices(1024)
+        serial.post_process(1024)
+        serial.sync()
+        a, b = piped.hrtf_accum().copy(), serial.hrtf_accum().copy()
+        assert np.array_equal(_bits(a), _bits(b)), f"HRTF accumulator differs after update {k}"
+        assert np.abs(b).max() > 1e-4
+    piped.close()
+    serial.close()

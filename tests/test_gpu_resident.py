@@ -161,6 +161,18 @@ def test_other_entry_points_park_the_resident_kernel(synth_mhr):
             if k % 3 == 2:
                 other.mix(1024, post_process=True)       # another context of the device
                 other.sync()
+            if k == 8:
+                # an object of the device created and destroyed while the launch runs: the destroy synchronises the device, so it
+                # tells the resident kernel to leave first -- it does not sit out the kernel's 2 s watchdog
+                import ctypes as C, time
+                G = oalgpu.lib
+                G.oalgpu_converter_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+                G.oalgpu_converter_destroy.argtypes = [C.c_void_p]; G.oalgpu_converter_destroy.restype = None
+                gh = C.c_void_p()
+                assert G.oalgpu_converter_create(0, 2, 6, 1, 44100, 48000, 1, C.byref(gh)) == 0, G.oalgpu_last_error()
+                t0 = time.perf_counter()
+                G.oalgpu_converter_destroy(gh)
+                assert time.perf_counter() - t0 < 1.0, "the destroy waited for the resident kernel's watchdog"
             if k % 5 == 4:
                 got.append(sc.dry().copy())
         got.append(sc.dry().copy())
