@@ -307,7 +307,6 @@ def calibrate_shards(oalgpu, synth, api, args, V, rank, world, mhr, hrtf, post, 
     moving = [v for v in allv if script.is_moving(v)]
     sc.set_params_batch(allv, param_array(oalgpu, script, allv, 0))
     blocks = [sc.param_block(moving, param_array(oalgpu, script, moving, k + 1)) for k in range(8)] if moving else []
-    join_ranks(oalgpu, sc, dist, torch, rank, world, local_rank, host_transport, "cal")
 
     def run(n):
         for k in range(n):
@@ -315,21 +314,34 @@ def calibrate_shards(oalgpu, synth, api, args, V, rank, world, mhr, hrtf, post, 
                 sc.apply_block(blocks[k % len(blocks)])
             sc.mix(UPDATE_SAMPLES, post_process=post)
         sc.sync()
+    tdev = "cpu" if host_transport else f"cuda:{local_rank}"
+
+    def gathered(us):
+        tt = torch.zeros(world, dtype=torch.float64, device=tdev)
+        tt[rank] = us
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        return [float(x) for x in tt.cpu()]
+    # the SAME scene on this rank alone, before the communicator is joined: what one GPU does with the workload every rank of the
+    # job gets -- the figure a scaling efficiency divides by (the N = 1 line of this bench is the same config; this is the same
+    # scene on the same machine in the same process)
     run(30)
     dist.barrier()
     t0 = time.perf_counter()
     run(60)
-    own_us = (time.perf_counter() - t0) / 60 * 1e6
-    tdev = "cpu" if host_transport else f"cuda:{local_rank}"
-    tt = torch.zeros(world, dtype=torch.float64, device=tdev)
-    tt[rank] = own_us
-    dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-    per_rank = [float(x) for x in tt.cpu()]
+    solo = gathered((time.perf_counter() - t0) / 60 * 1e6)
+    join_ranks(oalgpu, sc, dist, torch, rank, world, local_rank, host_transport, "cal")
+    run(30)
+    dist.barrier()
+    t0 = time.perf_counter()
+    run(60)
+    per_rank = gathered((time.perf_counter() - t0) / 60 * 1e6)
     others = sum(per_rank[1:]) / max(world - 1, 1)
     sc.close()
     dist.barrier()
     return {"rank_us_per_update": per_rank, "rank0_extra_us": max(0.0, per_rank[0] - others), "us_per_voice": others / V,
-            "note": "60 updates of an equal-share scene through the library's sharded path on this machine, every rank's own clock"}
+            "solo_us_per_update": solo, "solo_voices": V,
+            "note": "60 updates of an equal-share scene on this machine, every rank's own clock: first on every rank alone (solo_*: no "
+                    "communicator, the rank's own post-process), then through the library's sharded path"}
 
 
 def main():
@@ -338,8 +350,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5),
-                    help="BASELINE config (default: 3 = configs[2], the headline, on one GPU; 5 = configs[4], HRTF voices + the "
-                         "65536-tap convolution slot sharded over the GPUs, for --gpus N > 1)")
+                    help="BASELINE config (default: 3 = configs[2], the headline -- at every N, 4096 voices per GPU; 5 = configs[4], HRTF "
+                         "voices + the 65536-tap convolution slot on rank 0, sharded over the GPUs)")
     ap.add_argument("--transport", default="rccl", choices=("rccl", "host"),
                     help="N > 1: how the ranks' bus blocks reach rank 0 -- the library's ncclReduce over xGMI, or its host-staged "
                          "transport (several processes on ONE GPU: a rehearsal of the N > 1 code path, not a scaling measurement)")
@@ -388,7 +400,10 @@ def main():
     import torch
     dist = None
     if args.config is None:
-        args.config = 3 if world == 1 else 5
+        # the SAME workload at every N (BASELINE configs[2], the one the metric is quoted on, 4096 voices per GPU: weak scaling) -- a
+        # 1 -> 8 curve built from lines of different configs would show the configs' difference, not the scaling; configs[4]
+        # (HRTF voices + the 65536-tap convolution slot on rank 0) is --config 5
+        args.config = 3
     host_transport = world > 1 and args.transport == "host"
     if host_transport:
         local_rank = 0                       # every rank on the one GPU
@@ -756,7 +771,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "hbm_roofline_frac": hbm_achieved / HBM_PEAK_GBS,     # the second half of the metric string
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {nvoices_total // world} mono f32 voices per GPU "
+            "config": {"workload": (f"{world} ranks, each: " if world > 1 else "") + f"BASELINE configs[{args.config - 1}]: {nvoices_total // world} mono f32 voices per GPU "
                                    f"(44.1k->48k, bsinc24"
                                    + ((", HRTF Default HRTF.mhr (irSize 64), " if use_real else
                                        ", HRTF synthetic .mhr with Default-HRTF geometry irSize 64, ")
@@ -773,7 +788,17 @@ def main():
                        "transport": (args.transport if world > 1 else None),
                        "rccl_ranks": (comm_seen[2] if comm_seen and comm_seen[3] == "rccl" else None),
                        "comm": ({"rank": comm_seen[0], "world": comm_seen[1], "transport_ranks": comm_seen[2], "kind": comm_seen[3]} if comm_seen else None),
-                       "calibration": calibration, "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
+                       "calibration": calibration,
+                       # N > 1: rank 0's own rate on the equal-share scene of THIS config before the communicator was joined, and the job's
+                       # rate over N times that (what the driver's curve divides by is the N = 1 line; this is the same figure measured
+                       # in this very run)
+                       "single_gpu_same_workload": ({"voices_per_s": calibration["solo_voices"] / (calibration["solo_us_per_update"][0] * 1e-6),
+                                                     "ms_per_step": calibration["solo_us_per_update"][0] * 1e-3, "voices": calibration["solo_voices"],
+                                                     "config": args.config} if calibration and "solo_us_per_update" in calibration else None),
+                       "scaling_efficiency": ((nvoices_total * args.steps / elapsed)
+                                              / (world * calibration["solo_voices"] / (calibration["solo_us_per_update"][0] * 1e-6))
+                                              if calibration and "solo_us_per_update" in calibration else None),
+                       "realtime_voices": nvoices_total * args.steps / elapsed / 46.875,
                        "e2e_ms_per_update": e2e_ms, "e2e_ms_per_update_p90": e2e_p90_ms if e2e_ms is not None else None,
                        "e2e_throughput": e2e_tput,
                        "e2e_note": "one update alone through the C-ABI from host memory: oalgpu_voice_set_params of the "
