@@ -44,6 +44,7 @@
 #include <cstring>
 #include <chrono>
 #include <map>
+#include <unordered_map>
 #include <unordered_set>
 #include <span>
 #include <string>
@@ -136,12 +137,26 @@ public:
                 auto const st = v->mPlayState.load(std::memory_order_acquire);
                 if(st != Voice::Stopped && st != Voice::Pending) ++mExpected;
             }
-            mBatch.clear(); mBatchIndex.clear();
+            mBatch.clear(); mBatchIndex.clear(); mBatchNamed.clear(); mBatchDirs.clear();
+            mOrderedAt = 0; mDirAt = 0;
             mCursor = 0;
         }
         /* the voice loop walks the context's voices in order (alu.cpp:2201-2206): so does the cursor, and a voice's place in
          * that array is where its entry lives (voices are pooled; the array only grows, core/context.h:159-160) */
-        while(mCursor < voices.size() && voices[mCursor] != voice) ++mCursor;
+        /* (the voices CalcVoiceParams named through its hook come in that order too, alu.cpp:2177-2206: the list is consumed in step
+         * with the cursor -- one pointer comparison per voice of the array instead of a hash lookup per mixed voice) */
+        bool named = false;
+        size_t dirFrom = mDirAt;
+        while(mCursor < voices.size())
+        {
+            const bool hit = mOrderedAt < mOrdered.size() && mOrdered[mOrderedAt] == voices[mCursor];
+            if(hit) ++mOrderedAt;
+            dirFrom = mDirAt;
+            while(mDirAt < mDirList.size() && mDirList[mDirAt].voice == voices[mCursor]) ++mDirAt;
+            if(voices[mCursor] == voice) { named = hit; break; }
+            ++mCursor;
+        }
+        const uint32_t dirCount = uint32_t(mDirAt - dirFrom);
         if(mCursor == voices.size()) { mSeen = 0; failText(OALGPU_ERR_INVALID, "oalgpu_openal: a voice outside the context's voice array"); return false; }
         /* pipelined, with the parameter hook: a voice that just plays on -- known to the device context, no change of state, of
          * parameters or of its queue -- needs no word; only the others are walked when the batch is complete */
@@ -152,20 +167,33 @@ public:
             const Entry &e = mEntries[place];
             quiet = e.live && !e.queue && vstate == Voice::Playing && e.lastState == int(Voice::Playing)
                 && e.sourceId == voice->mSourceID.load(std::memory_order_relaxed) && !(voice->mStartTime > deviceTime)
-                && voice->mStep >= 1u && (mChanged.empty() || !mChanged.count(voice));
+                && voice->mStep >= 1u && !named && dirCount == 0u && (mChanged.empty() || !mChanged.count(voice));
         }
         if(!quiet)
         {
             mBatch.emplace_back(voice, vstate);
             mBatchIndex.push_back(uint32_t(place));
+            mBatchNamed.push_back(named ? 1 : 0);
+            mBatchDirs.emplace_back(uint32_t(dirFrom), dirCount);
         }
         if(++mSeen != mExpected) return false;
         mSeen = 0;
+        /* (names that were not met on the way -- the order of the two loops is the reference's, not this file's, to keep: then every
+         * voice is compared this once) */
+        while(mOrderedAt < mOrdered.size() && mCursor < voices.size())
+        {
+            if(mOrdered[mOrderedAt] == voices[mCursor]) ++mOrderedAt;
+            ++mCursor;
+        }
+        mCompareAll = mOrderedAt != mOrdered.size();
         const int rc = flush(context, dev, deviceTime, samplesToDo);
         mChanged.clear();
+        mOrdered.clear(); mOrderedAt = 0; mCompareAll = false;
+        mDirList.clear(); mDirAt = 0;
         if(rc != 0)
         {
             mResync = true;                 /* the caller mixes this update on the CPU: what the device context holds is stale then */
+            if(mHookDirs && dev.mHrtf) restoreTargets(*dev.mHrtf);     /* ... and its Voice::mix reads the targets the hook skipped */
             if(mDepth) leavePipelined(context, dev);   /* ... and the CPU loop needs the device's own post-process back */
         }
         return rc == 0;
@@ -223,6 +251,44 @@ public:
      * Without the hook (trackChanges(false), the default) every voice is compared. */
     void trackChanges(bool on) { mTrack = on; }
     void noteParamsChanged(const Voice *voice) { mChanged.insert(voice); }
+    /* the same from inside CalcVoiceParams (oalgpu_hook::ParamsChanged): the calls come in the order of the context's voice array,
+     * as the voice loop's do, so a list does */
+    void noteParamsChangedInOrder(const Voice *voice) { mOrdered.push_back(voice); }
+    /* The third: CalcPanningAndFilters' three HrtfStore::getCoeffs call sites (alc/alu.cpp:1214-1216, :1256-1258, :1296-1298),
+     * include/oalgpu_openal_hooks.h.  With hookDirections(true) on an HRTF device the call hands over the DIRECTION -- elevation,
+     * azimuth, distance, spread: 16 bytes -- and returns true: the reference neither indexes nor blends the four responses, the
+     * voice's Hrtf.Target.Coeffs / .Delay stay as they are, and flush() passes the directions on as oalgpu_voice_move records
+     * (the device context evaluates both halves of getCoeffs itself, bit for bit: SURVEY.md 8 f1) instead of 1 KB of blended
+     * HrirArray per moved voice.  Returns false -- the caller runs the reference's getCoeffs -- when the mode is off or the voice
+     * is none of this mixer's business.  An update that goes to the CPU loop first brings the skipped targets up to date
+     * (restoreTargets). */
+    void hookDirections(bool on) { mHookDirs = on; }
+    bool noteHrtfDirection(const Voice *voice, size_t chan, float ev, float az, float dist, float spread)
+    {
+        if(!mHookDirs || !mHrtfKnown || !mHrtf || chan > 255u) return false;
+        /* (in the order of the context's voice array, like noteParamsChangedInOrder's names: the seam picks them up in step) */
+        mDirList.push_back(DirNote{voice, {ev, az, dist, spread}, uint8_t(chan)});
+        return true;
+    }
+    /* the reference's own getCoeffs for every target the hook has skipped: before its Voice::mix reads them (an update on the
+     * CPU loop) -- store: DeviceBase::mHrtf */
+    void restoreTargets(const HrtfStore &store)
+    {
+        auto restore = [&store](const Voice *v, size_t c, const std::array<float, 4> &d)
+        {
+            auto *voice = const_cast<Voice*>(v);
+            if(c >= voice->mChans.size()) return;
+            store.getCoeffs(d[0], d[1], d[2], d[3], voice->mChans[c].mDryParams.Hrtf.Target.Coeffs, voice->mChans[c].mDryParams.Hrtf.Target.Delay);
+        };
+        for(Entry &e : mEntries)
+        {
+            if(!e.live || !e.voice) continue;
+            for(size_t c{0}; c < e.chans.size(); ++c)
+                if(e.chans[c].dirStale) { restore(e.voice, c, e.chans[c].dir); e.chans[c].dirStale = false; }
+        }
+        for(auto const &n : mDirList) restore(n.voice, n.chan, n.dir);     /* (this update's, not yet filed) */
+        mDirList.clear();
+    }
     /* alDeleteBuffers / alBufferData on a buffer the mixer has seen (the storage is freed and the item reused,
      * core/buffer_storage.h:47-77, core/voice.h:84-98): its HBM copy is given up; without the hook a changed item is noticed
      * the next time a voice starts on it (the key below) */
@@ -249,9 +315,12 @@ private:
         oalgpu_voice_params params{};
         bool haveTarget{false};
         HrtfFilter target{};                        /* the Hrtf.Target the device context was last given */
+        std::array<float, 4> dir{};                 /* hookDirections: the direction the device context was last given INSTEAD ... */
+        bool dirStale{false};                       /* ... and the Voice's own Hrtf.Target does not hold its response */
     };
     struct Entry {
         bool live{false};
+        const Voice *voice{nullptr};                /* whose entry (the Voice object at this place of the context's array) */
         int lastState{int(Voice::Playing)};
         unsigned sourceId{0};
         std::vector<Chan> chans;                    /* one device voice per mixed channel (Voice::mix's ChannelData loop) */
@@ -277,6 +346,7 @@ private:
         auto const auxspan = std::span{*context->mActiveAuxSlots.load(std::memory_order_acquire)};
         auto const auxslots = auxspan.first(auxspan.size() >> 1);
         mHrtf = dev.mRenderMode == RenderMode::Hrtf;
+        mHrtfKnown = true;
         oalgpu_context_desc d{};
         d.device = mDevice; d.math_mode = mMathMode; d.sample_rate = dev.mSampleRate;
         d.num_dry_channels = uint32_t(dev.Dry.Buffer.size());
@@ -488,6 +558,7 @@ private:
         ++mUpdateNo;
         auto const tWalk = std::chrono::steady_clock::now();
         std::vector<uint32_t> ids, tgtIds, tgtDelays;
+        std::vector<oalgpu_voice_move> moves;         /* hookDirections: directions instead of blended responses */
         std::vector<oalgpu_voice_params> params;
         std::vector<float> tgtCoeffs, tgtGains;
         mMixed.clear();
@@ -532,7 +603,7 @@ private:
                 BufferEntry *be = bufferEntry(voice, item);
                 if(!be) return mError;
                 if(mFreeIndex.size() < nch) return failText(OALGPU_ERR_CAPACITY, "oalgpu_openal: more playing voices than max_voices");
-                e.live = true; e.sourceId = sourceId; e.lastState = int(Voice::Playing);
+                e.live = true; e.voice = voice; e.sourceId = sourceId; e.lastState = int(Voice::Playing);
                 e.queue = !voice->mFlags.test(VoiceFlag::IsStatic);
                 auto *loop = voice->mLoopBuffer.load(std::memory_order_relaxed);
                 if(e.queue)
@@ -578,7 +649,7 @@ private:
                     if(int rc = oalgpu_voice_set_start_delay(mGpu, ch.index, outPos)) return fail(rc, "oalgpu_voice_set_start_delay");
             /* what CalcVoiceParams left in the Voice (alu.cpp:1512-1710, :2012-2031); with the maintainer's hook only for the
              * voices it ran for */
-            if(mTrack && !started && !mChanged.count(voice)) continue;
+            if(mTrack && !started && !mCompareAll && !mBatchNamed[bi] && !mChanged.count(voice)) continue;
             const float inv_rate = 1.0f / float(dev.mSampleRate);
             for(size_t c{0}; c < nch; ++c)
             {
@@ -592,6 +663,12 @@ private:
                 p.direct_filter.lf_norm = voice->mProps.Direct.LFReference * inv_rate;
                 p.direct_filter.gain_hf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.LowPass, -1.0f) : 1.0f;
                 p.direct_filter.gain_lf = voice->mDirect.FilterActive ? ShelfGainAt(chan.mDryParams.HighPass, 1.0f) : 1.0f;
+                /* an HRTF device without sends: that is all of it -- seven words against the ones sent last time, not the whole
+                 * record (a moved source's direction is the move record's below) */
+                const bool lean = mHrtf && dev.NumAuxSends == 0u;
+                if(lean && ch.haveParams && ch.params.step == p.step && ch.params.resampler == p.resampler
+                    && std::memcmp(&ch.params.direct_filter, &p.direct_filter, sizeof(p.direct_filter)) == 0)
+                    goto params_unchanged;
                 if(mHrtf) p.hrtf_dist = OALGPU_HRTF_KEEP_TARGET;       /* Hrtf.Target itself is handed over below */
                 else for(size_t l{0}; l < dev.Dry.Buffer.size(); ++l) p.dry_gains[l] = chan.mDryParams.Gains.Target[l];
                 for(unsigned s{0}; s < unsigned(OALGPU_MAX_SENDS); ++s)
@@ -618,7 +695,21 @@ private:
                     ids.push_back(ch.index);
                     params.push_back(p);
                 }
-                if(mHrtf)
+                params_unchanged:
+                const DirNote *note = nullptr;
+                for(uint32_t k{0}; k < mBatchDirs[bi].second; ++k)
+                    if(mDirList[mBatchDirs[bi].first + k].chan == c) note = &mDirList[mBatchDirs[bi].first + k];
+                if(note)
+                {   /* the getCoeffs hook took this channel's direction: 24 bytes go over, the device context blends */
+                    ch.dir = note->dir; ch.dirStale = true;
+                    moves.push_back(oalgpu_voice_move{ch.index, ch.dir[0], ch.dir[1], ch.dir[2], ch.dir[3], chan.mDryParams.Hrtf.Target.Gain});
+                    ch.haveTarget = false;              /* (what the Voice holds is not what the device context has) */
+                }
+                else if(mHrtf && ch.dirStale)
+                {   /* (parameters recomputed without a new direction do not exist -- CalcPanningAndFilters always asks for the
+                     * response -- but a comparison of every voice does come here: the device context has the right target) */
+                }
+                else if(mHrtf)
                 {
                     auto const &tg = chan.mDryParams.Hrtf.Target;
                     if(!ch.haveTarget || tg.Gain != ch.target.Gain || tg.Delay[0] != ch.target.Delay[0] || tg.Delay[1] != ch.target.Delay[1]
@@ -639,6 +730,8 @@ private:
         if(!tgtIds.empty())
             if(int rc = oalgpu_voice_set_hrtf_targets(mGpu, tgtIds.data(), tgtCoeffs.data(), tgtDelays.data(), tgtGains.data(), tgtIds.size()))
                 return fail(rc, "oalgpu_voice_set_hrtf_targets");
+        if(!moves.empty())
+            if(int rc = oalgpu_voice_move_async(mGpu, moves.data(), moves.size())) return fail(rc, "oalgpu_voice_move_async");
 
         /* (pipelined mode: the update is submitted with its post-process and nothing is read back here, see submitPipelined) */
         if(mDepth) return submitPipelined(context, dev, samplesToDo);
@@ -864,7 +957,18 @@ private:
     std::vector<uint32_t> mBatchIndex;
     std::vector<std::pair<Voice*, Entry*>> mMixed;
     bool mTrack{false}, mResync{false};
+    /* hookDirections: per voice, the directions the getCoeffs hook handed over (pending: not yet passed on to the device context;
+     * stale: the Voice's own Hrtf.Target does not hold them) */
+    struct DirNote { const Voice *voice; std::array<float, 4> dir; uint8_t chan; };
+    std::vector<DirNote> mDirList;                  /* this update's directions, in the order of the voice array */
+    size_t mDirAt{0};
+    std::vector<std::pair<uint32_t, uint32_t>> mBatchDirs;   /* [batch entry] its notes in mDirList: first, count */
+    bool mHookDirs{false}, mHrtfKnown{false};
     std::unordered_set<const Voice*> mChanged;
+    std::vector<const Voice*> mOrdered;             /* noteParamsChangedInOrder: this update's names, in voice-array order */
+    size_t mOrderedAt{0};
+    bool mCompareAll{false};
+    std::vector<uint8_t> mBatchNamed;               /* [batch entry] the voice was named through mOrdered */
     std::vector<float> mLines;
     std::vector<oalgpu_voice_brief> mBrief;
     int mError{0};

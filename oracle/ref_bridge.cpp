@@ -81,6 +81,7 @@
 
 #include "../include/oalgpu.h"
 #include "../include/oalgpu_openal.hpp"    /* THE PRODUCT'S host adapter: this file only drives it */
+#include "../include/oalgpu_openal_hooks.h" /* ... and defines its two hooks, which _ref/alu_hooked.cpp (alc/alu.cpp + four lines) calls */
 
 extern "C" {
 void oalbridge_voice_mix_cpu(void *voice, int vstate, void *context, long long device_ns, unsigned samples_to_do);
@@ -124,6 +125,9 @@ struct oalbridge {
     int error{0};
     std::string errorText;
     bool trackChanges{false};               /* the batch mixer is told which voices CalcSourceParams recomputes (its optional hook) */
+    bool hookAlu{false};                    /* ... by alc/alu.cpp itself (oalgpu_hook::ParamsChanged), and CalcPanningAndFilters hands over
+                                             * directions instead of blended responses (oalgpu_hook::GetCoeffs) */
+    unsigned long long hookedDirs{0};       /* directions the getCoeffs hook has taken so far */
     /* test aid for the output stage (ApplyDither / Write<T>, alu.cpp:2309-2408, are file-local): lines added
      * to DeviceBase::RealOut by the voice loop's first voice, so that the reference's own output stage
      * converts a known signal */
@@ -135,6 +139,31 @@ namespace {
 oalbridge *gActive = nullptr;               /* the bridge whose renderSamples is running (one mixer thread) */
 
 } // namespace
+
+/* ---- the binding's hooks inside alc/alu.cpp (include/oalgpu_openal_hooks.h; the library is built with oracle/_ref/
+ * alu_hooked.cpp = alc/alu.cpp with the four lines of INTEGRATION.md 3a, generated by oracle/Makefile) ---------------- */
+namespace oalgpu_hook {
+void ParamsChanged(Voice *voice) noexcept
+{
+    oalbridge *b = gActive;
+    if(b && b->mode == ModeBatch && b->hookAlu) b->batch->noteParamsChangedInOrder(voice);
+}
+void GetCoeffs(const HrtfStore &store, Voice *voice, float elevation, float azimuth, float distance, float spread, HrirSpan coeffs,
+    std::span<unsigned, 2> delays) noexcept
+{
+    oalbridge *b = gActive;
+    if(b && b->mode == ModeBatch && b->hookAlu)
+    {   /* which of the voice's channels: the one whose target the call site passed */
+        for(size_t c{0}; c < voice->mChans.size(); ++c)
+            if(voice->mChans[c].mDryParams.Hrtf.Target.Coeffs.data() == coeffs.data())
+            {
+                if(b->batch->noteHrtfDirection(voice, c, elevation, azimuth, distance, spread)) { ++b->hookedDirs; return; }
+                break;
+            }
+    }
+    store.getCoeffs(elevation, azimuth, distance, spread, coeffs, delays);
+}
+} // namespace oalgpu_hook
 
 /* ---- THE SEAM: the symbol ProcessContexts calls for every playing voice (alc/alu.cpp:2201-2206) ---------------- */
 void Voice::mix(State const vstate, ContextBase *const context, std::chrono::nanoseconds const deviceTime,
@@ -607,6 +636,18 @@ int oalbridge_track_changes(oalbridge *b, int on)
     b->batch->trackChanges(on != 0);
     return 0;
 }
+
+/* the hooks INSIDE alc/alu.cpp (include/oalgpu_openal_hooks.h): CalcVoiceParams names the voices it recomputes, and on an HRTF
+ * device CalcPanningAndFilters' getCoeffs call sites hand the batch mixer the direction (the device context evaluates getCoeffs)
+ * -- nothing on the application's side of the bridge tells the mixer anything */
+int oalbridge_hook_alu(oalbridge *b, int on)
+{
+    b->hookAlu = on != 0;
+    b->batch->trackChanges(on != 0);
+    b->batch->hookDirections(on != 0);
+    return 0;
+}
+unsigned long long oalbridge_hooked_directions(oalbridge *b) { return b->hookedDirs; }
 
 /* the batch mixer's pipelined mode (include/oalgpu_openal.hpp: the post-process behind the boundary too, an update's output
  * `depth` updates late), before the first update; oalbridge_drain collects what is outstanding: `depth` updates' output,

@@ -170,6 +170,18 @@ class Bridge:
     def track_changes(self, on=True):
         lib().oalbridge_track_changes(self.h, 1 if on else 0)
 
+    def hook_alu(self, on=True):
+        """the binding's hooks INSIDE alc/alu.cpp (include/oalgpu_openal_hooks.h; the bridge library is built with
+        oracle/_ref/alu_hooked.cpp): CalcVoiceParams names the voices it recomputes and CalcPanningAndFilters hands the batch mixer
+        directions instead of blended responses (the device context evaluates HrtfStore::getCoeffs)"""
+        lib().oalbridge_hook_alu.argtypes = [C.c_void_p, C.c_int]
+        lib().oalbridge_hook_alu(self.h, 1 if on else 0)
+
+    def hooked_directions(self):
+        lib().oalbridge_hooked_directions.argtypes = [C.c_void_p]
+        lib().oalbridge_hooked_directions.restype = C.c_ulonglong
+        return int(lib().oalbridge_hooked_directions(self.h))
+
     def add_buffer(self, data, loop_start=0, loop_end=None):
         data = np.ascontiguousarray(data, np.float32)
         return lib().oalbridge_add_buffer(self.h, data.ctypes.data_as(f32p), data.size, loop_start,

@@ -303,7 +303,7 @@ def test_hrtf_batched_update_at_the_headline_size():
 
 
 # ---- the pipelined mode of the batch mixer (include/oalgpu_openal.hpp) --------------------------------------
-def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=False, restart=False):
+def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=False, restart=False, hook=False):
     """The HRTF device without auxiliary sends: config-3-shaped sources, every 4th moving, one in sixteen running out of buffer in
     the third update, a ninth told to stop in the second.  pipelined: the batch mixer's pipelined mode with that depth; the
     outstanding updates are drained at the end.  -> ([updates (+ depth)][1024][2], play states)"""
@@ -312,6 +312,8 @@ def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=Fa
         b.set_pipelined(pipelined)
     if track:
         b.track_changes(True)
+    if hook:
+        b.hook_alu(True)            # the hooks inside alc/alu.cpp: directions instead of blended responses, changed voices named by CalcVoiceParams
     srcs = bl.build_config3(b, nsources, slot=-1)
     out = []
     for k in range(updates):
@@ -331,8 +333,51 @@ def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=Fa
         out.extend(b.drain(1024))
     states = [b.source_state(v)[0] for v in srcs]
     live = b.batch_live_voices() if mode == bl.MODE_BATCH else 0
+    if hook:
+        # every recomputed voice behind the first update went through the hook: a quarter of the sources per update
+        assert b.hooked_directions() >= (updates - 2) * (nsources // 4), b.hooked_directions()
     b.close()
     return np.stack(out), states, live
+
+
+@pytest.mark.gpu
+@needs_bridge
+@pytest.mark.parametrize("nsources,restart", [(256, True), (4096, False)])
+def test_the_getcoeffs_hook_hands_over_directions_instead_of_responses(nsources, restart):
+    """SURVEY.md 8 f1 behind the shipped binding (include/oalgpu_openal_hooks.h): the bridge library is built with alc/alu.cpp plus
+    the binding's four lines (oracle/_ref/alu_hooked.cpp) -- CalcPanningAndFilters hands the batch mixer the DIRECTION of every
+    voice it recomputes and never blends a response, the device context evaluates HrtfStore::getCoeffs from 24-byte move records
+    -- against the reference's own render (its getCoeffs, its Voice::mix, its MixDirectHrtf) of the same scene: a quarter of the
+    sources moving in every update, two updates late, integer state exact."""
+    import oalgpu
+    assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
+    U, D = 11, 2
+    want, sw, _ = render_hrtf_direct(bl.MODE_CPU, nsources, U, restart=restart)
+    got, sg, live = render_hrtf_direct(bl.MODE_BATCH, nsources, U, pipelined=D, hook=True, restart=restart)
+    assert got.shape[0] == U + D and not got[:D].any()
+    scale = float(np.abs(want).max())
+    assert scale > 0.02
+    tol = (4e-5 if nsources > 1000 else 2e-5) * scale + 1e-7
+    for u in range(U):
+        err = float(np.abs(got[u + D].astype(np.float64) - want[u]).max())
+        assert err <= tol, (u, err, tol)
+    assert sg == sw, [(i, a, b) for i, (a, b) in enumerate(zip(sg, sw)) if a != b][:6]
+    assert live == sum(1 for s in sw if s == 1)
+
+
+@pytest.mark.gpu
+@needs_bridge
+def test_the_getcoeffs_hook_in_the_synchronous_form():
+    """the same hook without the pipelined mode (every update's buses read back): 256 sources, six updates"""
+    import oalgpu
+    U = 6
+    want, sw, _ = render_hrtf_direct(bl.MODE_CPU, 256, U)
+    got, sg, live = render_hrtf_direct(bl.MODE_BATCH, 256, U, hook=True)
+    scale = float(np.abs(want).max())
+    for u in range(U):
+        err = float(np.abs(got[u].astype(np.float64) - want[u]).max())
+        assert err <= 2e-5 * scale + 1e-7, (u, err)
+    assert sg == sw
 
 
 @pytest.mark.gpu

@@ -29,14 +29,17 @@ def main():
     print(f"{N} HRTF sources behind the reference's renderSamples, 1024-sample updates, one host thread")
     print(f"{'':34s}{'us / update':>12s}{'voices/s':>12s}{'of which outside render: moves':>34s}")
     for scene in ("moving", "static"):
-        for name, mode, track, depth in (("reference Voice::mix (CPU)", bl.MODE_CPU, False, 0), ("batch mixer, every voice compared", bl.MODE_BATCH, False, 0),
-                                         ("batch mixer + parameter hook", bl.MODE_BATCH, True, 0),
-                                         ("batch mixer pipelined (post-process on the GPU, output 2 updates late) + hook", bl.MODE_BATCH, True, 2)):
+        for name, mode, track, depth, hook in (("reference Voice::mix (CPU)", bl.MODE_CPU, False, 0, False), ("batch mixer, every voice compared", bl.MODE_BATCH, False, 0, False),
+                                         ("batch mixer + parameter hook", bl.MODE_BATCH, True, 0, False),
+                                         ("batch mixer pipelined (post-process on the GPU, output 2 updates late) + hook", bl.MODE_BATCH, True, 2, False),
+                                         ("batch mixer pipelined + the hooks inside alc/alu.cpp (directions, not responses)", bl.MODE_BATCH, False, 2, True)):
             b = bl.Bridge(mode, oalgpu.MATH_FAST, hrtf=True, num_sends=0)
             if depth:
                 b.set_pipelined(depth)
             if track:
                 b.track_changes(True)
+            if hook:
+                b.hook_alu(True)
             srcs = bl.build_config3(b, N, slot=-1)
             for k in range(12):                                 # voices started, the sources that run out of buffer gone, clocks up
                 b.render(1024)
