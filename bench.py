@@ -217,7 +217,8 @@ def mfma_block(kernel, voices, kernel_ms, moving):
     K-chunks x 3 split-half products of v_mfma_f32_16x16x32_f16 (16 x 16 x 32 x 2 flop each), one more tile for a voice
     whose filter was replaced; against the dense f16 peak (MI355X_MICROARCH.md: 2.5 PFLOP/s)."""
     targs = [a.strip() for a in kernel[kernel.find("<") + 1:kernel.rfind(">")].split(",")] if "<" in kernel else []
-    if "VoiceWaveKernel<17, 64, 0" not in kernel or len(targs) < 5 or targs[4] != "true":     # (the fifth argument: MF)
+    wave_mf = "VoiceWaveKernel<17, 64, 0" in kernel and len(targs) >= 5 and targs[4] == "true"     # (the fifth argument: MF)
+    if not (wave_mf or kernel.startswith("VoiceWave16Kernel")):         # (voice_wave16.hip: the same tiles, a voice per wavefront)
         return None
     per = 16 * 16 * 32 * 2
     n = voices * 90 + moving * 18
@@ -735,7 +736,7 @@ def main():
                             "per call of VoiceWaveKernel<..., true> for such blocks"}
     # the same clock around an EMPTY kernel: what the dispatch-bound events include besides a kernel's own run time
     # (rocprofv3's kernel trace reports the voice kernel about this much shorter, profiles/README.md)
-    event_floor_ms = oalmeasure.event_floor_ms(sc, 200) if sc.voice_kernel_name().startswith("VoiceWaveKernel") else None
+    event_floor_ms = oalmeasure.event_floor_ms(sc, 200) if sc.voice_kernel_name().startswith(("VoiceWaveKernel", "VoiceWave16Kernel", "VoiceRowsKernel")) else None
 
     if rank == 0:
         nvoices_total = sum(shard_sizes)

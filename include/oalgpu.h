@@ -184,10 +184,11 @@ typedef struct oalgpu_context_desc {
                                    * instead of the matrix pipe in split half precision */
 #define OALGPU_CTX_PROFILE  2u    /* the voice kernel's measurement variant: per-phase cycle stamps and stage ablation,
                                    * read and set through the measurement build only (tools/measure/oalgpu_measure.h) */
-#define OALGPU_CTX_STREAM_ROWS 8u  /* FAST contexts that would keep their lines in the wavefronts' registers (dry-line contexts without sends
-                                   * and <= 6 lines; HRTF contexts with one first-order send): leave stream rows in HBM and mix them in the
-                                   * voice kernel's tail (the path of contexts with more lines) instead of accumulating the
-                                   * lines in the wavefronts' registers: for A/B runs and tests of the row path */
+#define OALGPU_CTX_STREAM_ROWS 8u  /* FAST contexts leave a 4 KB stream row per mixed signal in HBM and mix the rows in the voice kernel's tail
+                                   * (csrc/voice_wave.hip; the only form of contexts with near-field control and sends) instead of their default
+                                   * form -- the lines in the wavefronts' registers (dry-line contexts without sends and <= 6 lines; HRTF contexts
+                                   * with one first-order send) or the rows in LDS (dry-line contexts with sends or 7 .. 32 lines,
+                                   * csrc/voice_rows.hip): for A/B runs and tests of the row path */
 #define OALGPU_CTX_APPLY_IN_VOICE_KERNEL 16u /* pipelined HRTF contexts: oalgpu_mix_update is submitted with the NEXT library call on the
                                    * context, and when that call is oalgpu_param_block_apply the update's own voice kernel installs the
                                    * block (every wavefront the records of the voices it mixed) instead of a parameter kernel between
@@ -221,6 +222,12 @@ typedef struct oalgpu_context_desc {
                                    * inputs at a time (csrc/voice_wave16.hip).  This flag selects the form of rounds 1-5 instead:
                                    * two voices per wavefront, two wavefronts per SIMD (csrc/voice_wave.hip) -- for A/B runs; OALGPU_CTX_RESIDENT,
                                    * which exists for that form only, implies it.  Other contexts ignore the flag. */
+#define OALGPU_CTX_ROW_SLICES 512u /* (the DEFAULT form of these contexts since round 6; the flag is accepted and names it.)  FAST dry-line contexts
+                                   * with sends (or 7 .. 32 mix lines; no near-field control): a voice's signals never leave the compute unit AND
+                                   * its fixed work is done once -- a wavefront per voice resamples into a 4 KB slot of LDS, the round's filtered
+                                   * signals are jobs dealt to all eight wavefronts of the workgroup, and each wavefront adds its own 128-frame
+                                   * slice of every row to 32 line accumulators it keeps in registers for the whole launch
+                                   * (csrc/voice_rows.hip).  OALGPU_CTX_STREAM_ROWS selects the rows-in-HBM form instead. */
 #define OALGPU_CTX_SERIAL   4u    /* oalgpu_mix_update on one stream (no overlap of an update's reduction and
                                    * post-process with the next update's voices): a measurement aid */
 

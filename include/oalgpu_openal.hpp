@@ -255,7 +255,7 @@ public:
      * as the voice loop's do, so a list does */
     void noteParamsChangedInOrder(const Voice *voice) { mOrdered.push_back(voice); }
     /* The third: CalcPanningAndFilters' three HrtfStore::getCoeffs call sites (alc/alu.cpp:1214-1216, :1256-1258, :1296-1298),
-     * include/oalgpu_openal_hooks.h.  With hookDirections(true) on an HRTF device the call hands over the DIRECTION -- elevation,
+     * include/oalgpu_openal_hooks.hpp.  With hookDirections(true) on an HRTF device the call hands over the DIRECTION -- elevation,
      * azimuth, distance, spread: 16 bytes -- and returns true: the reference neither indexes nor blends the four responses, the
      * voice's Hrtf.Target.Coeffs / .Delay stay as they are, and flush() passes the directions on as oalgpu_voice_move records
      * (the device context evaluates both halves of getCoeffs itself, bit for bit: SURVEY.md 8 f1) instead of 1 KB of blended

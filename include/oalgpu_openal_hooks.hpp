@@ -1,4 +1,4 @@
-/* include/oalgpu_openal_hooks.h -- the two optional hooks of the reference-side binding (include/oalgpu_openal.hpp), as
+/* include/oalgpu_openal_hooks.hpp -- the two optional hooks of the reference-side binding (include/oalgpu_openal.hpp), as
  * alc/alu.cpp sees them: two free functions the maintainer's build defines next to its BatchMixer (oracle/ref_bridge.cpp is that
  * build here; INTEGRATION.md section 3a shows the four-line diff of alc/alu.cpp).
  *

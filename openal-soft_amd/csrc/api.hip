@@ -1104,6 +1104,8 @@ int oalgpu_biquad_dual_process(int device, oalgpu_biquad *f0, oalgpu_biquad *f1,
 // ---------------------------------------------------------------- context
 static int AllocStreamRows(oalgpu_context *c);
 
+static void SetRowsGroups(oalgpu_context *c);      // (voice_rows.hip's grid; defined beside RebalanceWaveGroups)
+
 int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
 {
     if(!desc || !out) return Fail(OALGPU_ERR_INVALID, "null argument");
@@ -1213,6 +1215,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     L.accLines = 0;
     L.sliceLines = 0;
     L.wave16 = 0;                           // (decided when the HRTF data set is known: InstallHrtfData)
+    L.rows8 = 0; L.rowsVpg = 0;
     if(c->useWave && !(desc->flags & OALGPU_CTX_STREAM_ROWS))
     {
         L.accLines = WaveKernelAccLines(L);
@@ -1220,6 +1223,11 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
         // OALGPU_CTX_SLICE_LINES -- a wavefront per 256-frame slice (voice_slice.hip: a third of the traffic, twice the time); the
         // measurement variants (OALGPU_CTX_PROFILE) exist for the stream-row kernel only
         if(!L.accLines && (desc->flags & OALGPU_CTX_SLICE_LINES) && !(desc->flags & OALGPU_CTX_PROFILE)) L.sliceLines = SliceKernelLines(L);
+        // ... by default the rows stay in LDS: a wavefront per voice produces, a wavefront per 128-frame slice of every line
+        // consumes, the round's filters are jobs dealt to all eight wavefronts (voice_rows.hip); one workgroup per compute unit
+        // (SetRowsGroups below).  OALGPU_CTX_STREAM_ROWS keeps the rows in HBM (above); OALGPU_CTX_ROW_SLICES asks for this form by name.
+        if(!L.accLines && !L.sliceLines && RowsKernelApplies(L))
+            L.rows8 = 1;
     }
     if(c->useWave && (!L.hrtf || L.numSends))
     {   // one partial bus per workgroup, from the wavefronts' line accumulators (accLines) or from stream rows mixed by the
@@ -1227,10 +1235,10 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
         L.lineStride = L.mixLines <= 8 ? 8u : (L.mixLines <= 16 ? 16u : 32u);
         L.streamsPerVoice = 2u + L.numSends;
     }
-    if(c->useWave && (!L.hrtf || L.numSends) && !L.accLines && !L.sliceLines) { if(int rc = AllocStreamRows(c.get())) return rc; }
+    if(c->useWave && (!L.hrtf || L.numSends) && !L.accLines && !L.sliceLines && !L.rows8) { if(int rc = AllocStreamRows(c.get())) return rc; }
     HIP_TRY(c->partLines.alloc(size_t{L.numLineGroups} * L.mixLines * kLine)); L.partLines = c->partLines.p;
     // the two-stream pipeline of oalgpu_mix_update alternates between two sets of partial buses
-    HIP_TRY(c->partLines2.alloc(c->useWave && (L.streams || L.accLines || L.sliceLines) ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
+    HIP_TRY(c->partLines2.alloc(c->useWave && (L.streams || L.accLines || L.sliceLines || L.rows8) ? size_t{L.numLineGroups} * L.mixLines * kLine : 0));
     c->partLinesBuf[0] = c->partLines.p; c->partLinesBuf[1] = c->partLines2.p;
     HIP_TRY(c->partHrtf.alloc(L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0)); L.partHrtf = c->partHrtf.p;
     HIP_TRY(c->partHrtf2.alloc(c->useWave && L.hrtf ? size_t{L.numGroups} * (kLine + kHrirLen) * 2 : 0));
@@ -1251,6 +1259,7 @@ int oalgpu_context_create(const oalgpu_context_desc *desc, oalgpu_context **out)
     HIP_TRY(c->dHfScale.alloc(L.numDry)); HIP_TRY(c->dHfScale.zero());
     HIP_TRY(c->dCoeffs.alloc(size_t{L.numDry} * kHrirLen * 2)); HIP_TRY(c->dCoeffs.zero());
     HIP_TRY(c->dTemp.alloc(size_t{L.numDry} * kLine + (kLine + kHrirLen) * 2));
+    if(L.rows8) SetRowsGroups(c.get());
     *out = c.release();
     return OALGPU_OK;
 }
@@ -1813,6 +1822,11 @@ int oalgpu_context_set_nfc(oalgpu_context *c, float w1, const uint32_t channels_
     {   // the wavefront kernel: every order adds one stream row per voice (near-field contexts mix through stream rows)
         L.accLines = 0;
         L.sliceLines = 0;
+        if(L.rows8)
+        {   // (back to the wavefront-per-voice grid: the rows kernel has no near-field rows)
+            L.rows8 = 0; L.rowsVpg = 0;
+            L.numGroups = std::max<uint32_t>(1u, WaveKernelGroups(L)); L.numLineGroups = L.numGroups;
+        }
         const uint32_t spv = 2u + L.numSends + orders;
         HIP_TRY(c->streams.alloc(nv * spv * kLine)); HIP_TRY(c->streams.zero());
         HIP_TRY(c->lineGains.alloc(nv * spv * LineBlockDwords(L.lineStride))); HIP_TRY(c->lineGains.zero());
@@ -3071,7 +3085,7 @@ int oalgpu_mix_voices_overlapped(oalgpu_context *c, uint32_t samples_to_do)
     const uint32_t p = c->parity;
     DeviceLayout L = c->L;
     L.partHrtf = c->partHrtfBuf[p];
-    if(L.streams || L.accLines || L.sliceLines) L.partLines = c->partLinesBuf[p];
+    if(L.streams || L.accLines || L.sliceLines || L.rows8) L.partLines = c->partLinesBuf[p];
     // main stream: this update's voices; its partial-bus buffer was last read by the reduction
     // of two updates ago
     // (almost always long done: then no barrier packet goes into the main queue in front of the voice kernel)
@@ -3411,8 +3425,42 @@ int oalgpu_slot_set_convolution(oalgpu_context *c, uint32_t slot, oalgpu_convolu
 // reverbs 85 -> 170 us in the updates between, profiles/r5/evidence/step_timeline_config4.txt).  With reverbs attached the
 // automatic voices-per-workgroup choice therefore leaves the instances their CUs: a few more voices per wavefront, so that the
 // grid fits on the CUs that are left -- one round, and the reverbs run beside it undisturbed.
+// voice_rows.hip's grid: one workgroup of eight wavefronts per compute unit -- the compute units the attached EAX reverb instances need
+// (a whole CU's LDS each, beside the NEXT update's voice kernel, see below) left out --, the voices dealt evenly
+static void SetRowsGroups(oalgpu_context *c)
+{
+    DeviceLayout &L = c->L;
+    uint32_t reverbs = 0;
+    for(oalgpu_reverb *r : c->slotReverb) reverbs += r ? 1u : 0u;
+    uint32_t cus = 256u;
+    hipDeviceProp_t prop{};
+    if(hipGetDeviceProperties(&prop, c->desc.device) == hipSuccess && prop.multiProcessorCount > 0) cus = uint32_t(prop.multiProcessorCount);
+    else (void)hipGetLastError();
+    const uint32_t waves = RowsWavesPerGroup();
+    uint32_t groups = std::min<uint32_t>(cus > reverbs ? cus - reverbs : 1u, (L.numVoices + waves - 1u) / waves);
+    if(c->desc.voices_per_group) groups = (L.numVoices + c->desc.voices_per_group - 1u) / c->desc.voices_per_group;
+    groups = std::max<uint32_t>(1u, std::min<uint32_t>(groups, c->groupsAllocated));
+    L.rowsVpg = (L.numVoices + groups - 1u) / groups;
+    L.numGroups = (L.numVoices + L.rowsVpg - 1u) / L.rowsVpg;
+    L.numLineGroups = L.numGroups;
+}
+
 static int RebalanceWaveGroups(oalgpu_context *c)
 {
+    if(c->useWave && c->L.rows8)
+    {
+        const uint32_t before = c->L.rowsVpg;
+        DeviceLayout T = c->L;
+        SetRowsGroups(c);
+        if(c->L.rowsVpg != before)
+        {   // (the streams may still run launches of the old grid)
+            const DeviceLayout N = c->L;
+            c->L = T;
+            if(int rc = oalgpu_sync(c)) return rc;
+            c->L = N;
+        }
+        return OALGPU_OK;
+    }
     if(!c->useWave || c->desc.voices_per_group != 0u || c->L.wave16) return OALGPU_OK;
     uint32_t reverbs = 0;
     for(oalgpu_reverb *r : c->slotReverb) reverbs += r ? 1u : 0u;

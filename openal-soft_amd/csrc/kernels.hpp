@@ -115,6 +115,8 @@ struct DeviceLayout {
     uint32_t sliceLines;                    // voice_slice.hip: the context's voices are mixed a wavefront per 256-frame slice (0 = no)
     uint32_t accLines;                      // voice_wave.hip: the mix lines accumulate in the wavefronts' registers (<= 8 lines;
                                             // the kernel's ACCL: 4, 6 or 8) instead of leaving stream rows; 0 = stream rows
+    uint32_t rows8, rowsVpg;                // voice_rows.hip (OALGPU_CTX_ROW_SLICES): dry lines and sends with the rows kept in LDS -- a wavefront per
+                                            // voice produces, a wavefront per 128-frame slice of every line consumes; rowsVpg voices per workgroup
     uint32_t wave16;                        // voice_wave16.hip: one voice per wavefront, this many (4, 8 or 16) wavefronts per workgroup (HRTF
                                             // contexts without sends, IrSize <= 64; 0 = voice_wave.hip's two voices per wavefront,
                                             // OALGPU_CTX_WAVE_PAIRS); numGroups = voices / wave16 then
@@ -469,6 +471,12 @@ const char *SliceKernelName();
 hipError_t LaunchVoiceSlice(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
 // the resident launch of the HRTF hot path (OALGPU_CTX_RESIDENT): see ResidentDoor above
 bool WaveKernelHasResident(const DeviceLayout &L);
+// ---- launcher (voice_rows.hip): dry lines and sends, the rows kept on the compute unit ----
+bool RowsKernelApplies(const DeviceLayout &L);
+const char *RowsKernelName();
+uint32_t RowsWavesPerGroup();
+hipError_t LaunchVoiceRows(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
+    const ParamRecord *nextRecs, const int32_t *nextMap);
 // ---- launcher (voice_wave16.hip): the HRTF hot path at four wavefronts per SIMD, one voice per wavefront ----
 bool Wave16Applies(const DeviceLayout &L);
 uint32_t Wave16WavesFor(uint32_t voices, uint32_t cus);

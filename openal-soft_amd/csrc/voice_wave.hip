@@ -1678,6 +1678,7 @@ uint32_t WaveKernelAccLines(const DeviceLayout &L)
 const char *WaveKernelName(const DeviceLayout &L)
 {
     if(L.wave16) return Wave16KernelName(L);
+    if(L.rows8) return RowsKernelName();
     if(L.sliceLines) return SliceKernelName();
     const bool sends = L.numSends != 0;
     if(L.accLines)
@@ -1691,6 +1692,7 @@ const char *WaveKernelName(const DeviceLayout &L)
 uint32_t WaveKernelGroups(const DeviceLayout &L)
 {
     if(L.wave16) return Wave16Groups(L);
+    if(L.rows8) return (L.numVoices + L.rowsVpg - 1u) / L.rowsVpg;
     return (L.numVoices + kWWaves * L.waveVoices - 1u) / (kWWaves * L.waveVoices);
 }
 
@@ -1704,6 +1706,7 @@ hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t sample
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)
 {
     if(L.wave16) return LaunchVoiceWave16(s, L, samplesToDo, prof, evStart, evStop, nextRecs, nextMap, L.hrtf ? nextRows : nullptr);   // (voice_wave16.hip)
+    if(L.rows8) return LaunchVoiceRows(s, L, samplesToDo, prof, evStart, evStop, nextRecs, nextMap);      // (voice_rows.hip)
     if(L.sliceLines) return LaunchVoiceSlice(s, L, samplesToDo, evStart, evStop);       // (voice_slice.hip)
     const NextBlock next{nextRecs, nextMap, L.hrtf ? nextRows : nullptr, ResidentArgs{}};
     const uint32_t groups = WaveKernelGroups(L);

@@ -85,6 +85,7 @@ CTX_FIR_VALU, CTX_PROFILE, CTX_SERIAL, CTX_STREAM_ROWS, CTX_APPLY_IN_VOICE_KERNE
 CTX_RESIDENT = 64
 CTX_SLICE_LINES = 128
 CTX_WAVE_PAIRS = 256
+CTX_ROW_SLICES = 512
 
 
 class VoiceDesc(C.Structure):

@@ -81,7 +81,7 @@
 
 #include "../include/oalgpu.h"
 #include "../include/oalgpu_openal.hpp"    /* THE PRODUCT'S host adapter: this file only drives it */
-#include "../include/oalgpu_openal_hooks.h" /* ... and defines its two hooks, which _ref/alu_hooked.cpp (alc/alu.cpp + four lines) calls */
+#include "../include/oalgpu_openal_hooks.hpp" /* ... and defines its two hooks, which _ref/alu_hooked.cpp (alc/alu.cpp + four lines) calls */
 
 extern "C" {
 void oalbridge_voice_mix_cpu(void *voice, int vstate, void *context, long long device_ns, unsigned samples_to_do);
@@ -140,7 +140,7 @@ oalbridge *gActive = nullptr;               /* the bridge whose renderSamples is
 
 } // namespace
 
-/* ---- the binding's hooks inside alc/alu.cpp (include/oalgpu_openal_hooks.h; the library is built with oracle/_ref/
+/* ---- the binding's hooks inside alc/alu.cpp (include/oalgpu_openal_hooks.hpp; the library is built with oracle/_ref/
  * alu_hooked.cpp = alc/alu.cpp with the four lines of INTEGRATION.md 3a, generated by oracle/Makefile) ---------------- */
 namespace oalgpu_hook {
 void ParamsChanged(Voice *voice) noexcept
@@ -637,7 +637,7 @@ int oalbridge_track_changes(oalbridge *b, int on)
     return 0;
 }
 
-/* the hooks INSIDE alc/alu.cpp (include/oalgpu_openal_hooks.h): CalcVoiceParams names the voices it recomputes, and on an HRTF
+/* the hooks INSIDE alc/alu.cpp (include/oalgpu_openal_hooks.hpp): CalcVoiceParams names the voices it recomputes, and on an HRTF
  * device CalcPanningAndFilters' getCoeffs call sites hand the batch mixer the direction (the device context evaluates getCoeffs)
  * -- nothing on the application's side of the bridge tells the mixer anything */
 int oalbridge_hook_alu(oalbridge *b, int on)

@@ -171,7 +171,7 @@ class Bridge:
         lib().oalbridge_track_changes(self.h, 1 if on else 0)
 
     def hook_alu(self, on=True):
-        """the binding's hooks INSIDE alc/alu.cpp (include/oalgpu_openal_hooks.h; the bridge library is built with
+        """the binding's hooks INSIDE alc/alu.cpp (include/oalgpu_openal_hooks.hpp; the bridge library is built with
         oracle/_ref/alu_hooked.cpp): CalcVoiceParams names the voices it recomputes and CalcPanningAndFilters hands the batch mixer
         directions instead of blended responses (the device context evaluates HrtfStore::getCoeffs)"""
         lib().oalbridge_hook_alu.argtypes = [C.c_void_p, C.c_int]

@@ -344,7 +344,7 @@ def render_hrtf_direct(mode, nsources, updates, pipelined=0, stop=True, track=Fa
 @needs_bridge
 @pytest.mark.parametrize("nsources,restart", [(256, True), (4096, False)])
 def test_the_getcoeffs_hook_hands_over_directions_instead_of_responses(nsources, restart):
-    """SURVEY.md 8 f1 behind the shipped binding (include/oalgpu_openal_hooks.h): the bridge library is built with alc/alu.cpp plus
+    """SURVEY.md 8 f1 behind the shipped binding (include/oalgpu_openal_hooks.hpp): the bridge library is built with alc/alu.cpp plus
     the binding's four lines (oracle/_ref/alu_hooked.cpp) -- CalcPanningAndFilters hands the batch mixer the DIRECTION of every
     voice it recomputes and never blends a response, the device context evaluates HrtfStore::getCoeffs from 24-byte move records
     -- against the reference's own render (its getCoeffs, its Voice::mix, its MixDirectHrtf) of the same scene: a quarter of the

@@ -67,8 +67,9 @@ CASES = {
     "hrtf exact (generic kernel)": dict(hrtf=True, sends=0, exact=True, flags=0),
     "dry lines fast (stream rows)": dict(hrtf=False, sends=0, exact=False, flags=0),
     "dry lines + sends exact": dict(hrtf=False, sends=2, exact=True, flags=0),
-    "dry lines + sends fast (stream rows)": dict(hrtf=False, sends=2, exact=False, flags=0),
+    "dry lines + sends fast (rows in LDS)": dict(hrtf=False, sends=2, exact=False, flags=0),
     "dry lines + sends fast (a wavefront per slice)": dict(hrtf=False, sends=2, exact=False, flags=128),      # OALGPU_CTX_SLICE_LINES
+    "dry lines + sends fast (stream rows)": dict(hrtf=False, sends=2, exact=False, flags=8),                  # OALGPU_CTX_STREAM_ROWS
 }
 
 

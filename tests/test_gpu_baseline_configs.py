@@ -208,7 +208,17 @@ def test_config3_4096_hrtf_voices(synth_mhr, data_set):
 
 
 def test_config4_8192_voices_four_reverb_slots(synth_mhr):
-    run_config(4, 8192, synth_mhr, expect_kernel="VoiceWaveKernel")
+    """the default form: the rows in LDS (csrc/voice_rows.hip) -- a wavefront per voice resamples ONCE into a 4 KB slot of LDS, the
+    round's filtered signals are jobs dealt to all eight wavefronts, each wavefront adds its own 128-frame slice of every row to
+    the 21 lines it keeps in registers -- against the reference at full size."""
+    run_config(4, 8192, synth_mhr, expect_kernel="VoiceRowsKernel")
+
+
+def test_config4_stream_rows(synth_mhr):
+    """OALGPU_CTX_STREAM_ROWS: a 4 KB row per mixed signal in HBM, mixed by the voice kernel's tail (csrc/voice_wave.hip; the default
+    of rounds 3-5, and still the form of contexts with near-field control and sends) -- against the reference at full size."""
+    import oalgpu
+    run_config(4, 8192, synth_mhr, ctx_flags=oalgpu.CTX_STREAM_ROWS, expect_kernel="VoiceWaveKernel")
 
 
 def test_config4_a_wavefront_per_slice(synth_mhr):
@@ -218,13 +228,20 @@ def test_config4_a_wavefront_per_slice(synth_mhr):
     run_config(4, 8192, synth_mhr, ctx_flags=oalgpu.CTX_SLICE_LINES, expect_kernel="VoiceSliceKernel")
 
 
-@pytest.mark.parametrize("path", ["stream rows", "a wavefront per slice"])
+def test_config4_rows_in_lds_by_name(synth_mhr):
+    """OALGPU_CTX_ROW_SLICES names the default form (include/oalgpu.h): the same kernel, the same results."""
+    import oalgpu
+    run_config(4, 8192, synth_mhr, ctx_flags=oalgpu.CTX_ROW_SLICES, expect_kernel="VoiceRowsKernel")
+
+
+PATHS = {"stream rows": (8, "VoiceWaveKernel"), "a wavefront per slice": (128, "VoiceSliceKernel"), "rows in LDS": (0, "VoiceRowsKernel")}
+
+
+@pytest.mark.parametrize("path", list(PATHS))
 def test_config4_odd_update_lengths_and_a_ragged_last_workgroup(synth_mhr, path):
     """Updates that end inside a 256-frame slice, inside the gain ramp (40 < 64 frames) or inside the first slice, and a
     voice count that leaves the last workgroup partly empty."""
-    import oalgpu
-    run_config(4, 2039, synth_mhr, todo=(1024, 1000, 300, 40, 257, 1024), ctx_flags=oalgpu.CTX_SLICE_LINES if "slice" in path else 0,
-               expect_kernel="VoiceSliceKernel" if "slice" in path else "VoiceWaveKernel")
+    run_config(4, 2039, synth_mhr, todo=(1024, 1000, 300, 40, 257, 1024), ctx_flags=PATHS[path][0], expect_kernel=PATHS[path][1])
 
 
 def test_config5_4096_hrtf_voices_and_a_65536_tap_convolution(synth_mhr):
@@ -251,7 +268,13 @@ def test_config3_parity_after_updates_1_2_8_50(sample_fmt):
 
 @pytest.mark.parametrize("sample_fmt", ["f32", "i16"])
 def test_config4_parity_after_updates_1_2_8_50(synth_mhr, sample_fmt):
-    run_config(4, 8192, synth_mhr, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt)
+    run_config(4, 8192, synth_mhr, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt=sample_fmt, expect_kernel="VoiceRowsKernel")
+
+
+def test_config4_stream_rows_after_updates_1_2_8_50(synth_mhr):
+    import oalgpu
+    run_config(4, 8192, synth_mhr, todo=(1024,) * 50, check_at=SCHEDULE, sample_fmt="i16", ctx_flags=oalgpu.CTX_STREAM_ROWS,
+               expect_kernel="VoiceWaveKernel")
 
 
 def test_config4_a_wavefront_per_slice_after_updates_1_2_8_50(synth_mhr):

@@ -53,11 +53,15 @@ def test_no_voices_at_all(libs):
         sc.close()
 
 
-def test_widest_bus(libs):
-    """28 dry + 4 wet = 32 mix lines: the stream-row kernels with S = 32.  One more line is refused
-    at context creation (OALGPU_ERR_CAPACITY), not mixed wrongly."""
+@pytest.mark.parametrize("form", ["rows in LDS", "stream rows"])
+def test_widest_bus(libs, form):
+    """28 dry + 4 wet = 32 mix lines: all 32 line accumulators of the rows-in-LDS kernel (the default), the stream-row
+    kernels with S = 32 (OALGPU_CTX_STREAM_ROWS).  One more line is refused at context creation (OALGPU_ERR_CAPACITY), not
+    mixed wrongly."""
     import oalgpu
     api, L, mhr = libs
+    if form == "stream rows":
+        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_STREAM_ROWS)
     nlines = 28
 
     def build(lib, **kw):
@@ -73,7 +77,7 @@ def test_widest_bus(libs):
         return sc
 
     gsc, osc = build(api, max_voices=10), build(L)
-    assert "VoiceWave" in gsc.voice_kernel_name()
+    assert ("VoiceRowsKernel" if form == "rows in LDS" else "VoiceWaveKernel") in gsc.voice_kernel_name(), gsc.voice_kernel_name()
     for k in range(3):
         gsc.mix(1000, post_process=False); osc.mix(1000, post_process=False)
         close(gsc.dry()[:, :1000], osc.dry()[:, :1000], f"dry, update {k}")

@@ -11,7 +11,8 @@ from oalgpu import synth
 import bench
 config = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 V = int(sys.argv[2]) if len(sys.argv) > 2 else (8192 if config == 4 else 4096)
-api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_PROFILE | oalgpu.CTX_SERIAL)
+# (config 4's default form has its own reader, tools/phase_times_rows.py: this one reads the stream-row kernel's stamps)
+api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_PROFILE | oalgpu.CTX_SERIAL | (oalgpu.CTX_STREAM_ROWS if config == 4 else 0))
 mhr = synth.synth_mhr_bytes(); api._mhr = mhr
 sc, script = bench.build_scene(oalgpu, synth, api, config, V, 0, mhr, 0)
 allv = list(range(V)); moving = [v for v in allv if script.is_moving(v)]
