@@ -234,11 +234,14 @@ PEAK_CLOCK_HZ = 2.4e9                # MI355X peak engine clock
 def lds_block(config_id, voices, kernel, kernel_ms):
     """The LDS side of the voice kernel, which is what its time follows: instructions, bytes and array-busy cycles
     per launch from the committed SQ counter passes of the same command (profiles/voice_kernel_sq_counters.json, written by
-    tools/r4_evidence.sh), against the pipe's peak -- 256 B per clock and CU."""
+    tools/r6_evidence.sh on this tree's kernel sources), against the pipe's peak -- 256 B per clock and CU."""
     try:
-        ent = json.load(open(os.path.join(ROOT, "profiles", "voice_kernel_sq_counters.json")))["configs"][str(config_id)]
+        doc = json.load(open(os.path.join(ROOT, "profiles", "voice_kernel_sq_counters.json")))
+        ent = doc["configs"][str(config_id)]
     except (OSError, ValueError, KeyError):
         return None
+    if not _counters_current(doc):
+        return {"refused": "profiles/voice_kernel_sq_counters.json was collected on other kernel sources (kernel_sources_sha256)"}
     if ent.get("voices") != voices or ent.get("kernel") != kernel:
         return None
     insts = ent["SQ_INSTS_LDS"]
@@ -250,8 +253,26 @@ def lds_block(config_id, voices, kernel, kernel_ms):
             "array_busy_frac": ent["SQ_LDS_IDX_ACTIVE"] / NUM_CUS / cyc, "bank_conflict_cycles": ent.get("SQ_LDS_BANK_CONFLICT"),
             "wave_cycles_waiting_on_lds_frac": ent["SQ_WAIT_INST_LDS"] / ent["SQ_WAVE_CYCLES"],
             "valu_instructions_per_launch": ent.get("SQ_INSTS_VALU"),
-            "note": "SQ_INSTS_LDS x 512 B; array_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles at 2.4 GHz); two wavefronts per SIMD "
-                    "issue 8-byte LDS reads at half the pipe's rate (MI355X_MICROARCH.md, LDS), so the pipe's busy share, not its byte rate, is the bound"}
+            "note": "SQ_INSTS_LDS x 512 B (the kernels' LDS traffic is 8-byte accesses); array_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel "
+                    "cycles at 2.4 GHz): the pipe's busy share, not its byte rate, is the bound (DESIGN.md 3.4, 3.13)"}
+
+
+def kernel_sources_hash():
+    """sha256 over what decides the kernels' instruction streams -- openal-soft_amd/csrc/*.hip, *.hpp and the Makefile (flags), in
+    name order.  Every committed counter file records the hash of the tree it was collected on (tools/r6_evidence.sh); a figure
+    read from a file with another hash is refused (the line then carries null and says why)."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "openal-soft_amd")
+    for path in sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.hpp"))) + [os.path.join(pkg, "Makefile")]:
+        h.update(os.path.basename(path).encode()); h.update(b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def _counters_current(doc):
+    """a committed counter file belongs to this tree's kernels"""
+    return doc.get("kernel_sources_sha256") == kernel_sources_hash()
 
 
 def _file_source(name):
@@ -751,7 +772,9 @@ def main():
         traffic_source = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "voice_kernel_traffic.json")))
-            for ent in tj.get("configs", {}).values():       # (config 4 has two entries: stream rows, and the opt-in slice kernel)
+            if not _counters_current(tj):
+                traffic_source = "refused: profiles/voice_kernel_traffic.json was collected on other kernel sources (kernel_sources_sha256)"
+            for ent in (tj.get("configs", {}).values() if _counters_current(tj) else ()):       # (config 4 has two entries: rows in LDS, stream rows)
                 if ent.get("config") == args.config and ent.get("voices") == V and ent.get("kernel") == sc.voice_kernel_name():
                     traffic = ent["hbm_bytes_per_launch"]
                     traffic_source = _file_source("voice_kernel_traffic.json")

@@ -227,7 +227,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kRowsThreads) VoiceRowsKe
     const uint32_t sendLanes = numSends * wetCh;
 #pragma unroll
     for(int i = 0; i < kPre; ++i) preN[i] = 0.0f;
-    auto request = [&](uint32_t round)
+    // (the scalar half runs twice per voice: when the voice's window is requested, and again at the start of its round -- the
+    // control line comes from L2 in a few hundred cycles, where some forty scalar values carried across a round went through
+    // spill lanes at every use)
+    auto requestScalars = [&](uint32_t round) __attribute__((always_inline))
     {
         const uint32_t vRaw = vBegin + round * uint32_t(kRowsWaves) + wave;
         rq.haveVoice = round < rounds && vRaw < vEnd;
@@ -257,6 +260,10 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kRowsThreads) VoiceRowsKe
         rq.regPath = rq.active && rq.plan.prefetch && eligK && (rq.head.rsKind == 2 || rq.head.rsKind == 3)
             && rq.head.rsFilterOffset * 8u + uint32_t(rq.head.rsKind) == offK * 8u + uint32_t(kK) && rq.sM == mK
             && !(rq.head.step == kFracOne && rq.head.positionFrac == 0u);
+    };
+    auto request = [&](uint32_t round) __attribute__((always_inline))
+    {
+        requestScalars(round);
         if(rq.regPath)
         {
             GatherStatic(preN, rq.plan.bsrc, rq.buf, rq.looping, uint32_t(rq.head.position), lane);
@@ -295,6 +302,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kRowsThreads) VoiceRowsKe
         };
         stamp(0);
         // ================= PRODUCE: this wavefront's voice (requested one round ago) =================
+        requestScalars(round);
         const Req cur = rq;
         // (the send slots as six values of their own: picked through an address, the whole request would live in scratch)
         const int32_t ss0 = rq.sendSlots[0], ss1 = rq.sendSlots[1], ss2 = rq.sendSlots[2], ss3 = rq.sendSlots[3], ss4 = rq.sendSlots[4], ss5 = rq.sendSlots[5];
@@ -501,7 +509,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kRowsThreads) VoiceRowsKe
         stamp(3);
 
         // consume: this wavefront's 128-frame slice of up to eight rows, in index order.  The rows' words come in ONE read (lane =
-        // index), every row's operands are requested before the first is used.
+        // index), every row's operands are requested before the first is used.  (Instruction-bound -- v_readlane, two FMAs per line and
+        // row; the gain through the FMA's DPP operand instead, quad_perm:[i,i,i,i] on a register per 4-line block, measured slower: 9.6 K
+        // against 7.3 K cycles, DPP operands run at half rate.)
         auto consume = [&](uint32_t mLive, uint32_t mBlocks, uint32_t mFade, auto rowOf, auto gainsOf)
         {
             float x0[kRowsWaves], x1[kRowsWaves], gv[kRowsWaves];
