@@ -30,13 +30,19 @@
  * they play, voice.cpp:563-594, :1182-1218), of every PCM sample type and both ADPCM types, with delayed starts
  * (voice.cpp:1023-1046), on a device in RenderMode::Normal (ambisonic dry lines) or RenderMode::Hrtf, with up to MaxSendCount
  * auxiliary sends into the context's active effect slots.  Buffers are registered when a voice first starts on them and given
- * up when their storage changes (oalgpu_buffer_release).  What is left -- callback, B-Format, UHJ and near-field-compensated
- * sources, direct channels -- makes mix() report an error BEFORE anything on the device changed, and the caller runs the
- * reference's own loop for that update; the device context then starts every voice over from its Voice.
+ * up when their storage changes (oalgpu_buffer_release).  On a RenderMode::Normal device also B-Format sources the device's order
+ * exceeds (VoiceFlag::IsAmbisonic: a device voice per channel with its HF / LF scales, oalgpu_voice_set_ambi_scale; voice.cpp:1082-1091)
+ * and near-field-compensated voices (VoiceFlag::HasNfc on a device with a control distance: oalgpu_context_set_nfc once,
+ * oalgpu_voice_set_nfc with the w0 CalcPanningAndFilters adjusted the voice's NFCtrlFilter to; voice.cpp:904-932).  Mono callback sources
+ * (VoiceFlag::IsCallback: the library calls the buffer's function from inside oalgpu_mix_update, voice.cpp:726-752, :1155-1180) on either
+ * device.  What is left -- UHJ sources, direct channels, B-Format sources on an HRTF device (they mix into the ambisonic dry lines the
+ * device context of an HRTF device does not have) -- makes mix() report an error BEFORE anything on the device changed, and the
+ * caller runs the reference's own loop for that update; the device context then starts every voice over from its Voice.
  *
- * BiquadInterpFilter keeps its target coefficients private; the shelf gains are recovered from them
- * (ShelfGainAt), so the including translation unit must see them -- upstream that is one friend declaration in
- * core/filters/biquad.h; this repository's compiled bridge (oracle/ref_bridge.cpp) opens the class instead. */
+ * BiquadInterpFilter keeps its target coefficients private and NfcFilter its sections; the shelf gains and w0 are recovered
+ * from them (ShelfGainAt, NfcW0), so the including translation unit must see them -- upstream that is one friend declaration
+ * each in core/filters/biquad.h and core/filters/nfc.h; this repository's compiled bridge (oracle/ref_bridge.cpp) opens the
+ * classes instead. */
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -108,6 +114,14 @@ inline float ShelfGainAt(const BiquadInterpFilter &f, float z /* +1: DC, -1: Nyq
 {
     const auto &c = f.mTargetCoeffs;
     return std::sqrt(std::max((c.mB0 + c.mB1*z + c.mB2) / (1.0f + c.mA1*z + c.mA2), 0.0f));
+}
+
+/* the w0 NfcFilter::adjust was last called with (alu.cpp:919-941, :1328-1341, :1415-1427): the first-order section keeps
+ * b1 = 2 (w0 / 2) / (1 + w0 / 2)  (NfcFilterAdjust1, core/filters/nfc.cpp:75-83) */
+inline float NfcW0(const NfcFilter &f)
+{
+    const float b1 = f.first.mCoeffs.b1;
+    return 2.0f * b1 / (2.0f - b1);
 }
 
 class BatchMixer {
@@ -317,6 +331,8 @@ private:
         HrtfFilter target{};                        /* the Hrtf.Target the device context was last given */
         std::array<float, 4> dir{};                 /* hookDirections: the direction the device context was last given INSTEAD ... */
         bool dirStale{false};                       /* ... and the Voice's own Hrtf.Target does not hold its response */
+        bool haveNfc{false};                        /* near-field control: the w0 the device context was last given (-1: none) */
+        float w0{-1.0f};
     };
     struct Entry {
         bool live{false};
@@ -327,7 +343,15 @@ private:
         bool queue{false};                          /* a streaming source: the items it has been linked through, in order */
         std::vector<std::pair<const VoiceBufferItem*, int>> chain;
         uint32_t doneSeen{0};
+        bool callback{false};                       /* a callback source (AL_SOFT_callback_buffer): the library calls the buffer's function */
     };
+    /* oalgpu_callback_fn -> the item's CallbackType (core/voice.h:85-86): called by oalgpu_mix_update on the mixer thread, for the
+     * byte counts Voice::mix would ask for (voice.cpp:726-752) */
+    static int32_t CallbackTrampoline(void *item_, void *data, int32_t numBytes)
+    {
+        auto *item = static_cast<VoiceBufferItem*>(item_);
+        return int32_t(item->mCallback(item->mUserData, data, numBytes));
+    }
 
     int fail(int rc, const char *what)
     {
@@ -365,6 +389,15 @@ private:
         d.max_voices = mMaxVoices; d.max_buffers = 1024; d.voices_per_group = 0; d.flags = 0;
         if(int rc = oalgpu_context_create(&d, &mGpu)) return fail(rc, "oalgpu_context_create");
         mNumSlots = d.num_slots; mWetChannels = d.wet_channels;
+        mNfc = false;
+        if(!mHrtf && dev.AvgSpeakerDist > 0.0f)
+        {   /* InitNearFieldCtrl (alc/panning.cpp:285-299): the control filter's w1 and the lines per order */
+            uint32_t perOrder[5]{};
+            for(size_t o{0}; o < 5 && o < dev.NumChannelsPerOrder.size(); ++o) perOrder[o] = dev.NumChannelsPerOrder[o];
+            const float w1 = SpeedOfSoundMetersPerSec / dev.AvgSpeakerDist / float(dev.mSampleRate);
+            if(int rc = oalgpu_context_set_nfc(mGpu, w1, perOrder)) return fail(rc, "oalgpu_context_set_nfc");
+            mNfc = true;
+        }
         if(mHrtf)
         {
             HrtfStore const *store = dev.mHrtf.get();
@@ -542,12 +575,16 @@ private:
         /* ---- pass 1: what the library cannot mix sends the whole update to the CPU loop BEFORE anything on the device changed */
         for(auto &[voice, vstate] : mBatch)
         {
-            if(voice->mFlags.test(VoiceFlag::IsCallback) || voice->mFlags.test(VoiceFlag::IsAmbisonic) || voice->mFlags.test(VoiceFlag::HasNfc)
-                || voice->mDecoder)
-                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: callback, B-Format, UHJ and near-field-compensated sources are not batched");
+            if(voice->mDecoder)
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: UHJ sources are not batched");
+            if(voice->mFlags.test(VoiceFlag::IsCallback) && (mDepth || voice->mFmtChannels != FmtMono || voice->mSamplesPerBlock != 1u))
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: callback sources are batched as mono PCM sources, and not in the pipelined mode "
+                    "(their state is mirrored back after every update)");
+            if(voice->mFlags.test(VoiceFlag::HasNfc) && !mNfc)
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: a near-field-compensated voice on a device context without near-field control");
             const bool hrtfVoice = voice->mFlags.test(VoiceFlag::HasHrtf);
             if(hrtfVoice != mHrtf || (!mHrtf && voice->mDirect.Buffer.data() != dev.Dry.Buffer.data()))
-                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: direct-channel voices are not batched");
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: direct-channel voices, and B-Format sources on an HRTF device, are not batched");
             if(!voice->mFlags.test(VoiceFlag::IsStatic))
             {
                 if(voice->mFmtChannels != FmtMono || voice->mDuplicateMono)
@@ -600,9 +637,24 @@ private:
                     if(vstate == Voice::Stopping) voice->mPlayState.store(Voice::Stopped, std::memory_order_release);
                     continue;
                 }
+                if(mFreeIndex.size() < nch) return failText(OALGPU_ERR_CAPACITY, "oalgpu_openal: more playing voices than max_voices");
+                if(voice->mFlags.test(VoiceFlag::IsCallback))
+                {   /* the samples come from the buffer's function (voice.cpp:726-752): the library calls it, through the trampoline, from
+                     * inside oalgpu_mix_update, and mirrors mNumCallbackBlocks / mCallbackBlockOffset / CallbackStopped */
+                    e.live = true; e.voice = voice; e.sourceId = sourceId; e.lastState = int(Voice::Playing);
+                    e.queue = false; e.callback = true; e.doneSeen = 0;
+                    Chan ch;
+                    ch.index = mFreeIndex.back(); mFreeIndex.pop_back();
+                    if(int rc = oalgpu_voice_init_callback(mGpu, ch.index, int(item->mSamples.index()), voice->mPositionFrac.load(std::memory_order_relaxed),
+                        &CallbackTrampoline, const_cast<VoiceBufferItem*>(item)))
+                        return fail(rc, "oalgpu_voice_init_callback");
+                    e.chans.push_back(ch);
+                    started = true;
+                }
+                else
+                {
                 BufferEntry *be = bufferEntry(voice, item);
                 if(!be) return mError;
-                if(mFreeIndex.size() < nch) return failText(OALGPU_ERR_CAPACITY, "oalgpu_openal: more playing voices than max_voices");
                 e.live = true; e.voice = voice; e.sourceId = sourceId; e.lastState = int(Voice::Playing);
                 e.queue = !voice->mFlags.test(VoiceFlag::IsStatic);
                 auto *loop = voice->mLoopBuffer.load(std::memory_order_relaxed);
@@ -631,10 +683,17 @@ private:
                         rc = oalgpu_voice_init(mGpu, ch.index, &vd);
                     }
                     if(rc) return fail(rc, "oalgpu_voice_init");
+                    if(voice->mFlags.test(VoiceFlag::IsAmbisonic))
+                    {   /* Voice::prepare's splitter and scales for this channel (voice.cpp:1353-1380) */
+                        auto const &cd = voice->mChans[c];
+                        if(int rc2 = oalgpu_voice_set_ambi_scale(mGpu, ch.index, dev.mXOverFreq / float(dev.mSampleRate), cd.mAmbiHFScale, cd.mAmbiLFScale))
+                            return fail(rc2, "oalgpu_voice_set_ambi_scale");
+                    }
                     e.chans.push_back(ch);
                 }
                 e.doneSeen = 0;
                 started = true;
+                }
             }
             else if(e.queue) { if(int rc = extendChain(voice, e)) return rc; }
             mMixed.emplace_back(voice, &e);
@@ -655,6 +714,19 @@ private:
             {
                 Chan &ch = e.chans[c];
                 auto &chan = voice->mChans[c];
+                if(mNfc)
+                {   /* NFCtrlFilter.adjust(w0) and VoiceFlag::HasNfc (alu.cpp:919-941, :1328-1341): a voice without the flag mixes its
+                     * samples onto every line unfiltered (voice.cpp:959-963) */
+                    const bool has = voice->mFlags.test(VoiceFlag::HasNfc);
+                    const float w0 = has ? NfcW0(chan.mDryParams.NFCtrlFilter) : -1.0f;
+                    if(!ch.haveNfc || ch.w0 != w0)
+                    {
+                        if(!has && ch.haveNfc && ch.w0 >= 0.0f)
+                            return failText(OALGPU_ERR_INVALID, "oalgpu_openal: a voice that loses VoiceFlag::HasNfc while it plays is not batched");
+                        if(has) { if(int rc = oalgpu_voice_set_nfc(mGpu, ch.index, w0)) return fail(rc, "oalgpu_voice_set_nfc"); }
+                        ch.haveNfc = true; ch.w0 = w0;
+                    }
+                }
                 oalgpu_voice_params p{};
                 p.step = voice->mStep;
                 p.resampler = int(voice->mProps.mResampler);
@@ -788,6 +860,22 @@ private:
             {   /* voice.cpp:1119-1123: faded out; the Voice object returns to the pool */
                 voice->mPlayState.store(Voice::Stopped, std::memory_order_release);
                 dropEntry(e);
+                continue;
+            }
+            if(e.callback)
+            {   /* voice.cpp:1155-1180: what the update left of the callback storage (the device-side position is relative to it) */
+                oalgpu_callback_state cs{};
+                if(int rc = oalgpu_voice_callback_state(mGpu, e.chans[0].index, &cs)) return fail(rc, "oalgpu_voice_callback_state");
+                voice->mPosition.store(cs.position, std::memory_order_relaxed);
+                voice->mPositionFrac.store(cs.position_frac, std::memory_order_relaxed);
+                voice->mNumCallbackBlocks = cs.num_blocks;
+                voice->mCallbackBlockOffset = cs.block_offset;
+                voice->mFlags.set(VoiceFlag::CallbackStopped, cs.stopped != 0);
+                if(!cs.has_buffer)
+                {
+                    endOfSource(voice, context);
+                    e.lastState = int(Voice::Stopping);
+                }
                 continue;
             }
             voice->mPosition.store(st.position, std::memory_order_relaxed);
@@ -947,6 +1035,7 @@ private:
     HrtfPostProcess mSavedPost;
     oalgpu_context *mGpu{nullptr};
     bool mHrtf{false};
+    bool mNfc{false};                               /* the device context has near-field control (DeviceBase::AvgSpeakerDist > 0) */
     uint32_t mNumSlots{0}, mWetChannels{4};
     std::map<const VoiceBufferItem*, BufferEntry> mBuffers;
     std::vector<Entry> mEntries;                    /* [place in the context's voice array] */

@@ -44,6 +44,7 @@
 #define protected public
 #define class struct
 #include "core/filters/biquad.h"
+#include "core/filters/nfc.h"           /* (NfcFilter's sections: the binding recovers w0 from them, oalgpu_openal::NfcW0) */
 #undef class
 #undef private
 #undef protected
@@ -234,7 +235,33 @@ oalbridge *oalbridge_create_ex(int mode, uint32_t sample_rate, int math_mode, in
     dev.FmtType = DevFmtFloat;
     dev.NumAuxSends = num_sends;
     dev.AvgSpeakerDist = 0.0f;
-    if(!hrtf)
+    if(hrtf == 2)
+    {
+        /* the same stereo device mixing SECOND-order 2D ambisonics (W, Y, X, V, U): what "ambi-order = 2" leaves -- a first-order
+         * B-Format source is then VoiceFlag::IsAmbisonic (Voice::prepare, core/voice.cpp:1353-1380: the device's order exceeds the
+         * source's) and, with a control distance, near-field compensated per order (DeviceBase::NumChannelsPerOrder = 1, 2, 2) */
+        dev.mAmbiOrder = 2;
+        dev.m2DMixing = true;
+        dev.mRenderMode = RenderMode::Normal;
+        dev.mXOverFreq = 400.0f;
+        constexpr size_t ambicount = 5, realcount = 2;
+        dev.MixBuffer.resize(ambicount + realcount);
+        dev.Dry.Buffer = std::span{dev.MixBuffer}.first(ambicount);
+        dev.RealOut.Buffer = std::span{dev.MixBuffer}.subspan(ambicount);
+        for(size_t i{0}; i < ambicount; ++i)
+            dev.Dry.AmbiMap[i] = BFChannelConfig{1.0f, AmbiIndex::FromACN2D[i].c_val};
+        dev.RealOut.ChannelIndex[FrontLeft] = 0_u8;
+        dev.RealOut.ChannelIndex[FrontRight] = 1_u8;
+        dev.NumChannelsPerOrder = {1u, 2u, 2u, 0u, 0u};
+        auto coeffs = std::vector<ChannelDec>(2);
+        coeffs[0] = ChannelDec{}; coeffs[1] = ChannelDec{};
+        coeffs[0][0] = 5.00000000e-1f; coeffs[0][1] =  2.88675135e-1f; coeffs[0][2] = 5.52305643e-2f; coeffs[0][3] =  3.1e-2f; coeffs[0][4] = -1.7e-2f;
+        coeffs[1][0] = 5.00000000e-1f; coeffs[1][1] = -2.88675135e-1f; coeffs[1][2] = 5.52305643e-2f; coeffs[1][3] = -3.1e-2f; coeffs[1][4] = -1.7e-2f;
+        auto dec = std::make_unique<BFormatDec>(ambicount, coeffs, std::span<const ChannelDec>{},
+            dev.mXOverFreq / float(sample_rate));
+        dev.mPostProcess.emplace<AmbiDecPostProcess>(AmbiDecPostProcess{std::move(dec)});
+    }
+    else if(!hrtf)
     {
         /* a stereo loopback device as alc/alc.cpp + alc/panning.cpp set it up (InitPanning with
          * StereoConfig, panning.cpp:548-556, :719-850): 3 first-order 2D ambisonic dry lines (W, Y, X)
@@ -333,6 +360,19 @@ oalbridge *oalbridge_create_ex(int mode, uint32_t sample_rate, int math_mode, in
 
 oalbridge *oalbridge_create(int mode, uint32_t sample_rate, int math_mode)
 { return oalbridge_create_ex(mode, sample_rate, math_mode, 0, nullptr, 0); }
+
+/* the second-order 2D device (above); control_distance > 0: with near-field control, as InitNearFieldCtrl leaves it
+ * (alc/panning.cpp:285-299) -- before any source exists: Voice::prepare copies DeviceBase::mNFCtrlFilter */
+oalbridge *oalbridge_create_ambi2(int mode, uint32_t sample_rate, int math_mode, uint32_t num_sends, float control_distance)
+{
+    oalbridge *b = oalbridge_create_ex(mode, sample_rate, math_mode, 2, nullptr, num_sends);
+    if(b && control_distance > 0.0f)
+    {
+        b->dev->AvgSpeakerDist = std::clamp(control_distance, 0.1f, 10.0f);
+        b->dev->mNFCtrlFilter.init(SpeedOfSoundMetersPerSec / b->dev->AvgSpeakerDist / float(sample_rate));
+    }
+    return b;
+}
 
 /* An effect slot of the context carrying the reference's own EAX reverb: what alGenAuxiliaryEffectSlots + alAuxiliaryEffectSloti
  * (al/auxeffectslot.cpp) leave in the core part -- a first-order wet bus, the ReverbState from its factory after
@@ -562,6 +602,113 @@ int oalbridge_add_source_stereo(oalbridge *b, int buffer, int looping, int posit
     v->mSourceID.store(unsigned(n + 1), std::memory_order_relaxed);
     auto *props = NewProps(b);
     FillProps(b, *props, gain, x, y, z, resampler, pitch, gain_hf);
+    v->mUpdate.store(props, std::memory_order_release);
+    v->mPlayState.store(Voice::Playing, std::memory_order_release);
+    ctx.mActiveVoiceCount.store(n + 1, std::memory_order_release);
+    b->sources.push_back(v);
+    return int(n);
+}
+
+/* a playing CALLBACK source (AL_SOFT_callback_buffer: alBufferCallbackSOFT + alSourcei(AL_BUFFER), al/buffer.cpp:455-490,
+ * al/source.cpp:1715-1730, :659-662): the item carries the function and a storage of MixerLineSize * MaxPitch + MaxResamplerEdge
+ * frames; Voice::mix asks the function for exactly the blocks it needs (voice.cpp:726-752).  The function here produces
+ * `total_frames` frames of a signal that depends on nothing but the frame's number and `seed`, then comes up short: the source
+ * plays what it has and ends. */
+struct CallbackGen { uint64_t produced{0}, total{0}; uint32_t seed{0}; };
+static int CallbackGenFn(void *user, void *data, int numBytes) noexcept
+{
+    auto *g = static_cast<CallbackGen*>(user);
+    auto *out = static_cast<float*>(data);
+    const uint64_t want = uint64_t(numBytes) / 4u, give = std::min<uint64_t>(want, g->total - g->produced);
+    for(uint64_t i{0}; i < give; ++i)
+    {
+        const uint64_t k = g->produced + i;
+        const uint32_t h = uint32_t(k * 2654435761u + g->seed * 40503u);
+        out[i] = 0.5f * std::sin(0.013f * float(k % 100000u) * float(1u + g->seed % 5u)) + 0.25f * (float((h >> 16) & 0xffu) / 255.0f - 0.5f);
+    }
+    g->produced += give;
+    return int(give * 4u);
+}
+static std::deque<CallbackGen> gCallbackGens;
+
+int oalbridge_add_source_callback(oalbridge *b, uint32_t total_frames, uint32_t seed, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf)
+{
+    auto &ctx = *b->ctx;
+    auto &buf = b->buffers.emplace_back();
+    auto &gen = gCallbackGens.emplace_back();
+    gen.total = total_frames; gen.seed = seed;
+    buf.samples.assign(size_t{BufferLineSize} * MaxPitch + MaxResamplerEdge + 8, 0.0f);
+    buf.item.mSamples = std::span<f32>{reinterpret_cast<f32*>(buf.samples.data()), size_t{BufferLineSize} * MaxPitch + MaxResamplerEdge};
+    buf.item.mCallback = CallbackGenFn;
+    buf.item.mUserData = &gen;
+    buf.item.mBlockAlign = 1;
+    buf.item.mSampleLen = 0;
+    buf.item.mLoopStart = 0;
+    buf.item.mLoopEnd = 0;
+    const size_t n = ctx.mActiveVoiceCount.load(std::memory_order_relaxed);
+    if(n >= ctx.mVoices.load(std::memory_order_relaxed)->size()) ctx.allocVoices(64);
+    Voice *v = (*ctx.mVoices.load(std::memory_order_relaxed))[n];
+    v->mLoopBuffer.store(nullptr, std::memory_order_relaxed);
+    v->mFmtChannels = FmtMono;
+    v->mFrequency = 44100;
+    v->mFrameStep = 1;
+    v->mBytesPerBlock = 4u;
+    v->mSamplesPerBlock = 1;
+    v->mAmbiOrder = 0;
+    v->mFlags.reset();
+    v->mFlags.set(VoiceFlag::IsCallback);
+    v->mNumCallbackBlocks = 0;
+    v->mCallbackBlockOffset = 0;
+    v->prepare(b->dev.get());
+    v->mPosition.store(0, std::memory_order_relaxed);
+    v->mPositionFrac.store(0u, std::memory_order_relaxed);
+    v->mCurrentBuffer.store(&buf.item, std::memory_order_relaxed);
+    v->mStartTime = {};
+    v->mSourceID.store(unsigned(n + 1), std::memory_order_relaxed);
+    auto *props = NewProps(b);
+    FillProps(b, *props, gain, x, y, z, resampler, pitch, gain_hf);
+    v->mUpdate.store(props, std::memory_order_release);
+    v->mPlayState.store(Voice::Playing, std::memory_order_release);
+    ctx.mActiveVoiceCount.store(n + 1, std::memory_order_release);
+    b->sources.push_back(v);
+    return int(n);
+}
+
+/* a playing first-order 2D B-FORMAT static source (three interleaved channels, ACN / SN3D): on the second-order device
+ * VoiceFlag::IsAmbisonic -- every channel's samples go through BandSplitter::processScale (voice.cpp:1082-1091) -- and, at the
+ * listener's place, its X / Y channels rotated by the source's orientation (alu.cpp:943-1100) */
+int oalbridge_add_source_bformat2d(oalbridge *b, int buffer, int looping, int position, float gain, float x, float y, float z,
+    int resampler, float pitch, float gain_hf, int send_slot, float send_gain)
+{
+    auto &ctx = *b->ctx;
+    auto &buf = b->buffers.at(size_t(buffer));
+    if(buf.channels != 3) return -1;
+    const size_t n = ctx.mActiveVoiceCount.load(std::memory_order_relaxed);
+    if(n >= ctx.mVoices.load(std::memory_order_relaxed)->size()) ctx.allocVoices(64);
+    Voice *v = (*ctx.mVoices.load(std::memory_order_relaxed))[n];
+    v->mLoopBuffer.store(looping ? &buf.item : nullptr, std::memory_order_relaxed);
+    v->mFmtChannels = FmtBFormat2D;
+    v->mFrequency = 44100;
+    v->mFrameStep = 3;
+    v->mBytesPerBlock = 12u;
+    v->mSamplesPerBlock = 1;
+    v->mAmbiLayout = AmbiLayout::ACN;
+    v->mAmbiScaling = AmbiScaling::SN3D;
+    v->mAmbiOrder = 1;
+    v->mFlags.reset();
+    v->mFlags.set(VoiceFlag::IsStatic);
+    v->mNumCallbackBlocks = 0;
+    v->mCallbackBlockOffset = 0;
+    v->prepare(b->dev.get());
+    v->mPosition.store(position, std::memory_order_relaxed);
+    v->mPositionFrac.store(0u, std::memory_order_relaxed);
+    v->mCurrentBuffer.store(&buf.item, std::memory_order_relaxed);
+    v->mStartTime = {};
+    v->mSourceID.store(unsigned(n + 1), std::memory_order_relaxed);
+    auto *props = NewProps(b);
+    FillProps(b, *props, gain, x, y, z, resampler, pitch, gain_hf, send_slot, send_gain, 1.0f);
+    props->OrientAt = {0.6f, 0.0f, -0.8f};          /* (turned a little: the rotation matrix is not the identity) */
     v->mUpdate.store(props, std::memory_order_release);
     v->mPlayState.store(Voice::Playing, std::memory_order_release);
     ctx.mActiveVoiceCount.store(n + 1, std::memory_order_release);

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(ROOT, "oracle", "_ref", "liboalbridge.so")
 MODE_CPU, MODE_ADAPTERS, MODE_BATCH = 0, 1, 2
 RS_LINEAR = 1
+RS_SPLINE = 2                           # enum class Resampler (core/mixer/defs.h:31-43): Point, Linear, Spline, Gaussian, ...
 RS_BSINC24 = 7
 GOLDEN = os.path.join(ROOT, "tests", "golden")          # holds default_hrtf.mhr, the reference's own Default HRTF.mhr
 f32p = C.POINTER(C.c_float)
@@ -31,6 +32,11 @@ def lib():
         L.oalbridge_create.argtypes = [C.c_int, C.c_uint32, C.c_int]
         L.oalbridge_create_ex.restype = C.c_void_p
         L.oalbridge_create_ex.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_uint32]
+        L.oalbridge_create_ambi2.restype = C.c_void_p
+        L.oalbridge_create_ambi2.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_float]
+        L.oalbridge_add_source_bformat2d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float,
+                                                                                                               C.c_int, C.c_float]
+        L.oalbridge_add_source_callback.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float]
         L.oalbridge_add_reverb_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
         L.oalbridge_add_buffer_i16.argtypes = [C.c_void_p, C.POINTER(C.c_int16), C.c_uint32, C.c_uint32, C.c_uint32]
         L.oalbridge_add_source_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float,
@@ -67,10 +73,14 @@ def lib():
 
 
 class Bridge:
-    def __init__(self, mode, math_mode=1, sample_rate=48000, hrtf=False, num_sends=0, mhr_dir=GOLDEN):
+    def __init__(self, mode, math_mode=1, sample_rate=48000, hrtf=False, num_sends=0, mhr_dir=GOLDEN, ambi2=False, control_distance=0.0):
         """hrtf: a RenderMode::Hrtf device on the .mhr under mhr_dir (the reference's InitHrtfPanning set-up);
-        num_sends: DeviceBase::NumAuxSends."""
-        self.h = lib().oalbridge_create_ex(mode, sample_rate, math_mode, 1 if hrtf else 0, mhr_dir.encode(), num_sends)
+        num_sends: DeviceBase::NumAuxSends; ambi2: the stereo device mixing second-order 2D ambisonics (first-order B-Format
+        sources are VoiceFlag::IsAmbisonic on it), with near-field control when control_distance > 0 (InitNearFieldCtrl)."""
+        if ambi2:
+            self.h = lib().oalbridge_create_ambi2(mode, sample_rate, math_mode, num_sends, control_distance)
+        else:
+            self.h = lib().oalbridge_create_ex(mode, sample_rate, math_mode, 1 if hrtf else 0, mhr_dir.encode(), num_sends)
         assert self.h, "oalbridge_create_ex failed (no .mhr under mhr_dir?)"
 
     def add_reverb_slot(self, props, gain=1.0):
@@ -103,6 +113,12 @@ class Bridge:
         lib().oalbridge_source_flags(self.h, source, st)
         return tuple(st)
 
+    def error(self):
+        """the first error the batch mixer reported (an update that went back to the CPU loop), '' if none"""
+        lib().oalbridge_error.restype = C.c_char_p
+        lib().oalbridge_error.argtypes = [C.c_void_p]
+        return (lib().oalbridge_error(self.h) or b"").decode()
+
     def close(self):
         if self.h:
             lib().oalbridge_destroy(self.h)
@@ -117,6 +133,18 @@ class Bridge:
 
     def add_source_stereo(self, buffer, looping, position, gain, pos, resampler=RS_LINEAR, pitch=1.0, gain_hf=1.0):
         src = lib().oalbridge_add_source_stereo(self.h, buffer, 1 if looping else 0, position, gain, *pos, resampler, pitch, gain_hf)
+        assert src >= 0
+        return src
+
+    def add_source_callback(self, total_frames, seed, gain, pos, resampler=RS_LINEAR, pitch=1.0, gain_hf=1.0):
+        """a playing AL_SOFT_callback_buffer source whose function yields total_frames frames, then comes up short"""
+        src = lib().oalbridge_add_source_callback(self.h, total_frames, seed, gain, *pos, resampler, pitch, gain_hf)
+        assert src >= 0
+        return src
+
+    def add_source_bformat2d(self, buffer, looping, position, gain, pos, resampler=RS_LINEAR, pitch=1.0, gain_hf=1.0, send_slot=-1, send_gain=1.0):
+        src = lib().oalbridge_add_source_bformat2d(self.h, buffer, 1 if looping else 0, position, gain, *pos, resampler, pitch, gain_hf,
+                                                   send_slot, send_gain)
         assert src >= 0
         return src
 
