@@ -39,9 +39,9 @@
  * device context of an HRTF device does not have) -- makes mix() report an error BEFORE anything on the device changed, and the
  * caller runs the reference's own loop for that update; the device context then starts every voice over from its Voice.
  *
- * BiquadInterpFilter keeps its target coefficients private and NfcFilter its sections; the shelf gains and w0 are recovered
- * from them (ShelfGainAt, NfcW0), so the including translation unit must see them -- upstream that is one friend declaration
- * each in core/filters/biquad.h and core/filters/nfc.h; this repository's compiled bridge (oracle/ref_bridge.cpp) opens the
+ * BiquadInterpFilter keeps its target coefficients private, NfcFilter its sections and BFormatDec its matrix; the shelf gains,
+ * w0 and the decoder are read from them (ShelfGainAt, NfcW0, createContext), so the including translation unit must see them --
+ * upstream that is one friend declaration each in core/filters/biquad.h, core/filters/nfc.h and core/bformatdec.h; this repository's compiled bridge (oracle/ref_bridge.cpp) opens the
  * classes instead. */
 #pragma once
 #include <algorithm>
@@ -228,8 +228,10 @@ public:
      * long landed in pinned memory).  Voice state comes back the same way, as a report of what CHANGED
      * (oalgpu_voice_events_async): a source that ran out of buffer is heard of `depth` updates late -- Voice::mStartTime-style
      * latency the application sees as `depth` x update size more output latency -- and Voice::mPosition is refreshed with such
-     * a report only (GetSourceOffset: oalgpu_voices_readback).  Scope: RenderMode::Hrtf without auxiliary sends (effect slots
-     * would have to move behind the boundary too: oalgpu_slot_set_*), a constant update size.  drain() collects what is
+     * a report only (GetSourceOffset: oalgpu_voices_readback).  On a RenderMode::Normal device the post-process that moves is the
+     * speaker decode (AmbiDecPostProcess: BFormatDec's matrix and crossover go to oalgpu_set_bformat_decoder) and the lines that
+     * come back are the device's real output lines.  Scope: devices without auxiliary sends (effect slots would have to move
+     * behind the boundary too: oalgpu_slot_set_*), a constant update size.  drain() collects what is
      * outstanding (before the device stops, or before leaving the mode). */
     void setPipelined(unsigned depth) { mDepth = std::min(depth, 2u); }
     bool pipelined() const { return mDepth != 0u; }
@@ -250,7 +252,12 @@ public:
         while(!mPending.empty()) { if(collect(context, dev, true)) { mPending.clear(); break; } }     /* (drain() first to keep their output) */
         mError = savedError; mErrorText = savedText;
         if(mSavedPost.mHrtfState) dev.mPostProcess.emplace<HrtfPostProcess>(std::move(mSavedPost));
-        if(mGpu) (void)oalgpu_set_carry_accum(mGpu, 0);
+        if(mSavedDec.mAmbiDecoder)
+        {
+            dev.mPostProcess.emplace<AmbiDecPostProcess>(std::move(mSavedDec));
+            if(mGpu) (void)oalgpu_set_bformat_decoder(mGpu, 0u, nullptr, nullptr, 0.0f);
+        }
+        if(mGpu && mHrtf) (void)oalgpu_set_carry_accum(mGpu, 0);
         mDepth = 0;
     }
     size_t pendingUpdates() const { return mPending.size(); }
@@ -416,11 +423,46 @@ private:
                 if(int rc = oalgpu_set_carry_accum(mGpu, 0)) return fail(rc, "oalgpu_set_carry_accum");
             }
         }
-        if(mDepth)
+        if(mDepth && !mHrtf)
+        {   /* a RenderMode::Normal device: the post-process that moves behind the boundary is the speaker decode, BFormatDec::process
+             * (DeviceBase::Process(AmbiDecPostProcess), alu.cpp:282-287) -- the decoder's matrix, per input channel in BFormatDec, goes
+             * over per output line; a dual-band decoder takes its crossover with it (core/bformatdec.cpp:27-95) */
+            auto *pp = std::get_if<AmbiDecPostProcess>(&dev.mPostProcess);
+            if(dev.NumAuxSends || !pp || !pp->mAmbiDecoder || dev.RealOut.Buffer.data() == dev.Dry.Buffer.data())
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: the pipelined mode covers devices without auxiliary sends whose post-process "
+                    "is HrtfPostProcess or AmbiDecPostProcess");
+            BFormatDec &dec = *pp->mAmbiDecoder;
+            const size_t nreal = dev.RealOut.Buffer.size(), ndry = dev.Dry.Buffer.size();
+            std::vector<float> hf(nreal * OALGPU_MAX_AMBI_CHANNELS, 0.0f), lf;
+            if(auto *single = std::get_if<BFormatDec::SBandDecoderVector>(&dec.mChannelDec))
+            {
+                for(size_t in{0}; in < ndry && in < single->size(); ++in)
+                    for(size_t out{0}; out < nreal; ++out) hf[out * OALGPU_MAX_AMBI_CHANNELS + in] = (*single)[in].mGains[out];
+            }
+            else
+            {
+                auto &dual = std::get<BFormatDec::DBandDecoderVector>(dec.mChannelDec);
+                lf.assign(hf.size(), 0.0f);
+                for(size_t in{0}; in < ndry && in < dual.size(); ++in)
+                    for(size_t out{0}; out < nreal; ++out)
+                    {
+                        hf[out * OALGPU_MAX_AMBI_CHANNELS + in] = dual[in].mGains[BFormatDec::sHFBand][out];
+                        lf[out * OALGPU_MAX_AMBI_CHANNELS + in] = dual[in].mGains[BFormatDec::sLFBand][out];
+                    }
+            }
+            if(int rc = oalgpu_set_bformat_decoder(mGpu, uint32_t(nreal), hf.data(), lf.empty() ? nullptr : lf.data(), dev.mXOverFreq / float(dev.mSampleRate)))
+                return fail(rc, "oalgpu_set_bformat_decoder");
+            mSavedDec = std::move(*pp);
+            dev.mPostProcess.emplace<std::monostate>();
+            mEntryOfIndex.assign(mMaxVoices, -1);
+            mIndexBorn.assign(mMaxVoices, 0u);
+        }
+        else if(mDepth)
         {   /* the post-process moves behind the boundary with the decoder InitHrtfPanning built (alc/panning.cpp:1100-1134) */
             auto *pp = std::get_if<HrtfPostProcess>(&dev.mPostProcess);
-            if(!mHrtf || dev.NumAuxSends || !pp || !pp->mHrtfState)
-                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: the pipelined mode covers RenderMode::Hrtf devices without auxiliary sends");
+            if(dev.NumAuxSends || !pp || !pp->mHrtfState)
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: the pipelined mode covers devices without auxiliary sends whose post-process "
+                    "is HrtfPostProcess or AmbiDecPostProcess");
             DirectHrtfState &st = *pp->mHrtfState;
             std::vector<float> coeffs(st.mChannels.size() * HrirLength * 2), hf(st.mChannels.size());
             for(size_t c{0}; c < st.mChannels.size(); ++c)
@@ -1033,6 +1075,7 @@ private:
     std::vector<uint64_t> mIndexBorn;               /* [device voice] the update it was initialised in */
     std::vector<oalgpu_voice_event> mEvents;
     HrtfPostProcess mSavedPost;
+    AmbiDecPostProcess mSavedDec;                   /* (a RenderMode::Normal device's, while its decode runs behind the boundary) */
     oalgpu_context *mGpu{nullptr};
     bool mHrtf{false};
     bool mNfc{false};                               /* the device context has near-field control (DeviceBase::AvgSpeakerDist > 0) */

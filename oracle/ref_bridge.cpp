@@ -40,11 +40,19 @@
 #include <span>
 #include "alnumeric.h"
 #include "opthelpers.h"
+#include <cstddef>
+#include <memory>
+#include <variant>
+#include <vector>
+#include "core/bufferline.h"
+#include "core/devformat.h"
+#include "core/filters/splitter.h"
 #define private public
 #define protected public
 #define class struct
 #include "core/filters/biquad.h"
 #include "core/filters/nfc.h"           /* (NfcFilter's sections: the binding recovers w0 from them, oalgpu_openal::NfcW0) */
+#include "core/bformatdec.h"            /* (BFormatDec::mChannelDec: the pipelined mode hands the speaker decode to the device context) */
 #undef class
 #undef private
 #undef protected

@@ -465,13 +465,16 @@ def test_pipelined_batch_mixer_delivers_the_same_render_two_updates_late(nsource
 
 @pytest.mark.gpu
 @needs_bridge
+@pytest.mark.parametrize("hrtf", [True, False], ids=["hrtf-device", "stereo-device"])
 @pytest.mark.parametrize("kind", ["stereo", "queue", "delay"])
-def test_pipelined_batch_mixer_with_the_other_voice_kinds(kind):
+def test_pipelined_batch_mixer_with_the_other_voice_kinds(kind, hrtf):
     """the pipelined mode with a multi-channel source, a streaming source on a growing queue (its progress comes back in the change
-    reports) and a delayed start among the mono sources: the render is the reference's, two updates late"""
+    reports) and a delayed start among the mono sources: the render is the reference's, two updates late -- on the HRTF device
+    (HrtfPostProcess behind the boundary) and on the stereo device (AmbiDecPostProcess: the BFormatDec speaker decode behind it,
+    the real output lines coming back)"""
     import oalgpu
-    want, _, _ = render_kinds(bl.MODE_CPU, kind, hrtf=True)
-    got, _, _ = render_kinds(bl.MODE_BATCH, kind, math_mode=oalgpu.MATH_FAST, hrtf=True, track=True, pipelined=2)
+    want, _, _ = render_kinds(bl.MODE_CPU, kind, hrtf=hrtf)
+    got, _, _ = render_kinds(bl.MODE_BATCH, kind, math_mode=oalgpu.MATH_FAST, hrtf=hrtf, track=True, pipelined=2)
     assert got.shape[0] == want.shape[0] + 2 * 1024 and not got[:2048].any()
     err = float(np.abs(got[2048:].astype(np.float64) - want).max())
     bound = 2e-5 * float(np.abs(want).max()) + 1e-7
