@@ -86,6 +86,59 @@ def test_slice_voice_kernel_keeps_its_lines_in_registers(tmp_path):
     assert 2 * granule(m["group_segment_fixed_size"], 1280) <= 160 * 1024, (name, m)
 
 
+def full_metadata(tmp_path, source):
+    """the kernels of a translation unit that needs the Makefile's complete flag set (include paths, per-file flags)"""
+    hip, per_file = makefile_flags()
+    out = tmp_path / (source + ".s")
+    subprocess.run([HIPCC, *hip, *per_file.get(source[:-4], []), "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", str(out),
+                    os.path.join(CSRC, source)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    meta = {}
+    for block in re.split(r"\n  - ", text[text.index("amdhsa.kernels:"):])[1:]:
+        fields = dict(re.findall(r"\.(\w+):\s+(\S+)", block))
+        if "name" in fields:
+            meta[fields["name"]] = {k: int(v) for k, v in fields.items() if v.isdigit()}
+    return meta, text
+
+
+def test_voice_per_wavefront_hrtf_kernel_runs_four_wavefronts_per_simd(voice_kernel, tmp_path):
+    """csrc/voice_wave16.hip (the HRTF voice kernel of round 6): a voice per wavefront at FOUR wavefronts per SIMD --
+    <= 112 registers beside the post stream's reduction (512 per SIMD lane, granules of 8), no scratch, the 16-wavefront
+    workgroup's LDS within one CU's 160 KB together with the post-process's granules, the 8-wavefront one twice per CU."""
+    _, per_file = makefile_flags()
+    assert "-disable-machine-licm" in per_file["voice_wave16"]
+    meta, _ = full_metadata(tmp_path, "voice_wave16.hip")
+    k16 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi16E" in n)
+    k8 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi8E" in n)
+    k4 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi4E" in n)
+    reduce4 = next(m for n, m in voice_kernel.items() if "BusReduceKernelILi4E" in n)
+    for m in (k16, k8):
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, m
+        assert 4 * granule(m["vgpr_count"] + m.get("agpr_count", 0)) <= 512, m        # four wavefronts per SIMD
+    # the headline form (16 wavefronts: a machine-filling scene): four voice wavefronts AND one of the reduction's on a SIMD
+    assert k16["vgpr_count"] + k16.get("agpr_count", 0) <= 112, k16
+    assert 4 * granule(k16["vgpr_count"] + k16.get("agpr_count", 0)) + granule(reduce4["vgpr_count"]) <= 512, (k16, reduce4)
+    post = kernel_metadata(tmp_path, "post_wave.hip", ["-mllvm", "-amdgpu-load-store-vectorizer=0"])
+    fused = next(m for n, m in post.items() if "PostFusedKernel" in n)
+    assert granule(k16["group_segment_fixed_size"], 1280) + granule(fused["group_segment_fixed_size"], 1280) <= 160 * 1024, k16
+    assert 2 * granule(k8["group_segment_fixed_size"], 1280) <= 160 * 1024, k8
+    # (small scenes: four wavefronts per workgroup, two per SIMD at most -- the register form of rounds 1-5)
+    assert k4["vgpr_spill_count"] == 0 and k4["vgpr_count"] + k4.get("agpr_count", 0) <= 256, k4
+
+
+def test_rows_in_lds_kernel_keeps_32_lines_per_wavefront_in_registers(tmp_path):
+    """csrc/voice_rows.hip (dry lines AND sends): eight wavefronts, two per SIMD, 32 line accumulators x 2 frames per
+    lane in registers for the whole launch -- no scratch (an accumulator indexed at run time, or a whole-array copy of the
+    resampler's outputs, puts them there: both happened while it was written) -- and ONE workgroup per CU."""
+    _, per_file = makefile_flags()
+    assert "-disable-machine-licm" in per_file["voice_rows"]
+    meta, _ = full_metadata(tmp_path, "voice_rows.hip")
+    (name, m), = [(n, m) for n, m in meta.items() if "VoiceRowsKernelILb0E" in n]
+    assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
+    assert m["vgpr_count"] + m.get("agpr_count", 0) <= 256, (name, m)
+    assert 80 * 1024 < m["group_segment_fixed_size"] <= 160 * 1024, (name, m)      # (one per CU by its LDS: the grid is sized for that)
+
+
 def test_reduction_fits_beside_the_hrtf_voice_kernel(voice_wave, voice_kernel, tmp_path):
     reduce4 = next(m for n, m in voice_kernel.items() if "BusReduceKernelILi4E" in n)
     assert reduce4["vgpr_spill_count"] == 0
