@@ -180,9 +180,9 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kRowsThreads) VoiceRowsKe
     const uint32_t vEnd = (vBegin + vpg < L.numVoices) ? vBegin + vpg : L.numVoices;
     const uint32_t lastVoice = L.numVoices - 1u;
 
-    float acc[kRowsLines][2];
+    f2 acc[kRowsLines];                         // (a line's two frames are ONE packed operand: v_pk_fma_f32 with the gain in a scalar pair)
 #pragma unroll
-    for(int c = 0; c < kRowsLines; ++c) { acc[c][0] = 0.0f; acc[c][1] = 0.0f; }
+    for(int c = 0; c < kRowsLines; ++c) acc[c] = f2{0.0f, 0.0f};
 
     // ---- the workgroup's resampler rows: those of its first voice (LDS-DMA, voice_wave16.hip); a voice on other rows takes the
     // generic loader ----
@@ -535,8 +535,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kRowsThreads) VoiceRowsKe
                     for(int i = 0; i < 4; ++i)
                     {
                         const float g = RowsReadLaneF(gv[ww], 4 * b + i);
-                        acc[4 * b + i][0] = __builtin_fmaf(x0[ww], g, acc[4 * b + i][0]);
-                        acc[4 * b + i][1] = __builtin_fmaf(x1[ww], g, acc[4 * b + i][1]);
+                        acc[4 * b + i] = pkfma(f2{x0[ww], x1[ww]}, splat(g), acc[4 * b + i]);
                     }
                 }
                 if(maxFade != 0u && wave == 0u)
@@ -552,7 +551,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kRowsThreads) VoiceRowsKe
                         for(int i = 0; i < 4; ++i)
                         {
                             const float a = RowsReadLaneF(av, 4 * b + i), bb = RowsReadLaneF(bv, 4 * b + i);
-                            acc[4 * b + i][0] = __builtin_fmaf(xr, __builtin_fmaf(bb, fl, a), acc[4 * b + i][0]);
+                            acc[4 * b + i].x = __builtin_fmaf(xr, __builtin_fmaf(bb, fl, a), acc[4 * b + i].x);
                         }
                     }
                 }
@@ -732,8 +731,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(kRowsThreads) VoiceRowsKe
         {   // (no early exit: the loop must unroll, or the accumulators are indexed at run time and live in scratch)
             if(uint32_t(c) < L.mixLines)
             {
-                StorePartial(pl + size_t(c) * kLine, acc[c][0]);
-                StorePartial(pl + size_t(c) * kLine + 64, acc[c][1]);
+                StorePartial(pl + size_t(c) * kLine, acc[c].x);
+                StorePartial(pl + size_t(c) * kLine + 64, acc[c].y);
             }
         }
     }
