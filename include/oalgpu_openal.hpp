@@ -130,7 +130,11 @@ public:
         : mMathMode{mathMode}, mDevice{device}, mMaxVoices{maxVoices} { }
     BatchMixer(const BatchMixer&) = delete;
     BatchMixer &operator=(const BatchMixer&) = delete;
-    ~BatchMixer() { if(mGpu) oalgpu_context_destroy(mGpu); }
+    ~BatchMixer()
+    {
+        if(mGpu) oalgpu_context_destroy(mGpu);
+        for(oalgpu_reverb *r : mReverbs) oalgpu_reverb_destroy(r);
+    }
 
     int error() const { return mError; }
     const std::string &errorText() const { return mErrorText; }
@@ -230,8 +234,9 @@ public:
      * latency the application sees as `depth` x update size more output latency -- and Voice::mPosition is refreshed with such
      * a report only (GetSourceOffset: oalgpu_voices_readback).  On a RenderMode::Normal device the post-process that moves is the
      * speaker decode (AmbiDecPostProcess: BFormatDec's matrix and crossover go to oalgpu_set_bformat_decoder) and the lines that
-     * come back are the device's real output lines.  Scope: devices without auxiliary sends (effect slots would have to move
-     * behind the boundary too: oalgpu_slot_set_*), a constant update size.  drain() collects what is
+     * come back are the device's real output lines.  Auxiliary sends on an HRTF device: the effect slots move too -- EAX reverb
+     * slots are bound once (oalgpu_reverb_create / _update from the slot's ReverbProps, oalgpu_slot_set_reverb), see createContext.
+     * Scope: a constant update size; sends on RenderMode::Normal devices and other effect types are not pipelined.  drain() collects what is
      * outstanding (before the device stops, or before leaving the mode). */
     void setPipelined(unsigned depth) { mDepth = std::min(depth, 2u); }
     bool pipelined() const { return mDepth != 0u; }
@@ -460,9 +465,44 @@ private:
         else if(mDepth)
         {   /* the post-process moves behind the boundary with the decoder InitHrtfPanning built (alc/panning.cpp:1100-1134) */
             auto *pp = std::get_if<HrtfPostProcess>(&dev.mPostProcess);
-            if(dev.NumAuxSends || !pp || !pp->mHrtfState)
-                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: the pipelined mode covers devices without auxiliary sends whose post-process "
-                    "is HrtfPostProcess or AmbiDecPostProcess");
+            if(!pp || !pp->mHrtfState)
+                return failText(OALGPU_ERR_INVALID, "oalgpu_openal: the pipelined mode covers devices whose post-process is HrtfPostProcess or "
+                    "AmbiDecPostProcess");
+            /* Auxiliary sends: the effect slots move behind the boundary as well -- nothing of a wet bus comes back in this mode, so what
+             * the slots' effects add to the dry lines has to be added THERE, in front of the device's post-process.  Covered: EAX reverb
+             * slots (EffectSlotBase::mEffectProps as ReverbProps, the slot's gain) on a device whose dry lines are ACN first order in
+             * order -- oalgpu_reverb_update pans for that map (ComputePanGains with AmbiMap[i] = {1, i}); the properties as they are
+             * when the mode is entered (a changed slot goes through leavePipelined / setPipelined).  The reference's own effect leg
+             * (alu.cpp:2209-2257) keeps running on the wet buffers nobody mixes into any more: silence in, silence out. */
+            if(dev.NumAuxSends)
+            {
+                if(dev.Dry.Buffer.size() != 4u) return failText(OALGPU_ERR_INVALID, "oalgpu_openal: pipelined sends need first-order ACN dry lines");
+                for(size_t i{0}; i < 4u; ++i)
+                    if(dev.Dry.AmbiMap[i].Index != i || dev.Dry.AmbiMap[i].Scale != 1.0f)
+                        return failText(OALGPU_ERR_INVALID, "oalgpu_openal: pipelined sends need first-order ACN dry lines");
+                for(size_t sidx{0}; sidx < auxslots.size(); ++sidx)
+                {
+                    EffectSlotBase *slot = auxslots[sidx];
+                    auto const *rp = std::get_if<ReverbProps>(&slot->mEffectProps);
+                    if(slot->EffectType != EffectSlotType::Reverb || !rp)
+                        return failText(OALGPU_ERR_INVALID, "oalgpu_openal: the pipelined mode binds EAX reverb slots only");
+                    oalgpu_reverb *rev{nullptr};
+                    if(int rc = oalgpu_reverb_create(mDevice, dev.mSampleRate, uint32_t(dev.Dry.Buffer.size()), &rev)) return fail(rc, "oalgpu_reverb_create");
+                    mReverbs.push_back(rev);
+                    oalgpu_reverb_props q{};
+                    q.density = rp->Density; q.diffusion = rp->Diffusion; q.gain = rp->Gain; q.gain_hf = rp->GainHF; q.gain_lf = rp->GainLF;
+                    q.decay_time = rp->DecayTime; q.decay_hf_ratio = rp->DecayHFRatio; q.decay_lf_ratio = rp->DecayLFRatio;
+                    q.reflections_gain = rp->ReflectionsGain; q.reflections_delay = rp->ReflectionsDelay;
+                    q.late_reverb_gain = rp->LateReverbGain; q.late_reverb_delay = rp->LateReverbDelay;
+                    for(size_t k{0}; k < 3u; ++k) { q.reflections_pan[k] = rp->ReflectionsPan[k]; q.late_reverb_pan[k] = rp->LateReverbPan[k]; }
+                    q.echo_time = rp->EchoTime; q.echo_depth = rp->EchoDepth; q.modulation_time = rp->ModulationTime;
+                    q.modulation_depth = rp->ModulationDepth; q.air_absorption_gain_hf = rp->AirAbsorptionGainHF;
+                    q.hf_reference = rp->HFReference; q.lf_reference = rp->LFReference; q.room_rolloff_factor = rp->RoomRolloffFactor;
+                    q.decay_hf_limit = rp->DecayHFLimit ? 1 : 0;
+                    if(int rc = oalgpu_slot_set_reverb(mGpu, uint32_t(sidx), rev)) return fail(rc, "oalgpu_slot_set_reverb");
+                    if(int rc = oalgpu_reverb_update(rev, &q, slot->Gain)) return fail(rc, "oalgpu_reverb_update");
+                }
+            }
             DirectHrtfState &st = *pp->mHrtfState;
             std::vector<float> coeffs(st.mChannels.size() * HrirLength * 2), hf(st.mChannels.size());
             for(size_t c{0}; c < st.mChannels.size(); ++c)
@@ -1075,6 +1115,7 @@ private:
     std::vector<uint64_t> mIndexBorn;               /* [device voice] the update it was initialised in */
     std::vector<oalgpu_voice_event> mEvents;
     HrtfPostProcess mSavedPost;
+    std::vector<oalgpu_reverb*> mReverbs;           /* the pipelined mode's EAX reverb instances, one per bound effect slot */
     AmbiDecPostProcess mSavedDec;                   /* (a RenderMode::Normal device's, while its decode runs behind the boundary) */
     oalgpu_context *mGpu{nullptr};
     bool mHrtf{false};

@@ -82,10 +82,12 @@ def test_batched_update_behind_the_reference_voice_loop(math_mode, scene):
 HRTF_TODO = (1024, 1024, 640, 1024)
 
 
-def render_hrtf(mode, math_mode=1, nsources=256, i16=False, todo=HRTF_TODO, slot_gain=1.0, stop=False, restart=False):
+def render_hrtf(mode, math_mode=1, nsources=256, i16=False, todo=HRTF_TODO, slot_gain=1.0, stop=False, restart=False, pipelined=0):
     import oracle_lib as ol
     b = bl.Bridge(mode, math_mode, hrtf=True, num_sends=1)
     slot = b.add_reverb_slot(ol.ReverbProps.make(), slot_gain)
+    if pipelined:
+        b.set_pipelined(pipelined)                      # (behind the slot: the mode binds the effect slots that exist when it is entered)
     srcs = bl.build_config3(b, nsources, i16=i16, slot=slot)
     out, live = [], []
     for k, n in enumerate(todo):
@@ -101,6 +103,9 @@ def render_hrtf(mode, math_mode=1, nsources=256, i16=False, todo=HRTF_TODO, slot
                                  0.5 if j % 2 else 1.0, slot, 0.5, 1.0)
         out.append(b.render(n))
         live.append(b.batch_live_voices())
+    if pipelined:
+        out.extend(b.drain(1024))
+        assert not b.error(), b.error()                 # (no update fell back to the CPU loop)
     states = [b.source_state(v) + b.source_flags(v) for v in srcs]
     b.close()
     return np.concatenate(out), states, live
@@ -125,6 +130,27 @@ def test_reference_plumbing_renders_the_hrtf_device_on_the_cpu():
     # the slot's reverb is part of the render: without the slot's gain the output differs
     dry, _, _ = render_hrtf(bl.MODE_CPU, nsources=64, slot_gain=0.0)
     assert np.abs(a - dry).max() > 1e-4
+
+
+@pytest.mark.gpu
+@needs_bridge
+def test_pipelined_batch_mixer_with_a_send_into_an_eax_reverb_slot():
+    """BatchMixer::setPipelined on the HRTF device WITH an auxiliary send: the effect slot moves behind the boundary too -- an
+    oalgpu_reverb created from the slot's ReverbProps and gain, bound with oalgpu_slot_set_reverb -- so that what the reverb adds to
+    the dry lines is added in front of the device's post-process, on the GPU; the render is the reference's (its Voice::mix, its
+    ReverbState, its MixDirectHrtf), two updates late."""
+    import oalgpu
+    todo = (1024,) * 7
+    want, sw, _ = render_hrtf(bl.MODE_CPU, todo=todo, stop=True)
+    got, sg, _ = render_hrtf(bl.MODE_BATCH, math_mode=oalgpu.MATH_FAST, todo=todo, stop=True, pipelined=2)
+    assert got.shape[0] == want.shape[0] + 2048 and not got[:2048].any()
+    scale = float(np.abs(want).max())
+    err = float(np.abs(got[2048:].astype(np.float64) - want).max())
+    assert err <= 4e-5 * scale + 1e-7, (err, scale)     # (the FAST reverb's block scans against the reference's serial filters)
+    assert [s[0] for s in sg] == [s[0] for s in sw]
+    # the reverb is part of the pipelined render: the same scene with the slot's gain at zero differs
+    dry, _, _ = render_hrtf(bl.MODE_CPU, todo=todo, stop=True, slot_gain=0.0)
+    assert float(np.abs(dry - want).max()) > 1e-4
 
 
 @pytest.mark.gpu
