@@ -217,11 +217,13 @@ typedef struct oalgpu_context_desc {
                                    * row ever leaves the CU (csrc/voice_slice.hip).  Measured on BASELINE configs[3]: the voice kernel's
                                    * HBM traffic falls to a third and its time nearly doubles -- the per-voice work is done four times and the
                                    * kernel is instruction-bound: an opt-in variant, for A/B runs.  Other contexts ignore it. */
-#define OALGPU_CTX_WAVE_PAIRS 256u /* FAST HRTF contexts without sends (IrSize <= 64) mix one voice per wavefront at four wavefronts per SIMD --
-                                   * 16, 8 or 4 wavefronts per workgroup by the scene's size; the resampler's outputs in registers, one ear's FIR
-                                   * inputs at a time (csrc/voice_wave16.hip).  This flag selects the form of rounds 1-5 instead:
-                                   * two voices per wavefront, two wavefronts per SIMD (csrc/voice_wave.hip) -- for A/B runs; OALGPU_CTX_RESIDENT,
-                                   * which exists for that form only, implies it.  Other contexts ignore the flag. */
+#define OALGPU_CTX_WAVE_PAIRS 256u /* FAST HRTF contexts (IrSize <= 64) mix one voice per wavefront at four wavefronts per SIMD -- 16, 8 or 4 wavefronts
+                                   * per workgroup by the scene's size; the resampler's outputs in registers, one ear's FIR inputs at a time
+                                   * (csrc/voice_wave16.hip); with auxiliary sends the send's signal leaves as one stream row per
+                                   * voice and send, and a small kernel behind the voice kernel mixes the rows onto the slots' wet lines.  This flag
+                                   * selects the form of rounds 1-5 instead: two voices per wavefront, two wavefronts per SIMD, one first-order
+                                   * slot's wet lines in registers (csrc/voice_wave.hip) -- for A/B runs; OALGPU_CTX_RESIDENT, which exists for that
+                                   * form only, implies it.  Other contexts ignore the flag. */
 #define OALGPU_CTX_ROW_SLICES 512u /* (the DEFAULT form of these contexts since round 6; the flag is accepted and names it.)  FAST dry-line contexts
                                    * with sends (or 7 .. 32 mix lines; no near-field control): a voice's signals never leave the compute unit AND
                                    * its fixed work is done once -- a wavefront per voice resamples into a 4 KB slot of LDS, the round's filtered

@@ -45,7 +45,11 @@ static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
     // buses than the context's buffers were sized for (the wavefront-per-voice kernel's grid has at least twice as many)
     if(c->useWave)
     {
-        const bool want16 = !(c->desc.flags & (OALGPU_CTX_WAVE_PAIRS | OALGPU_CTX_RESIDENT)) && Wave16Applies(L);
+        // (with sends: the voice-per-wavefront kernel leaves the sends' signals as stream rows and a small kernel behind it mixes them --
+        // the HRTF path keeps its four wavefronts per SIMD; OALGPU_CTX_WAVE_PAIRS keeps the wet lines in the registers of the
+        // two-voices-per-wavefront kernel, OALGPU_CTX_STREAM_ROWS its stream rows)
+        const bool want16 = !(c->desc.flags & (OALGPU_CTX_WAVE_PAIRS | OALGPU_CTX_RESIDENT)) && Wave16Applies(L)
+            && (L.numSends == 0 || !(c->desc.flags & (OALGPU_CTX_STREAM_ROWS | OALGPU_CTX_PROFILE | OALGPU_CTX_SLICE_LINES)));
         uint32_t cus = 256u;
         {
             hipDeviceProp_t prop{};
@@ -53,6 +57,11 @@ static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
             else (void)hipGetLastError();
         }
         L.wave16 = want16 ? Wave16WavesFor(L.numVoices, cus) : 0u;
+        if(L.wave16 && L.numSends)
+        {
+            L.accLines = 0;
+            if(!L.streams) { if(int rc = AllocStreamRows(c)) return rc; }
+        }
         const uint32_t groups = std::max<uint32_t>(1u, WaveKernelGroups(L));
         if(groups > c->groupsAllocated) return Fail(OALGPU_ERR_INVALID, "internal: the voice kernel's grid outgrew the partial buses");
         L.numGroups = groups; L.numLineGroups = groups;

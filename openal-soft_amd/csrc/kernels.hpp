@@ -479,6 +479,8 @@ hipError_t LaunchVoiceRows(hipStream_t s, const DeviceLayout &L, uint32_t sample
     const ParamRecord *nextRecs, const int32_t *nextMap);
 // ---- launcher (voice_wave16.hip): the HRTF hot path at four wavefronts per SIMD, one voice per wavefront ----
 bool Wave16Applies(const DeviceLayout &L);
+// the rows of workgroup-sized runs of voices onto partial buses, as a launch of its own (voice_wave.hip)
+hipError_t LaunchStreamRowsMix(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, uint32_t vpg, hipEvent_t evStop);
 uint32_t Wave16WavesFor(uint32_t voices, uint32_t cus);
 uint32_t Wave16Groups(const DeviceLayout &L);
 const char *Wave16KernelName(const DeviceLayout &L);

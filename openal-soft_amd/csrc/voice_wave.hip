@@ -147,12 +147,11 @@ __device__ __forceinline__ void MixRowAcc(float (&accL)[ACCL][R], float (&accRam
 // s * (rampA + rampB * f), the ramp's distance from the constant, behind the row's constant term.
 constexpr uint32_t kMixListMax = 512;             // live rows per staged chunk (>= kMixGainDwords / 32)
 constexpr uint32_t kMixGainDwords = 12288;        // staged gain blocks: 48 KB
-template<int S>
+template<int S, uint32_t kRowBatch = 4>
 __device__ __forceinline__ void WgMixRows(uint32_t *lds, const DeviceLayout &L, uint32_t group, uint32_t v0, uint32_t nv,
     uint32_t t, uint32_t N)
 {
     constexpr uint32_t kBlk = 3u * S + 8u;
-    constexpr uint32_t kRowBatch = 4;
     const uint32_t lane = t & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t spv = L.streamsPerVoice;
@@ -257,6 +256,18 @@ __device__ __forceinline__ void WgMixRows(uint32_t *lds, const DeviceLayout &L, 
         o.z = (4u * t + 2u < N) ? acc[c][2] : 0.0f; o.w = (4u * t + 3u < N) ? acc[c][3] : 0.0f;
         StorePartial(reinterpret_cast<f4*>(pl + size_t(c) * kLine), f4{o.x, o.y, o.z, o.w});
     }
+}
+
+// WgMixRows as a launch of its own (behind voice_wave16.hip's kernel with sends): workgroup g mixes the rows of voices
+// [g vpg, (g + 1) vpg) into partial bus g
+template<int S>
+__global__ void __launch_bounds__(kWThreads) StreamRowsMixKernel(DeviceLayout L, uint32_t samplesToDo, uint32_t vpg)
+{
+    __shared__ uint32_t lds[kMixListMax + 4u + kMixGainDwords];
+    const uint32_t group = blockIdx.x, v0 = group * vpg;
+    const uint32_t nv = v0 < L.numVoices ? ((L.numVoices - v0 < vpg) ? L.numVoices - v0 : vpg) : 0u;
+    // (a launch of its own has no resampler beside it to hide the rows' trip: a workgroup's sixteen live rows are requested at once)
+    WgMixRows<S, 4u>(lds, L, group, v0, nv, threadIdx.x, samplesToDo);
 }
 
 // NL == 0: HRTF voices (DoHrtfMix into the wave's register accumulator).
@@ -1700,7 +1711,16 @@ uint32_t WaveKernelGroups(const DeviceLayout &L)
 // evStart / evStop (both or neither): HIP events bound to the DISPATCH (hipExtLaunchKernel) -- the kernel's own start and end,
 // what rocprofv3's kernel trace reports, without the command-processor time an event recorded around the launch includes
 // the kernels whose wavefronts install a parameter block behind their voices: every VoiceWaveKernel (voice_slice.hip has no such epilogue)
-bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.sliceLines == 0; }      // (every VoiceWaveKernel; not the slice kernel)
+bool WaveKernelAppliesRecords(const DeviceLayout &L) { return L.sliceLines == 0 && !(L.wave16 && L.numSends); }      // (every VoiceWaveKernel; not the slice kernel, not voice_wave16.hip's with sends)
+
+hipError_t LaunchStreamRowsMix(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, uint32_t vpg, hipEvent_t evStop)
+{
+    const dim3 grid((L.numVoices + vpg - 1u) / vpg), block(kWThreads);
+    if(L.lineStride <= 8u) hipExtLaunchKernelGGL(StreamRowsMixKernel<8>, grid, block, 0, s, nullptr, evStop, 0u, L, samplesToDo, vpg);
+    else if(L.lineStride <= 16u) hipExtLaunchKernelGGL(StreamRowsMixKernel<16>, grid, block, 0, s, nullptr, evStop, 0u, L, samplesToDo, vpg);
+    else hipExtLaunchKernelGGL(StreamRowsMixKernel<32>, grid, block, 0, s, nullptr, evStop, 0u, L, samplesToDo, vpg);
+    return hipGetLastError();
+}
 
 hipError_t LaunchVoiceWave(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)

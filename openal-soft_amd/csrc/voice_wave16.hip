@@ -40,6 +40,7 @@ constexpr int kW16Rd2 = kMaxEdge + kPre * 64 + 8;       // the same window one s
 constexpr int kW16Area = kResampleDataSize + kLine;     // generic path: DeviceBase::mResampleData + the sample line
 static_assert(kW16Rd % 64 == 32 && kW16Rd >= kMaxPad + kPre * 64 + 8, "rd2 sits half the banks away from rd");
 static_assert(kW16Rd + kW16Rd2 <= kW16Area, "the twice-parked window fits");
+static_assert(kResampleDataSize >= kLine + 64, "a send's filter scan parks the unfiltered samples in the window's area");
 constexpr int kW16DumpF2 = 64 * 17 + 68;                // FirMfmaH's tiles as frames, 17 entries per 16 frames
 static_assert(kW16DumpF2 * 2 <= kW16Area, "the dump fits");
 struct W16PhaseB {
@@ -219,12 +220,20 @@ __device__ __forceinline__ uint32_t W16VoiceOf(uint32_t group, uint32_t wave, ui
 }
 
 struct Next16 { const ParamRecord *recs; const int32_t *map; const float *rows; };
+// SENDS: what the voice's auxiliary sends need of the context (voice.cpp:966-983).  The send's signal -- the resampled samples, through the
+// send's own filter pair when that is active -- leaves as ONE 4 KB stream row per voice and send with the resolved gains of the slot's
+// wet lines (voice_wave.hip's StoreRowBlock); StreamRowsMixKernel, launched behind this kernel, turns a workgroup's rows into its
+// partial wet lines.  The HRTF path keeps its 110 registers: no line accumulator lives beside the FIR.
+struct W16Sends {
+    BiquadSlot *sfilt; const float *sendTgt; float *sendCur; float *streams; uint32_t *lineGains;
+    uint32_t numSends, wetCh, lineStride, spv;
+};
 
 // PROF: the measurement variant (tools/phase_times16.py): s_memtime stamps per phase; the product variant carries none of it
 // WAVES: wavefronts (= voices) per workgroup -- 16 where the scene fills the machine that way (one workgroup per compute unit),
 // 8 or 4 for smaller scenes, so that every compute unit gets its share of them
-template<bool PROF, int WAVES>
-__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Kernel(WaveArgsHrtf L, uint32_t samplesToDo, Next16 next, WaveProf prof)
+template<bool PROF, int WAVES, bool SENDS = false>
+__global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Kernel(WaveArgsHrtf L, uint32_t samplesToDo, Next16 next, WaveProf prof, W16Sends S)
 {
     unsigned long long tEntry = 0;
     if constexpr (PROF) tEntry = __builtin_readcyclecounter();
@@ -406,6 +415,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
     float fstv = 0.0f, histv = 0.0f;
     f2 hT = {0.0f, 0.0f};
     int32_t bufferItem = head.curBuffer;
+    if constexpr (SENDS)
+    {   // nothing to mix for this voice in this update: the rows it left last time are dead (voice_wave.hip does the same)
+        if(haveVoice && !active && lane < S.spv)
+            S.lineGains[(size_t{v} * S.spv + lane) * LineBlockDwords(S.lineStride) + 3u * S.lineStride] = 0u;
+    }
     if(active)
     {
         float outs[kW16Outs];
@@ -463,32 +477,20 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
             for(int j = 0; j < kW16Outs; ++j) outs[j] = w.g.smp[lane + 64u * uint32_t(j)];
             WaveSync();
         };
-        if(head.flags & kFlagAmbiScale)
-        {   // VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
-            const AmbiScaleState a = L.ambi[v];
-            SplitterState sp{a.coeff, a.lpZ1, a.lpZ2, a.apZ1};
-            toLine();
-            SplitterScan<false>(sp, w.g.smp + outPos, N - outPos, a.hfScale, a.lfScale, lane);
-            fromLine();
-            if(lane == 0) { L.ambi[v].lpZ1 = sp.lpZ1; L.ambi[v].lpZ2 = sp.lpZ2; L.ambi[v].apZ1 = sp.apZ1; }
-        }
-        counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
-
-        // ---------------- DoFilters, direct path (voice.cpp:255-267) ----------------
+        // DoFilters (voice.cpp:255-267) for one filter pair whose 2 x 16 words are held lane-wise in `fv` (the states go through
+        // v_readlane into scalar registers: read back from LDS they were 26 vector registers at the scan's peak), over the sample line
+        auto doPair = [&](float fv, BiquadSlot *slots, bool on)
         {
-            const bool directFilter = (head.flags & kFlagDirectFilter) != 0;
             BiquadState f0, f1;
             {
                 float a[13], b[13];
 #pragma unroll
-                for(int k = 0; k < 13; ++k) { a[k] = W16ReadLaneF(fstv, k); b[k] = W16ReadLaneF(fstv, 16 + k); }
+                for(int k = 0; k < 13; ++k) { a[k] = W16ReadLaneF(fv, k); b[k] = W16ReadLaneF(fv, 16 + k); }
                 f0 = BiquadState{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], __builtin_bit_cast(int32_t, a[12])};
                 f1 = BiquadState{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11], __builtin_bit_cast(int32_t, b[12])};
             }
-            BiquadSlot *slots = &L.dfilt[size_t{v} * 2];
-            if(directFilter)
+            if(on)
             {
-                toLine();
                 if(f0.counter <= 0 && f1.counter <= 0)
                 {
                     BiquadDualWaveScan(f0, f1, w.g.smp + outPos, N - outPos, lane);
@@ -499,7 +501,6 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
                     if(lane == 0) BiquadDualInterp(f0, f1, w.g.smp + outPos, w.g.smp + outPos, N - outPos);
                     if(lane == 0) { slots[0].f = f0; slots[1].f = f1; }
                 }
-                fromLine();
             }
             else
             {   // an inactive pair is cleared (voice.cpp:264-265); the store is skipped when it already is clear
@@ -513,6 +514,119 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
                     slots[0].f = f0; slots[1].f = f1;
                 }
             }
+        };
+        if(head.flags & kFlagAmbiScale)
+        {   // VoiceFlag::IsAmbisonic: mAmbiSplitter.processScale, voice.cpp:1082-1091
+            const AmbiScaleState a = L.ambi[v];
+            SplitterState sp{a.coeff, a.lpZ1, a.lpZ2, a.apZ1};
+            toLine();
+            SplitterScan<false>(sp, w.g.smp + outPos, N - outPos, a.hfScale, a.lfScale, lane);
+            fromLine();
+            if(lane == 0) { L.ambi[v].lpZ1 = sp.lpZ1; L.ambi[v].lpZ2 = sp.lpZ2; L.ambi[v].apZ1 = sp.apZ1; }
+        }
+        counter = (head.flags & kFlagFading) ? (N < 64u ? N : 64u) : 0u;     // voice.cpp:1093
+
+        if constexpr (SENDS)
+        {   // ---------------- the auxiliary sends (voice.cpp:966-983): their rows leave before the direct filter runs ----------------
+            const uint32_t ls = S.lineStride, spv = S.spv, numSends = S.numSends, wetCh = S.wetCh;
+            float *rowsV = S.streams + size_t{v} * spv * kLine;
+            uint32_t *blkV = S.lineGains + size_t{v} * spv * LineBlockDwords(ls);
+            int32_t sendSlots[6];
+            {   // VoiceCtl::sendSlot, bytes 48..71 of the voice's control line: through the scalar cache
+                static_assert(offsetof(VoiceCtl, sendSlot) == 48, "VoiceCtl::sendSlot follows the head");
+                cu4 *src = (cu4*)(uintptr_t)(L.ctl + v);
+                const u4 a = src[3], b = src[4];
+                sendSlots[0] = int32_t(a.x); sendSlots[1] = int32_t(a.y); sendSlots[2] = int32_t(a.z); sendSlots[3] = int32_t(a.w);
+                sendSlots[4] = int32_t(b.x); sendSlots[5] = int32_t(b.y);
+            }
+            RowLineGain row0;                           // the unfiltered row's merged gains, wet line = lane
+            bool row0Live = false;
+            for(uint32_t si = 0; si < numSends; ++si)
+            {
+                int32_t slot = sendSlots[0];
+#pragma unroll
+                for(int k = 1; k < 6; ++k) slot = (si == uint32_t(k)) ? sendSlots[k] : slot;
+                uint32_t *blkS = blkV + size_t{2u + si} * LineBlockDwords(ls);
+                if(slot < 0) { if(lane == 0) blkS[3u * ls] = 0u; continue; }
+                const size_t vs = size_t{v} * numSends + si;
+                const bool sendFilter = (head.flags >> (kFlagSendFilterShift + si)) & 1u;
+                BiquadSlot *slots = &S.sfilt[vs * 2];
+                {   // DoFilters with the send's pair FIRST, with nothing of the gains alive across the scan (its registers are the
+                    // section's peak): the filtered copy stays in the sample line's place, the unfiltered samples wait in the
+                    // window's area (dead behind the resampler) -- in registers across the scan they were 16 more
+                    const float sfC = (lane < 32u) ? reinterpret_cast<const float*>(&S.sfilt[vs * 2])[lane] : 0.0f;
+                    if(sendFilter)
+                    {
+                        float *bak = w.g.rd;
+#pragma unroll
+                        for(int j = 0; j < kW16Outs; ++j) bak[lane + 64u * uint32_t(j)] = outs[j];
+                        toLine();
+                        doPair(sfC, slots, true);
+                        WaveSync();
+#pragma unroll
+                        for(int j = 0; j < kW16Outs; ++j) outs[j] = bak[lane + 64u * uint32_t(j)];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    else doPair(sfC, slots, false);
+                }
+                // the send's gains onto its slot's wet lines (voice.cpp:978-979); an HRTF context's mix lines ARE the wet lines
+                float stC = 0.0f, scC = 0.0f;
+                if(lane < wetCh) { stC = S.sendTgt[vs * wetCh + lane]; scC = S.sendCur[vs * wetCh + lane]; }
+                const uint32_t base = uint32_t(slot) * wetCh;
+                const bool mine = lane >= base && lane < base + wetCh;
+                float tg = 0.0f, cu = 0.0f;
+                float *curp = S.sendCur + vs * wetCh + (lane - base);
+                {
+                    const float tgS = __shfl(stC, int(lane - base)), cuS = __shfl(scC, int(lane - base));
+                    if(mine)
+                    {
+                        tg = playing ? tgS : 0.0f;
+                        cu = counter ? cuS : tg;
+                    }
+                }
+                const MixLineGain g = PrepareMixLine(cu, tg, counter, N);
+                if(mine) *curp = g.newCur;
+                if(sendFilter)
+                {
+                    RowLineGain r;
+                    if(mine) r.add(g);
+                    float *dst = rowsV + size_t{2u + si} * kLine;
+#pragma unroll
+                    for(int j = 0; j < kW16Outs; ++j)
+                    {
+                        const uint32_t k = lane + 64u * uint32_t(j);
+                        dst[k] = (k < N) ? w.g.smp[k] : 0.0f;
+                    }
+                    StoreRowBlock(blkS, ls, lane, r, true);
+                    WaveSync();
+                }
+                else
+                {
+                    if(mine) row0.add(g);
+                    row0Live = true;
+                    if(lane == 0) blkS[3u * ls] = 0u;
+                }
+            }
+            if(row0Live)
+            {
+#pragma unroll
+                for(int j = 0; j < kW16Outs; ++j) rowsV[lane + 64u * uint32_t(j)] = outs[j];
+            }
+            StoreRowBlock(blkV, ls, lane, row0, row0Live);
+            WaveSync();
+        }
+
+        // ---------------- DoFilters, direct path (voice.cpp:255-267) ----------------
+        {
+            const bool directFilter = (head.flags & kFlagDirectFilter) != 0;
+            BiquadSlot *slots = &L.dfilt[size_t{v} * 2];
+            if(directFilter)
+            {
+                toLine();
+                doPair(fstv, slots, true);
+                fromLine();
+            }
+            else doPair(fstv, slots, false);
         }
 
         stamp(2);
@@ -780,9 +894,12 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
 
 } // namespace
 
+// FAST HRTF contexts on the matrix-pipe FIR, without sends or -- `sends` -- with them (their rows leave as stream rows, see W16Sends)
 bool Wave16Applies(const DeviceLayout &L)
 {
-    return L.hrtf && L.numSends == 0 && L.firMfma && L.irStride >= 8 && L.irStride <= 64 && L.accLines == 0 && L.sliceLines == 0;
+    if(!(L.hrtf && L.firMfma && L.irStride >= 8 && L.irStride <= 64 && L.sliceLines == 0 && L.nfc == nullptr)) return false;
+    if(L.numSends == 0) return L.accLines == 0;
+    return L.numSends <= 6 && L.mixLines >= 1 && L.mixLines <= 32 && L.wetChannels <= 32u;
 }
 // wavefronts per workgroup for a scene of `voices` on a device of `cus` compute units: the smallest of 4 / 8 / 16 whose grid fits the
 // machine in one round (16 beyond that: the rounds follow each other out of phase)
@@ -794,6 +911,7 @@ uint32_t Wave16WavesFor(uint32_t voices, uint32_t cus)
 uint32_t Wave16Groups(const DeviceLayout &L) { return (L.numVoices + L.wave16 - 1u) / L.wave16; }
 const char *Wave16KernelName(const DeviceLayout &L)
 {
+    if(L.numSends) return L.wave16 == 16u ? "VoiceWave16Kernel<16, sends>" : (L.wave16 == 8u ? "VoiceWave16Kernel<8, sends>" : "VoiceWave16Kernel<4, sends>");
     return L.wave16 == 16u ? "VoiceWave16Kernel<16>" : (L.wave16 == 8u ? "VoiceWave16Kernel<8>" : "VoiceWave16Kernel<4>");
 }
 
@@ -803,14 +921,25 @@ hipError_t LaunchVoiceWave16(hipStream_t s, const DeviceLayout &L, uint32_t samp
     const Next16 next{nextRecs, nextMap, nextRows};
     const WaveProf none{nullptr, 0u};
     const dim3 grid(Wave16Groups(L)), block(L.wave16 * 64u);
-#define OALGPU_W16_LAUNCH(P, W, PA) hipExtLaunchKernelGGL((VoiceWave16Kernel<P, W>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, next, PA)
+    const W16Sends S{L.sfilt, L.sendTgt, L.sendCur, L.streams, L.lineGains, L.numSends, L.wetChannels, L.lineStride, L.streamsPerVoice};
+#define OALGPU_W16_LAUNCH(P, W, SD, PA) hipExtLaunchKernelGGL((VoiceWave16Kernel<P, W, SD>), grid, block, 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, samplesToDo, next, PA, S)
+    if(L.numSends)
+    {   // (no measurement variant and no parameter block installed by the kernel: WaveKernelAppliesRecords says so to the host)
+        // (the launch's stop event -- what the post stream waits for, and the end of what the host times -- belongs to the LAST kernel)
+        const Next16 noNext{nullptr, nullptr, nullptr};
+        if(L.wave16 == 16u) hipExtLaunchKernelGGL((VoiceWave16Kernel<false, 16, true>), grid, block, 0, s, evStart, nullptr, 0u, WaveArgsHrtf{L}, samplesToDo, noNext, none, S);
+        else if(L.wave16 == 8u) hipExtLaunchKernelGGL((VoiceWave16Kernel<false, 8, true>), grid, block, 0, s, evStart, nullptr, 0u, WaveArgsHrtf{L}, samplesToDo, noNext, none, S);
+        else hipExtLaunchKernelGGL((VoiceWave16Kernel<false, 4, true>), grid, block, 0, s, evStart, nullptr, 0u, WaveArgsHrtf{L}, samplesToDo, noNext, none, S);
+        if(hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        return LaunchStreamRowsMix(s, L, samplesToDo, L.wave16, evStop);     // (voice_wave.hip: the workgroups' rows onto their partial wet lines)
+    }
     if(prof)
     {
-        if(L.wave16 == 16u) OALGPU_W16_LAUNCH(true, 16, *prof); else if(L.wave16 == 8u) OALGPU_W16_LAUNCH(true, 8, *prof); else OALGPU_W16_LAUNCH(true, 4, *prof);
+        if(L.wave16 == 16u) OALGPU_W16_LAUNCH(true, 16, false, *prof); else if(L.wave16 == 8u) OALGPU_W16_LAUNCH(true, 8, false, *prof); else OALGPU_W16_LAUNCH(true, 4, false, *prof);
     }
     else
     {
-        if(L.wave16 == 16u) OALGPU_W16_LAUNCH(false, 16, none); else if(L.wave16 == 8u) OALGPU_W16_LAUNCH(false, 8, none); else OALGPU_W16_LAUNCH(false, 4, none);
+        if(L.wave16 == 16u) OALGPU_W16_LAUNCH(false, 16, false, none); else if(L.wave16 == 8u) OALGPU_W16_LAUNCH(false, 8, false, none); else OALGPU_W16_LAUNCH(false, 4, false, none);
     }
 #undef OALGPU_W16_LAUNCH
     return hipGetLastError();

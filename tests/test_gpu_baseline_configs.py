@@ -245,7 +245,15 @@ def test_config4_odd_update_lengths_and_a_ragged_last_workgroup(synth_mhr, path)
 
 
 def test_config5_4096_hrtf_voices_and_a_65536_tap_convolution(synth_mhr):
-    run_config(5, 4096, synth_mhr)
+    """the default form since round 6: the voice-per-wavefront HRTF kernel with the send's signal leaving as one stream row per voice,
+    mixed onto the slot's wet lines by a small kernel behind it (csrc/voice_wave16.hip: W16Sends, StreamRowsMixKernel)"""
+    run_config(5, 4096, synth_mhr, expect_kernel="VoiceWave16Kernel<16, sends>")
+
+
+def test_config5_wet_lines_in_the_registers_of_the_two_voice_kernel(synth_mhr):
+    """OALGPU_CTX_WAVE_PAIRS: the form of rounds 4-5 (two voices per wavefront, the slot's four wet lines accumulated in registers)"""
+    import oalgpu
+    run_config(5, 4096, synth_mhr, ctx_flags=oalgpu.CTX_WAVE_PAIRS, expect_kernel="DeviceLayout, 4>")
 
 
 # ---- SURVEY.md 8(d) "Parity check in the same run": after updates 1, 2, 8 and 50, f32 and i16 sources ----------------

@@ -108,15 +108,19 @@ def test_voice_per_wavefront_hrtf_kernel_runs_four_wavefronts_per_simd(voice_ker
     _, per_file = makefile_flags()
     assert "-disable-machine-licm" in per_file["voice_wave16"]
     meta, _ = full_metadata(tmp_path, "voice_wave16.hip")
-    k16 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi16E" in n)
-    k8 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi8E" in n)
-    k4 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi4E" in n)
+    k16 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi16ELb0E" in n)
+    k8 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi8ELb0E" in n)
+    k4 = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi4ELb0E" in n)
+    k16s = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi16ELb1E" in n)       # with sends (stream rows out of the registers)
     reduce4 = next(m for n, m in voice_kernel.items() if "BusReduceKernelILi4E" in n)
     for m in (k16, k8):
         assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, m
         assert 4 * granule(m["vgpr_count"] + m.get("agpr_count", 0)) <= 512, m        # four wavefronts per SIMD
     # the headline form (16 wavefronts: a machine-filling scene): four voice wavefronts AND one of the reduction's on a SIMD
     assert k16["vgpr_count"] + k16.get("agpr_count", 0) <= 112, k16
+    # ... and the same with sends (BASELINE configs[4]): read back from LDS the send's filter states put it at 123 registers,
+    # and the convolution's chain behind it lost its place beside the voices
+    assert k16s["vgpr_spill_count"] == 0 and k16s["private_segment_fixed_size"] == 0 and k16s["vgpr_count"] + k16s.get("agpr_count", 0) <= 112, k16s
     assert 4 * granule(k16["vgpr_count"] + k16.get("agpr_count", 0)) + granule(reduce4["vgpr_count"]) <= 512, (k16, reduce4)
     post = kernel_metadata(tmp_path, "post_wave.hip", ["-mllvm", "-amdgpu-load-store-vectorizer=0"])
     fused = next(m for n, m in post.items() if "PostFusedKernel" in n)
