@@ -184,11 +184,12 @@ typedef struct oalgpu_context_desc {
                                    * instead of the matrix pipe in split half precision */
 #define OALGPU_CTX_PROFILE  2u    /* the voice kernel's measurement variant: per-phase cycle stamps and stage ablation,
                                    * read and set through the measurement build only (tools/measure/oalgpu_measure.h) */
-#define OALGPU_CTX_STREAM_ROWS 8u  /* FAST contexts leave a 4 KB stream row per mixed signal in HBM and mix the rows in the voice kernel's tail
-                                   * (csrc/voice_wave.hip; the only form of contexts with near-field control and sends) instead of their default
-                                   * form -- the lines in the wavefronts' registers (dry-line contexts without sends and <= 6 lines; HRTF contexts
-                                   * with one first-order send) or the rows in LDS (dry-line contexts with sends or 7 .. 32 lines,
-                                   * csrc/voice_rows.hip): for A/B runs and tests of the row path */
+#define OALGPU_CTX_STREAM_ROWS 8u  /* FAST contexts leave a 4 KB stream row per mixed signal in HBM and mix the rows in the tail of the
+                                   * two-voices-per-wavefront kernel (csrc/voice_wave.hip; the only form of contexts with near-field control and
+                                   * sends) instead of their default form -- the lines in the wavefronts' registers (dry-line contexts without
+                                   * sends and <= 6 lines), the rows in LDS (dry-line contexts with sends or 7 .. 32 lines, csrc/voice_rows.hip),
+                                   * the voice-per-wavefront kernel with a row mixer behind it (HRTF contexts with sends, csrc/voice_wave16.hip):
+                                   * for A/B runs and tests of the row path */
 #define OALGPU_CTX_APPLY_IN_VOICE_KERNEL 16u /* pipelined HRTF contexts: oalgpu_mix_update is submitted with the NEXT library call on the
                                    * context, and when that call is oalgpu_param_block_apply the update's own voice kernel installs the
                                    * block (every wavefront the records of the voices it mixed) instead of a parameter kernel between
