@@ -198,8 +198,8 @@ typedef struct oalgpu_context_desc {
 #define OALGPU_CTX_FUSED_REDUCE 32u /* pipelined HRTF contexts without effect slots and without a collective: the bus reduction and the
                                    * post-process as ONE launch.  One launch less for the host, and measured 1.2-1.9 us per update
                                    * slower than the two launches: an opt-in variant, for A/B runs */
-#define OALGPU_CTX_RESIDENT 64u   /* pipelined FAST HRTF contexts without sends, effect slots or a collective (IrSize <= 64): ONE launch of the
-                                   * voice kernel stays on the machine over many updates.  Every oalgpu_mix_update (with its post-process) still
+#define OALGPU_CTX_RESIDENT 64u   /* pipelined FAST HRTF contexts without sends, effect slots or a collective (IrSize <= 64; a scene of more than 8 voices
+                                   * per compute unit, or OALGPU_CTX_WAVE_PAIRS): ONE launch of the voice kernel stays on the machine over many updates.  Every oalgpu_mix_update (with its post-process) still
                                    * submits one update and produces its own output: the call writes the update's doorbell slot -- the length and
                                    * the parameter block of the oalgpu_param_block_apply in front of it, which the kernel's wavefronts install for
                                    * their own voices -- and launches the update's reduction and post-process, which wait for device counters
@@ -223,8 +223,9 @@ typedef struct oalgpu_context_desc {
                                    * (csrc/voice_wave16.hip); with auxiliary sends the send's signal leaves as one stream row per
                                    * voice and send, and a small kernel behind the voice kernel mixes the rows onto the slots' wet lines.  This flag
                                    * selects the form of rounds 1-5 instead: two voices per wavefront, two wavefronts per SIMD, one first-order
-                                   * slot's wet lines in registers (csrc/voice_wave.hip) -- for A/B runs; OALGPU_CTX_RESIDENT, which exists for that
-                                   * form only, implies it.  Other contexts ignore the flag. */
+                                   * slot's wet lines in registers (csrc/voice_wave.hip) -- for A/B runs.  OALGPU_CTX_RESIDENT has a resident launch of
+                                   * either form: this kernel's with the flag, the 16-wavefront form of the voice-per-wavefront kernel (scenes that
+                                   * fill the machine) without.  Other contexts ignore the flag. */
 #define OALGPU_CTX_ROW_SLICES 512u /* (the DEFAULT form of these contexts since round 6; the flag is accepted and names it.)  FAST dry-line contexts
                                    * with sends (or 7 .. 32 mix lines; no near-field control): a voice's signals never leave the compute unit AND
                                    * its fixed work is done once -- a wavefront per voice resamples into a 4 KB slot of LDS, the round's filtered

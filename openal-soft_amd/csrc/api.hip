@@ -494,7 +494,7 @@ static int ResidentInit(oalgpu_context *c)
     hipDeviceProp_t prop{};
     HIP_TRY(hipGetDeviceProperties(&prop, c->desc.device));
     // every workgroup of the launch has to be on the machine at once: nothing ever leaves to make room
-    R.groupsPerCu = uint32_t(std::max(0, WaveResidentGroupsPerCu()));
+    R.groupsPerCu = uint32_t(std::max(0, WaveResidentGroupsPerCu(c->L)));
     if(uint64_t{R.groupsPerCu} * uint32_t(prop.multiProcessorCount) < c->L.numGroups)
         return ResidentGiveUp(c, "the device does not hold all of the launch's workgroups at once");
     // the reduce stream between the main stream's priority class (highest) and the post stream's (lowest): a class has its own

@@ -48,7 +48,7 @@ static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
         // (with sends: the voice-per-wavefront kernel leaves the sends' signals as stream rows and a small kernel behind it mixes them --
         // the HRTF path keeps its four wavefronts per SIMD; OALGPU_CTX_WAVE_PAIRS keeps the wet lines in the registers of the
         // two-voices-per-wavefront kernel, OALGPU_CTX_STREAM_ROWS its stream rows)
-        const bool want16 = !(c->desc.flags & (OALGPU_CTX_WAVE_PAIRS | OALGPU_CTX_RESIDENT)) && Wave16Applies(L)
+        const bool want16 = !(c->desc.flags & OALGPU_CTX_WAVE_PAIRS) && Wave16Applies(L)
             && (L.numSends == 0 || !(c->desc.flags & (OALGPU_CTX_STREAM_ROWS | OALGPU_CTX_PROFILE | OALGPU_CTX_SLICE_LINES)));
         uint32_t cus = 256u;
         {
@@ -65,7 +65,7 @@ static int InstallHrtfData(oalgpu_context *c, HrtfData &&parsed)
         const uint32_t groups = std::max<uint32_t>(1u, WaveKernelGroups(L));
         if(groups > c->groupsAllocated) return Fail(OALGPU_ERR_INVALID, "internal: the voice kernel's grid outgrew the partial buses");
         L.numGroups = groups; L.numLineGroups = groups;
-        if(L.wave16) c->res.enabled = false;
+        if(L.wave16 && (L.wave16 != 16u || L.numSends)) c->res.enabled = false;     // (the resident launch: the 16-wavefront form, or OALGPU_CTX_WAVE_PAIRS' kernel)
     }
     return OALGPU_OK;
 }

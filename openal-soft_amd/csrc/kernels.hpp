@@ -487,6 +487,8 @@ const char *Wave16KernelName(const DeviceLayout &L);
 hipError_t LaunchVoiceWave16(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows);
 hipError_t LaunchVoiceWaveResident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop);
-int WaveResidentGroupsPerCu();
+int WaveResidentGroupsPerCu(const DeviceLayout &L);
+hipError_t LaunchVoiceWave16Resident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop);
+int Wave16ResidentGroupsPerCu();
 
 } // namespace oalgpu

@@ -411,6 +411,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) BusR
 {
     __shared__ float slice[4][64];
     const uint32_t tid = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);              // (a short chain the resident voice wavefronts wait for: four of them share this SIMD, at priorities 2 .. 0)
     if(tid == 0)
     {
         if(!PostWaitCounter(A.counters + 16u * (kRcArrive0 + A.set), A.arriveTarget, 4, blockIdx.x == 0 ? A.counters + 16u * kRcWaitArrive : nullptr))
@@ -445,6 +446,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(64) __attribute__((amdgpu
     uint32_t reducedEpoch, PostResident PR)
 {
     __shared__ float xs[kLine + 64];
+    __builtin_amdgcn_s_setprio(3);
     PostFusedBlock<2>(xs, blockIdx.x, threadIdx.x, 0u, in, nch, spIn, spOut, hfscales, chanCoeffs, taps, accIn, carryOut, left, right, n,
         xf, arrived, epoch, runPower, hostOut, hostFlag, hostSeq, nullptr, reduced, reducedEpoch, PR);
 }

@@ -68,6 +68,7 @@ struct W16Wg {
     alignas(16) f2 tabF[12 * 32];                       // [tap pair][phase] = fil[2p], fil[2p+1]   (up to 24 taps)
     f2 tabP[12 * 32];
     uint32_t tabKey, tabM, tabL, pad;
+    uint32_t res[12];                                   // RES: what thread 0 learned at the door, for the workgroup
     W16Lds w[WAVES];
 };
 static_assert(sizeof(W16Wg<16>) <= 157440, "123 LDS granules: the post-process (4) and the reduction (1) fit beside it");
@@ -219,7 +220,7 @@ __device__ __forceinline__ uint32_t W16VoiceOf(uint32_t group, uint32_t wave, ui
     return group * waves + 4u * a + ((a + b) & 3u);
 }
 
-struct Next16 { const ParamRecord *recs; const int32_t *map; const float *rows; };
+struct Next16 { const ParamRecord *recs; const int32_t *map; const float *rows; ResidentArgs res; };   // (res: the resident launch's, RES)
 // SENDS: what the voice's auxiliary sends need of the context (voice.cpp:966-983).  The send's signal -- the resampled samples, through the
 // send's own filter pair when that is active -- leaves as ONE 4 KB stream row per voice and send with the resolved gains of the slot's
 // wet lines (voice_wave.hip's StoreRowBlock); StreamRowsMixKernel, launched behind this kernel, turns a workgroup's rows into its
@@ -232,7 +233,10 @@ struct W16Sends {
 // PROF: the measurement variant (tools/phase_times16.py): s_memtime stamps per phase; the product variant carries none of it
 // WAVES: wavefronts (= voices) per workgroup -- 16 where the scene fills the machine that way (one workgroup per compute unit),
 // 8 or 4 for smaller scenes, so that every compute unit gets its share of them
-template<bool PROF, int WAVES, bool SENDS = false>
+// RES: the resident launch (OALGPU_CTX_RESIDENT; the protocol: kernels.hpp ResidentDoor, voice_wave.hip) -- the kernel's body is one
+// UPDATE of a loop that ends when the host says so; everything a launch does per update it does per turn of that loop, in the same order
+// with the same operations: the bits are those of one launch per update (tests/test_gpu_resident.py).
+template<bool PROF, int WAVES, bool SENDS = false, bool RES = false>
 __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Kernel(WaveArgsHrtf L, uint32_t samplesToDo, Next16 next, WaveProf prof, W16Sends S)
 {
     unsigned long long tEntry = 0;
@@ -244,7 +248,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
     const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t group = blockIdx.x;
     const uint32_t irStride = L.irStride;
-    const uint32_t N = samplesToDo;
+    uint32_t N = samplesToDo;                   // (RES: every update brings its own length)
     W16Lds &w = sm.w[wave];
     asm volatile("; argument block resident" :: "s"(L.tables), "s"(L.buffers), "s"(L.ctl), "s"(L.prev), "s"(L.dfilt), "s"(L.hrtfOld),
         "s"(L.hrtfTgt), "s"(L.hist), "s"(L.ambi), "s"(L.startDelay), "s"(L.queueDone), "s"(L.partHrtf), "s"(L.hrirs),
@@ -255,6 +259,107 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
     const uint32_t lastVoice = L.numVoices - 1u;
     const uint32_t v = haveVoice ? vRaw : lastVoice;                 // (a wavefront without a voice reads a valid line and mixes nothing)
     const uint32_t keyVoice = group * uint32_t(kW16Waves);           // the voice whose resampler rows the workgroup stages
+
+    // ---- RES: this launch's turn of the update loop (one pass through the kernel's body otherwise) ----
+    uint32_t upd = 0u, updBase = 0u;
+    if constexpr (RES)
+    {
+        const ResidentArgs &RA = next.res;
+        upd = updBase = RA.base;
+        if(t == 0)
+        {   // the host launches nothing that waits for this kernel before every workgroup of it has a CU (see ResidentSubmit)
+            const uint32_t old = __hip_atomic_fetch_add(RA.counters + 16u * kRcStarted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(old + 1u == RA.startedTarget)
+                __hip_atomic_store(RA.hostFlags + 16u * kRhResident, RA.launchId, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    for(;;)
+    {
+    // RES: thread and lane index are re-derived per update behind an opaque move: what the body computes from them then is a few VALU
+    // per update, not a set of loop invariants kept in registers across the resampler and the FIR, whose peaks decide the register count
+    uint32_t tU = threadIdx.x;
+    if constexpr (RES) { asm volatile("" : "+v"(tU)); lane = tU & 63u; }
+    const uint32_t t = tU;
+    if constexpr (RES)
+    {
+        const ResidentArgs &RA = next.res;
+        // Thread 0 waits for the update: the doorbell (or the word to leave), and -- kResidentSets updates on -- for the reduction
+        // that still reads the partial set this update's sums go into (voice_wave.hip's loop, statement for statement).
+        if(t == 0)
+        {
+            const unsigned long long tTop = __builtin_amdgcn_s_memrealtime();
+            uint32_t go = 0u, fault = 0u;
+            unsigned long long recs = 0ull, map = 0ull, rowsP = 0ull;
+            uint32_t smp = 0u;
+            if(upd != RA.endSeq)
+            {
+                const ResidentDoor *door = RA.door;
+                const uint32_t *exitp = &door->exitSeq[RA.launchId & 3u];
+                const uint32_t *rr = RA.counters + 16u * kRcRedRead;
+                const bool needRed = int32_t(upd - kResidentSets) >= 0;
+                const uint32_t want = (upd - kResidentSets + 1u) * RA.redPerUpdate;
+                unsigned long long t0 = 0ull;
+                uint32_t waitedFor = 0u;                     // 1: the doorbell, 2: the reduction
+                for(uint32_t spins = 0;; ++spins)
+                {
+                    const uint32_t ex = ResLoadSys(exitp), sq = ResLoadSys(&door->seq), rd = needRed ? ResLoadDev(rr) : want;
+                    if(int32_t(ex - upd) <= 0) break;
+                    const bool rung = int32_t(sq - upd) > 0, redOk = int32_t(rd - want) >= 0;
+                    if(rung && redOk) { go = 1u; break; }
+                    if(spins == 0u) { t0 = __builtin_amdgcn_s_memrealtime(); waitedFor = rung ? 2u : 1u; }
+                    else if((spins & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t0 > kResidentWatchdogTicks)
+                    {
+                        fault = 1u;
+                        uint32_t *fi = RA.hostFlags + 16u * kRhFault;
+                        fi[0] = upd; fi[1] = sq; fi[2] = ex; fi[3] = rd; fi[4] = want; fi[5] = group; fi[6] = RA.launchId;
+                        fi[7] = uint32_t(__builtin_amdgcn_s_memrealtime() - t0);
+                        break;
+                    }
+                    if(spins < 32u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(24);
+                }
+                if(waitedFor && (group & 127u) == 0u)
+                    __hip_atomic_fetch_add(RA.counters + 16u * (waitedFor == 1u ? kRcWaitDoor : kRcWaitRed), uint32_t(__builtin_amdgcn_s_memrealtime() - t0),
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if(go)
+                {
+                    const ResidentSlot *sl = &door->slot[upd % kResidentSlots];
+                    recs = ResLoadSys(&sl->recs); map = ResLoadSys(&sl->map); rowsP = ResLoadSys(&sl->rows); smp = ResLoadSys(&sl->samples);
+                }
+            }
+            if(fault) __hip_atomic_store(RA.hostFlags + 16u * kRhError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if((group & 127u) == 0u)
+                __hip_atomic_fetch_add(RA.counters + 16u * kRcTop, uint32_t(__builtin_amdgcn_s_memrealtime() - tTop), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm.res[0] = go; sm.res[1] = smp;
+            sm.res[2] = uint32_t(recs); sm.res[3] = uint32_t(recs >> 32); sm.res[4] = uint32_t(map); sm.res[5] = uint32_t(map >> 32);
+            sm.res[8] = uint32_t(rowsP); sm.res[9] = uint32_t(rowsP >> 32);
+        }
+        __syncthreads();
+        const unsigned long long tSeen = __builtin_amdgcn_s_memrealtime();
+        if(__builtin_amdgcn_readfirstlane(sm.res[0]) == 0u) break;
+        N = __builtin_amdgcn_readfirstlane(sm.res[1]);
+        const unsigned long long recsU = (uint64_t{uint32_t(__builtin_amdgcn_readfirstlane(sm.res[3]))} << 32) | uint32_t(__builtin_amdgcn_readfirstlane(sm.res[2]));
+        const unsigned long long mapU = (uint64_t{uint32_t(__builtin_amdgcn_readfirstlane(sm.res[5]))} << 32) | uint32_t(__builtin_amdgcn_readfirstlane(sm.res[4]));
+        // the update's parameter block: every wavefront installs the record of its own voice, as ApplyParamsKernel would in front of a
+        // launch (the voice's state of the update before was written back by this very wavefront, in program order)
+        if(mapU && haveVoice)
+        {
+            const unsigned long long rowsU = (uint64_t{uint32_t(__builtin_amdgcn_readfirstlane(sm.res[9]))} << 32) | uint32_t(__builtin_amdgcn_readfirstlane(sm.res[8]));
+            InstallPair(L, reinterpret_cast<const int32_t*>(mapU), reinterpret_cast<const ParamRecord*>(recsU), reinterpret_cast<const float*>(rowsU), v, v, false, lane);
+        }
+        // What the update reads through the scalar cache -- the voices' control lines -- was written with vector stores, by this
+        // wavefront and (the key voice's head) by the key voice's: the stores are in L2 before the barrier, the scalar cache forgets behind it.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_s_dcache_inv();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if(t == 0)
+        {
+            const unsigned long long tIn = __builtin_amdgcn_s_memrealtime();
+            if((group & 127u) == 0u)
+                __hip_atomic_fetch_add(RA.counters + 16u * kRcInstall, uint32_t(tIn - tSeen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm.res[6] = uint32_t(tIn);
+        }
+    }
     auto stamp = [&](int slot)
     {
         if constexpr (PROF) { if(prof.times && haveVoice && (t & 63u) == 0u) prof.times[size_t{v} * 8 + slot] = __builtin_readcyclecounter(); }
@@ -277,7 +382,11 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
     // ---- the workgroup's resampler rows: LDS-DMA gathers, a tap pair per wavefront (voice_wave.hip's pass 0) ----
     const bool eligK = keyVoice < L.numVoices && (kK == 2 || (kK == 3 && (mK == 12 || mK == 24)))
         && (psK == OALGPU_VOICE_PLAYING || psK == OALGPU_VOICE_STOPPING);
-    if(eligK)
+    // (RES: the rows staged by an earlier update of this launch are still there unless the key voice's resampler changed)
+    bool stageRows = true;
+    if constexpr (RES) { if(upd != updBase) stageRows = !(eligK && sm.tabKey == offK * 8u + uint32_t(kK) && sm.tabM == mK); }
+    if constexpr (RES) __syncthreads();         // (everybody has compared before thread 0 rewrites the key)
+    if(eligK && stageRows)
     {
         typedef const __attribute__((address_space(1))) void *gvoidp;
         typedef __attribute__((address_space(3))) void *lvoidp;
@@ -847,7 +956,7 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
     // of the dump's barrier: the install is a chain of dependent round trips (map entry -> record -> stores), and all but the
     // workgroup's last wavefront spend it waiting for that one anyway.  The voice's state was written back by this very wavefront,
     // in program order.
-    if(next.map && haveVoice)
+    if(!RES && next.map && haveVoice)
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if(next.rows && irStride <= 64u) InstallPair(L, next.map, next.recs, next.rows, v, v, false, lane);
@@ -875,6 +984,8 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
         }
         __syncthreads();
         f2 *ph = reinterpret_cast<f2*>(L.partHrtf) + size_t{group} * (kLine + kHrirLen);
+        if constexpr (RES)      // the update's set of partial buses
+            ph = reinterpret_cast<f2*>(next.res.partBase + size_t{upd % kResidentSets} * next.res.setStride) + size_t{group} * (kLine + kHrirLen);
         for(uint32_t k = t; k < uint32_t(kLine + kHrirLen); k += uint32_t(kW16Threads))
         {
             f2 s = {0.0f, 0.0f};
@@ -885,11 +996,26 @@ __global__ void OALGPU_SINGLE_DS_OPS __launch_bounds__(WAVES * 64) VoiceWave16Ke
 #pragma unroll
                 for(int ww = 1; ww < WAVES; ++ww) { const f2 o = sm.w[ww].dump[at]; s.x += o.x; s.y += o.y; }
             }
-            StorePartial(&ph[k], s);
+            if constexpr (RES) StorePartialCoherent(&ph[k], s);       // (read by the reduction's launch while this one runs on)
+            else StorePartial(&ph[k], s);
         }
     }
     stamp(6);
-
+    if constexpr (!RES) break;
+    else
+    {   // the workgroup's partial is where the reduction will read it (written through, every thread's stores acknowledged)
+        // before the workgroup counts as arrived for this update; then on to the next one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if(t == 0)
+        {
+            __hip_atomic_fetch_add(next.res.counters + 16u * (kRcArrive0 + upd % kResidentSets), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if((group & 127u) == 0u)
+                __hip_atomic_fetch_add(next.res.counters + 16u * kRcBusy, uint32_t(__builtin_amdgcn_s_memrealtime()) - sm.res[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ++upd;
+    }
+    }
 }
 
 } // namespace
@@ -918,7 +1044,7 @@ const char *Wave16KernelName(const DeviceLayout &L)
 hipError_t LaunchVoiceWave16(hipStream_t s, const DeviceLayout &L, uint32_t samplesToDo, const WaveProf *prof, hipEvent_t evStart, hipEvent_t evStop,
     const ParamRecord *nextRecs, const int32_t *nextMap, const float *nextRows)
 {
-    const Next16 next{nextRecs, nextMap, nextRows};
+    const Next16 next{nextRecs, nextMap, nextRows, ResidentArgs{}};
     const WaveProf none{nullptr, 0u};
     const dim3 grid(Wave16Groups(L)), block(L.wave16 * 64u);
     const W16Sends S{L.sfilt, L.sendTgt, L.sendCur, L.streams, L.lineGains, L.numSends, L.wetChannels, L.lineStride, L.streamsPerVoice};
@@ -926,7 +1052,7 @@ hipError_t LaunchVoiceWave16(hipStream_t s, const DeviceLayout &L, uint32_t samp
     if(L.numSends)
     {   // (no measurement variant and no parameter block installed by the kernel: WaveKernelAppliesRecords says so to the host)
         // (the launch's stop event -- what the post stream waits for, and the end of what the host times -- belongs to the LAST kernel)
-        const Next16 noNext{nullptr, nullptr, nullptr};
+        const Next16 noNext{nullptr, nullptr, nullptr, ResidentArgs{}};
         if(L.wave16 == 16u) hipExtLaunchKernelGGL((VoiceWave16Kernel<false, 16, true>), grid, block, 0, s, evStart, nullptr, 0u, WaveArgsHrtf{L}, samplesToDo, noNext, none, S);
         else if(L.wave16 == 8u) hipExtLaunchKernelGGL((VoiceWave16Kernel<false, 8, true>), grid, block, 0, s, evStart, nullptr, 0u, WaveArgsHrtf{L}, samplesToDo, noNext, none, S);
         else hipExtLaunchKernelGGL((VoiceWave16Kernel<false, 4, true>), grid, block, 0, s, evStart, nullptr, 0u, WaveArgsHrtf{L}, samplesToDo, noNext, none, S);
@@ -943,6 +1069,21 @@ hipError_t LaunchVoiceWave16(hipStream_t s, const DeviceLayout &L, uint32_t samp
     }
 #undef OALGPU_W16_LAUNCH
     return hipGetLastError();
+}
+
+// the resident launch of the 16-wavefront form (OALGPU_CTX_RESIDENT; voice_wave_res.hip dispatches here)
+hipError_t LaunchVoiceWave16Resident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop)
+{
+    const Next16 next{nullptr, nullptr, nullptr, args};
+    const WaveProf none{nullptr, 0u};
+    hipExtLaunchKernelGGL((VoiceWave16Kernel<false, 16, false, true>), dim3(Wave16Groups(L)), dim3(1024), 0, s, evStart, evStop, 0u, WaveArgsHrtf{L}, 0u, next, none, W16Sends{});
+    return hipGetLastError();
+}
+int Wave16ResidentGroupsPerCu()
+{
+    int n = 0;
+    if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, VoiceWave16Kernel<false, 16, false, true>, 1024, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
 }
 
 } // namespace oalgpu

@@ -12,11 +12,13 @@ namespace oalgpu {
 // Which layouts have a resident launch, and the launch itself (evStart / evStop: HIP events bound to the dispatch, or null).
 bool WaveKernelHasResident(const DeviceLayout &L)
 {
-    return L.hrtf && L.numSends == 0 && L.firMfma && L.irStride >= 8 && L.irStride <= 64 && L.accLines == 0 && L.wave16 == 0;
+    // (the two-voices-per-wavefront kernel, or the 16-wavefront form of the voice-per-wavefront kernel: voice_wave16.hip)
+    return L.hrtf && L.numSends == 0 && L.firMfma && L.irStride >= 8 && L.irStride <= 64 && L.accLines == 0 && (L.wave16 == 0 || L.wave16 == 16u);
 }
 
 hipError_t LaunchVoiceWaveResident(hipStream_t s, const DeviceLayout &L, const ResidentArgs &args, hipEvent_t evStart, hipEvent_t evStop)
 {
+    if(L.wave16) return LaunchVoiceWave16Resident(s, L, args, evStart, evStop);
     const NextBlock next{nullptr, nullptr, nullptr, args};
     const WaveProf none{nullptr, 0u};
     hipExtLaunchKernelGGL((VoiceWaveKernel<17, 64, 0, false, true, false, WaveArgsHrtf, 0, true>), dim3(WaveKernelGroups(L)), dim3(kWThreads), 0, s,
@@ -25,8 +27,9 @@ hipError_t LaunchVoiceWaveResident(hipStream_t s, const DeviceLayout &L, const R
 }
 
 // workgroups of the resident kernel one compute unit holds at once (the launch needs ALL of its workgroups on the machine)
-int WaveResidentGroupsPerCu()
+int WaveResidentGroupsPerCu(const DeviceLayout &L)
 {
+    if(L.wave16) return Wave16ResidentGroupsPerCu();
     int n = 0;
     if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, VoiceWaveKernel<17, 64, 0, false, true, false, WaveArgsHrtf, 0, true>, kWThreads, 0) != hipSuccess)
     { (void)hipGetLastError(); return 0; }

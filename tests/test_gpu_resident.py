@@ -37,19 +37,24 @@ def _build(oalgpu, synth, bench, api, mhr, updates):
     return sc, blocks
 
 
-def test_resident_updates_equal_launched_updates(synth_mhr):
+FORMS = {"a voice per wavefront": 0, "two voices per wavefront": 256}      # 256: OALGPU_CTX_WAVE_PAIRS, the kernel of rounds 1-5
+
+
+@pytest.mark.parametrize("form", list(FORMS))
+def test_resident_updates_equal_launched_updates(synth_mhr, form):
     import oalgpu
     from oalgpu import synth
     import bench
     assert oalgpu.device_count() > 0, "GPU tests need a HIP device"
     mhr = synth.synth_mhr_bytes()
-    rapi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT)
-    sapi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_WAVE_PAIRS)     # (the launched form of the SAME kernel: the resident launch exists for the two-voices-per-wavefront form)
+    rapi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT | FORMS[form])
+    sapi = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=FORMS[form])              # (the launched form of the SAME kernel)
     rapi._mhr = mhr
     sapi._mhr = mhr
 
     # ---- the resident scene first, alone: another context's entry points would park its kernel every time
     res, rblocks = _build(oalgpu, synth, bench, rapi, mhr, UPDATES)
+    assert ("VoiceWave16Kernel<16>" if FORMS[form] == 0 else "VoiceWaveKernel<17, 64, 0, false, true>") in res.voice_kernel_name(), res.voice_kernel_name()
     res.resident_set_max_updates(9)                     # launches end by themselves every nine updates
     res.resident_set_timing(True)
     res.resident_set_short_run(0)                       # (the reads below keep the launches short: no falling back)
@@ -88,7 +93,8 @@ def test_resident_updates_equal_launched_updates(synth_mhr):
     ser.close()
 
 
-def test_resident_outputs_through_the_ring(synth_mhr):
+@pytest.mark.parametrize("form", list(FORMS))
+def test_resident_outputs_through_the_ring(synth_mhr, form):
     """every update's stereo output, collected two updates late through oalgpu_read_output_async / oalgpu_output_wait while the
     voice kernel stays resident (the post-process kernel fills the host's ring slot), against the launched path's lines"""
     import oalgpu
@@ -98,7 +104,7 @@ def test_resident_outputs_through_the_ring(synth_mhr):
     updates = 24
     outs = {}
     for mode in ("resident", "launched"):
-        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT if mode == "resident" else oalgpu.CTX_WAVE_PAIRS)
+        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=(oalgpu.CTX_RESIDENT if mode == "resident" else 0) | FORMS[form])
         api._mhr = mhr
         sc, blocks = _build(oalgpu, synth, bench, api, mhr, updates)
         got, tickets = [], []
@@ -129,7 +135,8 @@ def test_resident_outputs_through_the_ring(synth_mhr):
     assert max(float(np.abs(a).max()) for a in outs["launched"]) > 1e-3
 
 
-def test_other_entry_points_park_the_resident_kernel(synth_mhr):
+@pytest.mark.parametrize("form", list(FORMS))
+def test_other_entry_points_park_the_resident_kernel(synth_mhr, form):
     """anything but apply / mix / read_output_async / output_wait tells the kernel to leave, and the next update starts a new one:
     parameters set the launched way between resident updates, a second context used in between, a parameter block applied
     without an update behind it"""
@@ -138,13 +145,14 @@ def test_other_entry_points_park_the_resident_kernel(synth_mhr):
     import bench
     mhr = synth.synth_mhr_bytes()
     updates = 12
+    nv = 4096 if FORMS[form] == 0 else 512         # (the voice-per-wavefront kernel has a resident launch in its 16-wavefront form: a scene that fills the machine)
     outs = {}
     for mode in ("resident", "launched"):
-        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_RESIDENT if mode == "resident" else oalgpu.CTX_WAVE_PAIRS)
+        api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=(oalgpu.CTX_RESIDENT if mode == "resident" else 0) | FORMS[form])
         api._mhr = mhr
-        sc, script = bench.build_scene(oalgpu, synth, api, 3, 512, 0, mhr, 0)
+        sc, script = bench.build_scene(oalgpu, synth, api, 3, nv, 0, mhr, 0)
         other, _ = bench.build_scene(oalgpu, synth, api, 3, 64, 0, mhr, 0)
-        allv = list(range(512))
+        allv = list(range(nv))
         moving = [v for v in allv if script.is_moving(v)]
         sc.set_params_batch(allv, bench.param_array(oalgpu, script, allv, 0))
         blocks = [sc.param_block(moving, bench.param_array(oalgpu, script, moving, k + 1)) for k in range(updates)]

@@ -126,6 +126,17 @@ def test_voice_per_wavefront_hrtf_kernel_runs_four_wavefronts_per_simd(voice_ker
     fused = next(m for n, m in post.items() if "PostFusedKernel" in n)
     assert granule(k16["group_segment_fixed_size"], 1280) + granule(fused["group_segment_fixed_size"], 1280) <= 160 * 1024, k16
     assert 2 * granule(k8["group_segment_fixed_size"], 1280) <= 160 * 1024, k8
+    # the resident launch of the 16-wavefront form (OALGPU_CTX_RESIDENT): the voice workgroup never leaves its CU, and the reduction and
+    # the post-process of every update WAIT for it -- one wavefront of theirs must fit on a SIMD beside four voice wavefronts, one
+    # workgroup of each in the LDS the voice workgroup leaves (or nothing ever moves again)
+    k16r = next(m for n, m in meta.items() if "VoiceWave16KernelILb0ELi16ELb0ELb1E" in n)
+    assert k16r["vgpr_spill_count"] == 0 and k16r["private_segment_fixed_size"] == 0, k16r
+    red = next(m for n, m in post.items() if "BusReduceResidentKernel" in n)
+    pst = next(m for n, m in post.items() if "PostResidentKernel" in n)
+    for other in (red, pst):
+        assert other["vgpr_spill_count"] == 0, other
+        assert 4 * granule(k16r["vgpr_count"] + k16r.get("agpr_count", 0)) + granule(other["vgpr_count"]) <= 512, (k16r, other)
+    assert granule(k16r["group_segment_fixed_size"], 1280) + granule(red["group_segment_fixed_size"], 1280) + granule(pst["group_segment_fixed_size"], 1280) <= 160 * 1024, k16r
     # (small scenes: four wavefronts per workgroup, two per SIMD at most -- the register form of rounds 1-5)
     assert k4["vgpr_spill_count"] == 0 and k4["vgpr_count"] + k4.get("agpr_count", 0) <= 256, k4
 
