@@ -459,7 +459,10 @@ def main():
     # the epilogue since round 5, and configs 2 / 4 / 5 measured 1.6 / 13 / 3.3 us per step SLOWER with it than with the parameter
     # kernel -- their steps hang on the post chain, which the deferred submission starts a library call later:
     # profiles/r5/apply_in_kernel_other_configs.txt; --xflags 16 selects it for an A/B)
-    mode_flags = (oalgpu.CTX_RESIDENT if want_resident else 0) | (oalgpu.CTX_APPLY_IN_VOICE_KERNEL if hot and args.resident != "off" else 0)
+    # (N > 1 runs the same scene sharded: the block is installed by each rank's voice kernel there too -- the library's condition for it
+    # knows no communicator; only the resident launch is a single-GPU mode)
+    hot_kernel = args.config == 3 and args.math == "fast" and args.fir == "mfma"
+    mode_flags = (oalgpu.CTX_RESIDENT if want_resident else 0) | (oalgpu.CTX_APPLY_IN_VOICE_KERNEL if hot_kernel and args.resident != "off" else 0)
     api = oalgpu.Api(oalgpu.MATH_FAST if args.math == "fast" else oalgpu.MATH_EXACT, device=local_rank,
                      ctx_flags=(oalgpu.CTX_FIR_VALU if args.fir == "valu" else 0) | mode_flags | args.xflags)
     real_mhr = os.path.join(ROOT, "tests", "golden", "default_hrtf.mhr")

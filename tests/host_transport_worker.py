@@ -23,13 +23,22 @@ READ_AFTER = (7, 9)                            # the reads drain the pipeline: e
                                                # depth of the transport's ring, so the ranks do throttle each other
 
 
+BLOCKS = os.environ.get("OALGPU_TEST_PARAM_BLOCKS") == "1"
+held = []                                       # (a block stays alive until the update that installs it has run)
+
+
 def run(sc, script, nslots, hrtf):
     voices = list(range(script.nvoices))
     moving = [v for v in voices if script.is_moving(v)]
     out = {}
     for k, n in enumerate(SIZES):
         vs = voices if k == 0 else moving
-        if vs:
+        if vs and BLOCKS and k:
+            # bench.py's N > 1 form: a parameter block per update, installed by the rank's own voice kernel (OALGPU_CTX_APPLY_IN_VOICE_KERNEL)
+            blk = sc.param_block(vs, bench.param_array(oalgpu, script, vs, k))
+            sc.apply_block(blk)
+            held.append(blk)
+        elif vs:
             sc.set_params_batch(vs, bench.param_array(oalgpu, script, vs, k))
         sc.mix(n, post_process=True)
         if k in READ_AFTER:
@@ -54,7 +63,7 @@ def main():
     nslots = {4: 4, 5: 1}.get(config, 0)
     with open(mhr_path, "rb") as f:
         mhr = f.read()
-    api = oalgpu.Api(oalgpu.MATH_FAST)
+    api = oalgpu.Api(oalgpu.MATH_FAST, ctx_flags=oalgpu.CTX_APPLY_IN_VOICE_KERNEL if BLOCKS else 0)
     api._mhr = mhr
     probe = synth.SceneScript(config, total)
     costs = [voice_cost(hrtf, 24, {4: v % 5, 5: 1}.get(config, 0), probe.filter_active(v)) for v in range(total)]

@@ -99,7 +99,7 @@ def test_library_comm_single_rank_rccl(synth_mhr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config", [3, 4, 5])
+@pytest.mark.parametrize("config", [3, 4, 5, "3 with parameter blocks installed by the voice kernels"])
 def test_library_sharded_update_two_processes_one_gpu(synth_mhr, tmp_path, config):
     """The library's N > 1 path itself: two processes share the GPU, each with a context of its own, connected by
     oalgpu_comm_init_host (RCCL refuses two ranks on one device; the host-staged transport sits behind the same
@@ -111,13 +111,17 @@ def test_library_sharded_update_two_processes_one_gpu(synth_mhr, tmp_path, confi
     send rows reach the wet bus of rank 0's 65 536-tap convolution slot through the reduce
     (alc/effects/convolution.cpp:623-716 runs where the summed wet bus is)."""
     import numpy as np
+    env = dict(os.environ)
+    if not isinstance(config, int):             # (what bench.py --gpus N runs per rank: a parameter block per update, OALGPU_CTX_APPLY_IN_VOICE_KERNEL)
+        config = 3
+        env["OALGPU_TEST_PARAM_BLOCKS"] = "1"
     total = 600
-    name = f"/oalgpu_test_{os.getpid()}_{config}"
+    name = f"/oalgpu_test_{os.getpid()}_{config}_{len(env) % 7}"
     prefix = str(tmp_path / f"c{config}")
     procs = []
     for rank in range(2):
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "host_transport_worker.py"), str(config), str(rank), "2",
-                                       name, str(total), prefix, synth_mhr], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                       name, str(total), prefix, synth_mhr], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
     outs = []
     for p in procs:
         try:
