@@ -91,3 +91,22 @@ def test_delayed_voices_match_the_reference(case, synth_mhr):
     # the delays did something: voice 9 (2500 samples ahead) is silent for two updates and sounds in the third
     assert wi[0][9][1] == wi[1][9][1] and wi[2][9][1] != wi[1][9][1]
     assert wi[-1][7][0] == ol.VOICE_STOPPED
+
+
+def test_machine_filling_hrtf_scene_with_filtered_sends_matches_the_reference(synth_mhr):
+    """4096 voices (the 16-wavefront form of csrc/voice_wave16.hip with sends: every wavefront's send rows -- half of them through the
+    send's own filter pair -- go out as stream rows and StreamRowsMixKernel mixes them) against the reference: the same scene as
+    above at the size where the kernel's register budget is 112, delays, stops and odd update lengths included"""
+    import oalgpu
+    if not ol.available("ref"):
+        pytest.skip("needs the compiled reference")
+    L = ol.load("ref")
+    L.L.oal_set_simd(1)
+    n = 4096
+    want, wi = run(L, synth_mhr, True, 2, nvoices=n)
+    api = oalgpu.Api(oalgpu.MATH_FAST)
+    got, gi = run(api, synth_mhr, True, 2, nvoices=n)
+    for k in range(len(TODO)):
+        assert gi[k] == wi[k], (k, [(v, a, b) for v, (a, b) in enumerate(zip(gi[k], wi[k])) if a != b][:4])
+        err = np.abs(got[k] - want[k]).max()
+        assert err <= 4e-5 * np.abs(want[k]).max() + 1e-7, (k, err, np.abs(want[k]).max())
